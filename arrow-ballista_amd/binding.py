@@ -1,0 +1,201 @@
+"""ctypes binding of include/gpuq.h.  One-to-one with the C ABI; no compute happens here."""
+import ctypes as C
+import json
+import os
+
+T_NULL, T_BOOL, T_INT32, T_INT64, T_DATE32, T_FLOAT64, T_DECIMAL128, T_UTF8, T_UINT32, T_UINT64 = range(10)
+REPR_ARROW, REPR_PACKED15 = 0, 1
+_STATUS = {1: "INVALID", 2: "HIP", 3: "UNSUPPORTED", 4: "CAPACITY", 5: "INTERNAL"}
+
+
+class GpuqError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("gpuq %s: %s" % (_STATUS.get(status, status), message))
+        self.status = status
+        self.message = message
+
+
+class gpuq_column(C.Structure):
+    _fields_ = [("type", C.c_int32), ("precision", C.c_int32), ("scale", C.c_int32), ("repr", C.c_int32),
+                ("data", C.c_void_p), ("offsets", C.c_void_p), ("validity", C.c_void_p), ("length", C.c_int64)]
+
+
+class gpuq_field_info(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("type", C.c_int32), ("precision", C.c_int32), ("scale", C.c_int32),
+                ("nullable", C.c_int32), ("repr", C.c_int32), ("width", C.c_int32)]
+
+
+class gpuq_input(C.Structure):
+    _fields_ = [("cols", C.POINTER(gpuq_column)), ("n_cols", C.c_int32), ("n_via", C.c_int32), ("n_rows", C.c_int64),
+                ("via", C.c_void_p * 3)]
+
+
+class gpuq_lineitem_cols(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("l_orderkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount", "l_tax",
+                                          "l_shipdate", "l_returnflag", "l_returnflag_off", "l_linestatus", "l_linestatus_off")]
+
+
+class gpuq_orders_cols(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("o_orderkey", "o_custkey", "o_orderdate", "o_shippriority")]
+
+
+class gpuq_customer_cols(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("c_custkey", "c_nationkey", "c_mktsegment", "c_mktsegment_off")]
+
+
+class gpuq_supplier_cols(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("s_suppkey", "s_nationkey")]
+
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "libgpuq.so")
+
+
+def lib():
+    """Load libgpuq.so (built in-tree by build.py).  Raises when it is missing: there is no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise GpuqError(5, "libgpuq.so not built (%s); run `python arrow-ballista_amd/build.py`" % p)
+    L = C.CDLL(p)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+    sig = {
+        "gpuq_abi_version": (i32, []),
+        "gpuq_ctx_create": (vp, [i32, C.c_char_p]),
+        "gpuq_ctx_free": (None, [vp]),
+        "gpuq_last_error": (C.c_char_p, [vp]),
+        "gpuq_ctx_device_info": (i32, [vp, C.c_char_p, C.c_size_t]),
+        "gpuq_op_create": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
+        "gpuq_compile_check": (i32, [C.c_char_p, C.c_char_p, C.c_size_t]),
+        "gpuq_op_free": (None, [vp]),
+        "gpuq_op_num_outputs": (i32, [vp]),
+        "gpuq_op_output_field": (i32, [vp, i32, C.POINTER(gpuq_field_info)]),
+        "gpuq_filter_run": (i32, [vp, vp, C.POINTER(gpuq_input), i32, vp, vp]),
+        "gpuq_project_run": (i32, [vp, vp, C.POINTER(gpuq_input), C.POINTER(gpuq_column), i32]),
+        "gpuq_aggregate_run": (i32, [vp, vp, C.POINTER(gpuq_input), C.POINTER(gpuq_column), i32, i64, C.POINTER(i64)]),
+        "gpuq_join_build_run": (i32, [vp, vp, C.POINTER(gpuq_input), i32, i64, C.POINTER(vp)]),
+        "gpuq_join_table_free": (None, [vp]),
+        "gpuq_join_probe_run": (i32, [vp, vp, vp, C.POINTER(gpuq_input), i32, vp, vp, u64, vp]),
+        "gpuq_join_build_side_rows": (i32, [vp, vp, i32, vp, vp]),
+        "gpuq_sort_run": (i32, [vp, vp, C.POINTER(gpuq_input), vp]),
+        "gpuq_partition_run": (i32, [vp, vp, C.POINTER(gpuq_input), vp, vp]),
+        "gpuq_op_check": (i32, [vp, vp]),
+        "gpuq_unpack_utf8": (i32, [vp, vp, vp, i64, vp, vp, i64, C.POINTER(i64)]),
+        "gpuq_gen_lineitem": (i32, [vp, vp, u64, u64, i64, i64, i64, C.POINTER(gpuq_lineitem_cols)]),
+        "gpuq_gen_orders": (i32, [vp, vp, u64, i64, i64, i64, C.POINTER(gpuq_orders_cols)]),
+        "gpuq_gen_customer": (i32, [vp, vp, u64, i64, i64, C.POINTER(gpuq_customer_cols)]),
+        "gpuq_gen_supplier": (i32, [vp, vp, u64, i64, i64, C.POINTER(gpuq_supplier_cols)]),
+        "gpuq_timer_create": (i32, [vp, C.POINTER(vp)]),
+        "gpuq_timer_start": (i32, [vp, vp]),
+        "gpuq_timer_stop": (i32, [vp, vp]),
+        "gpuq_timer_elapsed_ms": (i32, [vp, C.POINTER(C.c_float)]),
+        "gpuq_timer_free": (None, [vp]),
+        "gpuq_op_profile": (i32, [vp, i32, C.POINTER(C.c_float), C.POINTER(i32)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError when the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    L._gpuq_symbols = sorted(sig)
+    _LIB = L
+    return L
+
+
+def compile_check(descriptor):
+    """Compile an operator descriptor on the host only (no device) and return its description."""
+    L = lib()
+    buf = C.create_string_buffer(1 << 18)
+    rc = L.gpuq_compile_check(json.dumps(descriptor).encode(), buf, len(buf))
+    if rc != 0:
+        raise GpuqError(rc, L.gpuq_last_error(None).decode())
+    return json.loads(buf.value.decode())
+
+
+class Context:
+    """gpuq_ctx: one device.  Raises GpuqError when no HIP device is usable (no CPU fallback)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = self.L.gpuq_ctx_create(int(device), None)
+        if not self.h:
+            raise GpuqError(2, self.L.gpuq_last_error(None).decode())
+        self.device = int(device)
+
+    def check(self, rc):
+        if rc != 0:
+            raise GpuqError(rc, self.L.gpuq_last_error(self.h).decode())
+
+    def info(self):
+        buf = C.create_string_buffer(1024)
+        self.check(self.L.gpuq_ctx_device_info(self.h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+    def close(self):
+        if self.h:
+            self.L.gpuq_ctx_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Op:
+    """gpuq_op: one compiled operator."""
+
+    def __init__(self, ctx, descriptor):
+        self.ctx = ctx
+        self.L = ctx.L
+        self.descriptor = descriptor
+        h = C.c_void_p()
+        ctx.check(self.L.gpuq_op_create(ctx.h, json.dumps(descriptor).encode(), C.byref(h)))
+        self.h = h
+        self.fields = []
+        for i in range(self.L.gpuq_op_num_outputs(h)):
+            f = gpuq_field_info()
+            ctx.check(self.L.gpuq_op_output_field(h, i, C.byref(f)))
+            self.fields.append(dict(name=f.name.decode(), type=f.type, precision=f.precision, scale=f.scale,
+                                    nullable=bool(f.nullable), repr=f.repr, width=f.width))
+
+    def check(self, stream=None):
+        self.ctx.check(self.L.gpuq_op_check(self.h, stream))
+
+    def profile(self, enable=True):
+        ms, n = C.c_float(0), C.c_int(0)
+        self.ctx.check(self.L.gpuq_op_profile(self.h, 1 if enable else 0, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gpuq_op_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class JoinTable:
+    def __init__(self, ctx, handle):
+        self.ctx, self.L, self.h = ctx, ctx.L, handle
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gpuq_join_table_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,962 @@
+// libgpuq.so C ABI (include/gpuq.h): operator descriptors -> compiled device programs,
+// workspace management, strategy selection, launches.  Host logic only; all arithmetic on the
+// data path runs in the HIP kernels (kernels_*.hip).  There is deliberately no CPU fallback.
+#include "../../include/gpuq.h"
+#include "expr_compile.h"
+#include "gpuq_kernels.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gpuq;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Capacity : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIPCHECK(expr)                                                                                   \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e));             \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  void* ensure(size_t bytes) {
+    if (bytes > cap) {
+      if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+      size_t want = bytes < 256 ? 256 : bytes;
+      HIPCHECK(hipMalloc(&p, want)); cap = want;
+    }
+    return p;
+  }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+u64 next_pow2(u64 v) { u64 r = 1; while (r < v) r <<= 1; return r; }
+
+}  // namespace
+
+struct gpuq_ctx {
+  int device = 0; int cus = 256; size_t hbm = 0; std::string name, arch, last_error;
+};
+
+struct gpuq_timer { hipEvent_t a = nullptr, b = nullptr; };
+
+enum OpKind { K_FILTER, K_PROJECT, K_AGG, K_JOIN_BUILD, K_JOIN_PROBE, K_SORT, K_PARTITION };
+
+struct gpuq_op {
+  gpuq_ctx* ctx = nullptr;
+  OpKind kind = K_FILTER;
+  Schema in_schema;
+  CompiledProgram prog;
+  DevBuf code_dev, flags_dev;
+  std::vector<gpuq_field_info> out_fields;
+  // aggregate
+  std::string mode = "Single", strategy = "auto";
+  AggSpec agg{}; KeySpec keys{};
+  std::vector<DType> key_types, acc_types;
+  CompiledProgram post; DevBuf post_code; Schema post_schema;
+  i64 expected_groups = 0;
+  // join
+  int join_type = JT_INNER; int null_eq = 0;
+  // sort
+  SortSpec sort{}; i64 fetch = -1;
+  // partition
+  uint32_t nparts = 0;
+  // scratch
+  DevBuf ws[10];
+  // profiling of the dominant kernel
+  bool profile = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float kernel_ms = 0; int launches = 0; bool ev_pending = false;
+  ~gpuq_op() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
+};
+
+struct gpuq_join_table {
+  gpuq_ctx* ctx = nullptr;
+  KeySpec keys{}; HashTable T{}; int null_eq = 0;
+  DevBuf slots, next, visited, present, ws_bitmap, ws_counts;
+  i64 bound = 0;
+  bool visited_ready = false;
+};
+
+namespace {
+
+void set_err(gpuq_ctx* c, const std::string& m) { g_last_error = m; if (c) c->last_error = m; }
+
+template <class F> int guarded(gpuq_ctx* ctx, F&& f) {
+  try { f(); return GPUQ_OK; }
+  catch (const HipError& e) { set_err(ctx, e.what()); return GPUQ_ERR_HIP; }
+  catch (const Unsupported& e) { set_err(ctx, e.what()); return GPUQ_ERR_UNSUPPORTED; }
+  catch (const Capacity& e) { set_err(ctx, e.what()); return GPUQ_ERR_CAPACITY; }
+  catch (const std::bad_alloc&) { set_err(ctx, "out of host memory"); return GPUQ_ERR_INTERNAL; }
+  catch (const std::exception& e) { set_err(ctx, e.what()); return GPUQ_ERR_INVALID; }
+}
+
+gpuq_field_info make_field(const std::string& name, const DType& t, bool nullable) {
+  gpuq_field_info f{};
+  std::snprintf(f.name, sizeof(f.name), "%s", name.c_str());
+  f.type = t.id; f.precision = t.p; f.scale = t.s; f.nullable = nullable;
+  f.repr = (t.id == T_UTF8) ? GPUQ_REPR_PACKED15 : GPUQ_REPR_ARROW;
+  f.width = (t.id == T_BOOL) ? 0 : type_width(t);
+  return f;
+}
+
+bool g_upload = true;   // false inside gpuq_compile_check (no device)
+void upload_code(const CompiledProgram& p, DevBuf& dst) {
+  if (!g_upload) return;
+  dst.ensure(sizeof(DevCode));
+  HIPCHECK(hipMemcpy(dst.p, &p.code, sizeof(DevCode), hipMemcpyHostToDevice));
+}
+
+// Bind the call's column pointers to a compiled program.
+DevProgram bind_program(const CompiledProgram& cp, const Schema& schema, const DevCode* code_dev, uint32_t* flags_dev, const gpuq_input* in) {
+  if (!in) throw std::runtime_error("input is NULL");
+  if (in->n_cols != (int)schema.fields.size())
+    throw std::runtime_error("input has " + std::to_string(in->n_cols) + " columns, operator expects " + std::to_string(schema.fields.size()));
+  if (in->n_via < 0 || in->n_via > MAX_VIA) throw std::runtime_error("n_via out of range");
+  if (in->n_rows < 0 || in->n_rows > 0xFFFFFFFEll) throw std::runtime_error("n_rows out of range (max 2^32-2 positions per call)");
+  DevProgram P{};
+  P.n_cols = (int)cp.col_field.size(); P.n_insns = cp.n_insns; P.pred_reg = cp.pred_reg; P.n_via = in->n_via;
+  for (int k = 0; k < in->n_via; ++k) { if (!in->via[k] && in->n_rows > 0) throw std::runtime_error("index vector is NULL"); P.via[k] = in->via[k]; }
+  P.code = code_dev; P.flags = flags_dev;
+  for (size_t c = 0; c < cp.col_field.size(); ++c) {
+    const int fi = cp.col_field[c];
+    const Field& f = schema.fields[fi];
+    const gpuq_column& col = in->cols[fi];
+    if (col.type != f.type.id || (f.type.id == T_DECIMAL128 && (col.precision != f.type.p || col.scale != f.type.s)))
+      throw std::runtime_error("column '" + f.name + "': type does not match the operator's input schema (" + f.type.to_string() + ")");
+    if (f.side > in->n_via) throw std::runtime_error("column '" + f.name + "' needs index vector " + std::to_string(f.side));
+    if (!col.data && col.length > 0 && in->n_rows > 0) throw std::runtime_error("column '" + f.name + "': data is NULL");
+    if (!f.nullable && f.side == 0 && col.validity) { /* declared non-nullable but carries a bitmap: honour the bitmap */ }
+    DevCol& d = P.cols[c];
+    d.data = col.data; d.offsets = col.offsets; d.validity = col.validity;
+    d.cls = f.raw128 ? CC_I128 : col_class_for(f.type);
+    if (d.cls == CC_STR && !f.raw128 && !col.offsets && col.length > 0) throw std::runtime_error("Utf8 column '" + f.name + "' has no offsets");
+    if (f.raw128 && f.type.id == T_UTF8) d.cls = CC_I128;
+    d.via = f.side;
+  }
+  return P;
+}
+
+void reset_flags(gpuq_op* op, hipStream_t s) { HIPCHECK(hipMemsetAsync(op->flags_dev.p, 0, 4, s)); }
+uint32_t read_flags(gpuq_op* op, hipStream_t s) {
+  uint32_t f = 0;
+  HIPCHECK(hipMemcpyAsync(&f, op->flags_dev.p, 4, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  return f;
+}
+void raise_flags(uint32_t f) {
+  if (f & FLAG_STR_TRUNC) throw Unsupported("a Utf8 value longer than 15 bytes reached a device string comparison/key (PACKED15 limit)");
+  if (f & FLAG_WIDE_MINMAX) throw Unsupported("MIN/MAX over a value outside the int64 range is not supported on device");
+  if (f & FLAG_DUP_BUILD_KEY) throw Unsupported("duplicate build keys without a chain buffer");
+  if (f & FLAG_OUT_OVERFLOW) throw Capacity("join output capacity exceeded; see the pair count for the required size");
+  if (f & FLAG_TABLE_FULL) throw std::runtime_error("hash table full");
+  if (f & FLAG_GROUP_OVERFLOW) throw Capacity("group capacity exceeded");
+}
+
+struct ProfScope {
+  gpuq_op* op; hipStream_t s;
+  ProfScope(gpuq_op* o, hipStream_t st) : op(o), s(st) {
+    if (op->profile) {
+      if (!op->ev0) { HIPCHECK(hipEventCreate(&op->ev0)); HIPCHECK(hipEventCreate(&op->ev1)); }
+      if (op->ev_pending) { float ms = 0; HIPCHECK(hipEventSynchronize(op->ev1)); HIPCHECK(hipEventElapsedTime(&ms, op->ev0, op->ev1)); op->kernel_ms += ms; op->ev_pending = false; }
+      HIPCHECK(hipEventRecord(op->ev0, s));
+    }
+  }
+  ~ProfScope() { if (op->profile) { (void)hipEventRecord(op->ev1, s); op->ev_pending = true; op->launches++; } }
+};
+
+// ---------------------------------------------------------------- key layout
+KeySpec make_keyspec(const std::vector<int>& regs, const std::vector<DType>& types, bool null_word) {
+  if (regs.size() > (size_t)MAX_KEYS) throw Unsupported("more than " + std::to_string(MAX_KEYS) + " key columns");
+  KeySpec K{};
+  K.n_keys = (int)regs.size(); K.null_word = null_word ? 1 : 0;
+  int w = 0;
+  for (size_t k = 0; k < regs.size(); ++k) {
+    K.key_reg[k] = regs[k];
+    const bool wide = types[k].id == T_DECIMAL128 || types[k].id == T_UTF8;
+    K.key_wide[k] = wide;
+    K.word_reg[w] = regs[k]; K.word_half[w] = 0; ++w;
+    if (wide) { K.word_reg[w] = regs[k]; K.word_half[w] = 1; ++w; }
+  }
+  if (null_word) { K.word_reg[w] = 0; K.word_half[w] = 2; ++w; }
+  K.key_words = w;
+  return K;
+}
+
+// ---------------------------------------------------------------- aggregate compilation
+struct AccDef { int kind; NodeP arg; DType type; };
+
+int find_or_add_acc(std::vector<AccDef>& accs, int kind, NodeP arg, const DType& type) {
+  for (size_t i = 0; i < accs.size(); ++i)
+    if (accs[i].kind == kind && ((!arg && !accs[i].arg) || (arg && accs[i].arg && arg->key == accs[i].arg->key))) return (int)i;
+  if ((int)accs.size() >= MAX_ACCS) throw Unsupported("aggregate needs more than " + std::to_string(MAX_ACCS) + " accumulators");
+  accs.push_back({kind, arg, type}); return (int)accs.size() - 1;
+}
+DType t_of(int id) { DType t; t.id = id; return t; }
+DType dec_t(int p, int s) { DType t; t.id = T_DECIMAL128; t.p = std::min(p, 38); t.s = std::min(s, 38); return t; }
+
+// How one SQL aggregate maps to accumulators (indices into accs) and to output columns.
+struct AggPlan {
+  std::string fn, name;
+  DType arg_type; bool arg_nullable = false;
+  int acc_sum = -1, acc_cnt = -1, acc_mm = -1;   // sum / count / min-max accumulators
+  bool is_float = false;
+};
+
+void compile_aggregate(gpuq_op* op, const Json& d) {
+  op->mode = d.get_str("mode", "Single");
+  const bool is_final = (op->mode == "Final" || op->mode == "FinalPartitioned");
+  const bool emit_state = (op->mode == "Partial");
+  if (!is_final && !emit_state && op->mode != "Single") throw std::runtime_error("unknown aggregate mode '" + op->mode + "'");
+  op->strategy = d.get_str("strategy", "auto");
+  op->expected_groups = d.get_i64("expected_groups", 0);
+  ExprCompiler ec(op->in_schema);
+  if (d.has("predicate")) ec.add_predicate(ec.from_json(d.at("predicate")));
+  std::vector<NodeP> key_nodes; std::vector<std::string> key_names;
+  if (d.has("group_expr")) for (const Json& g : d.at("group_expr").a) {
+    NodeP n = ec.from_json(g.at("expr"));
+    key_nodes.push_back(n); key_names.push_back(g.get_str("name", "group" + std::to_string(key_nodes.size() - 1)));
+  }
+  if (key_nodes.size() > (size_t)MAX_KEYS) throw Unsupported("more than " + std::to_string(MAX_KEYS) + " group-by columns");
+  std::vector<AccDef> accs; std::vector<AggPlan> plans;
+  size_t state_col = key_nodes.size();   // Final modes: state columns follow the group columns positionally
+  const Json& aggs = d.at("aggr_expr");
+  for (const Json& a : aggs.a) {
+    AggPlan pl; pl.fn = a.at("fn").str(); pl.name = a.get_str("name", pl.fn);
+    for (auto& ch : pl.fn) ch = (char)std::toupper(ch);
+    if (a.get_bool("distinct", false)) throw Unsupported("DISTINCT aggregates are not supported on device");
+    if (!is_final) {
+      NodeP arg = a.has("expr") ? ec.from_json(a.at("expr")) : nullptr;
+      if (pl.fn == "COUNT") {
+        if (!arg || !arg->nullable) pl.acc_cnt = find_or_add_acc(accs, ACC_COUNT_STAR, nullptr, t_of(T_INT64));
+        else pl.acc_cnt = find_or_add_acc(accs, ACC_COUNT, arg, t_of(T_INT64));
+        pl.arg_type = t_of(T_INT64);
+      } else {
+        if (!arg) throw std::runtime_error(pl.fn + " needs an argument");
+        pl.arg_type = arg->type; pl.arg_nullable = arg->nullable;
+        auto count_of = [&](NodeP x) { return x->nullable ? find_or_add_acc(accs, ACC_COUNT, x, t_of(T_INT64)) : find_or_add_acc(accs, ACC_COUNT_STAR, nullptr, t_of(T_INT64)); };
+        if (pl.fn == "SUM" || pl.fn == "AVG") {
+          if (arg->type.is_decimal()) {
+            pl.acc_sum = find_or_add_acc(accs, ACC_SUM, arg, dec_t(arg->type.p + 10, arg->type.s));
+          } else if (arg->type.is_int() && pl.fn == "SUM") {
+            NodeP x = ec.cast(arg, t_of(T_INT64));
+            pl.acc_sum = find_or_add_acc(accs, ACC_SUM, x, t_of(T_INT64));
+          } else if (arg->type.is_float() || arg->type.is_int()) {
+            NodeP x = ec.cast(arg, t_of(T_FLOAT64)); pl.is_float = true;
+            pl.acc_sum = find_or_add_acc(accs, ACC_FSUM, x, t_of(T_FLOAT64));
+          } else throw Unsupported(pl.fn + " over " + arg->type.to_string());
+          if (pl.fn == "AVG" || arg->nullable) pl.acc_cnt = count_of(arg);
+        } else if (pl.fn == "MIN" || pl.fn == "MAX") {
+          const bool mn = pl.fn == "MIN";
+          if (arg->type.is_float()) { pl.is_float = true; pl.acc_mm = find_or_add_acc(accs, mn ? ACC_FMIN : ACC_FMAX, arg, arg->type); }
+          else if (arg->type.is_int() || arg->type.is_decimal() || arg->type.id == T_DATE32) pl.acc_mm = find_or_add_acc(accs, mn ? ACC_MIN : ACC_MAX, arg, arg->type);
+          else throw Unsupported(pl.fn + " over " + arg->type.to_string());
+          if (arg->nullable) pl.acc_cnt = count_of(arg);
+        } else throw Unsupported("aggregate function " + pl.fn);
+      }
+    } else {
+      // merge of partial states: columns arrive positionally after the group columns
+      auto state = [&](void) { if (state_col >= op->in_schema.fields.size()) throw std::runtime_error("Final aggregate: input has too few state columns"); return ec.column((int)state_col++); };
+      if (pl.fn == "COUNT") { NodeP c = state(); pl.acc_cnt = find_or_add_acc(accs, ACC_SUM, ec.cast(c, t_of(T_INT64)), t_of(T_INT64)); pl.arg_type = t_of(T_INT64); }
+      else if (pl.fn == "SUM") {
+        NodeP s = state(); pl.arg_type = s->type; pl.arg_nullable = s->nullable;
+        if (s->type.is_float()) { pl.is_float = true; pl.acc_sum = find_or_add_acc(accs, ACC_FSUM, s, s->type); }
+        else pl.acc_sum = find_or_add_acc(accs, ACC_SUM, s, s->type);
+        if (s->nullable) pl.acc_cnt = find_or_add_acc(accs, ACC_COUNT, s, t_of(T_INT64));
+      } else if (pl.fn == "AVG") {
+        NodeP c = state(); NodeP s = state(); pl.arg_type = s->type;
+        pl.acc_cnt = find_or_add_acc(accs, ACC_SUM, ec.cast(c, t_of(T_INT64)), t_of(T_INT64));
+        if (s->type.is_float()) { pl.is_float = true; pl.acc_sum = find_or_add_acc(accs, ACC_FSUM, ec.coalesce0(s), s->type); }
+        else pl.acc_sum = find_or_add_acc(accs, ACC_SUM, s, s->type);
+      } else if (pl.fn == "MIN" || pl.fn == "MAX") {
+        NodeP s = state(); const bool mn = pl.fn == "MIN"; pl.arg_type = s->type; pl.arg_nullable = s->nullable;
+        if (s->type.is_float()) { pl.is_float = true; pl.acc_mm = find_or_add_acc(accs, mn ? ACC_FMIN : ACC_FMAX, s, s->type); }
+        else pl.acc_mm = find_or_add_acc(accs, mn ? ACC_MIN : ACC_MAX, s, s->type);
+        if (s->nullable) pl.acc_cnt = find_or_add_acc(accs, ACC_COUNT, s, t_of(T_INT64));
+      } else throw Unsupported("aggregate function " + pl.fn);
+    }
+    plans.push_back(pl);
+  }
+  if (accs.empty()) find_or_add_acc(accs, ACC_COUNT_STAR, nullptr, t_of(T_INT64));   // GROUP BY without aggregates still needs a cell
+  // scan program outputs: keys then accumulator arguments
+  std::vector<int> key_slots, acc_slots(accs.size(), -1);
+  for (auto& k : key_nodes) key_slots.push_back(ec.add_output(k));
+  for (size_t i = 0; i < accs.size(); ++i) if (accs[i].arg) acc_slots[i] = ec.add_output(accs[i].arg);
+  op->prog = ec.finish();
+  upload_code(op->prog, op->code_dev);
+  op->agg = AggSpec{};
+  op->agg.n_keys = (int)key_nodes.size(); op->agg.n_accs = (int)accs.size();
+  std::vector<int> kregs; bool any_null_key = false;
+  for (size_t k = 0; k < key_nodes.size(); ++k) {
+    op->agg.key_reg[k] = op->prog.out_reg[key_slots[k]]; kregs.push_back(op->agg.key_reg[k]);
+    op->key_types.push_back(key_nodes[k]->type); any_null_key = any_null_key || key_nodes[k]->nullable;
+    if (key_nodes[k]->type.id == T_BOOL || key_nodes[k]->type.id == T_NULL) throw Unsupported("group-by key of type " + key_nodes[k]->type.to_string());
+  }
+  for (size_t i = 0; i < accs.size(); ++i) {
+    op->agg.acc_kind[i] = accs[i].kind; op->agg.acc_reg[i] = accs[i].arg ? op->prog.out_reg[acc_slots[i]] : 0;
+    op->acc_types.push_back(accs[i].type);
+  }
+  op->keys = make_keyspec(kregs, op->key_types, any_null_key);
+
+  // post program over the SoA result: [key_0.., acc_0..] as raw (lo,hi) columns
+  for (size_t k = 0; k < key_nodes.size(); ++k) { Field f; f.name = key_names[k]; f.type = key_nodes[k]->type; f.nullable = key_nodes[k]->nullable; f.raw128 = 1; op->post_schema.fields.push_back(f); }
+  for (size_t i = 0; i < accs.size(); ++i) { Field f; f.name = "acc" + std::to_string(i); f.type = accs[i].type; f.nullable = false; f.raw128 = 1; op->post_schema.fields.push_back(f); }
+  ExprCompiler pc(op->post_schema);
+  const int nk = (int)key_nodes.size();
+  std::vector<std::string> out_names;
+  for (int k = 0; k < nk; ++k) { pc.add_output(pc.column(k)); out_names.push_back(key_names[k]); }
+  for (const AggPlan& pl : plans) {
+    auto acc = [&](int i) { return pc.column(nk + i); };
+    auto guard = [&](NodeP v) { return pl.acc_cnt >= 0 && (pl.arg_nullable) ? pc.nullif0(v, acc(pl.acc_cnt)) : v; };
+    if (pl.fn == "COUNT") { pc.add_output(acc(pl.acc_cnt)); out_names.push_back(emit_state ? pl.name + "[count]" : pl.name); }
+    else if (pl.fn == "SUM") { pc.add_output(guard(acc(pl.acc_sum))); out_names.push_back(emit_state ? pl.name + "[sum]" : pl.name); }
+    else if (pl.fn == "MIN" || pl.fn == "MAX") { pc.add_output(guard(acc(pl.acc_mm))); out_names.push_back(emit_state ? pl.name + (pl.fn == "MIN" ? "[min]" : "[max]") : pl.name); }
+    else if (pl.fn == "AVG") {
+      if (emit_state) {
+        pc.add_output(pc.cast(acc(pl.acc_cnt), t_of(T_UINT64))); out_names.push_back(pl.name + "[count]");
+        pc.add_output(guard(acc(pl.acc_sum))); out_names.push_back(pl.name + "[sum]");
+      } else if (pl.is_float) {
+        NodeP cnt = pc.cast(acc(pl.acc_cnt), t_of(T_FLOAT64));
+        pc.add_output(pc.nullif0(pc.raw(OP_FDIV, t_of(T_FLOAT64), true, 127, {acc(pl.acc_sum), cnt}), acc(pl.acc_cnt))); out_names.push_back(pl.name);
+      } else {
+        // Decimal AVG: sum * 10^(s_avg - s_sum) / count, truncating; count == 0 -> NULL (OP_DIV by zero)
+        const DType st = op->acc_types[pl.acc_sum];
+        // the sum state is Decimal(min(38,p+10), s); the argument was Decimal(p, s)
+        const int arg_p = is_final ? std::max(1, st.p - 10) : pl.arg_type.p;
+        const DType rt = dec_t(arg_p + 4, st.s + 4);
+        NodeP scaled = pc.raw(OP_MUL, rt, false, 127, {acc(pl.acc_sum), pc.lit_int(dec_t(38, 0), pow10_i128(rt.s - st.s))});
+        pc.add_output(pc.raw(OP_DIV, rt, true, 127, {scaled, acc(pl.acc_cnt)})); out_names.push_back(pl.name);
+      }
+    }
+  }
+  op->post = pc.finish();
+  upload_code(op->post, op->post_code);
+  for (size_t i = 0; i < op->post.out_type.size(); ++i) op->out_fields.push_back(make_field(out_names[i], op->post.out_type[i], op->post.out_nullable[i]));
+}
+
+OutSpec make_outspec(const CompiledProgram& cp, gpuq_column* outs, int n_outs, const std::vector<gpuq_field_info>& fields) {
+  if (n_outs != (int)cp.out_reg.size()) throw std::runtime_error("expected " + std::to_string(cp.out_reg.size()) + " output columns, got " + std::to_string(n_outs));
+  if (n_outs > MAX_OUTS) throw Unsupported("more than " + std::to_string(MAX_OUTS) + " output columns in one call");
+  OutSpec O{}; O.n_out = n_outs;
+  for (int i = 0; i < n_outs; ++i) {
+    if (!outs[i].data) throw std::runtime_error("output column " + std::to_string(i) + " has no data buffer");
+    O.cols[i].data = const_cast<void*>(outs[i].data);
+    O.cols[i].validity = (u64*)const_cast<uint8_t*>(outs[i].validity);
+    O.cols[i].reg = cp.out_reg[i];
+    O.cols[i].cls = col_class_for(cp.out_type[i]);
+    outs[i].type = fields[i].type; outs[i].precision = fields[i].precision; outs[i].scale = fields[i].scale; outs[i].repr = fields[i].repr;
+  }
+  return O;
+}
+
+void check_ctx(gpuq_ctx* c) { if (!c) throw std::runtime_error("ctx is NULL"); HIPCHECK(hipSetDevice(c->device)); }
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int gpuq_abi_version(void) { return GPUQ_ABI_VERSION; }
+
+gpuq_ctx* gpuq_ctx_create(int device_ordinal, const char* json_opts) {
+  gpuq_ctx* c = nullptr;
+  int rc = guarded(nullptr, [&]() {
+    int dev = device_ordinal;
+    if (json_opts && *json_opts) { Json o = JsonParser(json_opts).parse(); dev = (int)o.get_i64("device", dev); }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) throw HipError("no usable HIP device (gpuq has no CPU fallback): " + std::string(hipGetErrorString(e)));
+    if (dev < 0 || dev >= count) throw std::runtime_error("device ordinal out of range");
+    HIPCHECK(hipSetDevice(dev));
+    hipDeviceProp_t prop; HIPCHECK(hipGetDeviceProperties(&prop, dev));
+    c = new gpuq_ctx();
+    c->device = dev; c->cus = prop.multiProcessorCount; c->hbm = prop.totalGlobalMem; c->name = prop.name; c->arch = prop.gcnArchName;
+    set_num_cus(c->cus);
+  });
+  if (rc != GPUQ_OK) { delete c; return nullptr; }
+  return c;
+}
+void gpuq_ctx_free(gpuq_ctx* ctx) { delete ctx; }
+const char* gpuq_last_error(gpuq_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+int gpuq_ctx_device_info(gpuq_ctx* ctx, char* buf, size_t cap) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    std::snprintf(buf, cap, "{\"name\":\"%s\",\"arch\":\"%s\",\"cus\":%d,\"hbm_bytes\":%zu}", ctx->name.c_str(), ctx->arch.c_str(), ctx->cus, ctx->hbm);
+  });
+}
+
+// ---------------------------------------------------------------- op create
+static void compile_op(gpuq_op* op, const Json& d) {
+    const std::string kind = d.at("op").str();
+    op->in_schema = schema_from_json(d.at("input"));
+    if (kind == "filter") {
+      op->kind = K_FILTER;
+      ExprCompiler ec(op->in_schema); ec.add_predicate(ec.from_json(d.at("predicate")));
+      op->prog = ec.finish(); upload_code(op->prog, op->code_dev);
+    } else if (kind == "project") {
+      op->kind = K_PROJECT;
+      ExprCompiler ec(op->in_schema);
+      std::vector<std::string> names;
+      for (const Json& e : d.at("exprs").a) { ec.add_output(ec.from_json(e.at("expr"))); names.push_back(e.get_str("name", "col" + std::to_string(names.size()))); }
+      op->prog = ec.finish(); upload_code(op->prog, op->code_dev);
+      for (size_t i = 0; i < names.size(); ++i) op->out_fields.push_back(make_field(names[i], op->prog.out_type[i], op->prog.out_nullable[i]));
+    } else if (kind == "aggregate") {
+      op->kind = K_AGG; compile_aggregate(op, d);
+    } else if (kind == "join_build" || kind == "join_probe") {
+      op->kind = kind == "join_build" ? K_JOIN_BUILD : K_JOIN_PROBE;
+      ExprCompiler ec(op->in_schema);
+      if (d.has("predicate")) ec.add_predicate(ec.from_json(d.at("predicate")));
+      std::vector<NodeP> ks;
+      for (const Json& e : d.at("on").a) { NodeP n = ec.from_json(e); ks.push_back(n); ec.add_output(n); }
+      if (ks.empty()) throw std::runtime_error("join needs at least one key");
+      op->prog = ec.finish(); upload_code(op->prog, op->code_dev);
+      op->null_eq = d.get_bool("null_equals_null", false) ? 1 : 0;
+      std::vector<int> regs; for (size_t k = 0; k < ks.size(); ++k) { regs.push_back(op->prog.out_reg[k]); op->key_types.push_back(ks[k]->type); }
+      op->keys = make_keyspec(regs, op->key_types, op->null_eq != 0);
+      if (op->kind == K_JOIN_PROBE) {
+        static const std::map<std::string, int> jt = {{"Inner", JT_INNER}, {"Left", JT_LEFT}, {"Right", JT_RIGHT}, {"Full", JT_FULL},
+            {"LeftSemi", JT_LEFT_SEMI}, {"LeftAnti", JT_LEFT_ANTI}, {"RightSemi", JT_RIGHT_SEMI}, {"RightAnti", JT_RIGHT_ANTI}};
+        auto it = jt.find(d.get_str("join_type", "Inner"));
+        if (it == jt.end()) throw std::runtime_error("unknown join_type");
+        op->join_type = it->second;
+      }
+    } else if (kind == "sort") {
+      op->kind = K_SORT;
+      ExprCompiler ec(op->in_schema);
+      const auto& es = d.at("expr").a;
+      if (es.empty() || es.size() > (size_t)MAX_SORT_KEYS) throw Unsupported("sort needs 1.." + std::to_string(MAX_SORT_KEYS) + " keys");
+      std::vector<NodeP> ks;
+      for (const Json& e : es) { NodeP n = ec.from_json(e.at("expr")); ks.push_back(n); ec.add_output(n); }
+      op->prog = ec.finish(); upload_code(op->prog, op->code_dev);
+      op->sort.n_keys = (int)ks.size();
+      for (size_t k = 0; k < ks.size(); ++k) {
+        const bool asc = es[k].get_bool("asc", true);
+        op->sort.reg[k] = op->prog.out_reg[k]; op->sort.desc[k] = asc ? 0 : 1;
+        op->sort.nulls_first[k] = es[k].get_bool("nulls_first", !asc) ? 1 : 0;
+        op->sort.kind[k] = ks[k]->type.is_float() ? 1 : (ks[k]->type.id == T_UTF8 ? 2 : 0);
+      }
+      op->fetch = d.get_i64("fetch", -1);
+    } else if (kind == "partition") {
+      op->kind = K_PARTITION;
+      ExprCompiler ec(op->in_schema);
+      std::vector<NodeP> ks;
+      for (const Json& e : d.at("hash_expr").a) { NodeP n = ec.from_json(e); ks.push_back(n); ec.add_output(n); }
+      if (ks.empty()) throw std::runtime_error("partition needs at least one hash expression");
+      op->prog = ec.finish(); upload_code(op->prog, op->code_dev);
+      std::vector<int> regs; for (size_t k = 0; k < ks.size(); ++k) { regs.push_back(op->prog.out_reg[k]); op->key_types.push_back(ks[k]->type); }
+      op->keys = make_keyspec(regs, op->key_types, false);
+      const i64 np = d.at("partition_count").i64();
+      if (np < 1 || np > 65536) throw std::runtime_error("partition_count out of range (1..65536)");
+      op->nparts = (uint32_t)np;
+    } else throw std::runtime_error("unknown op '" + kind + "'");
+}
+
+int gpuq_op_create(gpuq_ctx* ctx, const char* json, gpuq_op** out) {
+  gpuq_op* op = nullptr;
+  int rc = guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!json || !out) throw std::runtime_error("json/out is NULL");
+    Json d = JsonParser(json).parse();
+    op = new gpuq_op(); op->ctx = ctx;
+    op->flags_dev.ensure(256); HIPCHECK(hipMemset(op->flags_dev.p, 0, 256));
+    g_upload = true;
+    compile_op(op, d);
+    *out = op;
+  });
+  if (rc != GPUQ_OK) { delete op; if (out) *out = nullptr; }
+  return rc;
+}
+
+static const char* op_name(int op) {
+  static const char* n[] = {"NOP","IMM","MOV","ADD","SUB","MUL","MULW","NEG","DIV","MOD","EQ","NE","LT","LE","GT","GE","FADD","FSUB","FMUL","FDIV","FNEG",
+    "FEQ","FNE","FLT","FLE","FGT","FGE","I2F","F2I","AND","OR","NOT","ISNULL","ISNOTNULL","SELECT","SHL","BOR","NULLIF0","COALESCE0"};
+  return (op >= 0 && op < (int)(sizeof(n) / sizeof(n[0]))) ? n[op] : "?";
+}
+static std::string describe_program(const CompiledProgram& p, const Schema& sc) {
+  std::string r = "{\"columns\":[";
+  for (size_t i = 0; i < p.col_field.size(); ++i) { if (i) r += ","; r += "\"" + sc.fields[p.col_field[i]].name + "\""; }
+  r += "],\"pred_reg\":" + std::to_string(p.pred_reg) + ",\"insns\":[";
+  for (int i = 0; i < p.n_insns; ++i) {
+    const DevInsn& in = p.code.insns[i];
+    if (i) r += ",";
+    r += std::string("\"") + op_name(in.op) + " r" + std::to_string(in.dst) + " r" + std::to_string(in.a) + " r" + std::to_string(in.b) + " #" + std::to_string(in.imm) + "\"";
+  }
+  r += "],\"out_reg\":[";
+  for (size_t i = 0; i < p.out_reg.size(); ++i) { if (i) r += ","; r += std::to_string(p.out_reg[i]); }
+  r += "],\"out_type\":[";
+  for (size_t i = 0; i < p.out_type.size(); ++i) { if (i) r += ","; r += "\"" + p.out_type[i].to_string() + "\""; }
+  return r + "]}";
+}
+
+// Host-only: compile a descriptor without touching a device and describe the result (CPU tests,
+// plan validation in a scheduler-side process).  buf receives JSON.
+int gpuq_compile_check(const char* json, char* buf, size_t cap) {
+  gpuq_op* op = nullptr;
+  int rc = guarded(nullptr, [&]() {
+    if (!json) throw std::runtime_error("json is NULL");
+    Json d = JsonParser(json).parse();
+    op = new gpuq_op();
+    g_upload = false;
+    compile_op(op, d);
+    g_upload = true;
+    std::string r = "{\"program\":" + describe_program(op->prog, op->in_schema);
+    if (op->kind == K_AGG) {
+      r += ",\"post\":" + describe_program(op->post, op->post_schema) + ",\"acc_kinds\":[";
+      for (int a = 0; a < op->agg.n_accs; ++a) { if (a) r += ","; r += std::to_string(op->agg.acc_kind[a]); }
+      r += "]";
+    }
+    r += ",\"outputs\":[";
+    for (size_t i = 0; i < op->out_fields.size(); ++i) {
+      const gpuq_field_info& f = op->out_fields[i];
+      if (i) r += ",";
+      DType t; t.id = f.type; t.p = f.precision; t.s = f.scale;
+      r += std::string("{\"name\":\"") + f.name + "\",\"type\":\"" + t.to_string() + "\",\"nullable\":" + (f.nullable ? "true" : "false") + "}";
+    }
+    r += "]}";
+    if (buf && cap) { std::snprintf(buf, cap, "%s", r.c_str()); if (r.size() + 1 > cap) throw Capacity("describe buffer too small"); }
+  });
+  g_upload = true;
+  delete op;
+  return rc;
+}
+void gpuq_op_free(gpuq_op* op) { delete op; }
+int gpuq_op_num_outputs(gpuq_op* op) { return op ? (int)op->out_fields.size() : 0; }
+int gpuq_op_output_field(gpuq_op* op, int i, gpuq_field_info* out) {
+  if (!op || !out || i < 0 || i >= (int)op->out_fields.size()) return GPUQ_ERR_INVALID;
+  *out = op->out_fields[i]; return GPUQ_OK;
+}
+int gpuq_op_check(gpuq_op* op, void* stream) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() { check_ctx(op->ctx); const uint32_t f = read_flags(op, (hipStream_t)stream); if (f) { reset_flags(op, (hipStream_t)stream); raise_flags(f); } });
+}
+int gpuq_op_profile(gpuq_op* op, int enable, float* kernel_ms_out, int* launches_out) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() {
+    if (op->ev_pending) { float ms = 0; HIPCHECK(hipEventSynchronize(op->ev1)); HIPCHECK(hipEventElapsedTime(&ms, op->ev0, op->ev1)); op->kernel_ms += ms; op->ev_pending = false; }
+    if (kernel_ms_out) *kernel_ms_out = op->kernel_ms;
+    if (launches_out) *launches_out = op->launches;
+    op->kernel_ms = 0; op->launches = 0; op->profile = enable != 0;
+  });
+}
+
+// ---------------------------------------------------------------- filter
+int gpuq_filter_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, uint32_t* sel_out, uint64_t* count_out) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() {
+    check_ctx(op->ctx);
+    if (op->kind != K_FILTER) throw std::runtime_error("not a filter operator");
+    hipStream_t s = (hipStream_t)stream;
+    DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
+    if (payload_via < 0 || payload_via > in->n_via) throw std::runtime_error("payload_via out of range");
+    const i64 n = in->n_rows;
+    if (n == 0) { if (count_out) HIPCHECK(hipMemsetAsync(count_out, 0, 8, s)); return; }
+    const i64 nwords = (n + 63) >> 6;
+    const i64 maxb = (i64)op->ctx->cus * 8;
+    i64 wpb = (nwords + maxb - 1) / maxb; if (wpb < 16) wpb = 16;
+    const int nblocks = (int)((nwords + wpb - 1) / wpb);
+    u64* bitmap = (u64*)op->ws[0].ensure((size_t)nwords * 8);
+    uint32_t* counts = (uint32_t*)op->ws[1].ensure((size_t)nblocks * 4 + 16);
+    u64* total = count_out ? (u64*)count_out : (u64*)op->ws[2].ensure(8);
+    { ProfScope ps(op, s); launch_filter_bitmap(s, P, n, bitmap, counts, nblocks, wpb); }
+    launch_scan_block_counts(s, counts, nblocks, total);
+    if (sel_out) launch_compact(s, bitmap, counts, nblocks, wpb, n, payload_via > 0 ? in->via[payload_via - 1] : nullptr, sel_out);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+// ---------------------------------------------------------------- project
+int gpuq_project_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() {
+    check_ctx(op->ctx);
+    if (op->kind != K_PROJECT) throw std::runtime_error("not a project operator");
+    hipStream_t s = (hipStream_t)stream;
+    DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
+    OutSpec O = make_outspec(op->prog, outs, n_outs, op->out_fields);
+    for (int i = 0; i < n_outs; ++i) outs[i].length = in->n_rows;
+    { ProfScope ps(op, s); launch_project(s, P, in->n_rows, O); }
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+// ---------------------------------------------------------------- aggregate
+int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs, int64_t cap, int64_t* n_groups_out) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() {
+    check_ctx(op->ctx);
+    if (op->kind != K_AGG) throw std::runtime_error("not an aggregate operator");
+    hipStream_t s = (hipStream_t)stream;
+    DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
+    const i64 n = in->n_rows;
+    const int nk = op->agg.n_keys, na = op->agg.n_accs, kstride = nk > 0 ? nk : 1;
+    uint32_t ng = 0;
+    AggOut raw{};
+    auto alloc_raw = [&](i64 rcap) {
+      raw.cap = (int32_t)rcap;
+      raw.keys = (u64*)op->ws[0].ensure((size_t)rcap * kstride * 16);
+      raw.key_nulls = (uint32_t*)op->ws[1].ensure((size_t)rcap * 4);
+      raw.cells = (u64*)op->ws[2].ensure((size_t)rcap * na * 16);
+      raw.n_groups = (uint32_t*)op->ws[3].ensure(16);
+      HIPCHECK(hipMemsetAsync(raw.n_groups, 0, 16, s));
+    };
+    auto read_ng = [&]() { uint32_t v = 0; HIPCHECK(hipMemcpyAsync(&v, raw.n_groups, 4, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s)); return v; };
+    bool done = false;
+    std::string strat = op->strategy;
+    if (nk == 0) strat = "tiny";
+    if (strat == "auto" || strat == "tiny") {
+      const int fit_big = agg_tiny_max_groups(na);
+      if (fit_big < 1) { if (strat == "tiny") throw Unsupported("too many accumulators for the LDS aggregate"); }
+      else {
+        int fit_small = 0; for (int g = 1; g <= fit_big; ++g) { int nb; (void)nb; if ((size_t)g * na * 2048 + 4096 <= 64 * 1024) fit_small = g; }
+        std::vector<int> tries;
+        if (nk == 0) tries = {1};
+        else { if (fit_small >= 4) tries.push_back(fit_small); tries.push_back(fit_big); }
+        for (int gmax : tries) {
+          int nb = 0; const size_t wsb = agg_tiny_workspace_bytes(gmax, nk, na, &nb);
+          void* wsp = op->ws[4].ensure(wsb);
+          alloc_raw(64);
+          reset_flags(op, s);
+          { ProfScope ps(op, s); launch_agg_tiny(s, P, n, op->agg, gmax, wsp, raw); }
+          HIPCHECK(hipGetLastError());
+          const uint32_t f = read_flags(op, s);
+          if (f & ~FLAG_GROUP_OVERFLOW) { reset_flags(op, s); raise_flags(f & ~FLAG_GROUP_OVERFLOW); }
+          if (!(f & FLAG_GROUP_OVERFLOW)) { ng = read_ng(); done = true; break; }
+        }
+        if (!done && strat == "tiny") throw Capacity("more groups than the LDS aggregate holds; use strategy hash/auto");
+      }
+    }
+    if (!done) {
+      // global hash table; grow on FLAG_TABLE_FULL
+      u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (u64)std::min<i64>(n, 1ll << 24);
+      if (est < 1024) est = 1024;
+      HashTable T{};
+      T.key_words = op->keys.key_words; T.slot_words = 1 + T.key_words + 2 * na;
+      for (;;) {
+        T.n_slots = next_pow2(est * 2);
+        T.slots = (u64*)op->ws[5].ensure((size_t)T.n_slots * T.slot_words * 8);
+        launch_ht_init(s, T, &op->agg);
+        reset_flags(op, s);
+        { ProfScope ps(op, s); launch_agg_hash(s, P, n, op->keys, op->agg, T); }
+        HIPCHECK(hipGetLastError());
+        const uint32_t f = read_flags(op, s);
+        if (f & FLAG_TABLE_FULL) { if (est >= (u64)std::max<i64>(n, 1024)) throw std::runtime_error("hash aggregate: table full at maximum size"); est = std::min<u64>(est * 4, (u64)std::max<i64>(n, 1024)); continue; }
+        if (f) { reset_flags(op, s); raise_flags(f); }
+        break;
+      }
+      // count live slots first so the raw buffers are sized exactly
+      alloc_raw(1);
+      raw.cap = 0;
+      launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
+      ng = read_ng();
+      reset_flags(op, s);
+      alloc_raw(std::max<i64>(ng, 1));
+      launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
+      HIPCHECK(hipGetLastError());
+      ng = read_ng();
+    }
+    if (n_groups_out) *n_groups_out = ng;
+    if ((i64)ng > cap) throw Capacity("aggregate produced " + std::to_string(ng) + " groups, output capacity is " + std::to_string(cap));
+    // AoS -> SoA, then the final projection into the caller's typed columns
+    const size_t colbytes = (size_t)std::max<uint32_t>(ng, 1) * 16, vbytes = ((size_t)ng + 63) / 64 * 8 + 8;
+    char* soa_mem = (char*)op->ws[6].ensure((size_t)(nk + na) * colbytes + (size_t)nk * vbytes);
+    AggSoA soa{};
+    std::vector<gpuq_column> pcols(nk + na);
+    for (int k = 0; k < nk; ++k) {
+      soa.key_col[k] = (ulonglong2*)(soa_mem + (size_t)k * colbytes);
+      soa.key_valid[k] = (u64*)(soa_mem + (size_t)(nk + na) * colbytes + (size_t)k * vbytes);
+      const DType& t = op->key_types[k];
+      pcols[k] = gpuq_column{t.id, t.p, t.s, 0, soa.key_col[k], nullptr, op->post_schema.fields[k].nullable ? (const uint8_t*)soa.key_valid[k] : nullptr, (int64_t)ng};
+    }
+    for (int a = 0; a < na; ++a) {
+      soa.acc_col[a] = (ulonglong2*)(soa_mem + (size_t)(nk + a) * colbytes);
+      const DType& t = op->acc_types[a];
+      pcols[nk + a] = gpuq_column{t.id, t.p, t.s, 0, soa.acc_col[a], nullptr, nullptr, (int64_t)ng};
+    }
+    launch_agg_emit(s, raw, nk, na, ng, soa);
+    gpuq_input pin{}; pin.cols = pcols.data(); pin.n_cols = nk + na; pin.n_rows = ng; pin.n_via = 0;
+    DevProgram PP = bind_program(op->post, op->post_schema, op->post_code.as<DevCode>(), op->flags_dev.as<uint32_t>(), &pin);
+    OutSpec O = make_outspec(op->post, outs, n_outs, op->out_fields);
+    for (int i = 0; i < n_outs; ++i) outs[i].length = ng;
+    launch_project(s, PP, ng, O);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(s));
+  });
+}
+
+// ---------------------------------------------------------------- join
+int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, int64_t build_rows_bound, gpuq_join_table** out) {
+  if (!op) return GPUQ_ERR_INVALID;
+  gpuq_join_table* t = nullptr;
+  int rc = guarded(op->ctx, [&]() {
+    check_ctx(op->ctx);
+    if (op->kind != K_JOIN_BUILD) throw std::runtime_error("not a join_build operator");
+    if (!out) throw std::runtime_error("out is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
+    if (payload_via < 0 || payload_via > in->n_via) throw std::runtime_error("payload_via out of range");
+    const i64 n = in->n_rows;
+    if (build_rows_bound < n && payload_via == 0) build_rows_bound = n;
+    if (build_rows_bound < 0 || build_rows_bound > 0xFFFFFFFEll) throw std::runtime_error("build_rows_bound out of range");
+    t = new gpuq_join_table(); t->ctx = op->ctx; t->keys = op->keys; t->null_eq = op->null_eq; t->bound = build_rows_bound;
+    t->T.key_words = op->keys.key_words; t->T.slot_words = 1 + t->T.key_words;
+    t->T.n_slots = next_pow2(std::max<u64>((u64)n * 2, 1024));
+    t->T.slots = (u64*)t->slots.ensure((size_t)t->T.n_slots * t->T.slot_words * 8);
+    uint32_t* next = (uint32_t*)t->next.ensure((size_t)std::max<i64>(build_rows_bound, 1) * 4);
+    const size_t bm = ((size_t)build_rows_bound + 63) / 64 * 8 + 8;
+    uint32_t* present = (uint32_t*)t->present.ensure(bm);
+    HIPCHECK(hipMemsetAsync(present, 0, bm, s));
+    launch_ht_init(s, t->T, nullptr);
+    reset_flags(op, s);
+    { ProfScope ps(op, s); launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq); }
+    HIPCHECK(hipGetLastError());
+    const uint32_t f = read_flags(op, s);
+    if (f & ~FLAG_DUP_BUILD_KEY) { reset_flags(op, s); raise_flags(f & ~FLAG_DUP_BUILD_KEY); }
+    if (f) reset_flags(op, s);
+    *out = t;
+  });
+  if (rc != GPUQ_OK) { delete t; if (out) *out = nullptr; }
+  return rc;
+}
+void gpuq_join_table_free(gpuq_join_table* t) { delete t; }
+
+int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpuq_input* in, int payload_via, uint32_t* out_build,
+                        uint32_t* out_probe, uint64_t out_cap, uint64_t* count_out) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() {
+    check_ctx(op->ctx);
+    if (op->kind != K_JOIN_PROBE) throw std::runtime_error("not a join_probe operator");
+    if (!t || !count_out) throw std::runtime_error("table/count_out is NULL");
+    if (op->keys.n_keys != t->keys.n_keys || op->keys.key_words != t->keys.key_words) throw std::runtime_error("probe keys do not match the build keys (count / width)");
+    for (int k = 0; k < op->keys.n_keys; ++k) if (op->keys.key_wide[k] != t->keys.key_wide[k]) throw std::runtime_error("probe key " + std::to_string(k) + " width class differs from the build key; cast one side");
+    hipStream_t s = (hipStream_t)stream;
+    DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
+    if (payload_via < 0 || payload_via > in->n_via) throw std::runtime_error("payload_via out of range");
+    const int jt = op->join_type;
+    const bool need_pairs = (jt == JT_INNER || jt == JT_LEFT || jt == JT_RIGHT || jt == JT_FULL);
+    if (need_pairs && (!out_build || !out_probe) && out_cap > 0) throw std::runtime_error("pair outputs are NULL");
+    if ((jt == JT_RIGHT_SEMI || jt == JT_RIGHT_ANTI) && !out_probe && out_cap > 0) throw std::runtime_error("out_probe is NULL");
+    uint32_t* visited = nullptr;
+    if (jt == JT_LEFT || jt == JT_FULL || jt == JT_LEFT_SEMI || jt == JT_LEFT_ANTI) {
+      const size_t bm = ((size_t)t->bound + 63) / 64 * 8 + 8;
+      visited = (uint32_t*)t->visited.ensure(bm);
+      if (!t->visited_ready) { HIPCHECK(hipMemsetAsync(visited, 0, bm, s)); t->visited_ready = true; }
+    }
+    HIPCHECK(hipMemsetAsync(count_out, 0, 8, s));
+    { ProfScope ps(op, s);
+      launch_join_probe(s, P, in->n_rows, op->keys, t->T, t->next.as<uint32_t>(), jt, payload_via, op->null_eq, out_build, out_probe, out_cap, (u64*)count_out, visited); }
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int gpuq_join_build_side_rows(gpuq_join_table* t, void* stream, int matched, uint32_t* rows_out, uint64_t* count_out) {
+  if (!t) return GPUQ_ERR_INVALID;
+  return guarded(t->ctx, [&]() {
+    check_ctx(t->ctx);
+    hipStream_t s = (hipStream_t)stream;
+    const i64 n = t->bound;
+    if (n == 0) { if (count_out) HIPCHECK(hipMemsetAsync(count_out, 0, 8, s)); return; }
+    const size_t bm = ((size_t)n + 63) / 64 * 8 + 8;
+    if (!t->visited_ready) { HIPCHECK(hipMemsetAsync(t->visited.ensure(bm), 0, bm, s)); t->visited_ready = true; }
+    const i64 nwords = (n + 63) >> 6;
+    const i64 maxb = (i64)t->ctx->cus * 8;
+    i64 wpb = (nwords + maxb - 1) / maxb; if (wpb < 16) wpb = 16;
+    const int nblocks = (int)((nwords + wpb - 1) / wpb);
+    u64* bitmap = (u64*)t->ws_bitmap.ensure((size_t)nwords * 8);
+    uint32_t* counts = (uint32_t*)t->ws_counts.ensure((size_t)nblocks * 4 + 16 + 8);
+    u64* total = count_out ? (u64*)count_out : (u64*)((char*)counts + (size_t)nblocks * 4 + 8 - ((size_t)nblocks * 4) % 8);
+    launch_bitmap_select(s, (const u64*)t->present.p, (const u64*)t->visited.p, matched, nwords, n, bitmap, counts, nblocks, wpb);
+    launch_scan_block_counts(s, counts, nblocks, total);
+    if (rows_out) launch_compact(s, bitmap, counts, nblocks, wpb, n, nullptr, rows_out);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+// ---------------------------------------------------------------- sort
+static int bitlen128(u128 v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() {
+    check_ctx(op->ctx);
+    if (op->kind != K_SORT) throw std::runtime_error("not a sort operator");
+    hipStream_t s = (hipStream_t)stream;
+    DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
+    const i64 n = in->n_rows;
+    if (n == 0) return;
+    if (n >= (1ll << 31)) throw Unsupported("sort of >= 2^31 rows in one call");
+    if (!perm_out) throw std::runtime_error("perm_out is NULL");
+    const SortSpec& S = op->sort;
+    // 1. per-key min/max in the ordered view
+    const int mb = sort_minmax_blocks(n);
+    u64* mm = (u64*)op->ws[0].ensure((size_t)mb * MAX_SORT_KEYS * 5 * 8);
+    launch_sort_minmax(s, P, n, S, mm, mb);
+    std::vector<u64> hmm((size_t)mb * MAX_SORT_KEYS * 5);
+    HIPCHECK(hipMemcpyAsync(hmm.data(), mm, hmm.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    SortPack K{}; int width[MAX_SORT_KEYS] = {0, 0, 0, 0}; int total = 0;
+    for (int k = 0; k < S.n_keys; ++k) {
+      i128 mn = ((i128)0x7FFFFFFFFFFFFFFFll << 64) | (i128)0xFFFFFFFFFFFFFFFFull, mx = -mn - 1; u64 fl = 0;
+      for (int b = 0; b < mb; ++b) {
+        const u64* o = &hmm[((size_t)b * MAX_SORT_KEYS + k) * 5];
+        if (!(o[4] & 1)) { fl |= o[4]; continue; }
+        const i128 a = (i128)(((u128)o[1] << 64) | o[0]), c = (i128)(((u128)o[3] << 64) | o[2]);
+        if (a < mn) mn = a;
+        if (c > mx) mx = c;
+        fl |= o[4];
+      }
+      int vb = 0;
+      if (fl & 1) { vb = bitlen128((u128)(mx - mn)); const i128 base = S.desc[k] ? mx : mn; K.base_lo[k] = (u64)base; K.base_hi[k] = (u64)((u128)base >> 64); }
+      K.null_bit[k] = (fl & 2) ? vb : -1;
+      width[k] = vb + ((fl & 2) ? 1 : 0);
+      total += width[k];
+    }
+    if (total > 128) throw Unsupported("composite sort key needs " + std::to_string(total) + " bits (max 128)");
+    { int sh = 0; for (int k = S.n_keys - 1; k >= 0; --k) { K.shift[k] = sh; sh += width[k]; } }
+    // 2. pack + LSD radix passes
+    u64* klo = (u64*)op->ws[1].ensure((size_t)n * 8);
+    u64* klo2 = (u64*)op->ws[2].ensure((size_t)n * 8);
+    u64* khi = total > 64 ? (u64*)op->ws[3].ensure((size_t)n * 8) : nullptr;
+    uint32_t* ids = (uint32_t*)op->ws[4].ensure((size_t)n * 4);
+    uint32_t* ids2 = (uint32_t*)op->ws[5].ensure((size_t)n * 4);
+    int nblocks; i64 tile; radix_geometry(n, &nblocks, &tile);
+    int32_t* hist = (int32_t*)op->ws[6].ensure(radix_hist_entries(nblocks) * 4 + 16);
+    const size_t swb = exclusive_scan_ws_bytes((i64)radix_hist_entries(nblocks));
+    void* sws = op->ws[7].ensure(swb);
+    ProfScope ps(op, s);
+    launch_sort_pack(s, P, n, S, K, klo, khi, ids);
+    auto run_passes = [&](int bits) {
+      for (int sh = 0; sh < bits; sh += 8) {
+        launch_radix_pass(s, klo, ids, n, sh, 0xFFu, klo2, ids2, hist, sws, swb);
+        std::swap(klo, klo2); std::swap(ids, ids2);
+      }
+    };
+    run_passes(std::min(total, 64));
+    if (total > 64) {
+      launch_gather_u64(s, khi, ids, n, klo);   // hi words in the current order
+      run_passes(total - 64);
+    }
+    HIPCHECK(hipMemcpyAsync(perm_out, ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+// ---------------------------------------------------------------- partition
+int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out, uint64_t* part_offsets_out) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() {
+    check_ctx(op->ctx);
+    if (op->kind != K_PARTITION) throw std::runtime_error("not a partition operator");
+    hipStream_t s = (hipStream_t)stream;
+    DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
+    const i64 n = in->n_rows;
+    const uint32_t np = op->nparts;
+    if (!part_offsets_out) throw std::runtime_error("part_offsets_out is NULL");
+    if (n == 0) { HIPCHECK(hipMemsetAsync(part_offsets_out, 0, (size_t)(np + 1) * 8, s)); return; }
+    if (n >= (1ll << 31)) throw Unsupported("partition of >= 2^31 rows in one call");
+    if (!perm_out) throw std::runtime_error("perm_out is NULL");
+    u64* pid = (u64*)op->ws[1].ensure((size_t)n * 8);
+    u64* pid2 = (u64*)op->ws[2].ensure((size_t)n * 8);
+    uint32_t* ids = (uint32_t*)op->ws[4].ensure((size_t)n * 4);
+    uint32_t* ids2 = (uint32_t*)op->ws[5].ensure((size_t)n * 4);
+    int nblocks; i64 tile; radix_geometry(n, &nblocks, &tile);
+    int32_t* hist = (int32_t*)op->ws[6].ensure(radix_hist_entries(nblocks) * 4 + 16);
+    const size_t swb = exclusive_scan_ws_bytes((i64)radix_hist_entries(nblocks));
+    void* sws = op->ws[7].ensure(swb);
+    ProfScope ps(op, s);
+    launch_part_pid(s, P, n, op->keys, np, pid, ids);
+    launch_part_offsets(s, pid, n, np, (uint32_t*)op->ws[8].ensure((size_t)(np + 1) * 4 + 16), (u64*)part_offsets_out);
+    int bits = 0; while ((1u << bits) < np) ++bits;
+    for (int sh = 0; sh < bits || sh == 0; sh += 8) {
+      launch_radix_pass(s, pid, ids, n, sh, 0xFFu, pid2, ids2, hist, sws, swb);
+      std::swap(pid, pid2); std::swap(ids, ids2);
+      if (bits == 0) break;
+    }
+    HIPCHECK(hipMemcpyAsync(perm_out, ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+// ---------------------------------------------------------------- utf8 unpack
+int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n, int32_t* offsets_out, uint8_t* data_out, int64_t data_cap,
+                     int64_t* data_len_out) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    if (n < 0 || !offsets_out) throw std::runtime_error("bad arguments");
+    if (n == 0) { HIPCHECK(hipMemsetAsync(offsets_out, 0, 4, s)); if (data_len_out) *data_len_out = 0; return; }
+    DevBuf ws; ws.ensure(exclusive_scan_ws_bytes(n));
+    launch_unpack_utf8_lengths(s, (const ulonglong2*)packed, n, offsets_out);
+    launch_exclusive_scan_i32(s, offsets_out, n, ws.p, ws.cap);
+    int32_t total = 0;
+    HIPCHECK(hipMemcpyAsync(&total, offsets_out + n, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (data_len_out) *data_len_out = total;
+    if (total > data_cap) throw Capacity("utf8 data needs " + std::to_string(total) + " bytes");
+    if (total > 0) { if (!data_out) throw std::runtime_error("data_out is NULL"); launch_unpack_utf8_bytes(s, (const ulonglong2*)packed, n, offsets_out, data_out); }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(s));
+  });
+}
+
+// ---------------------------------------------------------------- generators
+int gpuq_gen_lineitem(gpuq_ctx* ctx, void* stream, uint64_t seed, uint64_t seed_orders, int64_t row0, int64_t n, int64_t n_supp, const gpuq_lineitem_cols* c) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!c || n < 0 || n_supp < 1) throw std::runtime_error("bad arguments");
+    LineitemCols d{c->l_orderkey ? (i64*)c->l_orderkey : nullptr, (i64*)c->l_suppkey, (u64*)c->l_quantity, (u64*)c->l_extendedprice, (u64*)c->l_discount,
+                   (u64*)c->l_tax, c->l_shipdate, c->l_returnflag, c->l_returnflag_off, c->l_linestatus, c->l_linestatus_off};
+    launch_gen_lineitem((hipStream_t)stream, seed, seed_orders, row0, n, n_supp, d);
+    HIPCHECK(hipGetLastError());
+  });
+}
+int gpuq_gen_orders(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, int64_t n_cust, const gpuq_orders_cols* c) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!c || n < 0 || n_cust < 3) throw std::runtime_error("bad arguments");
+    OrdersCols d{(i64*)c->o_orderkey, (i64*)c->o_custkey, c->o_orderdate, c->o_shippriority};
+    launch_gen_orders((hipStream_t)stream, seed, row0, n, n_cust, d);
+    HIPCHECK(hipGetLastError());
+  });
+}
+int gpuq_gen_customer(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, const gpuq_customer_cols* c) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!c || n < 0 || row0 % 5 != 0) throw std::runtime_error("bad arguments (row0 must be a multiple of 5)");
+    CustomerCols d{(i64*)c->c_custkey, (i64*)c->c_nationkey, c->c_mktsegment, c->c_mktsegment_off};
+    launch_gen_customer((hipStream_t)stream, seed, row0, n, d);
+    HIPCHECK(hipGetLastError());
+  });
+}
+int gpuq_gen_supplier(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, const gpuq_supplier_cols* c) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!c || n < 0) throw std::runtime_error("bad arguments");
+    SupplierCols d{(i64*)c->s_suppkey, (i64*)c->s_nationkey};
+    launch_gen_supplier((hipStream_t)stream, seed, row0, n, d);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+// ---------------------------------------------------------------- timers
+int gpuq_timer_create(gpuq_ctx* ctx, gpuq_timer** out) {
+  return guarded(ctx, [&]() { check_ctx(ctx); auto* t = new gpuq_timer(); HIPCHECK(hipEventCreate(&t->a)); HIPCHECK(hipEventCreate(&t->b)); *out = t; });
+}
+int gpuq_timer_start(gpuq_timer* t, void* stream) { return guarded(nullptr, [&]() { HIPCHECK(hipEventRecord(t->a, (hipStream_t)stream)); }); }
+int gpuq_timer_stop(gpuq_timer* t, void* stream) { return guarded(nullptr, [&]() { HIPCHECK(hipEventRecord(t->b, (hipStream_t)stream)); }); }
+int gpuq_timer_elapsed_ms(gpuq_timer* t, float* ms_out) {
+  return guarded(nullptr, [&]() { HIPCHECK(hipEventSynchronize(t->b)); HIPCHECK(hipEventElapsedTime(ms_out, t->a, t->b)); });
+}
+void gpuq_timer_free(gpuq_timer* t) { if (t) { if (t->a) (void)hipEventDestroy(t->a); if (t->b) (void)hipEventDestroy(t->b); delete t; } }
+
+}  // extern "C"

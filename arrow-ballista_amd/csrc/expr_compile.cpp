@@ -1,0 +1,460 @@
+#include "expr_compile.h"
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <set>
+
+namespace gpuq {
+
+// ------------------------------------------------------------------ small helpers
+i128 pow10_i128(int k) { i128 r = 1; for (int i = 0; i < k; ++i) r *= 10; return r; }
+int bits_for_precision(int p) { int b = (int)std::ceil(p * 3.3219280948873626) + 1; return b > 127 ? 127 : b; }
+static int bits_of_value(i128 v) {
+  u128 m = v < 0 ? (u128)(-(v + 1)) + 1 : (u128)v;
+  int b = 0; while (m) { ++b; m >>= 1; }
+  return b + 1 > 127 ? 127 : b + 1;
+}
+i128 parse_i128(const std::string& s) {
+  size_t i = 0; bool neg = false;
+  while (i < s.size() && s[i] == ' ') ++i;
+  if (i < s.size() && (s[i] == '-' || s[i] == '+')) { neg = s[i] == '-'; ++i; }
+  i128 v = 0; bool any = false;
+  for (; i < s.size(); ++i) {
+    if (s[i] < '0' || s[i] > '9') throw std::runtime_error("bad integer literal '" + s + "'");
+    v = v * 10 + (s[i] - '0'); any = true;
+  }
+  if (!any) throw std::runtime_error("bad integer literal '" + s + "'");
+  return neg ? -v : v;
+}
+std::string i128_to_string(i128 v) {
+  if (v == 0) return "0";
+  bool neg = v < 0; u128 m = neg ? (u128)(-(v + 1)) + 1 : (u128)v;
+  std::string r; while (m) { r += (char)('0' + (int)(m % 10)); m /= 10; }
+  if (neg) r += '-';
+  std::reverse(r.begin(), r.end()); return r;
+}
+bool pack_str15(const std::string& s, u64& lo, u64& hi) {
+  if (s.size() > 15) return false;
+  hi = 0; lo = 0;
+  for (size_t k = 0; k < s.size(); ++k) {
+    u64 b = (unsigned char)s[k];
+    if (k < 8) hi |= b << (56 - 8 * k); else lo |= b << (56 - 8 * (k - 8));
+  }
+  lo |= (u64)s.size();
+  return true;
+}
+
+std::string DType::to_string() const {
+  switch (id) {
+    case T_NULL: return "Null"; case T_BOOL: return "Boolean"; case T_INT32: return "Int32"; case T_INT64: return "Int64";
+    case T_DATE32: return "Date32"; case T_FLOAT64: return "Float64"; case T_UTF8: return "Utf8";
+    case T_UINT32: return "UInt32"; case T_UINT64: return "UInt64";
+    case T_DECIMAL128: return "Decimal128(" + std::to_string(p) + "," + std::to_string(s) + ")";
+  }
+  return "?";
+}
+DType dtype_from_json(const Json& j) {
+  DType t;
+  if (j.is_str()) {
+    const std::string& s = j.s;
+    if (s == "Int32") t.id = T_INT32; else if (s == "Int64") t.id = T_INT64; else if (s == "Date32") t.id = T_DATE32;
+    else if (s == "Float64") t.id = T_FLOAT64; else if (s == "Utf8") t.id = T_UTF8; else if (s == "Boolean") t.id = T_BOOL;
+    else if (s == "UInt32") t.id = T_UINT32; else if (s == "UInt64") t.id = T_UINT64; else if (s == "Null") t.id = T_NULL;
+    else throw std::runtime_error("unsupported type '" + s + "'");
+    return t;
+  }
+  if (j.is_obj() && j.has("Decimal128")) {
+    const Json& a = j.at("Decimal128");
+    t.id = T_DECIMAL128; t.p = (int)a.a.at(0).i64(); t.s = (int)a.a.at(1).i64();
+    if (t.p < 1 || t.p > 38 || t.s < 0 || t.s > t.p) throw std::runtime_error("bad Decimal128 precision/scale");
+    return t;
+  }
+  throw std::runtime_error("unsupported type descriptor " + j.dump());
+}
+int col_class_for(const DType& t) {
+  switch (t.id) {
+    case T_INT32: case T_DATE32: return CC_I32;
+    case T_UINT32: return CC_U32;
+    case T_INT64: case T_UINT64: case T_FLOAT64: return CC_I64;
+    case T_DECIMAL128: return CC_I128;
+    case T_UTF8: return CC_STR;
+    case T_BOOL: return CC_BIT;
+    default: throw std::runtime_error("type " + t.to_string() + " has no device column class");
+  }
+}
+int type_width(const DType& t) {
+  switch (col_class_for(t)) { case CC_I32: case CC_U32: return 4; case CC_I64: return 8; case CC_I128: case CC_STR: return 16; default: return 0; }
+}
+int Schema::index_of(const std::string& name) const {
+  for (size_t i = 0; i < fields.size(); ++i) if (fields[i].name == name) return (int)i;
+  return -1;
+}
+Schema schema_from_json(const Json& j) {
+  Schema s;
+  const Json& fs = j.is_obj() ? j.at("fields") : j;
+  for (const Json& f : fs.a) {
+    Field fd; fd.name = f.at("name").str(); fd.type = dtype_from_json(f.at("type"));
+    fd.nullable = f.get_bool("nullable", true); fd.side = (int)f.get_i64("side", 0); fd.raw128 = (int)f.get_i64("raw128", 0);
+    s.fields.push_back(fd);
+  }
+  return s;
+}
+
+static int type_bits(const DType& t) {
+  switch (t.id) {
+    case T_BOOL: return 2; case T_INT32: case T_DATE32: return 32; case T_UINT32: return 33; case T_INT64: return 64;
+    case T_UINT64: return 65; case T_DECIMAL128: return bits_for_precision(t.p); default: return 127;
+  }
+}
+
+// ------------------------------------------------------------------ AST
+NodeP ExprCompiler::intern(NodeP n) {
+  auto it = interned_.find(n->key);
+  if (it != interned_.end()) return it->second;
+  interned_[n->key] = n; return n;
+}
+NodeP ExprCompiler::column(int fi) {
+  if (fi < 0 || fi >= (int)schema_.fields.size()) throw std::runtime_error("column index " + std::to_string(fi) + " out of range");
+  auto n = std::make_shared<Node>();
+  n->kind = Node::COL; n->col = fi; n->type = schema_.fields[fi].type; n->nullable = schema_.fields[fi].nullable || schema_.fields[fi].side > 0;
+  n->bits = type_bits(n->type); n->key = "c" + std::to_string(fi);
+  return intern(n);
+}
+NodeP ExprCompiler::lit_int(DType t, i128 v) {
+  auto n = std::make_shared<Node>();
+  n->kind = Node::LIT; n->type = t; n->nullable = false; n->lit_lo = (u64)v; n->lit_hi = (u64)((u128)v >> 64);
+  n->bits = bits_of_value(v); n->key = "l:" + t.to_string() + ":" + i128_to_string(v);
+  return intern(n);
+}
+NodeP ExprCompiler::lit_f64(double v) {
+  auto n = std::make_shared<Node>();
+  n->kind = Node::LIT; n->type.id = T_FLOAT64; n->nullable = false;
+  u64 b; std::memcpy(&b, &v, 8); n->lit_lo = b; n->key = "lf:" + std::to_string(b);
+  return intern(n);
+}
+NodeP ExprCompiler::lit_null(DType t) {
+  auto n = std::make_shared<Node>();
+  n->kind = Node::LIT; n->type = t; n->nullable = true; n->lit_null = true; n->bits = 1; n->key = "ln:" + t.to_string();
+  return intern(n);
+}
+NodeP ExprCompiler::lit_str(const std::string& s) {
+  auto n = std::make_shared<Node>();
+  n->kind = Node::LIT; n->type.id = T_UTF8; n->nullable = false;
+  if (!pack_str15(s, n->lit_lo, n->lit_hi)) throw std::runtime_error("Utf8 literal longer than 15 bytes is not supported on device: '" + s + "'");
+  n->key = "ls:" + s;
+  return intern(n);
+}
+NodeP ExprCompiler::raw(int op, DType t, bool nullable, int bits, std::vector<NodeP> ch, uint32_t imm) {
+  auto n = std::make_shared<Node>();
+  n->kind = Node::OPN; n->op = op; n->type = t; n->nullable = nullable; n->bits = bits > 127 ? 127 : bits; n->ch = std::move(ch); n->imm = imm;
+  std::string k = "o" + std::to_string(op) + ":" + t.to_string() + ":" + std::to_string(imm) + "(";
+  for (auto& c : n->ch) k += c->key + ",";
+  n->key = k + ")";
+  return intern(n);
+}
+
+static DType dec_type(int p, int s) { DType t; t.id = T_DECIMAL128; t.p = p > 38 ? 38 : p; t.s = s > 38 ? 38 : s; return t; }
+static DType as_decimal(const DType& t) {
+  if (t.id == T_DECIMAL128) return t;
+  if (t.id == T_INT32 || t.id == T_UINT32) return dec_type(10, 0);
+  if (t.id == T_INT64 || t.id == T_UINT64) return dec_type(20, 0);
+  throw std::runtime_error("cannot treat " + t.to_string() + " as decimal");
+}
+static DType mk(int id) { DType t; t.id = id; return t; }
+
+NodeP ExprCompiler::rescale(NodeP e, int new_scale) {
+  DType d = as_decimal(e->type);
+  if (d.s == new_scale) {
+    if (e->type.id == T_DECIMAL128) return e;
+    return raw(OP_MOV, d, e->nullable, e->bits, {e});
+  }
+  if (new_scale > d.s) {
+    const int k = new_scale - d.s;
+    if (e->kind == Node::LIT && !e->lit_null && e->bits + bits_for_precision(k + 1) < 127) {
+      // constant-fold the rescale of a literal
+      const i128 v = (i128)(((u128)e->lit_hi << 64) | e->lit_lo);
+      return lit_int(dec_type(d.p + k, new_scale), v * pow10_i128(k));
+    }
+    NodeP f = lit_int(dec_type(k + 1, 0), pow10_i128(k));
+    const int op = (e->bits <= 63 && f->bits <= 63) ? OP_MULW : OP_MUL;
+    return raw(op, dec_type(d.p + k, new_scale), e->nullable, e->bits + f->bits, {e, f});
+  }
+  // reducing scale: divide, round half away from zero (arrow cast_decimal_to_decimal) [UPSTREAM-KNOWLEDGE]
+  const int k = d.s - new_scale;
+  DType rt = dec_type(std::max(1, d.p - k), new_scale);
+  NodeP div = lit_int(dec_type(38, 0), pow10_i128(k));
+  NodeP half = lit_int(dec_type(38, 0), pow10_i128(k) / 2);
+  NodeP nhalf = lit_int(dec_type(38, 0), -(pow10_i128(k) / 2));
+  NodeP zero = lit_int(dec_type(38, 0), 0), one = lit_int(dec_type(38, 0), 1), mone = lit_int(dec_type(38, 0), -1);
+  NodeP q = raw(OP_DIV, rt, e->nullable, e->bits, {e, div});
+  NodeP r = raw(OP_MOD, rt, e->nullable, div->bits, {e, div});
+  NodeP nonneg = raw(OP_GE, mk(T_BOOL), e->nullable, 2, {e, zero});
+  NodeP up = raw(OP_SELECT, rt, e->nullable, 2, {raw(OP_GE, mk(T_BOOL), e->nullable, 2, {r, half}), one, zero});
+  NodeP down = raw(OP_SELECT, rt, e->nullable, 2, {raw(OP_LE, mk(T_BOOL), e->nullable, 2, {r, nhalf}), mone, zero});
+  NodeP adj = raw(OP_SELECT, rt, e->nullable, 2, {nonneg, up, down});
+  return raw(OP_ADD, rt, e->nullable, e->bits, {q, adj});
+}
+
+NodeP ExprCompiler::cast(NodeP e, DType to) {
+  const DType from = e->type;
+  if (from == to) return e;
+  if (from.id == T_NULL) return lit_null(to);
+  if (to.id == T_FLOAT64) {
+    if (from.is_int() || from.id == T_DATE32 || from.id == T_BOOL) return raw(OP_I2F, to, e->nullable, 127, {e});
+    if (from.is_decimal()) {
+      NodeP f = raw(OP_I2F, to, e->nullable, 127, {e});
+      if (from.s == 0) return f;
+      return raw(OP_FDIV, to, e->nullable, 127, {f, lit_f64(std::pow(10.0, from.s))});
+    }
+  }
+  if (to.is_decimal()) {
+    if (from.is_int() || from.is_decimal()) {
+      NodeP r = rescale(e, to.s);
+      if (r->type == to) return r;
+      return raw(OP_MOV, to, e->nullable, std::min(r->bits, bits_for_precision(to.p)), {r});
+    }
+  }
+  if (to.is_int() || to.id == T_DATE32) {
+    if (from.is_int() || from.id == T_DATE32 || from.id == T_BOOL) return raw(OP_MOV, to, e->nullable, std::min(e->bits, type_bits(to)), {e});
+    if (from.is_decimal()) { NodeP r = rescale(e, 0); return raw(OP_MOV, to, e->nullable, std::min(r->bits, type_bits(to)), {r}); }
+    if (from.is_float()) return raw(OP_F2I, to, e->nullable, type_bits(to), {e});
+  }
+  if (to.id == T_BOOL && from.is_int()) return raw(OP_NE, to, e->nullable, 2, {e, lit_int(from, 0)});
+  throw std::runtime_error("unsupported cast " + from.to_string() + " -> " + to.to_string());
+}
+
+static std::string norm_op(const std::string& op) {
+  static const std::map<std::string, std::string> m = {
+      {"Plus", "+"}, {"Minus", "-"}, {"Multiply", "*"}, {"Divide", "/"}, {"Modulo", "%"}, {"Eq", "="}, {"NotEq", "!="},
+      {"Lt", "<"}, {"LtEq", "<="}, {"Gt", ">"}, {"GtEq", ">="}, {"And", "AND"}, {"Or", "OR"}, {"and", "AND"}, {"or", "OR"}, {"<>", "!="}, {"==", "="}};
+  auto it = m.find(op); return it == m.end() ? op : it->second;
+}
+
+NodeP ExprCompiler::binary(const std::string& op_in, NodeP l, NodeP r) {
+  const std::string op = norm_op(op_in);
+  const bool nullable = l->nullable || r->nullable;
+  if (op == "AND" || op == "OR") {
+    if (l->type.id != T_BOOL || r->type.id != T_BOOL) throw std::runtime_error(op + " needs boolean operands");
+    return raw(op == "AND" ? OP_AND : OP_OR, mk(T_BOOL), nullable, 2, {l, r});
+  }
+  const bool is_cmp = (op == "=" || op == "!=" || op == "<" || op == "<=" || op == ">" || op == ">=");
+  const bool is_arith = (op == "+" || op == "-" || op == "*" || op == "/" || op == "%");
+  if (!is_cmp && !is_arith) throw std::runtime_error("unsupported binary operator '" + op_in + "'");
+  // NULL literal operand adopts the other side's type
+  if (l->type.id == T_NULL && r->type.id != T_NULL) l = lit_null(r->type);
+  if (r->type.id == T_NULL && l->type.id != T_NULL) r = lit_null(l->type);
+  if (is_cmp) {
+    static const std::map<std::string, std::pair<int, int>> ops = {
+        {"=", {OP_EQ, OP_FEQ}}, {"!=", {OP_NE, OP_FNE}}, {"<", {OP_LT, OP_FLT}}, {"<=", {OP_LE, OP_FLE}}, {">", {OP_GT, OP_FGT}}, {">=", {OP_GE, OP_FGE}}};
+    const auto pr = ops.at(op);
+    if (l->type.is_float() || r->type.is_float()) {
+      return raw(pr.second, mk(T_BOOL), nullable, 2, {cast(l, mk(T_FLOAT64)), cast(r, mk(T_FLOAT64))});
+    }
+    if (l->type.is_decimal() || r->type.is_decimal()) {
+      const int s = std::max(as_decimal(l->type).s, as_decimal(r->type).s);
+      return raw(pr.first, mk(T_BOOL), nullable, 2, {rescale(l, s), rescale(r, s)});
+    }
+    const bool lu = l->type.id == T_UTF8, ru = r->type.id == T_UTF8;
+    if (lu != ru) throw std::runtime_error("cannot compare " + l->type.to_string() + " with " + r->type.to_string());
+    const bool ld = l->type.id == T_DATE32, rd = r->type.id == T_DATE32;
+    if ((ld && !(rd || r->type.is_int())) || (rd && !(ld || l->type.is_int())))
+      throw std::runtime_error("cannot compare " + l->type.to_string() + " with " + r->type.to_string());
+    return raw(pr.first, mk(T_BOOL), nullable, 2, {l, r});
+  }
+  // arithmetic
+  if (l->type.is_float() || r->type.is_float()) {
+    static const std::map<std::string, int> fo = {{"+", OP_FADD}, {"-", OP_FSUB}, {"*", OP_FMUL}, {"/", OP_FDIV}};
+    auto it = fo.find(op); if (it == fo.end()) throw std::runtime_error("unsupported float operator " + op);
+    return raw(it->second, mk(T_FLOAT64), nullable, 127, {cast(l, mk(T_FLOAT64)), cast(r, mk(T_FLOAT64))});
+  }
+  if (l->type.is_decimal() || r->type.is_decimal()) {
+    if (!(l->type.is_decimal() || l->type.is_int()) || !(r->type.is_decimal() || r->type.is_int()))
+      throw std::runtime_error("unsupported decimal arithmetic operands " + l->type.to_string() + ", " + r->type.to_string());
+    const DType dl = as_decimal(l->type), dr = as_decimal(r->type);
+    if (op == "+" || op == "-") {
+      const int s = std::max(dl.s, dr.s);
+      const int p = std::min(38, std::max(dl.p - dl.s, dr.p - dr.s) + s + 1);
+      NodeP a = rescale(l, s), b = rescale(r, s);
+      return raw(op == "+" ? OP_ADD : OP_SUB, dec_type(p, s), nullable, std::max(a->bits, b->bits) + 1, {a, b});
+    }
+    if (op == "*") {
+      const DType rt = dec_type(std::min(38, dl.p + dl.s * 0 + dr.p + 1), std::min(38, dl.s + dr.s));
+      NodeP a = rescale(l, dl.s), b = rescale(r, dr.s);
+      const int o = (a->bits <= 63 && b->bits <= 63) ? OP_MULW : OP_MUL;
+      return raw(o, rt, nullable, a->bits + b->bits, {a, b});
+    }
+    throw std::runtime_error("decimal operator '" + op + "' is not supported on device yet");
+  }
+  if ((l->type.is_int() || l->type.id == T_DATE32) && (r->type.is_int() || r->type.id == T_DATE32)) {
+    DType rt = mk((l->type.id == T_INT64 || r->type.id == T_INT64 || l->type.id == T_UINT64 || r->type.id == T_UINT64) ? T_INT64 : T_INT32);
+    if (l->type.id == T_DATE32 && r->type.id == T_DATE32 && op == "-") rt = mk(T_INT32);
+    else if (l->type.id == T_DATE32 || r->type.id == T_DATE32) rt = mk(T_DATE32);
+    if (op == "+") return raw(OP_ADD, rt, nullable, std::max(l->bits, r->bits) + 1, {l, r});
+    if (op == "-") return raw(OP_SUB, rt, nullable, std::max(l->bits, r->bits) + 1, {l, r});
+    if (op == "*") return raw((l->bits <= 63 && r->bits <= 63) ? OP_MULW : OP_MUL, rt, nullable, l->bits + r->bits, {l, r});
+    if (op == "/") return raw(OP_DIV, rt, true, l->bits, {l, r});   // x/0 -> NULL (arrow raises DivideByZero)
+    if (op == "%") return raw(OP_MOD, rt, true, r->bits, {l, r});
+  }
+  throw std::runtime_error("unsupported operands for '" + op + "': " + l->type.to_string() + ", " + r->type.to_string());
+}
+
+NodeP ExprCompiler::not_(NodeP e) {
+  if (e->type.id != T_BOOL) throw std::runtime_error("NOT needs a boolean operand");
+  return raw(OP_NOT, mk(T_BOOL), e->nullable, 2, {e});
+}
+NodeP ExprCompiler::is_null(NodeP e, bool negate) { return raw(negate ? OP_ISNOTNULL : OP_ISNULL, mk(T_BOOL), false, 2, {e}); }
+NodeP ExprCompiler::negative(NodeP e) {
+  if (e->type.is_float()) return raw(OP_FNEG, e->type, e->nullable, 127, {e});
+  return raw(OP_NEG, e->type, e->nullable, e->bits + 1, {e});
+}
+NodeP ExprCompiler::select(NodeP c, NodeP t, NodeP f) {
+  if (t->type.id == T_NULL) t = lit_null(f->type);
+  if (f->type.id == T_NULL) f = lit_null(t->type);
+  if (t->type != f->type) {
+    if (t->type.is_float() || f->type.is_float()) { t = cast(t, mk(T_FLOAT64)); f = cast(f, mk(T_FLOAT64)); }
+    else if (t->type.is_decimal() || f->type.is_decimal()) {
+      const DType a = as_decimal(t->type), b = as_decimal(f->type);
+      const int s = std::max(a.s, b.s); const DType rt = dec_type(std::min(38, std::max(a.p - a.s, b.p - b.s) + s), s);
+      t = cast(t, rt); f = cast(f, rt);
+    } else if (t->type.is_int() && f->type.is_int()) { t = cast(t, mk(T_INT64)); f = cast(f, mk(T_INT64)); }
+    else throw std::runtime_error("CASE branches have incompatible types " + t->type.to_string() + ", " + f->type.to_string());
+  }
+  return raw(OP_SELECT, t->type, t->nullable || f->nullable, std::max(t->bits, f->bits), {c, t, f});
+}
+NodeP ExprCompiler::coalesce0(NodeP e) { return raw(OP_COALESCE0, e->type, false, e->bits, {e}); }
+NodeP ExprCompiler::nullif0(NodeP e, NodeP guard) { return raw(OP_NULLIF0, e->type, true, e->bits, {e, guard}); }
+
+NodeP ExprCompiler::from_json(const Json& e) {
+  if (!e.is_obj() || e.o.size() != 1) throw std::runtime_error("expression must be an object with one key: " + e.dump());
+  const std::string& kind = e.o[0].first;
+  const Json& v = e.o[0].second;
+  if (kind == "column") {
+    int idx = (int)v.get_i64("index", -1);
+    if (v.has("name")) {
+      const int byname = schema_.index_of(v.at("name").str());
+      if (idx < 0) idx = byname;
+      else if (byname >= 0 && idx < (int)schema_.fields.size() && schema_.fields[idx].name != v.at("name").str()) idx = byname;
+    }
+    if (idx < 0) throw std::runtime_error("unknown column " + v.dump());
+    return column(idx);
+  }
+  if (kind == "literal") {
+    const DType t = dtype_from_json(v.at("type"));
+    const Json* val = v.find("value");
+    if (!val || val->is_null()) return lit_null(t);
+    switch (t.id) {
+      case T_UTF8: return lit_str(val->str());
+      case T_FLOAT64: return lit_f64(val->f64());
+      case T_BOOL: return lit_int(t, val->boolean() ? 1 : 0);
+      default: return lit_int(t, parse_i128(val->is_str() ? val->s : val->s));
+    }
+  }
+  if (kind == "binary_expr") return binary(v.at("op").str(), from_json(v.at("l")), from_json(v.at("r")));
+  if (kind == "cast" || kind == "try_cast") return cast(from_json(v.at("expr")), dtype_from_json(v.at("arrow_type")));
+  if (kind == "not_expr") return not_(from_json(v.at("expr")));
+  if (kind == "is_null_expr") return is_null(from_json(v.at("expr")), false);
+  if (kind == "is_not_null_expr") return is_null(from_json(v.at("expr")), true);
+  if (kind == "negative") return negative(from_json(v.at("expr")));
+  if (kind == "in_list") {
+    NodeP x = from_json(v.at("expr"));
+    NodeP acc;
+    for (const Json& it : v.at("list").a) {
+      NodeP eq = binary("=", x, from_json(it));
+      acc = acc ? binary("OR", acc, eq) : eq;
+    }
+    if (!acc) acc = lit_int(mk(T_BOOL), 0);
+    return v.get_bool("negated", false) ? not_(acc) : acc;
+  }
+  if (kind == "case_") {
+    NodeP base = v.has("expr") ? from_json(v.at("expr")) : nullptr;
+    NodeP acc = v.has("else_expr") ? from_json(v.at("else_expr")) : lit_null(mk(T_NULL));
+    const auto& wt = v.at("when_then_expr").a;
+    for (size_t i = wt.size(); i-- > 0;) {
+      NodeP w = from_json(wt[i].at("when_expr"));
+      if (base) w = binary("=", base, w);
+      acc = select(w, from_json(wt[i].at("then_expr")), acc);
+    }
+    return acc;
+  }
+  throw std::runtime_error("unsupported expression node '" + kind + "'");
+}
+
+// ------------------------------------------------------------------ program assembly
+void ExprCompiler::add_predicate(NodeP e) {
+  if (e->type.id != T_BOOL) throw std::runtime_error("predicate must be boolean, got " + e->type.to_string());
+  pred_ = pred_ ? binary("AND", pred_, e) : e;
+}
+int ExprCompiler::add_output(NodeP e) { outs_.push_back(e); return (int)outs_.size() - 1; }
+
+CompiledProgram ExprCompiler::finish() {
+  CompiledProgram C;
+  // use counts over the DAG
+  std::map<Node*, int> uses;
+  std::set<Node*> seen;
+  std::function<void(const NodeP&)> visit = [&](const NodeP& n) {
+    uses[n.get()]++;
+    if (seen.count(n.get())) return;
+    seen.insert(n.get());
+    for (auto& c : n->ch) visit(c);
+  };
+  if (pred_) { visit(pred_); uses[pred_.get()] += 1000000; }
+  for (auto& o : outs_) { visit(o); uses[o.get()] += 1000000; }
+
+  // columns: slot = register, in first-visit order
+  std::map<Node*, int> reg;
+  std::vector<Node*> order;
+  std::set<Node*> ordered;
+  std::function<void(const NodeP&)> topo = [&](const NodeP& n) {
+    if (ordered.count(n.get())) return;
+    ordered.insert(n.get());
+    for (auto& c : n->ch) topo(c);
+    order.push_back(n.get());
+  };
+  if (pred_) topo(pred_);
+  for (auto& o : outs_) topo(o);
+  for (Node* n : order) if (n->kind == Node::COL) {
+    if ((int)C.col_field.size() >= MAX_COLS) throw std::runtime_error("expression references more than " + std::to_string(MAX_COLS) + " columns");
+    reg[n] = (int)C.col_field.size();
+    C.col_field.push_back(n->col);
+  }
+  std::vector<bool> busy(NREG, false);
+  for (size_t i = 0; i < C.col_field.size(); ++i) busy[i] = true;
+  auto alloc = [&]() { for (int r = 0; r < NREG; ++r) if (!busy[r]) { busy[r] = true; return r; } throw std::runtime_error("expression needs more than " + std::to_string(NREG) + " live registers"); return -1; };
+  std::vector<std::pair<u64, u64>> imms;
+  auto imm_index = [&](u64 lo, u64 hi) {
+    for (size_t i = 0; i < imms.size(); ++i) if (imms[i].first == lo && imms[i].second == hi) return (int)i;
+    if ((int)imms.size() >= MAX_IMMS) throw std::runtime_error("expression needs more than " + std::to_string(MAX_IMMS) + " immediates");
+    imms.push_back({lo, hi}); return (int)imms.size() - 1;
+  };
+  auto emit = [&](int op, int d, int a, int b, uint32_t imm) {
+    if (C.n_insns >= MAX_INSNS) throw std::runtime_error("expression program longer than " + std::to_string(MAX_INSNS) + " instructions");
+    DevInsn& in = C.code.insns[C.n_insns++];
+    in.op = (uint8_t)op; in.dst = (uint8_t)d; in.a = (uint8_t)a; in.b = (uint8_t)b; in.imm = imm;
+  };
+  std::map<Node*, int> remaining = uses;
+  auto release = [&](Node* c) { if (--remaining[c] == 0) busy[reg[c]] = false; };
+  for (Node* n : order) {
+    if (n->kind == Node::COL) continue;
+    if (n->kind == Node::LIT) {
+      const int d = alloc(); reg[n] = d;
+      if (n->lit_null) { emit(OP_IMM, d, 0, 0, (uint32_t)imm_index(0, 0)); emit(OP_NULLIF0, d, d, d, 0); }
+      else emit(OP_IMM, d, 0, 0, (uint32_t)imm_index(n->lit_lo, n->lit_hi));
+      continue;
+    }
+    const int a = n->ch.size() > 0 ? reg.at(n->ch[0].get()) : 0;
+    const int b = n->ch.size() > 1 ? reg.at(n->ch[1].get()) : a;
+    uint32_t imm = n->imm;
+    if (n->op == OP_SELECT) imm = (uint32_t)reg.at(n->ch[2].get());
+    for (auto& c : n->ch) release(c.get());     // operands are read before dst is written
+    const int d = alloc(); reg[n] = d;
+    emit(n->op, d, a, b, imm);
+  }
+  for (size_t i = 0; i < imms.size(); ++i) { C.code.imm_lo[i] = imms[i].first; C.code.imm_hi[i] = imms[i].second; }
+  C.pred_reg = pred_ ? reg.at(pred_.get()) : -1;
+  for (auto& o : outs_) {
+    C.out_reg.push_back(reg.at(o.get())); C.out_type.push_back(o->type); C.out_nullable.push_back(o->nullable); C.out_key.push_back(o->key);
+  }
+  return C;
+}
+
+}  // namespace gpuq

@@ -1,0 +1,292 @@
+// gpuq device-side core: column views, the expression bytecode and its
+// wave-uniform interpreter.  gfx950 (MI355X) only.
+//
+// What this replaces in the reference: DataFusion's PhysicalExpr::evaluate
+// (column-at-a-time arrow kernels, one materialised array per expression node;
+// parameter surface pinned by ballista/core/proto/datafusion.proto:1142-1180).
+// Here an expression tree is compiled on the host (expr_compile.cpp) to a short
+// register program that every lane runs on its own row; control flow is uniform
+// across the wave, operands live in a VGPR register file indexed through
+// s_set_gpr_idx (never scratch), intermediates never touch HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpuq {
+
+typedef unsigned long long u64;
+typedef long long i64;
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+constexpr int MAX_COLS = 12;   // input columns referenced by one program
+constexpr int NREG = 16;       // 128-bit virtual registers per lane
+constexpr int MAX_INSNS = 48;
+constexpr int MAX_IMMS = 12;
+constexpr int MAX_VIA = 3;     // index vectors (selection / join pair sides)
+constexpr uint32_t NULL_ROW = 0xFFFFFFFFu;  // index-vector entry meaning "no row" (outer join)
+
+// How a column's bytes become a 128-bit register value.
+enum ColClass : int32_t {
+  CC_I32 = 0,   // 4-byte signed (Int32, Date32) sign-extended
+  CC_I64 = 1,   // 8-byte (Int64; Float64 bit pattern)
+  CC_I128 = 2,  // 16-byte little-endian two's complement (Decimal128)
+  CC_STR = 3,   // Utf8: first <=15 bytes big-endian in bits 127..8, length in bits 7..0
+  CC_BIT = 4,   // Boolean (Arrow bit-packed) -> 0/1
+  CC_U32 = 5,   // 4-byte unsigned (row ids)
+};
+
+struct DevCol {
+  const void* data;
+  const int32_t* offsets;   // CC_STR only
+  const uint8_t* validity;  // Arrow validity bitmap or nullptr (all valid)
+  int32_t cls;
+  int32_t via;              // 0 = driving position, k>0 = row comes from via[k-1][pos]
+};
+
+enum Op : uint8_t {
+  OP_NOP = 0,
+  OP_IMM,    // dst <- imm[imm]
+  OP_MOV,    // dst <- a
+  OP_ADD, OP_SUB, OP_MUL, OP_MULW /* i64*i64 -> i128 */, OP_NEG, OP_DIV /* trunc */, OP_MOD,
+  OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE,            // signed 128-bit compares -> 0/1
+  OP_FADD, OP_FSUB, OP_FMUL, OP_FDIV, OP_FNEG,          // f64 in lo
+  OP_FEQ, OP_FNE, OP_FLT, OP_FLE, OP_FGT, OP_FGE,       // f64 total-order compares
+  OP_I2F, OP_F2I,
+  OP_AND, OP_OR, OP_NOT,                                // Kleene logic on 0/1 + null
+  OP_ISNULL, OP_ISNOTNULL,
+  OP_SELECT,  // dst <- (a is true) ? b : reg[imm]
+  OP_SHL,     // dst <- a << imm   (imm 0..127)
+  OP_BOR,     // dst <- a | b      (bitwise; key packing)
+  OP_NULLIF0, // dst <- a, NULL when b == 0 (guards OP_DIV by zero -> NULL)
+  OP_COALESCE0, // dst <- a, or 0 (non-null) when a is NULL
+};
+
+struct DevInsn { uint8_t op, dst, a, b; uint32_t imm; };
+
+// The instruction stream and immediates are uploaded once per compiled operator and read through a
+// uniform pointer (scalar loads).  They must NOT sit in the by-value kernel argument: hipcc copies a
+// dynamically indexed kernarg array into scratch.
+struct DevCode {
+  DevInsn insns[MAX_INSNS];
+  u64 imm_lo[MAX_IMMS];
+  u64 imm_hi[MAX_IMMS];
+};
+
+struct DevProgram {
+  int32_t n_cols;
+  int32_t n_insns;
+  int32_t pred_reg;   // register holding the row predicate, -1 = keep every row
+  int32_t n_via;
+  DevCol cols[MAX_COLS];
+  const uint32_t* via[MAX_VIA];
+  const DevCode* code;   // device memory
+  uint32_t* flags;       // device status word (FLAG_* bits)
+};
+
+constexpr uint32_t FLAG_STR_TRUNC = 1u;
+constexpr uint32_t FLAG_GROUP_OVERFLOW = 2u;
+constexpr uint32_t FLAG_TABLE_FULL = 4u;
+constexpr uint32_t FLAG_DUP_BUILD_KEY = 8u;
+constexpr uint32_t FLAG_OUT_OVERFLOW = 16u;
+constexpr uint32_t FLAG_WIDE_MINMAX = 32u;  // MIN/MAX over a value outside the int64 range
+
+// Per-lane register file.  lo/hi MUST be separate plain u64 arrays local to the kernel: hipcc then
+// keeps them in VGPRs and lowers wave-uniform dynamic indexing to s_set_gpr_idx_on.  Wrapped in a
+// struct, or as an __int128 array, they are demoted to scratch (build() asserts ScratchSize == 0).
+#define GPUQ_REGS_DECL ::gpuq::u64 rlo[::gpuq::NREG]; ::gpuq::u64 rhi[::gpuq::NREG]; uint32_t rnulls = 0
+#define GPUQ_REGS_PARAM ::gpuq::u64 (&rlo)[::gpuq::NREG], ::gpuq::u64 (&rhi)[::gpuq::NREG], uint32_t& rnulls
+#define GPUQ_REGS_CPARAM const ::gpuq::u64 (&rlo)[::gpuq::NREG], const ::gpuq::u64 (&rhi)[::gpuq::NREG], const uint32_t& rnulls
+#define GPUQ_REGS rlo, rhi, rnulls
+
+__device__ __forceinline__ i128 mk128(u64 lo, u64 hi) { return (i128)(((u128)hi << 64) | (u128)lo); }
+
+__device__ __forceinline__ i64 f64_total_key(u64 bits) {
+  // IEEE-754 totalOrder as a signed integer compare [UPSTREAM-KNOWLEDGE: arrow-ord 49 cmp kernels]
+  i64 s = (i64)bits;
+  return s ^ (i64)((u64)(s >> 63) >> 1);
+}
+
+// Truncating signed 128-bit division (hardware has none; the AMDGPU backend has no __divti3).
+// Only used on tiny outputs (AVG finalisation) and explicit '/' expressions.
+__device__ inline void divmod128(i128 n, i128 d, i128& q, i128& r) {
+  bool nn = n < 0, dn = d < 0;
+  u128 un = nn ? (u128)(-n) : (u128)n;
+  u128 ud = dn ? (u128)(-d) : (u128)d;
+  u128 uq = 0, ur = 0;
+  if (ud != 0) {
+    if ((ud >> 64) == 0 && (un >> 64) == 0) {
+      uq = (u64)un / (u64)ud; ur = (u64)un % (u64)ud;
+    } else {
+      for (int i = 127; i >= 0; --i) {
+        ur = (ur << 1) | ((un >> i) & 1);
+        if (ur >= ud) { ur -= ud; uq |= ((u128)1 << i); }
+      }
+    }
+  }
+  q = (nn != dn) ? -(i128)uq : (i128)uq;
+  r = nn ? -(i128)ur : (i128)ur;
+}
+
+// ---------------------------------------------------------------- column load
+__device__ __forceinline__ void load_one(const DevCol& c, uint32_t row, bool row_ok,
+                                         u64& lo, u64& hi, bool& isnull, uint32_t* flags) {
+  lo = 0; hi = 0; isnull = !row_ok;
+  if (!row_ok) return;
+  if (c.validity) {
+    uint8_t vb = c.validity[row >> 3];
+    if (!((vb >> (row & 7)) & 1)) { isnull = true; return; }
+  }
+  switch (c.cls) {
+    case CC_I32: { i64 v = ((const int32_t*)c.data)[row]; lo = (u64)v; hi = (u64)(v >> 63); break; }
+    case CC_U32: { lo = ((const uint32_t*)c.data)[row]; break; }
+    case CC_I64: { i64 v = ((const i64*)c.data)[row]; lo = (u64)v; hi = (u64)(v >> 63); break; }
+    case CC_I128: {
+      const ulonglong2 v = ((const ulonglong2*)c.data)[row];
+      lo = v.x; hi = v.y; break;
+    }
+    case CC_BIT: { uint8_t b = ((const uint8_t*)c.data)[row >> 3]; lo = (b >> (row & 7)) & 1; break; }
+    case CC_STR: {
+      int32_t o0 = c.offsets[row], o1 = c.offsets[row + 1];
+      int32_t len = o1 - o0;
+      if (len > 15) { if (flags) atomicOr(flags, FLAG_STR_TRUNC); }
+      int32_t n = len < 15 ? len : 15;
+      const uint8_t* p = (const uint8_t*)c.data + o0;
+      u64 h = 0, l = 0;
+      for (int k = 0; k < n; ++k) {
+        u64 b = p[k];
+        if (k < 8) h |= b << (56 - 8 * k);
+        else l |= b << (56 - 8 * (k - 8));
+      }
+      hi = h; lo = l | (u64)(len < 255 ? len : 255);
+      break;
+    }
+    default: break;
+  }
+}
+
+__device__ __forceinline__ void load_columns(const DevProgram& P, i64 pos, GPUQ_REGS_PARAM) {
+  uint32_t rows[MAX_VIA + 1];
+  rows[0] = (uint32_t)pos;
+#pragma unroll
+  for (int k = 0; k < MAX_VIA; ++k) rows[k + 1] = (k < P.n_via) ? P.via[k][pos] : 0u;
+  rnulls = 0;
+#pragma unroll
+  for (int c = 0; c < MAX_COLS; ++c) {
+    if (c < P.n_cols) {
+      const DevCol col = P.cols[c];
+      uint32_t row = rows[0];
+#pragma unroll
+      for (int k = 1; k <= MAX_VIA; ++k) if (col.via == k) row = rows[k];
+      bool ok = (col.via == 0) || (row != NULL_ROW);
+      u64 lo, hi; bool isnull;
+      load_one(col, row, ok, lo, hi, isnull, P.flags);
+      rlo[c] = lo; rhi[c] = hi;
+      if (isnull) rnulls |= (1u << c);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- interpreter
+__device__ __forceinline__ void run_program(const DevProgram& P, GPUQ_REGS_PARAM) {
+  for (int p = 0; p < P.n_insns; ++p) {
+    const DevInsn in = P.code->insns[p];
+    const int op = __builtin_amdgcn_readfirstlane((int)in.op);
+    const int d = __builtin_amdgcn_readfirstlane((int)in.dst);
+    const int a = __builtin_amdgcn_readfirstlane((int)in.a);
+    const int b = __builtin_amdgcn_readfirstlane((int)in.b);
+    const uint32_t imm = (uint32_t)__builtin_amdgcn_readfirstlane((int)in.imm);
+    const u64 alo = rlo[a], ahi = rhi[a], blo = rlo[b], bhi = rhi[b];
+    const bool an = (rnulls >> a) & 1, bn = (rnulls >> b) & 1;
+    u64 zlo = 0, zhi = 0;
+    bool zn = an || bn;  // default null propagation for binary ops
+    switch (op) {
+      case OP_IMM: zlo = P.code->imm_lo[imm]; zhi = P.code->imm_hi[imm]; zn = false; break;
+      case OP_MOV: zlo = alo; zhi = ahi; zn = an; break;
+      case OP_ADD: { i128 z = mk128(alo, ahi) + mk128(blo, bhi); zlo = (u64)z; zhi = (u64)((u128)z >> 64); break; }
+      case OP_SUB: { i128 z = mk128(alo, ahi) - mk128(blo, bhi); zlo = (u64)z; zhi = (u64)((u128)z >> 64); break; }
+      case OP_MUL: { i128 z = (i128)((u128)mk128(alo, ahi) * (u128)mk128(blo, bhi)); zlo = (u64)z; zhi = (u64)((u128)z >> 64); break; }
+      case OP_MULW: { i128 z = (i128)(i64)alo * (i128)(i64)blo; zlo = (u64)z; zhi = (u64)((u128)z >> 64); break; }
+      case OP_NEG: { i128 z = -mk128(alo, ahi); zlo = (u64)z; zhi = (u64)((u128)z >> 64); zn = an; break; }
+      case OP_DIV: case OP_MOD: {
+        i128 q, r; i128 den = mk128(blo, bhi);
+        if (den == 0) { zn = true; q = 0; r = 0; } else divmod128(mk128(alo, ahi), den, q, r);
+        i128 z = (op == OP_DIV) ? q : r; zlo = (u64)z; zhi = (u64)((u128)z >> 64); break;
+      }
+      case OP_EQ: zlo = (alo == blo) & (ahi == bhi); break;
+      case OP_NE: zlo = (alo != blo) | (ahi != bhi); break;
+      case OP_LT: zlo = mk128(alo, ahi) < mk128(blo, bhi); break;
+      case OP_LE: zlo = mk128(alo, ahi) <= mk128(blo, bhi); break;
+      case OP_GT: zlo = mk128(alo, ahi) > mk128(blo, bhi); break;
+      case OP_GE: zlo = mk128(alo, ahi) >= mk128(blo, bhi); break;
+      case OP_FADD: zlo = (u64)__double_as_longlong(__longlong_as_double((i64)alo) + __longlong_as_double((i64)blo)); break;
+      case OP_FSUB: zlo = (u64)__double_as_longlong(__longlong_as_double((i64)alo) - __longlong_as_double((i64)blo)); break;
+      case OP_FMUL: zlo = (u64)__double_as_longlong(__longlong_as_double((i64)alo) * __longlong_as_double((i64)blo)); break;
+      case OP_FDIV: zlo = (u64)__double_as_longlong(__longlong_as_double((i64)alo) / __longlong_as_double((i64)blo)); break;
+      case OP_FNEG: zlo = alo ^ 0x8000000000000000ull; zn = an; break;
+      case OP_FEQ: zlo = f64_total_key(alo) == f64_total_key(blo); break;
+      case OP_FNE: zlo = f64_total_key(alo) != f64_total_key(blo); break;
+      case OP_FLT: zlo = f64_total_key(alo) < f64_total_key(blo); break;
+      case OP_FLE: zlo = f64_total_key(alo) <= f64_total_key(blo); break;
+      case OP_FGT: zlo = f64_total_key(alo) > f64_total_key(blo); break;
+      case OP_FGE: zlo = f64_total_key(alo) >= f64_total_key(blo); break;
+      case OP_I2F: {
+        // i128 -> f64, correctly rounded for |a| < 2^64 (hi is sign extension), else via two halves
+        double v = ((i64)ahi == ((i64)alo >> 63)) ? (double)(i64)alo
+                                                  : ((double)(i64)ahi * 18446744073709551616.0 + (double)alo);
+        zlo = (u64)__double_as_longlong(v); zn = an; break;
+      }
+      case OP_F2I: { i64 v = (i64)__longlong_as_double((i64)alo); zlo = (u64)v; zhi = (u64)(v >> 63); zn = an; break; }
+      case OP_AND: {  // Kleene: false AND x = false
+        bool af = !an && alo == 0, bf = !bn && blo == 0;
+        zn = !(af || bf) && (an || bn);
+        zlo = (af || bf) ? 0 : 1; break;
+      }
+      case OP_OR: {
+        bool at = !an && alo != 0, bt = !bn && blo != 0;
+        zn = !(at || bt) && (an || bn);
+        zlo = (at || bt) ? 1 : 0; break;
+      }
+      case OP_NOT: zlo = alo ? 0 : 1; zn = an; break;
+      case OP_ISNULL: zlo = an; zn = false; break;
+      case OP_ISNOTNULL: zlo = !an; zn = false; break;
+      case OP_SELECT: {
+        bool t = !an && alo != 0;
+        const int e = (int)imm;
+        zlo = t ? blo : rlo[e]; zhi = t ? bhi : rhi[e];
+        zn = t ? bn : (bool)((rnulls >> e) & 1); break;
+      }
+      case OP_SHL: { u128 z = (u128)mk128(alo, ahi) << imm; zlo = (u64)z; zhi = (u64)(z >> 64); zn = an; break; }
+      case OP_BOR: zlo = alo | blo; zhi = ahi | bhi; break;
+      case OP_NULLIF0: zlo = alo; zhi = ahi; zn = an || bn || (blo == 0 && bhi == 0); break;
+      case OP_COALESCE0: zlo = an ? 0 : alo; zhi = an ? 0 : ahi; zn = false; break;
+      default: zn = false; break;
+    }
+    rlo[d] = zlo; rhi[d] = zhi;
+    rnulls = (rnulls & ~(1u << d)) | ((uint32_t)zn << d);
+  }
+}
+
+// Row predicate after run_program: NULL counts as false (SQL WHERE; FilterExec drops null).
+__device__ __forceinline__ bool row_passes(const DevProgram& P, GPUQ_REGS_CPARAM) {
+  if (P.pred_reg < 0) return true;
+  const int r = __builtin_amdgcn_readfirstlane(P.pred_reg);
+  return rlo[r] != 0 && !((rnulls >> r) & 1);
+}
+
+// ---------------------------------------------------------------- hashing
+// 64-bit mixer (splitmix64 finaliser).  This is gpuq's own partition/hash function;
+// DataFusion's ahash(RandomState::with_seeds(0,0,0,0)) is CPU-feature dependent and is
+// not a portable contract -- both sides of an exchange use this one.
+__device__ __host__ __forceinline__ u64 mix64(u64 x) {
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31; return x;
+}
+__device__ __host__ __forceinline__ u64 hash_combine(u64 h, u64 lo, u64 hi, bool isnull) {
+  // per-column combine: h' = mix(h ^ mix(value)); NULL hashes as a fixed constant
+  u64 v = isnull ? 0x9E3779B97F4A7C15ull : mix64(lo ^ mix64(hi + 0x632BE59BD9B4E019ull));
+  return mix64(h * 31 + v + 0x9E3779B97F4A7C15ull);
+}
+
+}  // namespace gpuq

@@ -1,0 +1,135 @@
+// Internal C++ launch interface between the C ABI (capi.cpp) and the HIP kernels.
+#pragma once
+#include "gpuq_dev.h"
+
+namespace gpuq {
+
+// ----- project / materialise
+constexpr int MAX_OUTS = 12;
+struct OutCol {
+  void* data;          // fixed-width destination (4/8/16 B per row by cls; CC_STR stores the 16-B packed form)
+  u64* validity;       // optional validity bitmap as 64-bit words (bit i of word w = row 64*w+i); nullptr = not written
+  int32_t reg;
+  int32_t cls;         // CC_I32 / CC_U32 / CC_I64 / CC_I128 / CC_STR / CC_BIT(data = u64 bitmap words)
+};
+struct OutSpec { int32_t n_out; int32_t pad; OutCol cols[MAX_OUTS]; };
+
+// ----- aggregate
+constexpr int MAX_ACCS = 12;
+constexpr int MAX_KEYS = 4;
+enum AccKind : int32_t { ACC_SUM = 0, ACC_COUNT = 1, ACC_COUNT_STAR = 2, ACC_MIN = 3, ACC_MAX = 4, ACC_FSUM = 5, ACC_FMIN = 6, ACC_FMAX = 7 };
+struct AggSpec {
+  int32_t n_keys, n_accs;
+  int32_t key_reg[MAX_KEYS];
+  int32_t acc_kind[MAX_ACCS];
+  int32_t acc_reg[MAX_ACCS];
+};
+
+// Result layout shared by the tiny and hash aggregates (device memory, caller allocated):
+//   keys  [cap][n_keys] as (lo,hi) u64 pairs      key_nulls[cap] bitmask over keys
+//   cells [cap][n_accs] as (lo,hi) u64 pairs      n_groups (device u32)
+struct AggOut {
+  u64* keys; uint32_t* key_nulls; u64* cells; uint32_t* n_groups; int32_t cap; int32_t pad;
+};
+
+// scan kernels (kernels_scan.hip)
+void set_num_cus(int n);
+int num_cus();
+void launch_filter_bitmap(hipStream_t s, const DevProgram& P, i64 n, u64* bitmap, uint32_t* block_counts, int nblocks, i64 words_per_block);
+void launch_scan_block_counts(hipStream_t s, uint32_t* block_counts, int nblocks, u64* total_out);
+void launch_compact(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 words_per_block, i64 n,
+                    const uint32_t* sel_in, uint32_t* sel_out);
+void launch_project(hipStream_t s, const DevProgram& P, i64 n, const OutSpec& O);
+
+int agg_tiny_max_groups(int n_accs);
+size_t agg_tiny_workspace_bytes(int gmax, int n_keys, int n_accs, int* nblocks_out);
+void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace, const AggOut& out);
+
+// hash kernels (kernels_hash.hip)
+constexpr int MAX_KW = 2 * MAX_KEYS + 1;
+struct KeySpec {
+  int32_t n_keys;
+  int32_t key_reg[MAX_KEYS];
+  int32_t key_wide[MAX_KEYS];  // 1: key needs both 64-bit halves (Decimal128, packed Utf8); 0: hi is the sign extension
+  int32_t null_word;           // 1: append the key null-mask as a key word (group-by keys, null_equals_null joins)
+  int32_t key_words;           // total u64 key words per slot
+  int32_t word_reg[MAX_KW];    // key word q comes from register word_reg[q] ...
+  int32_t word_half[MAX_KW];   // ... half 0 = lo, 1 = hi, 2 = the key null mask
+};
+// Open-addressing table, linear probing, one slot = slot_words u64:
+//   [0]            low 32 bits state (0 empty, 1 locked, else hash tag|2); high 32 bits payload (join: chain head row)
+//   [1..key_words] key words
+//   [1+key_words..] aggregate cells, two u64 (lo,hi) per accumulator
+struct HashTable {
+  u64* slots;
+  u64 n_slots;         // power of two
+  int32_t slot_words;
+  int32_t key_words;
+};
+enum JoinType : int32_t { JT_INNER = 0, JT_LEFT = 1, JT_RIGHT = 2, JT_FULL = 3, JT_LEFT_SEMI = 4, JT_LEFT_ANTI = 5, JT_RIGHT_SEMI = 6, JT_RIGHT_ANTI = 7 };
+
+void launch_ht_init(hipStream_t s, const HashTable& T, const AggSpec* A);
+void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T);
+void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags);
+// build: payload = payload_via ? via[payload_via-1][pos] : pos.  next == nullptr => unique keys only (FLAG_DUP_BUILD_KEY on a duplicate)
+void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
+                       int payload_via, int null_equals_null);
+void launch_bitmap_select(hipStream_t s, const u64* present, const u64* visited, int matched, i64 nwords, i64 n, u64* bitmap,
+                          uint32_t* block_counts, int nblocks, i64 wpb);
+void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, const uint32_t* next,
+                       int join_type, int payload_via, int null_equals_null, uint32_t* out_build, uint32_t* out_probe,
+                       u64 out_cap, u64* out_count, uint32_t* visited);
+
+// sort / partition (kernels_sort.hip)
+constexpr int MAX_SORT_KEYS = 4;
+struct SortSpec {
+  int32_t n_keys;
+  int32_t reg[MAX_SORT_KEYS];
+  int32_t desc[MAX_SORT_KEYS];
+  int32_t nulls_first[MAX_SORT_KEYS];
+  int32_t kind[MAX_SORT_KEYS];     // 0 integer/decimal/date, 1 float64 (total order), 2 packed Utf8
+};
+struct SortPack {                   // computed on the host from the per-key min/max
+  u64 base_lo[MAX_SORT_KEYS], base_hi[MAX_SORT_KEYS];   // min (ASC) or max (DESC) in the ordered view
+  int32_t shift[MAX_SORT_KEYS];     // bit position of the key's field in the composite
+  int32_t null_bit[MAX_SORT_KEYS];  // bit (inside the field) of the null flag, -1 = none
+};
+int sort_minmax_blocks(i64 n);
+void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks);
+void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids);
+void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, uint32_t nparts, u64* pid_out, uint32_t* ids);
+void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out);
+void launch_gather_u64(hipStream_t s, const u64* src, const uint32_t* idx, i64 n, u64* dst);
+void radix_geometry(i64 n, int* nblocks, i64* tile);
+size_t radix_hist_entries(int nblocks);
+void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, uint32_t mask, u64* keys_out, uint32_t* vals_out,
+                       int32_t* hist, void* scan_ws, size_t scan_ws_bytes);
+
+// aggregate post-processing (kernels_scan.hip): AoS result -> one (lo,hi) column per key / accumulator
+struct AggSoA {
+  ulonglong2* key_col[MAX_KEYS]; u64* key_valid[MAX_KEYS];   // validity words, bit g of word g/64
+  ulonglong2* acc_col[MAX_ACCS];
+};
+void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa);
+void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out);
+void launch_unpack_utf8_bytes(hipStream_t s, const ulonglong2* packed, i64 n, const int32_t* offsets, uint8_t* data_out);
+void launch_exclusive_scan_i32(hipStream_t s, int32_t* data, i64 n, void* workspace, size_t ws_bytes);   // in place, n+1 entries out
+size_t exclusive_scan_ws_bytes(i64 n);
+
+// generator (kernels_gen.hip)
+struct LineitemCols {
+  i64* l_orderkey; i64* l_suppkey;
+  u64* l_quantity; u64* l_extendedprice; u64* l_discount; u64* l_tax;   // Decimal128 as (lo,hi)
+  int32_t* l_shipdate;
+  uint8_t* l_returnflag; int32_t* l_returnflag_off;
+  uint8_t* l_linestatus; int32_t* l_linestatus_off;
+};
+struct OrdersCols { i64* o_orderkey; i64* o_custkey; int32_t* o_orderdate; int32_t* o_shippriority; };
+struct CustomerCols { i64* c_custkey; i64* c_nationkey; uint8_t* c_mktsegment; int32_t* c_mktsegment_off; };
+struct SupplierCols { i64* s_suppkey; i64* s_nationkey; };
+void launch_gen_lineitem(hipStream_t s, u64 seed, u64 seed_orders, i64 row0, i64 n, i64 n_supp, const LineitemCols& c);
+void launch_gen_orders(hipStream_t s, u64 seed, i64 row0, i64 n, i64 n_cust, const OrdersCols& c);
+void launch_gen_customer(hipStream_t s, u64 seed, i64 row0, i64 n, const CustomerCols& c);
+void launch_gen_supplier(hipStream_t s, u64 seed, i64 row0, i64 n, const SupplierCols& c);
+
+}  // namespace gpuq

@@ -1,0 +1,421 @@
+// Hash-table operators for gfx950: high-cardinality AggregateExec and HashJoinExec build/probe.
+//
+// Replaces, on the reference's path: a6 AggregateExec (datafusion.proto:1405-1450)
+// for large group counts and a7 HashJoinExec (datafusion.proto:1346-1360, join types :280-289;
+// ctor surface ballista/core/src/physical_optimizer/task_group.rs:306-315).  Integer hash / compare /
+// gather work, HBM- and atomic-bound; no MFMA.
+//
+// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, "8-B agent atomics both sides"):
+// every word of a slot that is read inside the kernel that writes it is accessed ONLY through
+// 8-byte agent-scope atomics.  A slot is claimed by CAS(state: EMPTY->LOCKED); the winner stores
+// the key words (write-through), drains them (s_waitcnt vmcnt(0)) and then publishes state=tag
+// with one more atomic store.  Readers poll the state with a relaxed atomic load and read the key
+// words with atomic loads only after they saw the tag.  Correctness never depends on dispatch
+// order or XCD placement; every probe sequence is bounded by n_slots.
+#include "gpuq_kernels.h"
+
+namespace gpuq {
+
+constexpr int HBLOCK = 256;
+constexpr int HWAVES = HBLOCK / 64;
+constexpr uint32_t NIL = 0xFFFFFFFFu;
+
+__device__ __forceinline__ int hlane() { return threadIdx.x & 63; }
+__device__ __forceinline__ int hwave() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ u64 a_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void a_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 a_cas(u64* p, u64 expected, u64 desired) {
+  __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return expected;
+}
+__device__ __forceinline__ u64 a_add(u64* p, u64 v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Key words of the current row + their hash.  Returns true when any key is NULL.
+__device__ __forceinline__ bool make_key(const KeySpec& K, GPUQ_REGS_CPARAM, u64 (&kw)[MAX_KW], u64& hash) {
+  uint32_t knull = 0;
+  u64 h = 0x243F6A8885A308D3ull;
+#pragma unroll
+  for (int k = 0; k < MAX_KEYS; ++k) {
+    if (k < K.n_keys) {
+      const int r = __builtin_amdgcn_readfirstlane(K.key_reg[k]);
+      const bool isn = (rnulls >> r) & 1;
+      const u64 lo = isn ? 0 : rlo[r], hi = isn ? 0 : rhi[r];
+      knull |= (uint32_t)isn << k;
+      h = hash_combine(h, lo, K.key_wide[k] ? hi : 0, isn);
+    }
+  }
+  // kw[] is indexed statically only (it must stay in VGPRs); the source register is the dynamic part
+#pragma unroll
+  for (int q = 0; q < MAX_KW; ++q) {
+    kw[q] = 0;
+    if (q < K.key_words) {
+      const int half = __builtin_amdgcn_readfirstlane(K.word_half[q]);
+      if (half == 2) kw[q] = knull;
+      else {
+        const int r = __builtin_amdgcn_readfirstlane(K.word_reg[q]);
+        const bool isn = (rnulls >> r) & 1;
+        const u64 vl = rlo[r], vh = rhi[r];   // read both: a select of element pointers would demote the file to scratch
+        const u64 v = (vl & ((u64)half - 1)) | (vh & (0 - (u64)half));
+        kw[q] = isn ? 0 : v;
+      }
+    }
+  }
+  hash = h;
+  return knull != 0;
+}
+
+__device__ __forceinline__ uint32_t tag_of(u64 h) { return (uint32_t)(h >> 32) | 2u; }
+
+// Find the slot of a key or claim a new one.  Returns slot index, or ~0 when the table is full.
+__device__ __forceinline__ u64 ht_find_or_insert(const HashTable& T, const u64 (&kw)[MAX_KW], u64 h, uint32_t payload, bool& inserted) {
+  const u64 mask = T.n_slots - 1;
+  u64 s = h & mask;
+  const uint32_t tag = tag_of(h);
+  inserted = false;
+  u64 probes = 0;
+  while (probes < T.n_slots) {
+    u64* slot = T.slots + s * (u64)T.slot_words;
+    u64 w0 = a_load(slot);
+    uint32_t st = (uint32_t)w0;
+    if (st == 0u) {
+      const u64 old = a_cas(slot, 0ull, 1ull);
+      if (old == 0ull) {
+#pragma unroll
+        for (int q = 0; q < MAX_KW; ++q) if (q < T.key_words) a_store(slot + 1 + q, kw[q]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // key words drained before the tag is visible
+        a_store(slot, ((u64)payload << 32) | tag);
+        inserted = true;
+        return s;
+      }
+      st = (uint32_t)old;
+    }
+    if (st == 1u) { __builtin_amdgcn_s_sleep(1); continue; }  // being published: look again
+    if (st == tag) {
+      bool eq = true;
+#pragma unroll
+      for (int q = 0; q < MAX_KW; ++q) if (q < T.key_words) eq = eq && (a_load(slot + 1 + q) == kw[q]);
+      if (eq) return s;
+    }
+    s = (s + 1) & mask;
+    ++probes;
+  }
+  return ~0ull;
+}
+
+// Read-only lookup (table finished by an earlier kernel): plain loads.
+__device__ __forceinline__ bool ht_find(const HashTable& T, const u64 (&kw)[MAX_KW], u64 h, uint32_t& payload) {
+  const u64 mask = T.n_slots - 1;
+  u64 s = h & mask;
+  const uint32_t tag = tag_of(h);
+  for (u64 probes = 0; probes < T.n_slots; ++probes) {
+    const u64* slot = T.slots + s * (u64)T.slot_words;
+    u64 w0, k0 = 0;
+    if (T.slot_words == 2) { const ulonglong2 v = *(const ulonglong2*)slot; w0 = v.x; k0 = v.y; }
+    else w0 = slot[0];
+    const uint32_t st = (uint32_t)w0;
+    if (st == 0u) return false;
+    if (st == tag) {
+      bool eq = true;
+      if (T.slot_words == 2) eq = (k0 == kw[0]);
+      else {
+#pragma unroll
+        for (int q = 0; q < MAX_KW; ++q) if (q < T.key_words) eq = eq && (slot[1 + q] == kw[q]);
+      }
+      if (eq) { payload = (uint32_t)(w0 >> 32); return true; }
+    }
+    s = (s + 1) & mask;
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------ table init
+__global__ void __launch_bounds__(HBLOCK) k_ht_init(const HashTable T, const AggSpec A, const int has_agg) {
+  const u64 total = T.n_slots * (u64)T.slot_words;
+  const int cell0 = 1 + T.key_words;
+  for (u64 i = (u64)blockIdx.x * HBLOCK + threadIdx.x; i < total; i += (u64)gridDim.x * HBLOCK) {
+    const int w = (int)(i % (u64)T.slot_words);
+    u64 v = 0;
+    if (has_agg && w >= cell0) {
+      const int a = (w - cell0) >> 1, half = (w - cell0) & 1;
+      if (a < A.n_accs) {
+        switch (A.acc_kind[a]) {
+          case ACC_MIN: v = half ? 0 : 0x7FFFFFFFFFFFFFFFull; break;
+          case ACC_MAX: v = half ? ~0ull : 0x8000000000000000ull; break;
+          case ACC_FMIN: v = half ? 0 : 0x7FF0000000000000ull; break;
+          case ACC_FMAX: v = half ? 0 : 0xFFF0000000000000ull; break;
+          default: break;
+        }
+      }
+    }
+    T.slots[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ hash aggregate
+__global__ void __launch_bounds__(HBLOCK) k_agg_hash(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T) {
+  const i64 nwords = (n + 63) >> 6;
+  const int cell0 = 1 + T.key_words;
+  for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
+    const i64 pos = (w << 6) + hlane();
+    bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) { load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    if (!active) continue;
+    u64 kw[MAX_KW]; u64 h;
+#pragma unroll
+    for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
+    make_key(K, GPUQ_REGS, kw, h);
+    bool inserted;
+    const u64 s = ht_find_or_insert(T, kw, h, 0u, inserted);
+    if (s == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
+    u64* cells = T.slots + s * (u64)T.slot_words + cell0;
+    for (int a = 0; a < A.n_accs; ++a) {
+      const int kind = A.acc_kind[a];
+      u64 vlo = 1, vhi = 0; bool vnull = false;
+      if (kind != ACC_COUNT_STAR) {
+        const int r = __builtin_amdgcn_readfirstlane(A.acc_reg[a]);
+        vlo = rlo[r]; vhi = rhi[r]; vnull = (rnulls >> r) & 1;
+      }
+      if (vnull) continue;
+      u64* c = cells + 2 * a;
+      switch (kind) {
+        case ACC_COUNT: case ACC_COUNT_STAR: a_add(c, 1); break;
+        case ACC_SUM: {
+          const u64 old = a_add(c, vlo);
+          const u64 carry = (old + vlo < old) ? 1 : 0;
+          if (vhi + carry) a_add(c + 1, vhi + carry);
+          break;
+        }
+        case ACC_MIN: case ACC_MAX: {
+          if ((i64)vhi != ((i64)vlo >> 63)) { atomicOr(P.flags, FLAG_WIDE_MINMAX); break; }
+          if (kind == ACC_MIN) __hip_atomic_fetch_min((i64*)c, (i64)vlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else __hip_atomic_fetch_max((i64*)c, (i64)vlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        case ACC_FSUM: unsafeAtomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;
+        case ACC_FMIN: case ACC_FMAX: {
+          // total-order min/max through a CAS loop on the bit pattern
+          u64 cur = a_load(c);
+          for (;;) {
+            const bool better = (kind == ACC_FMIN) ? (f64_total_key(vlo) < f64_total_key(cur)) : (f64_total_key(vlo) > f64_total_key(cur));
+            if (!better) break;
+            const u64 seen = a_cas(c, cur, vlo);
+            if (seen == cur) break;
+            cur = seen;
+          }
+          break;
+        }
+        default: break;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(HBLOCK) k_agg_hash_extract(const KeySpec K, const AggSpec A, const HashTable T, const AggOut out,
+                                                             uint32_t* __restrict__ flags) {
+  const int cell0 = 1 + T.key_words;
+  const int kstride = K.n_keys > 0 ? K.n_keys : 1;
+  const u64 rounds = (T.n_slots + (u64)gridDim.x * HBLOCK - 1) / ((u64)gridDim.x * HBLOCK);
+  for (u64 it = 0; it < rounds; ++it) {
+    const u64 s = (it * gridDim.x + blockIdx.x) * HBLOCK + threadIdx.x;
+    bool live = false;
+    const u64* slot = nullptr;
+    if (s < T.n_slots) { slot = T.slots + s * (u64)T.slot_words; live = ((uint32_t)slot[0]) >= 2u; }
+    const u64 m = __ballot(live);
+    if (m == 0) continue;
+    uint32_t base = 0;
+    if (hlane() == 0) base = atomicAdd(out.n_groups, (uint32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (!live) continue;
+    const uint32_t g = base + (uint32_t)__popcll(m & ((1ull << hlane()) - 1));
+    if (g >= (uint32_t)out.cap) { atomicOr(flags, FLAG_GROUP_OVERFLOW); continue; }
+    int w = 0;
+    for (int k = 0; k < K.n_keys; ++k) {
+      const u64 lo = slot[1 + w]; ++w;
+      u64 hi = (u64)((i64)lo >> 63);
+      if (K.key_wide[k]) { hi = slot[1 + w]; ++w; }
+      out.keys[((size_t)g * kstride + k) * 2] = lo;
+      out.keys[((size_t)g * kstride + k) * 2 + 1] = hi;
+    }
+    out.key_nulls[g] = K.null_word ? (uint32_t)slot[1 + w] : 0u;
+    for (int a = 0; a < A.n_accs; ++a) {
+      u64 lo = slot[cell0 + 2 * a], hi = slot[cell0 + 2 * a + 1];
+      const int kind = A.acc_kind[a];
+      if (kind == ACC_MIN || kind == ACC_MAX) hi = (u64)((i64)lo >> 63);
+      out.cells[((size_t)g * A.n_accs + a) * 2] = lo;
+      out.cells[((size_t)g * A.n_accs + a) * 2 + 1] = hi;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ join build
+__global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                       uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
+                                                       const int null_eq) {
+  const i64 nwords = (n + 63) >> 6;
+  for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
+    const i64 pos = (w << 6) + hlane();
+    bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) { load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    if (!active) continue;
+    u64 kw[MAX_KW]; u64 h;
+#pragma unroll
+    for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
+    const bool any_null = make_key(K, GPUQ_REGS, kw, h);
+    uint32_t row = (uint32_t)pos;
+    if (payload_via > 0) row = P.via[payload_via - 1][pos];
+    if (present) atomicOr(&present[row >> 5], 1u << (row & 31));   // every build-side row, NULL keys included (outer joins emit them)
+    if (any_null && !null_eq) continue;   // a NULL key never matches (SQL equi-join)
+    bool inserted;
+    const u64 s = ht_find_or_insert(T, kw, h, row, inserted);
+    if (s == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
+    if (inserted) {
+      if (next) next[row] = NIL;
+    } else {
+      if (next) {
+        uint32_t* head = (uint32_t*)(T.slots + s * (u64)T.slot_words) + 1;   // high half of word 0
+        const uint32_t old = __hip_atomic_exchange(head, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        next[row] = old;
+      } else {
+        atomicOr(P.flags, FLAG_DUP_BUILD_KEY);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ join probe
+// Emits (build_row, probe_row) pairs with wave-ballot compaction: one global atomic per wave per
+// chain step.  Pair order is not input order (DataFusion's is batch-local and unspecified across
+// partitions); the SET of pairs is deterministic.
+__global__ void __launch_bounds__(HBLOCK) k_join_probe(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                       const uint32_t* __restrict__ next, const int join_type, const int payload_via,
+                                                       const int null_eq, uint32_t* __restrict__ out_build, uint32_t* __restrict__ out_probe,
+                                                       const u64 out_cap, u64* __restrict__ out_count, uint32_t* __restrict__ visited) {
+  const i64 nwords = (n + 63) >> 6;
+  const bool emit_pairs = (join_type == JT_INNER || join_type == JT_LEFT || join_type == JT_RIGHT || join_type == JT_FULL);
+  const bool probe_outer = (join_type == JT_RIGHT || join_type == JT_FULL);
+  const bool mark = (visited != nullptr);
+  for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
+    const i64 pos = (w << 6) + hlane();
+    bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) { load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    uint32_t cur = NIL;
+    uint32_t prow = (uint32_t)pos;
+    if (active) {
+      if (payload_via > 0) prow = P.via[payload_via - 1][pos];
+      u64 kw[MAX_KW]; u64 h;
+#pragma unroll
+      for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
+      const bool any_null = make_key(K, GPUQ_REGS, kw, h);
+      if (!(any_null && !null_eq)) {
+        uint32_t payload;
+        if (ht_find(T, kw, h, payload)) cur = payload;
+      }
+    }
+    if (join_type == JT_RIGHT_SEMI || join_type == JT_RIGHT_ANTI) {
+      const bool emit = active && ((join_type == JT_RIGHT_SEMI) == (cur != NIL));
+      const u64 m = __ballot(emit);
+      if (m) {
+        u64 base = 0;
+        if (hlane() == 0) base = a_add(out_count, (u64)__popcll(m));
+        base = __shfl(base, 0);
+        if (emit) {
+          const u64 idx = base + (u64)__popcll(m & ((1ull << hlane()) - 1));
+          if (idx < out_cap) { if (out_build) out_build[idx] = NULL_ROW; out_probe[idx] = prow; }
+          else atomicOr(P.flags, FLAG_OUT_OVERFLOW);
+        }
+      }
+      continue;
+    }
+    bool first = true;
+    for (;;) {
+      const bool has = (cur != NIL);
+      const bool emit = emit_pairs && active && (has || (first && probe_outer));
+      const u64 m = __ballot(emit);
+      if (m) {
+        u64 base = 0;
+        if (hlane() == 0) base = a_add(out_count, (u64)__popcll(m));
+        base = __shfl(base, 0);
+        if (emit) {
+          const u64 idx = base + (u64)__popcll(m & ((1ull << hlane()) - 1));
+          if (idx < out_cap) { out_build[idx] = has ? cur : NULL_ROW; out_probe[idx] = prow; }
+          else atomicOr(P.flags, FLAG_OUT_OVERFLOW);
+        }
+      }
+      if (has) {
+        if (mark) atomicOr(&visited[cur >> 5], 1u << (cur & 31));
+        cur = next ? next[cur] : NIL;
+      }
+      first = false;
+      if (__ballot(cur != NIL) == 0) break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ launchers
+static int hgrid(i64 n, int blocks_per_cu) {
+  const i64 nwords = (n + 63) >> 6;
+  i64 need = (nwords + HWAVES - 1) / HWAVES;
+  if (need < 1) need = 1;
+  const i64 cap = (i64)num_cus() * blocks_per_cu;
+  return (int)(need < cap ? need : cap);
+}
+
+void launch_ht_init(hipStream_t s, const HashTable& T, const AggSpec* A) {
+  AggSpec dummy{};
+  const u64 total = T.n_slots * (u64)T.slot_words;
+  u64 need = (total + HBLOCK - 1) / HBLOCK;
+  const u64 cap = (u64)num_cus() * 16;
+  const int grid = (int)(need < cap ? (need ? need : 1) : cap);
+  hipLaunchKernelGGL(k_ht_init, dim3(grid), dim3(HBLOCK), 0, s, T, A ? *A : dummy, A ? 1 : 0);
+}
+void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_agg_hash, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, A, T);
+}
+void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags) {
+  u64 need = (T.n_slots + HBLOCK - 1) / HBLOCK;
+  const u64 cap = (u64)num_cus() * 16;
+  const int grid = (int)(need < cap ? (need ? need : 1) : cap);
+  hipLaunchKernelGGL(k_agg_hash_extract, dim3(grid), dim3(HBLOCK), 0, s, K, A, T, out, flags);
+}
+void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
+                       int payload_via, int null_equals_null) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_join_build, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, present, payload_via, null_equals_null);
+}
+
+// build-side row selection for Left/Full/LeftSemi/LeftAnti: present & (visited | ~visited)
+__global__ void __launch_bounds__(HBLOCK) k_bitmap_select(const u64* __restrict__ present, const u64* __restrict__ visited, const int matched,
+                                                          const i64 nwords, const i64 n, u64* __restrict__ bitmap,
+                                                          uint32_t* __restrict__ block_counts, const i64 wpb) {
+  __shared__ uint32_t wc[HWAVES];
+  const i64 w0 = (i64)blockIdx.x * wpb;
+  i64 w1 = w0 + wpb; if (w1 > nwords) w1 = nwords;
+  uint32_t cnt = 0;
+  for (i64 w = w0 + threadIdx.x; w < w1; w += HBLOCK) {
+    u64 m = present[w] & (matched ? visited[w] : ~visited[w]);
+    if (w == nwords - 1 && (n & 63)) m &= (1ull << (n & 63)) - 1;
+    bitmap[w] = m; cnt += (uint32_t)__popcll(m);
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if (hlane() == 0) wc[hwave()] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < HWAVES; ++k) t += wc[k]; block_counts[blockIdx.x] = t; }
+}
+void launch_bitmap_select(hipStream_t s, const u64* present, const u64* visited, int matched, i64 nwords, i64 n, u64* bitmap,
+                          uint32_t* block_counts, int nblocks, i64 wpb) {
+  hipLaunchKernelGGL(k_bitmap_select, dim3(nblocks), dim3(HBLOCK), 0, s, present, visited, matched, nwords, n, bitmap, block_counts, wpb);
+}
+void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, const uint32_t* next,
+                       int join_type, int payload_via, int null_equals_null, uint32_t* out_build, uint32_t* out_probe,
+                       u64 out_cap, u64* out_count, uint32_t* visited) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_join_probe, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, join_type, payload_via, null_equals_null,
+                     out_build, out_probe, out_cap, out_count, visited);
+}
+
+}  // namespace gpuq

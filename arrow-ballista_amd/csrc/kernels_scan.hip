@@ -1,0 +1,639 @@
+// Scan-side operators for gfx950: FilterExec (ordered ballot compaction),
+// ProjectionExec (expression materialisation / gather) and the low-cardinality
+// AggregateExec path (LDS-privatised per-lane accumulators).
+//
+// Replaces, on the reference's path: a5 FilterExec
+// (datafusion.proto:1291-1294), a9 ProjectionExec/CoalesceBatchesExec
+// (:1399-1403, :1487-1490) and a6 AggregateExec for small group counts
+// (:1405-1450), as driven by ballista/core/src/execution_plans/shuffle_writer.rs:255,341.
+// All of them are HBM-bound integer paths: every input byte is read once with
+// coalesced 4/8/16-B-per-lane loads, expression intermediates stay in VGPRs.
+#include "gpuq_kernels.h"
+
+namespace gpuq {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ------------------------------------------------------------------ filter
+// Pass 1: evaluate the predicate once per row, keep it as a bitmap (N/8 bytes) plus one
+// count per block.  Block b owns the contiguous word range [b*wpb, (b+1)*wpb).
+__global__ void __launch_bounds__(BLOCK) k_filter_bitmap(const DevProgram P, const i64 n, u64* __restrict__ bitmap,
+                                                         uint32_t* __restrict__ block_counts, const i64 wpb) {
+  __shared__ uint32_t wave_cnt[WAVES];
+  const i64 nwords = (n + 63) >> 6;
+  const i64 w0 = (i64)blockIdx.x * wpb;
+  i64 w1 = w0 + wpb; if (w1 > nwords) w1 = nwords;
+  uint32_t cnt = 0;
+  for (i64 w = w0 + wave_id(); w < w1; w += WAVES) {
+    const i64 pos = (w << 6) + lane_id();
+    bool pass = false;
+    if (pos < n) {
+      GPUQ_REGS_DECL;
+      load_columns(P, pos, GPUQ_REGS);
+      run_program(P, GPUQ_REGS);
+      pass = row_passes(P, GPUQ_REGS);
+    }
+    const u64 m = __ballot(pass);
+    if (lane_id() == 0) bitmap[w] = m;
+    cnt += (uint32_t)__popcll(m);
+  }
+  if (lane_id() == 0) wave_cnt[wave_id()] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int k = 0; k < WAVES; ++k) t += wave_cnt[k];
+    block_counts[blockIdx.x] = t;
+  }
+}
+
+// Exclusive scan of <= 1024*ITEMS block counts in place; single block of 1024 threads.
+__global__ void __launch_bounds__(1024) k_scan_counts(uint32_t* __restrict__ counts, const int n, u64* __restrict__ total_out) {
+  __shared__ u64 wsum[16];
+  const int t = threadIdx.x;
+  const int items = (n + 1023) / 1024;
+  const int i0 = t * items;
+  u64 local = 0;
+  for (int k = 0; k < items; ++k) if (i0 + k < n) local += counts[i0 + k];
+  // inclusive wave scan
+  u64 x = local;
+  for (int off = 1; off < 64; off <<= 1) {
+    u64 y = __shfl_up(x, off);
+    if ((t & 63) >= off) x += y;
+  }
+  if ((t & 63) == 63) wsum[t >> 6] = x;
+  __syncthreads();
+  if (t == 0) {
+    u64 run = 0;
+    for (int k = 0; k < 16; ++k) { u64 v = wsum[k]; wsum[k] = run; run += v; }
+    if (total_out) *total_out = run;
+  }
+  __syncthreads();
+  u64 excl = wsum[t >> 6] + x - local;
+  for (int k = 0; k < items; ++k) if (i0 + k < n) { uint32_t c = counts[i0 + k]; counts[i0 + k] = (uint32_t)excl; excl += c; }
+}
+
+// Pass 2: ordered compaction.  Each wave owns a contiguous slice of the block's words, so row
+// order is preserved (FilterExec keeps input order); one coalesced store per bitmap word.
+__global__ void __launch_bounds__(BLOCK) k_compact(const u64* __restrict__ bitmap, const uint32_t* __restrict__ block_offsets,
+                                                   const i64 wpb, const i64 n, const uint32_t* __restrict__ sel_in,
+                                                   uint32_t* __restrict__ sel_out) {
+  __shared__ uint32_t wave_cnt[WAVES];
+  const i64 nwords = (n + 63) >> 6;
+  const i64 w0 = (i64)blockIdx.x * wpb;
+  i64 w1 = w0 + wpb; if (w1 > nwords) w1 = nwords;
+  const i64 span = w1 > w0 ? (w1 - w0) : 0;
+  const i64 per = (span + WAVES - 1) / WAVES;
+  const i64 a = w0 + per * wave_id();
+  i64 b = a + per; if (b > w1) b = w1;
+  uint32_t cnt = 0;
+  for (i64 w = a + lane_id(); w < b; w += 64) cnt += (uint32_t)__popcll(bitmap[w]);
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if (lane_id() == 0) wave_cnt[wave_id()] = cnt;
+  __syncthreads();
+  u64 out = block_offsets[blockIdx.x];
+  for (int k = 0; k < wave_id(); ++k) out += wave_cnt[k];
+  for (i64 w = a; w < b; ++w) {
+    const u64 m = bitmap[w];
+    const int l = lane_id();
+    if ((m >> l) & 1) {
+      const uint32_t rank = (uint32_t)__popcll(m & ((1ull << l) - 1));
+      const i64 pos = (w << 6) + l;
+      sel_out[out + rank] = sel_in ? sel_in[pos] : (uint32_t)pos;
+    }
+    out += (uint32_t)__popcll(m);
+  }
+}
+
+// ------------------------------------------------------------------ project
+__global__ void __launch_bounds__(BLOCK) k_project(const DevProgram P, const i64 n, const OutSpec O) {
+  const i64 nwords = (n + 63) >> 6;
+  for (i64 w = (i64)blockIdx.x * WAVES + wave_id(); w < nwords; w += (i64)gridDim.x * WAVES) {
+    const i64 pos = (w << 6) + lane_id();
+    const bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) { load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); }
+#pragma unroll
+    for (int k = 0; k < MAX_OUTS; ++k) {
+      if (k < O.n_out) {
+        const OutCol oc = O.cols[k];
+        const int r = __builtin_amdgcn_readfirstlane(oc.reg);
+        u64 lo = 0, hi = 0; bool isnull = true;
+        if (active) { lo = rlo[r]; hi = rhi[r]; isnull = (rnulls >> r) & 1; }
+        if (oc.validity) {
+          const u64 vm = __ballot(active && !isnull);
+          if (lane_id() == 0) oc.validity[w] = vm;
+        }
+        if (isnull) { lo = 0; hi = 0; }
+        switch (oc.cls) {
+          case CC_I32: case CC_U32: if (active) ((uint32_t*)oc.data)[pos] = (uint32_t)lo; break;
+          case CC_I64: if (active) ((u64*)oc.data)[pos] = lo; break;
+          case CC_I128: case CC_STR: if (active) ((ulonglong2*)oc.data)[pos] = make_ulonglong2(lo, hi); break;
+          case CC_BIT: { const u64 bm = __ballot(active && lo != 0); if (lane_id() == 0) ((u64*)oc.data)[w] = bm; break; }
+          default: break;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ tiny-group aggregate
+// LDS layout (dynamic, 16-B aligned):
+//   lane_acc [cells][BLOCK] u64     per-lane 64-bit partials, conflict-free (lane-major)
+//   wide     [cells][2]     u64     block-shared 128-bit spill accumulators (atomic)
+//   dkeys    [gmax][n_keys][2] u64  block dictionary of group keys
+//   dnulls   [gmax] u32, dict_n u32, lock u32
+// cells = gmax * n_accs.  A lane keeps each SUM in a private 64-bit slot and only spills to the
+// shared 128-bit cell when the slot could overflow or the value does not fit 64 bits, so the hot
+// loop has no atomics and no bank conflicts.
+struct TinyLds {
+  u64* lane_acc; u64* wide; u64* dkeys; uint32_t* dnulls; uint32_t* dict_n; uint32_t* lock;
+};
+__device__ __forceinline__ TinyLds tiny_carve(char* smem, int gmax, int n_keys, int n_accs) {
+  TinyLds L;
+  const int cells = gmax * n_accs;
+  L.lane_acc = (u64*)smem; smem += (size_t)cells * BLOCK * 8;
+  L.wide = (u64*)smem; smem += (size_t)cells * 16;
+  L.dkeys = (u64*)smem; smem += (size_t)gmax * (n_keys > 0 ? n_keys : 1) * 16;
+  L.dnulls = (uint32_t*)smem; smem += (size_t)gmax * 4;
+  L.dict_n = (uint32_t*)smem; smem += 4;
+  L.lock = (uint32_t*)smem;
+  return L;
+}
+static size_t tiny_lds_bytes(int gmax, int n_keys, int n_accs) {
+  const size_t cells = (size_t)gmax * n_accs;
+  return cells * BLOCK * 8 + cells * 16 + (size_t)gmax * (n_keys > 0 ? n_keys : 1) * 16 + (size_t)gmax * 4 + 16;
+}
+
+__device__ __forceinline__ u64 acc_identity(int kind) {
+  switch (kind) {
+    case ACC_MIN: return 0x7FFFFFFFFFFFFFFFull;
+    case ACC_MAX: return 0x8000000000000000ull;
+    case ACC_FMIN: return 0x7FF0000000000000ull;  // +inf
+    case ACC_FMAX: return 0xFFF0000000000000ull;  // -inf
+    default: return 0;
+  }
+}
+
+__device__ __forceinline__ void wide_add(u64* wide, int cell, u64 lo, u64 hi) {
+  // 128-bit add into an LDS cell with two 64-bit atomics (adds commute, so the carry can trail)
+  const u64 old = atomicAdd(&wide[2 * cell], lo);
+  const u64 carry = (old + lo < old) ? 1 : 0;
+  if (hi + carry) atomicAdd(&wide[2 * cell + 1], hi + carry);
+}
+
+// per-block partial record in the workspace
+struct TinyPartialHdr { uint32_t n; uint32_t pad; };
+static size_t tiny_partial_bytes(int gmax, int n_keys, int n_accs) {
+  return 8 + (size_t)gmax * (n_keys > 0 ? n_keys : 1) * 16 + (size_t)gmax * 4 + ((gmax & 1) ? 4 : 0) + (size_t)gmax * n_accs * 16;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_agg_tiny(const DevProgram P, const i64 n, const AggSpec A, const int gmax,
+                                                    char* __restrict__ workspace, const size_t partial_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n_keys = A.n_keys, n_accs = A.n_accs;
+  const int kstride = n_keys > 0 ? n_keys : 1;
+  const TinyLds L = tiny_carve(smem, gmax, n_keys, n_accs);
+  const int cells = gmax * n_accs;
+  const int tid = threadIdx.x;
+  for (int c = 0; c < cells; ++c) L.lane_acc[c * BLOCK + tid] = acc_identity(A.acc_kind[c % n_accs]);
+  for (int c = tid; c < cells * 2; c += BLOCK) L.wide[c] = 0;
+  if (tid == 0) { *L.dict_n = 0; *L.lock = 0; }
+  __syncthreads();
+
+  volatile uint32_t* vn = L.dict_n;
+  volatile u64* vkeys = L.dkeys;
+  volatile uint32_t* vnulls = L.dnulls;
+
+  const i64 nwords = (n + 63) >> 6;
+  for (i64 w = (i64)blockIdx.x * WAVES + wave_id(); w < nwords; w += (i64)gridDim.x * WAVES) {
+    const i64 pos = (w << 6) + lane_id();
+    bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) { load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    // group key
+    u64 klo[MAX_KEYS], khi[MAX_KEYS]; uint32_t knull = 0;
+#pragma unroll
+    for (int k = 0; k < MAX_KEYS; ++k) {
+      klo[k] = 0; khi[k] = 0;
+      if (k < n_keys && active) {
+        const int r = __builtin_amdgcn_readfirstlane(A.key_reg[k]);
+        const bool isn = (rnulls >> r) & 1;
+        klo[k] = isn ? 0 : rlo[r]; khi[k] = isn ? 0 : rhi[r];
+        knull |= (uint32_t)isn << k;
+      }
+    }
+    int gid = -1;
+    uint32_t seen = 0;
+    for (;;) {
+      // lock-free lookup over the dictionary entries published so far
+      const uint32_t nd = *vn;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (active && gid < 0) {
+        for (uint32_t g = seen; g < nd; ++g) {
+          bool eq = vnulls[g] == knull;
+#pragma unroll
+          for (int k = 0; k < MAX_KEYS; ++k)
+            if (k < n_keys) eq = eq && vkeys[(g * kstride + k) * 2] == klo[k] && vkeys[(g * kstride + k) * 2 + 1] == khi[k];
+          if (eq) gid = (int)g;
+        }
+      }
+      seen = nd;
+      const u64 need = __ballot(active && gid < 0);
+      if (need == 0) break;
+      const int leader = __ffsll((long long)need) - 1;
+      if (lane_id() == leader) {
+        while (atomicCAS(L.lock, 0u, 1u) != 0u) {}
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t n2 = *vn;
+        int found = -1;
+        for (uint32_t g = nd; g < n2; ++g) {
+          bool eq = vnulls[g] == knull;
+#pragma unroll
+          for (int k = 0; k < MAX_KEYS; ++k)
+            if (k < n_keys) eq = eq && vkeys[(g * kstride + k) * 2] == klo[k] && vkeys[(g * kstride + k) * 2 + 1] == khi[k];
+          if (eq) found = (int)g;
+        }
+        if (found < 0) {
+          if (n2 < (uint32_t)gmax) {
+#pragma unroll
+            for (int k = 0; k < MAX_KEYS; ++k)
+              if (k < n_keys) { vkeys[(n2 * kstride + k) * 2] = klo[k]; vkeys[(n2 * kstride + k) * 2 + 1] = khi[k]; }
+            vnulls[n2] = knull;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            *vn = n2 + 1;
+            found = (int)n2;
+          } else {
+            atomicOr(P.flags, FLAG_GROUP_OVERFLOW);
+            found = 0;  // result is discarded by the host when the flag is set
+          }
+        }
+        gid = found;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicExch(L.lock, 0u);
+      }
+      // other lanes with the same key find it in the next lookup round
+    }
+    // accumulate
+    if (active) {
+      for (int a = 0; a < n_accs; ++a) {
+        const int kind = A.acc_kind[a];
+        const int cell = gid * n_accs + a;
+        u64* slot = &L.lane_acc[cell * BLOCK + tid];
+        u64 vlo = 1, vhi = 0; bool vnull = false;
+        if (kind != ACC_COUNT_STAR) {
+          const int r = __builtin_amdgcn_readfirstlane(A.acc_reg[a]);
+          vlo = rlo[r]; vhi = rhi[r]; vnull = (rnulls >> r) & 1;
+        }
+        if (vnull) continue;
+        switch (kind) {
+          case ACC_COUNT: case ACC_COUNT_STAR: *slot += 1; break;
+          case ACC_SUM: {
+            const i64 cur = (i64)*slot;
+            const bool fits = (i64)vhi == ((i64)vlo >> 63);
+            const i64 v = (i64)vlo;
+            // keep |slot| < 2^62 so one more 64-bit add cannot overflow
+            const bool small = fits && v > -(1ll << 61) && v < (1ll << 61);
+            if (small) {
+              i64 nv = cur + v;
+              if (nv > (1ll << 62) || nv < -(1ll << 62)) { wide_add(L.wide, cell, (u64)nv, (u64)(nv >> 63)); nv = 0; }
+              *slot = (u64)nv;
+            } else {
+              wide_add(L.wide, cell, vlo, vhi);
+            }
+            break;
+          }
+          case ACC_MIN: case ACC_MAX: {
+            const bool fits = (i64)vhi == ((i64)vlo >> 63);
+            if (!fits) { atomicOr(P.flags, FLAG_WIDE_MINMAX); break; }  // reported as unsupported by the host
+            const i64 cur = (i64)*slot, v = (i64)vlo;
+            if (kind == ACC_MIN ? (v < cur) : (v > cur)) *slot = (u64)v;
+            break;
+          }
+          case ACC_FSUM: *slot = (u64)__double_as_longlong(__longlong_as_double((i64)*slot) + __longlong_as_double((i64)vlo)); break;
+          case ACC_FMIN: if (f64_total_key(vlo) < f64_total_key(*slot)) *slot = vlo; break;
+          case ACC_FMAX: if (f64_total_key(vlo) > f64_total_key(*slot)) *slot = vlo; break;
+          default: break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // block reduction: fold the per-lane partials of every live cell, add the wide spill cell
+  __shared__ u64 red[WAVES * 2];
+  const int ng = (int)*L.dict_n;
+  char* rec = workspace + (size_t)blockIdx.x * partial_stride;
+  u64* out_keys = (u64*)(rec + 8);
+  uint32_t* out_nulls = (uint32_t*)(rec + 8 + (size_t)gmax * kstride * 16);
+  u64* out_cells = (u64*)(rec + 8 + (size_t)gmax * kstride * 16 + (size_t)gmax * 4 + ((gmax & 1) ? 4 : 0));
+  if (tid == 0) { ((uint32_t*)rec)[0] = (uint32_t)ng; ((uint32_t*)rec)[1] = 0; }
+  for (int i = tid; i < ng * kstride * 2; i += BLOCK) out_keys[i] = L.dkeys[i];
+  for (int i = tid; i < ng; i += BLOCK) out_nulls[i] = L.dnulls[i];
+  for (int c = 0; c < ng * n_accs; ++c) {
+    const int kind = A.acc_kind[c % n_accs];
+    const u64 v = L.lane_acc[c * BLOCK + tid];
+    u64 lo, hi;
+    if (kind == ACC_SUM) { lo = v; hi = (u64)((i64)v >> 63); } else { lo = v; hi = 0; }
+    for (int off = 32; off > 0; off >>= 1) {
+      const u64 olo = __shfl_xor(lo, off), ohi = __shfl_xor(hi, off);
+      switch (kind) {
+        case ACC_SUM: case ACC_COUNT: case ACC_COUNT_STAR: { const u64 s = lo + olo; hi = hi + ohi + (s < lo ? 1 : 0); lo = s; break; }
+        case ACC_MIN: if ((i64)olo < (i64)lo) lo = olo; break;
+        case ACC_MAX: if ((i64)olo > (i64)lo) lo = olo; break;
+        // lanes combine in a fixed butterfly order -> bitwise reproducible run to run
+        case ACC_FSUM: lo = (u64)__double_as_longlong(__longlong_as_double((i64)lo) + __longlong_as_double((i64)olo)); break;
+        case ACC_FMIN: if (f64_total_key(olo) < f64_total_key(lo)) lo = olo; break;
+        case ACC_FMAX: if (f64_total_key(olo) > f64_total_key(lo)) lo = olo; break;
+        default: break;
+      }
+    }
+    if (lane_id() == 0) { red[wave_id() * 2] = lo; red[wave_id() * 2 + 1] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+      u64 rlo = red[0], rhi = red[1];
+      for (int k = 1; k < WAVES; ++k) {
+        const u64 olo = red[2 * k], ohi = red[2 * k + 1];
+        switch (kind) {
+          case ACC_SUM: case ACC_COUNT: case ACC_COUNT_STAR: { const u64 s = rlo + olo; rhi = rhi + ohi + (s < rlo ? 1 : 0); rlo = s; break; }
+          case ACC_MIN: if ((i64)olo < (i64)rlo) rlo = olo; break;
+          case ACC_MAX: if ((i64)olo > (i64)rlo) rlo = olo; break;
+          case ACC_FSUM: rlo = (u64)__double_as_longlong(__longlong_as_double((i64)rlo) + __longlong_as_double((i64)olo)); break;
+          case ACC_FMIN: if (f64_total_key(olo) < f64_total_key(rlo)) rlo = olo; break;
+          case ACC_FMAX: if (f64_total_key(olo) > f64_total_key(rlo)) rlo = olo; break;
+          default: break;
+        }
+      }
+      if (kind == ACC_SUM) {
+        const u64 wlo = L.wide[2 * c], whi = L.wide[2 * c + 1];
+        const u64 s = rlo + wlo; rhi = rhi + whi + (s < rlo ? 1 : 0); rlo = s;
+      } else if (kind == ACC_MIN || kind == ACC_MAX) {
+        rhi = (u64)((i64)rlo >> 63);
+      }
+      out_cells[2 * c] = rlo; out_cells[2 * c + 1] = rhi;
+    }
+    __syncthreads();
+  }
+}
+
+// Merge the per-block partial records into the final groups.  One block; the work is
+// nblocks*gmax records, a few thousand at most.
+__global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const int gmax, const char* __restrict__ workspace,
+                                                          const size_t partial_stride, const int nblocks, const AggOut out,
+                                                          uint32_t* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n_keys = A.n_keys, n_accs = A.n_accs;
+  const int kstride = n_keys > 0 ? n_keys : 1;
+  const int cap = out.cap;
+  // LDS: fkeys[cap][kstride][2] u64, fnulls[cap] u32, map[nblocks*gmax] u16, fn, lock
+  u64* fkeys = (u64*)smem;
+  uint32_t* fnulls = (uint32_t*)(smem + (size_t)cap * kstride * 16);
+  uint16_t* map = (uint16_t*)((char*)fnulls + (size_t)cap * 4);
+  uint32_t* fn = (uint32_t*)((char*)map + (((size_t)nblocks * gmax * 2 + 15) & ~(size_t)15));
+  uint32_t* lock = fn + 1;
+  const int tid = threadIdx.x;
+  if (tid == 0) { *fn = 0; *lock = 0; }
+  __syncthreads();
+  volatile uint32_t* vfn = fn;
+  volatile u64* vk = fkeys;
+  volatile uint32_t* vnl = fnulls;
+  const size_t keys_off = 8, nulls_off = 8 + (size_t)gmax * kstride * 16;
+  const size_t cells_off = nulls_off + (size_t)gmax * 4 + ((gmax & 1) ? 4 : 0);
+  // phase 1: map every (block, local group) to a final group id
+  for (int e = tid; e < nblocks * gmax; e += BLOCK) {
+    const int b = e / gmax, g = e % gmax;
+    const char* rec = workspace + (size_t)b * partial_stride;
+    const uint32_t ng = ((const uint32_t*)rec)[0];
+    if ((uint32_t)g >= ng) { map[e] = 0xFFFF; continue; }
+    const u64* k = (const u64*)(rec + keys_off) + (size_t)g * kstride * 2;
+    const uint32_t kn = ((const uint32_t*)(rec + nulls_off))[g];
+    int found = -1; uint32_t seen = 0;
+    while (found < 0) {
+      const uint32_t nd = *vfn;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      for (uint32_t f = seen; f < nd && found < 0; ++f) {
+        bool eq = vnl[f] == kn;
+        for (int q = 0; q < n_keys; ++q) eq = eq && vk[(f * kstride + q) * 2] == k[2 * q] && vk[(f * kstride + q) * 2 + 1] == k[2 * q + 1];
+        if (eq) found = (int)f;
+      }
+      seen = nd;
+      if (found >= 0) break;
+      if (atomicCAS(lock, 0u, 1u) == 0u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t n2 = *vfn;
+        for (uint32_t f = seen; f < n2 && found < 0; ++f) {
+          bool eq = vnl[f] == kn;
+          for (int q = 0; q < n_keys; ++q) eq = eq && vk[(f * kstride + q) * 2] == k[2 * q] && vk[(f * kstride + q) * 2 + 1] == k[2 * q + 1];
+          if (eq) found = (int)f;
+        }
+        if (found < 0) {
+          if (n2 < (uint32_t)cap) {
+            for (int q = 0; q < n_keys; ++q) { vk[(n2 * kstride + q) * 2] = k[2 * q]; vk[(n2 * kstride + q) * 2 + 1] = k[2 * q + 1]; }
+            vnl[n2] = kn;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            *vfn = n2 + 1;
+            found = (int)n2;
+          } else { atomicOr(flags, FLAG_GROUP_OVERFLOW); found = 0; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicExch(lock, 0u);
+      }
+    }
+    map[e] = (uint16_t)found;
+  }
+  __syncthreads();
+  const int nf = (int)*fn;
+  // phase 2: one thread per final cell, records folded in block order (fixed order -> deterministic)
+  for (int c = tid; c < nf * n_accs; c += BLOCK) {
+    const int f = c / n_accs, a = c % n_accs;
+    const int kind = A.acc_kind[a];
+    u64 rlo = acc_identity(kind), rhi = (kind == ACC_MIN) ? 0 : ((kind == ACC_MAX) ? ~0ull : 0);
+    for (int b = 0; b < nblocks; ++b) {
+      const char* rec = workspace + (size_t)b * partial_stride;
+      const u64* cellsb = (const u64*)(rec + cells_off);
+      for (int g = 0; g < gmax; ++g) {
+        if (map[b * gmax + g] != (uint16_t)f) continue;
+        const u64 olo = cellsb[(size_t)(g * n_accs + a) * 2], ohi = cellsb[(size_t)(g * n_accs + a) * 2 + 1];
+        switch (kind) {
+          case ACC_SUM: case ACC_COUNT: case ACC_COUNT_STAR: { const u64 s = rlo + olo; rhi = rhi + ohi + (s < rlo ? 1 : 0); rlo = s; break; }
+          case ACC_MIN: if ((i64)olo < (i64)rlo) { rlo = olo; rhi = ohi; } break;
+          case ACC_MAX: if ((i64)olo > (i64)rlo) { rlo = olo; rhi = ohi; } break;
+          case ACC_FSUM: rlo = (u64)__double_as_longlong(__longlong_as_double((i64)rlo) + __longlong_as_double((i64)olo)); break;
+          case ACC_FMIN: if (f64_total_key(olo) < f64_total_key(rlo)) rlo = olo; break;
+          case ACC_FMAX: if (f64_total_key(olo) > f64_total_key(rlo)) rlo = olo; break;
+          default: break;
+        }
+      }
+    }
+    out.cells[(size_t)c * 2] = rlo; out.cells[(size_t)c * 2 + 1] = rhi;
+  }
+  for (int i = tid; i < nf * kstride * 2; i += BLOCK) out.keys[i] = fkeys[i];
+  for (int i = tid; i < nf; i += BLOCK) out.key_nulls[i] = fnulls[i];
+  if (tid == 0) *out.n_groups = (uint32_t)nf;
+}
+
+// ------------------------------------------------------------------ aggregate result AoS -> SoA
+__global__ void __launch_bounds__(BLOCK) k_agg_emit(const AggOut raw, const int n_keys, const int n_accs, const uint32_t ng, const AggSoA soa) {
+  const int kstride = n_keys > 0 ? n_keys : 1;
+  const uint32_t nwords = (ng + 63) >> 6;
+  for (uint32_t w = blockIdx.x * WAVES + wave_id(); w < nwords; w += gridDim.x * WAVES) {
+    const uint32_t g = (w << 6) + lane_id();
+    const bool active = g < ng;
+    const uint32_t kn = active ? raw.key_nulls[g] : 0u;
+    for (int k = 0; k < n_keys; ++k) {
+      const bool valid = active && !((kn >> k) & 1);
+      if (soa.key_valid[k]) { const u64 m = __ballot(valid); if (lane_id() == 0) soa.key_valid[k][w] = m; }
+      if (active) soa.key_col[k][g] = make_ulonglong2(raw.keys[((size_t)g * kstride + k) * 2], raw.keys[((size_t)g * kstride + k) * 2 + 1]);
+    }
+    for (int a = 0; a < n_accs; ++a)
+      if (active) soa.acc_col[a][g] = make_ulonglong2(raw.cells[((size_t)g * n_accs + a) * 2], raw.cells[((size_t)g * n_accs + a) * 2 + 1]);
+  }
+}
+
+// ------------------------------------------------------------------ packed Utf8 -> Arrow Utf8
+__global__ void __launch_bounds__(BLOCK) k_unpack_lengths(const ulonglong2* __restrict__ packed, const i64 n, int32_t* __restrict__ lens) {
+  for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) lens[i] = (int32_t)(packed[i].x & 0xFF);
+}
+__global__ void __launch_bounds__(BLOCK) k_unpack_bytes(const ulonglong2* __restrict__ packed, const i64 n, const int32_t* __restrict__ offsets,
+                                                        uint8_t* __restrict__ out) {
+  for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    const ulonglong2 v = packed[i];
+    const int len = (int)(v.x & 0xFF);
+    uint8_t* p = out + offsets[i];
+    for (int k = 0; k < len && k < 15; ++k) p[k] = (uint8_t)(k < 8 ? (v.y >> (56 - 8 * k)) : (v.x >> (56 - 8 * (k - 8))));
+  }
+}
+
+// Exclusive scan of int32 lengths into offsets (n+1 entries, in place): three-kernel
+// reduce / scan-of-tiles / downsweep over tiles of 2048 elements.
+constexpr int SCAN_TILE = 2048;
+__global__ void __launch_bounds__(BLOCK) k_scan_tile_sums(const int32_t* __restrict__ d, const i64 n, u64* __restrict__ tile_sums) {
+  __shared__ u64 ws[WAVES];
+  const i64 base = (i64)blockIdx.x * SCAN_TILE;
+  u64 s = 0;
+  for (int k = threadIdx.x; k < SCAN_TILE; k += BLOCK) if (base + k < n) s += (u64)(uint32_t)d[base + k];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane_id() == 0) ws[wave_id()] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { u64 t = 0; for (int k = 0; k < WAVES; ++k) t += ws[k]; tile_sums[blockIdx.x] = t; }
+}
+__global__ void __launch_bounds__(1024) k_scan_tiles_serial(u64* __restrict__ tile_sums, const i64 ntiles) {
+  // one block; thread-strided sequential chunks then a serial fix-up over <=1024 partials
+  __shared__ u64 part[1024];
+  const int t = threadIdx.x;
+  const i64 per = (ntiles + 1023) / 1024;
+  const i64 a = (i64)t * per; i64 b = a + per; if (b > ntiles) b = ntiles;
+  u64 s = 0; for (i64 i = a; i < b; ++i) s += tile_sums[i];
+  part[t] = s; __syncthreads();
+  if (t == 0) { u64 run = 0; for (int k = 0; k < 1024; ++k) { const u64 v = part[k]; part[k] = run; run += v; } }
+  __syncthreads();
+  u64 run = part[t];
+  for (i64 i = a; i < b; ++i) { const u64 v = tile_sums[i]; tile_sums[i] = run; run += v; }
+}
+__global__ void __launch_bounds__(BLOCK) k_scan_downsweep(int32_t* __restrict__ d, const i64 n, const u64* __restrict__ tile_offsets) {
+  __shared__ u64 ws[WAVES];
+  const i64 base = (i64)blockIdx.x * SCAN_TILE;
+  constexpr int PER = SCAN_TILE / BLOCK;   // consecutive items per thread
+  int32_t v[PER]; u64 local = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { const i64 i = base + (i64)threadIdx.x * PER + k; v[k] = (i < n) ? d[i] : 0; local += (u64)(uint32_t)v[k]; }
+  u64 x = local;
+  for (int off = 1; off < 64; off <<= 1) { const u64 y = __shfl_up(x, off); if (lane_id() >= off) x += y; }
+  if (lane_id() == 63) ws[wave_id()] = x;
+  __syncthreads();
+  u64 wbase = 0; for (int k = 0; k < wave_id(); ++k) wbase += ws[k];
+  u64 run = tile_offsets[blockIdx.x] + wbase + x - local;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { const i64 i = base + (i64)threadIdx.x * PER + k; if (i <= n) { if (i < n) d[i] = (int32_t)run; else d[i] = (int32_t)run; } run += (u64)(uint32_t)v[k]; }
+}
+
+// ------------------------------------------------------------------ launchers
+static int g_num_cus = 256;
+void set_num_cus(int n) { if (n > 0) g_num_cus = n; }
+int num_cus() { return g_num_cus; }
+
+static int grid_for(i64 n, int blocks_per_cu) {
+  const i64 nwords = (n + 63) >> 6;
+  i64 need = (nwords + WAVES - 1) / WAVES;
+  i64 cap = (i64)g_num_cus * blocks_per_cu;
+  if (need < 1) need = 1;
+  return (int)(need < cap ? need : cap);
+}
+
+void launch_filter_bitmap(hipStream_t s, const DevProgram& P, i64 n, u64* bitmap, uint32_t* block_counts, int nblocks, i64 wpb) {
+  hipLaunchKernelGGL(k_filter_bitmap, dim3(nblocks), dim3(BLOCK), 0, s, P, n, bitmap, block_counts, wpb);
+}
+void launch_scan_block_counts(hipStream_t s, uint32_t* block_counts, int nblocks, u64* total_out) {
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total_out);
+}
+void launch_compact(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 wpb, i64 n,
+                    const uint32_t* sel_in, uint32_t* sel_out) {
+  hipLaunchKernelGGL(k_compact, dim3(nblocks), dim3(BLOCK), 0, s, bitmap, block_offsets, wpb, n, sel_in, sel_out);
+}
+void launch_project(hipStream_t s, const DevProgram& P, i64 n, const OutSpec& O) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_project, dim3(grid_for(n, 8)), dim3(BLOCK), 0, s, P, n, O);
+}
+
+// LDS budget: keep one block within 64 KiB so at least two blocks (8 waves) share a CU.
+int agg_tiny_max_groups(int n_accs) {
+  int best = 0;
+  for (int g = 1; g <= 64; ++g) if (tiny_lds_bytes(g, MAX_KEYS, n_accs) <= 150 * 1024) best = g;
+  return best;
+}
+static int tiny_blocks_per_cu(int gmax, int n_keys, int n_accs) {
+  size_t b = tiny_lds_bytes(gmax, n_keys, n_accs);
+  int k = (int)((160 * 1024) / b);
+  if (k < 1) k = 1;
+  if (k > 4) k = 4;
+  return k;
+}
+size_t agg_tiny_workspace_bytes(int gmax, int n_keys, int n_accs, int* nblocks_out) {
+  const int nb = g_num_cus * tiny_blocks_per_cu(gmax, n_keys, n_accs);
+  if (nblocks_out) *nblocks_out = nb;
+  return (size_t)nb * ((tiny_partial_bytes(gmax, n_keys, n_accs) + 15) & ~(size_t)15);
+}
+void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace, const AggOut& out) {
+  const size_t stride = (tiny_partial_bytes(gmax, A.n_keys, A.n_accs) + 15) & ~(size_t)15;
+  int nb_cap = g_num_cus * tiny_blocks_per_cu(gmax, A.n_keys, A.n_accs);
+  int nb = grid_for(n, 64);
+  if (nb > nb_cap) nb = nb_cap;
+  const size_t lds = tiny_lds_bytes(gmax, A.n_keys, A.n_accs);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_agg_tiny, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_agg_tiny_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_agg_tiny, dim3(nb), dim3(BLOCK), lds, s, P, n, A, gmax, (char*)workspace, stride);
+  const int kstride = A.n_keys > 0 ? A.n_keys : 1;
+  const size_t mlds = (size_t)out.cap * kstride * 16 + (size_t)out.cap * 4 + (((size_t)nb * gmax * 2 + 15) & ~(size_t)15) + 16;
+  hipLaunchKernelGGL(k_agg_tiny_merge, dim3(1), dim3(BLOCK), mlds, s, A, gmax, (const char*)workspace, stride, nb, out, P.flags);
+}
+
+void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa) {
+  if (n_groups == 0) return;
+  const uint32_t nwords = (n_groups + 63) >> 6;
+  uint32_t grid = (nwords + WAVES - 1) / WAVES; if (grid > (uint32_t)g_num_cus * 8) grid = g_num_cus * 8;
+  hipLaunchKernelGGL(k_agg_emit, dim3(grid), dim3(BLOCK), 0, s, raw, n_keys, n_accs, n_groups, soa);
+}
+static int lin_grid(i64 n) { i64 need = (n + BLOCK - 1) / BLOCK; if (need < 1) need = 1; const i64 cap = (i64)g_num_cus * 16; return (int)(need < cap ? need : cap); }
+void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out) {
+  if (n > 0) hipLaunchKernelGGL(k_unpack_lengths, dim3(lin_grid(n)), dim3(BLOCK), 0, s, packed, n, lens_out);
+}
+void launch_unpack_utf8_bytes(hipStream_t s, const ulonglong2* packed, i64 n, const int32_t* offsets, uint8_t* data_out) {
+  if (n > 0) hipLaunchKernelGGL(k_unpack_bytes, dim3(lin_grid(n)), dim3(BLOCK), 0, s, packed, n, offsets, data_out);
+}
+size_t exclusive_scan_ws_bytes(i64 n) { return (size_t)((n + 1 + SCAN_TILE - 1) / SCAN_TILE + 1) * 8; }
+void launch_exclusive_scan_i32(hipStream_t s, int32_t* data, i64 n, void* workspace, size_t) {
+  // data holds n lengths (entry n is scratch); afterwards data[0..n] are the offsets
+  const i64 ntiles = (n + 1 + SCAN_TILE - 1) / SCAN_TILE;
+  u64* tiles = (u64*)workspace;
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(BLOCK), 0, s, (const int32_t*)data, n, tiles);
+  hipLaunchKernelGGL(k_scan_tiles_serial, dim3(1), dim3(1024), 0, s, tiles, ntiles);
+  hipLaunchKernelGGL(k_scan_downsweep, dim3((unsigned)ntiles), dim3(BLOCK), 0, s, data, n, (const u64*)tiles);
+}
+
+}  // namespace gpuq

@@ -1,0 +1,663 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Class and argument names follow DataFusion's ExecutionPlan implementations as Ballista names them
+(ballista/core/src/physical_optimizer/task_group.rs:23-31, ballista/core/src/utils.rs:40-48) and
+the stage driver of ballista/core/src/execution_plans/shuffle_writer.rs:234-456 /
+ballista/executor/src/execution_engine.rs:34-133, so that a test written against the reference
+reads the same here.  `execute(partition, context)` returns the partition's whole result as a
+DeviceTable (possibly a late-materialised view): on a 288 GB HBM device a task's partition is
+processed as whole columns by chip-filling launches, not as a stream of 8192-row batches.
+
+All operator work is done by libgpuq.so; this file only plans launches (operator fusion by
+expression inlining, index-vector composition, output allocation).
+"""
+import ctypes as C
+import json
+import os
+import time
+import uuid
+
+from . import binding as B
+from . import expr as E
+from .table import DeviceColumn, DeviceTable, type_id, type_json, type_width
+
+NULL_ROW = 0xFFFFFFFF
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class TaskContext:
+    """Mirror of datafusion::execution::TaskContext for this engine: device context, op cache, config."""
+
+    def __init__(self, ctx=None, device=0, batch_size=8192, task_id="task", session_id="session"):
+        self.ctx = ctx if ctx is not None else B.Context(device)
+        self.device = "cuda:%d" % self.ctx.device
+        self.batch_size = batch_size
+        self.task_id, self.session_id = task_id, session_id
+        self._ops = {}
+
+    def op(self, descriptor):
+        key = json.dumps(descriptor, sort_keys=True)
+        o = self._ops.get(key)
+        if o is None:
+            o = B.Op(self.ctx, descriptor)
+            self._ops[key] = o
+        return o
+
+    def stream_ptr(self):
+        torch = _torch()
+        return C.c_void_p(torch.cuda.current_stream(self.ctx.device).cuda_stream)
+
+    def sync(self):
+        _torch().cuda.current_stream(self.ctx.device).synchronize()
+
+
+class Metrics:
+    def __init__(self):
+        self.output_rows = 0
+        self.elapsed_compute_ns = 0
+        self.extra = {}
+
+    def as_dict(self):
+        d = {"output_rows": self.output_rows, "elapsed_compute": self.elapsed_compute_ns}
+        d.update(self.extra)
+        return d
+
+
+# ---------------------------------------------------------------------------------- helpers
+def _alloc_outputs(op, n, device):
+    """Allocate caller-side output columns for op.fields with capacity n rows."""
+    torch = _torch()
+    cols, arr = [], (B.gpuq_column * max(1, len(op.fields)))()
+    for i, f in enumerate(op.fields):
+        tj = type_json(f["type"], f["precision"], f["scale"])
+        if f["type"] == B.T_BOOL:
+            data = torch.zeros(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=device)
+        else:
+            data = torch.empty(max(1, n) * f["width"] + 16, dtype=torch.uint8, device=device)
+        validity = torch.zeros(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=device) if f["nullable"] else None
+        col = DeviceColumn(f["name"], tj, data, n, validity=validity, nullable=f["nullable"], repr=f["repr"])
+        cols.append(col)
+        arr[i] = col.to_c()
+    return cols, arr
+
+
+def _project(tc, table, exprs, names):
+    """ProjectionExec kernel call: evaluate `exprs` over (a view of) `table` into a materialised table."""
+    schema = table.schema()
+    desc = {"op": "project", "input": {"fields": schema},
+            "exprs": [{"expr": E.rebind(e, schema), "name": n} for e, n in zip(exprs, names)]}
+    op = tc.op(desc)
+    n = table.num_rows
+    cols, arr = _alloc_outputs(op, n, tc.device)
+    inp, keep = table.input_struct()
+    tc.ctx.check(tc.ctx.L.gpuq_project_run(op.h, tc.stream_ptr(), C.byref(inp), arr, len(cols)))
+    return DeviceTable(cols, n)
+
+
+def _take_u32(tc, vec, idx, n):
+    """new[j] = vec[idx[j]] with NULL_ROW propagated; vec/idx are int32-typed uint32 tensors."""
+    src = DeviceTable([DeviceColumn("v", "UInt32", vec, vec.numel())], n, via=[idx], sides=[1])
+    e = E.case([(E.is_null(E.col("v", index=0)), E.lit(NULL_ROW, "UInt32"))], E.col("v", index=0))
+    out = _project(tc, src, [e], ["v"])
+    return out.columns[0].data[: max(1, n) * 4].view(_torch().int32)[:n]
+
+
+def _select_view(tc, table, idx, n):
+    """View of `table` at driving positions idx[0..n)."""
+    if not table.is_view():
+        return DeviceTable(table.columns, n, via=[idx], sides=[1] * len(table.columns))
+    new_via = [_take_u32(tc, v, idx, n) for v in table.via]
+    return DeviceTable(table.columns, n, via=new_via, sides=table.sides)
+
+
+def materialize(tc, table):
+    if not table.is_view():
+        return table
+    sch = table.plain_schema()
+    return _project(tc, table, [E.col(f["name"], index=i) for i, f in enumerate(sch)], [f["name"] for f in sch])
+
+
+def _fuse(plan):
+    """Walk down through Filter / Projection / CoalesceBatches: returns (source_plan, predicate, colmap).
+    colmap maps an output column name of `plan` to an expression over source columns (None = identity)."""
+    if isinstance(plan, CoalesceBatchesExec):
+        return _fuse(plan.input)
+    if isinstance(plan, FilterExec):
+        src, p, m = _fuse(plan.input)
+        mine = E.inline_projection(plan.predicate, m) if m else plan.predicate
+        return src, (E.and_(p, mine) if p is not None else mine), m
+    if isinstance(plan, ProjectionExec):
+        src, p, m = _fuse(plan.input)
+        new = {name: (E.inline_projection(e, m) if m else e) for e, name in plan.expr}
+        return src, p, new
+    return plan, None, None
+
+
+def _inl(e, m):
+    return E.inline_projection(e, m) if m else e
+
+
+# ---------------------------------------------------------------------------------- plan nodes
+class ExecutionPlan:
+    def __init__(self):
+        self.metrics = Metrics()
+
+    def children(self):
+        return []
+
+    def schema(self):
+        raise NotImplementedError
+
+    def output_partition_count(self):
+        ch = self.children()
+        return ch[0].output_partition_count() if ch else 1
+
+    def execute(self, partition, context):
+        raise NotImplementedError
+
+    def _timed(self, t0, table):
+        self.metrics.elapsed_compute_ns += int((time.perf_counter() - t0) * 1e9)
+        self.metrics.output_rows += table.num_rows
+        return table
+
+    def __str__(self):
+        return type(self).__name__
+
+
+class MemoryExec(ExecutionPlan):
+    """datafusion MemoryExec: partitions of pyarrow RecordBatches/Tables (uploaded on first use) or DeviceTables."""
+
+    def __init__(self, partitions, schema=None):
+        super().__init__()
+        self.partitions = list(partitions)
+        self._dev = {}
+        self._schema = schema
+
+    def output_partition_count(self):
+        return len(self.partitions)
+
+    def schema(self):
+        if self._schema is None:
+            p = self.partitions[0]
+            if isinstance(p, DeviceTable):
+                self._schema = p.plain_schema()
+            else:
+                import pyarrow as pa
+                t = pa.Table.from_batches(p) if isinstance(p, (list, tuple)) else p
+                self._schema = _arrow_schema(t.schema)
+        return self._schema
+
+    def execute(self, partition, context):
+        t0 = time.perf_counter()
+        p = self.partitions[partition]
+        if isinstance(p, DeviceTable):
+            return self._timed(t0, p)
+        if partition not in self._dev:
+            import pyarrow as pa
+            t = pa.Table.from_batches(p) if isinstance(p, (list, tuple)) else p
+            self._dev[partition] = DeviceTable.from_arrow(t, context.device)
+        return self._timed(t0, self._dev[partition])
+
+
+def _arrow_schema(s):
+    import pyarrow as pa
+    out = []
+    for f in s:
+        t = f.type
+        if pa.types.is_decimal128(t):
+            tj = {"Decimal128": [t.precision, t.scale]}
+        else:
+            tj = {pa.int32(): "Int32", pa.int64(): "Int64", pa.date32(): "Date32", pa.float64(): "Float64", pa.string(): "Utf8",
+                  pa.large_string(): "Utf8", pa.bool_(): "Boolean", pa.uint32(): "UInt32", pa.uint64(): "UInt64", pa.binary(): "Utf8"}[t]
+        out.append({"name": f.name, "type": tj, "nullable": f.nullable})
+    return out
+
+
+class CoalesceBatchesExec(ExecutionPlan):
+    """Pass-through: the device engine already works on whole partitions (datafusion.proto:1487-1490)."""
+
+    def __init__(self, input, target_batch_size=8192):
+        super().__init__()
+        self.input, self.target_batch_size = input, target_batch_size
+
+    def children(self):
+        return [self.input]
+
+    def schema(self):
+        return self.input.schema()
+
+    def execute(self, partition, context):
+        return self.input.execute(partition, context)
+
+
+class FilterExec(ExecutionPlan):
+    """FilterExec(predicate, input) -- datafusion.proto:1291-1294.  Returns a selection view in input order."""
+
+    def __init__(self, predicate, input):
+        super().__init__()
+        self.predicate, self.input = predicate, input
+
+    def children(self):
+        return [self.input]
+
+    def schema(self):
+        return self.input.schema()
+
+    def execute(self, partition, context):
+        table = self.input.execute(partition, context)
+        t0 = time.perf_counter()
+        return self._timed(t0, filter_table(context, table, self.predicate))
+
+
+def filter_table(tc, table, predicate):
+    torch = _torch()
+    schema = table.schema()
+    op = tc.op({"op": "filter", "input": {"fields": schema}, "predicate": E.rebind(predicate, schema)})
+    n = table.num_rows
+    sel = torch.empty(max(1, n), dtype=torch.int32, device=tc.device)
+    cnt = torch.zeros(2, dtype=torch.int64, device=tc.device)
+    inp, keep = table.input_struct()
+    tc.ctx.check(tc.ctx.L.gpuq_filter_run(op.h, tc.stream_ptr(), C.byref(inp), 0, sel.data_ptr(), cnt.data_ptr()))
+    k = int(cnt[0].item())
+    op.check(tc.stream_ptr())
+    return _select_view(tc, table, sel[:k], k)
+
+
+class ProjectionExec(ExecutionPlan):
+    """ProjectionExec(expr: [(PhysicalExpr, name)], input) -- datafusion.proto:1399-1403."""
+
+    def __init__(self, expr, input):
+        super().__init__()
+        self.expr, self.input = list(expr), input
+
+    def children(self):
+        return [self.input]
+
+    def schema(self):
+        d = B.compile_check({"op": "project", "input": {"fields": self.input.schema()},
+                             "exprs": [{"expr": E.rebind(e, self.input.schema()), "name": n} for e, n in self.expr]})
+        return [_field_from_desc(o) for o in d["outputs"]]
+
+    def execute(self, partition, context):
+        src, pred, m = _fuse(self)
+        table = src.execute(partition, context)
+        t0 = time.perf_counter()
+        if pred is not None:
+            table = filter_table(context, table, pred)
+        out = _project(context, table, [m[name] for _, name in self.expr], [name for _, name in self.expr])
+        return self._timed(t0, out)
+
+
+def _field_from_desc(o):
+    t = o["type"]
+    if t.startswith("Decimal128("):
+        p, s = t[len("Decimal128("):-1].split(",")
+        t = {"Decimal128": [int(p), int(s)]}
+    return {"name": o["name"], "type": t, "nullable": bool(o["nullable"])}
+
+
+class AggregateExec(ExecutionPlan):
+    """AggregateExec(mode, group_expr, aggr_expr, input) -- datafusion.proto:1405-1450.
+    group_expr: [(expr, name)];  aggr_expr: [{"fn": "SUM"|"AVG"|"COUNT"|"MIN"|"MAX", "expr": e, "name": n}].
+    Modes: Partial (emits state columns), Final / FinalPartitioned (merge states), Single."""
+
+    def __init__(self, mode, group_expr, aggr_expr, input, strategy="auto", expected_groups=0):
+        super().__init__()
+        self.mode, self.group_expr, self.aggr_expr, self.input = mode, list(group_expr), list(aggr_expr), input
+        self.strategy, self.expected_groups = strategy, expected_groups
+
+    def children(self):
+        return [self.input]
+
+    def _descriptor(self, schema, pred, m):
+        d = {"op": "aggregate", "mode": self.mode, "input": {"fields": schema}, "strategy": self.strategy,
+             "group_expr": [{"expr": E.rebind(_inl(e, m), schema), "name": n} for e, n in self.group_expr],
+             "aggr_expr": [dict(fn=a["fn"], name=a["name"], **({"expr": E.rebind(_inl(a["expr"], m), schema)} if a.get("expr") is not None else {}))
+                           for a in self.aggr_expr]}
+        if pred is not None:
+            d["predicate"] = E.rebind(pred, schema)
+        if self.expected_groups:
+            d["expected_groups"] = int(self.expected_groups)
+        return d
+
+    def schema(self):
+        d = B.compile_check(self._descriptor(self.input.schema(), None, None))
+        return [_field_from_desc(o) for o in d["outputs"]]
+
+    def execute(self, partition, context):
+        final = self.mode in ("Final", "FinalPartitioned")
+        src, pred, m = (self.input, None, None) if final else _fuse(self.input)
+        table = src.execute(partition, context)
+        t0 = time.perf_counter()
+        out = aggregate_table(context, table, self._descriptor(table.schema(), pred, m))
+        return self._timed(t0, out)
+
+
+def aggregate_table(tc, table, descriptor, cap=None):
+    op = tc.op(descriptor)
+    n = table.num_rows
+    if cap is None:
+        cap = 4096 if not descriptor["group_expr"] else max(4096, min(n, 1 << 22))
+    inp, keep = table.input_struct()
+    while True:
+        cols, arr = _alloc_outputs(op, cap, tc.device)
+        ng = C.c_int64(0)
+        rc = tc.ctx.L.gpuq_aggregate_run(op.h, tc.stream_ptr(), C.byref(inp), arr, len(cols), cap, C.byref(ng))
+        if rc == 4 and ng.value > cap:
+            cap = int(ng.value)
+            continue
+        tc.ctx.check(rc)
+        break
+    for c in cols:
+        c.length = ng.value
+    return DeviceTable(cols, ng.value)
+
+
+class HashJoinExec(ExecutionPlan):
+    """HashJoinExec(left, right, on: [(left_col, right_col)], filter, join_type, partition_mode, null_equals_null)
+    -- ctor surface of ballista/core/src/physical_optimizer/task_group.rs:306-315, datafusion.proto:1346-1360.
+    The LEFT input is the build side.  Output columns = left columns then right columns (a view)."""
+
+    def __init__(self, left, right, on, filter=None, join_type="Inner", partition_mode="CollectLeft", null_equals_null=False):
+        super().__init__()
+        self.left, self.right, self.on, self.filter = left, right, list(on), filter
+        self.join_type, self.partition_mode, self.null_equals_null = join_type, partition_mode, null_equals_null
+
+    def children(self):
+        return [self.left, self.right]
+
+    def output_partition_count(self):
+        return self.right.output_partition_count()
+
+    def schema(self):
+        ls, rs = self.left.schema(), self.right.schema()
+        jt = self.join_type
+        if jt in ("LeftSemi", "LeftAnti"):
+            return ls
+        if jt in ("RightSemi", "RightAnti"):
+            return rs
+        ln = jt in ("Right", "Full")
+        rn = jt in ("Left", "Full")
+        return [dict(f, nullable=f["nullable"] or ln) for f in ls] + [dict(f, nullable=f["nullable"] or rn) for f in rs]
+
+    def _side(self, plan, partition, context, key_exprs):
+        src, pred, m = _fuse(plan)
+        if m is not None:
+            # computed projection below the join: execute it (materialised) and do not fuse
+            table = plan.execute(partition, context)
+            return table, None, key_exprs
+        table = src.execute(partition, context)
+        return table, pred, key_exprs
+
+    def execute(self, partition, context):
+        torch = _torch()
+        tc = context
+        jt = self.join_type
+        lkeys = [l for l, _ in self.on]
+        rkeys = [r for _, r in self.on]
+        # CollectLeft: every probe partition sees the whole build side; Partitioned: co-partitioned inputs
+        lpart = partition if self.partition_mode == "Partitioned" else None
+        if lpart is None:
+            cache = getattr(self, "_build_cache", None)
+            if cache is None:
+                parts = [self._side(self.left, p, tc, lkeys) for p in range(self.left.output_partition_count())]
+                if len(parts) != 1:
+                    raise B.GpuqError(3, "CollectLeft with a multi-partition build side: wrap the left input in a single partition")
+                cache = self._build_cache = parts[0]
+            ltab, lpred, _ = cache
+        else:
+            ltab, lpred, _ = self._side(self.left, lpart, tc, lkeys)
+        rtab, rpred, _ = self._side(self.right, partition, tc, rkeys)
+        t0 = time.perf_counter()
+        lschema, rschema = ltab.schema(), rtab.schema()
+        bdesc = {"op": "join_build", "input": {"fields": lschema}, "on": [E.rebind(k, lschema) for k in lkeys],
+                 "null_equals_null": bool(self.null_equals_null)}
+        if lpred is not None:
+            bdesc["predicate"] = E.rebind(lpred, lschema)
+        pdesc = {"op": "join_probe", "input": {"fields": rschema}, "on": [E.rebind(k, rschema) for k in rkeys],
+                 "join_type": jt, "null_equals_null": bool(self.null_equals_null)}
+        if rpred is not None:
+            pdesc["predicate"] = E.rebind(rpred, rschema)
+        bop, pop = tc.op(bdesc), tc.op(pdesc)
+        linp, lk = ltab.input_struct()
+        h = C.c_void_p()
+        tc.ctx.check(tc.ctx.L.gpuq_join_build_run(bop.h, tc.stream_ptr(), C.byref(linp), 0, ltab.num_rows, C.byref(h)))
+        jtab = B.JoinTable(tc.ctx, h)
+        try:
+            rinp, rk = rtab.input_struct()
+            nprobe = rtab.num_rows
+            cap = max(1, nprobe) + (ltab.num_rows if jt in ("Left", "Full") else 0)
+            cnt = torch.zeros(2, dtype=torch.int64, device=tc.device)
+            while True:
+                ob = torch.empty(cap, dtype=torch.int32, device=tc.device)
+                opb = torch.empty(cap, dtype=torch.int32, device=tc.device)
+                tc.ctx.check(tc.ctx.L.gpuq_join_probe_run(pop.h, tc.stream_ptr(), jtab.h, C.byref(rinp), 0, ob.data_ptr(), opb.data_ptr(),
+                                                          cap - (ltab.num_rows if jt in ("Left", "Full") else 0), cnt.data_ptr()))
+                k = int(cnt[0].item())
+                try:
+                    pop.check(tc.stream_ptr())
+                    break
+                except B.GpuqError as e:
+                    if e.status != 4:
+                        raise
+                    cap = k + (ltab.num_rows if jt in ("Left", "Full") else 0) + 1
+            if jt in ("LeftSemi", "LeftAnti", "Left", "Full"):
+                extra = torch.zeros(2, dtype=torch.int64, device=tc.device)
+                if jt in ("LeftSemi", "LeftAnti"):
+                    rows = torch.empty(max(1, ltab.num_rows), dtype=torch.int32, device=tc.device)
+                    tc.ctx.check(tc.ctx.L.gpuq_join_build_side_rows(jtab.h, tc.stream_ptr(), 1 if jt == "LeftSemi" else 0, rows.data_ptr(), extra.data_ptr()))
+                    m = int(extra[0].item())
+                    out = _select_view(tc, ltab, rows[:m], m)
+                    return self._timed(t0, out)
+                tc.ctx.check(tc.ctx.L.gpuq_join_build_side_rows(jtab.h, tc.stream_ptr(), 0, ob.data_ptr() + 4 * k, extra.data_ptr()))
+                m = int(extra[0].item())
+                opb[k:k + m] = -1       # NULL_ROW on the probe side
+                k += m
+            if jt in ("RightSemi", "RightAnti"):
+                return self._timed(t0, _select_view(tc, rtab, opb[:k], k))
+            out = _join_view(tc, ltab, rtab, ob[:k], opb[:k], k)
+            if self.filter is not None:
+                if jt != "Inner":
+                    raise B.GpuqError(3, "JoinFilter on a non-inner join is not supported on device yet")
+                out = filter_table(tc, out, self.filter)
+            return self._timed(t0, out)
+        finally:
+            jtab.close()
+
+
+def _join_view(tc, ltab, rtab, ob, opb, k):
+    lv = [ob] if not ltab.is_view() else [_take_u32(tc, v, ob, k) for v in ltab.via]
+    rv = [opb] if not rtab.is_view() else [_take_u32(tc, v, opb, k) for v in rtab.via]
+    if len(lv) + len(rv) > 3:
+        # too many index vectors: materialise the wider side
+        if len(lv) >= len(rv):
+            ltab = materialize(tc, DeviceTable(ltab.columns, k, via=lv, sides=ltab.sides if ltab.is_view() else [1] * len(ltab.columns)))
+            lv = []
+            lsides = [0] * len(ltab.columns)
+            rsides = [(s if rtab.is_view() else 1) for s in (rtab.sides if rtab.is_view() else [1] * len(rtab.columns))]
+            return DeviceTable(ltab.columns + rtab.columns, k, via=rv, sides=lsides + rsides)
+        rtab = materialize(tc, DeviceTable(rtab.columns, k, via=rv, sides=rtab.sides if rtab.is_view() else [1] * len(rtab.columns)))
+        lsides = ltab.sides if ltab.is_view() else [1] * len(ltab.columns)
+        return DeviceTable(ltab.columns + rtab.columns, k, via=lv, sides=lsides + [0] * len(rtab.columns))
+    lsides = ltab.sides if ltab.is_view() else [1] * len(ltab.columns)
+    rbase = len(lv)
+    rsides = [s + rbase for s in (rtab.sides if rtab.is_view() else [1] * len(rtab.columns))]
+    return DeviceTable(ltab.columns + rtab.columns, k, via=lv + rv, sides=list(lsides) + rsides)
+
+
+class SortExec(ExecutionPlan):
+    """SortExec(expr: [{"expr", "asc", "nulls_first"}], input, fetch) -- datafusion.proto:1465-1471, :1247-1251."""
+
+    def __init__(self, expr, input, fetch=None, preserve_partitioning=False):
+        super().__init__()
+        self.expr, self.input, self.fetch, self.preserve_partitioning = list(expr), input, fetch, preserve_partitioning
+
+    def children(self):
+        return [self.input]
+
+    def schema(self):
+        return self.input.schema()
+
+    def execute(self, partition, context):
+        torch = _torch()
+        table = self.input.execute(partition, context)
+        t0 = time.perf_counter()
+        schema = table.schema()
+        desc = {"op": "sort", "input": {"fields": schema},
+                "expr": [{"expr": E.rebind(s["expr"], schema), "asc": bool(s.get("asc", True)),
+                          "nulls_first": bool(s.get("nulls_first", not s.get("asc", True)))} for s in self.expr]}
+        op = context.op(desc)
+        n = table.num_rows
+        perm = torch.empty(max(1, n), dtype=torch.int32, device=context.device)
+        inp, keep = table.input_struct()
+        context.ctx.check(context.ctx.L.gpuq_sort_run(op.h, context.stream_ptr(), C.byref(inp), perm.data_ptr()))
+        k = n if self.fetch is None or self.fetch < 0 else min(n, int(self.fetch))
+        return self._timed(t0, _select_view(context, table, perm[:k], k))
+
+
+class RepartitionExec(ExecutionPlan):
+    """Hash repartition of ONE input partition into n outputs (BatchPartitioner call site,
+    shuffle_writer.rs:336-391).  execute_all(partition) returns the n per-partition views."""
+
+    def __init__(self, input, hash_expr, partition_count):
+        super().__init__()
+        self.input, self.hash_expr, self.partition_count = input, list(hash_expr), int(partition_count)
+
+    def children(self):
+        return [self.input]
+
+    def schema(self):
+        return self.input.schema()
+
+    def execute_all(self, partition, context):
+        table = self.input.execute(partition, context)
+        t0 = time.perf_counter()
+        outs = partition_table(context, table, self.hash_expr, self.partition_count)
+        self.metrics.elapsed_compute_ns += int((time.perf_counter() - t0) * 1e9)
+        self.metrics.output_rows += table.num_rows
+        return outs
+
+
+def partition_table(tc, table, hash_expr, partition_count):
+    torch = _torch()
+    schema = table.schema()
+    op = tc.op({"op": "partition", "input": {"fields": schema}, "hash_expr": [E.rebind(e, schema) for e in hash_expr],
+                "partition_count": int(partition_count)})
+    n = table.num_rows
+    perm = torch.empty(max(1, n), dtype=torch.int32, device=tc.device)
+    offs = torch.zeros(partition_count + 2, dtype=torch.int64, device=tc.device)
+    inp, keep = table.input_struct()
+    tc.ctx.check(tc.ctx.L.gpuq_partition_run(op.h, tc.stream_ptr(), C.byref(inp), perm.data_ptr(), offs.data_ptr()))
+    o = offs.cpu().tolist()
+    return [_select_view(tc, table, perm[o[p]:o[p + 1]], o[p + 1] - o[p]) for p in range(partition_count)]
+
+
+class ShuffleWritePartition(dict):
+    """Stats record of shuffle_writer.rs:410-420 (partition_id, path, num_batches, num_rows, num_bytes)."""
+
+
+class ShuffleWriterExec(ExecutionPlan):
+    """Stage driver: ShuffleWriterExec(job_id, stage_id, plan, work_dir, shuffle_output_partitioning)
+    -- ballista/core/src/execution_plans/shuffle_writer.rs:234-456.  Output files are Arrow IPC
+    streams with LZ4_FRAME bodies in the reference's path layout (Appendix B.6 of SURVEY.md), so
+    unchanged ShuffleReaderExec / Flight peers can consume them."""
+
+    def __init__(self, job_id, stage_id, plan, work_dir, shuffle_output_partitioning=None, partitions=None):
+        super().__init__()
+        self.job_id, self.stage_id, self.plan, self.work_dir = job_id, stage_id, plan, work_dir
+        self.shuffle_output_partitioning = shuffle_output_partitioning   # None or (hash_exprs, n)
+        self.partitions = partitions
+
+    def children(self):
+        return [self.plan]
+
+    def schema(self):
+        return self.plan.schema()
+
+    def execute_shuffle_write(self, input_partitions, context):
+        import pyarrow as pa
+        t0 = time.perf_counter()
+        parts = list(input_partitions) if input_partitions is not None else (self.partitions or range(self.plan.output_partition_count()))
+        out = []
+        opts = pa.ipc.IpcWriteOptions(compression="lz4")
+        for p in parts:
+            table = self.plan.execute(p, context)
+            base = os.path.join(self.work_dir, self.job_id, str(self.stage_id))
+            if self.shuffle_output_partitioning is None:
+                path = os.path.join(base, str(uuid.uuid4()), "data.arrow")
+                host = materialize(context, table).to_arrow(context.ctx)
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                nb = 0
+                with pa.OSFile(path, "wb") as f, pa.ipc.new_stream(f, host.schema, options=opts) as w:
+                    for b in host.to_batches(max_chunksize=context.batch_size):
+                        if b.num_rows:
+                            w.write_batch(b)
+                            nb += 1
+                out.append(ShuffleWritePartition(partition_id=p, path=path, num_batches=nb, num_rows=host.num_rows, num_bytes=host.nbytes))
+            else:
+                exprs, n = self.shuffle_output_partitioning
+                views = partition_table(context, table, exprs, n)
+                for q, v in enumerate(views):
+                    if v.num_rows == 0:
+                        continue    # lazily created writers: empty partitions produce no file (shuffle_writer.rs:329-334)
+                    path = os.path.join(base, str(q), "%s.arrow" % uuid.uuid4())
+                    host = materialize(context, v).to_arrow(context.ctx)
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    nb = 0
+                    with pa.OSFile(path, "wb") as f, pa.ipc.new_stream(f, host.schema, options=opts) as w:
+                        for b in host.to_batches(max_chunksize=context.batch_size):
+                            w.write_batch(b)
+                            nb += 1
+                    out.append(ShuffleWritePartition(partition_id=q, path=path, num_batches=nb, num_rows=host.num_rows,
+                                                     num_bytes=os.path.getsize(path)))
+        self.metrics.elapsed_compute_ns += int((time.perf_counter() - t0) * 1e9)
+        self.metrics.output_rows += sum(o["num_rows"] for o in out)
+        return out
+
+
+class DefaultQueryStageExec:
+    """QueryStageExecutor (execution_engine.rs:49-60, :97-133)."""
+
+    def __init__(self, shuffle_writer):
+        self.shuffle_writer = shuffle_writer
+
+    def execute_query_stage(self, input_partitions, context):
+        return self.shuffle_writer.execute_shuffle_write(input_partitions, context)
+
+    def collect_plan_metrics(self):
+        out = []
+
+        def walk(p):
+            out.append(p.metrics.as_dict())
+            for c in p.children():
+                walk(c)
+        walk(self.shuffle_writer.plan)
+        return out
+
+    def schema(self):
+        return self.shuffle_writer.schema()
+
+    def __str__(self):
+        lines = []
+
+        def walk(p, d):
+            lines.append("  " * d + "%s, metrics=%s" % (p, p.metrics.as_dict()))
+            for c in p.children():
+                walk(c, d + 1)
+        walk(self.shuffle_writer, 0)
+        return "\n".join(lines)
+
+
+class DefaultExecutionEngine:
+    """ExecutionEngine (execution_engine.rs:34-43, :62-95): the plan root must be a ShuffleWriterExec; it is
+    re-created with the executor's work_dir."""
+
+    def create_query_stage_exec(self, job_id, stage_id, plan, work_dir, sender=None):
+        if not isinstance(plan, ShuffleWriterExec):
+            raise B.GpuqError(1, "Plan passed to new_query_stage_exec is not a ShuffleWriterExec")
+        w = ShuffleWriterExec(job_id, stage_id, plan.plan, work_dir, plan.shuffle_output_partitioning, plan.partitions)
+        return DefaultQueryStageExec(w)

@@ -1,0 +1,208 @@
+/*
+ * gpuq.h -- C ABI of libgpuq.so, the MI355X (gfx950) columnar physical-operator engine that stands
+ * behind Ballista's executor as the task runner for the DataFusion hot path
+ * (FilterExec / ProjectionExec / AggregateExec / HashJoinExec / SortExec / hash repartition).
+ *
+ * Drop-in boundary (citations relative to the reference tree, coralogix/arrow-ballista @ 2025-02-02):
+ *   - ballista/executor/src/execution_engine.rs:34-60   ExecutionEngine / QueryStageExecutor traits:
+ *     a GPU engine implements them in Rust and forwards the operator work to the functions below
+ *     (binding shown in INTEGRATION.md).
+ *   - ballista/core/src/execution_plans/shuffle_writer.rs:255,341-392  the per-batch pull loop and
+ *     BatchPartitioner::partition that gpuq_partition_* replaces.
+ *   - DataFusion v34 operators named by ballista/core/src/physical_optimizer/task_group.rs:23-31,
+ *     parameter surface pinned by ballista/core/proto/datafusion.proto:1109-1525.
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, POD structs.  No C++/torch/Arrow-library types.
+ *   - Every function returns a gpuq_status (0 = OK); gpuq_last_error(ctx) gives the UTF-8 message.
+ *     No exception crosses the boundary.
+ *   - All data pointers in gpuq_column / index vectors are DEVICE pointers (HBM) unless a parameter
+ *     says otherwise.  Layouts are Arrow's physical layouts (little-endian values, int32 offsets +
+ *     bytes for Utf8, LSB-first validity bitmaps), so a host that owns Arrow buffers copies them to
+ *     the device byte-for-byte.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls enqueue work on that
+ *     stream; the ones documented as synchronous also wait for it.
+ *   - Handles are freed by exactly one *_free; distinct handles may be used from distinct threads.
+ *   - There is no CPU fallback: without a usable HIP device gpuq_ctx_create fails.
+ */
+#ifndef GPUQ_H
+#define GPUQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPUQ_ABI_VERSION 1
+
+typedef enum gpuq_status {
+  GPUQ_OK = 0,
+  GPUQ_ERR_INVALID = 1,      /* bad argument / malformed descriptor */
+  GPUQ_ERR_HIP = 2,          /* HIP runtime error (message has the hipError) */
+  GPUQ_ERR_UNSUPPORTED = 3,  /* valid request the device path does not implement (fails loudly, never falls back) */
+  GPUQ_ERR_CAPACITY = 4,     /* caller-provided output capacity too small; required size reported */
+  GPUQ_ERR_INTERNAL = 5
+} gpuq_status;
+
+/* Logical types (subset of ballista/core/proto/datafusion.proto:1004-1040 ArrowType). */
+typedef enum gpuq_type {
+  GPUQ_NULL = 0, GPUQ_BOOL = 1, GPUQ_INT32 = 2, GPUQ_INT64 = 3, GPUQ_DATE32 = 4, GPUQ_FLOAT64 = 5,
+  GPUQ_DECIMAL128 = 6, GPUQ_UTF8 = 7, GPUQ_UINT32 = 8, GPUQ_UINT64 = 9
+} gpuq_type;
+
+/* Device representation of an output column. */
+#define GPUQ_REPR_ARROW 0     /* Arrow physical layout */
+#define GPUQ_REPR_PACKED15 1  /* Utf8 of <= 15 bytes as 16-byte value: bytes big-endian in bits 127..8, length in bits 7..0
+                                 (convert with gpuq_unpack_utf8) */
+
+typedef struct gpuq_column {
+  int32_t type;            /* gpuq_type */
+  int32_t precision;       /* Decimal128 */
+  int32_t scale;           /* Decimal128 */
+  int32_t repr;            /* GPUQ_REPR_* (inputs: ARROW) */
+  const void* data;        /* values; Utf8: bytes; Bool: bitmap */
+  const int32_t* offsets;  /* Utf8: length+1 offsets, else NULL */
+  const uint8_t* validity; /* Arrow validity bitmap or NULL (no nulls) */
+  int64_t length;
+} gpuq_column;
+
+typedef struct gpuq_field_info {
+  char name[96];
+  int32_t type, precision, scale, nullable, repr, width; /* width = bytes per row in the fixed-width device layout */
+} gpuq_field_info;
+
+typedef struct gpuq_ctx gpuq_ctx;
+typedef struct gpuq_op gpuq_op;
+typedef struct gpuq_join_table gpuq_join_table;
+
+/* ---- context ----------------------------------------------------------------------------- */
+int gpuq_abi_version(void);
+/* json_opts: NULL or {"device":N}.  Fails (returns NULL) when no HIP device is usable;
+   gpuq_last_error(NULL) then holds the reason. */
+gpuq_ctx* gpuq_ctx_create(int device_ordinal, const char* json_opts);
+void gpuq_ctx_free(gpuq_ctx* ctx);
+const char* gpuq_last_error(gpuq_ctx* ctx);
+int gpuq_ctx_device_info(gpuq_ctx* ctx, char* buf, size_t cap); /* JSON: name, arch, cus, hbm_bytes */
+
+/* ---- compiled operators ------------------------------------------------------------------ */
+/* Descriptor JSON (see INTEGRATION.md for the grammar).  Expression nodes mirror PhysicalExprNode
+   (datafusion.proto:1142-1180): column, literal, binary_expr, cast, try_cast, not_expr, is_null_expr,
+   is_not_null_expr, negative, in_list, case_.  "op" is one of
+     "filter"      FilterExec        {input, predicate}
+     "project"     ProjectionExec    {input, exprs:[{expr,name}]}
+     "aggregate"   AggregateExec     {input, mode:Partial|Final|FinalPartitioned|Single, group_expr:[{expr,name}],
+                                      aggr_expr:[{fn:SUM|AVG|COUNT|MIN|MAX, expr, name}], predicate?, strategy?:auto|tiny|hash}
+     "join_build"  HashJoinExec build (left) side  {input, on:[expr], predicate?, null_equals_null?}
+     "join_probe"  HashJoinExec probe (right) side {input, on:[expr], predicate?, join_type, null_equals_null?}
+     "sort"        SortExec          {input, expr:[{expr, asc, nulls_first}], fetch?}
+     "partition"   BatchPartitioner  {input, hash_expr:[expr], partition_count}
+   "input" = {"fields":[{"name","type","nullable","side"}]}; side k>0 means the column is addressed
+   through index vector k of the call (late materialisation after a filter or join). */
+int gpuq_op_create(gpuq_ctx* ctx, const char* json, gpuq_op** out);
+/* Host-only: compiles the descriptor without a device and writes a JSON description (program
+   listing, output schema) to buf.  Used for plan validation and by the CPU test-suite. */
+int gpuq_compile_check(const char* json, char* buf, size_t cap);
+void gpuq_op_free(gpuq_op* op);
+int gpuq_op_num_outputs(gpuq_op* op);
+int gpuq_op_output_field(gpuq_op* op, int i, gpuq_field_info* out);
+
+/* Input of one operator call: columns in the order of the descriptor's input.fields.
+   n_rows = number of driving positions: the table length, or the length of the index vectors when
+   any are given (every index vector has n_rows entries; 0xFFFFFFFF = no row -> NULLs). */
+typedef struct gpuq_input {
+  const gpuq_column* cols;
+  int32_t n_cols;
+  int32_t n_via;
+  int64_t n_rows;
+  const uint32_t* via[3];
+} gpuq_input;
+
+/* FilterExec.  Writes the passing driving positions (or via[payload_via-1][pos] when payload_via>0),
+   in input order, to sel_out (capacity n_rows) and their number to *count_out (device u64).
+   Asynchronous.  NULL predicate results drop the row. */
+int gpuq_filter_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, uint32_t* sel_out, uint64_t* count_out);
+
+/* ProjectionExec / take: evaluates the expressions for every driving position into caller-allocated
+   fixed-width columns (outs[i].data: n_rows * width bytes; outs[i].validity: ceil(n_rows/64)*8 bytes or
+   NULL).  Asynchronous. */
+int gpuq_project_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs);
+
+/* AggregateExec.  outs: caller-allocated columns of capacity `cap` rows in output-schema order.
+   Synchronous (the group count decides the strategy and the result length); *n_groups_out (host)
+   receives the number of groups.  GPUQ_ERR_CAPACITY when cap is too small. */
+int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs, int64_t cap,
+                       int64_t* n_groups_out);
+
+/* HashJoinExec build side: inserts every passing row; the table keeps, per key, the chain of build
+   row ids (payload = driving position, or via[payload_via-1][pos]).  build_rows_bound = exclusive
+   upper bound of payload values.  Synchronous. */
+int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, int64_t build_rows_bound,
+                        gpuq_join_table** out);
+void gpuq_join_table_free(gpuq_join_table* t);
+/* Probe side.  Emits matching (build_row, probe_row) pairs (probe_row = position or via[..]) into
+   out_build/out_probe (capacity out_cap pairs; out_build may be NULL for RightSemi/RightAnti) and the
+   total pair count into *count_out (device u64).  Join types follow datafusion.proto:280-289; the
+   build side is DataFusion's LEFT input.  For Left/Full/LeftSemi/LeftAnti the build rows reached are
+   marked in the table; fetch them with gpuq_join_build_side_rows.  Asynchronous; call
+   gpuq_op_check afterwards to learn about capacity overflow. */
+int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpuq_input* in, int payload_via,
+                        uint32_t* out_build, uint32_t* out_probe, uint64_t out_cap, uint64_t* count_out);
+/* matched != 0: build rows with >= 1 match (LeftSemi); matched == 0: build rows never matched
+   (Left/Full outer remainder, LeftAnti).  Ordered.  Asynchronous. */
+int gpuq_join_build_side_rows(gpuq_join_table* t, void* stream, int matched, uint32_t* rows_out, uint64_t* count_out);
+
+/* SortExec: writes the permutation (driving positions in sorted order; stable) to perm_out (n_rows).
+   Asynchronous. */
+int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out);
+
+/* Hash repartition (BatchPartitioner::partition call site, shuffle_writer.rs:336-391):
+   perm_out lists driving positions grouped by partition (input order inside a partition),
+   part_offsets_out[p]..[p+1] (device u64, partition_count+1 entries) delimit partition p.
+   partition = mix64-hash(keys) % partition_count -- gpuq's own function (ahash
+   assignment is not a portable contract).  Asynchronous. */
+int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out, uint64_t* part_offsets_out);
+
+/* Waits for `stream`, then reports device-side conditions raised by the op's kernels since the last
+   check (string longer than 15 bytes in a packed comparison, output capacity overflow, ...). */
+int gpuq_op_check(gpuq_op* op, void* stream);
+
+/* Utf8 PACKED15 -> Arrow offsets+bytes.  offsets_out: n+1 int32; data_out capacity data_cap bytes.
+   Synchronous; *data_len_out (host) = bytes written. */
+int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n, int32_t* offsets_out, uint8_t* data_out,
+                     int64_t data_cap, int64_t* data_len_out);
+
+/* ---- synthetic TPC-H-shaped input (bench/test support) ------------------- */
+typedef struct gpuq_lineitem_cols {
+  int64_t* l_orderkey; int64_t* l_suppkey;
+  void* l_quantity; void* l_extendedprice; void* l_discount; void* l_tax; /* Decimal128(15,2), 16 B/row */
+  int32_t* l_shipdate;
+  uint8_t* l_returnflag; int32_t* l_returnflag_off;  /* Utf8: n bytes, n+1 offsets */
+  uint8_t* l_linestatus; int32_t* l_linestatus_off;
+} gpuq_lineitem_cols;
+typedef struct gpuq_orders_cols { int64_t* o_orderkey; int64_t* o_custkey; int32_t* o_orderdate; int32_t* o_shippriority; } gpuq_orders_cols;
+typedef struct gpuq_customer_cols { int64_t* c_custkey; int64_t* c_nationkey; uint8_t* c_mktsegment; int32_t* c_mktsegment_off; } gpuq_customer_cols;
+typedef struct gpuq_supplier_cols { int64_t* s_suppkey; int64_t* s_nationkey; } gpuq_supplier_cols;
+/* Any pointer may be NULL (column skipped).  Rows [row0, row0+n) of the table. */
+int gpuq_gen_lineitem(gpuq_ctx* ctx, void* stream, uint64_t seed, uint64_t seed_orders, int64_t row0, int64_t n, int64_t n_supp,
+                      const gpuq_lineitem_cols* cols);
+int gpuq_gen_orders(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, int64_t n_cust, const gpuq_orders_cols* cols);
+int gpuq_gen_customer(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, const gpuq_customer_cols* cols);
+int gpuq_gen_supplier(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, const gpuq_supplier_cols* cols);
+
+/* ---- timing support for bench.py: HIP events on the caller's stream ---------------------- */
+typedef struct gpuq_timer gpuq_timer;
+int gpuq_timer_create(gpuq_ctx* ctx, gpuq_timer** out);
+int gpuq_timer_start(gpuq_timer* t, void* stream);
+int gpuq_timer_stop(gpuq_timer* t, void* stream);
+int gpuq_timer_elapsed_ms(gpuq_timer* t, float* ms_out); /* synchronises on the stop event */
+void gpuq_timer_free(gpuq_timer* t);
+/* Per-op device time of the last call(s): the op brackets its dominant kernel with HIP events when
+   enabled; returns the accumulated ms and launch count since the last reset. */
+int gpuq_op_profile(gpuq_op* op, int enable, float* kernel_ms_out, int* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUQ_H */
