@@ -21,7 +21,7 @@ class gpuq_column(C.Structure):
 
 
 class gpuq_field_info(C.Structure):
-    _fields_ = [("name", C.c_char * 96), ("type", C.c_int32), ("precision", C.c_int32), ("scale", C.c_int32),
+    _fields_ = [("name", C.c_char * 256), ("type", C.c_int32), ("precision", C.c_int32), ("scale", C.c_int32),
                 ("nullable", C.c_int32), ("repr", C.c_int32), ("width", C.c_int32)]
 
 

@@ -388,30 +388,33 @@ int ExprCompiler::add_output(NodeP e) { outs_.push_back(e); return (int)outs_.si
 
 CompiledProgram ExprCompiler::finish() {
   CompiledProgram C;
-  // use counts over the DAG
+  // OP_MOV only re-types a value (same 128-bit pattern): it aliases its operand's register
+  auto rep = [](Node* n) { while (n->kind == Node::OPN && n->op == OP_MOV) n = n->ch[0].get(); return n; };
+  // use counts over the DAG of representatives
   std::map<Node*, int> uses;
   std::set<Node*> seen;
-  std::function<void(const NodeP&)> visit = [&](const NodeP& n) {
-    uses[n.get()]++;
-    if (seen.count(n.get())) return;
-    seen.insert(n.get());
-    for (auto& c : n->ch) visit(c);
+  std::function<void(Node*)> visit = [&](Node* n0) {
+    Node* n = rep(n0);
+    uses[n]++;
+    if (seen.count(n)) return;
+    seen.insert(n);
+    for (auto& c : n->ch) visit(c.get());
   };
-  if (pred_) { visit(pred_); uses[pred_.get()] += 1000000; }
-  for (auto& o : outs_) { visit(o); uses[o.get()] += 1000000; }
+  if (pred_) { visit(pred_.get()); uses[rep(pred_.get())] += 1000000; }
+  for (auto& o : outs_) { visit(o.get()); uses[rep(o.get())] += 1000000; }
 
-  // columns: slot = register, in first-visit order
   std::map<Node*, int> reg;
   std::vector<Node*> order;
   std::set<Node*> ordered;
-  std::function<void(const NodeP&)> topo = [&](const NodeP& n) {
-    if (ordered.count(n.get())) return;
-    ordered.insert(n.get());
-    for (auto& c : n->ch) topo(c);
-    order.push_back(n.get());
+  std::function<void(Node*)> topo = [&](Node* n0) {
+    Node* n = rep(n0);
+    if (ordered.count(n)) return;
+    ordered.insert(n);
+    for (auto& c : n->ch) topo(c.get());
+    order.push_back(n);
   };
-  if (pred_) topo(pred_);
-  for (auto& o : outs_) topo(o);
+  if (pred_) topo(pred_.get());
+  for (auto& o : outs_) topo(o.get());
   for (Node* n : order) if (n->kind == Node::COL) {
     if ((int)C.col_field.size() >= MAX_COLS) throw std::runtime_error("expression references more than " + std::to_string(MAX_COLS) + " columns");
     reg[n] = (int)C.col_field.size();
@@ -432,7 +435,7 @@ CompiledProgram ExprCompiler::finish() {
     in.op = (uint8_t)op; in.dst = (uint8_t)d; in.a = (uint8_t)a; in.b = (uint8_t)b; in.imm = imm;
   };
   std::map<Node*, int> remaining = uses;
-  auto release = [&](Node* c) { if (--remaining[c] == 0) busy[reg[c]] = false; };
+  auto release = [&](Node* c0) { Node* c = rep(c0); if (--remaining[c] == 0) busy[reg[c]] = false; };
   for (Node* n : order) {
     if (n->kind == Node::COL) continue;
     if (n->kind == Node::LIT) {
@@ -441,18 +444,18 @@ CompiledProgram ExprCompiler::finish() {
       else emit(OP_IMM, d, 0, 0, (uint32_t)imm_index(n->lit_lo, n->lit_hi));
       continue;
     }
-    const int a = n->ch.size() > 0 ? reg.at(n->ch[0].get()) : 0;
-    const int b = n->ch.size() > 1 ? reg.at(n->ch[1].get()) : a;
+    const int a = n->ch.size() > 0 ? reg.at(rep(n->ch[0].get())) : 0;
+    const int b = n->ch.size() > 1 ? reg.at(rep(n->ch[1].get())) : a;
     uint32_t imm = n->imm;
-    if (n->op == OP_SELECT) imm = (uint32_t)reg.at(n->ch[2].get());
+    if (n->op == OP_SELECT) imm = (uint32_t)reg.at(rep(n->ch[2].get()));
     for (auto& c : n->ch) release(c.get());     // operands are read before dst is written
     const int d = alloc(); reg[n] = d;
     emit(n->op, d, a, b, imm);
   }
   for (size_t i = 0; i < imms.size(); ++i) { C.code.imm_lo[i] = imms[i].first; C.code.imm_hi[i] = imms[i].second; }
-  C.pred_reg = pred_ ? reg.at(pred_.get()) : -1;
+  C.pred_reg = pred_ ? reg.at(rep(pred_.get())) : -1;
   for (auto& o : outs_) {
-    C.out_reg.push_back(reg.at(o.get())); C.out_type.push_back(o->type); C.out_nullable.push_back(o->nullable); C.out_key.push_back(o->key);
+    C.out_reg.push_back(reg.at(rep(o.get()))); C.out_type.push_back(o->type); C.out_nullable.push_back(o->nullable); C.out_key.push_back(o->key);
   }
   return C;
 }

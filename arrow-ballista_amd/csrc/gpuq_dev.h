@@ -19,7 +19,7 @@ typedef long long i64;
 typedef __int128 i128;
 typedef unsigned __int128 u128;
 
-constexpr int MAX_COLS = 12;   // input columns referenced by one program
+constexpr int MAX_COLS = 16;   // input columns referenced by one program
 constexpr int NREG = 16;       // 128-bit virtual registers per lane
 constexpr int MAX_INSNS = 48;
 constexpr int MAX_IMMS = 12;

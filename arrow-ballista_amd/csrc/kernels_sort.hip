@@ -32,49 +32,43 @@ __device__ __forceinline__ i128 sort_view(u64 lo, u64 hi, int kind) {
 
 // ------------------------------------------------------------------ min / max per key
 // out per block: [block][key] {min_lo,min_hi,max_lo,max_hi,flags(bit0 any non-null, bit1 any null)}
+struct MinMax { u64 mn_lo, mn_hi, mx_lo, mx_hi; uint32_t fl; };
+__device__ __forceinline__ void mm_init(MinMax& m) { m.mn_lo = ~0ull; m.mn_hi = 0x7FFFFFFFFFFFFFFFull; m.mx_lo = 0; m.mx_hi = 0x8000000000000000ull; m.fl = 0; }
+__device__ __forceinline__ void mm_update(MinMax& m, i128 v) {
+  if (v < mk128(m.mn_lo, m.mn_hi)) { m.mn_lo = (u64)v; m.mn_hi = (u64)((u128)v >> 64); }
+  if (v > mk128(m.mx_lo, m.mx_hi)) { m.mx_lo = (u64)v; m.mx_hi = (u64)((u128)v >> 64); }
+}
+__device__ __forceinline__ void mm_row(MinMax& m, const SortSpec& S, int k, GPUQ_REGS_CPARAM) {
+  if (k < S.n_keys) {
+    const int r = __builtin_amdgcn_readfirstlane(S.reg[k]);
+    const bool isn = (rnulls >> r) & 1;
+    if (isn) m.fl |= 2u;
+    else { m.fl |= 1u; mm_update(m, sort_view(rlo[r], rhi[r], S.kind[k])); }
+  }
+}
+__device__ __forceinline__ void mm_reduce_store(MinMax& m, int k, u64 (*red)[MAX_SORT_KEYS][5]) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const i128 omn = mk128(__shfl_xor(m.mn_lo, off), __shfl_xor(m.mn_hi, off));
+    const i128 omx = mk128(__shfl_xor(m.mx_lo, off), __shfl_xor(m.mx_hi, off));
+    mm_update(m, omn); mm_update(m, omx);
+    m.fl |= __shfl_xor(m.fl, off);
+  }
+  if (slane() == 0) { red[swave()][k][0] = m.mn_lo; red[swave()][k][1] = m.mn_hi; red[swave()][k][2] = m.mx_lo; red[swave()][k][3] = m.mx_hi; red[swave()][k][4] = m.fl; }
+}
 __global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out) {
   __shared__ u64 red[SWAVES][MAX_SORT_KEYS][5];
-  i128 mn[MAX_SORT_KEYS], mx[MAX_SORT_KEYS]; uint32_t fl[MAX_SORT_KEYS];
-#pragma unroll
-  for (int k = 0; k < MAX_SORT_KEYS; ++k) { mn[k] = ((i128)0x7FFFFFFFFFFFFFFFll << 64) | (i128)0xFFFFFFFFFFFFFFFFull; mx[k] = -mn[k] - 1; fl[k] = 0; }
+  MinMax m0, m1, m2, m3;   // scalars on purpose: an indexed array here competes with the register file for promotion
+  mm_init(m0); mm_init(m1); mm_init(m2); mm_init(m3);
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * SWAVES + swave(); w < nwords; w += (i64)gridDim.x * SWAVES) {
     const i64 pos = (w << 6) + slane();
     if (pos >= n) continue;
     GPUQ_REGS_DECL;
     load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS);
-#pragma unroll
-    for (int k = 0; k < MAX_SORT_KEYS; ++k) {
-      if (k < S.n_keys) {
-        const int r = __builtin_amdgcn_readfirstlane(S.reg[k]);
-        const bool isn = (rnulls >> r) & 1;
-        if (isn) fl[k] |= 2u;
-        else {
-          fl[k] |= 1u;
-          const i128 v = sort_view(rlo[r], rhi[r], S.kind[k]);
-          if (v < mn[k]) mn[k] = v;
-          if (v > mx[k]) mx[k] = v;
-        }
-      }
-    }
+    mm_row(m0, S, 0, GPUQ_REGS); mm_row(m1, S, 1, GPUQ_REGS); mm_row(m2, S, 2, GPUQ_REGS); mm_row(m3, S, 3, GPUQ_REGS);
   }
-#pragma unroll
-  for (int k = 0; k < MAX_SORT_KEYS; ++k) {
-    if (k < S.n_keys) {
-      for (int off = 32; off > 0; off >>= 1) {
-        const i128 omn = mk128(__shfl_xor((u64)mn[k], off), __shfl_xor((u64)((u128)mn[k] >> 64), off));
-        const i128 omx = mk128(__shfl_xor((u64)mx[k], off), __shfl_xor((u64)((u128)mx[k] >> 64), off));
-        if (omn < mn[k]) mn[k] = omn;
-        if (omx > mx[k]) mx[k] = omx;
-        fl[k] |= __shfl_xor(fl[k], off);
-      }
-      if (slane() == 0) {
-        red[swave()][k][0] = (u64)mn[k]; red[swave()][k][1] = (u64)((u128)mn[k] >> 64);
-        red[swave()][k][2] = (u64)mx[k]; red[swave()][k][3] = (u64)((u128)mx[k] >> 64);
-        red[swave()][k][4] = fl[k];
-      }
-    }
-  }
+  // a lane that saw no value keeps (max,min) sentinels, which never win a reduction
+  mm_reduce_store(m0, 0, red); mm_reduce_store(m1, 1, red); mm_reduce_store(m2, 2, red); mm_reduce_store(m3, 3, red);
   __syncthreads();
   if (threadIdx.x < S.n_keys) {
     const int k = threadIdx.x;

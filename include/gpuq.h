@@ -69,7 +69,7 @@ typedef struct gpuq_column {
 } gpuq_column;
 
 typedef struct gpuq_field_info {
-  char name[96];
+  char name[256];
   int32_t type, precision, scale, nullable, repr, width; /* width = bytes per row in the fixed-width device layout */
 } gpuq_field_info;
 
