@@ -63,6 +63,13 @@ def lib():
     p = lib_path()
     if not os.path.exists(p):
         raise GpuqError(5, "libgpuq.so not built (%s); run `python arrow-ballista_amd/build.py`" % p)
+    # One HIP runtime per process: the torch wheel bundles its own libamdhip64.so.7.  Load torch first so
+    # libgpuq.so's NEEDED libamdhip64.so.7 resolves to that same instance; otherwise two runtimes would
+    # be live and torch tensors' device pointers would belong to a different runtime than our streams.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(p)
     vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
     sig = {

@@ -809,14 +809,18 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
       i128 mn = ((i128)0x7FFFFFFFFFFFFFFFll << 64) | (i128)0xFFFFFFFFFFFFFFFFull, mx = -mn - 1; u64 fl = 0;
       for (int b = 0; b < mb; ++b) {
         const u64* o = &hmm[((size_t)b * MAX_SORT_KEYS + k) * 5];
-        if (!(o[4] & 1)) { fl |= o[4]; continue; }
+        if (!(o[4] & 1)) { fl |= (o[4] & 0xFF); continue; }
         const i128 a = (i128)(((u128)o[1] << 64) | o[0]), c = (i128)(((u128)o[3] << 64) | o[2]);
         if (a < mn) mn = a;
         if (c > mx) mx = c;
-        fl |= o[4];
+        fl = ((fl | o[4]) & 0xFF) | std::max<u64>(fl & 0xFF00, o[4] & 0xFF00);
       }
       int vb = 0;
-      if (fl & 1) { vb = bitlen128((u128)(mx - mn)); const i128 base = S.desc[k] ? mx : mn; K.base_lo[k] = (u64)base; K.base_hi[k] = (u64)((u128)base >> 64); }
+      if (S.kind[k] == 2) { const int maxlen = std::min<int>((int)((fl >> 8) & 0xFF), 15); K.rshift[k] = 8 * (15 - maxlen) + 8; }
+      if (fl & 1) {
+        mn >>= K.rshift[k]; mx >>= K.rshift[k];
+        vb = bitlen128((u128)(mx - mn)); const i128 base = S.desc[k] ? mx : mn; K.base_lo[k] = (u64)base; K.base_hi[k] = (u64)((u128)base >> 64);
+      }
       K.null_bit[k] = (fl & 2) ? vb : -1;
       width[k] = vb + ((fl & 2) ? 1 : 0);
       total += width[k];

@@ -5,7 +5,7 @@
 namespace gpuq {
 
 // ----- project / materialise
-constexpr int MAX_OUTS = 12;
+constexpr int MAX_OUTS = 16;
 struct OutCol {
   void* data;          // fixed-width destination (4/8/16 B per row by cls; CC_STR stores the 16-B packed form)
   u64* validity;       // optional validity bitmap as 64-bit words (bit i of word w = row 64*w+i); nullptr = not written
@@ -93,6 +93,7 @@ struct SortPack {                   // computed on the host from the per-key min
   u64 base_lo[MAX_SORT_KEYS], base_hi[MAX_SORT_KEYS];   // min (ASC) or max (DESC) in the ordered view
   int32_t shift[MAX_SORT_KEYS];     // bit position of the key's field in the composite
   int32_t null_bit[MAX_SORT_KEYS];  // bit (inside the field) of the null flag, -1 = none
+  int32_t rshift[MAX_SORT_KEYS];    // packed Utf8: drop the length byte and the bytes beyond the longest string
 };
 int sort_minmax_blocks(i64 n);
 void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks);

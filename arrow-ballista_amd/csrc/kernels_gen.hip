@@ -13,8 +13,15 @@ namespace gpuq {
 __device__ __host__ __forceinline__ u64 gen_u64(u64 seed, u64 col, u64 row) {
   return mix64((seed + col * 0xD1B54A32D192ED03ull) ^ (row * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull));
 }
+// Range reduction on a folded 32-bit hash with a 32-bit modulus.  (Deliberate: hipcc 7.2 miscompiles
+// `u64 % even_constant` when the remainder feeds 64-bit arithmetic -- the magic-number division keeps
+// only 28 bits of the quotient's low word -- so no 64-bit modulo by a constant appears in this file.)
+__device__ __host__ __forceinline__ uint32_t gen_mod(u64 seed, u64 col, u64 row, uint32_t m) {
+  const u64 x = gen_u64(seed, col, row);
+  return ((uint32_t)(x >> 32) ^ (uint32_t)x) % m;
+}
 __device__ __host__ __forceinline__ i64 order_key(i64 o) { return (o >> 3) * 32 + (o & 7) + 1; }   // sparse: 8 of every 32 ids
-__device__ __host__ __forceinline__ int32_t order_date(u64 seed_orders, i64 o) { return 8035 + (int32_t)(gen_u64(seed_orders, 4, (u64)o) % 2406); }
+__device__ __host__ __forceinline__ int32_t order_date(u64 seed_orders, i64 o) { return 8035 + (int32_t)gen_mod(seed_orders, 4, (u64)o, 2406u); }
 
 // column ids: lineitem 1..9, orders 1..5, customer 1..3, supplier 1..2
 __global__ void __launch_bounds__(256) k_gen_lineitem(const u64 seed, const u64 seed_orders, const i64 row0, const i64 n, const i64 n_supp,
@@ -23,14 +30,14 @@ __global__ void __launch_bounds__(256) k_gen_lineitem(const u64 seed, const u64 
     const i64 i = row0 + j;
     const i64 o = i >> 2;
     const int32_t odate = order_date(seed_orders, o);
-    const int32_t ship = odate + 1 + (int32_t)(gen_u64(seed, 1, (u64)i) % 121);
-    const int32_t receipt = ship + 1 + (int32_t)(gen_u64(seed, 2, (u64)i) % 30);
+    const int32_t ship = odate + 1 + (int32_t)gen_mod(seed, 1, (u64)i, 121u);
+    const int32_t receipt = ship + 1 + (int32_t)gen_mod(seed, 2, (u64)i, 30u);
     if (c.l_orderkey) c.l_orderkey[j] = order_key(o);
-    if (c.l_suppkey) c.l_suppkey[j] = 1 + (i64)(gen_u64(seed, 3, (u64)i) % (u64)n_supp);
-    if (c.l_quantity) { c.l_quantity[2 * j] = (1 + gen_u64(seed, 4, (u64)i) % 50) * 100; c.l_quantity[2 * j + 1] = 0; }
-    if (c.l_extendedprice) { c.l_extendedprice[2 * j] = 90100 + gen_u64(seed, 5, (u64)i) % 10404851ull; c.l_extendedprice[2 * j + 1] = 0; }
-    if (c.l_discount) { c.l_discount[2 * j] = gen_u64(seed, 6, (u64)i) % 11; c.l_discount[2 * j + 1] = 0; }
-    if (c.l_tax) { c.l_tax[2 * j] = gen_u64(seed, 7, (u64)i) % 9; c.l_tax[2 * j + 1] = 0; }
+    if (c.l_suppkey) c.l_suppkey[j] = 1 + (i64)gen_mod(seed, 3, (u64)i, (uint32_t)n_supp);
+    if (c.l_quantity) { c.l_quantity[2 * j] = (u64)((gen_mod(seed, 4, (u64)i, 50u) + 1u) * 100u); c.l_quantity[2 * j + 1] = 0; }
+    if (c.l_extendedprice) { c.l_extendedprice[2 * j] = (u64)(90100u + gen_mod(seed, 5, (u64)i, 10404851u)); c.l_extendedprice[2 * j + 1] = 0; }
+    if (c.l_discount) { c.l_discount[2 * j] = (u64)gen_mod(seed, 6, (u64)i, 11u); c.l_discount[2 * j + 1] = 0; }
+    if (c.l_tax) { c.l_tax[2 * j] = (u64)gen_mod(seed, 7, (u64)i, 9u); c.l_tax[2 * j + 1] = 0; }
     if (c.l_shipdate) c.l_shipdate[j] = ship;
     if (c.l_returnflag) {
       c.l_returnflag[j] = (receipt <= 9298) ? ((gen_u64(seed, 8, (u64)i) & 1) ? 'R' : 'A') : 'N';
@@ -51,8 +58,7 @@ __global__ void __launch_bounds__(256) k_gen_orders(const u64 seed, const i64 ro
     if (c.o_orderkey) c.o_orderkey[j] = order_key(o);
     if (c.o_custkey) {
       // custkey never a multiple of 3 (one third of customers place no orders)
-      const u64 x = gen_u64(seed, 2, (u64)o);
-      c.o_custkey[j] = 3 * (i64)(x % (u64)(n_cust / 3)) + 1 + (i64)((x >> 40) & 1);
+      c.o_custkey[j] = 3 * (i64)gen_mod(seed, 2, (u64)o, (uint32_t)(n_cust / 3)) + 1 + (i64)((gen_u64(seed, 2, (u64)o) >> 40) & 1);
     }
     if (c.o_orderdate) c.o_orderdate[j] = order_date(seed, o);
     if (c.o_shippriority) c.o_shippriority[j] = 0;
@@ -64,11 +70,12 @@ __constant__ const int kSegLen[5] = {10, 8, 9, 9, 9};
 
 // Each run of 5 consecutive customers holds a random permutation of the 5 segments, so the Utf8
 // offsets have a closed form (45 bytes per run) and the segment selectivity is exactly 1/5.
-__device__ __forceinline__ void seg_perm(u64 x, int (&perm)[5]) {
+__device__ __forceinline__ void seg_perm(u64 x64, int (&perm)[5]) {
+  uint32_t x = (uint32_t)(x64 >> 32) ^ (uint32_t)x64;
   int pool[5] = {0, 1, 2, 3, 4};
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
-    const int r = (int)(x % (u64)(5 - k)); x /= (u64)(5 - k);
+    const int r = (int)(x % (uint32_t)(5 - k)); x /= (uint32_t)(5 - k);
     int pick = 0, seen = 0;
 #pragma unroll
     for (int q = 0; q < 5; ++q) { if (pool[q] >= 0) { if (seen == r) pick = q; ++seen; } }
@@ -83,7 +90,7 @@ __global__ void __launch_bounds__(256) k_gen_customer(const u64 seed, const i64 
   for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
     const i64 i = row0 + j;
     if (c.c_custkey) c.c_custkey[j] = i + 1;
-    if (c.c_nationkey) c.c_nationkey[j] = (i64)(gen_u64(seed, 2, (u64)i) % 25);
+    if (c.c_nationkey) c.c_nationkey[j] = (i64)gen_mod(seed, 2, (u64)i, 25u);
     if (c.c_mktsegment) {
       const i64 run = i / 5; const int m = (int)(i % 5);
       int perm[5]; seg_perm(gen_u64(seed, 3, (u64)run), perm);
@@ -105,7 +112,7 @@ __global__ void __launch_bounds__(256) k_gen_supplier(const u64 seed, const i64 
   for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
     const i64 i = row0 + j;
     if (c.s_suppkey) c.s_suppkey[j] = i + 1;
-    if (c.s_nationkey) c.s_nationkey[j] = (i64)(gen_u64(seed, 2, (u64)i) % 25);
+    if (c.s_nationkey) c.s_nationkey[j] = (i64)gen_mod(seed, 2, (u64)i, 25u);
   }
 }
 

@@ -601,15 +601,19 @@ void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A
   int nb = grid_for(n, 64);
   if (nb > nb_cap) nb = nb_cap;
   const size_t lds = tiny_lds_bytes(gmax, A.n_keys, A.n_accs);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_agg_tiny, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_agg_tiny_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  // > 64 KiB of dynamic LDS needs an explicit opt-in; the request must leave room for the static part
+  static size_t attr_main = 0, attr_merge = 0;
+  if (lds > 60 * 1024 && lds > attr_main) {
+    if (hipFuncSetAttribute((const void*)k_agg_tiny, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_main = lds;
+    else (void)hipGetLastError();
   }
   hipLaunchKernelGGL(k_agg_tiny, dim3(nb), dim3(BLOCK), lds, s, P, n, A, gmax, (char*)workspace, stride);
   const int kstride = A.n_keys > 0 ? A.n_keys : 1;
   const size_t mlds = (size_t)out.cap * kstride * 16 + (size_t)out.cap * 4 + (((size_t)nb * gmax * 2 + 15) & ~(size_t)15) + 16;
+  if (mlds > 60 * 1024 && mlds > attr_merge) {
+    if (hipFuncSetAttribute((const void*)k_agg_tiny_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) == hipSuccess) attr_merge = mlds;
+    else (void)hipGetLastError();
+  }
   hipLaunchKernelGGL(k_agg_tiny_merge, dim3(1), dim3(BLOCK), mlds, s, A, gmax, (const char*)workspace, stride, nb, out, P.flags);
 }
 

@@ -43,15 +43,19 @@ __device__ __forceinline__ void mm_row(MinMax& m, const SortSpec& S, int k, GPUQ
     const int r = __builtin_amdgcn_readfirstlane(S.reg[k]);
     const bool isn = (rnulls >> r) & 1;
     if (isn) m.fl |= 2u;
-    else { m.fl |= 1u; mm_update(m, sort_view(rlo[r], rhi[r], S.kind[k])); }
+    else {
+      m.fl |= 1u; mm_update(m, sort_view(rlo[r], rhi[r], S.kind[k]));
+      if (S.kind[k] == 2) { const uint32_t len = (uint32_t)(rlo[r] & 0xFF) << 8; if (len > (m.fl & 0xFF00u)) m.fl = (m.fl & ~0xFF00u) | len; }   // longest string, bits 8..15
+    }
   }
 }
 __device__ __forceinline__ void mm_reduce_store(MinMax& m, int k, u64 (*red)[MAX_SORT_KEYS][5]) {
   for (int off = 32; off > 0; off >>= 1) {
     const i128 omn = mk128(__shfl_xor(m.mn_lo, off), __shfl_xor(m.mn_hi, off));
     const i128 omx = mk128(__shfl_xor(m.mx_lo, off), __shfl_xor(m.mx_hi, off));
-    mm_update(m, omn); mm_update(m, omx);
-    m.fl |= __shfl_xor(m.fl, off);
+    if (omn < mk128(m.mn_lo, m.mn_hi)) { m.mn_lo = (u64)omn; m.mn_hi = (u64)((u128)omn >> 64); }
+    if (omx > mk128(m.mx_lo, m.mx_hi)) { m.mx_lo = (u64)omx; m.mx_hi = (u64)((u128)omx >> 64); }
+    { const uint32_t of = __shfl_xor(m.fl, off); const uint32_t ml = (of & 0xFF00u) > (m.fl & 0xFF00u) ? (of & 0xFF00u) : (m.fl & 0xFF00u); m.fl = ((m.fl | of) & 0xFFu) | ml; }
   }
   if (slane() == 0) { red[swave()][k][0] = m.mn_lo; red[swave()][k][1] = m.mn_hi; red[swave()][k][2] = m.mx_lo; red[swave()][k][3] = m.mx_hi; red[swave()][k][4] = m.fl; }
 }
@@ -77,7 +81,7 @@ __global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, cons
       const i128 oa = mk128(red[q][k][0], red[q][k][1]), ob = mk128(red[q][k][2], red[q][k][3]);
       if (oa < a) a = oa;
       if (ob > b) b = ob;
-      f |= red[q][k][4];
+      { const u64 of = red[q][k][4]; const u64 ml = (of & 0xFF00u) > (f & 0xFF00u) ? (of & 0xFF00u) : (f & 0xFF00u); f = ((f | of) & 0xFFu) | ml; }
     }
     u64* o = out + ((size_t)blockIdx.x * MAX_SORT_KEYS + k) * 5;
     o[0] = (u64)a; o[1] = (u64)((u128)a >> 64); o[2] = (u64)b; o[3] = (u64)((u128)b >> 64); o[4] = f;
@@ -101,7 +105,7 @@ __global__ void __launch_bounds__(SBLOCK) k_sort_pack(const DevProgram P, const 
         const bool isn = (rnulls >> r) & 1;
         u128 field = 0;
         if (!isn) {
-          const i128 v = sort_view(rlo[r], rhi[r], S.kind[k]);
+          const i128 v = sort_view(rlo[r], rhi[r], S.kind[k]) >> K.rshift[k];   // arithmetic shift keeps the order
           const i128 base = mk128(K.base_lo[k], K.base_hi[k]);
           field = S.desc[k] ? (u128)(base - v) : (u128)(v - base);
         }

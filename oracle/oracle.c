@@ -43,8 +43,12 @@ static inline u64 mix64(u64 x) {
 static inline u64 gen_u64(u64 seed, u64 col, u64 row) {
   return mix64((seed + col * 0xD1B54A32D192ED03ull) ^ (row * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull));
 }
+static inline uint32_t gen_mod(u64 seed, u64 col, u64 row, uint32_t m) {
+  const u64 x = gen_u64(seed, col, row);
+  return ((uint32_t)(x >> 32) ^ (uint32_t)x) % m;
+}
 static inline i64 order_key(i64 o) { return (o >> 3) * 32 + (o & 7) + 1; }
-static inline int32_t order_date(u64 seed_orders, i64 o) { return 8035 + (int32_t)(gen_u64(seed_orders, 4, (u64)o) % 2406); }
+static inline int32_t order_date(u64 seed_orders, i64 o) { return 8035 + (int32_t)gen_mod(seed_orders, 4, (u64)o, 2406u); }
 
 /* Decimal128 columns are written as 16-byte little-endian values (lo, hi). */
 void oracle_gen_lineitem(u64 seed, u64 seed_orders, i64 row0, i64 n, i64 n_supp, i64* l_orderkey, i64* l_suppkey, u64* l_quantity,
@@ -54,14 +58,14 @@ void oracle_gen_lineitem(u64 seed, u64 seed_orders, i64 row0, i64 n, i64 n_supp,
   for (i64 j = 0; j < n; ++j) {
     const i64 i = row0 + j, o = i >> 2;
     const int32_t odate = order_date(seed_orders, o);
-    const int32_t ship = odate + 1 + (int32_t)(gen_u64(seed, 1, (u64)i) % 121);
-    const int32_t receipt = ship + 1 + (int32_t)(gen_u64(seed, 2, (u64)i) % 30);
+    const int32_t ship = odate + 1 + (int32_t)gen_mod(seed, 1, (u64)i, 121u);
+    const int32_t receipt = ship + 1 + (int32_t)gen_mod(seed, 2, (u64)i, 30u);
     if (l_orderkey) l_orderkey[j] = order_key(o);
-    if (l_suppkey) l_suppkey[j] = 1 + (i64)(gen_u64(seed, 3, (u64)i) % (u64)n_supp);
-    if (l_quantity) { l_quantity[2 * j] = (1 + gen_u64(seed, 4, (u64)i) % 50) * 100; l_quantity[2 * j + 1] = 0; }
-    if (l_extendedprice) { l_extendedprice[2 * j] = 90100 + gen_u64(seed, 5, (u64)i) % 10404851ull; l_extendedprice[2 * j + 1] = 0; }
-    if (l_discount) { l_discount[2 * j] = gen_u64(seed, 6, (u64)i) % 11; l_discount[2 * j + 1] = 0; }
-    if (l_tax) { l_tax[2 * j] = gen_u64(seed, 7, (u64)i) % 9; l_tax[2 * j + 1] = 0; }
+    if (l_suppkey) l_suppkey[j] = 1 + (i64)gen_mod(seed, 3, (u64)i, (uint32_t)n_supp);
+    if (l_quantity) { l_quantity[2 * j] = (u64)((gen_mod(seed, 4, (u64)i, 50u) + 1u) * 100u); l_quantity[2 * j + 1] = 0; }
+    if (l_extendedprice) { l_extendedprice[2 * j] = (u64)(90100u + gen_mod(seed, 5, (u64)i, 10404851u)); l_extendedprice[2 * j + 1] = 0; }
+    if (l_discount) { l_discount[2 * j] = (u64)gen_mod(seed, 6, (u64)i, 11u); l_discount[2 * j + 1] = 0; }
+    if (l_tax) { l_tax[2 * j] = (u64)gen_mod(seed, 7, (u64)i, 9u); l_tax[2 * j + 1] = 0; }
     if (l_shipdate) l_shipdate[j] = ship;
     if (l_returnflag) { l_returnflag[j] = (receipt <= 9298) ? ((gen_u64(seed, 8, (u64)i) & 1) ? 'R' : 'A') : 'N'; l_returnflag_off[j] = (int32_t)j; }
     if (l_linestatus) { l_linestatus[j] = (ship > 9298) ? 'O' : 'F'; l_linestatus_off[j] = (int32_t)j; }
@@ -75,7 +79,7 @@ void oracle_gen_orders(u64 seed, i64 row0, i64 n, i64 n_cust, i64* o_orderkey, i
   for (i64 j = 0; j < n; ++j) {
     const i64 o = row0 + j;
     if (o_orderkey) o_orderkey[j] = order_key(o);
-    if (o_custkey) { const u64 x = gen_u64(seed, 2, (u64)o); o_custkey[j] = 3 * (i64)(x % (u64)(n_cust / 3)) + 1 + (i64)((x >> 40) & 1); }
+    if (o_custkey) o_custkey[j] = 3 * (i64)gen_mod(seed, 2, (u64)o, (uint32_t)(n_cust / 3)) + 1 + (i64)((gen_u64(seed, 2, (u64)o) >> 40) & 1);
     if (o_orderdate) o_orderdate[j] = order_date(seed, o);
     if (o_shippriority) o_shippriority[j] = 0;
   }
@@ -83,10 +87,11 @@ void oracle_gen_orders(u64 seed, i64 row0, i64 n, i64 n_cust, i64* o_orderkey, i
 
 static const char* kSegments[5] = {"AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"};
 static const int kSegLen[5] = {10, 8, 9, 9, 9};
-static void seg_perm(u64 x, int perm[5]) {
+static void seg_perm(u64 x64, int perm[5]) {
+  uint32_t x = (uint32_t)(x64 >> 32) ^ (uint32_t)x64;
   int pool[5] = {0, 1, 2, 3, 4};
   for (int k = 0; k < 5; ++k) {
-    const int r = (int)(x % (u64)(5 - k)); x /= (u64)(5 - k);
+    const int r = (int)(x % (uint32_t)(5 - k)); x /= (uint32_t)(5 - k);
     int pick = 0, seen = 0;
     for (int q = 0; q < 5; ++q) if (pool[q] >= 0) { if (seen == r) pick = q; ++seen; }
     perm[k] = pool[pick]; pool[pick] = -1;
@@ -97,7 +102,7 @@ void oracle_gen_customer(u64 seed, i64 row0, i64 n, i64* c_custkey, i64* c_natio
   for (i64 j = 0; j < n; ++j) {
     const i64 i = row0 + j;
     if (c_custkey) c_custkey[j] = i + 1;
-    if (c_nationkey) c_nationkey[j] = (i64)(gen_u64(seed, 2, (u64)i) % 25);
+    if (c_nationkey) c_nationkey[j] = (i64)gen_mod(seed, 2, (u64)i, 25u);
     if (c_mktsegment) {
       const i64 run = i / 5; const int m = (int)(i % 5);
       int perm[5]; seg_perm(gen_u64(seed, 3, (u64)run), perm);
@@ -114,7 +119,7 @@ void oracle_gen_supplier(u64 seed, i64 row0, i64 n, i64* s_suppkey, i64* s_natio
   for (i64 j = 0; j < n; ++j) {
     const i64 i = row0 + j;
     if (s_suppkey) s_suppkey[j] = i + 1;
-    if (s_nationkey) s_nationkey[j] = (i64)(gen_u64(seed, 2, (u64)i) % 25);
+    if (s_nationkey) s_nationkey[j] = (i64)gen_mod(seed, 2, (u64)i, 25u);
   }
 }
 
