@@ -621,7 +621,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         int fit_small = 0; for (int g = 1; g <= fit_big; ++g) { int nb; (void)nb; if ((size_t)g * na * 2048 + 4096 <= 64 * 1024) fit_small = g; }
         std::vector<int> tries;
         if (nk == 0) tries = {1};
-        else { if (fit_small >= 4) tries.push_back(fit_small); tries.push_back(fit_big); }
+        else { if (fit_small > 4) { tries.push_back(4); } if (fit_small >= 2) tries.push_back(fit_small); if (fit_big > fit_small) tries.push_back(fit_big); }
         for (int gmax : tries) {
           int nb = 0; const size_t wsb = agg_tiny_workspace_bytes(gmax, nk, na, &nb);
           void* wsp = op->ws[4].ensure(wsb);

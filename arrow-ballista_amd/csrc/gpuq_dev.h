@@ -129,68 +129,94 @@ __device__ inline void divmod128(i128 n, i128 d, i128& q, i128& r) {
 }
 
 // ---------------------------------------------------------------- column load
-__device__ __forceinline__ void load_one(const DevCol& c, uint32_t row, bool row_ok,
-                                         u64& lo, u64& hi, bool& isnull, uint32_t* flags) {
-  lo = 0; hi = 0; isnull = !row_ok;
-  if (!row_ok) return;
-  if (c.validity) {
-    uint8_t vb = c.validity[row >> 3];
-    if (!((vb >> (row & 7)) & 1)) { isnull = true; return; }
-  }
-  switch (c.cls) {
-    case CC_I32: { i64 v = ((const int32_t*)c.data)[row]; lo = (u64)v; hi = (u64)(v >> 63); break; }
-    case CC_U32: { lo = ((const uint32_t*)c.data)[row]; break; }
-    case CC_I64: { i64 v = ((const i64*)c.data)[row]; lo = (u64)v; hi = (u64)(v >> 63); break; }
-    case CC_I128: {
-      const ulonglong2 v = ((const ulonglong2*)c.data)[row];
-      lo = v.x; hi = v.y; break;
-    }
-    case CC_BIT: { uint8_t b = ((const uint8_t*)c.data)[row >> 3]; lo = (b >> (row & 7)) & 1; break; }
-    case CC_STR: {
-      int32_t o0 = c.offsets[row], o1 = c.offsets[row + 1];
-      int32_t len = o1 - o0;
-      if (len > 15) { if (flags) atomicOr(flags, FLAG_STR_TRUNC); }
-      int32_t n = len < 15 ? len : 15;
-      const uint8_t* p = (const uint8_t*)c.data + o0;
-      u64 h = 0, l = 0;
-      for (int k = 0; k < n; ++k) {
-        u64 b = p[k];
-        if (k < 8) h |= b << (56 - 8 * k);
-        else l |= b << (56 - 8 * (k - 8));
-      }
-      hi = h; lo = l | (u64)(len < 255 ? len : 255);
-      break;
-    }
-    default: break;
-  }
-}
-
+// Two phases so that a wave has EVERY column's first-level load in flight before it consumes any of
+// them (one HBM round trip per row instead of one per column):
+//   phase A  issue the raw loads (values, Utf8 offset pairs, validity bytes) -- no dependent ALU work
+//   phase B  sign-extend / unpack; Utf8 issues its second-level byte loads here
 __device__ __forceinline__ void load_columns(const DevProgram& P, i64 pos, GPUQ_REGS_PARAM) {
   uint32_t rows[MAX_VIA + 1];
   rows[0] = (uint32_t)pos;
 #pragma unroll
   for (int k = 0; k < MAX_VIA; ++k) rows[k + 1] = (k < P.n_via) ? P.via[k][pos] : 0u;
   rnulls = 0;
+  uint32_t vraw[MAX_COLS];
+  // ---- phase A   (register-file elements are assigned exactly once per phase, outside any branch:
+  //                 vector updates under control flow make the allocator copy the whole file)
 #pragma unroll
   for (int c = 0; c < MAX_COLS; ++c) {
+    u64 lo = 0, hi = 0; uint32_t vr = 0xFFu;
     if (c < P.n_cols) {
       const DevCol col = P.cols[c];
       uint32_t row = rows[0];
 #pragma unroll
       for (int k = 1; k <= MAX_VIA; ++k) if (col.via == k) row = rows[k];
-      bool ok = (col.via == 0) || (row != NULL_ROW);
-      u64 lo, hi; bool isnull;
-      load_one(col, row, ok, lo, hi, isnull, P.flags);
-      rlo[c] = lo; rhi[c] = hi;
-      if (isnull) rnulls |= (1u << c);
+      const bool ok = (col.via == 0) || (row != NULL_ROW);
+      if (ok) {
+        if (col.validity) vr = col.validity[row >> 3] >> (row & 7);
+        switch (col.cls) {
+          case CC_I32: case CC_U32: lo = ((const uint32_t*)col.data)[row]; break;
+          case CC_I64: lo = ((const u64*)col.data)[row]; break;
+          case CC_I128: { const ulonglong2 v = ((const ulonglong2*)col.data)[row]; lo = v.x; hi = v.y; break; }
+          case CC_BIT: lo = ((const uint8_t*)col.data)[row >> 3] >> (row & 7); break;
+          case CC_STR: lo = (u64)(uint32_t)col.offsets[row] | ((u64)(uint32_t)col.offsets[row + 1] << 32); break;
+          default: break;
+        }
+      } else {
+        vr = 0;
+      }
     }
+    rlo[c] = lo; rhi[c] = hi; vraw[c] = vr;
+  }
+  // ---- phase B
+#pragma unroll
+  for (int c = 0; c < MAX_COLS; ++c) {
+    u64 lo = rlo[c], hi = rhi[c];
+    if (c < P.n_cols) {
+      const DevCol col = P.cols[c];
+      const bool isnull = !(vraw[c] & 1u);
+      if (isnull) { rnulls |= (1u << c); lo = 0; hi = 0; }
+      else {
+        switch (col.cls) {
+          case CC_I32: { const i64 v = (int32_t)(uint32_t)lo; lo = (u64)v; hi = (u64)(v >> 63); break; }
+          case CC_I64: hi = (u64)((i64)lo >> 63); break;
+          case CC_BIT: lo &= 1; break;
+          case CC_STR: {
+            const int32_t o0 = (int32_t)(uint32_t)lo, o1 = (int32_t)(uint32_t)(lo >> 32);
+            const int32_t len = o1 - o0;
+            if (len > 15) { if (P.flags) atomicOr(P.flags, FLAG_STR_TRUNC); }
+            const int32_t n = len < 15 ? len : 15;
+            const uint8_t* p = (const uint8_t*)col.data + o0;
+            u64 h = 0, l = 0;
+            for (int k = 0; k < n; ++k) {
+              const u64 b = p[k];
+              if (k < 8) h |= b << (56 - 8 * k);
+              else l |= b << (56 - 8 * (k - 8));
+            }
+            hi = h; lo = l | (u64)(len < 255 ? len : 255);
+            break;
+          }
+          default: break;
+        }
+      }
+    }
+    rlo[c] = lo; rhi[c] = hi;
   }
 }
 
 // ---------------------------------------------------------------- interpreter
+// The instruction stream is read through a CONSTANT-address-space pointer: with a wave-uniform index
+// that makes every fetch an s_load (scalar cache) instead of a per-lane global_load + vmcnt wait,
+// which would put one L2 round trip in front of every interpreted instruction.
+typedef const DevCode __attribute__((address_space(4))) * ConstCode;
+__device__ __forceinline__ ConstCode const_code(const DevProgram& P) {
+  return (ConstCode)(unsigned long long)(const void*)P.code;
+}
 __device__ __forceinline__ void run_program(const DevProgram& P, GPUQ_REGS_PARAM) {
+  ConstCode code = const_code(P);
   for (int p = 0; p < P.n_insns; ++p) {
-    const DevInsn in = P.code->insns[p];
+    const unsigned long long raw = *(const unsigned long long __attribute__((address_space(4)))*)&code->insns[p];
+    DevInsn in;
+    in.op = (uint8_t)raw; in.dst = (uint8_t)(raw >> 8); in.a = (uint8_t)(raw >> 16); in.b = (uint8_t)(raw >> 24); in.imm = (uint32_t)(raw >> 32);
     const int op = __builtin_amdgcn_readfirstlane((int)in.op);
     const int d = __builtin_amdgcn_readfirstlane((int)in.dst);
     const int a = __builtin_amdgcn_readfirstlane((int)in.a);
@@ -201,7 +227,7 @@ __device__ __forceinline__ void run_program(const DevProgram& P, GPUQ_REGS_PARAM
     u64 zlo = 0, zhi = 0;
     bool zn = an || bn;  // default null propagation for binary ops
     switch (op) {
-      case OP_IMM: zlo = P.code->imm_lo[imm]; zhi = P.code->imm_hi[imm]; zn = false; break;
+      case OP_IMM: zlo = code->imm_lo[imm]; zhi = code->imm_hi[imm]; zn = false; break;
       case OP_MOV: zlo = alo; zhi = ahi; zn = an; break;
       case OP_ADD: { i128 z = mk128(alo, ahi) + mk128(blo, bhi); zlo = (u64)z; zhi = (u64)((u128)z >> 64); break; }
       case OP_SUB: { i128 z = mk128(alo, ahi) - mk128(blo, bhi); zlo = (u64)z; zhi = (u64)((u128)z >> 64); break; }

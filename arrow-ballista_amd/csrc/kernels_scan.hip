@@ -445,29 +445,70 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const
   }
   __syncthreads();
   const int nf = (int)*fn;
-  // phase 2: one thread per final cell, records folded in block order (fixed order -> deterministic)
+  // phase 2: integer cells are folded with LDS atomics (any order gives the same bits); float sums
+  // are folded by one thread per cell in block order so that results are reproducible run to run.
+  u64* fcells = (u64*)(lock + 3);   // [cap][n_accs][2], 8-byte aligned by construction
   for (int c = tid; c < nf * n_accs; c += BLOCK) {
-    const int f = c / n_accs, a = c % n_accs;
-    const int kind = A.acc_kind[a];
-    u64 rlo = acc_identity(kind), rhi = (kind == ACC_MIN) ? 0 : ((kind == ACC_MAX) ? ~0ull : 0);
-    for (int b = 0; b < nblocks; ++b) {
-      const char* rec = workspace + (size_t)b * partial_stride;
-      const u64* cellsb = (const u64*)(rec + cells_off);
-      for (int g = 0; g < gmax; ++g) {
-        if (map[b * gmax + g] != (uint16_t)f) continue;
-        const u64 olo = cellsb[(size_t)(g * n_accs + a) * 2], ohi = cellsb[(size_t)(g * n_accs + a) * 2 + 1];
-        switch (kind) {
-          case ACC_SUM: case ACC_COUNT: case ACC_COUNT_STAR: { const u64 s = rlo + olo; rhi = rhi + ohi + (s < rlo ? 1 : 0); rlo = s; break; }
-          case ACC_MIN: if ((i64)olo < (i64)rlo) { rlo = olo; rhi = ohi; } break;
-          case ACC_MAX: if ((i64)olo > (i64)rlo) { rlo = olo; rhi = ohi; } break;
-          case ACC_FSUM: rlo = (u64)__double_as_longlong(__longlong_as_double((i64)rlo) + __longlong_as_double((i64)olo)); break;
-          case ACC_FMIN: if (f64_total_key(olo) < f64_total_key(rlo)) rlo = olo; break;
-          case ACC_FMAX: if (f64_total_key(olo) > f64_total_key(rlo)) rlo = olo; break;
-          default: break;
+    const int kind = A.acc_kind[c % n_accs];
+    fcells[2 * c] = acc_identity(kind);
+    fcells[2 * c + 1] = (kind == ACC_MAX) ? ~0ull : 0;
+  }
+  __syncthreads();
+  bool has_float = false;
+  for (int a = 0; a < n_accs; ++a) has_float = has_float || A.acc_kind[a] == ACC_FSUM;
+  for (int e = tid; e < nblocks * gmax; e += BLOCK) {
+    const uint16_t f = map[e];
+    if (f == 0xFFFF) continue;
+    const int b = e / gmax, g = e % gmax;
+    const u64* cellsb = (const u64*)(workspace + (size_t)b * partial_stride + cells_off);
+    for (int a = 0; a < n_accs; ++a) {
+      const int kind = A.acc_kind[a];
+      const u64 olo = cellsb[(size_t)(g * n_accs + a) * 2], ohi = cellsb[(size_t)(g * n_accs + a) * 2 + 1];
+      u64* dst = &fcells[((size_t)f * n_accs + a) * 2];
+      switch (kind) {
+        case ACC_SUM: case ACC_COUNT: case ACC_COUNT_STAR: {
+          const u64 old = atomicAdd(dst, olo);
+          const u64 carry = (old + olo < old) ? 1 : 0;
+          if (ohi + carry) atomicAdd(dst + 1, ohi + carry);
+          break;
         }
+        case ACC_MIN: atomicMin((long long*)dst, (long long)olo); break;
+        case ACC_MAX: atomicMax((long long*)dst, (long long)olo); break;
+        case ACC_FMIN: case ACC_FMAX: {
+          u64 cur = *(volatile u64*)dst;
+          for (;;) {
+            const bool better = (kind == ACC_FMIN) ? (f64_total_key(olo) < f64_total_key(cur)) : (f64_total_key(olo) > f64_total_key(cur));
+            if (!better) break;
+            const u64 seen = atomicCAS(dst, cur, olo);
+            if (seen == cur) break;
+            cur = seen;
+          }
+          break;
+        }
+        default: break;
       }
     }
-    out.cells[(size_t)c * 2] = rlo; out.cells[(size_t)c * 2 + 1] = rhi;
+  }
+  __syncthreads();
+  if (has_float) {
+    for (int c = tid; c < nf * n_accs; c += BLOCK) {
+      const int f = c / n_accs, a = c % n_accs;
+      if (A.acc_kind[a] != ACC_FSUM) continue;
+      double acc = 0.0;
+      for (int b = 0; b < nblocks; ++b) {
+        const u64* cellsb = (const u64*)(workspace + (size_t)b * partial_stride + cells_off);
+        for (int g = 0; g < gmax; ++g)
+          if (map[b * gmax + g] == (uint16_t)f) acc += __longlong_as_double((i64)cellsb[(size_t)(g * n_accs + a) * 2]);
+      }
+      fcells[2 * c] = (u64)__double_as_longlong(acc); fcells[2 * c + 1] = 0;
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < nf * n_accs; c += BLOCK) {
+    const int kind = A.acc_kind[c % n_accs];
+    u64 lo = fcells[2 * c], hi = fcells[2 * c + 1];
+    if (kind == ACC_MIN || kind == ACC_MAX) hi = (u64)((i64)lo >> 63);
+    out.cells[(size_t)c * 2] = lo; out.cells[(size_t)c * 2 + 1] = hi;
   }
   for (int i = tid; i < nf * kstride * 2; i += BLOCK) out.keys[i] = fkeys[i];
   for (int i = tid; i < nf; i += BLOCK) out.key_nulls[i] = fnulls[i];
@@ -609,7 +650,7 @@ void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A
   }
   hipLaunchKernelGGL(k_agg_tiny, dim3(nb), dim3(BLOCK), lds, s, P, n, A, gmax, (char*)workspace, stride);
   const int kstride = A.n_keys > 0 ? A.n_keys : 1;
-  const size_t mlds = (size_t)out.cap * kstride * 16 + (size_t)out.cap * 4 + (((size_t)nb * gmax * 2 + 15) & ~(size_t)15) + 16;
+  const size_t mlds = (size_t)out.cap * kstride * 16 + (size_t)out.cap * 4 + (((size_t)nb * gmax * 2 + 15) & ~(size_t)15) + 32 + (size_t)out.cap * A.n_accs * 16;
   if (mlds > 60 * 1024 && mlds > attr_merge) {
     if (hipFuncSetAttribute((const void*)k_agg_tiny_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) == hipSuccess) attr_merge = mlds;
     else (void)hipGetLastError();

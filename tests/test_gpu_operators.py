@@ -1,0 +1,388 @@
+"""Parity of every operator on the device path against the oracle (oracle/oracle_np.py), on seeded
+random Arrow tables: FilterExec, ProjectionExec, AggregateExec (all modes / strategies), HashJoinExec
+(all join types), SortExec, hash repartition and the ShuffleWriterExec stage driver.  Bit-exact for
+integer / decimal / string / index results; float64 SUM/AVG within 1e-9 relative (order of adds differs)."""
+import decimal
+import math
+import os
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import arrow_ballista_amd as g
+from arrow_ballista_amd.expr import Operator as Op
+from arrow_ballista_amd.expr import (and_, binary, case, cast, col, in_list, is_not_null, is_null, lit, negative, not_, or_)
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+D152 = ("Decimal128", 15, 2)
+
+
+def rand_table(seed, n, nulls=0.0):
+    r = np.random.default_rng(seed)
+
+    def mask():
+        return (r.random(n) < nulls) if nulls > 0 else None
+    dec = [decimal.Decimal(int(v)).scaleb(-2) for v in r.integers(-10**9, 10**9, n)]
+    segs = np.array(["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY", "", "x"])
+    cols = {
+        "k64": pa.array(r.integers(0, max(2, n // 3), n), type=pa.int64(), mask=mask()),
+        "k32": pa.array(r.integers(-50, 50, n).astype(np.int32), type=pa.int32(), mask=mask()),
+        "d": pa.array(r.integers(8000, 10500, n).astype(np.int32), type=pa.int32(), mask=mask()).cast(pa.date32()),
+        "dec": pa.array(dec, type=pa.decimal128(15, 2), mask=mask()),
+        "f": pa.array(r.normal(0, 1e3, n), type=pa.float64(), mask=mask()),
+        "s": pa.array(segs[r.integers(0, len(segs), n)], type=pa.string(), mask=mask()),
+        "flag": pa.array(np.array(["A", "N", "R"])[r.integers(0, 3, n)], type=pa.string(), mask=mask()),
+        "b": pa.array(r.integers(0, 2, n).astype(bool), type=pa.bool_(), mask=mask()),
+    }
+    fields = [pa.field(k, v.type, nullable=nulls > 0) for k, v in cols.items()]
+    return pa.Table.from_arrays(list(cols.values()), schema=pa.schema(fields))
+
+
+def dev_rows(tc, table):
+    import tpch_util as T
+    return T.table_to_rows(tc, g.plan.materialize(tc, table))
+
+
+def ora_rows(t):
+    return [tuple(r) for r in t.rows()]
+
+
+def norm(rows):
+    return sorted(rows, key=lambda r: tuple((x is None, 0 if x is None else x) if not isinstance(x, float) else (x is None, O.total_order_key(x)) for x in r))
+
+
+def close_rows(a, b, rel=1e-9):
+    assert len(a) == len(b), (len(a), len(b))
+    for ra, rb in zip(a, b):
+        assert len(ra) == len(rb)
+        for x, y in zip(ra, rb):
+            if isinstance(x, float) or isinstance(y, float):
+                if x is None or y is None:
+                    assert x is None and y is None, (ra, rb)
+                elif math.isnan(x) or math.isnan(y):
+                    assert math.isnan(x) and math.isnan(y), (ra, rb)
+                else:
+                    assert abs(x - y) <= rel * max(1.0, abs(x), abs(y)), (ra, rb)
+            else:
+                assert x == y, (ra, rb)
+
+
+# ------------------------------------------------------------------------------------ filter
+PREDICATES = [
+    lambda s: binary(col("k32", s), Op.Gt, lit(0, "Int32")),
+    lambda s: and_(binary(col("d", s), Op.LtEq, lit(9500, "Date32")), binary(col("dec", s), Op.Gt, lit(0, D152))),
+    lambda s: or_(binary(col("s", s), Op.Eq, lit("BUILDING")), binary(col("flag", s), Op.NotEq, lit("A"))),
+    lambda s: binary(binary(col("dec", s), Op.Multiply, lit(3)), Op.Lt, binary(col("k64", s), Op.Plus, lit(100))),
+    lambda s: in_list(col("s", s), [lit("MACHINERY"), lit("x"), lit("")]),
+    lambda s: not_(in_list(col("k32", s), [lit(1, "Int32"), lit(2, "Int32")])),
+    lambda s: or_(is_null(col("f", s)), binary(col("f", s), Op.Lt, lit(0.0))),
+    lambda s: and_(col("b", s), is_not_null(col("k64", s))),
+    lambda s: binary(col("f", s), Op.GtEq, cast(col("k32", s), "Float64")),
+    lambda s: binary(case([(binary(col("k32", s), Op.Lt, lit(0, "Int32")), negative(col("k32", s)))], col("k32", s)), Op.Gt, lit(25, "Int32")),
+]
+
+
+@pytest.mark.parametrize("nulls", [0.0, 0.2])
+@pytest.mark.parametrize("n", [0, 1, 64, 1000, 70_001])
+def test_filter_exec(tc, n, nulls):
+    t = rand_table(n + 1, n, nulls)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    for mk in PREDICATES:
+        pred = mk(s)
+        got = dev_rows(tc, g.FilterExec(pred, src).execute(0, tc))
+        exp = ora_rows(ot.take(O.filter_rows(ot, pred)))
+        close_rows(got, exp)        # order preserved: FilterExec keeps input order
+
+
+def test_filter_of_filter_and_projection(tc):
+    t = rand_table(5, 5000, 0.1)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    p1 = binary(col("k32", s), Op.Gt, lit(-10, "Int32"))
+    p2 = binary(col("dec", s), Op.Lt, lit(500000, D152))
+    exprs = [(binary(col("dec", s), Op.Multiply, binary(lit(1, ("Decimal128", 20, 0)), Op.Minus, col("dec", s))), "x"),
+             (binary(col("k64", s), Op.Plus, cast(col("k32", s), "Int64")), "y"), (col("s", s), "s"), (col("f", s), "f"),
+             (binary(col("f", s), Op.Multiply, lit(2.0)), "f2"), (binary(col("k32", s), Op.Gt, lit(3, "Int32")), "flagb")]
+    plan = g.ProjectionExec(exprs, g.FilterExec(p2, g.CoalesceBatchesExec(g.FilterExec(p1, src))))
+    got = dev_rows(tc, plan.execute(0, tc))
+    sub = ot.take(O.filter_rows(ot, and_(p1, p2)))
+    exp = ora_rows(O.project(sub, [e for e, _ in exprs], [n for _, n in exprs]))
+    close_rows(got, exp)
+
+
+def test_projection_decimal_types_and_cast(tc):
+    t = rand_table(9, 3000, 0.1)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    exprs = [(binary(col("dec", s), Op.Plus, lit(1)), "a"), (binary(col("dec", s), Op.Minus, col("k64", s)), "b"),
+             (binary(binary(col("dec", s), Op.Multiply, col("dec", s)), Op.Multiply, lit(7, D152)), "c"),
+             (cast(col("dec", s), ("Decimal128", 20, 4)), "up"), (cast(col("dec", s), ("Decimal128", 12, 0)), "down"),
+             (cast(col("dec", s), "Float64"), "tf"), (cast(col("k32", s), ("Decimal128", 12, 2)), "i2d"),
+             (binary(col("k64", s), Op.Divide, cast(col("k32", s), "Int64")), "idiv"), (binary(col("k64", s), Op.Modulo, lit(7)), "imod")]
+    plan = g.ProjectionExec(exprs, src)
+    got = dev_rows(tc, plan.execute(0, tc))
+    exp = ora_rows(O.project(ot, [e for e, _ in exprs], [n for _, n in exprs]))
+    close_rows(got, exp)
+    # declared result types follow the DataFusion rules
+    ty = {f["name"]: f["type"] for f in plan.schema()}
+    assert ty["a"] == {"Decimal128": [24, 2]} and ty["c"] == {"Decimal128": [38, 6]} and ty["up"] == {"Decimal128": [20, 4]}
+
+
+# ------------------------------------------------------------------------------------ aggregate
+def agg_cases(s):
+    return [
+        ([(col("flag", s), "flag")], [{"fn": "SUM", "expr": col("dec", s), "name": "sd"}, {"fn": "AVG", "expr": col("dec", s), "name": "ad"},
+                                       {"fn": "COUNT", "expr": lit(1), "name": "c"}, {"fn": "COUNT", "expr": col("k64", s), "name": "ck"},
+                                       {"fn": "MIN", "expr": col("k32", s), "name": "mn"}, {"fn": "MAX", "expr": col("d", s), "name": "mx"}]),
+        ([(col("flag", s), "flag"), (col("s", s), "s")], [{"fn": "SUM", "expr": col("k64", s), "name": "sk"}, {"fn": "AVG", "expr": col("k32", s), "name": "ak"},
+                                                           {"fn": "SUM", "expr": col("f", s), "name": "sf"}, {"fn": "MIN", "expr": col("f", s), "name": "mf"},
+                                                           {"fn": "MAX", "expr": col("dec", s), "name": "xd"}]),
+        ([], [{"fn": "SUM", "expr": binary(col("dec", s), Op.Multiply, col("dec", s)), "name": "s2"}, {"fn": "COUNT", "expr": lit(1), "name": "c"},
+              {"fn": "AVG", "expr": col("f", s), "name": "af"}, {"fn": "MIN", "expr": col("dec", s), "name": "md"}]),
+        ([(col("k64", s), "k64")], [{"fn": "SUM", "expr": col("dec", s), "name": "sd"}, {"fn": "COUNT", "expr": lit(1), "name": "c"},
+                                    {"fn": "MAX", "expr": col("k32", s), "name": "mx"}, {"fn": "AVG", "expr": col("dec", s), "name": "ad"}]),
+        ([(col("k64", s), "k64"), (col("d", s), "d"), (col("k32", s), "k32")], [{"fn": "SUM", "expr": col("dec", s), "name": "sd"}]),
+    ]
+
+
+@pytest.mark.parametrize("nulls", [0.0, 0.15])
+@pytest.mark.parametrize("n", [0, 1, 500, 40_000])
+def test_aggregate_single(tc, n, nulls):
+    t = rand_table(100 + n, n, nulls)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    for groups, aggs in agg_cases(s):
+        got = norm(dev_rows(tc, g.AggregateExec("Single", groups, aggs, src).execute(0, tc)))
+        exp = norm(ora_rows(O.aggregate(ot, groups, aggs, "Single")))
+        close_rows(got, exp)
+
+
+@pytest.mark.parametrize("strategy", ["tiny", "hash"])
+def test_aggregate_partial_final_and_strategies(tc, strategy):
+    parts = [rand_table(7 + i, 20_000, 0.1) for i in range(3)]
+    src = g.MemoryExec(parts)
+    s = src.schema()
+    ot_all = O.Table.from_arrow(pa.concat_tables(parts))
+    for groups, aggs in agg_cases(s)[:3]:
+        partial = g.AggregateExec("Partial", groups, aggs, g.FilterExec(is_not_null(col("k32", s)), src), strategy=strategy)
+        states = [g.plan.materialize(tc, partial.execute(p, tc)).to_arrow(tc.ctx) for p in range(3)]
+        merged = g.MemoryExec([pa.concat_tables(states)])
+        fs = merged.schema()
+        final = g.AggregateExec("FinalPartitioned", [(col(n, fs), n) for _, n in groups], [dict(a, expr=None) for a in aggs], merged)
+        got = norm(dev_rows(tc, final.execute(0, tc)))
+        exp = norm(ora_rows(O.aggregate(ot_all, groups, aggs, "Single", predicate=is_not_null(col("k32", s)))))
+        close_rows(got, exp)
+        # the oracle's own two-phase path gives the same
+        ost = [O.aggregate(O.Table.from_arrow(p), groups, aggs, "Partial", predicate=is_not_null(col("k32", s))) for p in parts]
+        cat = O.Table(ost[0].names, ost[0].types, [sum((o.cols[i] for o in ost), []) for i in range(len(ost[0].names))])
+        exp2 = norm(ora_rows(O.aggregate(cat, [({"column": {"name": n}}, n) for _, n in groups], aggs, "Final")))
+        close_rows(got, exp2)
+
+
+def test_aggregate_kat_alltypes_plain(tc):
+    """Known answers of the reference's own test-suite (ballista/client/src/context.rs:762-967) over
+    ballista/client/testdata/alltypes_plain.parquet, committed as tests/golden/alltypes_plain.arrow."""
+    with pa.ipc.open_file(os.path.join(os.path.dirname(__file__), "golden", "alltypes_plain.arrow")) as f:
+        t = f.read_all().select(["id", "bigint_col", "double_col"])
+    src = g.MemoryExec([t])
+    s = src.schema()
+    aggs = [{"fn": fn, "expr": col("id", s), "name": fn} for fn in ("MIN", "MAX", "SUM", "AVG", "COUNT")]
+    got = dev_rows(tc, g.AggregateExec("Single", [], aggs, src).execute(0, tc))
+    assert got == [(0, 7, 28, 3.5, 8)]
+
+
+# ------------------------------------------------------------------------------------ join
+def pairs_of(tc, view, nl):
+    """(left_row | None, right_row | None) pairs of a join view built over tables that carry a row-id column."""
+    rows = dev_rows(tc, view)
+    return rows
+
+
+JOIN_TYPES = ["Inner", "Left", "Right", "Full", "LeftSemi", "LeftAnti", "RightSemi", "RightAnti"]
+
+
+@pytest.mark.parametrize("nulls", [0.0, 0.2])
+@pytest.mark.parametrize("jt", JOIN_TYPES)
+def test_hash_join_types(tc, jt, nulls):
+    nl, nr = 3000, 7000
+    lt = rand_table(21, nl, nulls).append_column("lid", pa.array(np.arange(nl, dtype=np.int64)))
+    rt = rand_table(22, nr, nulls).append_column("rid", pa.array(np.arange(nr, dtype=np.int64)))
+    rt = rt.rename_columns([c if c == "rid" else "r_" + c for c in rt.schema.names])
+    L, R = g.MemoryExec([lt]), g.MemoryExec([rt])
+    ls, rs = L.schema(), R.schema()
+    ol, orr = O.Table.from_arrow(lt), O.Table.from_arrow(rt)
+    for on in ([(col("k64", ls), col("r_k64", rs))],                       # duplicate keys on both sides
+               [(col("k32", ls), col("r_k32", rs)), (col("flag", ls), col("r_flag", rs))],   # composite int + string key
+               [(col("dec", ls), col("r_dec", rs))]):
+        plan = g.HashJoinExec(L, R, on, None, jt, "CollectLeft", False)
+        if jt in ("LeftSemi", "LeftAnti"):
+            proj = g.ProjectionExec([(col("lid", ls), "lid")], plan)
+            got = sorted(r[0] for r in dev_rows(tc, proj.execute(0, tc)))
+            exp = sorted(i for i, _ in O.hash_join(ol, orr, on, jt))
+        elif jt in ("RightSemi", "RightAnti"):
+            proj = g.ProjectionExec([(col("rid", rs), "rid")], plan)
+            got = sorted(r[0] for r in dev_rows(tc, proj.execute(0, tc)))
+            exp = sorted(j for _, j in O.hash_join(ol, orr, on, jt))
+        else:
+            js = plan.schema()
+            proj = g.ProjectionExec([(col("lid", js), "lid"), (col("rid", js), "rid"), (col("s", js), "s"), (col("r_dec", js), "r_dec")], plan)
+            got = norm(dev_rows(tc, proj.execute(0, tc)))
+            exp = norm([(i, j, None if i is None else ol.col("s")[i], None if j is None else orr.col("r_dec")[j]) for i, j in O.hash_join(ol, orr, on, jt)])
+        assert got == exp, (jt, on)
+
+
+def test_hash_join_null_equals_null_and_fused_filters(tc):
+    nl, nr = 2000, 5000
+    lt = rand_table(31, nl, 0.3).append_column("lid", pa.array(np.arange(nl, dtype=np.int64)))
+    rt = rand_table(32, nr, 0.3).append_column("rid", pa.array(np.arange(nr, dtype=np.int64)))
+    rt = rt.rename_columns([c if c == "rid" else "r_" + c for c in rt.schema.names])
+    L, R = g.MemoryExec([lt]), g.MemoryExec([rt])
+    ls, rs = L.schema(), R.schema()
+    ol, orr = O.Table.from_arrow(lt), O.Table.from_arrow(rt)
+    lp = binary(col("k32", ls), Op.Gt, lit(-20, "Int32"))
+    rp = binary(col("r_d", rs), Op.Lt, lit(10000, "Date32"))
+    on = [(col("k32", ls), col("r_k32", rs))]
+    plan = g.HashJoinExec(g.FilterExec(lp, L), g.CoalesceBatchesExec(g.FilterExec(rp, R)), on, None, "Inner", "CollectLeft", True)
+    js = plan.schema()
+    got = norm(dev_rows(tc, g.ProjectionExec([(col("lid", js), "lid"), (col("rid", js), "rid")], plan).execute(0, tc)))
+    exp = norm(O.hash_join(ol, orr, on, "Inner", null_equals_null=True, left_pred=lp, right_pred=rp))
+    assert got == exp
+    # residual JoinFilter on an inner join
+    jf = binary(col("dec", js), Op.Lt, col("r_dec", js))
+    plan2 = g.HashJoinExec(L, R, on, jf, "Inner", "CollectLeft", False)
+    got2 = norm(dev_rows(tc, g.ProjectionExec([(col("lid", js), "lid"), (col("rid", js), "rid")], plan2).execute(0, tc)))
+    exp2 = norm([(i, j) for i, j in O.hash_join(ol, orr, on, "Inner")
+                 if ol.col("dec")[i] is not None and orr.col("r_dec")[j] is not None and ol.col("dec")[i] < orr.col("r_dec")[j]])
+    assert got2 == exp2
+
+
+def test_join_then_aggregate_then_sort_pipeline(tc):
+    """q3-shaped: filter -> join -> join -> group-by -> sort, all through late-materialised views."""
+    r = np.random.default_rng(3)
+    nc, no, nl = 500, 3000, 12000
+    cust = pa.table({"c_custkey": pa.array(np.arange(1, nc + 1, dtype=np.int64)), "c_seg": pa.array(np.array(["BUILDING", "MACHINERY", "HOUSEHOLD"])[r.integers(0, 3, nc)])})
+    orders = pa.table({"o_orderkey": pa.array(np.arange(1, no + 1, dtype=np.int64) * 4), "o_custkey": pa.array(r.integers(1, nc + 1, no)),
+                       "o_orderdate": pa.array(r.integers(9000, 9400, no).astype(np.int32)).cast(pa.date32()), "o_shippriority": pa.array(np.zeros(no, dtype=np.int32))})
+    li = pa.table({"l_orderkey": pa.array(r.integers(1, no + 1, nl) * 4), "l_extendedprice": pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in r.integers(90000, 10**7, nl)], type=pa.decimal128(15, 2)),
+                   "l_discount": pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in r.integers(0, 11, nl)], type=pa.decimal128(15, 2)),
+                   "l_shipdate": pa.array(r.integers(9000, 9500, nl).astype(np.int32)).cast(pa.date32())})
+    C, Od, Li = g.MemoryExec([cust]), g.MemoryExec([orders]), g.MemoryExec([li])
+    cs, os_, lsch = C.schema(), Od.schema(), Li.schema()
+    cut = 9200
+    j1 = g.HashJoinExec(g.FilterExec(binary(col("c_seg", cs), Op.Eq, lit("BUILDING")), C),
+                        g.FilterExec(binary(col("o_orderdate", os_), Op.Lt, lit(cut, "Date32")), Od),
+                        [(col("c_custkey", cs), col("o_custkey", os_))], None, "Inner", "CollectLeft", False)
+    j1s = j1.schema()
+    j2 = g.HashJoinExec(j1, g.FilterExec(binary(col("l_shipdate", lsch), Op.Gt, lit(cut, "Date32")), Li),
+                        [(col("o_orderkey", j1s), col("l_orderkey", lsch))], None, "Inner", "CollectLeft", False)
+    j2s = j2.schema()
+    rev = binary(col("l_extendedprice", j2s), Op.Multiply, binary(lit(1, ("Decimal128", 20, 0)), Op.Minus, col("l_discount", j2s)))
+    agg = g.AggregateExec("Single", [(col("l_orderkey", j2s), "l_orderkey"), (col("o_orderdate", j2s), "o_orderdate"), (col("o_shippriority", j2s), "o_shippriority")],
+                          [{"fn": "SUM", "expr": rev, "name": "revenue"}], j2)
+    as_ = agg.schema()
+    plan = g.SortExec([{"expr": col("revenue", as_), "asc": False, "nulls_first": True}, {"expr": col("o_orderdate", as_), "asc": True, "nulls_first": False}], agg)
+    got = dev_rows(tc, plan.execute(0, tc))
+    # oracle
+    oc, oo, ol = O.Table.from_arrow(cust), O.Table.from_arrow(orders), O.Table.from_arrow(li)
+    p1 = O.hash_join(oc, oo, [(col("c_custkey", cs), col("o_custkey", os_))], "Inner", left_pred=binary(col("c_seg", cs), Op.Eq, lit("BUILDING")),
+                     right_pred=binary(col("o_orderdate", os_), Op.Lt, lit(cut, "Date32")))
+    okeys = {}
+    for _, j in p1:
+        okeys.setdefault(oo.col("o_orderkey")[j], []).append(j)
+    groups = {}
+    for i in range(ol.n):
+        if ol.col("l_shipdate")[i] > cut:
+            for j in okeys.get(ol.col("l_orderkey")[i], []):
+                k = (ol.col("l_orderkey")[i], oo.col("o_orderdate")[j], oo.col("o_shippriority")[j])
+                groups[k] = groups.get(k, 0) + ol.col("l_extendedprice")[i] * (100 - ol.col("l_discount")[i])
+    exp = sorted(((k[0], k[1], k[2], v) for k, v in groups.items()), key=lambda x: (-x[3], x[1]))
+    assert len(got) == len(exp)
+    assert [(r_[3], r_[1]) for r_ in got] == [(e[3], e[1]) for e in exp]       # ORDER BY columns in order
+    assert norm(got) == norm(exp)
+
+
+# ------------------------------------------------------------------------------------ sort
+@pytest.mark.parametrize("nulls", [0.0, 0.2])
+@pytest.mark.parametrize("n", [0, 1, 2, 257, 10_000, 300_000])
+def test_sort_exec(tc, n, nulls):
+    t = rand_table(40 + n, n, nulls)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    for spec in ([{"expr": col("k32", s), "asc": True, "nulls_first": False}],
+                 [{"expr": col("dec", s), "asc": False, "nulls_first": True}, {"expr": col("d", s), "asc": True, "nulls_first": False}],
+                 [{"expr": col("flag", s), "asc": True, "nulls_first": True}, {"expr": col("s", s), "asc": False, "nulls_first": False}, {"expr": col("k64", s), "asc": True, "nulls_first": False}],
+                 [{"expr": col("f", s), "asc": False, "nulls_first": False}],
+                 [{"expr": binary(col("k64", s), Op.Minus, cast(col("k32", s), "Int64")), "asc": True, "nulls_first": False}]):
+        plan = g.SortExec(spec, g.ProjectionExec([(col(c, s), c) for c in ("k64", "k32", "d", "dec", "f", "s", "flag")], src))
+        got = dev_rows(tc, plan.execute(0, tc))
+        keys = O.sort_keys(ot, spec)
+        # sortedness on the oracle's key function + same multiset of rows
+        got_t = O.Table(ot.names[:7], ot.types[:7], [list(c) for c in zip(*got)] if got else [[] for _ in range(7)])
+        gk = O.sort_keys(got_t, spec)
+        assert all(gk[i] <= gk[i + 1] for i in range(len(gk) - 1))
+        exp = [tuple(c[i] for c in ot.cols[:7]) for i in O.sort_perm(ot, spec)]
+        close_rows(norm(got), norm(exp))
+        assert [k for k in gk] == sorted(keys)
+
+
+def test_sort_fetch(tc):
+    t = rand_table(77, 5000, 0.0)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    spec = [{"expr": col("dec", s), "asc": False, "nulls_first": True}, {"expr": col("k64", s), "asc": True, "nulls_first": False}]
+    got = dev_rows(tc, g.SortExec(spec, g.ProjectionExec([(col("dec", s), "dec"), (col("k64", s), "k64")], src), fetch=10).execute(0, tc))
+    exp = [(ot.col("dec")[i], ot.col("k64")[i]) for i in O.sort_perm(ot, spec)[:10]]
+    assert got == exp
+
+
+# ------------------------------------------------------------------------------------ partition / shuffle
+@pytest.mark.parametrize("nparts", [1, 2, 16, 200, 1000])
+def test_hash_partition(tc, nparts):
+    t = rand_table(55, 20_000, 0.1)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    for keys in ([col("k64", s)], [col("k32", s), col("flag", s)], [col("dec", s)]):
+        views = g.RepartitionExec(src, keys, nparts).execute_all(0, tc)
+        pid = O.hash_partition(ot, keys, nparts)
+        assert sum(v.num_rows for v in views) == t.num_rows
+        for p, v in enumerate(views):
+            got = dev_rows(tc, v)
+            exp = [tuple(c[i] for c in ot.cols) for i in range(ot.n) if pid[i] == p]    # input order kept inside a partition
+            close_rows(got, exp)
+
+
+def test_shuffle_writer_round_trip(tc, tmp_path):
+    """Stage driver: files in the reference's layout, LZ4-framed Arrow IPC streams, exact row counts
+    (readers drop locations with num_rows == 0, shuffle_reader.rs:251)."""
+    parts = [rand_table(60 + i, 5000, 0.1) for i in range(2)]
+    src = g.MemoryExec(parts)
+    s = src.schema()
+    plan = g.ShuffleWriterExec("job1", 3, g.FilterExec(binary(col("k32", s), Op.Gt, lit(0, "Int32")), src), "", ([col("k64", s)], 4))
+    stage = g.DefaultExecutionEngine().create_query_stage_exec("job1", 3, plan, str(tmp_path))
+    out = stage.execute_query_stage([0, 1], tc)
+    ot = O.Table.from_arrow(pa.concat_tables(parts))
+    keep = O.filter_rows(ot, binary(col("k32", s), Op.Gt, lit(0, "Int32")))
+    assert sum(o["num_rows"] for o in out) == len(keep)
+    seen = []
+    for o in out:
+        assert o["path"].startswith(os.path.join(str(tmp_path), "job1", "3", str(o["partition_id"])))
+        with pa.OSFile(o["path"], "rb") as f:
+            rd = pa.ipc.open_stream(f).read_all()
+        assert rd.num_rows == o["num_rows"] and o["num_rows"] > 0
+        pid = O.hash_partition(O.Table.from_arrow(rd), [col("k64", s)], 4)
+        assert set(pid) == {o["partition_id"]}
+        seen += ora_rows(O.Table.from_arrow(rd))
+    close_rows(norm(seen), norm(ora_rows(ot.take(keep))))
+    with pytest.raises(g.GpuqError):
+        g.DefaultExecutionEngine().create_query_stage_exec("j", 1, src, str(tmp_path))
+    assert stage.collect_plan_metrics()[0]["output_rows"] > 0
