@@ -244,7 +244,7 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
         pl.arg_type = t_of(T_INT64);
       } else {
         if (!arg) throw std::runtime_error(pl.fn + " needs an argument");
-        pl.arg_type = arg->type; pl.arg_nullable = arg->nullable;
+        pl.arg_type = arg->type; pl.arg_nullable = arg->nullable || key_nodes.empty();   // ungrouped: zero input rows -> NULL
         auto count_of = [&](NodeP x) { return x->nullable ? find_or_add_acc(accs, ACC_COUNT, x, t_of(T_INT64)) : find_or_add_acc(accs, ACC_COUNT_STAR, nullptr, t_of(T_INT64)); };
         if (pl.fn == "SUM" || pl.fn == "AVG") {
           if (arg->type.is_decimal()) {
@@ -256,13 +256,13 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
             NodeP x = ec.cast(arg, t_of(T_FLOAT64)); pl.is_float = true;
             pl.acc_sum = find_or_add_acc(accs, ACC_FSUM, x, t_of(T_FLOAT64));
           } else throw Unsupported(pl.fn + " over " + arg->type.to_string());
-          if (pl.fn == "AVG" || arg->nullable) pl.acc_cnt = count_of(arg);
+          if (pl.fn == "AVG" || pl.arg_nullable) pl.acc_cnt = count_of(arg);
         } else if (pl.fn == "MIN" || pl.fn == "MAX") {
           const bool mn = pl.fn == "MIN";
           if (arg->type.is_float()) { pl.is_float = true; pl.acc_mm = find_or_add_acc(accs, mn ? ACC_FMIN : ACC_FMAX, arg, arg->type); }
           else if (arg->type.is_int() || arg->type.is_decimal() || arg->type.id == T_DATE32) pl.acc_mm = find_or_add_acc(accs, mn ? ACC_MIN : ACC_MAX, arg, arg->type);
           else throw Unsupported(pl.fn + " over " + arg->type.to_string());
-          if (arg->nullable) pl.acc_cnt = count_of(arg);
+          if (pl.arg_nullable) pl.acc_cnt = count_of(arg);
         } else throw Unsupported("aggregate function " + pl.fn);
       }
     } else {
@@ -270,20 +270,20 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
       auto state = [&](void) { if (state_col >= op->in_schema.fields.size()) throw std::runtime_error("Final aggregate: input has too few state columns"); return ec.column((int)state_col++); };
       if (pl.fn == "COUNT") { NodeP c = state(); pl.acc_cnt = find_or_add_acc(accs, ACC_SUM, ec.cast(c, t_of(T_INT64)), t_of(T_INT64)); pl.arg_type = t_of(T_INT64); }
       else if (pl.fn == "SUM") {
-        NodeP s = state(); pl.arg_type = s->type; pl.arg_nullable = s->nullable;
-        if (s->type.is_float()) { pl.is_float = true; pl.acc_sum = find_or_add_acc(accs, ACC_FSUM, s, s->type); }
+        NodeP s = state(); pl.arg_type = s->type; pl.arg_nullable = s->nullable || key_nodes.empty();
+        if (s->type.is_float()) { pl.is_float = true; pl.acc_sum = find_or_add_acc(accs, ACC_FSUM, ec.coalesce0(s), s->type); }
         else pl.acc_sum = find_or_add_acc(accs, ACC_SUM, s, s->type);
-        if (s->nullable) pl.acc_cnt = find_or_add_acc(accs, ACC_COUNT, s, t_of(T_INT64));
+        if (pl.arg_nullable) pl.acc_cnt = s->nullable ? find_or_add_acc(accs, ACC_COUNT, s, t_of(T_INT64)) : find_or_add_acc(accs, ACC_COUNT_STAR, nullptr, t_of(T_INT64));
       } else if (pl.fn == "AVG") {
         NodeP c = state(); NodeP s = state(); pl.arg_type = s->type;
         pl.acc_cnt = find_or_add_acc(accs, ACC_SUM, ec.cast(c, t_of(T_INT64)), t_of(T_INT64));
         if (s->type.is_float()) { pl.is_float = true; pl.acc_sum = find_or_add_acc(accs, ACC_FSUM, ec.coalesce0(s), s->type); }
         else pl.acc_sum = find_or_add_acc(accs, ACC_SUM, s, s->type);
       } else if (pl.fn == "MIN" || pl.fn == "MAX") {
-        NodeP s = state(); const bool mn = pl.fn == "MIN"; pl.arg_type = s->type; pl.arg_nullable = s->nullable;
+        NodeP s = state(); const bool mn = pl.fn == "MIN"; pl.arg_type = s->type; pl.arg_nullable = s->nullable || key_nodes.empty();
         if (s->type.is_float()) { pl.is_float = true; pl.acc_mm = find_or_add_acc(accs, mn ? ACC_FMIN : ACC_FMAX, s, s->type); }
         else pl.acc_mm = find_or_add_acc(accs, mn ? ACC_MIN : ACC_MAX, s, s->type);
-        if (s->nullable) pl.acc_cnt = find_or_add_acc(accs, ACC_COUNT, s, t_of(T_INT64));
+        if (pl.arg_nullable) pl.acc_cnt = s->nullable ? find_or_add_acc(accs, ACC_COUNT, s, t_of(T_INT64)) : find_or_add_acc(accs, ACC_COUNT_STAR, nullptr, t_of(T_INT64));
       } else throw Unsupported("aggregate function " + pl.fn);
     }
     plans.push_back(pl);

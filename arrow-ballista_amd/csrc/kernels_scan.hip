@@ -201,7 +201,8 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny(const DevProgram P, const i6
   const int tid = threadIdx.x;
   for (int c = 0; c < cells; ++c) L.lane_acc[c * BLOCK + tid] = acc_identity(A.acc_kind[c % n_accs]);
   for (int c = tid; c < cells * 2; c += BLOCK) L.wide[c] = 0;
-  if (tid == 0) { *L.dict_n = 0; *L.lock = 0; }
+  // an aggregate without GROUP BY always has exactly one group, even over zero rows
+  if (tid == 0) { *L.dict_n = (n_keys == 0) ? 1u : 0u; *L.lock = 0; L.dnulls[0] = 0; }
   __syncthreads();
 
   volatile uint32_t* vn = L.dict_n;
