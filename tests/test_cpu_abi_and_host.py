@@ -1,0 +1,126 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gpuq.h declares; the host logic
+(descriptor parsing, expression typing = DataFusion's decimal rules, register allocation, plan schema
+propagation) works without a device; the product path refuses to run without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import arrow_ballista_amd as g
+from arrow_ballista_amd.expr import Operator as Op
+from arrow_ballista_amd.expr import binary, case, cast, col, in_list, lit
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+D152 = {"Decimal128": [15, 2]}
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gpuq.h")).read()
+    declared = set(re.findall(r"\b(gpuq_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"gpuq_status"}
+    L = C.CDLL(g.lib_path())
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert len(declared) >= 30
+    assert g.lib().gpuq_abi_version() == 1
+    assert set(g.lib()._gpuq_symbols) <= declared | {"gpuq_abi_version"}
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(g.GpuqError) as e:
+        g.Context(0)
+    assert "no CPU fallback" in str(e.value)
+
+
+FIELDS = [{"name": "q", "type": D152, "nullable": False}, {"name": "e", "type": D152, "nullable": False}, {"name": "d", "type": D152, "nullable": True},
+          {"name": "i", "type": "Int64", "nullable": False}, {"name": "j", "type": "Int32", "nullable": False}, {"name": "f", "type": "Float64", "nullable": False},
+          {"name": "s", "type": "Utf8", "nullable": False}, {"name": "dt", "type": "Date32", "nullable": False}]
+
+
+def out_types(exprs):
+    d = g.compile_check({"op": "project", "input": {"fields": FIELDS}, "exprs": [{"expr": e, "name": "c%d" % i} for i, e in enumerate(exprs)]})
+    return [o["type"] for o in d["outputs"]], d
+
+
+def test_decimal_type_rules():
+    one = lit(1, ("Decimal128", 20, 0))
+    t, d = out_types([
+        binary(one, Op.Minus, col("d", FIELDS)),                                   # (20,0)-(15,2) -> (23,2)
+        binary(col("e", FIELDS), Op.Multiply, binary(one, Op.Minus, col("d", FIELDS))),   # (15,2)*(23,2) -> (38,4)
+        binary(binary(col("e", FIELDS), Op.Multiply, binary(one, Op.Minus, col("d", FIELDS))), Op.Multiply, binary(one, Op.Plus, col("q", FIELDS))),
+        binary(col("q", FIELDS), Op.Plus, col("i", FIELDS)),                       # Int64 -> (20,0): max(13,20)+2+1
+        binary(col("q", FIELDS), Op.Multiply, col("j", FIELDS)),                   # Int32 -> (10,0): 15+10+1
+        binary(col("i", FIELDS), Op.Plus, col("j", FIELDS)),
+        binary(col("f", FIELDS), Op.Multiply, col("q", FIELDS)),
+        cast(col("q", FIELDS), ("Decimal128", 20, 4)),
+        binary(col("q", FIELDS), Op.Lt, col("i", FIELDS)),
+        case([(binary(col("j", FIELDS), Op.Gt, lit(0, "Int32")), col("q", FIELDS))], lit(0)),
+    ])
+    assert t == ["Decimal128(23,2)", "Decimal128(38,4)", "Decimal128(38,6)", "Decimal128(23,2)", "Decimal128(26,2)", "Int64", "Float64",
+                 "Decimal128(20,4)", "Boolean", "Decimal128(22,2)"]
+    # the shared subexpression e*(1-d) is evaluated once (CSE) and 64x64->128 multiplies are used when ranges allow
+    insns = " ".join(d["program"]["insns"])
+    assert insns.count("MULW") >= 1 and "MUL r" in insns
+
+
+def test_aggregate_schema_and_states():
+    groups = [{"expr": col("s", FIELDS), "name": "s"}]
+    aggs = [{"fn": "SUM", "expr": col("q", FIELDS), "name": "SUM(q)"}, {"fn": "AVG", "expr": col("q", FIELDS), "name": "AVG(q)"},
+            {"fn": "AVG", "expr": col("i", FIELDS), "name": "AVG(i)"}, {"fn": "COUNT", "expr": lit(1), "name": "COUNT(*)"},
+            {"fn": "SUM", "expr": col("j", FIELDS), "name": "SUM(j)"}, {"fn": "MIN", "expr": col("dt", FIELDS), "name": "MIN(dt)"}]
+    part = g.compile_check({"op": "aggregate", "mode": "Partial", "input": {"fields": FIELDS}, "group_expr": groups, "aggr_expr": aggs})
+    assert [(o["name"], o["type"]) for o in part["outputs"]] == [
+        ("s", "Utf8"), ("SUM(q)[sum]", "Decimal128(25,2)"), ("AVG(q)[count]", "UInt64"), ("AVG(q)[sum]", "Decimal128(25,2)"),
+        ("AVG(i)[count]", "UInt64"), ("AVG(i)[sum]", "Float64"), ("COUNT(*)[count]", "Int64"), ("SUM(j)[sum]", "Int64"), ("MIN(dt)[min]", "Date32")]
+    # SUM(q) and AVG(q) share one accumulator; COUNT(*) and the AVG counts share another
+    assert len(part["acc_kinds"]) == 5
+    single = g.compile_check({"op": "aggregate", "mode": "Single", "input": {"fields": FIELDS}, "group_expr": groups, "aggr_expr": aggs})
+    assert [o["type"] for o in single["outputs"]] == ["Utf8", "Decimal128(25,2)", "Decimal128(19,6)", "Float64", "Int64", "Int64", "Date32"]
+
+
+def test_descriptor_errors_are_loud():
+    for bad, msg in [
+        ({"op": "filter", "input": {"fields": FIELDS}, "predicate": col("q", FIELDS)}, "predicate must be boolean"),
+        ({"op": "project", "input": {"fields": FIELDS}, "exprs": [{"expr": binary(col("s", FIELDS), Op.Plus, lit(1)), "name": "x"}]}, "unsupported operands"),
+        ({"op": "project", "input": {"fields": FIELDS}, "exprs": [{"expr": binary(col("s", FIELDS), Op.Eq, lit("a string longer than fifteen bytes")), "name": "x"}]}, "15 bytes"),
+        ({"op": "frobnicate", "input": {"fields": FIELDS}}, "unknown op"),
+        ({"op": "sort", "input": {"fields": FIELDS}, "expr": []}, "sort needs"),
+        ({"op": "aggregate", "mode": "Single", "input": {"fields": FIELDS}, "group_expr": [], "aggr_expr": [{"fn": "MEDIAN", "expr": col("q", FIELDS), "name": "m"}]}, "MEDIAN"),
+    ]:
+        with pytest.raises(g.GpuqError) as e:
+            g.compile_check(bad)
+        assert msg in str(e.value), (msg, str(e.value))
+
+
+def test_in_list_and_register_pressure():
+    e = in_list(col("j", FIELDS), [lit(k, "Int32") for k in range(8)])
+    d = g.compile_check({"op": "filter", "input": {"fields": FIELDS}, "predicate": e})
+    assert d["program"]["pred_reg"] >= 0 and len(d["program"]["insns"]) <= 48
+    with pytest.raises(g.GpuqError):
+        g.compile_check({"op": "filter", "input": {"fields": FIELDS}, "predicate": in_list(col("j", FIELDS), [lit(k, "Int32") for k in range(40)])})
+
+
+def test_q1_plan_schema_matches_reference_answer_shape():
+    """benchmarks/src/bin/tpch.rs:1101-1112 get_answer_schema(1): 10 columns, Utf8 x2, 7 decimals, Int64 count."""
+    import tpch_util as T
+    cols = [g.DeviceColumn(n, t, None, 0, nullable=False) for n, t in [("l_quantity", D152), ("l_extendedprice", D152), ("l_discount", D152), ("l_tax", D152),
+                                                                       ("l_returnflag", "Utf8"), ("l_linestatus", "Utf8"), ("l_shipdate", "Date32")]]
+    plan = T.q1_plan(g.MemoryExec([g.DeviceTable(cols, 0)]))
+    sch = plan.schema()
+    assert [f["name"] for f in sch] == ["l_returnflag", "l_linestatus", "sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc", "count_order"]
+    assert [f["type"] for f in sch] == ["Utf8", "Utf8", {"Decimal128": [25, 2]}, {"Decimal128": [25, 2]}, {"Decimal128": [38, 4]}, {"Decimal128": [38, 6]},
+                                        {"Decimal128": [19, 6]}, {"Decimal128": [19, 6]}, {"Decimal128": [19, 6]}, "Int64"]
+    # stage tree as in scheduler/src/planner.rs:376-392
+    names = []
+    p = plan
+    while True:
+        names.append(type(p).__name__)
+        ch = p.children()
+        if not ch:
+            break
+        p = ch[0]
+    assert names == ["SortExec", "ProjectionExec", "AggregateExec", "CoalesceBatchesExec", "AggregateExec", "ProjectionExec", "CoalesceBatchesExec", "FilterExec", "MemoryExec"]

@@ -37,6 +37,14 @@ def oracle_lib():
         L.oracle_join_free.argtypes = [C.c_void_p]
         L.oracle_join_probe.restype = C.c_int64
         L.oracle_join_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        vp, i64, u64, i32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int32
+        L.oracle_sort_u64.argtypes = [vp, i64, vp]
+        L.oracle_partition_ids_i64.argtypes = [vp, i64, C.c_uint32, vp]
+        L.oracle_gen_lineitem.argtypes = [u64, u64, i64, i64, i64] + [vp] * 11
+        L.oracle_gen_orders.argtypes = [u64, i64, i64, i64] + [vp] * 4
+        L.oracle_gen_customer.argtypes = [u64, i64, i64] + [vp] * 4
+        L.oracle_gen_supplier.argtypes = [u64, i64, i64] + [vp] * 2
+        L.oracle_q1.argtypes = [i64] + [vp] * 9 + [i32] + [vp] * 3
         _ORACLE = L
     return _ORACLE
 
