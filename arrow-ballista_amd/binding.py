@@ -78,6 +78,16 @@ def lib():
         "gpuq_ctx_free": (None, [vp]),
         "gpuq_last_error": (C.c_char_p, [vp]),
         "gpuq_ctx_device_info": (i32, [vp, C.c_char_p, C.c_size_t]),
+        "gpuq_buffer_alloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
+        "gpuq_buffer_free": (i32, [vp, vp]),
+        "gpuq_copy_h2d": (i32, [vp, vp, vp, vp, C.c_size_t]),
+        "gpuq_copy_d2h": (i32, [vp, vp, vp, vp, C.c_size_t]),
+        "gpuq_table_import_arrow": (i32, [vp, vp, vp, vp, C.POINTER(vp)]),
+        "gpuq_table_num_rows": (i64, [vp]),
+        "gpuq_table_num_columns": (i32, [vp]),
+        "gpuq_table_column": (i32, [vp, i32, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info)]),
+        "gpuq_table_free": (None, [vp]),
+        "gpuq_export_arrow": (i32, [vp, vp, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info), i32, i64, vp, vp]),
         "gpuq_op_create": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
         "gpuq_compile_check": (i32, [C.c_char_p, C.c_char_p, C.c_size_t]),
         "gpuq_op_free": (None, [vp]),

@@ -6,6 +6,7 @@
 #include "gpuq_kernels.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <memory>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -951,7 +952,200 @@ int gpuq_gen_supplier(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, 
     HIPCHECK(hipGetLastError());
   });
 }
+}  // extern "C"
 
+// ---------------------------------------------------------------- device memory + Arrow C Data Interface
+namespace {
+struct Staging {   // two pinned buffers, copies alternate between them (H2D overlaps the next memcpy into pinned memory)
+  void* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; size_t cap = 0; int next = 0;
+  ~Staging() { for (int i = 0; i < 2; ++i) { if (buf[i]) (void)hipHostFree(buf[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); } }
+  void ensure() {
+    if (cap) return;
+    cap = 32u << 20;
+    for (int i = 0; i < 2; ++i) { HIPCHECK(hipHostMalloc(&buf[i], cap, hipHostMallocDefault)); HIPCHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)); }
+  }
+  void h2d(hipStream_t s, void* dst, const void* src, size_t bytes) {
+    ensure();
+    size_t done = 0;
+    while (done < bytes) {
+      const size_t n = std::min(cap, bytes - done);
+      const int k = next; next ^= 1;
+      if (used[k]) HIPCHECK(hipEventSynchronize(ev[k]));
+      std::memcpy(buf[k], (const char*)src + done, n);
+      HIPCHECK(hipMemcpyAsync((char*)dst + done, buf[k], n, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipEventRecord(ev[k], s)); used[k] = true;
+      done += n;
+    }
+  }
+  void drain() { for (int k = 0; k < 2; ++k) if (used[k]) { HIPCHECK(hipEventSynchronize(ev[k])); used[k] = false; } }
+};
+thread_local Staging g_staging;
+
+struct ImportedCol { gpuq_column col{}; gpuq_field_info field{}; DevBuf data, offsets, validity; };
+
+DType dtype_from_format(const char* f) {
+  DType t; const std::string s = f ? f : "";
+  if (s == "i") t.id = T_INT32; else if (s == "l") t.id = T_INT64; else if (s == "tdD") t.id = T_DATE32; else if (s == "g") t.id = T_FLOAT64;
+  else if (s == "u") t.id = T_UTF8; else if (s == "b") t.id = T_BOOL; else if (s == "I") t.id = T_UINT32; else if (s == "L") t.id = T_UINT64;
+  else if (s.rfind("d:", 0) == 0) {
+    int p = 0, sc = 0, bits = 128;
+    if (std::sscanf(s.c_str(), "d:%d,%d,%d", &p, &sc, &bits) < 2 || bits != 128) throw Unsupported("decimal format '" + s + "'");
+    t.id = T_DECIMAL128; t.p = p; t.s = sc;
+  } else throw Unsupported("Arrow format '" + s + "' is not supported on device");
+  return t;
+}
+std::string format_of(const gpuq_field_info& f) {
+  switch (f.type) {
+    case T_INT32: return "i"; case T_INT64: return "l"; case T_DATE32: return "tdD"; case T_FLOAT64: return "g"; case T_UTF8: return "u";
+    case T_BOOL: return "b"; case T_UINT32: return "I"; case T_UINT64: return "L";
+    case T_DECIMAL128: return "d:" + std::to_string(f.precision) + "," + std::to_string(f.scale);
+  }
+  throw Unsupported("type has no Arrow format");
+}
+// copy `nbits` bits starting at bit `off` of src into a fresh LSB-aligned bitmap
+std::vector<uint8_t> realign_bits(const uint8_t* src, int64_t off, int64_t nbits) {
+  std::vector<uint8_t> out((size_t)(nbits + 7) / 8 + 8, 0);
+  for (int64_t i = 0; i < nbits; ++i) if ((src[(off + i) >> 3] >> ((off + i) & 7)) & 1) out[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+  return out;
+}
+}  // namespace
+
+struct gpuq_table { gpuq_ctx* ctx = nullptr; int64_t n_rows = 0; std::vector<std::unique_ptr<ImportedCol>> cols; };
+
+extern "C" {
+int gpuq_buffer_alloc(gpuq_ctx* ctx, size_t bytes, void** dev_out) {
+  return guarded(ctx, [&]() { check_ctx(ctx); if (!dev_out) throw std::runtime_error("dev_out is NULL"); HIPCHECK(hipMalloc(dev_out, bytes ? bytes : 1)); });
+}
+int gpuq_buffer_free(gpuq_ctx* ctx, void* dev) { return guarded(ctx, [&]() { check_ctx(ctx); if (dev) HIPCHECK(hipFree(dev)); }); }
+int gpuq_copy_h2d(gpuq_ctx* ctx, void* stream, void* dst_dev, const void* src_host, size_t bytes) {
+  return guarded(ctx, [&]() { check_ctx(ctx); if (bytes) { g_staging.h2d((hipStream_t)stream, dst_dev, src_host, bytes); g_staging.drain(); } });
+}
+int gpuq_copy_d2h(gpuq_ctx* ctx, void* stream, void* dst_host, const void* src_dev, size_t bytes) {
+  return guarded(ctx, [&]() { check_ctx(ctx); if (bytes) { HIPCHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); HIPCHECK(hipStreamSynchronize((hipStream_t)stream)); } });
+}
+
+int gpuq_table_import_arrow(gpuq_ctx* ctx, void* stream, const struct ArrowArray* batch, const struct ArrowSchema* schema, gpuq_table** out) {
+  gpuq_table* t = nullptr;
+  int rc = guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!batch || !schema || !out) throw std::runtime_error("batch/schema/out is NULL");
+    if (std::string(schema->format ? schema->format : "") != "+s") throw std::runtime_error("expected a struct-typed ArrowArray (RecordBatch)");
+    if (batch->n_children != schema->n_children) throw std::runtime_error("array/schema children mismatch");
+    hipStream_t s = (hipStream_t)stream;
+    t = new gpuq_table(); t->ctx = ctx; t->n_rows = batch->length;
+    for (int64_t c = 0; c < batch->n_children; ++c) {
+      const ArrowArray* a = batch->children[c]; const ArrowSchema* f = schema->children[c];
+      if (a->dictionary) throw Unsupported("dictionary-encoded column '" + std::string(f->name ? f->name : "") + "'");
+      const DType ty = dtype_from_format(f->format);
+      auto ic = std::make_unique<ImportedCol>();
+      const int64_t n = a->length, off = a->offset + batch->offset;
+      ic->field = make_field(f->name ? f->name : "", ty, (f->flags & 2) != 0);
+      ic->field.repr = GPUQ_REPR_ARROW;
+      ic->col.type = ty.id; ic->col.precision = ty.p; ic->col.scale = ty.s; ic->col.repr = GPUQ_REPR_ARROW; ic->col.length = n;
+      if (a->null_count != 0 && a->n_buffers > 0 && a->buffers[0]) {
+        std::vector<uint8_t> bits = realign_bits((const uint8_t*)a->buffers[0], off, n);
+        ic->validity.ensure(bits.size()); g_staging.h2d(s, ic->validity.p, bits.data(), bits.size()); g_staging.drain();
+        ic->col.validity = (const uint8_t*)ic->validity.p;
+      }
+      if (ty.id == T_UTF8) {
+        const int32_t* offs = (const int32_t*)a->buffers[1] + off;
+        const int32_t last = n > 0 ? offs[n] : 0;
+        ic->offsets.ensure((size_t)(n + 1) * 4 + 16); g_staging.h2d(s, ic->offsets.p, offs, (size_t)(n + 1) * 4);
+        ic->data.ensure((size_t)last + 16); if (last > 0) g_staging.h2d(s, ic->data.p, a->buffers[2], (size_t)last);
+        ic->col.offsets = (const int32_t*)ic->offsets.p;
+      } else if (ty.id == T_BOOL) {
+        std::vector<uint8_t> bits = realign_bits((const uint8_t*)a->buffers[1], off, n);
+        ic->data.ensure(bits.size()); g_staging.h2d(s, ic->data.p, bits.data(), bits.size()); g_staging.drain();
+      } else {
+        const int w = type_width(ty);
+        ic->data.ensure((size_t)n * w + 16); if (n > 0) g_staging.h2d(s, ic->data.p, (const char*)a->buffers[1] + (size_t)off * w, (size_t)n * w);
+      }
+      ic->col.data = ic->data.p;
+      t->cols.push_back(std::move(ic));
+    }
+    g_staging.drain();
+    *out = t;
+  });
+  if (rc != GPUQ_OK) { delete t; if (out) *out = nullptr; }
+  return rc;
+}
+int64_t gpuq_table_num_rows(const gpuq_table* t) { return t ? t->n_rows : 0; }
+int gpuq_table_num_columns(const gpuq_table* t) { return t ? (int)t->cols.size() : 0; }
+int gpuq_table_column(const gpuq_table* t, int i, gpuq_column* col_out, gpuq_field_info* field_out) {
+  if (!t || i < 0 || i >= (int)t->cols.size()) return GPUQ_ERR_INVALID;
+  if (col_out) *col_out = t->cols[i]->col;
+  if (field_out) *field_out = t->cols[i]->field;
+  return GPUQ_OK;
+}
+void gpuq_table_free(gpuq_table* t) { delete t; }
+
+namespace {
+struct ExportPriv { std::vector<std::vector<uint8_t>> bufs; std::vector<const void*> ptrs; std::vector<ArrowArray> kids; std::vector<ArrowArray*> kid_ptrs;
+                    std::vector<std::vector<const void*>> kid_bufs; };
+struct ExportSchemaPriv { std::vector<std::string> strs; std::vector<ArrowSchema> kids; std::vector<ArrowSchema*> kid_ptrs; };
+void release_array(ArrowArray* a) { if (a && a->release) { delete (ExportPriv*)a->private_data; a->release = nullptr; } }
+void release_child(ArrowArray* a) { if (a) a->release = nullptr; }
+void release_schema(ArrowSchema* s) { if (s && s->release) { delete (ExportSchemaPriv*)s->private_data; s->release = nullptr; } }
+void release_schema_child(ArrowSchema* s) { if (s) s->release = nullptr; }
+}  // namespace
+
+int gpuq_export_arrow(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, const gpuq_field_info* fields, int n_cols, int64_t n_rows,
+                      struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!cols || !fields || !out || !out_schema || n_cols < 0 || n_rows < 0) throw std::runtime_error("bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    auto* P = new ExportPriv(); auto* S = new ExportSchemaPriv();
+    std::unique_ptr<ExportPriv> gp(P); std::unique_ptr<ExportSchemaPriv> gs(S);
+    P->kids.resize(n_cols); P->kid_bufs.resize(n_cols); S->kids.resize(n_cols); S->strs.reserve((size_t)n_cols * 2 + 2);
+    auto fetch = [&](const void* dev, size_t bytes) -> const void* {
+      P->bufs.emplace_back(bytes + 8, 0);
+      if (bytes) HIPCHECK(hipMemcpyAsync(P->bufs.back().data(), dev, bytes, hipMemcpyDeviceToHost, s));
+      return P->bufs.back().data();
+    };
+    for (int c = 0; c < n_cols; ++c) {
+      const gpuq_column& col = cols[c]; const gpuq_field_info& f = fields[c];
+      ArrowArray& a = P->kids[c]; std::memset(&a, 0, sizeof(a));
+      a.length = n_rows; a.null_count = col.validity ? -1 : 0; a.release = release_child;
+      std::vector<const void*>& b = P->kid_bufs[c];
+      b.push_back(col.validity ? fetch(col.validity, (size_t)(n_rows + 7) / 8) : nullptr);
+      DType ty; ty.id = f.type; ty.p = f.precision; ty.s = f.scale;
+      if (f.type == T_UTF8) {
+        if (col.repr == GPUQ_REPR_PACKED15) {
+          DevBuf offs, data; offs.ensure((size_t)(n_rows + 1) * 4 + 16); data.ensure((size_t)n_rows * 15 + 16);
+          int64_t dl = 0;
+          int rc2 = gpuq_unpack_utf8(ctx, stream, col.data, n_rows, (int32_t*)offs.p, (uint8_t*)data.p, n_rows * 15 + 16, &dl);
+          if (rc2 != GPUQ_OK) throw std::runtime_error(ctx->last_error);
+          b.push_back(fetch(offs.p, (size_t)(n_rows + 1) * 4)); b.push_back(fetch(data.p, (size_t)dl));
+          HIPCHECK(hipStreamSynchronize(s));
+        } else {
+          int32_t last = 0;
+          if (n_rows > 0) { HIPCHECK(hipMemcpyAsync(&last, col.offsets + n_rows, 4, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s)); }
+          b.push_back(fetch(col.offsets, (size_t)(n_rows + 1) * 4)); b.push_back(fetch(col.data, (size_t)last));
+        }
+      } else if (f.type == T_BOOL) b.push_back(fetch(col.data, (size_t)(n_rows + 7) / 8));
+      else b.push_back(fetch(col.data, (size_t)n_rows * type_width(ty)));
+      a.n_buffers = (int64_t)b.size(); a.buffers = b.data();
+      ArrowSchema& sc = S->kids[c]; std::memset(&sc, 0, sizeof(sc));
+      S->strs.push_back(format_of(f)); sc.format = S->strs.back().c_str();
+      S->strs.push_back(f.name); sc.name = S->strs.back().c_str();
+      sc.flags = f.nullable ? 2 : 0; sc.release = release_schema_child;
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+    for (auto& k : P->kids) P->kid_ptrs.push_back(&k);
+    for (auto& k : S->kids) S->kid_ptrs.push_back(&k);
+    std::memset(out, 0, sizeof(*out));
+    P->ptrs.push_back(nullptr);
+    out->length = n_rows; out->n_buffers = 1; out->buffers = P->ptrs.data(); out->n_children = n_cols; out->children = P->kid_ptrs.data();
+    out->release = release_array; out->private_data = gp.release();
+    std::memset(out_schema, 0, sizeof(*out_schema));
+    out_schema->format = "+s"; out_schema->name = ""; out_schema->n_children = n_cols; out_schema->children = S->kid_ptrs.data();
+    out_schema->release = release_schema; out_schema->private_data = gs.release();
+  });
+}
+}  // extern "C"
+
+extern "C" {
 // ---------------------------------------------------------------- timers
 int gpuq_timer_create(gpuq_ctx* ctx, gpuq_timer** out) {
   return guarded(ctx, [&]() { check_ctx(ctx); auto* t = new gpuq_timer(); HIPCHECK(hipEventCreate(&t->a)); HIPCHECK(hipEventCreate(&t->b)); *out = t; });

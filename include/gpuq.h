@@ -86,6 +86,37 @@ void gpuq_ctx_free(gpuq_ctx* ctx);
 const char* gpuq_last_error(gpuq_ctx* ctx);
 int gpuq_ctx_device_info(gpuq_ctx* ctx, char* buf, size_t cap); /* JSON: name, arch, cus, hbm_bytes */
 
+/* ---- device memory + Arrow C Data Interface ingest/egress ---------------------------------- */
+/* A host that owns Arrow RecordBatches (arrow-rs `arrow::ffi`, pyarrow `_export_to_c`) hands them over
+   here; buffers are copied to HBM through double-buffered pinned staging on `stream`.
+   The structs are the Arrow C Data Interface ABI (https://arrow.apache.org/docs/format/CDataInterface.html). */
+struct ArrowSchema {
+  const char* format; const char* name; const char* metadata; int64_t flags; int64_t n_children;
+  struct ArrowSchema** children; struct ArrowSchema* dictionary; void (*release)(struct ArrowSchema*); void* private_data;
+};
+struct ArrowArray {
+  int64_t length; int64_t null_count; int64_t offset; int64_t n_buffers; int64_t n_children;
+  const void** buffers; struct ArrowArray** children; struct ArrowArray* dictionary; void (*release)(struct ArrowArray*); void* private_data;
+};
+typedef struct gpuq_table gpuq_table;
+
+int gpuq_buffer_alloc(gpuq_ctx* ctx, size_t bytes, void** dev_out);
+int gpuq_buffer_free(gpuq_ctx* ctx, void* dev);
+int gpuq_copy_h2d(gpuq_ctx* ctx, void* stream, void* dst_dev, const void* src_host, size_t bytes); /* returns after the copy is enqueued and the host buffer is reusable */
+int gpuq_copy_d2h(gpuq_ctx* ctx, void* stream, void* dst_host, const void* src_dev, size_t bytes); /* synchronous */
+
+/* Import one RecordBatch (a struct-typed ArrowArray + its ArrowSchema).  The batch is NOT consumed: the
+   caller keeps ownership and releases it as usual.  Supported column formats: i l tdD g d:p,s u b I L. */
+int gpuq_table_import_arrow(gpuq_ctx* ctx, void* stream, const struct ArrowArray* batch, const struct ArrowSchema* schema, gpuq_table** out);
+int64_t gpuq_table_num_rows(const gpuq_table* t);
+int gpuq_table_num_columns(const gpuq_table* t);
+int gpuq_table_column(const gpuq_table* t, int i, gpuq_column* col_out, gpuq_field_info* field_out);
+void gpuq_table_free(gpuq_table* t);
+/* Export device columns (GPUQ_REPR_ARROW or PACKED15) as a host RecordBatch; the caller releases `out`
+   and `out_schema` through their release callbacks.  Synchronous. */
+int gpuq_export_arrow(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, const gpuq_field_info* fields, int n_cols, int64_t n_rows,
+                      struct ArrowArray* out, struct ArrowSchema* out_schema);
+
 /* ---- compiled operators ------------------------------------------------------------------ */
 /* Descriptor JSON (see INTEGRATION.md for the grammar).  Expression nodes mirror PhysicalExprNode
    (datafusion.proto:1142-1180): column, literal, binary_expr, cast, try_cast, not_expr, is_null_expr,
