@@ -106,19 +106,39 @@ def _take_u32(tc, vec, idx, n):
     return out.columns[0].data[: max(1, n) * 4].view(_torch().int32)[:n]
 
 
+def _reindex(tc, table, idx, n):
+    """Address `table`'s rows through idx[0..n): returns (columns, index vectors, sides).  A view may mix
+    columns read at the driving position (side 0) with columns read through index vectors; the former
+    get `idx` itself as their vector, the latter get their vector composed with idx."""
+    if not table.is_view():
+        return table.columns, [idx], [1] * len(table.columns)
+    has0 = any(s == 0 for s in table.sides)
+    if len(table.via) + (1 if has0 else 0) > 3:
+        table = materialize(tc, table)
+        return table.columns, [idx], [1] * len(table.columns)
+    vias = ([idx] if has0 else []) + [_take_u32(tc, v, idx, n) for v in table.via]
+    shift = 1 if has0 else 0
+    return table.columns, vias, [1 if s == 0 else s + shift for s in table.sides]
+
+
 def _select_view(tc, table, idx, n):
     """View of `table` at driving positions idx[0..n)."""
-    if not table.is_view():
-        return DeviceTable(table.columns, n, via=[idx], sides=[1] * len(table.columns))
-    new_via = [_take_u32(tc, v, idx, n) for v in table.via]
-    return DeviceTable(table.columns, n, via=new_via, sides=table.sides)
+    cols, vias, sides = _reindex(tc, table, idx, n)
+    return DeviceTable(cols, n, via=vias, sides=sides)
 
 
 def materialize(tc, table):
+    """Gather a late-materialised view into plain columns (<= 12 columns per kernel call)."""
     if not table.is_view():
         return table
     sch = table.plain_schema()
-    return _project(tc, table, [E.col(f["name"], index=i) for i, f in enumerate(sch)], [f["name"] for f in sch])
+    out = []
+    for a in range(0, len(sch), 12):
+        idxs = list(range(a, min(a + 12, len(sch))))
+        sub = DeviceTable([table.columns[i] for i in idxs], table.num_rows, via=table.via, sides=[table.sides[i] for i in idxs])
+        ss = sub.plain_schema()
+        out += _project(tc, sub, [E.col(f["name"], index=i) for i, f in enumerate(ss)], [f["name"] for f in ss]).columns
+    return DeviceTable(out, table.num_rows)
 
 
 def _fuse(plan):
@@ -470,23 +490,16 @@ class HashJoinExec(ExecutionPlan):
 
 
 def _join_view(tc, ltab, rtab, ob, opb, k):
-    lv = [ob] if not ltab.is_view() else [_take_u32(tc, v, ob, k) for v in ltab.via]
-    rv = [opb] if not rtab.is_view() else [_take_u32(tc, v, opb, k) for v in rtab.via]
+    lcols, lv, lsides = _reindex(tc, ltab, ob, k)
+    rcols, rv, rsides = _reindex(tc, rtab, opb, k)
     if len(lv) + len(rv) > 3:
-        # too many index vectors: materialise the wider side
+        # too many index vectors for one kernel call: materialise the side that carries more of them
         if len(lv) >= len(rv):
-            ltab = materialize(tc, DeviceTable(ltab.columns, k, via=lv, sides=ltab.sides if ltab.is_view() else [1] * len(ltab.columns)))
-            lv = []
-            lsides = [0] * len(ltab.columns)
-            rsides = [(s if rtab.is_view() else 1) for s in (rtab.sides if rtab.is_view() else [1] * len(rtab.columns))]
-            return DeviceTable(ltab.columns + rtab.columns, k, via=rv, sides=lsides + rsides)
-        rtab = materialize(tc, DeviceTable(rtab.columns, k, via=rv, sides=rtab.sides if rtab.is_view() else [1] * len(rtab.columns)))
-        lsides = ltab.sides if ltab.is_view() else [1] * len(ltab.columns)
-        return DeviceTable(ltab.columns + rtab.columns, k, via=lv, sides=lsides + [0] * len(rtab.columns))
-    lsides = ltab.sides if ltab.is_view() else [1] * len(ltab.columns)
-    rbase = len(lv)
-    rsides = [s + rbase for s in (rtab.sides if rtab.is_view() else [1] * len(rtab.columns))]
-    return DeviceTable(ltab.columns + rtab.columns, k, via=lv + rv, sides=list(lsides) + rsides)
+            m = materialize(tc, DeviceTable(lcols, k, via=lv, sides=lsides))
+            return DeviceTable(m.columns + list(rcols), k, via=rv, sides=[0] * len(m.columns) + list(rsides))
+        m = materialize(tc, DeviceTable(rcols, k, via=rv, sides=rsides))
+        return DeviceTable(list(lcols) + m.columns, k, via=lv, sides=list(lsides) + [0] * len(m.columns))
+    return DeviceTable(list(lcols) + list(rcols), k, via=lv + rv, sides=list(lsides) + [s + len(lv) for s in rsides])
 
 
 class SortExec(ExecutionPlan):

@@ -224,3 +224,169 @@ def table_to_rows(tc, table):
 
 def q1_result_to_rows(tc, table):
     return [tuple(r) for r in table_to_rows(tc, table)]
+
+
+# ------------------------------------------------------------------ other tables (device generator + oracle restatement)
+NATIONS = [("ALGERIA", 0), ("ARGENTINA", 1), ("BRAZIL", 1), ("CANADA", 1), ("EGYPT", 4), ("ETHIOPIA", 0), ("FRANCE", 3), ("GERMANY", 3), ("INDIA", 2),
+           ("INDONESIA", 2), ("IRAN", 4), ("IRAQ", 4), ("JAPAN", 2), ("JORDAN", 4), ("KENYA", 0), ("MOROCCO", 0), ("MOZAMBIQUE", 0), ("PERU", 1),
+           ("CHINA", 2), ("ROMANIA", 3), ("SAUDI ARABIA", 4), ("VIETNAM", 2), ("RUSSIA", 3), ("UNITED KINGDOM", 3), ("UNITED STATES", 1)]
+REGIONS = ["AFRICA", "AMERICA", "ASIA", "EUROPE", "MIDDLE EAST"]      # ids as in ballista/scheduler/testdata/region/region.tbl
+
+
+def nation_region_arrow():
+    import pyarrow as pa
+    nation = pa.table({"n_nationkey": pa.array(range(25), type=pa.int64()), "n_name": pa.array([n for n, _ in NATIONS]),
+                       "n_regionkey": pa.array([r for _, r in NATIONS], type=pa.int64())})
+    region = pa.table({"r_regionkey": pa.array(range(5), type=pa.int64()), "r_name": pa.array(REGIONS)})
+    nation = nation.cast(pa.schema([pa.field(f.name, f.type, nullable=False) for f in nation.schema]))
+    region = region.cast(pa.schema([pa.field(f.name, f.type, nullable=False) for f in region.schema]))
+    return nation, region
+
+
+def _dev_cols(tc, spec, n):
+    """spec: [(name, type, bytes_per_row | ('utf8', data_bytes))] -> (columns, {name: ptr})"""
+    import torch
+    import arrow_ballista_amd as g
+    cols, ptrs = [], {}
+    for name, ty, w in spec:
+        if isinstance(w, tuple):
+            t = torch.empty(w[1] + 16, dtype=torch.uint8, device=tc.device)
+            o = torch.empty(n + 4, dtype=torch.int32, device=tc.device)
+            ptrs[name], ptrs[name + "_off"] = t.data_ptr(), o.data_ptr()
+            cols.append(g.DeviceColumn(name, ty, t, n, offsets=o, nullable=False))
+        else:
+            t = torch.empty(w * n + 16, dtype=torch.uint8, device=tc.device)
+            ptrs[name] = t.data_ptr()
+            cols.append(g.DeviceColumn(name, ty, t, n, nullable=False))
+    return cols, ptrs
+
+
+def gen_orders_device(tc, n, n_cust, seed=SEED_ORDERS, row0=0):
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd import binding as B
+    cols, p = _dev_cols(tc, [("o_orderkey", "Int64", 8), ("o_custkey", "Int64", 8), ("o_orderdate", "Date32", 4), ("o_shippriority", "Int32", 4)], n)
+    cs = B.gpuq_orders_cols(**p)
+    tc.ctx.check(tc.ctx.L.gpuq_gen_orders(tc.ctx.h, tc.stream_ptr(), seed, row0, n, n_cust, C.byref(cs)))
+    tc.sync()
+    return g.DeviceTable(cols, n)
+
+
+def gen_customer_device(tc, n, seed=SEED_CUSTOMER):
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd import binding as B
+    assert n % 5 == 0
+    cols, p = _dev_cols(tc, [("c_custkey", "Int64", 8), ("c_nationkey", "Int64", 8), ("c_mktsegment", "Utf8", ("utf8", n * 9))], n)
+    cs = B.gpuq_customer_cols(**p)
+    tc.ctx.check(tc.ctx.L.gpuq_gen_customer(tc.ctx.h, tc.stream_ptr(), seed, 0, n, C.byref(cs)))
+    tc.sync()
+    return g.DeviceTable(cols, n)
+
+
+def gen_supplier_device(tc, n, seed=SEED_SUPPLIER):
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd import binding as B
+    cols, p = _dev_cols(tc, [("s_suppkey", "Int64", 8), ("s_nationkey", "Int64", 8)], n)
+    cs = B.gpuq_supplier_cols(**p)
+    tc.ctx.check(tc.ctx.L.gpuq_gen_supplier(tc.ctx.h, tc.stream_ptr(), seed, 0, n, C.byref(cs)))
+    tc.sync()
+    return g.DeviceTable(cols, n)
+
+
+def gen_other_tables_host(n_orders, n_cust, n_supp):
+    """Oracle-side restatement of orders / customer / supplier as pyarrow tables."""
+    import pyarrow as pa
+    L = oracle_lib()
+    ok, oc, od, osp = np.empty(n_orders, np.int64), np.empty(n_orders, np.int64), np.empty(n_orders, np.int32), np.empty(n_orders, np.int32)
+    L.oracle_gen_orders(SEED_ORDERS, 0, n_orders, n_cust, _p(ok), _p(oc), _p(od), _p(osp))
+    ck, cn, cm, co = np.empty(n_cust, np.int64), np.empty(n_cust, np.int64), np.empty(n_cust * 9 + 16, np.uint8), np.empty(n_cust + 1, np.int32)
+    L.oracle_gen_customer(SEED_CUSTOMER, 0, n_cust, _p(ck), _p(cn), _p(cm), _p(co))
+    sk, sn = np.empty(n_supp, np.int64), np.empty(n_supp, np.int64)
+    L.oracle_gen_supplier(SEED_SUPPLIER, 0, n_supp, _p(sk), _p(sn))
+    orders = pa.table({"o_orderkey": ok, "o_custkey": oc, "o_orderdate": pa.array(od).cast(pa.date32()), "o_shippriority": osp})
+    seg = pa.Array.from_buffers(pa.string(), n_cust, [None, pa.py_buffer(co.tobytes()), pa.py_buffer(cm.tobytes())])
+    customer = pa.table({"c_custkey": ck, "c_nationkey": cn, "c_mktsegment": seg})
+    supplier = pa.table({"s_suppkey": sk, "s_nationkey": sn})
+    return orders, customer, supplier
+
+
+Q3_DATE = 9204       # date '1995-03-15'
+Q5_DATE_LO, Q5_DATE_HI = 8766, 9131      # 1994-01-01, 1995-01-01 (the folded ints of planner.rs:489)
+
+
+def q3_plan(customer, orders, lineitem):
+    """reference benchmarks/queries/q3.sql as the physical plan DataFusion builds: build sides on the LEFT."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, Operator as Op
+    cs, os_, ls = customer.schema(), orders.schema(), lineitem.schema()
+    c = g.FilterExec(binary(col("c_mktsegment", cs), Op.Eq, lit("BUILDING")), customer)
+    o = g.FilterExec(binary(col("o_orderdate", os_), Op.Lt, lit(Q3_DATE, "Date32")), orders)
+    j1 = g.HashJoinExec(g.CoalesceBatchesExec(c), g.CoalesceBatchesExec(o), [(col("c_custkey", cs), col("o_custkey", os_))], None, "Inner", "CollectLeft", False)
+    j1s = j1.schema()
+    l = g.FilterExec(binary(col("l_shipdate", ls), Op.Gt, lit(Q3_DATE, "Date32")), lineitem)
+    j2 = g.HashJoinExec(j1, g.CoalesceBatchesExec(l), [(col("o_orderkey", j1s), col("l_orderkey", ls))], None, "Inner", "CollectLeft", False)
+    j2s = j2.schema()
+    rev = binary(col("l_extendedprice", j2s), Op.Multiply, binary(lit(1, ("Decimal128", 20, 0)), Op.Minus, col("l_discount", j2s)))
+    agg = g.AggregateExec("Single", [(col("l_orderkey", j2s), "l_orderkey"), (col("o_orderdate", j2s), "o_orderdate"), (col("o_shippriority", j2s), "o_shippriority")],
+                          [{"fn": "SUM", "expr": rev, "name": "revenue"}], j2, strategy="hash")
+    as_ = agg.schema()
+    proj = g.ProjectionExec([(col("l_orderkey", as_), "l_orderkey"), (col("revenue", as_), "revenue"), (col("o_orderdate", as_), "o_orderdate"),
+                             (col("o_shippriority", as_), "o_shippriority")], agg)
+    ps = proj.schema()
+    return g.SortExec([{"expr": col("revenue", ps), "asc": False, "nulls_first": True}, {"expr": col("o_orderdate", ps), "asc": True, "nulls_first": False}], proj)
+
+
+def q5_plan(customer, orders, lineitem, supplier, nation, region):
+    """reference benchmarks/queries/q5.sql: region |x| nation |x| customer |x| orders |x| lineitem |x| supplier (2-column key)."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, Operator as Op
+    rs, ns, cs, os_, ls, ss = region.schema(), nation.schema(), customer.schema(), orders.schema(), lineitem.schema(), supplier.schema()
+    r = g.FilterExec(binary(col("r_name", rs), Op.Eq, lit("ASIA")), region)
+    j1 = g.HashJoinExec(r, nation, [(col("r_regionkey", rs), col("n_regionkey", ns))], None, "Inner", "CollectLeft", False)
+    j1s = j1.schema()
+    j2 = g.HashJoinExec(j1, customer, [(col("n_nationkey", j1s), col("c_nationkey", cs))], None, "Inner", "CollectLeft", False)
+    j2s = j2.schema()
+    o = g.FilterExec(and_(binary(col("o_orderdate", os_), Op.GtEq, lit(Q5_DATE_LO, "Date32")), binary(col("o_orderdate", os_), Op.Lt, lit(Q5_DATE_HI, "Date32"))), orders)
+    j3 = g.HashJoinExec(j2, o, [(col("c_custkey", j2s), col("o_custkey", os_))], None, "Inner", "CollectLeft", False)
+    j3s = j3.schema()
+    j4 = g.HashJoinExec(j3, lineitem, [(col("o_orderkey", j3s), col("l_orderkey", ls))], None, "Inner", "CollectLeft", False)
+    j4s = j4.schema()
+    j5 = g.HashJoinExec(supplier, j4, [(col("s_suppkey", ss), col("l_suppkey", j4s)), (col("s_nationkey", ss), col("c_nationkey", j4s))], None, "Inner", "CollectLeft", False)
+    j5s = j5.schema()
+    rev = binary(col("l_extendedprice", j5s), Op.Multiply, binary(lit(1, ("Decimal128", 20, 0)), Op.Minus, col("l_discount", j5s)))
+    agg = g.AggregateExec("Single", [(col("n_name", j5s), "n_name")], [{"fn": "SUM", "expr": rev, "name": "revenue"}], j5)
+    as_ = agg.schema()
+    return g.SortExec([{"expr": col("revenue", as_), "asc": False, "nulls_first": True}], agg)
+
+
+def q3_oracle(customer, orders, lineitem):
+    """numpy restatement of q3 over pyarrow tables -> rows ordered by (revenue desc, o_orderdate)."""
+    ck = customer["c_custkey"].to_numpy(); seg = np.array(customer["c_mktsegment"].to_pylist())
+    good_c = set(ck[seg == "BUILDING"].tolist())
+    ok, oc, od, osp = (orders[c].to_numpy() if c != "o_orderdate" else orders[c].cast("int32").to_numpy() for c in ("o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"))
+    omap = {int(k): (int(d), int(s)) for k, c, d, s in zip(ok, oc, od, osp) if d < Q3_DATE and int(c) in good_c}
+    lk = lineitem["l_orderkey"].to_numpy(); ls = lineitem["l_shipdate"].cast("int32").to_numpy()
+    ext = [int(x.scaleb(2)) for x in lineitem["l_extendedprice"].to_pylist()]; disc = [int(x.scaleb(2)) for x in lineitem["l_discount"].to_pylist()]
+    groups = {}
+    for i in range(len(lk)):
+        if ls[i] > Q3_DATE and int(lk[i]) in omap:
+            d, s = omap[int(lk[i])]
+            k = (int(lk[i]), d, s)
+            groups[k] = groups.get(k, 0) + ext[i] * (100 - disc[i])
+    return sorted(((k[0], v, k[1], k[2]) for k, v in groups.items()), key=lambda r: (-r[1], r[2]))
+
+
+def q5_oracle(customer, orders, lineitem, supplier):
+    asia = {i for i, (_, r) in enumerate(NATIONS) if r == 2}
+    cn = dict(zip(customer["c_custkey"].to_pylist(), customer["c_nationkey"].to_pylist()))
+    sn = dict(zip(supplier["s_suppkey"].to_pylist(), supplier["s_nationkey"].to_pylist()))
+    od = orders["o_orderdate"].cast("int32").to_numpy()
+    omap = {int(k): cn[int(c)] for k, c, d in zip(orders["o_orderkey"].to_numpy(), orders["o_custkey"].to_numpy(), od)
+            if Q5_DATE_LO <= d < Q5_DATE_HI and cn[int(c)] in asia}
+    lk = lineitem["l_orderkey"].to_numpy(); lsup = lineitem["l_suppkey"].to_numpy()
+    ext = [int(x.scaleb(2)) for x in lineitem["l_extendedprice"].to_pylist()]; disc = [int(x.scaleb(2)) for x in lineitem["l_discount"].to_pylist()]
+    groups = {}
+    for i in range(len(lk)):
+        nk = omap.get(int(lk[i]))
+        if nk is not None and sn[int(lsup[i])] == nk:
+            groups[NATIONS[nk][0]] = groups.get(NATIONS[nk][0], 0) + ext[i] * (100 - disc[i])
+    return sorted(groups.items(), key=lambda r: -r[1])
