@@ -88,6 +88,7 @@ struct gpuq_join_table {
   DevBuf slots, next, visited, present, ws_bitmap, ws_counts;
   i64 bound = 0;
   bool visited_ready = false;
+  bool has_dups = false;   // some key occurs on more than one build row -> chained probe
 };
 
 namespace {
@@ -724,6 +725,7 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     const uint32_t f = read_flags(op, s);
     if (f & ~FLAG_DUP_BUILD_KEY) { reset_flags(op, s); raise_flags(f & ~FLAG_DUP_BUILD_KEY); }
     if (f) reset_flags(op, s);
+    t->has_dups = (f & FLAG_DUP_BUILD_KEY) != 0;
     *out = t;
   });
   if (rc != GPUQ_OK) { delete t; if (out) *out = nullptr; }
@@ -752,6 +754,25 @@ int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpu
       const size_t bm = ((size_t)t->bound + 63) / 64 * 8 + 8;
       visited = (uint32_t*)t->visited.ensure(bm);
       if (!t->visited_ready) { HIPCHECK(hipMemsetAsync(visited, 0, bm, s)); t->visited_ready = true; }
+    }
+    if (!t->has_dups) {
+      // unique build keys: atomic-free two-pass probe, output in probe order
+      const i64 n = in->n_rows;
+      if (n == 0) { HIPCHECK(hipMemsetAsync(count_out, 0, 8, s)); return; }
+      const i64 nwords = (n + 63) >> 6;
+      const i64 maxb = (i64)op->ctx->cus * 8;
+      i64 wpb = (nwords + maxb - 1) / maxb; if (wpb < 16) wpb = 16;
+      const int nblocks = (int)((nwords + wpb - 1) / wpb);
+      uint32_t* match = (uint32_t*)op->ws[0].ensure((size_t)n * 4 + 16);
+      u64* bitmap = (u64*)op->ws[1].ensure((size_t)nwords * 8);
+      uint32_t* counts = (uint32_t*)op->ws[2].ensure((size_t)nblocks * 4 + 16);
+      { ProfScope ps(op, s);
+        launch_join_probe_unique(s, P, n, op->keys, t->T, jt, op->null_eq, match, bitmap, counts, nblocks, wpb, visited); }
+      launch_scan_block_counts(s, counts, nblocks, (u64*)count_out);
+      if (out_probe) launch_compact_pairs(s, bitmap, counts, nblocks, wpb, n, match, payload_via > 0 ? in->via[payload_via - 1] : nullptr,
+                                          out_build, out_probe, out_cap, op->flags_dev.as<uint32_t>());
+      HIPCHECK(hipGetLastError());
+      return;
     }
     HIPCHECK(hipMemsetAsync(count_out, 0, 8, s));
     { ProfScope ps(op, s);

@@ -84,6 +84,15 @@ struct DevProgram {
   uint32_t* flags;       // device status word (FLAG_* bits)
 };
 
+// launcher-side dispatch over the column-slot template parameter
+#define GPUQ_DISPATCH_MAXC(ncols, CALL)          \
+  do {                                           \
+    if ((ncols) <= 2) { CALL(2); }               \
+    else if ((ncols) <= 4) { CALL(4); }          \
+    else if ((ncols) <= 8) { CALL(8); }          \
+    else { CALL(16); }                           \
+  } while (0)
+
 constexpr uint32_t FLAG_STR_TRUNC = 1u;
 constexpr uint32_t FLAG_GROUP_OVERFLOW = 2u;
 constexpr uint32_t FLAG_TABLE_FULL = 4u;
@@ -129,65 +138,97 @@ __device__ inline void divmod128(i128 n, i128 d, i128& q, i128& r) {
 }
 
 // ---------------------------------------------------------------- column load
-// Two phases so that a wave has EVERY column's first-level load in flight before it consumes any of
-// them (one HBM round trip per row instead of one per column):
-//   phase A  issue the raw loads (values, Utf8 offset pairs, validity bytes) -- no dependent ALU work
-//   phase B  sign-extend / unpack; Utf8 issues its second-level byte loads here
-__device__ __forceinline__ void load_columns(const DevProgram& P, i64 pos, GPUQ_REGS_PARAM) {
-  uint32_t rows[MAX_VIA + 1];
-  rows[0] = (uint32_t)pos;
-#pragma unroll
-  for (int k = 0; k < MAX_VIA; ++k) rows[k + 1] = (k < P.n_via) ? P.via[k][pos] : 0u;
-  rnulls = 0;
-  uint32_t vraw[MAX_COLS];
-  // ---- phase A   (register-file elements are assigned exactly once per phase, outside any branch:
-  //                 vector updates under control flow make the allocator copy the whole file)
-#pragma unroll
-  for (int c = 0; c < MAX_COLS; ++c) {
-    u64 lo = 0, hi = 0; uint32_t vr = 0xFFu;
-    if (c < P.n_cols) {
-      const DevCol col = P.cols[c];
-      uint32_t row = rows[0];
-#pragma unroll
-      for (int k = 1; k <= MAX_VIA; ++k) if (col.via == k) row = rows[k];
+// Three phases, so that a wave has every column's load in flight before it consumes any of them
+// (one HBM round trip per 64-row step instead of one per column):
+//   A   issue the raw first-level loads into per-slot scalar registers with NO ALU work on loaded data.
+//       Any use -- a select against a default, a copy into an array element -- makes the compiler put
+//       s_waitcnt vmcnt(0) right behind the load and serialises the columns.  The slots therefore live
+//       in a recursive struct of scalars addressed by compile-time indices (arrays get vectorised and
+//       loaded values are then *copied* into them).
+//   B1  Utf8 only: issue the load of byte 0 of every string column (second level, again all in flight)
+//   B2  convert (sign-extend / pack strings / apply validity) and move into the register file, one
+//       assignment per register outside any branch.
+// MAXC = number of column slots (2/4/8/16, chosen by the launcher from P.n_cols); every slot costs
+// instructions whether or not a column sits in it.
+struct RawSlot { uint32_t r0, r1, r2, r3, v, b; };
+template <int N> struct RawSlots { RawSlot s; RawSlots<N - 1> rest; };
+template <> struct RawSlots<0> {};
+template <int C, int N> __device__ __forceinline__ RawSlot& raw_slot(RawSlots<N>& r) {
+  if constexpr (C == 0) return r.s; else return raw_slot<C - 1>(r.rest);
+}
+// rows are passed as a struct of scalars: an array indexed by the (uniform) via number is turned into a
+// dynamically indexed private array, i.e. scratch.
+struct RowIdx { uint32_t r0, r1, r2, r3; };
+__device__ __forceinline__ uint32_t slot_row(const DevCol& col, const RowIdx& rows) {
+  const int v = col.via;
+  return v == 1 ? rows.r1 : (v == 2 ? rows.r2 : (v == 3 ? rows.r3 : rows.r0));
+}
+
+template <int C, int MAXC>
+__device__ __forceinline__ void load_phase_a(const DevProgram& P, const RowIdx& rows, RawSlots<MAXC>& raw) {
+  if constexpr (C < MAXC) {
+    RawSlot& r = raw_slot<C>(raw);
+    if (C < P.n_cols) {
+      const DevCol col = P.cols[C];
+      const uint32_t row = slot_row(col, rows);
       const bool ok = (col.via == 0) || (row != NULL_ROW);
       if (ok) {
-        if (col.validity) vr = col.validity[row >> 3] >> (row & 7);
+        if (col.validity) r.v = col.validity[row >> 3];
         switch (col.cls) {
-          case CC_I32: case CC_U32: lo = ((const uint32_t*)col.data)[row]; break;
-          case CC_I64: lo = ((const u64*)col.data)[row]; break;
-          case CC_I128: { const ulonglong2 v = ((const ulonglong2*)col.data)[row]; lo = v.x; hi = v.y; break; }
-          case CC_BIT: lo = ((const uint8_t*)col.data)[row >> 3] >> (row & 7); break;
-          case CC_STR: lo = (u64)(uint32_t)col.offsets[row] | ((u64)(uint32_t)col.offsets[row + 1] << 32); break;
+          case CC_I32: case CC_U32: r.r0 = ((const uint32_t*)col.data)[row]; break;
+          case CC_I64: { const uint2 v = ((const uint2*)col.data)[row]; r.r0 = v.x; r.r1 = v.y; break; }
+          case CC_I128: { const uint4 v = ((const uint4*)col.data)[row]; r.r0 = v.x; r.r1 = v.y; r.r2 = v.z; r.r3 = v.w; break; }
+          case CC_BIT: r.r0 = ((const uint8_t*)col.data)[row >> 3]; break;
+          case CC_STR: r.r0 = (uint32_t)col.offsets[row]; r.r1 = (uint32_t)col.offsets[row + 1]; break;
           default: break;
         }
-      } else {
-        vr = 0;
       }
     }
-    rlo[c] = lo; rhi[c] = hi; vraw[c] = vr;
+    load_phase_a<C + 1, MAXC>(P, rows, raw);
   }
-  // ---- phase B
-#pragma unroll
-  for (int c = 0; c < MAX_COLS; ++c) {
-    u64 lo = rlo[c], hi = rhi[c];
-    if (c < P.n_cols) {
-      const DevCol col = P.cols[c];
-      const bool isnull = !(vraw[c] & 1u);
-      if (isnull) { rnulls |= (1u << c); lo = 0; hi = 0; }
+}
+template <int C, int MAXC>
+__device__ __forceinline__ void load_phase_b1(const DevProgram& P, const RowIdx& rows, RawSlots<MAXC>& raw) {
+  if constexpr (C < MAXC) {
+    RawSlot& r = raw_slot<C>(raw);
+    if (C < P.n_cols) {
+      const DevCol col = P.cols[C];
+      if (col.cls == CC_STR) {
+        const uint32_t row = slot_row(col, rows);
+        const bool ok = (col.via == 0) || (row != NULL_ROW);
+        if (ok && r.r1 != r.r0) r.b = ((const uint8_t*)col.data)[(int32_t)r.r0];
+      }
+    }
+    load_phase_b1<C + 1, MAXC>(P, rows, raw);
+  }
+}
+template <int C, int MAXC>
+__device__ __forceinline__ void load_phase_b2(const DevProgram& P, const RowIdx& rows, RawSlots<MAXC>& raw, GPUQ_REGS_PARAM) {
+  if constexpr (C < MAXC) {
+    RawSlot& r = raw_slot<C>(raw);
+    u64 lo = 0, hi = 0;
+    if (C < P.n_cols) {
+      const DevCol col = P.cols[C];
+      const uint32_t row = slot_row(col, rows);
+      const bool ok = (col.via == 0) || (row != NULL_ROW);
+      bool isnull = !ok;
+      if (ok && col.validity) isnull = !((r.v >> (row & 7)) & 1u);
+      if (isnull) rnulls |= (1u << C);
       else {
         switch (col.cls) {
-          case CC_I32: { const i64 v = (int32_t)(uint32_t)lo; lo = (u64)v; hi = (u64)(v >> 63); break; }
-          case CC_I64: hi = (u64)((i64)lo >> 63); break;
-          case CC_BIT: lo &= 1; break;
+          case CC_I32: { const i64 v = (int32_t)r.r0; lo = (u64)v; hi = (u64)(v >> 63); break; }
+          case CC_U32: lo = r.r0; break;
+          case CC_I64: lo = (u64)r.r0 | ((u64)r.r1 << 32); hi = (u64)((i64)lo >> 63); break;
+          case CC_I128: lo = (u64)r.r0 | ((u64)r.r1 << 32); hi = (u64)r.r2 | ((u64)r.r3 << 32); break;
+          case CC_BIT: lo = (r.r0 >> (row & 7)) & 1u; break;
           case CC_STR: {
-            const int32_t o0 = (int32_t)(uint32_t)lo, o1 = (int32_t)(uint32_t)(lo >> 32);
+            const int32_t o0 = (int32_t)r.r0, o1 = (int32_t)r.r1;
             const int32_t len = o1 - o0;
             if (len > 15) { if (P.flags) atomicOr(P.flags, FLAG_STR_TRUNC); }
             const int32_t n = len < 15 ? len : 15;
             const uint8_t* p = (const uint8_t*)col.data + o0;
-            u64 h = 0, l = 0;
-            for (int k = 0; k < n; ++k) {
+            u64 h = (n > 0) ? ((u64)(r.b & 0xFFu) << 56) : 0, l = 0;
+            for (int k = 1; k < n; ++k) {
               const u64 b = p[k];
               if (k < 8) h |= b << (56 - 8 * k);
               else l |= b << (56 - 8 * (k - 8));
@@ -199,8 +240,23 @@ __device__ __forceinline__ void load_columns(const DevProgram& P, i64 pos, GPUQ_
         }
       }
     }
-    rlo[c] = lo; rhi[c] = hi;
+    rlo[C] = lo; rhi[C] = hi;
+    load_phase_b2<C + 1, MAXC>(P, rows, raw, GPUQ_REGS);
   }
+}
+
+template <int MAXC>
+__device__ __forceinline__ void load_columns(const DevProgram& P, i64 pos, GPUQ_REGS_PARAM) {
+  RowIdx rows;
+  rows.r0 = (uint32_t)pos;
+  rows.r1 = (P.n_via > 0) ? P.via[0][pos] : 0u;
+  rows.r2 = (P.n_via > 1) ? P.via[1][pos] : 0u;
+  rows.r3 = (P.n_via > 2) ? P.via[2][pos] : 0u;
+  rnulls = 0;
+  RawSlots<MAXC> raw;
+  load_phase_a<0, MAXC>(P, rows, raw);
+  load_phase_b1<0, MAXC>(P, rows, raw);
+  load_phase_b2<0, MAXC>(P, rows, raw, GPUQ_REGS);
 }
 
 // ---------------------------------------------------------------- interpreter

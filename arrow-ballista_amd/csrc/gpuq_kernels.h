@@ -74,6 +74,10 @@ void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, 
 // build: payload = payload_via ? via[payload_via-1][pos] : pos.  next == nullptr => unique keys only (FLAG_DUP_BUILD_KEY on a duplicate)
 void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
                        int payload_via, int null_equals_null);
+void launch_join_probe_unique(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int join_type, int null_equals_null,
+                              uint32_t* match, u64* bitmap, uint32_t* block_counts, int nblocks, i64 wpb, uint32_t* visited);
+void launch_compact_pairs(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 wpb, i64 n, const uint32_t* match,
+                          const uint32_t* probe_via, uint32_t* out_build, uint32_t* out_probe, u64 out_cap, uint32_t* flags);
 void launch_bitmap_select(hipStream_t s, const u64* present, const u64* visited, int matched, i64 nwords, i64 n, u64* bitmap,
                           uint32_t* block_counts, int nblocks, i64 wpb);
 void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, const uint32_t* next,

@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(HBLOCK) k_ht_init(const HashTable T, const Agg
 }
 
 // ------------------------------------------------------------------ hash aggregate
+template <int MAXC>
 __global__ void __launch_bounds__(HBLOCK) k_agg_hash(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T) {
   const i64 nwords = (n + 63) >> 6;
   const int cell0 = 1 + T.key_words;
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(HBLOCK) k_agg_hash(const DevProgram P, const i
     const i64 pos = (w << 6) + hlane();
     bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
     if (!active) continue;
     u64 kw[MAX_KW]; u64 h;
 #pragma unroll
@@ -250,6 +251,7 @@ __global__ void __launch_bounds__(HBLOCK) k_agg_hash_extract(const KeySpec K, co
 }
 
 // ------------------------------------------------------------------ join build
+template <int MAXC>
 __global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
                                                        uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
                                                        const int null_eq) {
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const
     const i64 pos = (w << 6) + hlane();
     bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
     if (!active) continue;
     u64 kw[MAX_KW]; u64 h;
 #pragma unroll
@@ -274,12 +276,12 @@ __global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const
     if (inserted) {
       if (next) next[row] = NIL;
     } else {
+      // duplicate key: remember it (the host then uses the chained probe) -- test first, one word must not be hammered
+      if (!(__hip_atomic_load(P.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_DUP_BUILD_KEY)) atomicOr(P.flags, FLAG_DUP_BUILD_KEY);
       if (next) {
         uint32_t* head = (uint32_t*)(T.slots + s * (u64)T.slot_words) + 1;   // high half of word 0
         const uint32_t old = __hip_atomic_exchange(head, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         next[row] = old;
-      } else {
-        atomicOr(P.flags, FLAG_DUP_BUILD_KEY);
       }
     }
   }
@@ -289,6 +291,7 @@ __global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const
 // Emits (build_row, probe_row) pairs with wave-ballot compaction: one global atomic per wave per
 // chain step.  Pair order is not input order (DataFusion's is batch-local and unspecified across
 // partitions); the SET of pairs is deterministic.
+template <int MAXC>
 __global__ void __launch_bounds__(HBLOCK) k_join_probe(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
                                                        const uint32_t* __restrict__ next, const int join_type, const int payload_via,
                                                        const int null_eq, uint32_t* __restrict__ out_build, uint32_t* __restrict__ out_probe,
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(HBLOCK) k_join_probe(const DevProgram P, const
     const i64 pos = (w << 6) + hlane();
     bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
     uint32_t cur = NIL;
     uint32_t prow = (uint32_t)pos;
     if (active) {
@@ -355,6 +358,85 @@ __global__ void __launch_bounds__(HBLOCK) k_join_probe(const DevProgram P, const
   }
 }
 
+// ------------------------------------------------------------------ join probe, unique build keys
+// No output atomics: pass 1 writes one match word per probe position (build row or NIL) plus the
+// emit bitmap and per-block counts; pass 2 (k_compact_pairs) turns them into dense, PROBE-ORDERED
+// (build_row, probe_row) pairs.  A single global counter would serialise the whole probe
+// (measured: 51 ms for 2^28 probes whatever the table size -- one device-scope atomic per wave step).
+template <int MAXC>
+__global__ void __launch_bounds__(HBLOCK) k_join_probe_unique(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                              const int join_type, const int null_eq, uint32_t* __restrict__ match,
+                                                              u64* __restrict__ bitmap, uint32_t* __restrict__ block_counts, const i64 wpb,
+                                                              uint32_t* __restrict__ visited) {
+  __shared__ uint32_t wave_cnt[HWAVES];
+  const i64 nwords = (n + 63) >> 6;
+  const i64 w0 = (i64)blockIdx.x * wpb;
+  i64 w1 = w0 + wpb; if (w1 > nwords) w1 = nwords;
+  const bool probe_outer = (join_type == JT_RIGHT || join_type == JT_FULL);
+  const bool want_pairs = (join_type == JT_INNER || join_type == JT_LEFT || join_type == JT_RIGHT || join_type == JT_FULL);
+  uint32_t cnt = 0;
+  for (i64 w = w0 + hwave(); w < w1; w += HWAVES) {
+    const i64 pos = (w << 6) + hlane();
+    bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    uint32_t hit = NIL;
+    if (active) {
+      u64 kw[MAX_KW]; u64 h;
+#pragma unroll
+      for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
+      const bool any_null = make_key(K, GPUQ_REGS, kw, h);
+      if (!(any_null && !null_eq)) { uint32_t payload; if (ht_find(T, kw, h, payload)) hit = payload; }
+      if (visited && hit != NIL) atomicOr(&visited[hit >> 5], 1u << (hit & 31));
+    }
+    bool emit;
+    if (join_type == JT_RIGHT_SEMI) emit = active && hit != NIL;
+    else if (join_type == JT_RIGHT_ANTI) emit = active && hit == NIL;
+    else emit = want_pairs && active && (hit != NIL || probe_outer);
+    if (pos < n) match[pos] = hit;
+    const u64 m = __ballot(emit);
+    if (hlane() == 0) bitmap[w] = m;
+    cnt += (uint32_t)__popcll(m);
+  }
+  if (hlane() == 0) wave_cnt[hwave()] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < HWAVES; ++k) t += wave_cnt[k]; block_counts[blockIdx.x] = t; }
+}
+
+__global__ void __launch_bounds__(HBLOCK) k_compact_pairs(const u64* __restrict__ bitmap, const uint32_t* __restrict__ block_offsets, const i64 wpb,
+                                                          const i64 n, const uint32_t* __restrict__ match, const uint32_t* __restrict__ probe_via,
+                                                          uint32_t* __restrict__ out_build, uint32_t* __restrict__ out_probe, const u64 out_cap,
+                                                          uint32_t* __restrict__ flags) {
+  __shared__ uint32_t wave_cnt[HWAVES];
+  const i64 nwords = (n + 63) >> 6;
+  const i64 w0 = (i64)blockIdx.x * wpb;
+  i64 w1 = w0 + wpb; if (w1 > nwords) w1 = nwords;
+  const i64 span = w1 > w0 ? (w1 - w0) : 0;
+  const i64 per = (span + HWAVES - 1) / HWAVES;
+  const i64 a = w0 + per * hwave();
+  i64 b = a + per; if (b > w1) b = w1;
+  uint32_t cnt = 0;
+  for (i64 w = a + hlane(); w < b; w += 64) cnt += (uint32_t)__popcll(bitmap[w]);
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if (hlane() == 0) wave_cnt[hwave()] = cnt;
+  __syncthreads();
+  u64 out = block_offsets[blockIdx.x];
+  for (int k = 0; k < hwave(); ++k) out += wave_cnt[k];
+  for (i64 w = a; w < b; ++w) {
+    const u64 m = bitmap[w];
+    const int l = hlane();
+    if ((m >> l) & 1) {
+      const u64 idx = out + (u64)__popcll(m & ((1ull << l) - 1));
+      const i64 pos = (w << 6) + l;
+      if (idx < out_cap) {
+        if (out_build) out_build[idx] = match[pos];
+        out_probe[idx] = probe_via ? probe_via[pos] : (uint32_t)pos;
+      } else atomicOr(flags, FLAG_OUT_OVERFLOW);
+    }
+    out += (u64)__popcll(m);
+  }
+}
+
 // ------------------------------------------------------------------ launchers
 static int hgrid(i64 n, int blocks_per_cu) {
   const i64 nwords = (n + 63) >> 6;
@@ -374,7 +456,9 @@ void launch_ht_init(hipStream_t s, const HashTable& T, const AggSpec* A) {
 }
 void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_agg_hash, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, A, T);
+#define CALL(M) hipLaunchKernelGGL(k_agg_hash<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, A, T)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
 }
 void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags) {
   u64 need = (T.n_slots + HBLOCK - 1) / HBLOCK;
@@ -385,7 +469,9 @@ void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, 
 void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
                        int payload_via, int null_equals_null) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_join_build, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, present, payload_via, null_equals_null);
+#define CALL(M) hipLaunchKernelGGL(k_join_build<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, present, payload_via, null_equals_null)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
 }
 
 // build-side row selection for Left/Full/LeftSemi/LeftAnti: present & (visited | ~visited)
@@ -414,8 +500,21 @@ void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec&
                        int join_type, int payload_via, int null_equals_null, uint32_t* out_build, uint32_t* out_probe,
                        u64 out_cap, u64* out_count, uint32_t* visited) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_join_probe, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, join_type, payload_via, null_equals_null,
-                     out_build, out_probe, out_cap, out_count, visited);
+#define CALL(M) hipLaunchKernelGGL(k_join_probe<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, join_type, payload_via, null_equals_null, \
+                                   out_build, out_probe, out_cap, out_count, visited)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
+}
+
+void launch_join_probe_unique(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int join_type, int null_equals_null,
+                              uint32_t* match, u64* bitmap, uint32_t* block_counts, int nblocks, i64 wpb, uint32_t* visited) {
+#define CALL(M) hipLaunchKernelGGL(k_join_probe_unique<M>, dim3(nblocks), dim3(HBLOCK), 0, s, P, n, K, T, join_type, null_equals_null, match, bitmap, block_counts, wpb, visited)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
+}
+void launch_compact_pairs(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 wpb, i64 n, const uint32_t* match,
+                          const uint32_t* probe_via, uint32_t* out_build, uint32_t* out_probe, u64 out_cap, uint32_t* flags) {
+  hipLaunchKernelGGL(k_compact_pairs, dim3(nblocks), dim3(HBLOCK), 0, s, bitmap, block_offsets, wpb, n, match, probe_via, out_build, out_probe, out_cap, flags);
 }
 
 }  // namespace gpuq

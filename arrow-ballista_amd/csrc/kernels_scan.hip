@@ -21,6 +21,7 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 // ------------------------------------------------------------------ filter
 // Pass 1: evaluate the predicate once per row, keep it as a bitmap (N/8 bytes) plus one
 // count per block.  Block b owns the contiguous word range [b*wpb, (b+1)*wpb).
+template <int MAXC>
 __global__ void __launch_bounds__(BLOCK) k_filter_bitmap(const DevProgram P, const i64 n, u64* __restrict__ bitmap,
                                                          uint32_t* __restrict__ block_counts, const i64 wpb) {
   __shared__ uint32_t wave_cnt[WAVES];
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(BLOCK) k_filter_bitmap(const DevProgram P, con
     bool pass = false;
     if (pos < n) {
       GPUQ_REGS_DECL;
-      load_columns(P, pos, GPUQ_REGS);
+      load_columns<MAXC>(P, pos, GPUQ_REGS);
       run_program(P, GPUQ_REGS);
       pass = row_passes(P, GPUQ_REGS);
     }
@@ -109,13 +110,14 @@ __global__ void __launch_bounds__(BLOCK) k_compact(const u64* __restrict__ bitma
 }
 
 // ------------------------------------------------------------------ project
+template <int MAXC>
 __global__ void __launch_bounds__(BLOCK) k_project(const DevProgram P, const i64 n, const OutSpec O) {
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * WAVES + wave_id(); w < nwords; w += (i64)gridDim.x * WAVES) {
     const i64 pos = (w << 6) + lane_id();
     const bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); }
+    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); }
 #pragma unroll
     for (int k = 0; k < MAX_OUTS; ++k) {
       if (k < O.n_out) {
@@ -191,6 +193,7 @@ static size_t tiny_partial_bytes(int gmax, int n_keys, int n_accs) {
   return 8 + (size_t)gmax * (n_keys > 0 ? n_keys : 1) * 16 + (size_t)gmax * 4 + ((gmax & 1) ? 4 : 0) + (size_t)gmax * n_accs * 16;
 }
 
+template <int MAXC>
 __global__ void __launch_bounds__(BLOCK) k_agg_tiny(const DevProgram P, const i64 n, const AggSpec A, const int gmax,
                                                     char* __restrict__ workspace, const size_t partial_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,16 +217,18 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny(const DevProgram P, const i6
     const i64 pos = (w << 6) + lane_id();
     bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
-    // group key
-    u64 klo[MAX_KEYS], khi[MAX_KEYS]; uint32_t knull = 0;
+    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    // group key (explicit scalars: a small array here ends up in scratch once the loader's slots are live)
+    u64 k0lo = 0, k0hi = 0, k1lo = 0, k1hi = 0, k2lo = 0, k2hi = 0, k3lo = 0, k3hi = 0; uint32_t knull = 0;
+#define GPUQ_KLO(k) ((k) == 0 ? k0lo : (k) == 1 ? k1lo : (k) == 2 ? k2lo : k3lo)
+#define GPUQ_KHI(k) ((k) == 0 ? k0hi : (k) == 1 ? k1hi : (k) == 2 ? k2hi : k3hi)
 #pragma unroll
     for (int k = 0; k < MAX_KEYS; ++k) {
-      klo[k] = 0; khi[k] = 0;
       if (k < n_keys && active) {
         const int r = __builtin_amdgcn_readfirstlane(A.key_reg[k]);
         const bool isn = (rnulls >> r) & 1;
-        klo[k] = isn ? 0 : rlo[r]; khi[k] = isn ? 0 : rhi[r];
+        const u64 vlo = isn ? 0 : rlo[r], vhi = isn ? 0 : rhi[r];
+        if (k == 0) { k0lo = vlo; k0hi = vhi; } else if (k == 1) { k1lo = vlo; k1hi = vhi; } else if (k == 2) { k2lo = vlo; k2hi = vhi; } else { k3lo = vlo; k3hi = vhi; }
         knull |= (uint32_t)isn << k;
       }
     }
@@ -238,7 +243,7 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny(const DevProgram P, const i6
           bool eq = vnulls[g] == knull;
 #pragma unroll
           for (int k = 0; k < MAX_KEYS; ++k)
-            if (k < n_keys) eq = eq && vkeys[(g * kstride + k) * 2] == klo[k] && vkeys[(g * kstride + k) * 2 + 1] == khi[k];
+            if (k < n_keys) eq = eq && vkeys[(g * kstride + k) * 2] == GPUQ_KLO(k) && vkeys[(g * kstride + k) * 2 + 1] == GPUQ_KHI(k);
           if (eq) gid = (int)g;
         }
       }
@@ -255,14 +260,14 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny(const DevProgram P, const i6
           bool eq = vnulls[g] == knull;
 #pragma unroll
           for (int k = 0; k < MAX_KEYS; ++k)
-            if (k < n_keys) eq = eq && vkeys[(g * kstride + k) * 2] == klo[k] && vkeys[(g * kstride + k) * 2 + 1] == khi[k];
+            if (k < n_keys) eq = eq && vkeys[(g * kstride + k) * 2] == GPUQ_KLO(k) && vkeys[(g * kstride + k) * 2 + 1] == GPUQ_KHI(k);
           if (eq) found = (int)g;
         }
         if (found < 0) {
           if (n2 < (uint32_t)gmax) {
 #pragma unroll
             for (int k = 0; k < MAX_KEYS; ++k)
-              if (k < n_keys) { vkeys[(n2 * kstride + k) * 2] = klo[k]; vkeys[(n2 * kstride + k) * 2 + 1] = khi[k]; }
+              if (k < n_keys) { vkeys[(n2 * kstride + k) * 2] = GPUQ_KLO(k); vkeys[(n2 * kstride + k) * 2 + 1] = GPUQ_KHI(k); }
             vnulls[n2] = knull;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             *vn = n2 + 1;
@@ -605,7 +610,9 @@ static int grid_for(i64 n, int blocks_per_cu) {
 }
 
 void launch_filter_bitmap(hipStream_t s, const DevProgram& P, i64 n, u64* bitmap, uint32_t* block_counts, int nblocks, i64 wpb) {
-  hipLaunchKernelGGL(k_filter_bitmap, dim3(nblocks), dim3(BLOCK), 0, s, P, n, bitmap, block_counts, wpb);
+#define CALL(M) hipLaunchKernelGGL(k_filter_bitmap<M>, dim3(nblocks), dim3(BLOCK), 0, s, P, n, bitmap, block_counts, wpb)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
 }
 void launch_scan_block_counts(hipStream_t s, uint32_t* block_counts, int nblocks, u64* total_out) {
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total_out);
@@ -616,7 +623,9 @@ void launch_compact(hipStream_t s, const u64* bitmap, const uint32_t* block_offs
 }
 void launch_project(hipStream_t s, const DevProgram& P, i64 n, const OutSpec& O) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_project, dim3(grid_for(n, 8)), dim3(BLOCK), 0, s, P, n, O);
+#define CALL(M) hipLaunchKernelGGL(k_project<M>, dim3(grid_for(n, 8)), dim3(BLOCK), 0, s, P, n, O)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
 }
 
 // LDS budget: keep one block within 64 KiB so at least two blocks (8 waves) share a CU.
@@ -643,13 +652,19 @@ void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A
   int nb = grid_for(n, 64);
   if (nb > nb_cap) nb = nb_cap;
   const size_t lds = tiny_lds_bytes(gmax, A.n_keys, A.n_accs);
-  // > 64 KiB of dynamic LDS needs an explicit opt-in; the request must leave room for the static part
-  static size_t attr_main = 0, attr_merge = 0;
-  if (lds > 60 * 1024 && lds > attr_main) {
-    if (hipFuncSetAttribute((const void*)k_agg_tiny, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_main = lds;
-    else (void)hipGetLastError();
-  }
-  hipLaunchKernelGGL(k_agg_tiny, dim3(nb), dim3(BLOCK), lds, s, P, n, A, gmax, (char*)workspace, stride);
+  // > 64 KiB of dynamic LDS needs an explicit opt-in (per template instantiation)
+#define CALL(M)                                                                                                                          \
+  do {                                                                                                                                   \
+    static size_t attr_main = 0;                                                                                                         \
+    if (lds > 60 * 1024 && lds > attr_main) {                                                                                            \
+      if (hipFuncSetAttribute((const void*)k_agg_tiny<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_main = lds; \
+      else (void)hipGetLastError();                                                                                                      \
+    }                                                                                                                                    \
+    hipLaunchKernelGGL(k_agg_tiny<M>, dim3(nb), dim3(BLOCK), lds, s, P, n, A, gmax, (char*)workspace, stride);                           \
+  } while (0)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
+  static size_t attr_merge = 0;
   const int kstride = A.n_keys > 0 ? A.n_keys : 1;
   const size_t mlds = (size_t)out.cap * kstride * 16 + (size_t)out.cap * 4 + (((size_t)nb * gmax * 2 + 15) & ~(size_t)15) + 32 + (size_t)out.cap * A.n_accs * 16;
   if (mlds > 60 * 1024 && mlds > attr_merge) {

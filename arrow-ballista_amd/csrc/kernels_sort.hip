@@ -59,6 +59,7 @@ __device__ __forceinline__ void mm_reduce_store(MinMax& m, int k, u64 (*red)[MAX
   }
   if (slane() == 0) { red[swave()][k][0] = m.mn_lo; red[swave()][k][1] = m.mn_hi; red[swave()][k][2] = m.mx_lo; red[swave()][k][3] = m.mx_hi; red[swave()][k][4] = m.fl; }
 }
+template <int MAXC>
 __global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out) {
   __shared__ u64 red[SWAVES][MAX_SORT_KEYS][5];
   MinMax m0, m1, m2, m3;   // scalars on purpose: an indexed array here competes with the register file for promotion
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, cons
     const i64 pos = (w << 6) + slane();
     if (pos >= n) continue;
     GPUQ_REGS_DECL;
-    load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS);
+    load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS);
     mm_row(m0, S, 0, GPUQ_REGS); mm_row(m1, S, 1, GPUQ_REGS); mm_row(m2, S, 2, GPUQ_REGS); mm_row(m3, S, 3, GPUQ_REGS);
   }
   // a lane that saw no value keeps (max,min) sentinels, which never win a reduction
@@ -89,6 +90,7 @@ __global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, cons
 }
 
 // ------------------------------------------------------------------ composite key
+template <int MAXC>
 __global__ void __launch_bounds__(SBLOCK) k_sort_pack(const DevProgram P, const i64 n, const SortSpec S, const SortPack K,
                                                       u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids) {
   const i64 nwords = (n + 63) >> 6;
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(SBLOCK) k_sort_pack(const DevProgram P, const 
     const i64 pos = (w << 6) + slane();
     if (pos >= n) continue;
     GPUQ_REGS_DECL;
-    load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS);
+    load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS);
     u128 comp = 0;
 #pragma unroll
     for (int k = 0; k < MAX_SORT_KEYS; ++k) {
@@ -124,6 +126,7 @@ __global__ void __launch_bounds__(SBLOCK) k_sort_pack(const DevProgram P, const 
 }
 
 // ------------------------------------------------------------------ partition ids
+template <int MAXC>
 __global__ void __launch_bounds__(SBLOCK) k_part_pid(const DevProgram P, const i64 n, const KeySpec K, const uint32_t nparts,
                                                      u64* __restrict__ pid_out, uint32_t* __restrict__ ids) {
   const i64 nwords = (n + 63) >> 6;
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(SBLOCK) k_part_pid(const DevProgram P, const i
     const i64 pos = (w << 6) + slane();
     if (pos >= n) continue;
     GPUQ_REGS_DECL;
-    load_columns(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS);
+    load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS);
     u64 h = 0x243F6A8885A308D3ull;
 #pragma unroll
     for (int k = 0; k < MAX_KEYS; ++k) {
@@ -246,13 +249,21 @@ static int sgrid(i64 n, int blocks_per_cu) {
 }
 int sort_minmax_blocks(i64 n) { return sgrid(n, 4); }
 void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks) {
-  hipLaunchKernelGGL(k_sort_minmax, dim3(nblocks), dim3(SBLOCK), 0, s, P, n, S, out);
+#define CALL(M) hipLaunchKernelGGL(k_sort_minmax<M>, dim3(nblocks), dim3(SBLOCK), 0, s, P, n, S, out)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
 }
 void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids) {
-  if (n > 0) hipLaunchKernelGGL(k_sort_pack, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, S, K, key_lo, key_hi, ids);
+  if (n <= 0) return;
+#define CALL(M) hipLaunchKernelGGL(k_sort_pack<M>, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, S, K, key_lo, key_hi, ids)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
 }
 void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, uint32_t nparts, u64* pid_out, uint32_t* ids) {
-  if (n > 0) hipLaunchKernelGGL(k_part_pid, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, K, nparts, pid_out, ids);
+  if (n <= 0) return;
+#define CALL(M) hipLaunchKernelGGL(k_part_pid<M>, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, K, nparts, pid_out, ids)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
 }
 void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out) {
   (void)hipMemsetAsync(counts_ws, 0, (size_t)(nparts + 1) * 4, s);

@@ -1,0 +1,103 @@
+"""Secondary measurements attached to bench.py's JSON line under "extra" (--extras): the hash-join probe
+micro-benchmark of SURVEY.md §8(d) (the other half of BASELINE.json's metric) and the q3 / q5 operator
+pipelines.  Kernel times come from HIP events around the launch (gpuq_op_profile)."""
+import ctypes as C
+import time
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _sync(tc):
+    tc.sync()
+
+
+def join_probe_micro(tc, g, log2_build, log2_probe, hit_rate, reps=3):
+    """build: 2^b unique int64 keys (shuffled); probe: 2^p uniform keys, `hit_rate` of them present.
+    Algorithmic bytes: 24 B per probe row (8 key + 16 slot touch) + 12 B per emitted pair."""
+    import torch
+    from arrow_ballista_amd.expr import col
+    dev = tc.device
+    nb, npb = 1 << log2_build, 1 << log2_probe
+    gen = torch.Generator(device=dev); gen.manual_seed(1234 + log2_build)
+    bkeys = torch.randperm(nb, device=dev, generator=gen, dtype=torch.int64) * 2 + 1           # odd keys
+    span = int(nb / max(hit_rate, 1e-9))
+    pkeys = torch.randint(0, span, (npb,), device=dev, generator=gen, dtype=torch.int64) * 2 + 1   # odd key < 2*nb exists
+    btab = g.DeviceTable([g.DeviceColumn("k", "Int64", bkeys.view(torch.uint8), nb, nullable=False)], nb)
+    ptab = g.DeviceTable([g.DeviceColumn("k", "Int64", pkeys.view(torch.uint8), npb, nullable=False)], npb)
+    bs, ps = btab.schema(), ptab.schema()
+    bop = tc.op({"op": "join_build", "input": {"fields": bs}, "on": [col("k", bs)]})
+    pop = tc.op({"op": "join_probe", "input": {"fields": ps}, "on": [col("k", ps)], "join_type": "Inner"})
+    binp, _k1 = btab.input_struct()
+    pinp, _k2 = ptab.input_struct()
+    h = C.c_void_p()
+    bop.profile(True)
+    tc.ctx.check(tc.ctx.L.gpuq_join_build_run(bop.h, tc.stream_ptr(), C.byref(binp), 0, nb, C.byref(h)))
+    build_ms, _ = bop.profile(False)
+    ob = torch.empty(npb, dtype=torch.int32, device=dev)
+    opb = torch.empty(npb, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    best = None
+    for r in range(reps + 1):
+        pop.profile(True)
+        tc.ctx.check(tc.ctx.L.gpuq_join_probe_run(pop.h, tc.stream_ptr(), h, C.byref(pinp), 0, ob.data_ptr(), opb.data_ptr(), npb, cnt.data_ptr()))
+        _sync(tc)
+        ms, _ = pop.profile(False)
+        if r > 0:
+            best = ms if best is None or ms < best else best
+    matches = int(cnt[0].item())
+    pop.check(tc.stream_ptr())
+    tc.ctx.L.gpuq_join_table_free(h)
+    # spot-check: every emitted pair joins equal keys
+    k = min(matches, 1 << 16)
+    ok = bool((bkeys[ob[:k].long()] == pkeys[opb[:k].long()]).all().item()) if k else True
+    exp = int(((pkeys < 2 * nb)).sum().item())
+    alg_bytes = 24 * npb + 12 * matches
+    return {"build_rows": nb, "probe_rows": npb, "hit_rate": hit_rate, "matches": matches, "matches_expected": exp, "pairs_valid": ok,
+            "probe_ms": best, "probe_rows_per_s": npb / (best * 1e-3), "algorithmic_GBs": alg_bytes / (best * 1e-3) / 1e9,
+            "frac_hbm_peak": alg_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "build_ms": build_ms, "build_rows_per_s": nb / (build_ms * 1e-3)}
+
+
+def tpch_pipelines(tc, T, g, sf):
+    """q3 and q5 wall time (operator work only, inputs resident in HBM, synthetic TPC-H-shaped tables)."""
+    n_li = T.LINEITEM_ROWS.get(sf, int(6_000_000 * sf))
+    n_orders, n_cust, n_supp = (n_li + 3) // 4, int(150_000 * sf), int(10_000 * sf)
+    li = T.gen_lineitem_device(tc, n_li, n_supp=n_supp, columns=("l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate"))
+    od = T.gen_orders_device(tc, n_orders, n_cust)
+    cu = T.gen_customer_device(tc, n_cust)
+    su = T.gen_supplier_device(tc, n_supp)
+    nation, region = T.nation_region_arrow()
+    out = {"sf": sf, "lineitem_rows": n_li}
+    for name, mk in (("q3", lambda: T.q3_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]))),
+                     ("q5", lambda: T.q5_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), g.MemoryExec([su]), g.MemoryExec([nation]), g.MemoryExec([region])))):
+        times = []
+        for r in range(3):
+            plan = mk()
+            _sync(tc)
+            t0 = time.perf_counter()
+            res = g.plan.materialize(tc, plan.execute(0, tc))
+            _sync(tc)
+            times.append(time.perf_counter() - t0)
+        out[name] = {"wall_ms_best": min(times[1:]) * 1e3, "wall_ms_first": times[0] * 1e3, "result_rows": res.num_rows,
+                     "lineitem_rows_per_s": n_li / min(times[1:])}
+    return out
+
+
+def run(tc, T, g, full=True):
+    extra = {"join_probe": []}
+    grid = [(20, 28, 1.0), (24, 28, 1.0), (27, 28, 1.0), (24, 28, 0.5), (24, 28, 0.1)] if full else [(20, 24, 1.0)]
+    for b, p, h in grid:
+        extra["join_probe"].append(join_probe_micro(tc, g, b, p, h))
+    extra["tpch"] = tpch_pipelines(tc, T, g, 10 if full else 1)
+    return extra
+
+
+if __name__ == "__main__":
+    import json
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tpch_util as T
+    import arrow_ballista_amd as g
+    tc = g.TaskContext(device=0)
+    print(json.dumps(run(tc, T, g, full="--small" not in sys.argv), indent=1))
