@@ -7,7 +7,7 @@ anywhere (so descriptors can be compiled and validated on a host without a GPU),
 :class:`Context` without a HIP device raises.
 """
 from .binding import (  # noqa: F401
-    GpuqError, Context, Op, JoinTable, lib, lib_path, compile_check,
+    GpuqError, Context, Op, JoinTable, lib, lib_path, compile_check, compile_jit_source,
     T_NULL, T_BOOL, T_INT32, T_INT64, T_DATE32, T_FLOAT64, T_DECIMAL128, T_UTF8, T_UINT32, T_UINT64,
 )
 from . import expr  # noqa: F401

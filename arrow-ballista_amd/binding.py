@@ -88,8 +88,12 @@ def lib():
         "gpuq_table_column": (i32, [vp, i32, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info)]),
         "gpuq_table_free": (None, [vp]),
         "gpuq_export_arrow": (i32, [vp, vp, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info), i32, i64, vp, vp]),
+        "gpuq_ctx_set_jit": (i32, [vp, C.c_char_p, i64]),
+        "gpuq_ctx_jit_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]),
+        "gpuq_op_jit_source": (i32, [vp, i32, C.c_char_p, C.c_size_t]),
         "gpuq_op_create": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
         "gpuq_compile_check": (i32, [C.c_char_p, C.c_char_p, C.c_size_t]),
+        "gpuq_compile_jit_source": (i32, [C.c_char_p, i32, C.c_char_p, C.c_size_t]),
         "gpuq_op_free": (None, [vp]),
         "gpuq_op_num_outputs": (i32, [vp]),
         "gpuq_op_output_field": (i32, [vp, i32, C.POINTER(gpuq_field_info)]),
@@ -134,6 +138,16 @@ def compile_check(descriptor):
     return json.loads(buf.value.decode())
 
 
+def compile_jit_source(descriptor, kernel_id):
+    """Host only: the source the JIT path hands to hiprtc for this descriptor and sink kernel."""
+    L = lib()
+    buf = C.create_string_buffer(1 << 20)
+    rc = L.gpuq_compile_jit_source(json.dumps(descriptor).encode(), int(kernel_id), buf, len(buf))
+    if rc != 0:
+        raise GpuqError(rc, L.gpuq_last_error(None).decode())
+    return buf.value.decode()
+
+
 class Context:
     """gpuq_ctx: one device.  Raises GpuqError when no HIP device is usable (no CPU fallback)."""
 
@@ -147,6 +161,15 @@ class Context:
     def check(self, rc):
         if rc != 0:
             raise GpuqError(rc, self.L.gpuq_last_error(self.h).decode())
+
+    def set_jit(self, mode, min_rows=-1):
+        self.check(self.L.gpuq_ctx_set_jit(self.h, mode.encode(), int(min_rows)))
+
+    def jit_stats(self):
+        a, n = C.c_int(0), C.c_int(0)
+        buf = C.create_string_buffer(8192)
+        self.L.gpuq_ctx_jit_stats(self.h, C.byref(a), C.byref(n), buf, len(buf))
+        return {"available": bool(a.value), "launches": n.value, "last_error": buf.value.decode(errors="replace")}
 
     def info(self):
         buf = C.create_string_buffer(1024)
@@ -184,6 +207,11 @@ class Op:
 
     def check(self, stream=None):
         self.ctx.check(self.L.gpuq_op_check(self.h, stream))
+
+    def jit_source(self, kernel_id):
+        buf = C.create_string_buffer(1 << 20)
+        self.ctx.check(self.L.gpuq_op_jit_source(self.h, kernel_id, buf, len(buf)))
+        return buf.value.decode()
 
     def profile(self, enable=True):
         ms, n = C.c_float(0), C.c_int(0)

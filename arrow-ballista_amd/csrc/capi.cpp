@@ -4,10 +4,12 @@
 #include "../../include/gpuq.h"
 #include "expr_compile.h"
 #include "gpuq_kernels.h"
+#include "jit_runtime.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <memory>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -50,6 +52,10 @@ u64 next_pow2(u64 v) { u64 r = 1; while (r < v) r <<= 1; return r; }
 
 struct gpuq_ctx {
   int device = 0; int cus = 256; size_t hbm = 0; std::string name, arch, last_error;
+  int jit_mode = 1;                 // 0 off, 1 auto (inputs >= jit_min_rows), 2 force
+  i64 jit_min_rows = 1ll << 21;
+  std::string last_jit_error;       // auto mode: why the last specialisation fell back to the interpreter kernels
+  int jit_launches = 0;
 };
 
 struct gpuq_timer { hipEvent_t a = nullptr, b = nullptr; };
@@ -176,6 +182,25 @@ struct ProfScope {
     }
   }
   ~ProfScope() { if (op->profile) { (void)hipEventRecord(op->ev1, s); op->ev_pending = true; op->launches++; } }
+};
+
+// Route the next launch of sink kernel `kernel_id` to the hiprtc-specialised function when the context's
+// policy asks for it.  force: failures are errors.  auto: fall back to the (always present) interpreter kernels.
+struct JitScope {
+  bool active = false;
+  JitScope(gpuq_op* op, const CompiledProgram& cp, int kernel_id, i64 n) {
+    gpuq_ctx* c = op->ctx;
+    const bool use = c->jit_mode == 2 || (c->jit_mode == 1 && n >= c->jit_min_rows);
+    if (!use || cp.jit_src.empty()) return;
+    try {
+      const JitFn* f = jit_get(cp.jit_src, kernel_id);
+      jit_override().fn = f->fn; jit_override().kernel_id = kernel_id; active = true; c->jit_launches++;
+    } catch (const std::exception& e) {
+      if (c->jit_mode == 2) throw Unsupported(e.what());
+      c->last_jit_error = e.what();
+    }
+  }
+  ~JitScope() { jit_override().fn = nullptr; jit_override().kernel_id = 0; }
 };
 
 // ---------------------------------------------------------------- key layout
@@ -385,6 +410,10 @@ gpuq_ctx* gpuq_ctx_create(int device_ordinal, const char* json_opts) {
     c = new gpuq_ctx();
     c->device = dev; c->cus = prop.multiProcessorCount; c->hbm = prop.totalGlobalMem; c->name = prop.name; c->arch = prop.gcnArchName;
     set_num_cus(c->cus);
+    std::string jm = std::getenv("GPUQ_JIT") ? std::getenv("GPUQ_JIT") : "";
+    if (json_opts && *json_opts) { Json o = JsonParser(json_opts).parse(); jm = o.get_str("jit", jm); c->jit_min_rows = o.get_i64("jit_min_rows", c->jit_min_rows); }
+    if (jm == "off" || jm == "0") c->jit_mode = 0; else if (jm == "force" || jm == "2") c->jit_mode = 2; else c->jit_mode = 1;
+    if (!jit_available() && c->jit_mode == 1) c->jit_mode = 0;
   });
   if (rc != GPUQ_OK) { delete c; return nullptr; }
   return c;
@@ -532,6 +561,24 @@ int gpuq_compile_check(const char* json, char* buf, size_t cap) {
   delete op;
   return rc;
 }
+// Host-only: the hiprtc input for a descriptor + sink kernel, without a device (build-time check of the JIT path).
+int gpuq_compile_jit_source(const char* json, int kernel_id, char* buf, size_t cap) {
+  gpuq_op* op = nullptr;
+  int rc = guarded(nullptr, [&]() {
+    if (!json) throw std::runtime_error("json is NULL");
+    Json d = JsonParser(json).parse();
+    op = new gpuq_op();
+    g_upload = false;
+    compile_op(op, d);
+    g_upload = true;
+    const std::string src = jit_full_source(op->prog.jit_src, kernel_id);
+    if (src.size() + 1 > cap) throw Capacity("source needs " + std::to_string(src.size() + 1) + " bytes");
+    std::memcpy(buf, src.c_str(), src.size() + 1);
+  });
+  g_upload = true;
+  delete op;
+  return rc;
+}
 void gpuq_op_free(gpuq_op* op) { delete op; }
 int gpuq_op_num_outputs(gpuq_op* op) { return op ? (int)op->out_fields.size() : 0; }
 int gpuq_op_output_field(gpuq_op* op, int i, gpuq_field_info* out) {
@@ -570,7 +617,7 @@ int gpuq_filter_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload
     u64* bitmap = (u64*)op->ws[0].ensure((size_t)nwords * 8);
     uint32_t* counts = (uint32_t*)op->ws[1].ensure((size_t)nblocks * 4 + 16);
     u64* total = count_out ? (u64*)count_out : (u64*)op->ws[2].ensure(8);
-    { ProfScope ps(op, s); launch_filter_bitmap(s, P, n, bitmap, counts, nblocks, wpb); }
+    { JitScope js(op, op->prog, 1, n); ProfScope ps(op, s); launch_filter_bitmap(s, P, n, bitmap, counts, nblocks, wpb); }
     launch_scan_block_counts(s, counts, nblocks, total);
     if (sel_out) launch_compact(s, bitmap, counts, nblocks, wpb, n, payload_via > 0 ? in->via[payload_via - 1] : nullptr, sel_out);
     HIPCHECK(hipGetLastError());
@@ -587,7 +634,7 @@ int gpuq_project_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_colum
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     OutSpec O = make_outspec(op->prog, outs, n_outs, op->out_fields);
     for (int i = 0; i < n_outs; ++i) outs[i].length = in->n_rows;
-    { ProfScope ps(op, s); launch_project(s, P, in->n_rows, O); }
+    { JitScope js(op, op->prog, 2, in->n_rows); ProfScope ps(op, s); launch_project(s, P, in->n_rows, O); }
     HIPCHECK(hipGetLastError());
   });
 }
@@ -629,7 +676,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
           void* wsp = op->ws[4].ensure(wsb);
           alloc_raw(64);
           reset_flags(op, s);
-          { ProfScope ps(op, s); launch_agg_tiny(s, P, n, op->agg, gmax, wsp, raw); }
+          { JitScope js(op, op->prog, 3, n); ProfScope ps(op, s); launch_agg_tiny(s, P, n, op->agg, gmax, wsp, raw); }
           HIPCHECK(hipGetLastError());
           const uint32_t f = read_flags(op, s);
           if (f & ~FLAG_GROUP_OVERFLOW) { reset_flags(op, s); raise_flags(f & ~FLAG_GROUP_OVERFLOW); }
@@ -649,7 +696,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         T.slots = (u64*)op->ws[5].ensure((size_t)T.n_slots * T.slot_words * 8);
         launch_ht_init(s, T, &op->agg);
         reset_flags(op, s);
-        { ProfScope ps(op, s); launch_agg_hash(s, P, n, op->keys, op->agg, T); }
+        { JitScope js(op, op->prog, 4, n); ProfScope ps(op, s); launch_agg_hash(s, P, n, op->keys, op->agg, T); }
         HIPCHECK(hipGetLastError());
         const uint32_t f = read_flags(op, s);
         if (f & FLAG_TABLE_FULL) { if (est >= (u64)std::max<i64>(n, 1024)) throw std::runtime_error("hash aggregate: table full at maximum size"); est = std::min<u64>(est * 4, (u64)std::max<i64>(n, 1024)); continue; }
@@ -720,7 +767,7 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     HIPCHECK(hipMemsetAsync(present, 0, bm, s));
     launch_ht_init(s, t->T, nullptr);
     reset_flags(op, s);
-    { ProfScope ps(op, s); launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq); }
+    { JitScope js(op, op->prog, 5, n); ProfScope ps(op, s); launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq); }
     HIPCHECK(hipGetLastError());
     const uint32_t f = read_flags(op, s);
     if (f & ~FLAG_DUP_BUILD_KEY) { reset_flags(op, s); raise_flags(f & ~FLAG_DUP_BUILD_KEY); }
@@ -766,7 +813,7 @@ int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpu
       uint32_t* match = (uint32_t*)op->ws[0].ensure((size_t)n * 4 + 16);
       u64* bitmap = (u64*)op->ws[1].ensure((size_t)nwords * 8);
       uint32_t* counts = (uint32_t*)op->ws[2].ensure((size_t)nblocks * 4 + 16);
-      { ProfScope ps(op, s);
+      { JitScope js(op, op->prog, 7, n); ProfScope ps(op, s);
         launch_join_probe_unique(s, P, n, op->keys, t->T, jt, op->null_eq, match, bitmap, counts, nblocks, wpb, visited); }
       launch_scan_block_counts(s, counts, nblocks, (u64*)count_out);
       if (out_probe) launch_compact_pairs(s, bitmap, counts, nblocks, wpb, n, match, payload_via > 0 ? in->via[payload_via - 1] : nullptr,
@@ -775,7 +822,7 @@ int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpu
       return;
     }
     HIPCHECK(hipMemsetAsync(count_out, 0, 8, s));
-    { ProfScope ps(op, s);
+    { JitScope js(op, op->prog, 6, in->n_rows); ProfScope ps(op, s);
       launch_join_probe(s, P, in->n_rows, op->keys, t->T, t->next.as<uint32_t>(), jt, payload_via, op->null_eq, out_build, out_probe, out_cap, (u64*)count_out, visited); }
     HIPCHECK(hipGetLastError());
   });
@@ -822,7 +869,7 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
     // 1. per-key min/max in the ordered view
     const int mb = sort_minmax_blocks(n);
     u64* mm = (u64*)op->ws[0].ensure((size_t)mb * MAX_SORT_KEYS * 5 * 8);
-    launch_sort_minmax(s, P, n, S, mm, mb);
+    { JitScope js(op, op->prog, 8, n); launch_sort_minmax(s, P, n, S, mm, mb); }
     std::vector<u64> hmm((size_t)mb * MAX_SORT_KEYS * 5);
     HIPCHECK(hipMemcpyAsync(hmm.data(), mm, hmm.size() * 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
@@ -860,7 +907,7 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
     const size_t swb = exclusive_scan_ws_bytes((i64)radix_hist_entries(nblocks));
     void* sws = op->ws[7].ensure(swb);
     ProfScope ps(op, s);
-    launch_sort_pack(s, P, n, S, K, klo, khi, ids);
+    { JitScope js(op, op->prog, 9, n); launch_sort_pack(s, P, n, S, K, klo, khi, ids); }
     auto run_passes = [&](int bits) {
       for (int sh = 0; sh < bits; sh += 8) {
         launch_radix_pass(s, klo, ids, n, sh, 0xFFu, klo2, ids2, hist, sws, swb);
@@ -900,7 +947,7 @@ int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t
     const size_t swb = exclusive_scan_ws_bytes((i64)radix_hist_entries(nblocks));
     void* sws = op->ws[7].ensure(swb);
     ProfScope ps(op, s);
-    launch_part_pid(s, P, n, op->keys, np, pid, ids);
+    { JitScope js(op, op->prog, 10, n); launch_part_pid(s, P, n, op->keys, np, pid, ids); }
     launch_part_offsets(s, pid, n, np, (uint32_t*)op->ws[8].ensure((size_t)(np + 1) * 4 + 16), (u64*)part_offsets_out);
     int bits = 0; while ((1u << bits) < np) ++bits;
     for (int sh = 0; sh < bits || sh == 0; sh += 8) {
@@ -1167,6 +1214,32 @@ int gpuq_export_arrow(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, cons
 }  // extern "C"
 
 extern "C" {
+// ---------------------------------------------------------------- JIT control / introspection
+int gpuq_ctx_set_jit(gpuq_ctx* ctx, const char* mode, int64_t min_rows) {
+  return guarded(ctx, [&]() {
+    if (!ctx || !mode) throw std::runtime_error("ctx/mode is NULL");
+    const std::string m = mode;
+    if (m == "off") ctx->jit_mode = 0; else if (m == "auto") ctx->jit_mode = jit_available() ? 1 : 0; else if (m == "force") ctx->jit_mode = 2;
+    else throw std::runtime_error("jit mode must be off|auto|force");
+    if (min_rows >= 0) ctx->jit_min_rows = min_rows;
+  });
+}
+int gpuq_ctx_jit_stats(gpuq_ctx* ctx, int* available, int* launches, char* last_error, size_t cap) {
+  if (!ctx) return GPUQ_ERR_INVALID;
+  if (available) *available = jit_available() ? 1 : 0;
+  if (launches) *launches = ctx->jit_launches;
+  if (last_error && cap) std::snprintf(last_error, cap, "%s", ctx->last_jit_error.c_str());
+  return GPUQ_OK;
+}
+int gpuq_op_jit_source(gpuq_op* op, int kernel_id, char* buf, size_t cap) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() {
+    const std::string src = jit_full_source(op->prog.jit_src, kernel_id);
+    if (buf && cap) std::snprintf(buf, cap, "%s", src.c_str());
+    if (src.size() + 1 > cap) throw Capacity("source needs " + std::to_string(src.size() + 1) + " bytes");
+  });
+}
+
 // ---------------------------------------------------------------- timers
 int gpuq_timer_create(gpuq_ctx* ctx, gpuq_timer** out) {
   return guarded(ctx, [&]() { check_ctx(ctx); auto* t = new gpuq_timer(); HIPCHECK(hipEventCreate(&t->a)); HIPCHECK(hipEventCreate(&t->b)); *out = t; });

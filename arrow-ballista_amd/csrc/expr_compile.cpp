@@ -457,7 +457,230 @@ CompiledProgram ExprCompiler::finish() {
   for (auto& o : outs_) {
     C.out_reg.push_back(reg.at(rep(o.get()))); C.out_type.push_back(o->type); C.out_nullable.push_back(o->nullable); C.out_key.push_back(o->key);
   }
+  C.jit_src = jit_source(C, order, reg);
   return C;
+}
+
+// ------------------------------------------------------------------ JIT source
+// Same DAG, emitted as one straight-line typed function: every first-level load is issued before any
+// loaded value is touched, integers stay 64-bit wherever the range analysis allows, the predicate
+// returns early, and only the registers a sink reads are written.
+std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector<Node*>& order, const std::map<Node*, int>& /*reg*/) {
+  auto rep = [](Node* n) { while (n->kind == Node::OPN && n->op == OP_MOV) n = n->ch[0].get(); return n; };
+  std::string S;
+  auto L = [&](const std::string& l) { S += "  " + l + "\n"; };
+  std::map<Node*, std::string> name;       // value expression of a node (variable name)
+  std::map<Node*, std::string> nul;        // null expression ("false" or variable)
+  auto is_str = [](const Node* n) { return n->type.id == T_UTF8; };
+  auto is_f = [](const Node* n) { return n->type.id == T_FLOAT64; };
+  auto is_b = [](const Node* n) { return n->type.id == T_BOOL; };
+  auto wide = [&](const Node* n) { return !is_str(n) && !is_f(n) && !is_b(n) && n->bits > 64; };
+  auto ctype = [&](const Node* n) { return is_f(n) ? std::string("double") : (is_b(n) ? std::string("bool") : (wide(n) ? std::string("i128") : std::string("i64"))); };
+  S += "__device__ __forceinline__ bool gpuq_jit_eval(const DevProgram& P, i64 pos, GPUQ_REGS_PARAM) {\n";
+  // ---- rows
+  bool via_used[MAX_VIA + 1] = {false, false, false, false};
+  for (size_t c = 0; c < C.col_field.size(); ++c) via_used[schema_.fields[C.col_field[c]].side] = true;
+  L("const uint32_t row0 = (uint32_t)pos;");
+  for (int k = 1; k <= MAX_VIA; ++k) if (via_used[k]) L("const uint32_t row" + std::to_string(k) + " = P.via[" + std::to_string(k - 1) + "][pos];");
+  // ---- phase A: loads only
+  for (size_t c = 0; c < C.col_field.size(); ++c) {
+    const Field& f = schema_.fields[C.col_field[c]];
+    const std::string cs = std::to_string(c), row = "row" + std::to_string(f.side);
+    L("const DevCol& col" + cs + " = P.cols[" + cs + "];");
+    if (f.side > 0) { L("const bool ok" + cs + " = " + row + " != NULL_ROW;"); L("const uint32_t r" + cs + " = ok" + cs + " ? " + row + " : 0u;"); }
+    else L("const uint32_t r" + cs + " = " + row + ";");
+    if (f.nullable) L("const uint32_t vb" + cs + " = (col" + cs + ".validity ? col" + cs + ".validity : (const uint8_t*)P.code)[col" + cs + ".validity ? (r" + cs + " >> 3) : 0u];");
+    const int cls = f.raw128 ? (int)CC_I128 : col_class_for(f.type);
+    switch (cls) {
+      case CC_I32: case CC_U32: L("const uint32_t a" + cs + " = ((const uint32_t*)col" + cs + ".data)[r" + cs + "];"); break;
+      case CC_I64: L("const u64 a" + cs + " = ((const u64*)col" + cs + ".data)[r" + cs + "];"); break;
+      case CC_I128: L("const ulonglong2 a" + cs + " = ((const ulonglong2*)col" + cs + ".data)[r" + cs + "];"); break;
+      case CC_BIT: L("const uint32_t a" + cs + " = ((const uint8_t*)col" + cs + ".data)[r" + cs + " >> 3];"); break;
+      case CC_STR: L("const int32_t o" + cs + "a = col" + cs + ".offsets[r" + cs + "], o" + cs + "b = col" + cs + ".offsets[r" + cs + " + 1];"); break;
+    }
+  }
+  // ---- phase B1: first byte of every string column
+  for (size_t c = 0; c < C.col_field.size(); ++c) {
+    const Field& f = schema_.fields[C.col_field[c]];
+    if (f.raw128 || f.type.id != T_UTF8) continue;
+    const std::string cs = std::to_string(c);
+    L("const int32_t len" + cs + " = o" + cs + "b - o" + cs + "a;");
+    L("const uint8_t* sp" + cs + " = (const uint8_t*)col" + cs + ".data + o" + cs + "a;");
+    L("const u64 fb" + cs + " = (len" + cs + " > 0) ? (u64)sp" + cs + "[0] : 0ull;");
+  }
+  // ---- phase B2: typed column values
+  std::map<int, std::string> col_null;
+  for (Node* n : order) {
+    if (n->kind != Node::COL) continue;
+    int c = -1; for (size_t k = 0; k < C.col_field.size(); ++k) if (C.col_field[k] == n->col) c = (int)k;
+    const Field& f = schema_.fields[n->col];
+    const std::string cs = std::to_string(c);
+    std::string nn = "false";
+    if (f.nullable || f.side > 0) {
+      std::string e;
+      if (f.side > 0) e = "!ok" + cs;
+      if (f.nullable) e += std::string(e.empty() ? "" : " || ") + "(col" + cs + ".validity && !((vb" + cs + " >> (r" + cs + " & 7)) & 1u))";
+      L("const bool n_c" + cs + " = " + e + ";");
+      nn = "n_c" + cs;
+    }
+    nul[n] = nn;
+    const int cls = f.raw128 ? (int)CC_I128 : col_class_for(f.type);
+    if (is_str(n)) {
+      if (f.raw128) { L("const u64 c" + cs + "_lo = a" + cs + ".x, c" + cs + "_hi = a" + cs + ".y;"); }
+      else {
+        L("if (len" + cs + " > 15 && P.flags) atomicOr(P.flags, FLAG_STR_TRUNC);");
+        L("u64 c" + cs + "_hi = fb" + cs + " << 56, c" + cs + "_lo = 0;");
+        L("{ const int nb = len" + cs + " < 15 ? len" + cs + " : 15; for (int k = 1; k < nb; ++k) { const u64 b = sp" + cs + "[k]; if (k < 8) c" + cs + "_hi |= b << (56 - 8 * k); else c" + cs + "_lo |= b << (56 - 8 * (k - 8)); } }");
+        L("c" + cs + "_lo |= (u64)(len" + cs + " < 255 ? len" + cs + " : 255);");
+      }
+      name[n] = "c" + cs;
+      continue;
+    }
+    std::string v;
+    switch (cls) {
+      case CC_I32: v = "(i64)(int32_t)a" + cs; break;
+      case CC_U32: v = "(i64)a" + cs; break;
+      case CC_I64: v = is_f(n) ? "__longlong_as_double((i64)a" + cs + ")" : "(i64)a" + cs; break;
+      case CC_I128:
+        if (is_f(n)) v = "__longlong_as_double((i64)a" + cs + ".x)";
+        else if (is_b(n)) v = "(a" + cs + ".x != 0)";
+        else v = wide(n) ? "mk128(a" + cs + ".x, a" + cs + ".y)" : "(i64)a" + cs + ".x";
+        break;
+      case CC_BIT: v = "(((a" + cs + " >> (r" + cs + " & 7)) & 1u) != 0)"; break;
+    }
+    L("const " + ctype(n) + " c" + cs + " = " + v + ";");
+    name[n] = "c" + cs;
+  }
+  // ---- expressions
+  int vid = 0;
+  auto V = [&](const NodeP& x) { return name.at(rep(x.get())); };
+  auto N = [&](const NodeP& x) { return nul.at(rep(x.get())); };
+  auto orn = [&](std::initializer_list<std::string> xs) { std::string r; for (auto& x : xs) if (x != "false") r += (r.empty() ? "" : " || ") + x; return r.empty() ? std::string("false") : r; };
+  auto as128 = [&](const NodeP& x) { Node* r = rep(x.get()); return is_str(r) ? "mk128(" + name.at(r) + "_lo, " + name.at(r) + "_hi)" : "(i128)" + name.at(r); };
+  Node* predn = pred_ ? rep(pred_.get()) : nullptr;
+  bool pred_done = false;
+  auto emit_pred = [&]() { if (predn && !pred_done && name.count(predn)) { L("if (" + (nul.at(predn) == "false" ? std::string("") : "(" + nul.at(predn) + ") || ") + "!" + name.at(predn) + ") return false;"); pred_done = true; } };
+  emit_pred();
+  for (Node* n : order) {
+    if (n->kind == Node::COL) continue;
+    const std::string t = "t" + std::to_string(vid++);
+    if (n->kind == Node::LIT) {
+      if (n->lit_null) { nul[n] = "true"; if (is_str(n)) { L("const u64 " + t + "_lo = 0, " + t + "_hi = 0;"); } else L("const " + ctype(n) + " " + t + " = 0;"); name[n] = t; continue; }
+      nul[n] = "false";
+      if (is_str(n)) L("const u64 " + t + "_lo = " + std::to_string(n->lit_lo) + "ull, " + t + "_hi = " + std::to_string(n->lit_hi) + "ull;");
+      else if (is_f(n)) L("const double " + t + " = __longlong_as_double((i64)" + std::to_string(n->lit_lo) + "ull);");
+      else if (is_b(n)) L("const bool " + t + " = " + (n->lit_lo ? "true" : "false") + ";");
+      else if (wide(n)) L("const i128 " + t + " = mk128(" + std::to_string(n->lit_lo) + "ull, " + std::to_string(n->lit_hi) + "ull);");
+      else L("const i64 " + t + " = (i64)" + std::to_string(n->lit_lo) + "ull;");
+      name[n] = t; continue;
+    }
+    const NodeP& a = n->ch[0];
+    const NodeP& b = n->ch.size() > 1 ? n->ch[1] : n->ch[0];
+    const std::string T = ctype(n);
+    std::string e, ne = orn({N(a), n->ch.size() > 1 ? N(b) : std::string("false")});
+    auto cmp = [&](const char* op) {
+      Node* ra = rep(a.get());
+      if (is_str(ra)) {
+        if (std::string(op) == "==") return "(" + V(a) + "_lo == " + V(b) + "_lo && " + V(a) + "_hi == " + V(b) + "_hi)";
+        if (std::string(op) == "!=") return "(" + V(a) + "_lo != " + V(b) + "_lo || " + V(a) + "_hi != " + V(b) + "_hi)";
+        return "(" + as128(a) + " " + op + " " + as128(b) + ")";
+      }
+      if (is_b(ra)) return "((int)" + V(a) + " " + op + " (int)" + V(b) + ")";
+      return "(" + V(a) + " " + op + " " + V(b) + ")";
+    };
+    auto fkey = [&](const NodeP& x) { return "f64_total_key((u64)__double_as_longlong(" + V(x) + "))"; };
+    bool two_vars = false;
+    switch (n->op) {
+      case OP_ADD: e = wide(n) ? "(" + as128(a) + " + " + as128(b) + ")" : "(i64)((u64)" + V(a) + " + (u64)" + V(b) + ")"; break;
+      case OP_SUB: e = wide(n) ? "(" + as128(a) + " - " + as128(b) + ")" : "(i64)((u64)" + V(a) + " - (u64)" + V(b) + ")"; break;
+      case OP_MUL: case OP_MULW:
+        e = wide(n) ? "(i128)((u128)" + as128(a) + " * (u128)" + as128(b) + ")" : "(i64)((u64)" + V(a) + " * (u64)" + V(b) + ")"; break;
+      case OP_NEG: e = wide(n) ? "(-" + as128(a) + ")" : "(i64)(0ull - (u64)" + V(a) + ")"; ne = N(a); break;
+      case OP_DIV: case OP_MOD: {
+        const bool narrow = !wide(rep(a.get())) && !wide(rep(b.get()));
+        L("const bool " + t + "_z = (" + V(b) + " == 0);");
+        if (narrow) e = "(" + t + "_z ? (i64)0 : (i64)(" + V(a) + (n->op == OP_DIV ? " / " : " % ") + "(" + t + "_z ? (i64)1 : (i64)" + V(b) + ")))";
+        else { L("i128 " + t + "_q = 0, " + t + "_r = 0; if (!" + t + "_z) divmod128(" + as128(a) + ", " + as128(b) + ", " + t + "_q, " + t + "_r);");
+               e = std::string("(") + T + ")" + t + (n->op == OP_DIV ? "_q" : "_r"); }
+        ne = orn({N(a), N(b), t + "_z"});
+        break;
+      }
+      case OP_EQ: e = cmp("=="); break;  case OP_NE: e = cmp("!="); break;  case OP_LT: e = cmp("<"); break;
+      case OP_LE: e = cmp("<="); break;  case OP_GT: e = cmp(">"); break;   case OP_GE: e = cmp(">="); break;
+      case OP_FADD: e = "(" + V(a) + " + " + V(b) + ")"; break;  case OP_FSUB: e = "(" + V(a) + " - " + V(b) + ")"; break;
+      case OP_FMUL: e = "(" + V(a) + " * " + V(b) + ")"; break;  case OP_FDIV: e = "(" + V(a) + " / " + V(b) + ")"; break;
+      case OP_FNEG: e = "__longlong_as_double(__double_as_longlong(" + V(a) + ") ^ (i64)0x8000000000000000ull)"; ne = N(a); break;
+      case OP_FEQ: e = "(" + fkey(a) + " == " + fkey(b) + ")"; break;  case OP_FNE: e = "(" + fkey(a) + " != " + fkey(b) + ")"; break;
+      case OP_FLT: e = "(" + fkey(a) + " < " + fkey(b) + ")"; break;   case OP_FLE: e = "(" + fkey(a) + " <= " + fkey(b) + ")"; break;
+      case OP_FGT: e = "(" + fkey(a) + " > " + fkey(b) + ")"; break;   case OP_FGE: e = "(" + fkey(a) + " >= " + fkey(b) + ")"; break;
+      case OP_I2F: {
+        Node* ra = rep(a.get());
+        if (is_b(ra)) e = "(double)(int)" + V(a);
+        else if (!wide(ra)) e = "(double)" + V(a);
+        else e = "(((i64)((u128)" + V(a) + " >> 64) == ((i64)(u64)" + V(a) + " >> 63)) ? (double)(i64)(u64)" + V(a) + " : ((double)(i64)((u128)" + V(a) + " >> 64) * 18446744073709551616.0 + (double)(u64)" + V(a) + "))";
+        ne = N(a); break;
+      }
+      case OP_F2I: e = "(i64)" + V(a); ne = N(a); break;
+      case OP_AND: {
+        const std::string af = "(!(" + N(a) + ") && !" + V(a) + ")", bf = "(!(" + N(b) + ") && !" + V(b) + ")";
+        e = "!(" + af + " || " + bf + ")"; ne = "(!(" + af + " || " + bf + ") && (" + orn({N(a), N(b)}) + "))"; break;
+      }
+      case OP_OR: {
+        const std::string at = "(!(" + N(a) + ") && " + V(a) + ")", bt = "(!(" + N(b) + ") && " + V(b) + ")";
+        e = "(" + at + " || " + bt + ")"; ne = "(!(" + at + " || " + bt + ") && (" + orn({N(a), N(b)}) + "))"; break;
+      }
+      case OP_NOT: e = "!" + V(a); ne = N(a); break;
+      case OP_ISNULL: e = "(" + N(a) + ")"; ne = "false"; break;
+      case OP_ISNOTNULL: e = "!(" + N(a) + ")"; ne = "false"; break;
+      case OP_SELECT: {
+        const NodeP& f = n->ch[2];
+        L("const bool " + t + "_c = !(" + N(a) + ") && " + V(a) + ";");
+        if (is_str(n)) { L("const u64 " + t + "_lo = " + t + "_c ? " + V(b) + "_lo : " + V(f) + "_lo, " + t + "_hi = " + t + "_c ? " + V(b) + "_hi : " + V(f) + "_hi;"); two_vars = true; }
+        else e = "(" + t + "_c ? (" + T + ")" + V(b) + " : (" + T + ")" + V(f) + ")";
+        ne = (N(b) == "false" && N(f) == "false") ? "false" : "(" + t + "_c ? (" + N(b) + ") : (" + N(f) + "))";
+        break;
+      }
+      case OP_SHL: e = "(i128)((u128)" + as128(a) + " << " + std::to_string(n->imm) + ")"; ne = N(a); break;
+      case OP_BOR: e = "(" + as128(a) + " | " + as128(b) + ")"; break;
+      case OP_NULLIF0: {
+        Node* rb = rep(b.get());
+        const std::string bz = is_str(rb) ? "(" + V(b) + "_lo == 0 && " + V(b) + "_hi == 0)" : (is_f(rb) ? "(__double_as_longlong(" + V(b) + ") == 0)" : "(" + V(b) + " == 0)");
+        if (is_str(n)) { L("const u64 " + t + "_lo = " + V(a) + "_lo, " + t + "_hi = " + V(a) + "_hi;"); two_vars = true; } else e = "(" + T + ")" + V(a);
+        ne = orn({N(a), N(b), bz}); break;
+      }
+      case OP_COALESCE0:
+        if (is_str(n)) { L("const u64 " + t + "_lo = (" + N(a) + ") ? 0 : " + V(a) + "_lo, " + t + "_hi = (" + N(a) + ") ? 0 : " + V(a) + "_hi;"); two_vars = true; }
+        else e = "((" + N(a) + ") ? (" + T + ")0 : (" + T + ")" + V(a) + ")";
+        ne = "false"; break;
+      default: throw std::runtime_error("jit: unsupported op " + std::to_string(n->op));
+    }
+    if (!two_vars) L("const " + T + " " + t + " = (" + T + ")" + e + ";");
+    if (!n->nullable || ne == "false") nul[n] = "false";
+    else { L("const bool " + t + "_n = " + ne + ";"); nul[n] = t + "_n"; }
+    name[n] = t;
+    emit_pred();
+  }
+  emit_pred();
+  // ---- outputs into the registers the sink reads
+  L("uint32_t nm = 0;");
+  std::set<int> done;
+  for (size_t k = 0; k < outs_.size(); ++k) {
+    Node* o = rep(outs_[k].get());
+    const int r = C.out_reg[k];
+    if (done.count(r)) continue;
+    done.insert(r);
+    const std::string rs = std::to_string(r);
+    if (is_str(o)) L("rlo[" + rs + "] = " + name.at(o) + "_lo; rhi[" + rs + "] = " + name.at(o) + "_hi;");
+    else if (is_f(o)) L("rlo[" + rs + "] = (u64)__double_as_longlong(" + name.at(o) + "); rhi[" + rs + "] = 0;");
+    else if (is_b(o)) L("rlo[" + rs + "] = " + name.at(o) + " ? 1ull : 0ull; rhi[" + rs + "] = 0;");
+    else if (wide(o)) L("rlo[" + rs + "] = (u64)" + name.at(o) + "; rhi[" + rs + "] = (u64)((u128)" + name.at(o) + " >> 64);");
+    else L("rlo[" + rs + "] = (u64)" + name.at(o) + "; rhi[" + rs + "] = (u64)(" + name.at(o) + " >> 63);");
+    if (nul.at(o) != "false") L("if (" + nul.at(o) + ") nm |= " + std::to_string(1u << r) + "u;");
+  }
+  L("rnulls = nm;");
+  L("return true;");
+  S += "}\n";
+  return S;
 }
 
 }  // namespace gpuq

@@ -77,6 +77,7 @@ struct CompiledProgram {
   std::vector<DType> out_type;
   std::vector<bool> out_nullable;
   std::vector<std::string> out_key;
+  std::string jit_src;          // C++ source of gpuq_jit_eval() for this program (typed, straight-line)
 };
 
 class ExprCompiler {
@@ -111,6 +112,7 @@ class ExprCompiler {
   std::vector<NodeP> outs_;
   std::map<std::string, NodeP> interned_;
   NodeP intern(NodeP n);
+  std::string jit_source(const CompiledProgram& C, const std::vector<Node*>& order, const std::map<Node*, int>& reg);
 };
 
 i128 pow10_i128(int k);

@@ -9,8 +9,16 @@
 // across the wave, operands live in a VGPR register file indexed through
 // s_set_gpr_idx (never scratch), intermediates never touch HBM.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+// hiprtc keeps the fixed-width integer names inside __hip_internal
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef signed int int32_t;
+typedef unsigned int uint32_t;
+#endif
 
 namespace gpuq {
 
@@ -137,6 +145,7 @@ __device__ inline void divmod128(i128 n, i128 d, i128& q, i128& r) {
   r = nn ? -(i128)ur : (i128)ur;
 }
 
+#ifndef GPUQ_JIT
 // ---------------------------------------------------------------- column load
 // Three phases, so that a wave has every column's load in flight before it consumes any of them
 // (one HBM round trip per 64-row step instead of one per column):
@@ -355,6 +364,14 @@ __device__ __forceinline__ bool row_passes(const DevProgram& P, GPUQ_REGS_CPARAM
   const int r = __builtin_amdgcn_readfirstlane(P.pred_reg);
   return rlo[r] != 0 && !((rnulls >> r) & 1);
 }
+
+#define GPUQ_EVAL(MAXC, P, pos) (load_columns<MAXC>(P, pos, GPUQ_REGS), run_program(P, GPUQ_REGS), row_passes(P, GPUQ_REGS))
+#else
+// JIT build: the row front-end is a generated, typed, straight-line function (jit_codegen.cpp) with the
+// same contract: fills the registers the sink reads and returns the row predicate.
+__device__ __forceinline__ bool gpuq_jit_eval(const DevProgram& P, i64 pos, GPUQ_REGS_PARAM);
+#define GPUQ_EVAL(MAXC, P, pos) gpuq_jit_eval(P, pos, GPUQ_REGS)
+#endif
 
 // ---------------------------------------------------------------- hashing
 // 64-bit mixer (splitmix64 finaliser).  This is gpuq's own partition/hash function;

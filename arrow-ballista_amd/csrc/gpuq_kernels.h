@@ -33,17 +33,7 @@ struct AggOut {
 };
 
 // scan kernels (kernels_scan.hip)
-void set_num_cus(int n);
-int num_cus();
-void launch_filter_bitmap(hipStream_t s, const DevProgram& P, i64 n, u64* bitmap, uint32_t* block_counts, int nblocks, i64 words_per_block);
-void launch_scan_block_counts(hipStream_t s, uint32_t* block_counts, int nblocks, u64* total_out);
-void launch_compact(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 words_per_block, i64 n,
-                    const uint32_t* sel_in, uint32_t* sel_out);
-void launch_project(hipStream_t s, const DevProgram& P, i64 n, const OutSpec& O);
 
-int agg_tiny_max_groups(int n_accs);
-size_t agg_tiny_workspace_bytes(int gmax, int n_keys, int n_accs, int* nblocks_out);
-void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace, const AggOut& out);
 
 // hash kernels (kernels_hash.hip)
 constexpr int MAX_KW = 2 * MAX_KEYS + 1;
@@ -68,21 +58,7 @@ struct HashTable {
 };
 enum JoinType : int32_t { JT_INNER = 0, JT_LEFT = 1, JT_RIGHT = 2, JT_FULL = 3, JT_LEFT_SEMI = 4, JT_LEFT_ANTI = 5, JT_RIGHT_SEMI = 6, JT_RIGHT_ANTI = 7 };
 
-void launch_ht_init(hipStream_t s, const HashTable& T, const AggSpec* A);
-void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T);
-void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags);
 // build: payload = payload_via ? via[payload_via-1][pos] : pos.  next == nullptr => unique keys only (FLAG_DUP_BUILD_KEY on a duplicate)
-void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
-                       int payload_via, int null_equals_null);
-void launch_join_probe_unique(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int join_type, int null_equals_null,
-                              uint32_t* match, u64* bitmap, uint32_t* block_counts, int nblocks, i64 wpb, uint32_t* visited);
-void launch_compact_pairs(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 wpb, i64 n, const uint32_t* match,
-                          const uint32_t* probe_via, uint32_t* out_build, uint32_t* out_probe, u64 out_cap, uint32_t* flags);
-void launch_bitmap_select(hipStream_t s, const u64* present, const u64* visited, int matched, i64 nwords, i64 n, u64* bitmap,
-                          uint32_t* block_counts, int nblocks, i64 wpb);
-void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, const uint32_t* next,
-                       int join_type, int payload_via, int null_equals_null, uint32_t* out_build, uint32_t* out_probe,
-                       u64 out_cap, u64* out_count, uint32_t* visited);
 
 // sort / partition (kernels_sort.hip)
 constexpr int MAX_SORT_KEYS = 4;
@@ -99,27 +75,12 @@ struct SortPack {                   // computed on the host from the per-key min
   int32_t null_bit[MAX_SORT_KEYS];  // bit (inside the field) of the null flag, -1 = none
   int32_t rshift[MAX_SORT_KEYS];    // packed Utf8: drop the length byte and the bytes beyond the longest string
 };
-int sort_minmax_blocks(i64 n);
-void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks);
-void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids);
-void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, uint32_t nparts, u64* pid_out, uint32_t* ids);
-void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out);
-void launch_gather_u64(hipStream_t s, const u64* src, const uint32_t* idx, i64 n, u64* dst);
-void radix_geometry(i64 n, int* nblocks, i64* tile);
-size_t radix_hist_entries(int nblocks);
-void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, uint32_t mask, u64* keys_out, uint32_t* vals_out,
-                       int32_t* hist, void* scan_ws, size_t scan_ws_bytes);
 
 // aggregate post-processing (kernels_scan.hip): AoS result -> one (lo,hi) column per key / accumulator
 struct AggSoA {
   ulonglong2* key_col[MAX_KEYS]; u64* key_valid[MAX_KEYS];   // validity words, bit g of word g/64
   ulonglong2* acc_col[MAX_ACCS];
 };
-void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa);
-void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out);
-void launch_unpack_utf8_bytes(hipStream_t s, const ulonglong2* packed, i64 n, const int32_t* offsets, uint8_t* data_out);
-void launch_exclusive_scan_i32(hipStream_t s, int32_t* data, i64 n, void* workspace, size_t ws_bytes);   // in place, n+1 entries out
-size_t exclusive_scan_ws_bytes(i64 n);
 
 // generator (kernels_gen.hip)
 struct LineitemCols {
@@ -132,9 +93,62 @@ struct LineitemCols {
 struct OrdersCols { i64* o_orderkey; i64* o_custkey; int32_t* o_orderdate; int32_t* o_shippriority; };
 struct CustomerCols { i64* c_custkey; i64* c_nationkey; uint8_t* c_mktsegment; int32_t* c_mktsegment_off; };
 struct SupplierCols { i64* s_suppkey; i64* s_nationkey; };
+
+#ifndef GPUQ_JIT
+// ---- host launch interface (AOT build only)
+void set_num_cus(int n);
+int num_cus();
+void launch_filter_bitmap(hipStream_t s, const DevProgram& P, i64 n, u64* bitmap, uint32_t* block_counts, int nblocks, i64 words_per_block);
+void launch_scan_block_counts(hipStream_t s, uint32_t* block_counts, int nblocks, u64* total_out);
+void launch_compact(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 words_per_block, i64 n,
+                    const uint32_t* sel_in, uint32_t* sel_out);
+void launch_project(hipStream_t s, const DevProgram& P, i64 n, const OutSpec& O);
+int agg_tiny_max_groups(int n_accs);
+size_t agg_tiny_workspace_bytes(int gmax, int n_keys, int n_accs, int* nblocks_out);
+void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace, const AggOut& out);
+void launch_ht_init(hipStream_t s, const HashTable& T, const AggSpec* A);
+void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T);
+void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags);
+void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
+                       int payload_via, int null_equals_null);
+void launch_join_probe_unique(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int join_type, int null_equals_null,
+                              uint32_t* match, u64* bitmap, uint32_t* block_counts, int nblocks, i64 wpb, uint32_t* visited);
+void launch_compact_pairs(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 wpb, i64 n, const uint32_t* match,
+                          const uint32_t* probe_via, uint32_t* out_build, uint32_t* out_probe, u64 out_cap, uint32_t* flags);
+void launch_bitmap_select(hipStream_t s, const u64* present, const u64* visited, int matched, i64 nwords, i64 n, u64* bitmap,
+                          uint32_t* block_counts, int nblocks, i64 wpb);
+void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, const uint32_t* next,
+                       int join_type, int payload_via, int null_equals_null, uint32_t* out_build, uint32_t* out_probe,
+                       u64 out_cap, u64* out_count, uint32_t* visited);
+int sort_minmax_blocks(i64 n);
+void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks);
+void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids);
+void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, uint32_t nparts, u64* pid_out, uint32_t* ids);
+void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out);
+void launch_gather_u64(hipStream_t s, const u64* src, const uint32_t* idx, i64 n, u64* dst);
+void radix_geometry(i64 n, int* nblocks, i64* tile);
+size_t radix_hist_entries(int nblocks);
+void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, uint32_t mask, u64* keys_out, uint32_t* vals_out,
+                       int32_t* hist, void* scan_ws, size_t scan_ws_bytes);
+void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa);
+void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out);
+void launch_unpack_utf8_bytes(hipStream_t s, const ulonglong2* packed, i64 n, const int32_t* offsets, uint8_t* data_out);
+void launch_exclusive_scan_i32(hipStream_t s, int32_t* data, i64 n, void* workspace, size_t ws_bytes);   // in place, n+1 entries out
+size_t exclusive_scan_ws_bytes(i64 n);
 void launch_gen_lineitem(hipStream_t s, u64 seed, u64 seed_orders, i64 row0, i64 n, i64 n_supp, const LineitemCols& c);
 void launch_gen_orders(hipStream_t s, u64 seed, i64 row0, i64 n, i64 n_cust, const OrdersCols& c);
 void launch_gen_customer(hipStream_t s, u64 seed, i64 row0, i64 n, const CustomerCols& c);
 void launch_gen_supplier(hipStream_t s, u64 seed, i64 row0, i64 n, const SupplierCols& c);
+
+// JIT redirection: while a JitOverride is alive on this thread, the next launch of the kernel family it
+// names goes to the hiprtc-compiled function instead of the AOT template instantiation.
+struct JitOverride { void* fn = nullptr; int kernel_id = 0; };
+JitOverride& jit_override();
+template <class... Args>
+inline hipError_t jit_launch(void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+  void* a[] = {(void*)&args...};
+  return hipModuleLaunchKernel((hipFunction_t)fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)lds, s, a, nullptr);
+}
+#endif  // GPUQ_JIT
 
 }  // namespace gpuq

@@ -1,0 +1,103 @@
+// Runtime specialisation of the row front-end with hiprtc.
+//
+// For large inputs the interpreter's per-row dispatch cost matters: the same typed DAG the
+// bytecode comes from is emitted as a straight-line C++ function (expr_compile.cpp::jit_source) and
+// compiled together with the UNCHANGED sink kernel source (embedded in this library at build time) into
+// one gfx950 code object.  hiprtc is loaded with dlopen, so the library still loads where it is absent;
+// the interpreter kernels are always there.
+#include "jit_runtime.h"
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <vector>
+
+extern "C" {
+extern const char* const gpuq_embedded_names[];
+extern const char* const gpuq_embedded_sources[];
+extern const int gpuq_embedded_count;
+}
+
+namespace gpuq {
+namespace {
+typedef struct _hiprtcProgram* hiprtcProgram;
+struct Rtc {
+  void* h = nullptr;
+  int (*Create)(hiprtcProgram*, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+  int (*Compile)(hiprtcProgram, int, const char* const*) = nullptr;
+  int (*LogSize)(hiprtcProgram, size_t*) = nullptr;
+  int (*Log)(hiprtcProgram, char*) = nullptr;
+  int (*CodeSize)(hiprtcProgram, size_t*) = nullptr;
+  int (*Code)(hiprtcProgram, char*) = nullptr;
+  int (*Destroy)(hiprtcProgram*) = nullptr;
+  bool ok = false;
+};
+Rtc& rtc() {
+  static Rtc r;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    for (const char* n : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) { r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+    if (!r.h) return;
+    r.Create = (decltype(r.Create))dlsym(r.h, "hiprtcCreateProgram");
+    r.Compile = (decltype(r.Compile))dlsym(r.h, "hiprtcCompileProgram");
+    r.LogSize = (decltype(r.LogSize))dlsym(r.h, "hiprtcGetProgramLogSize");
+    r.Log = (decltype(r.Log))dlsym(r.h, "hiprtcGetProgramLog");
+    r.CodeSize = (decltype(r.CodeSize))dlsym(r.h, "hiprtcGetCodeSize");
+    r.Code = (decltype(r.Code))dlsym(r.h, "hiprtcGetCode");
+    r.Destroy = (decltype(r.Destroy))dlsym(r.h, "hiprtcDestroyProgram");
+    r.ok = r.Create && r.Compile && r.LogSize && r.Log && r.CodeSize && r.Code && r.Destroy;
+  });
+  return r;
+}
+const char* file_of(int kernel_id) {
+  if (kernel_id >= 1 && kernel_id <= 3) return "kernels_scan.hip";
+  if (kernel_id >= 4 && kernel_id <= 7) return "kernels_hash.hip";
+  if (kernel_id >= 8 && kernel_id <= 10) return "kernels_sort.hip";
+  throw std::runtime_error("jit: bad kernel id");
+}
+std::mutex g_mu;
+std::map<std::string, JitFn> g_cache;
+}  // namespace
+
+bool jit_available() { return rtc().ok; }
+
+std::string jit_full_source(const std::string& eval_src, int kernel_id) {
+  return "#define GPUQ_JIT 1\n#define GPUQ_JIT_KERNEL " + std::to_string(kernel_id) +
+         "\n#include \"gpuq_kernels.h\"\nnamespace gpuq {\n" + eval_src + "}\n#include \"" + file_of(kernel_id) + "\"\n";
+}
+
+const JitFn* jit_get(const std::string& eval_src, int kernel_id) {
+  const std::string key = std::to_string(kernel_id) + "|" + eval_src;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_cache.find(key);
+  if (it != g_cache.end()) return &it->second;
+  Rtc& r = rtc();
+  if (!r.ok) throw std::runtime_error("jit: hiprtc is not available on this host");
+  const std::string src = jit_full_source(eval_src, kernel_id);
+  hiprtcProgram prog = nullptr;
+  if (r.Create(&prog, src.c_str(), "gpuq_jit.hip", gpuq_embedded_count, gpuq_embedded_sources, gpuq_embedded_names) != 0)
+    throw std::runtime_error("jit: hiprtcCreateProgram failed");
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+  const int rc = r.Compile(prog, 3, opts);
+  if (rc != 0) {
+    size_t ls = 0; r.LogSize(prog, &ls);
+    std::string log(ls + 1, 0); if (ls) r.Log(prog, &log[0]);
+    r.Destroy(&prog);
+    throw std::runtime_error("jit: compile failed:\n" + log.substr(0, 4000));
+  }
+  size_t cs = 0; r.CodeSize(prog, &cs);
+  std::vector<char> code(cs); r.Code(prog, code.data());
+  r.Destroy(&prog);
+  JitFn f{};
+  hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
+  hipError_t e = hipModuleLoadData(&mod, code.data());
+  if (e != hipSuccess) throw std::runtime_error(std::string("jit: hipModuleLoadData: ") + hipGetErrorString(e));
+  e = hipModuleGetFunction(&fn, mod, "gpuq_jit_entry");
+  if (e != hipSuccess) throw std::runtime_error(std::string("jit: hipModuleGetFunction: ") + hipGetErrorString(e));
+  f.module = mod; f.fn = fn;
+  return &(g_cache[key] = f);
+}
+
+}  // namespace gpuq

@@ -24,6 +24,7 @@ __device__ __host__ __forceinline__ i64 order_key(i64 o) { return (o >> 3) * 32 
 __device__ __host__ __forceinline__ int32_t order_date(u64 seed_orders, i64 o) { return 8035 + (int32_t)gen_mod(seed_orders, 4, (u64)o, 2406u); }
 
 // column ids: lineitem 1..9, orders 1..5, customer 1..3, supplier 1..2
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(256) k_gen_lineitem(const u64 seed, const u64 seed_orders, const i64 row0, const i64 n, const i64 n_supp,
                                                       const LineitemCols c) {
   for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
@@ -51,7 +52,9 @@ __global__ void __launch_bounds__(256) k_gen_lineitem(const u64 seed, const u64 
     }
   }
 }
+#endif
 
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(256) k_gen_orders(const u64 seed, const i64 row0, const i64 n, const i64 n_cust, const OrdersCols c) {
   for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
     const i64 o = row0 + j;
@@ -64,6 +67,7 @@ __global__ void __launch_bounds__(256) k_gen_orders(const u64 seed, const i64 ro
     if (c.o_shippriority) c.o_shippriority[j] = 0;
   }
 }
+#endif
 
 __constant__ const char kSegments[5][11] = {"AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"};
 __constant__ const int kSegLen[5] = {10, 8, 9, 9, 9};
@@ -85,6 +89,7 @@ __device__ __forceinline__ void seg_perm(u64 x64, int (&perm)[5]) {
   }
 }
 
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(256) k_gen_customer(const u64 seed, const i64 row0, const i64 n, const CustomerCols c) {
   // row0 must be a multiple of 5
   for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
@@ -107,7 +112,9 @@ __global__ void __launch_bounds__(256) k_gen_customer(const u64 seed, const i64 
     }
   }
 }
+#endif
 
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(256) k_gen_supplier(const u64 seed, const i64 row0, const i64 n, const SupplierCols c) {
   for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
     const i64 i = row0 + j;
@@ -115,7 +122,9 @@ __global__ void __launch_bounds__(256) k_gen_supplier(const u64 seed, const i64 
     if (c.s_nationkey) c.s_nationkey[j] = (i64)gen_mod(seed, 2, (u64)i, 25u);
   }
 }
+#endif
 
+#ifndef GPUQ_JIT
 static int ggrid(i64 n) {
   i64 need = (n + 255) / 256; if (need < 1) need = 1;
   const i64 cap = (i64)num_cus() * 16;
@@ -133,5 +142,7 @@ void launch_gen_customer(hipStream_t s, u64 seed, i64 row0, i64 n, const Custome
 void launch_gen_supplier(hipStream_t s, u64 seed, i64 row0, i64 n, const SupplierCols& c) {
   if (n > 0) hipLaunchKernelGGL(k_gen_supplier, dim3(ggrid(n)), dim3(256), 0, s, seed, row0, n, c);
 }
+
+#endif  // GPUQ_JIT
 
 }  // namespace gpuq

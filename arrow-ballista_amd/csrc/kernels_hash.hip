@@ -130,6 +130,7 @@ __device__ __forceinline__ bool ht_find(const HashTable& T, const u64 (&kw)[MAX_
 }
 
 // ------------------------------------------------------------------ table init
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(HBLOCK) k_ht_init(const HashTable T, const AggSpec A, const int has_agg) {
   const u64 total = T.n_slots * (u64)T.slot_words;
   const int cell0 = 1 + T.key_words;
@@ -151,17 +152,18 @@ __global__ void __launch_bounds__(HBLOCK) k_ht_init(const HashTable T, const Agg
     T.slots[i] = v;
   }
 }
+#endif
 
 // ------------------------------------------------------------------ hash aggregate
 template <int MAXC>
-__global__ void __launch_bounds__(HBLOCK) k_agg_hash(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T) {
+__device__ __forceinline__ void k_agg_hash_body(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T) {
   const i64 nwords = (n + 63) >> 6;
   const int cell0 = 1 + T.key_words;
   for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
     const i64 pos = (w << 6) + hlane();
     bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
     if (!active) continue;
     u64 kw[MAX_KW]; u64 h;
 #pragma unroll
@@ -212,7 +214,16 @@ __global__ void __launch_bounds__(HBLOCK) k_agg_hash(const DevProgram P, const i
     }
   }
 }
+#ifndef GPUQ_JIT
+template <int MAXC>
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(HBLOCK) k_agg_hash(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T) { k_agg_hash_body<MAXC>(P, n, K, A, T); }
+#endif
+#elif GPUQ_JIT_KERNEL == 4
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T) { k_agg_hash_body<0>(P, n, K, A, T); }
+#endif
 
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(HBLOCK) k_agg_hash_extract(const KeySpec K, const AggSpec A, const HashTable T, const AggOut out,
                                                              uint32_t* __restrict__ flags) {
   const int cell0 = 1 + T.key_words;
@@ -249,10 +260,11 @@ __global__ void __launch_bounds__(HBLOCK) k_agg_hash_extract(const KeySpec K, co
     }
   }
 }
+#endif
 
 // ------------------------------------------------------------------ join build
 template <int MAXC>
-__global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+__device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
                                                        uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
                                                        const int null_eq) {
   const i64 nwords = (n + 63) >> 6;
@@ -260,7 +272,7 @@ __global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const
     const i64 pos = (w << 6) + hlane();
     bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
     if (!active) continue;
     u64 kw[MAX_KW]; u64 h;
 #pragma unroll
@@ -286,13 +298,25 @@ __global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const
     }
   }
 }
+#ifndef GPUQ_JIT
+template <int MAXC>
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                       uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
+                                                       const int null_eq) { k_join_build_body<MAXC>(P, n, K, T, next, present, payload_via, null_eq); }
+#endif
+#elif GPUQ_JIT_KERNEL == 5
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                       uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
+                                                       const int null_eq) { k_join_build_body<0>(P, n, K, T, next, present, payload_via, null_eq); }
+#endif
 
 // ------------------------------------------------------------------ join probe
 // Emits (build_row, probe_row) pairs with wave-ballot compaction: one global atomic per wave per
 // chain step.  Pair order is not input order (DataFusion's is batch-local and unspecified across
 // partitions); the SET of pairs is deterministic.
 template <int MAXC>
-__global__ void __launch_bounds__(HBLOCK) k_join_probe(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+__device__ __forceinline__ void k_join_probe_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
                                                        const uint32_t* __restrict__ next, const int join_type, const int payload_via,
                                                        const int null_eq, uint32_t* __restrict__ out_build, uint32_t* __restrict__ out_probe,
                                                        const u64 out_cap, u64* __restrict__ out_count, uint32_t* __restrict__ visited) {
@@ -304,7 +328,7 @@ __global__ void __launch_bounds__(HBLOCK) k_join_probe(const DevProgram P, const
     const i64 pos = (w << 6) + hlane();
     bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
     uint32_t cur = NIL;
     uint32_t prow = (uint32_t)pos;
     if (active) {
@@ -357,6 +381,20 @@ __global__ void __launch_bounds__(HBLOCK) k_join_probe(const DevProgram P, const
     }
   }
 }
+#ifndef GPUQ_JIT
+template <int MAXC>
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(HBLOCK) k_join_probe(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                       const uint32_t* __restrict__ next, const int join_type, const int payload_via,
+                                                       const int null_eq, uint32_t* __restrict__ out_build, uint32_t* __restrict__ out_probe,
+                                                       const u64 out_cap, u64* __restrict__ out_count, uint32_t* __restrict__ visited) { k_join_probe_body<MAXC>(P, n, K, T, next, join_type, payload_via, null_eq, out_build, out_probe, out_cap, out_count, visited); }
+#endif
+#elif GPUQ_JIT_KERNEL == 6
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                       const uint32_t* __restrict__ next, const int join_type, const int payload_via,
+                                                       const int null_eq, uint32_t* __restrict__ out_build, uint32_t* __restrict__ out_probe,
+                                                       const u64 out_cap, u64* __restrict__ out_count, uint32_t* __restrict__ visited) { k_join_probe_body<0>(P, n, K, T, next, join_type, payload_via, null_eq, out_build, out_probe, out_cap, out_count, visited); }
+#endif
 
 // ------------------------------------------------------------------ join probe, unique build keys
 // No output atomics: pass 1 writes one match word per probe position (build row or NIL) plus the
@@ -364,7 +402,7 @@ __global__ void __launch_bounds__(HBLOCK) k_join_probe(const DevProgram P, const
 // (build_row, probe_row) pairs.  A single global counter would serialise the whole probe
 // (measured: 51 ms for 2^28 probes whatever the table size -- one device-scope atomic per wave step).
 template <int MAXC>
-__global__ void __launch_bounds__(HBLOCK) k_join_probe_unique(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+__device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
                                                               const int join_type, const int null_eq, uint32_t* __restrict__ match,
                                                               u64* __restrict__ bitmap, uint32_t* __restrict__ block_counts, const i64 wpb,
                                                               uint32_t* __restrict__ visited) {
@@ -379,7 +417,7 @@ __global__ void __launch_bounds__(HBLOCK) k_join_probe_unique(const DevProgram P
     const i64 pos = (w << 6) + hlane();
     bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
     uint32_t hit = NIL;
     if (active) {
       u64 kw[MAX_KW]; u64 h;
@@ -402,7 +440,22 @@ __global__ void __launch_bounds__(HBLOCK) k_join_probe_unique(const DevProgram P
   __syncthreads();
   if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < HWAVES; ++k) t += wave_cnt[k]; block_counts[blockIdx.x] = t; }
 }
+#ifndef GPUQ_JIT
+template <int MAXC>
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(HBLOCK) k_join_probe_unique(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                              const int join_type, const int null_eq, uint32_t* __restrict__ match,
+                                                              u64* __restrict__ bitmap, uint32_t* __restrict__ block_counts, const i64 wpb,
+                                                              uint32_t* __restrict__ visited) { k_join_probe_unique_body<MAXC>(P, n, K, T, join_type, null_eq, match, bitmap, block_counts, wpb, visited); }
+#endif
+#elif GPUQ_JIT_KERNEL == 7
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                              const int join_type, const int null_eq, uint32_t* __restrict__ match,
+                                                              u64* __restrict__ bitmap, uint32_t* __restrict__ block_counts, const i64 wpb,
+                                                              uint32_t* __restrict__ visited) { k_join_probe_unique_body<0>(P, n, K, T, join_type, null_eq, match, bitmap, block_counts, wpb, visited); }
+#endif
 
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(HBLOCK) k_compact_pairs(const u64* __restrict__ bitmap, const uint32_t* __restrict__ block_offsets, const i64 wpb,
                                                           const i64 n, const uint32_t* __restrict__ match, const uint32_t* __restrict__ probe_via,
                                                           uint32_t* __restrict__ out_build, uint32_t* __restrict__ out_probe, const u64 out_cap,
@@ -436,7 +489,9 @@ __global__ void __launch_bounds__(HBLOCK) k_compact_pairs(const u64* __restrict_
     out += (u64)__popcll(m);
   }
 }
+#endif
 
+#ifndef GPUQ_JIT
 // ------------------------------------------------------------------ launchers
 static int hgrid(i64 n, int blocks_per_cu) {
   const i64 nwords = (n + 63) >> 6;
@@ -456,9 +511,13 @@ void launch_ht_init(hipStream_t s, const HashTable& T, const AggSpec* A) {
 }
 void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T) {
   if (n <= 0) return;
+  if (jit_override().fn && jit_override().kernel_id == 4) {
+    (void)jit_launch(jit_override().fn, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, A, T);
+  } else {
 #define CALL(M) hipLaunchKernelGGL(k_agg_hash<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, A, T)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
 }
 void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags) {
   u64 need = (T.n_slots + HBLOCK - 1) / HBLOCK;
@@ -469,12 +528,17 @@ void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, 
 void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
                        int payload_via, int null_equals_null) {
   if (n <= 0) return;
+  if (jit_override().fn && jit_override().kernel_id == 5) {
+    (void)jit_launch(jit_override().fn, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, present, payload_via, null_equals_null);
+  } else {
 #define CALL(M) hipLaunchKernelGGL(k_join_build<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, present, payload_via, null_equals_null)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
 }
 
 // build-side row selection for Left/Full/LeftSemi/LeftAnti: present & (visited | ~visited)
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(HBLOCK) k_bitmap_select(const u64* __restrict__ present, const u64* __restrict__ visited, const int matched,
                                                           const i64 nwords, const i64 n, u64* __restrict__ bitmap,
                                                           uint32_t* __restrict__ block_counts, const i64 wpb) {
@@ -492,6 +556,7 @@ __global__ void __launch_bounds__(HBLOCK) k_bitmap_select(const u64* __restrict_
   __syncthreads();
   if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < HWAVES; ++k) t += wc[k]; block_counts[blockIdx.x] = t; }
 }
+#endif
 void launch_bitmap_select(hipStream_t s, const u64* present, const u64* visited, int matched, i64 nwords, i64 n, u64* bitmap,
                           uint32_t* block_counts, int nblocks, i64 wpb) {
   hipLaunchKernelGGL(k_bitmap_select, dim3(nblocks), dim3(HBLOCK), 0, s, present, visited, matched, nwords, n, bitmap, block_counts, wpb);
@@ -500,21 +565,30 @@ void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec&
                        int join_type, int payload_via, int null_equals_null, uint32_t* out_build, uint32_t* out_probe,
                        u64 out_cap, u64* out_count, uint32_t* visited) {
   if (n <= 0) return;
-#define CALL(M) hipLaunchKernelGGL(k_join_probe<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, join_type, payload_via, null_equals_null, \
-                                   out_build, out_probe, out_cap, out_count, visited)
+  if (jit_override().fn && jit_override().kernel_id == 6) {
+    (void)jit_launch(jit_override().fn, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, join_type, payload_via, null_equals_null, out_build, out_probe, out_cap, out_count, visited);
+  } else {
+#define CALL(M) hipLaunchKernelGGL(k_join_probe<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, join_type, payload_via, null_equals_null,                                     out_build, out_probe, out_cap, out_count, visited)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
 }
 
 void launch_join_probe_unique(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int join_type, int null_equals_null,
                               uint32_t* match, u64* bitmap, uint32_t* block_counts, int nblocks, i64 wpb, uint32_t* visited) {
+  if (jit_override().fn && jit_override().kernel_id == 7) {
+    (void)jit_launch(jit_override().fn, dim3(nblocks), dim3(HBLOCK), 0, s, P, n, K, T, join_type, null_equals_null, match, bitmap, block_counts, wpb, visited);
+  } else {
 #define CALL(M) hipLaunchKernelGGL(k_join_probe_unique<M>, dim3(nblocks), dim3(HBLOCK), 0, s, P, n, K, T, join_type, null_equals_null, match, bitmap, block_counts, wpb, visited)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
 }
 void launch_compact_pairs(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 wpb, i64 n, const uint32_t* match,
                           const uint32_t* probe_via, uint32_t* out_build, uint32_t* out_probe, u64 out_cap, uint32_t* flags) {
   hipLaunchKernelGGL(k_compact_pairs, dim3(nblocks), dim3(HBLOCK), 0, s, bitmap, block_offsets, wpb, n, match, probe_via, out_build, out_probe, out_cap, flags);
 }
+
+#endif  // GPUQ_JIT
 
 }  // namespace gpuq

@@ -22,7 +22,7 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 // Pass 1: evaluate the predicate once per row, keep it as a bitmap (N/8 bytes) plus one
 // count per block.  Block b owns the contiguous word range [b*wpb, (b+1)*wpb).
 template <int MAXC>
-__global__ void __launch_bounds__(BLOCK) k_filter_bitmap(const DevProgram P, const i64 n, u64* __restrict__ bitmap,
+__device__ __forceinline__ void k_filter_bitmap_body(const DevProgram P, const i64 n, u64* __restrict__ bitmap,
                                                          uint32_t* __restrict__ block_counts, const i64 wpb) {
   __shared__ uint32_t wave_cnt[WAVES];
   const i64 nwords = (n + 63) >> 6;
@@ -34,9 +34,7 @@ __global__ void __launch_bounds__(BLOCK) k_filter_bitmap(const DevProgram P, con
     bool pass = false;
     if (pos < n) {
       GPUQ_REGS_DECL;
-      load_columns<MAXC>(P, pos, GPUQ_REGS);
-      run_program(P, GPUQ_REGS);
-      pass = row_passes(P, GPUQ_REGS);
+      pass = GPUQ_EVAL(MAXC, P, pos);
     }
     const u64 m = __ballot(pass);
     if (lane_id() == 0) bitmap[w] = m;
@@ -50,8 +48,19 @@ __global__ void __launch_bounds__(BLOCK) k_filter_bitmap(const DevProgram P, con
     block_counts[blockIdx.x] = t;
   }
 }
+#ifndef GPUQ_JIT
+template <int MAXC>
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(BLOCK) k_filter_bitmap(const DevProgram P, const i64 n, u64* __restrict__ bitmap,
+                                                         uint32_t* __restrict__ block_counts, const i64 wpb) { k_filter_bitmap_body<MAXC>(P, n, bitmap, block_counts, wpb); }
+#endif
+#elif GPUQ_JIT_KERNEL == 1
+extern "C" __global__ void __launch_bounds__(BLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, u64* __restrict__ bitmap,
+                                                         uint32_t* __restrict__ block_counts, const i64 wpb) { k_filter_bitmap_body<0>(P, n, bitmap, block_counts, wpb); }
+#endif
 
 // Exclusive scan of <= 1024*ITEMS block counts in place; single block of 1024 threads.
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(1024) k_scan_counts(uint32_t* __restrict__ counts, const int n, u64* __restrict__ total_out) {
   __shared__ u64 wsum[16];
   const int t = threadIdx.x;
@@ -76,9 +85,11 @@ __global__ void __launch_bounds__(1024) k_scan_counts(uint32_t* __restrict__ cou
   u64 excl = wsum[t >> 6] + x - local;
   for (int k = 0; k < items; ++k) if (i0 + k < n) { uint32_t c = counts[i0 + k]; counts[i0 + k] = (uint32_t)excl; excl += c; }
 }
+#endif
 
 // Pass 2: ordered compaction.  Each wave owns a contiguous slice of the block's words, so row
 // order is preserved (FilterExec keeps input order); one coalesced store per bitmap word.
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(BLOCK) k_compact(const u64* __restrict__ bitmap, const uint32_t* __restrict__ block_offsets,
                                                    const i64 wpb, const i64 n, const uint32_t* __restrict__ sel_in,
                                                    uint32_t* __restrict__ sel_out) {
@@ -108,16 +119,17 @@ __global__ void __launch_bounds__(BLOCK) k_compact(const u64* __restrict__ bitma
     out += (uint32_t)__popcll(m);
   }
 }
+#endif
 
 // ------------------------------------------------------------------ project
 template <int MAXC>
-__global__ void __launch_bounds__(BLOCK) k_project(const DevProgram P, const i64 n, const OutSpec O) {
+__device__ __forceinline__ void k_project_body(const DevProgram P, const i64 n, const OutSpec O) {
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * WAVES + wave_id(); w < nwords; w += (i64)gridDim.x * WAVES) {
     const i64 pos = (w << 6) + lane_id();
     const bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); }
+    if (active) (void)GPUQ_EVAL(MAXC, P, pos);
 #pragma unroll
     for (int k = 0; k < MAX_OUTS; ++k) {
       if (k < O.n_out) {
@@ -141,6 +153,14 @@ __global__ void __launch_bounds__(BLOCK) k_project(const DevProgram P, const i64
     }
   }
 }
+#ifndef GPUQ_JIT
+template <int MAXC>
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(BLOCK) k_project(const DevProgram P, const i64 n, const OutSpec O) { k_project_body<MAXC>(P, n, O); }
+#endif
+#elif GPUQ_JIT_KERNEL == 2
+extern "C" __global__ void __launch_bounds__(BLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const OutSpec O) { k_project_body<0>(P, n, O); }
+#endif
 
 // ------------------------------------------------------------------ tiny-group aggregate
 // LDS layout (dynamic, 16-B aligned):
@@ -194,7 +214,7 @@ static size_t tiny_partial_bytes(int gmax, int n_keys, int n_accs) {
 }
 
 template <int MAXC>
-__global__ void __launch_bounds__(BLOCK) k_agg_tiny(const DevProgram P, const i64 n, const AggSpec A, const int gmax,
+__device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n, const AggSpec A, const int gmax,
                                                     char* __restrict__ workspace, const size_t partial_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n_keys = A.n_keys, n_accs = A.n_accs;
@@ -217,7 +237,7 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny(const DevProgram P, const i6
     const i64 pos = (w << 6) + lane_id();
     bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) { load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS); active = row_passes(P, GPUQ_REGS); }
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
     // group key (explicit scalars: a small array here ends up in scratch once the loader's slots are live)
     u64 k0lo = 0, k0hi = 0, k1lo = 0, k1hi = 0, k2lo = 0, k2hi = 0, k3lo = 0, k3hi = 0; uint32_t knull = 0;
 #define GPUQ_KLO(k) ((k) == 0 ? k0lo : (k) == 1 ? k1lo : (k) == 2 ? k2lo : k3lo)
@@ -383,9 +403,20 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny(const DevProgram P, const i6
     __syncthreads();
   }
 }
+#ifndef GPUQ_JIT
+template <int MAXC>
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(BLOCK) k_agg_tiny(const DevProgram P, const i64 n, const AggSpec A, const int gmax,
+                                                    char* __restrict__ workspace, const size_t partial_stride) { k_agg_tiny_body<MAXC>(P, n, A, gmax, workspace, partial_stride); }
+#endif
+#elif GPUQ_JIT_KERNEL == 3
+extern "C" __global__ void __launch_bounds__(BLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const AggSpec A, const int gmax,
+                                                    char* __restrict__ workspace, const size_t partial_stride) { k_agg_tiny_body<0>(P, n, A, gmax, workspace, partial_stride); }
+#endif
 
 // Merge the per-block partial records into the final groups.  One block; the work is
 // nblocks*gmax records, a few thousand at most.
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const int gmax, const char* __restrict__ workspace,
                                                           const size_t partial_stride, const int nblocks, const AggOut out,
                                                           uint32_t* __restrict__ flags) {
@@ -520,8 +551,10 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const
   for (int i = tid; i < nf; i += BLOCK) out.key_nulls[i] = fnulls[i];
   if (tid == 0) *out.n_groups = (uint32_t)nf;
 }
+#endif
 
 // ------------------------------------------------------------------ aggregate result AoS -> SoA
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(BLOCK) k_agg_emit(const AggOut raw, const int n_keys, const int n_accs, const uint32_t ng, const AggSoA soa) {
   const int kstride = n_keys > 0 ? n_keys : 1;
   const uint32_t nwords = (ng + 63) >> 6;
@@ -538,11 +571,15 @@ __global__ void __launch_bounds__(BLOCK) k_agg_emit(const AggOut raw, const int 
       if (active) soa.acc_col[a][g] = make_ulonglong2(raw.cells[((size_t)g * n_accs + a) * 2], raw.cells[((size_t)g * n_accs + a) * 2 + 1]);
   }
 }
+#endif
 
 // ------------------------------------------------------------------ packed Utf8 -> Arrow Utf8
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(BLOCK) k_unpack_lengths(const ulonglong2* __restrict__ packed, const i64 n, int32_t* __restrict__ lens) {
   for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) lens[i] = (int32_t)(packed[i].x & 0xFF);
 }
+#endif
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(BLOCK) k_unpack_bytes(const ulonglong2* __restrict__ packed, const i64 n, const int32_t* __restrict__ offsets,
                                                         uint8_t* __restrict__ out) {
   for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
@@ -552,10 +589,12 @@ __global__ void __launch_bounds__(BLOCK) k_unpack_bytes(const ulonglong2* __rest
     for (int k = 0; k < len && k < 15; ++k) p[k] = (uint8_t)(k < 8 ? (v.y >> (56 - 8 * k)) : (v.x >> (56 - 8 * (k - 8))));
   }
 }
+#endif
 
 // Exclusive scan of int32 lengths into offsets (n+1 entries, in place): three-kernel
 // reduce / scan-of-tiles / downsweep over tiles of 2048 elements.
 constexpr int SCAN_TILE = 2048;
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(BLOCK) k_scan_tile_sums(const int32_t* __restrict__ d, const i64 n, u64* __restrict__ tile_sums) {
   __shared__ u64 ws[WAVES];
   const i64 base = (i64)blockIdx.x * SCAN_TILE;
@@ -566,6 +605,8 @@ __global__ void __launch_bounds__(BLOCK) k_scan_tile_sums(const int32_t* __restr
   __syncthreads();
   if (threadIdx.x == 0) { u64 t = 0; for (int k = 0; k < WAVES; ++k) t += ws[k]; tile_sums[blockIdx.x] = t; }
 }
+#endif
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(1024) k_scan_tiles_serial(u64* __restrict__ tile_sums, const i64 ntiles) {
   // one block; thread-strided sequential chunks then a serial fix-up over <=1024 partials
   __shared__ u64 part[1024];
@@ -579,6 +620,8 @@ __global__ void __launch_bounds__(1024) k_scan_tiles_serial(u64* __restrict__ ti
   u64 run = part[t];
   for (i64 i = a; i < b; ++i) { const u64 v = tile_sums[i]; tile_sums[i] = run; run += v; }
 }
+#endif
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(BLOCK) k_scan_downsweep(int32_t* __restrict__ d, const i64 n, const u64* __restrict__ tile_offsets) {
   __shared__ u64 ws[WAVES];
   const i64 base = (i64)blockIdx.x * SCAN_TILE;
@@ -595,9 +638,12 @@ __global__ void __launch_bounds__(BLOCK) k_scan_downsweep(int32_t* __restrict__ 
 #pragma unroll
   for (int k = 0; k < PER; ++k) { const i64 i = base + (i64)threadIdx.x * PER + k; if (i <= n) { if (i < n) d[i] = (int32_t)run; else d[i] = (int32_t)run; } run += (u64)(uint32_t)v[k]; }
 }
+#endif
 
+#ifndef GPUQ_JIT
 // ------------------------------------------------------------------ launchers
 static int g_num_cus = 256;
+JitOverride& jit_override() { static thread_local JitOverride o; return o; }
 void set_num_cus(int n) { if (n > 0) g_num_cus = n; }
 int num_cus() { return g_num_cus; }
 
@@ -610,9 +656,13 @@ static int grid_for(i64 n, int blocks_per_cu) {
 }
 
 void launch_filter_bitmap(hipStream_t s, const DevProgram& P, i64 n, u64* bitmap, uint32_t* block_counts, int nblocks, i64 wpb) {
+  if (jit_override().fn && jit_override().kernel_id == 1) {
+    (void)jit_launch(jit_override().fn, dim3(nblocks), dim3(BLOCK), 0, s, P, n, bitmap, block_counts, wpb);
+  } else {
 #define CALL(M) hipLaunchKernelGGL(k_filter_bitmap<M>, dim3(nblocks), dim3(BLOCK), 0, s, P, n, bitmap, block_counts, wpb)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
 }
 void launch_scan_block_counts(hipStream_t s, uint32_t* block_counts, int nblocks, u64* total_out) {
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total_out);
@@ -623,9 +673,13 @@ void launch_compact(hipStream_t s, const u64* bitmap, const uint32_t* block_offs
 }
 void launch_project(hipStream_t s, const DevProgram& P, i64 n, const OutSpec& O) {
   if (n <= 0) return;
+  if (jit_override().fn && jit_override().kernel_id == 2) {
+    (void)jit_launch(jit_override().fn, dim3(grid_for(n, 8)), dim3(BLOCK), 0, s, P, n, O);
+  } else {
 #define CALL(M) hipLaunchKernelGGL(k_project<M>, dim3(grid_for(n, 8)), dim3(BLOCK), 0, s, P, n, O)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
 }
 
 // LDS budget: keep one block within 64 KiB so at least two blocks (8 waves) share a CU.
@@ -652,7 +706,11 @@ void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A
   int nb = grid_for(n, 64);
   if (nb > nb_cap) nb = nb_cap;
   const size_t lds = tiny_lds_bytes(gmax, A.n_keys, A.n_accs);
-  // > 64 KiB of dynamic LDS needs an explicit opt-in (per template instantiation)
+  // > 64 KiB of dynamic LDS needs an explicit opt-in (per template instantiation); the JIT'd function is
+  // only used while the request stays within the default 64 KiB
+  if (jit_override().fn && jit_override().kernel_id == 3 && lds <= 60 * 1024) {
+    (void)jit_launch(jit_override().fn, dim3(nb), dim3(BLOCK), lds, s, P, n, A, gmax, (char*)workspace, stride);
+  } else {
 #define CALL(M)                                                                                                                          \
   do {                                                                                                                                   \
     static size_t attr_main = 0;                                                                                                         \
@@ -664,6 +722,7 @@ void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A
   } while (0)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
   static size_t attr_merge = 0;
   const int kstride = A.n_keys > 0 ? A.n_keys : 1;
   const size_t mlds = (size_t)out.cap * kstride * 16 + (size_t)out.cap * 4 + (((size_t)nb * gmax * 2 + 15) & ~(size_t)15) + 32 + (size_t)out.cap * A.n_accs * 16;
@@ -696,5 +755,7 @@ void launch_exclusive_scan_i32(hipStream_t s, int32_t* data, i64 n, void* worksp
   hipLaunchKernelGGL(k_scan_tiles_serial, dim3(1), dim3(1024), 0, s, tiles, ntiles);
   hipLaunchKernelGGL(k_scan_downsweep, dim3((unsigned)ntiles), dim3(BLOCK), 0, s, data, n, (const u64*)tiles);
 }
+
+#endif  // GPUQ_JIT
 
 }  // namespace gpuq

@@ -60,7 +60,7 @@ __device__ __forceinline__ void mm_reduce_store(MinMax& m, int k, u64 (*red)[MAX
   if (slane() == 0) { red[swave()][k][0] = m.mn_lo; red[swave()][k][1] = m.mn_hi; red[swave()][k][2] = m.mx_lo; red[swave()][k][3] = m.mx_hi; red[swave()][k][4] = m.fl; }
 }
 template <int MAXC>
-__global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out) {
+__device__ __forceinline__ void k_sort_minmax_body(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out) {
   __shared__ u64 red[SWAVES][MAX_SORT_KEYS][5];
   MinMax m0, m1, m2, m3;   // scalars on purpose: an indexed array here competes with the register file for promotion
   mm_init(m0); mm_init(m1); mm_init(m2); mm_init(m3);
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, cons
     const i64 pos = (w << 6) + slane();
     if (pos >= n) continue;
     GPUQ_REGS_DECL;
-    load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS);
+    (void)GPUQ_EVAL(MAXC, P, pos);
     mm_row(m0, S, 0, GPUQ_REGS); mm_row(m1, S, 1, GPUQ_REGS); mm_row(m2, S, 2, GPUQ_REGS); mm_row(m3, S, 3, GPUQ_REGS);
   }
   // a lane that saw no value keeps (max,min) sentinels, which never win a reduction
@@ -88,17 +88,25 @@ __global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, cons
     o[0] = (u64)a; o[1] = (u64)((u128)a >> 64); o[2] = (u64)b; o[3] = (u64)((u128)b >> 64); o[4] = f;
   }
 }
+#ifndef GPUQ_JIT
+template <int MAXC>
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out) { k_sort_minmax_body<MAXC>(P, n, S, out); }
+#endif
+#elif GPUQ_JIT_KERNEL == 8
+extern "C" __global__ void __launch_bounds__(SBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out) { k_sort_minmax_body<0>(P, n, S, out); }
+#endif
 
 // ------------------------------------------------------------------ composite key
 template <int MAXC>
-__global__ void __launch_bounds__(SBLOCK) k_sort_pack(const DevProgram P, const i64 n, const SortSpec S, const SortPack K,
+__device__ __forceinline__ void k_sort_pack_body(const DevProgram P, const i64 n, const SortSpec S, const SortPack K,
                                                       u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids) {
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * SWAVES + swave(); w < nwords; w += (i64)gridDim.x * SWAVES) {
     const i64 pos = (w << 6) + slane();
     if (pos >= n) continue;
     GPUQ_REGS_DECL;
-    load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS);
+    (void)GPUQ_EVAL(MAXC, P, pos);
     u128 comp = 0;
 #pragma unroll
     for (int k = 0; k < MAX_SORT_KEYS; ++k) {
@@ -124,17 +132,27 @@ __global__ void __launch_bounds__(SBLOCK) k_sort_pack(const DevProgram P, const 
     ids[pos] = (uint32_t)pos;
   }
 }
+#ifndef GPUQ_JIT
+template <int MAXC>
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(SBLOCK) k_sort_pack(const DevProgram P, const i64 n, const SortSpec S, const SortPack K,
+                                                      u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids) { k_sort_pack_body<MAXC>(P, n, S, K, key_lo, key_hi, ids); }
+#endif
+#elif GPUQ_JIT_KERNEL == 9
+extern "C" __global__ void __launch_bounds__(SBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const SortSpec S, const SortPack K,
+                                                      u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids) { k_sort_pack_body<0>(P, n, S, K, key_lo, key_hi, ids); }
+#endif
 
 // ------------------------------------------------------------------ partition ids
 template <int MAXC>
-__global__ void __launch_bounds__(SBLOCK) k_part_pid(const DevProgram P, const i64 n, const KeySpec K, const uint32_t nparts,
+__device__ __forceinline__ void k_part_pid_body(const DevProgram P, const i64 n, const KeySpec K, const uint32_t nparts,
                                                      u64* __restrict__ pid_out, uint32_t* __restrict__ ids) {
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * SWAVES + swave(); w < nwords; w += (i64)gridDim.x * SWAVES) {
     const i64 pos = (w << 6) + slane();
     if (pos >= n) continue;
     GPUQ_REGS_DECL;
-    load_columns<MAXC>(P, pos, GPUQ_REGS); run_program(P, GPUQ_REGS);
+    (void)GPUQ_EVAL(MAXC, P, pos);
     u64 h = 0x243F6A8885A308D3ull;
 #pragma unroll
     for (int k = 0; k < MAX_KEYS; ++k) {
@@ -148,8 +166,19 @@ __global__ void __launch_bounds__(SBLOCK) k_part_pid(const DevProgram P, const i
     ids[pos] = (uint32_t)pos;
   }
 }
+#ifndef GPUQ_JIT
+template <int MAXC>
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(SBLOCK) k_part_pid(const DevProgram P, const i64 n, const KeySpec K, const uint32_t nparts,
+                                                     u64* __restrict__ pid_out, uint32_t* __restrict__ ids) { k_part_pid_body<MAXC>(P, n, K, nparts, pid_out, ids); }
+#endif
+#elif GPUQ_JIT_KERNEL == 10
+extern "C" __global__ void __launch_bounds__(SBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const uint32_t nparts,
+                                                     u64* __restrict__ pid_out, uint32_t* __restrict__ ids) { k_part_pid_body<0>(P, n, K, nparts, pid_out, ids); }
+#endif
 
 // partition sizes: counts via wave-aggregated global atomics, then a one-block exclusive scan
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(SBLOCK) k_pid_count(const u64* __restrict__ pid, const i64 n, uint32_t* __restrict__ counts) {
   for (i64 i0 = ((i64)blockIdx.x * SBLOCK + threadIdx.x) & ~(i64)63; i0 < n; i0 += (i64)gridDim.x * SBLOCK) {
     const i64 i = i0 + slane();
@@ -161,6 +190,8 @@ __global__ void __launch_bounds__(SBLOCK) k_pid_count(const u64* __restrict__ pi
     if (act && (same & ((1ull << slane()) - 1)) == 0) atomicAdd(&counts[d], (uint32_t)__popcll(same));
   }
 }
+#endif
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(1024) k_part_scan(const uint32_t* __restrict__ counts, const uint32_t np, u64* __restrict__ offsets) {
   __shared__ u64 part[1024];
   const int t = threadIdx.x;
@@ -173,15 +204,19 @@ __global__ void __launch_bounds__(1024) k_part_scan(const uint32_t* __restrict__
   u64 run = part[t];
   for (uint32_t i = a; i < b; ++i) { offsets[i] = run; run += counts[i]; }
 }
+#endif
 
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(SBLOCK) k_gather_u64(const u64* __restrict__ src, const uint32_t* __restrict__ idx, const i64 n, u64* __restrict__ dst) {
   for (i64 i = (i64)blockIdx.x * SBLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * SBLOCK) dst[i] = src[idx[i]];
 }
+#endif
 
 // ------------------------------------------------------------------ stable radix pass
 // Tile = the contiguous range of a block: each wave owns a contiguous quarter, processed 64 keys
 // at a time, so (block, wave, step, lane) order == input order and the pass is stable.
 // hist layout: [digit][block] (digit-major) so one exclusive scan gives global scatter bases.
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(SBLOCK) k_radix_hist(const u64* __restrict__ keys, const i64 n, const int shift, const uint32_t mask,
                                                        const i64 tile, int32_t* __restrict__ hist, const int nblocks) {
   __shared__ uint32_t cnt[RADIX];
@@ -193,7 +228,9 @@ __global__ void __launch_bounds__(SBLOCK) k_radix_hist(const u64* __restrict__ k
   __syncthreads();
   for (int d = threadIdx.x; d < RADIX; d += SBLOCK) hist[(size_t)d * nblocks + blockIdx.x] = (int32_t)cnt[d];
 }
+#endif
 
+#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(SBLOCK) k_radix_scatter(const u64* __restrict__ keys, const uint32_t* __restrict__ vals, const i64 n,
                                                           const int shift, const uint32_t mask, const i64 tile,
                                                           const int32_t* __restrict__ offsets, const int nblocks,
@@ -239,7 +276,9 @@ __global__ void __launch_bounds__(SBLOCK) k_radix_scatter(const u64* __restrict_
     __builtin_amdgcn_wave_barrier();
   }
 }
+#endif
 
+#ifndef GPUQ_JIT
 // ------------------------------------------------------------------ launchers
 static int sgrid(i64 n, int blocks_per_cu) {
   const i64 nwords = (n + 63) >> 6;
@@ -249,21 +288,33 @@ static int sgrid(i64 n, int blocks_per_cu) {
 }
 int sort_minmax_blocks(i64 n) { return sgrid(n, 4); }
 void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks) {
+  if (jit_override().fn && jit_override().kernel_id == 8) {
+    (void)jit_launch(jit_override().fn, dim3(nblocks), dim3(SBLOCK), 0, s, P, n, S, out);
+  } else {
 #define CALL(M) hipLaunchKernelGGL(k_sort_minmax<M>, dim3(nblocks), dim3(SBLOCK), 0, s, P, n, S, out)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
 }
 void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids) {
   if (n <= 0) return;
+  if (jit_override().fn && jit_override().kernel_id == 9) {
+    (void)jit_launch(jit_override().fn, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, S, K, key_lo, key_hi, ids);
+  } else {
 #define CALL(M) hipLaunchKernelGGL(k_sort_pack<M>, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, S, K, key_lo, key_hi, ids)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
 }
 void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, uint32_t nparts, u64* pid_out, uint32_t* ids) {
   if (n <= 0) return;
+  if (jit_override().fn && jit_override().kernel_id == 10) {
+    (void)jit_launch(jit_override().fn, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, K, nparts, pid_out, ids);
+  } else {
 #define CALL(M) hipLaunchKernelGGL(k_part_pid<M>, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, K, nparts, pid_out, ids)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
 }
 void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out) {
   (void)hipMemsetAsync(counts_ws, 0, (size_t)(nparts + 1) * 4, s);
@@ -292,5 +343,7 @@ void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64
   hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(SBLOCK), 0, s, keys, vals, n, shift, mask, tile, (const int32_t*)hist, nblocks,
                      keys_out, vals_out);
 }
+
+#endif  // GPUQ_JIT
 
 }  // namespace gpuq

@@ -86,6 +86,15 @@ void gpuq_ctx_free(gpuq_ctx* ctx);
 const char* gpuq_last_error(gpuq_ctx* ctx);
 int gpuq_ctx_device_info(gpuq_ctx* ctx, char* buf, size_t cap); /* JSON: name, arch, cus, hbm_bytes */
 
+/* ---- runtime specialisation (JIT) ---------------------------------------------------------- */
+/* The row front-end (column loads + expressions) of every operator exists twice: as interpreter kernels
+   compiled ahead of time (always available, best for small inputs) and as a typed straight-line function
+   generated from the same expression DAG and compiled with hiprtc on first use (best for large inputs).
+   mode: "off" | "auto" (inputs >= min_rows, falls back to the interpreter kernels when hiprtc is missing)
+   | "force" (errors are reported).  Default "auto", 2^21 rows; env GPUQ_JIT overrides at ctx creation. */
+int gpuq_ctx_set_jit(gpuq_ctx* ctx, const char* mode, int64_t min_rows /* <0 = keep */);
+int gpuq_ctx_jit_stats(gpuq_ctx* ctx, int* available, int* launches, char* last_error, size_t cap);
+
 /* ---- device memory + Arrow C Data Interface ingest/egress ---------------------------------- */
 /* A host that owns Arrow RecordBatches (arrow-rs `arrow::ffi`, pyarrow `_export_to_c`) hands them over
    here; buffers are copied to HBM through double-buffered pinned staging on `stream`.
@@ -135,6 +144,8 @@ int gpuq_op_create(gpuq_ctx* ctx, const char* json, gpuq_op** out);
 /* Host-only: compiles the descriptor without a device and writes a JSON description (program
    listing, output schema) to buf.  Used for plan validation and by the CPU test-suite. */
 int gpuq_compile_check(const char* json, char* buf, size_t cap);
+/* Host-only: the source the JIT path would hand to hiprtc for this descriptor and sink kernel id. */
+int gpuq_compile_jit_source(const char* json, int kernel_id, char* buf, size_t cap);
 void gpuq_op_free(gpuq_op* op);
 int gpuq_op_num_outputs(gpuq_op* op);
 int gpuq_op_output_field(gpuq_op* op, int i, gpuq_field_info* out);
@@ -198,6 +209,9 @@ int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t
 /* Waits for `stream`, then reports device-side conditions raised by the op's kernels since the last
    check (string longer than 15 bytes in a packed comparison, output capacity overflow, ...). */
 int gpuq_op_check(gpuq_op* op, void* stream);
+/* Debug: the full source handed to hiprtc for sink kernel `kernel_id` (1 filter, 2 project, 3 aggregate-LDS,
+   4 aggregate-hash, 5 join build, 6 probe chained, 7 probe unique, 8 sort min/max, 9 sort pack, 10 partition). */
+int gpuq_op_jit_source(gpuq_op* op, int kernel_id, char* buf, size_t cap);
 
 /* Utf8 PACKED15 -> Arrow offsets+bytes.  offsets_out: n+1 int32; data_out capacity data_cap bytes.
    Synchronous; *data_len_out (host) = bytes written. */
