@@ -188,12 +188,12 @@ struct ProfScope {
 // policy asks for it.  force: failures are errors.  auto: fall back to the (always present) interpreter kernels.
 struct JitScope {
   bool active = false;
-  JitScope(gpuq_op* op, const CompiledProgram& cp, int kernel_id, i64 n) {
+  JitScope(gpuq_op* op, const CompiledProgram& cp, int kernel_id, i64 n, const std::string& spec = std::string()) {
     gpuq_ctx* c = op->ctx;
     const bool use = c->jit_mode == 2 || (c->jit_mode == 1 && n >= c->jit_min_rows);
     if (!use || cp.jit_src.empty()) return;
     try {
-      const JitFn* f = jit_get(cp.jit_src, kernel_id);
+      const JitFn* f = jit_get(cp.jit_src + spec, kernel_id);
       jit_override().fn = f->fn; jit_override().kernel_id = kernel_id; active = true; c->jit_launches++;
     } catch (const std::exception& e) {
       if (c->jit_mode == 2) throw Unsupported(e.what());
@@ -676,7 +676,13 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
           void* wsp = op->ws[4].ensure(wsb);
           alloc_raw(64);
           reset_flags(op, s);
-          { JitScope js(op, op->prog, 3, n); ProfScope ps(op, s); launch_agg_tiny(s, P, n, op->agg, gmax, wsp, raw); }
+          // the LDS aggregate is specialised on its whole shape (keys, accumulators, group capacity)
+          std::string spec = "#define GPUQ_JIT_SPEC 1\nconstexpr int JIT_NKEYS = " + std::to_string(nk) + ", JIT_NACCS = " + std::to_string(na) +
+                             ", JIT_GMAX = " + std::to_string(gmax) + ", JIT_NKC = " + std::to_string(nk > 0 ? nk : 1) + ";\n";
+          auto arr = [](const char* name, const int32_t* v, int n_) { std::string r = std::string("constexpr int ") + name + "[" + std::to_string(n_) + "] = {";
+                                                                     for (int i = 0; i < n_; ++i) r += std::to_string(v[i]) + (i + 1 < n_ ? "," : ""); return r + "};\n"; };
+          spec += arr("JIT_KEY_REG", op->agg.key_reg, MAX_KEYS) + arr("JIT_ACC_KIND", op->agg.acc_kind, MAX_ACCS) + arr("JIT_ACC_REG", op->agg.acc_reg, MAX_ACCS);
+          { JitScope js(op, op->prog, 3, n, spec); ProfScope ps(op, s); launch_agg_tiny(s, P, n, op->agg, gmax, wsp, raw); }
           HIPCHECK(hipGetLastError());
           const uint32_t f = read_flags(op, s);
           if (f & ~FLAG_GROUP_OVERFLOW) { reset_flags(op, s); raise_flags(f & ~FLAG_GROUP_OVERFLOW); }

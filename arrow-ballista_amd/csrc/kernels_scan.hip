@@ -17,6 +17,9 @@ constexpr int WAVES = BLOCK / 64;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ u64 uniform_u64(u64 v) {   // value known to be equal in all lanes -> SGPR pair
+  return (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
 
 // ------------------------------------------------------------------ filter
 // Pass 1: evaluate the predicate once per row, keep it as a bitmap (N/8 bytes) plus one
@@ -214,15 +217,32 @@ static size_t tiny_partial_bytes(int gmax, int n_keys, int n_accs) {
 }
 
 template <int MAXC>
-__device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n, const AggSpec A, const int gmax,
+__device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n, const AggSpec A, const int gmax_arg,
                                                     char* __restrict__ workspace, const size_t partial_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // Under the JIT the aggregate's shape is a compile-time constant (capi.cpp emits JIT_* into the source):
+  // loops unroll, the switch over accumulator kinds folds, every register index is static.
+#ifdef GPUQ_JIT_SPEC
+  constexpr int n_keys = JIT_NKEYS, n_accs = JIT_NACCS;
+  constexpr int gmax = JIT_GMAX;
+  (void)gmax_arg;
+#define SPEC_KEY_REG(k) JIT_KEY_REG[k]
+#define SPEC_ACC_KIND(a) JIT_ACC_KIND[a]
+#define SPEC_ACC_REG(a) JIT_ACC_REG[a]
+#define SPEC_UNROLL _Pragma("unroll")
+#else
   const int n_keys = A.n_keys, n_accs = A.n_accs;
+  const int gmax = gmax_arg;
+#define SPEC_KEY_REG(k) __builtin_amdgcn_readfirstlane(A.key_reg[k])
+#define SPEC_ACC_KIND(a) A.acc_kind[a]
+#define SPEC_ACC_REG(a) __builtin_amdgcn_readfirstlane(A.acc_reg[a])
+#define SPEC_UNROLL
+#endif
   const int kstride = n_keys > 0 ? n_keys : 1;
   const TinyLds L = tiny_carve(smem, gmax, n_keys, n_accs);
   const int cells = gmax * n_accs;
   const int tid = threadIdx.x;
-  for (int c = 0; c < cells; ++c) L.lane_acc[c * BLOCK + tid] = acc_identity(A.acc_kind[c % n_accs]);
+  for (int c = 0; c < cells; ++c) L.lane_acc[c * BLOCK + tid] = acc_identity(SPEC_ACC_KIND(c % n_accs));
   for (int c = tid; c < cells * 2; c += BLOCK) L.wide[c] = 0;
   // an aggregate without GROUP BY always has exactly one group, even over zero rows
   if (tid == 0) { *L.dict_n = (n_keys == 0) ? 1u : 0u; *L.lock = 0; L.dnulls[0] = 0; }
@@ -232,6 +252,13 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
   volatile u64* vkeys = L.dkeys;
   volatile uint32_t* vnulls = L.dnulls;
 
+#ifdef GPUQ_JIT_SPEC
+  u64 dc_lo[JIT_GMAX][JIT_NKC], dc_hi[JIT_GMAX][JIT_NKC]; uint32_t dc_nl[JIT_GMAX]; uint32_t cached_n = 0;
+#pragma unroll
+  for (int g = 0; g < JIT_GMAX; ++g) { dc_nl[g] = 0;
+#pragma unroll
+    for (int k = 0; k < JIT_NKC; ++k) { dc_lo[g][k] = 0; dc_hi[g][k] = 0; } }
+#endif
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * WAVES + wave_id(); w < nwords; w += (i64)gridDim.x * WAVES) {
     const i64 pos = (w << 6) + lane_id();
@@ -245,7 +272,7 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
 #pragma unroll
     for (int k = 0; k < MAX_KEYS; ++k) {
       if (k < n_keys && active) {
-        const int r = __builtin_amdgcn_readfirstlane(A.key_reg[k]);
+        const int r = SPEC_KEY_REG(k);
         const bool isn = (rnulls >> r) & 1;
         const u64 vlo = isn ? 0 : rlo[r], vhi = isn ? 0 : rhi[r];
         if (k == 0) { k0lo = vlo; k0hi = vhi; } else if (k == 1) { k1lo = vlo; k1hi = vhi; } else if (k == 2) { k2lo = vlo; k2hi = vhi; } else { k3lo = vlo; k3hi = vhi; }
@@ -258,6 +285,34 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
       // lock-free lookup over the dictionary entries published so far
       const uint32_t nd = *vn;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef GPUQ_JIT_SPEC
+      // dictionary entries live in (wave-uniform) registers and are refreshed only when the block's
+      // dictionary grew: the common row pays one LDS word (dict_n), not 2*n_keys*groups LDS reads
+      if (nd != cached_n) {
+#pragma unroll
+        for (int g = 0; g < JIT_GMAX; ++g) {
+          if ((uint32_t)g >= cached_n && (uint32_t)g < nd) {
+            dc_nl[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)vnulls[g]);
+#pragma unroll
+            for (int k = 0; k < JIT_NKC; ++k) {
+              if (k < n_keys) { dc_lo[g][k] = uniform_u64(vkeys[(g * kstride + k) * 2]); dc_hi[g][k] = uniform_u64(vkeys[(g * kstride + k) * 2 + 1]); }
+            }
+          }
+        }
+        cached_n = nd;
+      }
+      if (active && gid < 0) {
+#pragma unroll
+        for (int g = 0; g < JIT_GMAX; ++g) {
+          if ((uint32_t)g < cached_n) {
+            bool eq = dc_nl[g] == knull;
+#pragma unroll
+            for (int k = 0; k < JIT_NKC; ++k) if (k < n_keys) eq = eq && dc_lo[g][k] == GPUQ_KLO(k) && dc_hi[g][k] == GPUQ_KHI(k);
+            if (eq) gid = g;
+          }
+        }
+      }
+#else
       if (active && gid < 0) {
         for (uint32_t g = seen; g < nd; ++g) {
           bool eq = vnulls[g] == knull;
@@ -267,6 +322,7 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
           if (eq) gid = (int)g;
         }
       }
+#endif
       seen = nd;
       const u64 need = __ballot(active && gid < 0);
       if (need == 0) break;
@@ -305,13 +361,14 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
     }
     // accumulate
     if (active) {
+      SPEC_UNROLL
       for (int a = 0; a < n_accs; ++a) {
-        const int kind = A.acc_kind[a];
+        const int kind = SPEC_ACC_KIND(a);
         const int cell = gid * n_accs + a;
         u64* slot = &L.lane_acc[cell * BLOCK + tid];
         u64 vlo = 1, vhi = 0; bool vnull = false;
         if (kind != ACC_COUNT_STAR) {
-          const int r = __builtin_amdgcn_readfirstlane(A.acc_reg[a]);
+          const int r = SPEC_ACC_REG(a);
           vlo = rlo[r]; vhi = rhi[r]; vnull = (rnulls >> r) & 1;
         }
         if (vnull) continue;
@@ -359,7 +416,7 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
   for (int i = tid; i < ng * kstride * 2; i += BLOCK) out_keys[i] = L.dkeys[i];
   for (int i = tid; i < ng; i += BLOCK) out_nulls[i] = L.dnulls[i];
   for (int c = 0; c < ng * n_accs; ++c) {
-    const int kind = A.acc_kind[c % n_accs];
+    const int kind = SPEC_ACC_KIND(c % n_accs);
     const u64 v = L.lane_acc[c * BLOCK + tid];
     u64 lo, hi;
     if (kind == ACC_SUM) { lo = v; hi = (u64)((i64)v >> 63); } else { lo = v; hi = 0; }
@@ -403,6 +460,10 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
     __syncthreads();
   }
 }
+#undef SPEC_KEY_REG
+#undef SPEC_ACC_KIND
+#undef SPEC_ACC_REG
+#undef SPEC_UNROLL
 #ifndef GPUQ_JIT
 template <int MAXC>
 #ifndef GPUQ_JIT
