@@ -656,13 +656,14 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
       raw.keys = (u64*)op->ws[0].ensure((size_t)rcap * kstride * 16);
       raw.key_nulls = (uint32_t*)op->ws[1].ensure((size_t)rcap * 4);
       raw.cells = (u64*)op->ws[2].ensure((size_t)rcap * na * 16);
-      raw.n_groups = (uint32_t*)op->ws[3].ensure(16);
-      HIPCHECK(hipMemsetAsync(raw.n_groups, 0, 16, s));
+      raw.n_groups = op->flags_dev.as<uint32_t>() + 2;     // next to the flags word: one copy reads both
+      HIPCHECK(hipMemsetAsync(raw.n_groups, 0, 8, s));
     };
     auto read_ng = [&]() { uint32_t v = 0; HIPCHECK(hipMemcpyAsync(&v, raw.n_groups, 4, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s)); return v; };
     bool done = false;
     std::string strat = op->strategy;
     if (nk == 0) strat = "tiny";
+    else if (strat == "auto" && n <= 16384) strat = "hash";   // tiny input: a 2n-slot table beats the LDS kernel's fixed per-block cost
     if (strat == "auto" || strat == "tiny") {
       const int fit_big = agg_tiny_max_groups(na);
       if (fit_big < 1) { if (strat == "tiny") throw Unsupported("too many accumulators for the LDS aggregate"); }
@@ -684,17 +685,20 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
           spec += arr("JIT_KEY_REG", op->agg.key_reg, MAX_KEYS) + arr("JIT_ACC_KIND", op->agg.acc_kind, MAX_ACCS) + arr("JIT_ACC_REG", op->agg.acc_reg, MAX_ACCS);
           { JitScope js(op, op->prog, 3, n, spec); ProfScope ps(op, s); launch_agg_tiny(s, P, n, op->agg, gmax, wsp, raw); }
           HIPCHECK(hipGetLastError());
-          const uint32_t f = read_flags(op, s);
+          uint32_t fw[4] = {0, 0, 0, 0};
+          HIPCHECK(hipMemcpyAsync(fw, op->flags_dev.p, 16, hipMemcpyDeviceToHost, s));
+          HIPCHECK(hipStreamSynchronize(s));
+          const uint32_t f = fw[0];
           if (f & ~FLAG_GROUP_OVERFLOW) { reset_flags(op, s); raise_flags(f & ~FLAG_GROUP_OVERFLOW); }
-          if (!(f & FLAG_GROUP_OVERFLOW)) { ng = read_ng(); done = true; break; }
+          if (!(f & FLAG_GROUP_OVERFLOW)) { ng = fw[2]; done = true; break; }
         }
         if (!done && strat == "tiny") throw Capacity("more groups than the LDS aggregate holds; use strategy hash/auto");
       }
     }
     if (!done) {
       // global hash table; grow on FLAG_TABLE_FULL
-      u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (u64)std::min<i64>(n, 1ll << 24);
-      if (est < 1024) est = 1024;
+      u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (u64)std::min<i64>(std::max<i64>(n, 1), 1ll << 24);
+      if (est < 64) est = 64;
       HashTable T{};
       T.key_words = op->keys.key_words; T.slot_words = 1 + T.key_words + 2 * na;
       for (;;) {
@@ -704,21 +708,33 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         reset_flags(op, s);
         { JitScope js(op, op->prog, 4, n); ProfScope ps(op, s); launch_agg_hash(s, P, n, op->keys, op->agg, T); }
         HIPCHECK(hipGetLastError());
-        const uint32_t f = read_flags(op, s);
+        const uint32_t f = (n <= (1ll << 20) && est >= (u64)n) ? 0u : read_flags(op, s);   // a 2n-slot table cannot fill up; other flags surface after extract
         if (f & FLAG_TABLE_FULL) { if (est >= (u64)std::max<i64>(n, 1024)) throw std::runtime_error("hash aggregate: table full at maximum size"); est = std::min<u64>(est * 4, (u64)std::max<i64>(n, 1024)); continue; }
         if (f) { reset_flags(op, s); raise_flags(f); }
         break;
       }
-      // count live slots first so the raw buffers are sized exactly
-      alloc_raw(1);
-      raw.cap = 0;
-      launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
-      ng = read_ng();
-      reset_flags(op, s);
-      alloc_raw(std::max<i64>(ng, 1));
-      launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
-      HIPCHECK(hipGetLastError());
-      ng = read_ng();
+      if (n <= (1ll << 20)) {
+        // small input: groups <= rows, so size the raw result by n and extract once (one sync instead of three)
+        alloc_raw(std::max<i64>(n, 1));
+        launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
+        HIPCHECK(hipGetLastError());
+        uint32_t fw[4] = {0, 0, 0, 0};
+        HIPCHECK(hipMemcpyAsync(fw, op->flags_dev.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        if (fw[0]) { reset_flags(op, s); raise_flags(fw[0]); }
+        ng = fw[2];
+      } else {
+        // count live slots first so the raw buffers are sized exactly
+        alloc_raw(1);
+        raw.cap = 0;
+        launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
+        ng = read_ng();
+        reset_flags(op, s);
+        alloc_raw(std::max<i64>(ng, 1));
+        launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
+        HIPCHECK(hipGetLastError());
+        ng = read_ng();
+      }
     }
     if (n_groups_out) *n_groups_out = ng;
     if ((i64)ng > cap) throw Capacity("aggregate produced " + std::to_string(ng) + " groups, output capacity is " + std::to_string(cap));
@@ -819,7 +835,10 @@ int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpu
       uint32_t* match = (uint32_t*)op->ws[0].ensure((size_t)n * 4 + 16);
       u64* bitmap = (u64*)op->ws[1].ensure((size_t)nwords * 8);
       uint32_t* counts = (uint32_t*)op->ws[2].ensure((size_t)nblocks * 4 + 16);
-      { JitScope js(op, op->prog, 7, n); ProfScope ps(op, s);
+      std::string spec;
+      if (op->keys.n_keys == 1 && op->keys.key_words == 1 && t->T.slot_words == 2)     // one narrow key, 16-byte slots
+        spec = "#define GPUQ_JIT_PROBE1 1\nconstexpr int JIT_KEY_REG0 = " + std::to_string(op->keys.key_reg[0]) + ";\n";
+      { JitScope js(op, op->prog, 7, n, spec); ProfScope ps(op, s);
         launch_join_probe_unique(s, P, n, op->keys, t->T, jt, op->null_eq, match, bitmap, counts, nblocks, wpb, visited); }
       launch_scan_block_counts(s, counts, nblocks, (u64*)count_out);
       if (out_probe) launch_compact_pairs(s, bitmap, counts, nblocks, wpb, n, match, payload_via > 0 ? in->via[payload_via - 1] : nullptr,

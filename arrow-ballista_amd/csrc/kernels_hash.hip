@@ -401,6 +401,79 @@ extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevPro
 // emit bitmap and per-block counts; pass 2 (k_compact_pairs) turns them into dense, PROBE-ORDERED
 // (build_row, probe_row) pairs.  A single global counter would serialise the whole probe
 // (measured: 51 ms for 2^28 probes whatever the table size -- one device-scope atomic per wave step).
+#ifdef GPUQ_JIT_PROBE1
+// JIT specialisation for the common PK/FK shape: ONE narrow (<= 64-bit) non-null-word key, 16-byte slots.
+// Each lane keeps U probe rows in flight: U key evaluations, then U slot loads issued back to back, then U
+// resolutions -- the random slot access is the long pole of a probe, and one outstanding access per
+// lane cannot cover its latency (measured: 26-38 G probes/s with U = 1 whatever the table size).
+template <int MAXC>
+__device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                              const int join_type, const int null_eq, uint32_t* __restrict__ match,
+                                                              u64* __restrict__ bitmap, uint32_t* __restrict__ block_counts, const i64 wpb,
+                                                              uint32_t* __restrict__ visited) {
+  constexpr int U = 4;
+  __shared__ uint32_t wave_cnt[HWAVES];
+  const i64 nwords = (n + 63) >> 6;
+  const i64 w0 = (i64)blockIdx.x * wpb;
+  i64 w1 = w0 + wpb; if (w1 > nwords) w1 = nwords;
+  const bool probe_outer = (join_type == JT_RIGHT || join_type == JT_FULL);
+  const bool want_pairs = (join_type == JT_INNER || join_type == JT_LEFT || join_type == JT_RIGHT || join_type == JT_FULL);
+  const u64 mask = T.n_slots - 1;
+  const ulonglong2* __restrict__ slots = (const ulonglong2*)T.slots;
+  uint32_t cnt = 0;
+  for (i64 wb = w0 + (i64)hwave() * U; wb < w1; wb += (i64)HWAVES * U) {
+    bool act[U]; u64 key[U]; u64 hs[U]; bool isn[U];
+    // stage 1: evaluate U rows (column loads of all U rows are independent -> in flight together)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const i64 pos = ((wb + u) << 6) + hlane();
+      act[u] = (wb + u) < w1 && pos < n;
+      key[u] = 0; hs[u] = 0; isn[u] = false;
+      if (act[u]) {
+        GPUQ_REGS_DECL;
+        act[u] = GPUQ_EVAL(MAXC, P, pos);
+        isn[u] = (rnulls >> JIT_KEY_REG0) & 1;
+        key[u] = isn[u] ? 0 : rlo[JIT_KEY_REG0];
+        hs[u] = hash_combine(0x243F6A8885A308D3ull, key[u], 0, isn[u]);
+      }
+    }
+    // stage 2: first slot of every row
+    ulonglong2 sv[U]; u64 si[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { si[u] = hs[u] & mask; sv[u] = make_ulonglong2(0, 0); if (act[u] && !(isn[u] && !null_eq)) sv[u] = slots[si[u]]; }
+    // stage 3: resolve (linear probing continues per row only on a tag/key mismatch)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const i64 pos = ((wb + u) << 6) + hlane();
+      uint32_t hit = NIL;
+      if (act[u] && !(isn[u] && !null_eq)) {
+        const uint32_t tag = tag_of(hs[u]);
+        ulonglong2 v = sv[u]; u64 sidx = si[u];
+        for (u64 probes = 0; probes < T.n_slots; ++probes) {
+          const uint32_t st = (uint32_t)v.x;
+          if (st == 0u) break;
+          if (st == tag && v.y == key[u]) { hit = (uint32_t)(v.x >> 32); break; }
+          sidx = (sidx + 1) & mask; v = slots[sidx];
+        }
+        if (visited && hit != NIL) atomicOr(&visited[hit >> 5], 1u << (hit & 31));
+      }
+      bool emit;
+      if (join_type == JT_RIGHT_SEMI) emit = act[u] && hit != NIL;
+      else if (join_type == JT_RIGHT_ANTI) emit = act[u] && hit == NIL;
+      else emit = want_pairs && act[u] && (hit != NIL || probe_outer);
+      if ((wb + u) < w1) {
+        if (pos < n) match[pos] = hit;
+        const u64 m = __ballot(emit);
+        if (hlane() == 0) bitmap[wb + u] = m;
+        cnt += (uint32_t)__popcll(m);
+      }
+    }
+  }
+  if (hlane() == 0) wave_cnt[hwave()] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < HWAVES; ++k) t += wave_cnt[k]; block_counts[blockIdx.x] = t; }
+}
+#else
 template <int MAXC>
 __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
                                                               const int join_type, const int null_eq, uint32_t* __restrict__ match,
@@ -440,6 +513,7 @@ __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, con
   __syncthreads();
   if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < HWAVES; ++k) t += wave_cnt[k]; block_counts[blockIdx.x] = t; }
 }
+#endif  // GPUQ_JIT_PROBE1
 #ifndef GPUQ_JIT
 template <int MAXC>
 #ifndef GPUQ_JIT

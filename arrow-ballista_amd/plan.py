@@ -38,6 +38,7 @@ class TaskContext:
         self.batch_size = batch_size
         self.task_id, self.session_id = task_id, session_id
         self._ops = {}
+        self._memo = {}      # (kind, plan-node / expression identity, table signature) -> compiled Op
 
     def op(self, descriptor):
         key = json.dumps(descriptor, sort_keys=True)
@@ -53,6 +54,12 @@ class TaskContext:
 
     def sync(self):
         _torch().cuda.current_stream(self.ctx.device).synchronize()
+
+
+def table_sig(table):
+    """Cheap hashable signature of a table's layout (what a compiled operator depends on)."""
+    return (len(table.via),) + tuple((c.name, c.type if isinstance(c.type, str) else (c.type["Decimal128"][0], c.type["Decimal128"][1]),
+                                      c.nullable, sd, c.repr) for c, sd in zip(table.columns, table.sides))
 
 
 class Metrics:
@@ -75,22 +82,34 @@ def _alloc_outputs(op, n, device):
     for i, f in enumerate(op.fields):
         tj = type_json(f["type"], f["precision"], f["scale"])
         if f["type"] == B.T_BOOL:
-            data = torch.zeros(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=device)
+            data = torch.empty(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=device)
         else:
             data = torch.empty(max(1, n) * f["width"] + 16, dtype=torch.uint8, device=device)
-        validity = torch.zeros(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=device) if f["nullable"] else None
+        validity = torch.empty(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=device) if f["nullable"] else None   # every word is written by the kernel
         col = DeviceColumn(f["name"], tj, data, n, validity=validity, nullable=f["nullable"], repr=f["repr"])
         cols.append(col)
         arr[i] = col.to_c()
     return cols, arr
 
 
-def _project(tc, table, exprs, names):
-    """ProjectionExec kernel call: evaluate `exprs` over (a view of) `table` into a materialised table."""
-    schema = table.schema()
-    desc = {"op": "project", "input": {"fields": schema},
-            "exprs": [{"expr": E.rebind(e, schema), "name": n} for e, n in zip(exprs, names)]}
-    op = tc.op(desc)
+def _project(tc, table, exprs, names, memo_key=None, memo=None):
+    """ProjectionExec kernel call: evaluate `exprs` over (a view of) `table` into a materialised table.
+    memo_key: hashable identity of (exprs, names) so the compiled operator is found without rebuilding the descriptor."""
+    op = None
+    if memo is None:
+        memo = tc._memo
+    if memo_key is not None:
+        mk = ("project", id(tc), memo_key, table_sig(table))
+        op = memo.get(mk)
+    if op is None:
+        schema = table.schema()
+        if callable(exprs):
+            exprs, names = exprs()
+        desc = {"op": "project", "input": {"fields": schema},
+                "exprs": [{"expr": E.rebind(e, schema), "name": n} for e, n in zip(exprs, names)]}
+        op = tc.op(desc)
+        if memo_key is not None:
+            memo[mk] = op
     n = table.num_rows
     cols, arr = _alloc_outputs(op, n, tc.device)
     inp, keep = table.input_struct()
@@ -101,8 +120,7 @@ def _project(tc, table, exprs, names):
 def _take_u32(tc, vec, idx, n):
     """new[j] = vec[idx[j]] with NULL_ROW propagated; vec/idx are int32-typed uint32 tensors."""
     src = DeviceTable([DeviceColumn("v", "UInt32", vec, vec.numel())], n, via=[idx], sides=[1])
-    e = E.case([(E.is_null(E.col("v", index=0)), E.lit(NULL_ROW, "UInt32"))], E.col("v", index=0))
-    out = _project(tc, src, [e], ["v"])
+    out = _project(tc, src, lambda: ([E.case([(E.is_null(E.col("v", index=0)), E.lit(NULL_ROW, "UInt32"))], E.col("v", index=0))], ["v"]), None, memo_key="take_u32")
     return out.columns[0].data[: max(1, n) * 4].view(_torch().int32)[:n]
 
 
@@ -136,8 +154,10 @@ def materialize(tc, table):
     for a in range(0, len(sch), 12):
         idxs = list(range(a, min(a + 12, len(sch))))
         sub = DeviceTable([table.columns[i] for i in idxs], table.num_rows, via=table.via, sides=[table.sides[i] for i in idxs])
-        ss = sub.plain_schema()
-        out += _project(tc, sub, [E.col(f["name"], index=i) for i, f in enumerate(ss)], [f["name"] for f in ss]).columns
+        def mk(sub=sub):
+            ss = sub.plain_schema()
+            return [E.col(f["name"], index=i) for i, f in enumerate(ss)], [f["name"] for f in ss]
+        out += _project(tc, sub, mk, None, memo_key="materialize").columns
     return DeviceTable(out, table.num_rows)
 
 
@@ -165,6 +185,7 @@ def _inl(e, m):
 class ExecutionPlan:
     def __init__(self):
         self.metrics = Metrics()
+        self._memo = {}       # compiled operators of this node, keyed by (context, input table signature)
 
     def children(self):
         return []
@@ -270,13 +291,22 @@ class FilterExec(ExecutionPlan):
     def execute(self, partition, context):
         table = self.input.execute(partition, context)
         t0 = time.perf_counter()
-        return self._timed(t0, filter_table(context, table, self.predicate))
+        return self._timed(t0, filter_table(context, table, self.predicate, memo_key="self", memo=self._memo))
 
 
-def filter_table(tc, table, predicate):
+def filter_table(tc, table, predicate, memo_key=None, memo=None):
     torch = _torch()
-    schema = table.schema()
-    op = tc.op({"op": "filter", "input": {"fields": schema}, "predicate": E.rebind(predicate, schema)})
+    op = None
+    if memo is None:
+        memo = tc._memo
+    if memo_key is not None:
+        mk = ("filter", id(tc), memo_key, table_sig(table))
+        op = memo.get(mk)
+    if op is None:
+        schema = table.schema()
+        op = tc.op({"op": "filter", "input": {"fields": schema}, "predicate": E.rebind(predicate, schema)})
+        if memo_key is not None:
+            memo[mk] = op
     n = table.num_rows
     sel = torch.empty(max(1, n), dtype=torch.int32, device=tc.device)
     cnt = torch.zeros(2, dtype=torch.int64, device=tc.device)
@@ -303,12 +333,14 @@ class ProjectionExec(ExecutionPlan):
         return [_field_from_desc(o) for o in d["outputs"]]
 
     def execute(self, partition, context):
-        src, pred, m = _fuse(self)
+        if not hasattr(self, "_fused"):
+            self._fused = _fuse(self)          # plan nodes are immutable once built: fuse once
+        src, pred, m = self._fused
         table = src.execute(partition, context)
         t0 = time.perf_counter()
         if pred is not None:
-            table = filter_table(context, table, pred)
-        out = _project(context, table, [m[name] for _, name in self.expr], [name for _, name in self.expr])
+            table = filter_table(context, table, pred, memo_key="pf", memo=self._memo)
+        out = _project(context, table, lambda: ([m[name] for _, name in self.expr], [name for _, name in self.expr]), None, memo_key="pe", memo=self._memo)
         return self._timed(t0, out)
 
 
@@ -350,15 +382,23 @@ class AggregateExec(ExecutionPlan):
 
     def execute(self, partition, context):
         final = self.mode in ("Final", "FinalPartitioned")
-        src, pred, m = (self.input, None, None) if final else _fuse(self.input)
+        fused_for = getattr(self, "_fused_for", None)
+        if fused_for is not self.input:
+            self._fused = (self.input, None, None) if final else _fuse(self.input)
+            self._fused_for = self.input
+        src, pred, m = self._fused
         table = src.execute(partition, context)
         t0 = time.perf_counter()
-        out = aggregate_table(context, table, self._descriptor(table.schema(), pred, m))
+        mk = ("agg", id(context), id(self.input), table_sig(table))
+        op = self._memo.get(mk)
+        if op is None:
+            op = self._memo[mk] = context.op(self._descriptor(table.schema(), pred, m))
+        out = aggregate_table(context, table, op.descriptor, op=op)
         return self._timed(t0, out)
 
 
-def aggregate_table(tc, table, descriptor, cap=None):
-    op = tc.op(descriptor)
+def aggregate_table(tc, table, descriptor, cap=None, op=None):
+    op = op if op is not None else tc.op(descriptor)
     n = table.num_rows
     if cap is None:
         cap = 4096 if not descriptor["group_expr"] else max(4096, min(n, 1 << 22))
@@ -433,16 +473,20 @@ class HashJoinExec(ExecutionPlan):
             ltab, lpred, _ = self._side(self.left, lpart, tc, lkeys)
         rtab, rpred, _ = self._side(self.right, partition, tc, rkeys)
         t0 = time.perf_counter()
-        lschema, rschema = ltab.schema(), rtab.schema()
-        bdesc = {"op": "join_build", "input": {"fields": lschema}, "on": [E.rebind(k, lschema) for k in lkeys],
+        mk = ("join", id(tc), table_sig(ltab), table_sig(rtab))
+        ops = self._memo.get(mk)
+        lschema, rschema = (None, None) if ops else (ltab.schema(), rtab.schema())
+        bdesc = None if ops else {"op": "join_build", "input": {"fields": lschema}, "on": [E.rebind(k, lschema) for k in lkeys],
                  "null_equals_null": bool(self.null_equals_null)}
-        if lpred is not None:
+        if bdesc is not None and lpred is not None:
             bdesc["predicate"] = E.rebind(lpred, lschema)
-        pdesc = {"op": "join_probe", "input": {"fields": rschema}, "on": [E.rebind(k, rschema) for k in rkeys],
+        pdesc = None if ops else {"op": "join_probe", "input": {"fields": rschema}, "on": [E.rebind(k, rschema) for k in rkeys],
                  "join_type": jt, "null_equals_null": bool(self.null_equals_null)}
-        if rpred is not None:
+        if pdesc is not None and rpred is not None:
             pdesc["predicate"] = E.rebind(rpred, rschema)
-        bop, pop = tc.op(bdesc), tc.op(pdesc)
+        if ops is None:
+            ops = self._memo[mk] = (tc.op(bdesc), tc.op(pdesc))
+        bop, pop = ops
         linp, lk = ltab.input_struct()
         h = C.c_void_p()
         tc.ctx.check(tc.ctx.L.gpuq_join_build_run(bop.h, tc.stream_ptr(), C.byref(linp), 0, ltab.num_rows, C.byref(h)))
@@ -519,11 +563,14 @@ class SortExec(ExecutionPlan):
         torch = _torch()
         table = self.input.execute(partition, context)
         t0 = time.perf_counter()
-        schema = table.schema()
-        desc = {"op": "sort", "input": {"fields": schema},
-                "expr": [{"expr": E.rebind(s["expr"], schema), "asc": bool(s.get("asc", True)),
-                          "nulls_first": bool(s.get("nulls_first", not s.get("asc", True)))} for s in self.expr]}
-        op = context.op(desc)
+        mk = ("sort", id(context), table_sig(table))
+        op = self._memo.get(mk)
+        if op is None:
+            schema = table.schema()
+            desc = {"op": "sort", "input": {"fields": schema},
+                    "expr": [{"expr": E.rebind(s["expr"], schema), "asc": bool(s.get("asc", True)),
+                              "nulls_first": bool(s.get("nulls_first", not s.get("asc", True)))} for s in self.expr]}
+            op = self._memo[mk] = context.op(desc)
         n = table.num_rows
         perm = torch.empty(max(1, n), dtype=torch.int32, device=context.device)
         inp, keep = table.input_struct()

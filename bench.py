@@ -92,12 +92,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Python's cyclic GC walks the whole torch/pyarrow heap (~40 ms per full collection): keep it out of the timed region
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     kernel_ms, launches = pop.profile(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=tc.device)
