@@ -125,8 +125,14 @@ def main():
     if launches > 0:
         avg_ms = kernel_ms / launches
         achieved = Q1_BYTES_PER_ROW * n / (avg_ms * 1e-3) / 1e9
-        line["roofline"] = {"bound": "hbm", "kernel": "k_agg_tiny", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+        # HBM traffic per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes over this same
+        # command, gfx950 correction applied; provenance in profiles/r01_traffic.json).  Only valid for the default workload.
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if n == T.LINEITEM_ROWS[10] and os.path.exists(tp):
+            traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
+        line["roofline"] = {"bound": "hbm", "kernel": "k_agg_tiny (hiprtc-specialised: gpuq_jit_entry)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
                             "algorithmic_bytes_per_launch": Q1_BYTES_PER_ROW * n}
 
     if rank == 0 and not args.no_cpu_baseline:
