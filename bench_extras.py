@@ -57,6 +57,24 @@ def join_probe_micro(tc, g, log2_build, log2_probe, hit_rate, reps=3):
             "frac_hbm_peak": alg_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "build_ms": build_ms, "build_rows_per_s": nb / (build_ms * 1e-3)}
 
 
+def q1_pipeline(tc, T, g, sf):
+    import torch
+    n_li = T.LINEITEM_ROWS.get(sf, int(6_000_000 * sf))
+    li = T.gen_lineitem_device(tc, n_li)
+    plan = T.q1_plan(g.MemoryExec([li]), two_phase=True)
+    times = []
+    for r in range(4):
+        _sync(tc)
+        t0 = time.perf_counter()
+        res = g.plan.materialize(tc, plan.execute(0, tc))
+        _sync(tc)
+        times.append(time.perf_counter() - t0)
+    del li
+    torch.cuda.empty_cache()
+    return {"wall_ms_best": min(times[1:]) * 1e3, "wall_ms_first": times[0] * 1e3, "result_rows": res.num_rows, "lineitem_rows": n_li,
+            "lineitem_rows_per_s": n_li / min(times[1:])}
+
+
 def tpch_pipelines(tc, T, g, sf):
     """q3 and q5 wall time (operator work only, inputs resident in HBM, synthetic TPC-H-shaped tables)."""
     n_li = T.LINEITEM_ROWS.get(sf, int(6_000_000 * sf))
@@ -100,4 +118,9 @@ if __name__ == "__main__":
     import tpch_util as T
     import arrow_ballista_amd as g
     tc = g.TaskContext(device=0)
-    print(json.dumps(run(tc, T, g, full="--small" not in sys.argv), indent=1))
+    if "--sf100" in sys.argv:
+        out = {"q1": q1_pipeline(tc, T, g, 100)}
+        out.update(tpch_pipelines(tc, T, g, 100))
+        print(json.dumps(out, indent=1))
+    else:
+        print(json.dumps(run(tc, T, g, full="--small" not in sys.argv), indent=1))
