@@ -15,11 +15,13 @@ from .table import DeviceColumn, DeviceTable  # noqa: F401
 from .plan import (  # noqa: F401
     MemoryExec, FilterExec, ProjectionExec, AggregateExec, HashJoinExec, SortExec, CoalesceBatchesExec,
     RepartitionExec, ShuffleWriterExec, DefaultExecutionEngine, TaskContext,
+    CoalesceTasksExec, CoalescePartitionsExec, SortPreservingMergeExec, UnionExec, LocalLimitExec, GlobalLimitExec,
 )
 
 __all__ = [
     "GpuqError", "Context", "Op", "JoinTable", "lib", "lib_path", "compile_check", "expr",
     "DeviceColumn", "DeviceTable", "MemoryExec", "FilterExec", "ProjectionExec", "AggregateExec",
     "HashJoinExec", "SortExec", "CoalesceBatchesExec", "RepartitionExec", "ShuffleWriterExec",
-    "DefaultExecutionEngine", "TaskContext",
+    "DefaultExecutionEngine", "TaskContext", "CoalesceTasksExec", "CoalescePartitionsExec", "SortPreservingMergeExec",
+    "UnionExec", "LocalLimitExec", "GlobalLimitExec",
 ]

@@ -108,6 +108,7 @@ def lib():
         "gpuq_partition_run": (i32, [vp, vp, C.POINTER(gpuq_input), vp, vp]),
         "gpuq_op_check": (i32, [vp, vp]),
         "gpuq_unpack_utf8": (i32, [vp, vp, vp, i64, vp, vp, i64, C.POINTER(i64)]),
+        "gpuq_concat_bitmap": (i32, [vp, vp, vp, i64, vp, i64]),
         "gpuq_gen_lineitem": (i32, [vp, vp, u64, u64, i64, i64, i64, C.POINTER(gpuq_lineitem_cols)]),
         "gpuq_gen_orders": (i32, [vp, vp, u64, i64, i64, i64, C.POINTER(gpuq_orders_cols)]),
         "gpuq_gen_customer": (i32, [vp, vp, u64, i64, i64, C.POINTER(gpuq_customer_cols)]),

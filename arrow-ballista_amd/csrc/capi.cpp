@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <deque>
+#include <functional>
 #include <vector>
 
 using namespace gpuq;
@@ -73,7 +75,8 @@ struct gpuq_op {
   std::string mode = "Single", strategy = "auto";
   AggSpec agg{}; KeySpec keys{};
   std::vector<DType> key_types, acc_types;
-  CompiledProgram post; DevBuf post_code; Schema post_schema;
+  struct PostChunk { CompiledProgram prog; DevBuf code; int first_out = 0; };
+  std::deque<PostChunk> posts; Schema post_schema;
   i64 expected_groups = 0;
   // join
   int join_type = JT_INNER; int null_eq = 0;
@@ -238,8 +241,25 @@ struct AggPlan {
   std::string fn, name;
   DType arg_type; bool arg_nullable = false;
   int acc_sum = -1, acc_cnt = -1, acc_mm = -1;   // sum / count / min-max accumulators
+  int acc_sx = -1, acc_sy = -1, acc_sxx = -1, acc_syy = -1, acc_sxy = -1;   // variance family: f64 power sums
   bool is_float = false;
 };
+
+// VARIANCE / STDDEV / COVARIANCE / CORRELATION (datafusion.proto:639-645).  The reference keeps Welford-style
+// running (count, mean, m2[, algo_const]) states [UPSTREAM-KNOWLEDGE]; a data-parallel device cannot follow a
+// row order, so the accumulators are the order-free power sums n, Sx, Sy, Sxx, Syy, Sxy in f64 and the
+// reference's state columns are derived from them (mean = Sx/n, m2 = Sxx - Sx^2/n, algo = Sxy - Sx*Sy/n).
+// Results agree with the reference to f64 rounding (tolerance stated in tests/test_gpu_operators.py).
+int var_family(const std::string& fn) {   // 1: one-argument (x), 2: two-argument (x, y)
+  if (fn == "VARIANCE" || fn == "VAR" || fn == "VAR_SAMP" || fn == "VARIANCE_POP" || fn == "VAR_POP" ||
+      fn == "STDDEV" || fn == "STDDEV_SAMP" || fn == "STDDEV_POP") return 1;
+  if (fn == "COVARIANCE" || fn == "COVAR" || fn == "COVAR_SAMP" || fn == "COVARIANCE_POP" || fn == "COVAR_POP" ||
+      fn == "CORRELATION" || fn == "CORR") return 2;
+  return 0;
+}
+bool var_is_pop(const std::string& fn) { return fn.size() > 4 && fn.compare(fn.size() - 4, 4, "_POP") == 0; }
+bool var_is_corr(const std::string& fn) { return fn == "CORRELATION" || fn == "CORR"; }
+bool var_is_stddev(const std::string& fn) { return fn.compare(0, 6, "STDDEV") == 0; }
 
 void compile_aggregate(gpuq_op* op, const Json& d) {
   op->mode = d.get_str("mode", "Single");
@@ -290,6 +310,26 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
           else if (arg->type.is_int() || arg->type.is_decimal() || arg->type.id == T_DATE32) pl.acc_mm = find_or_add_acc(accs, mn ? ACC_MIN : ACC_MAX, arg, arg->type);
           else throw Unsupported(pl.fn + " over " + arg->type.to_string());
           if (pl.arg_nullable) pl.acc_cnt = count_of(arg);
+        } else if (var_family(pl.fn)) {
+          const DType f64 = t_of(T_FLOAT64);
+          if (!(arg->type.is_float() || arg->type.is_int() || arg->type.is_decimal())) throw Unsupported(pl.fn + " over " + arg->type.to_string());
+          NodeP x = ec.cast(arg, f64), y;
+          pl.is_float = true;
+          if (var_family(pl.fn) == 2) {
+            if (!a.has("expr2")) throw std::runtime_error(pl.fn + " needs two arguments (expr, expr2)");
+            y = ec.cast(ec.from_json(a.at("expr2")), f64);
+            // rows where either argument is NULL are skipped for every sum
+            NodeP both = ec.binary("AND", ec.is_null(x, true), ec.is_null(y, true));
+            if (x->nullable || y->nullable) { NodeP x2 = ec.select(both, x, ec.lit_null(f64)); NodeP y2 = ec.select(both, y, ec.lit_null(f64)); x = x2; y = y2; }
+          }
+          pl.acc_cnt = count_of(x);
+          pl.acc_sx = find_or_add_acc(accs, ACC_FSUM, x, f64);
+          if (var_family(pl.fn) == 1 || var_is_corr(pl.fn)) pl.acc_sxx = find_or_add_acc(accs, ACC_FSUM, ec.binary("*", x, x), f64);
+          if (y) {
+            pl.acc_sy = find_or_add_acc(accs, ACC_FSUM, y, f64);
+            pl.acc_sxy = find_or_add_acc(accs, ACC_FSUM, ec.binary("*", x, y), f64);
+            if (var_is_corr(pl.fn)) pl.acc_syy = find_or_add_acc(accs, ACC_FSUM, ec.binary("*", y, y), f64);
+          }
         } else throw Unsupported("aggregate function " + pl.fn);
       }
     } else {
@@ -311,6 +351,27 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
         if (s->type.is_float()) { pl.is_float = true; pl.acc_mm = find_or_add_acc(accs, mn ? ACC_FMIN : ACC_FMAX, s, s->type); }
         else pl.acc_mm = find_or_add_acc(accs, mn ? ACC_MIN : ACC_MAX, s, s->type);
         if (pl.arg_nullable) pl.acc_cnt = s->nullable ? find_or_add_acc(accs, ACC_COUNT, s, t_of(T_INT64)) : find_or_add_acc(accs, ACC_COUNT_STAR, nullptr, t_of(T_INT64));
+      } else if (var_family(pl.fn)) {
+        // reference state columns: VAR/STDDEV [count, mean, m2]; COVAR [count, mean1, mean2, algo_const];
+        // CORR [count, mean1, m2_1, mean2, m2_2, algo_const] [UPSTREAM-KNOWLEDGE].  Back to power sums, then add.
+        const DType f64 = t_of(T_FLOAT64); pl.is_float = true;
+        NodeP c = state(); NodeP cf = ec.cast(c, f64);
+        auto fs = [&](NodeP e) { return find_or_add_acc(accs, ACC_FSUM, ec.coalesce0(e), f64); };
+        auto mul = [&](NodeP l, NodeP r) { return ec.binary("*", l, r); };
+        auto add = [&](NodeP l, NodeP r) { return ec.binary("+", l, r); };
+        pl.acc_cnt = find_or_add_acc(accs, ACC_SUM, ec.cast(c, t_of(T_INT64)), t_of(T_INT64));
+        if (var_family(pl.fn) == 1) {
+          NodeP mean = ec.cast(state(), f64), m2 = ec.cast(state(), f64);
+          pl.acc_sx = fs(mul(cf, mean)); pl.acc_sxx = fs(add(m2, mul(cf, mul(mean, mean))));
+        } else if (!var_is_corr(pl.fn)) {
+          NodeP m1 = ec.cast(state(), f64), m2 = ec.cast(state(), f64), al = ec.cast(state(), f64);
+          pl.acc_sx = fs(mul(cf, m1)); pl.acc_sy = fs(mul(cf, m2)); pl.acc_sxy = fs(add(al, mul(cf, mul(m1, m2))));
+        } else {
+          NodeP m1 = ec.cast(state(), f64), v1 = ec.cast(state(), f64), m2 = ec.cast(state(), f64), v2 = ec.cast(state(), f64), al = ec.cast(state(), f64);
+          pl.acc_sx = fs(mul(cf, m1)); pl.acc_sxx = fs(add(v1, mul(cf, mul(m1, m1))));
+          pl.acc_sy = fs(mul(cf, m2)); pl.acc_syy = fs(add(v2, mul(cf, mul(m2, m2))));
+          pl.acc_sxy = fs(add(al, mul(cf, mul(m1, m2))));
+        }
       } else throw Unsupported("aggregate function " + pl.fn);
     }
     plans.push_back(pl);
@@ -339,16 +400,58 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
   // post program over the SoA result: [key_0.., acc_0..] as raw (lo,hi) columns
   for (size_t k = 0; k < key_nodes.size(); ++k) { Field f; f.name = key_names[k]; f.type = key_nodes[k]->type; f.nullable = key_nodes[k]->nullable; f.raw128 = 1; op->post_schema.fields.push_back(f); }
   for (size_t i = 0; i < accs.size(); ++i) { Field f; f.name = "acc" + std::to_string(i); f.type = accs[i].type; f.nullable = false; f.raw128 = 1; op->post_schema.fields.push_back(f); }
-  ExprCompiler pc(op->post_schema);
   const int nk = (int)key_nodes.size();
-  std::vector<std::string> out_names;
-  for (int k = 0; k < nk; ++k) { pc.add_output(pc.column(k)); out_names.push_back(key_names[k]); }
-  for (const AggPlan& pl : plans) {
+  // The post program runs in the same 16-register machine: when all outputs do not fit, the plan list is split and
+  // each chunk becomes its own program over the same SoA columns (a few extra launches over <= n_groups rows).
+  auto build_chunk = [&](ExprCompiler& pc, size_t lo, size_t hi, bool with_keys, std::vector<std::string>& out_names) {
+  if (with_keys) for (int k = 0; k < nk; ++k) { pc.add_output(pc.column(k)); out_names.push_back(key_names[k]); }
+  for (size_t pi = lo; pi < hi; ++pi) {
+    const AggPlan& pl = plans[pi];
     auto acc = [&](int i) { return pc.column(nk + i); };
     auto guard = [&](NodeP v) { return pl.acc_cnt >= 0 && (pl.arg_nullable) ? pc.nullif0(v, acc(pl.acc_cnt)) : v; };
     if (pl.fn == "COUNT") { pc.add_output(acc(pl.acc_cnt)); out_names.push_back(emit_state ? pl.name + "[count]" : pl.name); }
     else if (pl.fn == "SUM") { pc.add_output(guard(acc(pl.acc_sum))); out_names.push_back(emit_state ? pl.name + "[sum]" : pl.name); }
     else if (pl.fn == "MIN" || pl.fn == "MAX") { pc.add_output(guard(acc(pl.acc_mm))); out_names.push_back(emit_state ? pl.name + (pl.fn == "MIN" ? "[min]" : "[max]") : pl.name); }
+    else if (var_family(pl.fn)) {
+      const DType f64 = t_of(T_FLOAT64);
+      auto F = [&](int op_, NodeP l, NodeP r) { return pc.raw(op_, f64, false, 127, {l, r}); };
+      NodeP n = acc(pl.acc_cnt), nf = pc.cast(n, f64), zero = pc.lit_f64(0.0);
+      NodeP n_is0 = pc.binary("=", n, pc.lit_int(t_of(T_INT64), 0));
+      NodeP n_le1 = pc.binary("<=", n, pc.lit_int(t_of(T_INT64), 1));
+      auto when0 = [&](NodeP v) { return pc.select(n_is0, zero, v); };                    // state columns of an empty group are 0
+      auto centred = [&](int sab, int sa, int sb) { return when0(F(OP_FSUB, acc(sab), F(OP_FDIV, F(OP_FMUL, acc(sa), acc(sb)), nf))); };
+      auto nonneg = [&](NodeP v) { return pc.select(pc.raw(OP_FLT, t_of(T_BOOL), false, 1, {v, zero}), zero, v); };   // rounding can leave -eps
+      NodeP mean_x = when0(F(OP_FDIV, acc(pl.acc_sx), nf));
+      NodeP m2x = pl.acc_sxx >= 0 ? nonneg(centred(pl.acc_sxx, pl.acc_sx, pl.acc_sx)) : nullptr;
+      NodeP mean_y = pl.acc_sy >= 0 ? when0(F(OP_FDIV, acc(pl.acc_sy), nf)) : nullptr;
+      NodeP m2y = pl.acc_syy >= 0 ? nonneg(centred(pl.acc_syy, pl.acc_sy, pl.acc_sy)) : nullptr;
+      NodeP cxy = pl.acc_sxy >= 0 ? centred(pl.acc_sxy, pl.acc_sx, pl.acc_sy) : nullptr;
+      auto out = [&](NodeP v, const std::string& nm) { pc.add_output(v); out_names.push_back(nm); };
+      if (emit_state) {
+        out(pc.cast(n, t_of(T_UINT64)), pl.name + "[count]");
+        if (var_family(pl.fn) == 1) { out(mean_x, pl.name + "[mean]"); out(m2x, pl.name + "[m2]"); }
+        else if (!var_is_corr(pl.fn)) { out(mean_x, pl.name + "[mean1]"); out(mean_y, pl.name + "[mean2]"); out(cxy, pl.name + "[algoConst]"); }
+        else { out(mean_x, pl.name + "[mean1]"); out(m2x, pl.name + "[m2_1]"); out(mean_y, pl.name + "[mean2]"); out(m2y, pl.name + "[m2_2]"); out(cxy, pl.name + "[algoConst]"); }
+      } else {
+        const bool pop = var_is_pop(pl.fn);
+        NodeP null64 = pc.lit_null(f64);
+        NodeP denom = pop ? nf : F(OP_FSUB, nf, pc.lit_f64(1.0));
+        NodeP undefined = pop ? n_is0 : n_le1;                                            // sample statistics need n >= 2, population n >= 1
+        if (var_family(pl.fn) == 1) {
+          NodeP v = F(OP_FDIV, m2x, denom);
+          if (var_is_stddev(pl.fn)) v = pc.raw(OP_FSQRT, f64, false, 127, {v});
+          out(pc.select(undefined, null64, v), pl.name);
+        } else if (!var_is_corr(pl.fn)) {
+          out(pc.select(undefined, null64, F(OP_FDIV, cxy, denom)), pl.name);
+        } else {
+          // corr = cov_pop / (sd_pop_x * sd_pop_y); 0 when either deviation is 0; NULL over no rows
+          NodeP sx = pc.raw(OP_FSQRT, f64, false, 127, {F(OP_FDIV, m2x, nf)}), sy = pc.raw(OP_FSQRT, f64, false, 127, {F(OP_FDIV, m2y, nf)});
+          NodeP flat = pc.binary("OR", pc.raw(OP_FEQ, t_of(T_BOOL), false, 1, {sx, zero}), pc.raw(OP_FEQ, t_of(T_BOOL), false, 1, {sy, zero}));
+          NodeP v = F(OP_FDIV, F(OP_FDIV, F(OP_FDIV, cxy, nf), sx), sy);
+          out(pc.select(n_is0, null64, pc.select(flat, zero, v)), pl.name);
+        }
+      }
+    }
     else if (pl.fn == "AVG") {
       if (emit_state) {
         pc.add_output(pc.cast(acc(pl.acc_cnt), t_of(T_UINT64))); out_names.push_back(pl.name + "[count]");
@@ -367,9 +470,24 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
       }
     }
   }
-  op->post = pc.finish();
-  upload_code(op->post, op->post_code);
-  for (size_t i = 0; i < op->post.out_type.size(); ++i) op->out_fields.push_back(make_field(out_names[i], op->post.out_type[i], op->post.out_nullable[i]));
+  };
+  std::function<void(size_t, size_t, bool)> emit = [&](size_t lo, size_t hi, bool with_keys) {
+    ExprCompiler pc(op->post_schema);
+    std::vector<std::string> names; CompiledProgram cp;
+    try { build_chunk(pc, lo, hi, with_keys, names); cp = pc.finish(); }
+    catch (const Unsupported&) { throw; }
+    catch (const std::runtime_error&) {
+      if (hi - lo + (with_keys ? 1 : 0) <= 1) throw;
+      if (with_keys && hi > lo) { emit(lo, lo, true); emit(lo, hi, false); }
+      else { const size_t mid = lo + (hi - lo) / 2; emit(lo, mid, with_keys); emit(mid, hi, false); }
+      return;
+    }
+    if (cp.out_reg.empty()) return;
+    op->posts.emplace_back(); gpuq_op::PostChunk& pcn = op->posts.back();
+    pcn.prog = cp; upload_code(pcn.prog, pcn.code); pcn.first_out = (int)op->out_fields.size();
+    for (size_t i = 0; i < cp.out_type.size(); ++i) op->out_fields.push_back(make_field(names[i], cp.out_type[i], cp.out_nullable[i]));
+  };
+  emit(0, plans.size(), true);
 }
 
 OutSpec make_outspec(const CompiledProgram& cp, gpuq_column* outs, int n_outs, const std::vector<gpuq_field_info>& fields) {
@@ -510,7 +628,7 @@ int gpuq_op_create(gpuq_ctx* ctx, const char* json, gpuq_op** out) {
 }
 
 static const char* op_name(int op) {
-  static const char* n[] = {"NOP","IMM","MOV","ADD","SUB","MUL","MULW","NEG","DIV","MOD","EQ","NE","LT","LE","GT","GE","FADD","FSUB","FMUL","FDIV","FNEG",
+  static const char* n[] = {"NOP","IMM","MOV","ADD","SUB","MUL","MULW","NEG","DIV","MOD","EQ","NE","LT","LE","GT","GE","FADD","FSUB","FMUL","FDIV","FNEG","FSQRT",
     "FEQ","FNE","FLT","FLE","FGT","FGE","I2F","F2I","AND","OR","NOT","ISNULL","ISNOTNULL","SELECT","SHL","BOR","NULLIF0","COALESCE0"};
   return (op >= 0 && op < (int)(sizeof(n) / sizeof(n[0]))) ? n[op] : "?";
 }
@@ -543,7 +661,7 @@ int gpuq_compile_check(const char* json, char* buf, size_t cap) {
     g_upload = true;
     std::string r = "{\"program\":" + describe_program(op->prog, op->in_schema);
     if (op->kind == K_AGG) {
-      r += ",\"post\":" + describe_program(op->post, op->post_schema) + ",\"acc_kinds\":[";
+      r += ",\"post\":" + describe_program(op->posts.front().prog, op->post_schema) + ",\"post_programs\":" + std::to_string(op->posts.size()) + ",\"acc_kinds\":[";
       for (int a = 0; a < op->agg.n_accs; ++a) { if (a) r += ","; r += std::to_string(op->agg.acc_kind[a]); }
       r += "]";
     }
@@ -756,10 +874,15 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
     }
     launch_agg_emit(s, raw, nk, na, ng, soa);
     gpuq_input pin{}; pin.cols = pcols.data(); pin.n_cols = nk + na; pin.n_rows = ng; pin.n_via = 0;
-    DevProgram PP = bind_program(op->post, op->post_schema, op->post_code.as<DevCode>(), op->flags_dev.as<uint32_t>(), &pin);
-    OutSpec O = make_outspec(op->post, outs, n_outs, op->out_fields);
+    if (n_outs != (int)op->out_fields.size()) throw std::runtime_error("expected " + std::to_string(op->out_fields.size()) + " output columns, got " + std::to_string(n_outs));
     for (int i = 0; i < n_outs; ++i) outs[i].length = ng;
-    launch_project(s, PP, ng, O);
+    for (auto& pc : op->posts) {
+      DevProgram PP = bind_program(pc.prog, op->post_schema, pc.code.as<DevCode>(), op->flags_dev.as<uint32_t>(), &pin);
+      const int no = (int)pc.prog.out_reg.size();
+      std::vector<gpuq_field_info> fi(op->out_fields.begin() + pc.first_out, op->out_fields.begin() + pc.first_out + no);
+      OutSpec O = make_outspec(pc.prog, outs + pc.first_out, no, fi);
+      launch_project(s, PP, ng, O);
+    }
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(s));
   });
@@ -981,6 +1104,17 @@ int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t
       if (bits == 0) break;
     }
     HIPCHECK(hipMemcpyAsync(perm_out, ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+// ---------------------------------------------------------------- fan-in support
+int gpuq_concat_bitmap(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src, int64_t n_bits) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!dst || dst_bit_offset < 0 || n_bits < 0) throw std::runtime_error("bad arguments");
+    if (((uintptr_t)dst & 7) != 0) throw std::runtime_error("dst bitmap must be 8-byte aligned");
+    launch_concat_bitmap((hipStream_t)stream, (u64*)dst, dst_bit_offset, src, n_bits);
     HIPCHECK(hipGetLastError());
   });
 }

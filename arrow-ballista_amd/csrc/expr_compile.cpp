@@ -610,6 +610,7 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
       case OP_FADD: e = "(" + V(a) + " + " + V(b) + ")"; break;  case OP_FSUB: e = "(" + V(a) + " - " + V(b) + ")"; break;
       case OP_FMUL: e = "(" + V(a) + " * " + V(b) + ")"; break;  case OP_FDIV: e = "(" + V(a) + " / " + V(b) + ")"; break;
       case OP_FNEG: e = "__longlong_as_double(__double_as_longlong(" + V(a) + ") ^ (i64)0x8000000000000000ull)"; ne = N(a); break;
+      case OP_FSQRT: e = "sqrt(" + V(a) + ")"; ne = N(a); break;
       case OP_FEQ: e = "(" + fkey(a) + " == " + fkey(b) + ")"; break;  case OP_FNE: e = "(" + fkey(a) + " != " + fkey(b) + ")"; break;
       case OP_FLT: e = "(" + fkey(a) + " < " + fkey(b) + ")"; break;   case OP_FLE: e = "(" + fkey(a) + " <= " + fkey(b) + ")"; break;
       case OP_FGT: e = "(" + fkey(a) + " > " + fkey(b) + ")"; break;   case OP_FGE: e = "(" + fkey(a) + " >= " + fkey(b) + ")"; break;

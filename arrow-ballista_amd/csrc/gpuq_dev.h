@@ -29,8 +29,8 @@ typedef unsigned __int128 u128;
 
 constexpr int MAX_COLS = 16;   // input columns referenced by one program
 constexpr int NREG = 16;       // 128-bit virtual registers per lane
-constexpr int MAX_INSNS = 48;
-constexpr int MAX_IMMS = 12;
+constexpr int MAX_INSNS = 96;
+constexpr int MAX_IMMS = 16;
 constexpr int MAX_VIA = 3;     // index vectors (selection / join pair sides)
 constexpr uint32_t NULL_ROW = 0xFFFFFFFFu;  // index-vector entry meaning "no row" (outer join)
 
@@ -58,7 +58,7 @@ enum Op : uint8_t {
   OP_MOV,    // dst <- a
   OP_ADD, OP_SUB, OP_MUL, OP_MULW /* i64*i64 -> i128 */, OP_NEG, OP_DIV /* trunc */, OP_MOD,
   OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE,            // signed 128-bit compares -> 0/1
-  OP_FADD, OP_FSUB, OP_FMUL, OP_FDIV, OP_FNEG,          // f64 in lo
+  OP_FADD, OP_FSUB, OP_FMUL, OP_FDIV, OP_FNEG, OP_FSQRT,  // f64 in lo
   OP_FEQ, OP_FNE, OP_FLT, OP_FLE, OP_FGT, OP_FGE,       // f64 total-order compares
   OP_I2F, OP_F2I,
   OP_AND, OP_OR, OP_NOT,                                // Kleene logic on 0/1 + null
@@ -315,6 +315,7 @@ __device__ __forceinline__ void run_program(const DevProgram& P, GPUQ_REGS_PARAM
       case OP_FMUL: zlo = (u64)__double_as_longlong(__longlong_as_double((i64)alo) * __longlong_as_double((i64)blo)); break;
       case OP_FDIV: zlo = (u64)__double_as_longlong(__longlong_as_double((i64)alo) / __longlong_as_double((i64)blo)); break;
       case OP_FNEG: zlo = alo ^ 0x8000000000000000ull; zn = an; break;
+      case OP_FSQRT: zlo = (u64)__double_as_longlong(sqrt(__longlong_as_double((i64)alo))); zn = an; break;
       case OP_FEQ: zlo = f64_total_key(alo) == f64_total_key(blo); break;
       case OP_FNE: zlo = f64_total_key(alo) != f64_total_key(blo); break;
       case OP_FLT: zlo = f64_total_key(alo) < f64_total_key(blo); break;

@@ -145,9 +145,10 @@ def _select_view(tc, table, idx, n):
     return DeviceTable(cols, n, via=vias, sides=sides)
 
 
-def materialize(tc, table):
-    """Gather a late-materialised view into plain columns (<= 12 columns per kernel call)."""
-    if not table.is_view():
+def materialize(tc, table, force=False):
+    """Gather a late-materialised view into plain columns (<= 12 columns per kernel call).  force=True also
+    re-encodes a plain table (Utf8 offsets+bytes -> fixed-width PACKED15), which concat_tables needs."""
+    if not table.is_view() and not force:
         return table
     sch = table.plain_schema()
     out = []
@@ -159,6 +160,77 @@ def materialize(tc, table):
             return [E.col(f["name"], index=i) for i, f in enumerate(ss)], [f["name"] for f in ss]
         out += _project(tc, sub, mk, None, memo_key="materialize").columns
     return DeviceTable(out, table.num_rows)
+
+
+def concat_tables(tc, tables):
+    """Fan-in of partitions into one table (row order = partition order, then row order inside a partition).
+    Every piece is first brought to the fixed-width device layout; data buffers are joined with device copies
+    (torch.cat) and validity / Boolean bitmaps with gpuq_concat_bitmap."""
+    torch = _torch()
+    tables = list(tables)
+    live = [t for t in tables if t.num_rows > 0]
+    if len(live) == 1 and not live[0].is_view():
+        return live[0]
+    if not live:
+        live = tables[:1]
+    parts = [materialize(tc, t, force=any(c.offsets is not None for c in t.columns)) for t in live]
+    n = sum(p.num_rows for p in parts)
+    cols = []
+    L = tc.ctx.L
+
+    def bitmap(pieces):      # pieces: [(uint8 tensor | None, n_bits)]
+        out = torch.zeros(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=tc.device)
+        off = 0
+        for src, nb in pieces:
+            if nb > 0:
+                tc.ctx.check(L.gpuq_concat_bitmap(tc.ctx.h, tc.stream_ptr(), out.data_ptr(), off, src.data_ptr() if src is not None else None, nb))
+            off += nb
+        return out
+    for i, c0 in enumerate(parts[0].columns):
+        pcs = [p.columns[i] for p in parts]
+        if any(c.repr != c0.repr or c.type != c0.type for c in pcs):
+            raise B.GpuqError(2, "concat: column %r has different layouts across partitions" % c0.name)
+        w = type_width(c0.type)
+        if w == 0:           # Boolean: bit-packed
+            data = bitmap([(c.data, p.num_rows) for c, p in zip(pcs, parts)])
+        else:
+            data = torch.cat([c.data[: p.num_rows * w] for c, p in zip(pcs, parts)] + [torch.zeros(16, dtype=torch.uint8, device=tc.device)])
+        nullable = any(c.nullable for c in pcs)
+        validity = bitmap([(c.validity, p.num_rows) for c, p in zip(pcs, parts)]) if any(c.validity is not None for c in pcs) else None
+        cols.append(DeviceColumn(c0.name, c0.type, data, n, validity=validity, nullable=nullable, repr=c0.repr))
+    return DeviceTable(cols, n)
+
+
+def sort_table(tc, table, sort_expr, fetch=None, memo=None):
+    """Stable sort of one table by [{"expr","asc","nulls_first"}]: returns a view (permutation applied lazily)."""
+    torch = _torch()
+    memo = tc._memo if memo is None else memo
+    mk = ("sort", id(tc), repr(sort_expr) if memo is tc._memo else None, table_sig(table))
+    op = memo.get(mk)
+    if op is None:
+        schema = table.schema()
+        desc = {"op": "sort", "input": {"fields": schema},
+                "expr": [{"expr": E.rebind(s["expr"], schema), "asc": bool(s.get("asc", True)),
+                          "nulls_first": bool(s.get("nulls_first", not s.get("asc", True)))} for s in sort_expr]}
+        op = memo[mk] = tc.op(desc)
+    n = table.num_rows
+    perm = torch.empty(max(1, n), dtype=torch.int32, device=tc.device)
+    inp, keep = table.input_struct()
+    tc.ctx.check(tc.ctx.L.gpuq_sort_run(op.h, tc.stream_ptr(), C.byref(inp), perm.data_ptr()))
+    k = n if fetch is None or fetch < 0 else min(n, int(fetch))
+    return _select_view(tc, table, perm[:k], k)
+
+
+def slice_table(tc, table, skip, fetch):
+    """Rows [skip, skip+fetch) of a table as a view (fetch None: to the end)."""
+    torch = _torch()
+    n = table.num_rows
+    lo = min(max(0, int(skip)), n)
+    hi = n if fetch is None or fetch < 0 else min(n, lo + int(fetch))
+    if lo == 0 and hi == n:
+        return table
+    idx = torch.arange(lo, max(hi, lo + 1), dtype=torch.int32, device=tc.device)
+    return _select_view(tc, table, idx[: hi - lo], hi - lo)
 
 
 def _fuse(plan):
@@ -354,7 +426,8 @@ def _field_from_desc(o):
 
 class AggregateExec(ExecutionPlan):
     """AggregateExec(mode, group_expr, aggr_expr, input) -- datafusion.proto:1405-1450.
-    group_expr: [(expr, name)];  aggr_expr: [{"fn": "SUM"|"AVG"|"COUNT"|"MIN"|"MAX", "expr": e, "name": n}].
+    group_expr: [(expr, name)];  aggr_expr: [{"fn": "SUM"|"AVG"|"COUNT"|"MIN"|"MAX"|"VARIANCE[_POP]"|"STDDEV[_POP]"|
+    "COVARIANCE[_POP]"|"CORRELATION", "expr": e[, "expr2": e2], "name": n}]  (function names: datafusion.proto:631-669).
     Modes: Partial (emits state columns), Final / FinalPartitioned (merge states), Single."""
 
     def __init__(self, mode, group_expr, aggr_expr, input, strategy="auto", expected_groups=0):
@@ -368,7 +441,7 @@ class AggregateExec(ExecutionPlan):
     def _descriptor(self, schema, pred, m):
         d = {"op": "aggregate", "mode": self.mode, "input": {"fields": schema}, "strategy": self.strategy,
              "group_expr": [{"expr": E.rebind(_inl(e, m), schema), "name": n} for e, n in self.group_expr],
-             "aggr_expr": [dict(fn=a["fn"], name=a["name"], **({"expr": E.rebind(_inl(a["expr"], m), schema)} if a.get("expr") is not None else {}))
+             "aggr_expr": [dict(fn=a["fn"], name=a["name"], **{k: E.rebind(_inl(a[k], m), schema) for k in ("expr", "expr2") if a.get(k) is not None})
                            for a in self.aggr_expr]}
         if pred is not None:
             d["predicate"] = E.rebind(pred, schema)
@@ -560,23 +633,153 @@ class SortExec(ExecutionPlan):
         return self.input.schema()
 
     def execute(self, partition, context):
-        torch = _torch()
         table = self.input.execute(partition, context)
         t0 = time.perf_counter()
-        mk = ("sort", id(context), table_sig(table))
-        op = self._memo.get(mk)
-        if op is None:
-            schema = table.schema()
-            desc = {"op": "sort", "input": {"fields": schema},
-                    "expr": [{"expr": E.rebind(s["expr"], schema), "asc": bool(s.get("asc", True)),
-                              "nulls_first": bool(s.get("nulls_first", not s.get("asc", True)))} for s in self.expr]}
-            op = self._memo[mk] = context.op(desc)
-        n = table.num_rows
-        perm = torch.empty(max(1, n), dtype=torch.int32, device=context.device)
-        inp, keep = table.input_struct()
-        context.ctx.check(context.ctx.L.gpuq_sort_run(op.h, context.stream_ptr(), C.byref(inp), perm.data_ptr()))
-        k = n if self.fetch is None or self.fetch < 0 else min(n, int(self.fetch))
-        return self._timed(t0, _select_view(context, table, perm[:k], k))
+        return self._timed(t0, sort_table(context, table, self.expr, self.fetch, memo=self._memo))
+
+
+class SortPreservingMergeExec(ExecutionPlan):
+    """SortPreservingMergeExec(expr, input, fetch) -- datafusion.proto:1473-1478: merges the input's sorted partitions
+    into one sorted partition.  On the device the k-way merge is a concatenation in partition order followed by the
+    stable LSD radix sort: equal keys keep (partition, row) order, which is what a merge that prefers the
+    lower-numbered stream on ties produces [UPSTREAM-KNOWLEDGE: streaming_merge loser tree]."""
+
+    def __init__(self, expr, input, fetch=None):
+        super().__init__()
+        self.expr, self.input, self.fetch = list(expr), input, fetch
+
+    def children(self):
+        return [self.input]
+
+    def schema(self):
+        return self.input.schema()
+
+    def output_partition_count(self):
+        return 1
+
+    def execute(self, partition, context):
+        parts = [self.input.execute(p, context) for p in range(self.input.output_partition_count())]
+        t0 = time.perf_counter()
+        merged = concat_tables(context, parts)
+        return self._timed(t0, sort_table(context, merged, self.expr, self.fetch, memo=self._memo))
+
+
+class CoalesceTasksExec(ExecutionPlan):
+    """CoalesceTasksExec(input, partitions, order_by) -- ballista/core/src/execution_plans/coalesce_tasks.rs:46-70.
+    One listed partition: passed through (:143-145).  order_by given: ALL input partitions are merged preserving
+    the order (:148-171, the reference iterates 0..input_partitions there, not `partitions`); otherwise the listed
+    partitions are concatenated (:172-221; the reference interleaves batches in arrival order, row order across
+    partitions is unspecified -- here it is partition order)."""
+
+    def __init__(self, input, partitions, order_by=None):
+        super().__init__()
+        self.input, self.partitions, self.order_by = input, list(partitions), (list(order_by) if order_by else None)
+
+    def children(self):
+        return [self.input]
+
+    def schema(self):
+        return self.input.schema()
+
+    def output_partition_count(self):
+        return 1
+
+    def execute(self, partition, context):
+        if len(self.partitions) == 1:
+            return self.input.execute(self.partitions[0], context)
+        which = range(self.input.output_partition_count()) if self.order_by else self.partitions
+        parts = [self.input.execute(p, context) for p in which]
+        t0 = time.perf_counter()
+        out = concat_tables(context, parts)
+        if self.order_by:
+            out = sort_table(context, out, self.order_by, None, memo=self._memo)
+        return self._timed(t0, out)
+
+    def __str__(self):
+        return "CoalesceTasksExec" + (": sort_expr=%s" % (self.order_by,) if self.order_by else "")
+
+
+class CoalescePartitionsExec(CoalesceTasksExec):
+    """datafusion CoalescePartitionsExec (datafusion.proto:1492-1494): all input partitions -> one, unordered."""
+
+    def __init__(self, input):
+        ExecutionPlan.__init__(self)
+        self.input, self.order_by = input, None
+
+    @property
+    def partitions(self):
+        return list(range(self.input.output_partition_count()))
+
+    def __str__(self):
+        return "CoalescePartitionsExec"
+
+
+class UnionExec(ExecutionPlan):
+    """UnionExec(inputs) -- datafusion.proto:1319-1321: output partitions are the inputs' partitions, one after another
+    (UNION ALL; UNION adds an AggregateExec over all columns, client/src/context.rs:691-733)."""
+
+    def __init__(self, inputs):
+        super().__init__()
+        self.inputs = list(inputs)
+
+    def children(self):
+        return list(self.inputs)
+
+    def schema(self):
+        return self.inputs[0].schema()
+
+    def output_partition_count(self):
+        return sum(i.output_partition_count() for i in self.inputs)
+
+    def execute(self, partition, context):
+        for i in self.inputs:
+            k = i.output_partition_count()
+            if partition < k:
+                t = i.execute(partition, context)
+                self.metrics.output_rows += t.num_rows
+                return t
+            partition -= k
+        raise IndexError("UnionExec partition out of range")
+
+
+class LocalLimitExec(ExecutionPlan):
+    """LocalLimitExec(input, fetch) -- datafusion.proto:1460-1463: the first `fetch` rows of EACH partition."""
+
+    def __init__(self, input, fetch):
+        super().__init__()
+        self.input, self.fetch = input, int(fetch)
+
+    def children(self):
+        return [self.input]
+
+    def schema(self):
+        return self.input.schema()
+
+    def execute(self, partition, context):
+        table = self.input.execute(partition, context)
+        t0 = time.perf_counter()
+        return self._timed(t0, slice_table(context, table, 0, self.fetch))
+
+
+class GlobalLimitExec(ExecutionPlan):
+    """GlobalLimitExec(input, skip, fetch) -- datafusion.proto:1453-1458: rows [skip, skip+fetch) of a single-partition input."""
+
+    def __init__(self, input, skip=0, fetch=None):
+        super().__init__()
+        self.input, self.skip, self.fetch = input, int(skip), fetch
+
+    def children(self):
+        return [self.input]
+
+    def schema(self):
+        return self.input.schema()
+
+    def execute(self, partition, context):
+        if self.input.output_partition_count() != 1:
+            raise B.GpuqError(1, "GlobalLimitExec requires a single input partition")
+        table = self.input.execute(0, context)
+        t0 = time.perf_counter()
+        return self._timed(t0, slice_table(context, table, self.skip, self.fetch))
 
 
 class RepartitionExec(ExecutionPlan):

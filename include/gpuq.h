@@ -218,6 +218,12 @@ int gpuq_op_jit_source(gpuq_op* op, int kernel_id, char* buf, size_t cap);
 int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n, int32_t* offsets_out, uint8_t* data_out,
                      int64_t data_cap, int64_t* data_len_out);
 
+/* Bitmap concatenation for CoalesceTasksExec / CoalescePartitionsExec / UnionExec fan-in (coalesce_tasks.rs:130-229:
+   P partition streams -> 1): dst bits [dst_bit_offset, +n_bits) |= src bits [0, n_bits); src == NULL appends ones
+   (a piece without a validity buffer).  dst (8-byte aligned, padded to a multiple of 8 bytes) must be zeroed first.
+   Fixed-width data buffers are concatenated with plain device copies.  Asynchronous on `stream`. */
+int gpuq_concat_bitmap(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src, int64_t n_bits);
+
 /* ---- synthetic TPC-H-shaped input (bench/test support) ------------------- */
 typedef struct gpuq_lineitem_cols {
   int64_t* l_orderkey; int64_t* l_suppkey;

@@ -398,10 +398,34 @@ def aggregate(tab, group_exprs, aggs, mode="Single", predicate=None):
                     xs = [av[i] for i in groups[k] if av[i] is not None]
                     vals.append(pick(xs, key=key) if xs else None)
                 names.append(a["name"] + (("[min]" if fn == "MIN" else "[max]") if mode == "Partial" else "")); types.append(at); cols.append(vals)
+            elif fn in _VAR1 or fn in _VAR2:
+                xv = _to_float(av, at)
+                yv = None
+                if fn in _VAR2:
+                    yt, yraw = eval_expr(a["expr2"], tab)
+                    yv = _to_float(yraw, yt)
+                sts = [_var_state([(xv[i], yv[i] if yv is not None else 0.0) for i in groups[k]
+                                   if xv[i] is not None and (yv is None or yv[i] is not None)]) for k in order]
+                if mode == "Partial":
+                    lay = _var_layout(fn)
+                    names += [a["name"] + "[%s]" % nm for nm, _ in lay]; types += ["UInt64"] + ["Float64"] * (len(lay) - 1)
+                    cols += [[st[key] for st in sts] for _, key in lay]
+                else:
+                    names.append(a["name"]); types.append("Float64"); cols.append([_var_final(fn, st) for st in sts])
             else:
                 raise NotImplementedError(fn)
         else:
-            if fn == "COUNT":
+            if fn in _VAR1 or fn in _VAR2:
+                lay = _var_layout(fn)
+                sv = [tab.cols[state_col + j] for j in range(len(lay))]; state_col += len(lay)
+                vals = []
+                for k in order:
+                    st = _var_state([])
+                    for i in groups[k]:
+                        st = _var_merge(st, {key: sv[j][i] for j, (_, key) in enumerate(lay)})
+                    vals.append(_var_final(fn, st))
+                names.append(a["name"]); types.append("Float64"); cols.append(vals)
+            elif fn == "COUNT":
                 sv = tab.cols[state_col]; state_col += 1
                 names.append(a["name"]); types.append("Int64"); cols.append([sum(sv[i] for i in groups[k]) for k in order])
             elif fn == "SUM":
@@ -428,6 +452,72 @@ def aggregate(tab, group_exprs, aggs, mode="Single", predicate=None):
             else:
                 raise NotImplementedError(fn)
     return Table(names, types, cols)
+
+
+# ---- VARIANCE / STDDEV / COVARIANCE / CORRELATION (datafusion.proto:639-645).
+# Restates DataFusion v34's running accumulators [UPSTREAM-KNOWLEDGE: VarianceAccumulator / CovarianceAccumulator /
+# CorrelationAccumulator]: rows are folded one at a time IN ROW ORDER with Welford updates, partial states merge with
+# Chan's formula.  Pinned by ballista/client/src/context.rs:845-937 (tests/test_oracle_pins.py): the KAT values
+# 6.000000000000001 / 5.250000000000001 / 2.4494897427831783 / 0.28571428571428586 / 0.21821789023599245 are
+# reproduced bit for bit only by this update order.
+_VAR1 = ("VARIANCE", "VAR", "VAR_SAMP", "VARIANCE_POP", "VAR_POP", "STDDEV", "STDDEV_SAMP", "STDDEV_POP")
+_VAR2 = ("COVARIANCE", "COVAR", "COVAR_SAMP", "COVARIANCE_POP", "COVAR_POP", "CORRELATION", "CORR")
+
+
+def _var_layout(fn):
+    """Partial-state columns in the reference's order: (suffix, state key)."""
+    if fn in _VAR1:
+        return [("count", "n"), ("mean", "m1"), ("m2", "v1")]
+    if fn in ("CORRELATION", "CORR"):
+        return [("count", "n"), ("mean1", "m1"), ("m2_1", "v1"), ("mean2", "m2"), ("m2_2", "v2"), ("algoConst", "al")]
+    return [("count", "n"), ("mean1", "m1"), ("mean2", "m2"), ("algoConst", "al")]
+
+
+def _var_state(pairs):
+    n, m1, m2, v1, v2, al = 0, 0.0, 0.0, 0.0, 0.0, 0.0
+    for x, y in pairs:
+        n += 1
+        d1 = x - m1; nm1 = d1 / n + m1
+        d2 = y - m2; nm2 = d2 / n + m2
+        v1 += d1 * (x - nm1)
+        v2 += d2 * (y - nm2)
+        al += d1 * (y - nm2)
+        m1, m2 = nm1, nm2
+    return {"n": n, "m1": m1, "m2": m2, "v1": v1, "v2": v2, "al": al}
+
+
+def _var_merge(a, b):
+    b = dict({"m2": 0.0, "v1": 0.0, "v2": 0.0, "al": 0.0}, **b)
+    if b["n"] == 0:
+        return a
+    if a["n"] == 0:
+        return dict(b)
+    n = a["n"] + b["n"]
+    d1 = a["m1"] - b["m1"]; d2 = a["m2"] - b["m2"]
+    return {"n": n,
+            "m1": a["m1"] * a["n"] / n + b["m1"] * b["n"] / n,
+            "m2": a["m2"] * a["n"] / n + b["m2"] * b["n"] / n,
+            "v1": a["v1"] + b["v1"] + d1 * d1 * a["n"] * b["n"] / n,
+            "v2": a["v2"] + b["v2"] + d2 * d2 * a["n"] * b["n"] / n,
+            "al": a["al"] + b["al"] + d1 * d2 * a["n"] * b["n"] / n}
+
+
+def _var_final(fn, st):
+    import math
+    n = st["n"]
+    pop = fn.endswith("_POP")
+    if fn in ("CORRELATION", "CORR"):
+        if n == 0:
+            return None
+        s1, s2 = math.sqrt(st["v1"] / n), math.sqrt(st["v2"] / n)
+        return 0.0 if s1 == 0 or s2 == 0 else st["al"] / n / s1 / s2
+    if n == 0 or (n == 1 and not pop):
+        return None
+    d = n if pop else n - 1
+    if fn in _VAR2:
+        return st["al"] / d
+    v = st["v1"] / d
+    return math.sqrt(v) if fn.startswith("STDDEV") else v
 
 
 def _sum_or_none(xs):

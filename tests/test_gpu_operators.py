@@ -199,6 +199,65 @@ def test_aggregate_kat_alltypes_plain(tc):
     assert got == [(0, 7, 28, 3.5, 8)]
 
 
+VAR_KATS = [("VARIANCE", None, "6.000000000000001"), ("VARIANCE_POP", None, "5.250000000000001"), ("STDDEV", None, "2.4494897427831783"),
+            ("COVARIANCE", "tinyint_col", "0.28571428571428586"), ("CORRELATION", "tinyint_col", "0.21821789023599245")]
+
+
+def test_variance_family_kat_alltypes_plain(tc):
+    """context.rs:845-937.  The reference folds rows one at a time (Welford), the device adds order-free power
+    sums: stated tolerance 4 ulp (|rel| <= 1e-15), not bit equality.  The oracle reproduces the KAT strings exactly."""
+    with pa.ipc.open_file(os.path.join(os.path.dirname(__file__), "golden", "alltypes_plain.arrow")) as f:
+        t = f.read_all().select(["id", "tinyint_col", "double_col"])
+    src = g.MemoryExec([t])
+    s = src.schema()
+    aggs = [dict({"fn": fn, "expr": col("id", s), "name": fn}, **({"expr2": col(y, s)} if y else {})) for fn, y, _ in VAR_KATS]
+    for lo in (0, 3):   # at most 12 accumulators per operator
+        got = dev_rows(tc, g.AggregateExec("Single", [], aggs[lo:lo + 3], src).execute(0, tc))[0]
+        for v, (_, _, kat) in zip(got, VAR_KATS[lo:lo + 3]):
+            assert abs(v - float(kat)) <= 1e-15 * float(kat), (v, kat)
+
+
+@pytest.mark.parametrize("nulls", [0.0, 0.2])
+def test_variance_family_grouped_two_phase(tc, nulls):
+    """Grouped VAR/STDDEV/COVAR/CORR over Float64, Int and Decimal arguments, Single and Partial->Final, vs the oracle's
+    sequential accumulators.  Tolerance 1e-9 relative to the spread of the data (power sums cancel where Welford does not)."""
+    parts = [rand_table(300 + i, 5_000, nulls) for i in range(2)]
+    src = g.MemoryExec([pa.concat_tables(parts)])
+    s = src.schema()
+    ot = O.Table.from_arrow(pa.concat_tables(parts))
+    groups = [(col("flag", s), "flag")]
+    sets = [[{"fn": "VARIANCE", "expr": col("f", s), "name": "v"}, {"fn": "STDDEV_POP", "expr": col("k32", s), "name": "sp"},
+             {"fn": "VARIANCE_POP", "expr": col("dec", s), "name": "vd"}],
+            [{"fn": "COVARIANCE", "expr": col("f", s), "expr2": col("k32", s), "name": "cv"}, {"fn": "COVARIANCE_POP", "expr": col("k32", s), "expr2": col("f", s), "name": "cp"}],
+            [{"fn": "CORRELATION", "expr": col("f", s), "expr2": col("dec", s), "name": "cr"}, {"fn": "STDDEV", "expr": col("f", s), "name": "sd"}]]
+    for aggs in sets:
+        exp = norm(ora_rows(O.aggregate(ot, groups, aggs, "Single")))
+        got = norm(dev_rows(tc, g.AggregateExec("Single", groups, aggs, src).execute(0, tc)))
+        close_rows(got, exp, rel=1e-9)
+        psrc = g.MemoryExec(parts)
+        partial = g.AggregateExec("Partial", groups, aggs, psrc)
+        states = [g.plan.materialize(tc, partial.execute(p, tc)).to_arrow(tc.ctx) for p in range(2)]
+        merged = g.MemoryExec([pa.concat_tables(states)])
+        fs = merged.schema()
+        final = g.AggregateExec("FinalPartitioned", [(col("flag", fs), "flag")], [dict(a, expr=None, expr2=None) for a in aggs], merged)
+        close_rows(norm(dev_rows(tc, final.execute(0, tc))), exp, rel=1e-9)
+        # state layout is the reference's: count, mean[, m2 | mean2, algoConst | m2_1, mean2, m2_2, algoConst]
+        ost = O.aggregate(O.Table.from_arrow(parts[0]), groups, aggs, "Partial")
+        assert states[0].schema.names == ost.names
+        close_rows(norm([tuple(r.values()) for r in states[0].to_pylist()]), norm(ora_rows(ost)), rel=1e-9)
+
+
+def test_variance_of_single_row_and_empty_groups(tc):
+    t = pa.table({"g": pa.array([1, 2, 2], pa.int64()), "x": pa.array([5.0, None, None], pa.float64())})
+    src = g.MemoryExec([t])
+    s = src.schema()
+    aggs = [{"fn": "VARIANCE", "expr": col("x", s), "name": "v"}, {"fn": "VARIANCE_POP", "expr": col("x", s), "name": "vp"},
+            {"fn": "STDDEV", "expr": col("x", s), "name": "sd"}, {"fn": "CORRELATION", "expr": col("x", s), "expr2": col("x", s), "name": "c"}]
+    got = norm(dev_rows(tc, g.AggregateExec("Single", [(col("g", s), "g")], aggs, src).execute(0, tc)))
+    assert got == [(1, None, 0.0, None, 0.0), (2, None, None, None, None)]
+    assert got == norm(ora_rows(O.aggregate(O.Table.from_arrow(t), [(col("g", s), "g")], aggs, "Single")))
+
+
 # ------------------------------------------------------------------------------------ join
 def pairs_of(tc, view, nl):
     """(left_row | None, right_row | None) pairs of a join view built over tables that carry a row-id column."""
@@ -387,3 +446,63 @@ def test_shuffle_writer_round_trip(tc, tmp_path):
     with pytest.raises(g.GpuqError):
         g.DefaultExecutionEngine().create_query_stage_exec("j", 1, src, str(tmp_path))
     assert stage.collect_plan_metrics()[0]["output_rows"] > 0
+
+
+# ------------------------------------------------------------------------------------ fan-in / merge / limit / union
+@pytest.mark.parametrize("nulls", [0.0, 0.2])
+def test_coalesce_tasks_unordered_and_ordered(tc, nulls):
+    """CoalesceTasksExec (coalesce_tasks.rs:130-229): unordered = concatenation of the listed partitions; with order_by =
+    k-way merge of ALL input partitions.  Sizes are chosen so that piece boundaries fall inside bitmap words."""
+    parts = [rand_table(500 + i, n, nulls) for i, n in enumerate([1000, 0, 77, 4099, 1])]
+    src = g.MemoryExec(parts)
+    s = src.schema()
+    ots = [O.Table.from_arrow(p) for p in parts]
+    got = dev_rows(tc, g.CoalesceTasksExec(src, [0, 1, 2, 3, 4]).execute(0, tc))
+    exp = sum((ora_rows(o) for o in ots), [])
+    close_rows(got, exp, rel=0.0)
+    got = dev_rows(tc, g.CoalesceTasksExec(src, [3, 2]).execute(0, tc))
+    close_rows(got, ora_rows(ots[3]) + ora_rows(ots[2]), rel=0.0)
+    assert dev_rows(tc, g.CoalesceTasksExec(src, [2]).execute(0, tc)) == dev_rows(tc, src.execute(2, tc))
+    assert dev_rows(tc, g.CoalescePartitionsExec(src).execute(0, tc)) == dev_rows(tc, g.CoalesceTasksExec(src, [0, 1, 2, 3, 4]).execute(0, tc))
+    # ordered: every partition sorted by (flag asc, dec desc), then merged; ties resolved by (partition, row) order
+    order = [{"expr": col("flag", s), "asc": True, "nulls_first": False}, {"expr": col("dec", s), "asc": False, "nulls_first": True}]
+    sorted_src = g.SortExec(order, src, preserve_partitioning=True)
+    merged = g.CoalesceTasksExec(sorted_src, [0, 3], order_by=order)      # the reference merges all partitions here
+    got = dev_rows(tc, merged.execute(0, tc))
+    cat = O.Table(ots[0].names, ots[0].types, [sum((o.cols[i] for o in ots), []) for i in range(len(ots[0].names))])
+    perm = O.sort_perm(cat, order)
+    # concatenation of per-partition sorted runs followed by a stable sort == stable sort of the sorted runs
+    runs = []
+    for o in ots:
+        pi = O.sort_perm(o, order)
+        runs += [tuple(o.cols[c][i] for c in range(len(o.names))) for i in pi]
+    rt = O.Table(ots[0].names, ots[0].types, [[r[c] for r in runs] for c in range(len(ots[0].names))])
+    exp = [runs[i] for i in O.sort_perm(rt, order)]
+    close_rows(got, exp, rel=0.0)
+    assert len(perm) == len(got)
+    got2 = dev_rows(tc, g.SortPreservingMergeExec(order, sorted_src, fetch=10).execute(0, tc))
+    close_rows(got2, exp[:10], rel=0.0)
+
+
+def test_limits_and_union_kat(tc):
+    t = rand_table(9, 1000, 0.1)
+    src = g.MemoryExec([t, rand_table(10, 5, 0.0)])
+    rows0 = dev_rows(tc, src.execute(0, tc))
+    assert dev_rows(tc, g.LocalLimitExec(src, 7).execute(0, tc)) == rows0[:7]
+    assert len(dev_rows(tc, g.LocalLimitExec(src, 7).execute(1, tc))) == 5
+    one = g.CoalescePartitionsExec(src)
+    assert dev_rows(tc, g.GlobalLimitExec(one, skip=998, fetch=4).execute(0, tc)) == (rows0 + dev_rows(tc, src.execute(1, tc)))[998:1002]
+    assert dev_rows(tc, g.GlobalLimitExec(one, skip=2000, fetch=4).execute(0, tc)) == []
+    # over a view (filter output) as well
+    s = src.schema()
+    f = g.FilterExec(binary(col("k32", s), Op.Gt, lit(0, "Int32")), src)
+    fr = dev_rows(tc, f.execute(0, tc))
+    assert dev_rows(tc, g.GlobalLimitExec(g.CoalesceTasksExec(f, [0]), skip=3, fetch=5).execute(0, tc)) == fr[3:8]
+    # context.rs:691-733: "SELECT 1 as NUMBER union SELECT 1 as NUMBER" -> one row; "union all" -> two rows
+    a = pa.table({"NUMBER": pa.array([1], pa.int64())})
+    u = g.UnionExec([g.MemoryExec([a]), g.MemoryExec([a])])
+    assert u.output_partition_count() == 2
+    assert dev_rows(tc, g.CoalescePartitionsExec(u).execute(0, tc)) == [(1,), (1,)]
+    us = u.schema()
+    dedup = g.AggregateExec("Single", [(col("NUMBER", us), "NUMBER")], [], g.CoalescePartitionsExec(u))
+    assert dev_rows(tc, dedup.execute(0, tc)) == [(1,)]

@@ -14,7 +14,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 def _alltypes():
     with pa.ipc.open_file(os.path.join(GOLD, "alltypes_plain.arrow")) as f:
-        return O.Table.from_arrow(f.read_all().select(["id", "bigint_col", "double_col", "int_col"]))
+        return O.Table.from_arrow(f.read_all().select(["id", "bigint_col", "double_col", "int_col", "tinyint_col"]))
 
 
 def col(n):
@@ -29,6 +29,30 @@ def test_alltypes_plain_known_answers():
     # context.rs: MIN(test.id)=0  MAX=7  SUM=28  AVG=3.5  COUNT=8
     assert out.rows() == [(0, 7, 28, 3.5, 8)]
     assert out.types == ["Int32", "Int32", "Int64", "Float64", "Int64"]
+
+
+def test_alltypes_plain_variance_family_known_answers():
+    """context.rs:845-937: VAR / VAR_POP / VAR_SAMP / STDDEV / STDDEV_SAMP / COVAR / CORR, printed with Rust's
+    shortest round-trip formatting, i.e. the exact f64."""
+    t = _alltypes()
+    one = lambda fn, **kw: O.aggregate(t, [], [dict({"fn": fn, "expr": col("id"), "name": "v"}, **kw)], "Single").rows()[0][0]
+    assert repr(one("VARIANCE")) == "6.000000000000001"
+    assert repr(one("VAR_SAMP")) == "6.000000000000001"
+    assert repr(one("VARIANCE_POP")) == "5.250000000000001"
+    assert repr(one("STDDEV")) == "2.4494897427831783"
+    assert repr(one("STDDEV_SAMP")) == "2.4494897427831783"
+    assert repr(one("COVARIANCE", expr2=col("tinyint_col"))) == "0.28571428571428586"
+    assert repr(one("CORRELATION", expr2=col("tinyint_col"))) == "0.21821789023599245"
+
+
+def test_variance_two_phase_merges_to_single_within_rounding():
+    t = _alltypes()
+    for fn, kw in (("VARIANCE", {}), ("STDDEV_POP", {}), ("COVARIANCE_POP", {"expr2": col("tinyint_col")}), ("CORRELATION", {"expr2": col("tinyint_col")})):
+        aggs = [dict({"fn": fn, "expr": col("id"), "name": "v"}, **kw)]
+        single = O.aggregate(t, [], aggs, "Single").rows()[0][0]
+        part = O.aggregate(t, [(col("int_col"), "g")], aggs, "Partial")       # 2 groups -> 2 partial states
+        final = O.aggregate(part.select(part.names[1:]) if hasattr(part, "select") else O.Table(part.names[1:], part.types[1:], part.cols[1:]), [], aggs, "Final").rows()[0][0]
+        assert abs(final - single) <= 1e-12 * max(1.0, abs(single)), (fn, final, single)
 
 
 def test_two_phase_equals_single():
