@@ -505,6 +505,16 @@ OutSpec make_outspec(const CompiledProgram& cp, gpuq_column* outs, int n_outs, c
   return O;
 }
 
+// the LDS aggregate is specialised on its whole shape (keys, accumulators, group capacity)
+std::string agg_tiny_spec(const gpuq_op* op, int gmax) {
+  const int nk = op->agg.n_keys, na = op->agg.n_accs;
+  std::string spec = "#define GPUQ_JIT_SPEC 1\nconstexpr int JIT_NKEYS = " + std::to_string(nk) + ", JIT_NACCS = " + std::to_string(na) +
+                     ", JIT_GMAX = " + std::to_string(gmax) + ", JIT_NKC = " + std::to_string(nk > 0 ? nk : 1) + ";\n";
+  auto arr = [](const char* name, const int32_t* v, int n_) { std::string r = std::string("constexpr int ") + name + "[" + std::to_string(n_) + "] = {";
+                                                             for (int i = 0; i < n_; ++i) r += std::to_string(v[i]) + (i + 1 < n_ ? "," : ""); return r + "};\n"; };
+  return spec + arr("JIT_KEY_REG", op->agg.key_reg, MAX_KEYS) + arr("JIT_ACC_KIND", op->agg.acc_kind, MAX_ACCS) + arr("JIT_ACC_REG", op->agg.acc_reg, MAX_ACCS);
+}
+
 void check_ctx(gpuq_ctx* c) { if (!c) throw std::runtime_error("ctx is NULL"); HIPCHECK(hipSetDevice(c->device)); }
 
 }  // namespace
@@ -689,7 +699,9 @@ int gpuq_compile_jit_source(const char* json, int kernel_id, char* buf, size_t c
     g_upload = false;
     compile_op(op, d);
     g_upload = true;
-    const std::string src = jit_full_source(op->prog.jit_src, kernel_id);
+    std::string eval = op->prog.jit_src;
+    if (kernel_id == 3 && op->kind == K_AGG) eval += agg_tiny_spec(op, (int)d.get_i64("jit_gmax", 4));   // what the run-time path appends
+    const std::string src = jit_full_source(eval, kernel_id);
     if (src.size() + 1 > cap) throw Capacity("source needs " + std::to_string(src.size() + 1) + " bytes");
     std::memcpy(buf, src.c_str(), src.size() + 1);
   });
@@ -796,11 +808,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
           alloc_raw(64);
           reset_flags(op, s);
           // the LDS aggregate is specialised on its whole shape (keys, accumulators, group capacity)
-          std::string spec = "#define GPUQ_JIT_SPEC 1\nconstexpr int JIT_NKEYS = " + std::to_string(nk) + ", JIT_NACCS = " + std::to_string(na) +
-                             ", JIT_GMAX = " + std::to_string(gmax) + ", JIT_NKC = " + std::to_string(nk > 0 ? nk : 1) + ";\n";
-          auto arr = [](const char* name, const int32_t* v, int n_) { std::string r = std::string("constexpr int ") + name + "[" + std::to_string(n_) + "] = {";
-                                                                     for (int i = 0; i < n_; ++i) r += std::to_string(v[i]) + (i + 1 < n_ ? "," : ""); return r + "};\n"; };
-          spec += arr("JIT_KEY_REG", op->agg.key_reg, MAX_KEYS) + arr("JIT_ACC_KIND", op->agg.acc_kind, MAX_ACCS) + arr("JIT_ACC_REG", op->agg.acc_reg, MAX_ACCS);
+          const std::string spec = agg_tiny_spec(op, gmax);
           { JitScope js(op, op->prog, 3, n, spec); ProfScope ps(op, s); launch_agg_tiny(s, P, n, op->agg, gmax, wsp, raw); }
           HIPCHECK(hipGetLastError());
           uint32_t fw[4] = {0, 0, 0, 0};

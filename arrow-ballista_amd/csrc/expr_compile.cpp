@@ -476,37 +476,96 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
   auto is_b = [](const Node* n) { return n->type.id == T_BOOL; };
   auto wide = [&](const Node* n) { return !is_str(n) && !is_f(n) && !is_b(n) && n->bits > 64; };
   auto ctype = [&](const Node* n) { return is_f(n) ? std::string("double") : (is_b(n) ? std::string("bool") : (wide(n) ? std::string("i128") : std::string("i64"))); };
-  S += "__device__ __forceinline__ bool gpuq_jit_eval(const DevProgram& P, i64 pos, GPUQ_REGS_PARAM) {\n";
+  // Three stages so that a sink can software-pipeline rows (k_agg_tiny_body does): gpuq_jit_pre issues the loads other
+  // loads depend on (index vectors, Utf8 offsets of directly addressed columns), gpuq_jit_load issues every remaining
+  // first-touch load into a JitRaw record without looking at any loaded value, gpuq_jit_compute is pure arithmetic
+  // (plus the bytes of strings longer than one byte).  gpuq_jit_eval is the three in sequence.
+  std::string SP, SLD, FP, FR;       // stage bodies / struct fields
+  auto LP = [&](const std::string& l) { SP += "  " + l + "\n"; };
+  auto LL = [&](const std::string& l) { SLD += "  " + l + "\n"; };
+  auto fieldP = [&](const std::string& ty, const std::string& nm) { FP += "  " + ty + " " + nm + ";\n"; };
+  std::string touch;                 // every loaded record field is read once, unconditionally, at the top of the compute stage
+  auto fieldR = [&](const std::string& ty, const std::string& nm) {
+    FR += "  " + ty + " " + nm + ";\n";
+    if (ty == "ulonglong2") touch += "  asm volatile(\"\" :: \"v\"(w." + nm + ".x), \"v\"(w." + nm + ".y));\n";
+    else if (ty != "bool") touch += "  asm volatile(\"\" :: \"v\"(w." + nm + "));\n";
+  };
   // ---- rows
   bool via_used[MAX_VIA + 1] = {false, false, false, false};
   for (size_t c = 0; c < C.col_field.size(); ++c) via_used[schema_.fields[C.col_field[c]].side] = true;
-  L("const uint32_t row0 = (uint32_t)pos;");
-  for (int k = 1; k <= MAX_VIA; ++k) if (via_used[k]) L("const uint32_t row" + std::to_string(k) + " = P.via[" + std::to_string(k - 1) + "][pos];");
-  // ---- phase A: loads only
+  LP("const uint32_t row0 = (uint32_t)pos; (void)row0;");
+  LL("const uint32_t row0 = (uint32_t)pos; (void)row0;");
+  L("const uint32_t row0 = (uint32_t)pos; (void)row0;");
+  for (int k = 1; k <= MAX_VIA; ++k) if (via_used[k]) {
+    const std::string ks = std::to_string(k);
+    fieldP("uint32_t", "row" + ks);
+    LP("q.row" + ks + " = P.via[" + std::to_string(k - 1) + "][pos];");
+    LL("const uint32_t row" + ks + " = q.row" + ks + ";");
+  }
+  // 16-byte columns of which only the low 8 bytes are read (Decimal128 whose precision bounds |v| < 2^63, Float64 / Bool in raw cells)
+  std::vector<bool> narrow128(C.col_field.size(), false);
+  for (size_t c = 0; c < C.col_field.size(); ++c) {
+    const Field& f = schema_.fields[C.col_field[c]];
+    const int cls = f.raw128 ? (int)CC_I128 : col_class_for(f.type);
+    if (cls != CC_I128 || f.type.id == T_UTF8) continue;
+    bool all_narrow = true, seen = false;
+    for (Node* n : order) if (n->kind == Node::COL && n->col == C.col_field[c]) { seen = true; if (wide(n)) all_narrow = false; }
+    narrow128[c] = seen && all_narrow;
+  }
+  // ---- loads
   for (size_t c = 0; c < C.col_field.size(); ++c) {
     const Field& f = schema_.fields[C.col_field[c]];
     const std::string cs = std::to_string(c), row = "row" + std::to_string(f.side);
-    L("const DevCol& col" + cs + " = P.cols[" + cs + "];");
-    if (f.side > 0) { L("const bool ok" + cs + " = " + row + " != NULL_ROW;"); L("const uint32_t r" + cs + " = ok" + cs + " ? " + row + " : 0u;"); }
-    else L("const uint32_t r" + cs + " = " + row + ";");
-    if (f.nullable) L("const uint32_t vb" + cs + " = (col" + cs + ".validity ? col" + cs + ".validity : (const uint8_t*)P.code)[col" + cs + ".validity ? (r" + cs + " >> 3) : 0u];");
+    LL("const DevCol& col" + cs + " = P.cols[" + cs + "];");
+    L("const DevCol& col" + cs + " = P.cols[" + cs + "]; (void)col" + cs + ";");
+    if (f.side > 0) {
+      LL("const bool ok" + cs + " = " + row + " != NULL_ROW;"); LL("const uint32_t r" + cs + " = ok" + cs + " ? " + row + " : 0u;");
+      fieldR("bool", "ok" + cs); LL("w.ok" + cs + " = ok" + cs + ";"); L("const bool ok" + cs + " = w.ok" + cs + ";");
+      fieldR("uint32_t", "r" + cs); LL("w.r" + cs + " = r" + cs + ";"); L("const uint32_t r" + cs + " = w.r" + cs + "; (void)r" + cs + ";");
+    } else { LL("const uint32_t r" + cs + " = row0;"); L("const uint32_t r" + cs + " = row0; (void)r" + cs + ";"); }
+    if (f.nullable) {
+      LL("w.vb" + cs + " = (col" + cs + ".validity ? col" + cs + ".validity : (const uint8_t*)P.code)[col" + cs + ".validity ? (r" + cs + " >> 3) : 0u];");
+      fieldR("uint32_t", "vb" + cs); L("const uint32_t vb" + cs + " = w.vb" + cs + ";");
+    }
     const int cls = f.raw128 ? (int)CC_I128 : col_class_for(f.type);
+    const std::string A = "a" + cs;
     switch (cls) {
-      case CC_I32: case CC_U32: L("const uint32_t a" + cs + " = ((const uint32_t*)col" + cs + ".data)[r" + cs + "];"); break;
-      case CC_I64: L("const u64 a" + cs + " = ((const u64*)col" + cs + ".data)[r" + cs + "];"); break;
-      case CC_I128: L("const ulonglong2 a" + cs + " = ((const ulonglong2*)col" + cs + ".data)[r" + cs + "];"); break;
-      case CC_BIT: L("const uint32_t a" + cs + " = ((const uint8_t*)col" + cs + ".data)[r" + cs + " >> 3];"); break;
-      case CC_STR: L("const int32_t o" + cs + "a = col" + cs + ".offsets[r" + cs + "], o" + cs + "b = col" + cs + ".offsets[r" + cs + " + 1];"); break;
+      case CC_I32: case CC_U32: fieldR("uint32_t", A); LL("w." + A + " = ((const uint32_t*)col" + cs + ".data)[r" + cs + "];"); L("const uint32_t " + A + " = w." + A + ";"); break;
+      case CC_I64: fieldR("u64", A); LL("w." + A + " = ((const u64*)col" + cs + ".data)[r" + cs + "];"); L("const u64 " + A + " = w." + A + ";"); break;
+      case CC_I128:
+        if (narrow128[c]) {   // declared precision fits 64 bits: only the low half of the 16-byte value is ever used
+          fieldR("u64", A); LL("w." + A + " = ((const u64*)col" + cs + ".data)[2 * (size_t)r" + cs + "];"); L("const ulonglong2 " + A + " = make_ulonglong2(w." + A + ", 0ull);");
+        } else { fieldR("ulonglong2", A); LL("w." + A + " = ((const ulonglong2*)col" + cs + ".data)[r" + cs + "];"); L("const ulonglong2 " + A + " = w." + A + ";"); }
+        break;
+      case CC_BIT: fieldR("uint32_t", A); LL("w." + A + " = ((const uint8_t*)col" + cs + ".data)[r" + cs + " >> 3];"); L("const uint32_t " + A + " = w." + A + ";"); break;
+      case CC_STR: {
+        const std::string oa = "o" + cs + "a", ob = "o" + cs + "b";
+        fieldR("int32_t", oa); fieldR("int32_t", ob);
+        if (f.side == 0) {
+          // offsets one stage early, first byte in the load stage
+          fieldP("int32_t", oa); fieldP("int32_t", ob);
+          LP("q." + oa + " = P.cols[" + cs + "].offsets[row0]; q." + ob + " = P.cols[" + cs + "].offsets[row0 + 1];");
+          LL("w." + oa + " = q." + oa + "; w." + ob + " = q." + ob + ";");
+          fieldR("uint32_t", "fb" + cs);
+          // unconditional load through a selected address: a branch here would make the wave wait for the byte at once
+          LL("w.fb" + cs + " = (uint32_t)*((q." + ob + " > q." + oa + ") ? (const uint8_t*)col" + cs + ".data + q." + oa + " : (const uint8_t*)P.code);");
+        } else {
+          LL("w." + oa + " = col" + cs + ".offsets[r" + cs + "]; w." + ob + " = col" + cs + ".offsets[r" + cs + " + 1];");
+        }
+        L("const int32_t " + oa + " = w." + oa + ", " + ob + " = w." + ob + ";");
+        break;
+      }
     }
   }
-  // ---- phase B1: first byte of every string column
+  // ---- first byte of every string column
   for (size_t c = 0; c < C.col_field.size(); ++c) {
     const Field& f = schema_.fields[C.col_field[c]];
     if (f.raw128 || f.type.id != T_UTF8) continue;
     const std::string cs = std::to_string(c);
     L("const int32_t len" + cs + " = o" + cs + "b - o" + cs + "a;");
     L("const uint8_t* sp" + cs + " = (const uint8_t*)col" + cs + ".data + o" + cs + "a;");
-    L("const u64 fb" + cs + " = (len" + cs + " > 0) ? (u64)sp" + cs + "[0] : 0ull;");
+    if (f.side == 0) L("const u64 fb" + cs + " = (len" + cs + " > 0) ? (u64)w.fb" + cs + " : 0ull;");
+    else L("const u64 fb" + cs + " = (len" + cs + " > 0) ? (u64)sp" + cs + "[0] : 0ull;");
   }
   // ---- phase B2: typed column values
   std::map<int, std::string> col_null;
@@ -680,8 +739,16 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
   }
   L("rnulls = nm;");
   L("return true;");
-  S += "}\n";
-  return S;
+  std::string R = "struct JitPre {\n" + FP + "  int32_t pad_;\n};\nstruct JitRaw {\n" + FR + "  int32_t pad_;\n};\n";
+  R += "__device__ __forceinline__ void gpuq_jit_pre(const DevProgram& P, i64 pos, JitPre& q) {\n" + SP + "  (void)P; (void)q;\n}\n";
+  R += "__device__ __forceinline__ void gpuq_jit_load(const DevProgram& P, i64 pos, const JitPre& q, JitRaw& w) {\n" + SLD + "  (void)q; (void)w;\n}\n";
+  // The empty asm statements make the wave wait for the whole record at one point that every path crosses; without them a
+  // field first used under a branch (predicate, inactive tail lanes) stays "pending" on the bypass path and the next loop
+  // iteration has to drain all loads before it may reuse the registers.
+  R += "__device__ __forceinline__ bool gpuq_jit_compute(const DevProgram& P, i64 pos, const JitRaw& w, GPUQ_REGS_PARAM) {\n" + touch + S + "}\n";
+  R += "__device__ __forceinline__ bool gpuq_jit_eval(const DevProgram& P, i64 pos, GPUQ_REGS_PARAM) {\n"
+       "  JitPre q; gpuq_jit_pre(P, pos, q);\n  JitRaw w; gpuq_jit_load(P, pos, q, w);\n  return gpuq_jit_compute(P, pos, w, GPUQ_REGS);\n}\n";
+  return R;
 }
 
 }  // namespace gpuq

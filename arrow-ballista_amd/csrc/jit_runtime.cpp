@@ -63,8 +63,22 @@ std::map<std::string, JitFn> g_cache;
 
 bool jit_available() { return rtc().ok; }
 
+// GPUQ_JIT_DEFINES="A=1;B=2" (environment, tuning experiments): extra #defines in front of every JIT translation unit
+static std::string env_defines() {
+  const char* e = std::getenv("GPUQ_JIT_DEFINES");
+  std::string r, tok;
+  if (!e) return r;
+  for (const char* p = e;; ++p) {
+    if (*p == ';' || *p == 0) {
+      if (!tok.empty()) { const size_t eq = tok.find('='); r += "#define " + (eq == std::string::npos ? tok + " 1" : tok.substr(0, eq) + " " + tok.substr(eq + 1)) + "\n"; }
+      tok.clear(); if (!*p) break;
+    } else tok += *p;
+  }
+  return r;
+}
+
 std::string jit_full_source(const std::string& eval_src, int kernel_id) {
-  return "#define GPUQ_JIT 1\n#define GPUQ_JIT_KERNEL " + std::to_string(kernel_id) +
+  return env_defines() + "#define GPUQ_JIT 1\n#define GPUQ_JIT_KERNEL " + std::to_string(kernel_id) +
          "\n#include \"gpuq_kernels.h\"\nnamespace gpuq {\n" + eval_src + "}\n#include \"" + file_of(kernel_id) + "\"\n";
 }
 

@@ -216,6 +216,23 @@ static size_t tiny_partial_bytes(int gmax, int n_keys, int n_accs) {
   return 8 + (size_t)gmax * (n_keys > 0 ? n_keys : 1) * 16 + (size_t)gmax * 4 + ((gmax & 1) ? 4 : 0) + (size_t)gmax * n_accs * 16;
 }
 
+#ifdef GPUQ_MARKERS
+#define GPUQ_MARK(name) asm volatile("; gpuq-mark " name)
+#else
+#define GPUQ_MARK(name)
+#endif
+
+// LDS words shared between the waves of a block.  Relaxed workgroup-scope atomics compile to plain ds_read / ds_write;
+// a volatile generic pointer compiles to flat_load sc0 sc1 followed by s_waitcnt vmcnt(0), which drains every global load
+// the wave has in flight (and with it the row pipeline below).  The fences are restricted to the local address space for
+// the same reason: ordering between LDS accesses only needs lgkmcnt.
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ u64 lds_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
+#define LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+
 template <int MAXC>
 __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n, const AggSpec A, const int gmax_arg,
                                                     char* __restrict__ workspace, const size_t partial_stride) {
@@ -248,9 +265,6 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
   if (tid == 0) { *L.dict_n = (n_keys == 0) ? 1u : 0u; *L.lock = 0; L.dnulls[0] = 0; }
   __syncthreads();
 
-  volatile uint32_t* vn = L.dict_n;
-  volatile u64* vkeys = L.dkeys;
-  volatile uint32_t* vnulls = L.dnulls;
 
 #ifdef GPUQ_JIT_SPEC
   u64 dc_lo[JIT_GMAX][JIT_NKC], dc_hi[JIT_GMAX][JIT_NKC]; uint32_t dc_nl[JIT_GMAX]; uint32_t cached_n = 0;
@@ -260,11 +274,9 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
     for (int k = 0; k < JIT_NKC; ++k) { dc_lo[g][k] = 0; dc_hi[g][k] = 0; } }
 #endif
   const i64 nwords = (n + 63) >> 6;
-  for (i64 w = (i64)blockIdx.x * WAVES + wave_id(); w < nwords; w += (i64)gridDim.x * WAVES) {
-    const i64 pos = (w << 6) + lane_id();
-    bool active = pos < n;
-    GPUQ_REGS_DECL;
-    if (active) active = GPUQ_EVAL(MAXC, P, pos);
+  // one evaluated row -> its group -> its accumulators
+  auto accumulate_row = [&](bool active, GPUQ_REGS_PARAM) __attribute__((always_inline)) {
+    GPUQ_MARK("key");
     // group key (explicit scalars: a small array here ends up in scratch once the loader's slots are live)
     u64 k0lo = 0, k0hi = 0, k1lo = 0, k1hi = 0, k2lo = 0, k2hi = 0, k3lo = 0, k3hi = 0; uint32_t knull = 0;
 #define GPUQ_KLO(k) ((k) == 0 ? k0lo : (k) == 1 ? k1lo : (k) == 2 ? k2lo : k3lo)
@@ -279,12 +291,13 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
         knull |= (uint32_t)isn << k;
       }
     }
+    GPUQ_MARK("lookup");
     int gid = -1;
     uint32_t seen = 0;
     for (;;) {
       // lock-free lookup over the dictionary entries published so far
-      const uint32_t nd = *vn;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const uint32_t nd = lds_ld(L.dict_n);
+      LDS_ACQUIRE();
 #ifdef GPUQ_JIT_SPEC
       // dictionary entries live in (wave-uniform) registers and are refreshed only when the block's
       // dictionary grew: the common row pays one LDS word (dict_n), not 2*n_keys*groups LDS reads
@@ -292,10 +305,10 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
 #pragma unroll
         for (int g = 0; g < JIT_GMAX; ++g) {
           if ((uint32_t)g >= cached_n && (uint32_t)g < nd) {
-            dc_nl[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)vnulls[g]);
+            dc_nl[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ld(&L.dnulls[g]));
 #pragma unroll
             for (int k = 0; k < JIT_NKC; ++k) {
-              if (k < n_keys) { dc_lo[g][k] = uniform_u64(vkeys[(g * kstride + k) * 2]); dc_hi[g][k] = uniform_u64(vkeys[(g * kstride + k) * 2 + 1]); }
+              if (k < n_keys) { dc_lo[g][k] = uniform_u64(lds_ld(&L.dkeys[(g * kstride + k) * 2])); dc_hi[g][k] = uniform_u64(lds_ld(&L.dkeys[(g * kstride + k) * 2 + 1])); }
             }
           }
         }
@@ -315,10 +328,10 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
 #else
       if (active && gid < 0) {
         for (uint32_t g = seen; g < nd; ++g) {
-          bool eq = vnulls[g] == knull;
+          bool eq = lds_ld(&L.dnulls[g]) == knull;
 #pragma unroll
           for (int k = 0; k < MAX_KEYS; ++k)
-            if (k < n_keys) eq = eq && vkeys[(g * kstride + k) * 2] == GPUQ_KLO(k) && vkeys[(g * kstride + k) * 2 + 1] == GPUQ_KHI(k);
+            if (k < n_keys) eq = eq && lds_ld(&L.dkeys[(g * kstride + k) * 2]) == GPUQ_KLO(k) && lds_ld(&L.dkeys[(g * kstride + k) * 2 + 1]) == GPUQ_KHI(k);
           if (eq) gid = (int)g;
         }
       }
@@ -329,24 +342,24 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
       const int leader = __ffsll((long long)need) - 1;
       if (lane_id() == leader) {
         while (atomicCAS(L.lock, 0u, 1u) != 0u) {}
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint32_t n2 = *vn;
+        LDS_ACQUIRE();
+        const uint32_t n2 = lds_ld(L.dict_n);
         int found = -1;
         for (uint32_t g = nd; g < n2; ++g) {
-          bool eq = vnulls[g] == knull;
+          bool eq = lds_ld(&L.dnulls[g]) == knull;
 #pragma unroll
           for (int k = 0; k < MAX_KEYS; ++k)
-            if (k < n_keys) eq = eq && vkeys[(g * kstride + k) * 2] == GPUQ_KLO(k) && vkeys[(g * kstride + k) * 2 + 1] == GPUQ_KHI(k);
+            if (k < n_keys) eq = eq && lds_ld(&L.dkeys[(g * kstride + k) * 2]) == GPUQ_KLO(k) && lds_ld(&L.dkeys[(g * kstride + k) * 2 + 1]) == GPUQ_KHI(k);
           if (eq) found = (int)g;
         }
         if (found < 0) {
           if (n2 < (uint32_t)gmax) {
 #pragma unroll
             for (int k = 0; k < MAX_KEYS; ++k)
-              if (k < n_keys) { vkeys[(n2 * kstride + k) * 2] = GPUQ_KLO(k); vkeys[(n2 * kstride + k) * 2 + 1] = GPUQ_KHI(k); }
-            vnulls[n2] = knull;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            *vn = n2 + 1;
+              if (k < n_keys) { lds_st(&L.dkeys[(n2 * kstride + k) * 2], GPUQ_KLO(k)); lds_st(&L.dkeys[(n2 * kstride + k) * 2 + 1], GPUQ_KHI(k)); }
+            lds_st(&L.dnulls[n2], knull);
+            LDS_RELEASE();
+            lds_st(L.dict_n, n2 + 1);
             found = (int)n2;
           } else {
             atomicOr(P.flags, FLAG_GROUP_OVERFLOW);
@@ -354,11 +367,12 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
           }
         }
         gid = found;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        LDS_RELEASE();
         atomicExch(L.lock, 0u);
       }
       // other lanes with the same key find it in the next lookup round
     }
+    GPUQ_MARK("accumulate");
     // accumulate
     if (active) {
       SPEC_UNROLL
@@ -403,7 +417,72 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
         }
       }
     }
+  };
+#ifdef GPUQ_JIT
+  // Software pipeline over rows.  A wave step covers PU consecutive 64-row words (PU rows per lane).  While the rows of
+  // step t are evaluated and accumulated, the column loads of step t+1 ("records") and the dependent-load roots (index
+  // vectors, Utf8 offsets) of step t+2 are in flight.  The LDS footprint limits a CU to 3 waves per SIMD, so the bytes
+  // in flight have to come from the rows a wave keeps outstanding, not from occupancy.
+  // Two record sets alternate and the loop is unrolled twice, so every record keeps its registers: rotating records by
+  // assignment would read registers whose loads are still in flight.
+#ifndef GPUQ_PIPE_ROWS
+#define GPUQ_PIPE_ROWS 1
+#endif
+  constexpr int PU = GPUQ_PIPE_ROWS;
+  const i64 nsteps = (nwords + PU - 1) / PU;
+  const i64 tstride = (i64)gridDim.x * WAVES;
+  i64 t = (i64)blockIdx.x * WAVES + wave_id();
+  // Rows past the end are clamped to the last row (loaded, evaluated, never accumulated): unconditional loads keep the
+  // stages free of exec-masked regions, which lets the compiler leave them in flight.
+  const i64 last = n - 1;
+  auto row_of = [&](i64 step, int u) { return ((step * PU + u) << 6) + lane_id(); };
+  JitRaw raws[2][PU]; JitPre pres[2][PU];
+#pragma unroll
+  for (int u = 0; u < PU; ++u) {
+    pres[0][u] = JitPre{}; pres[1][u] = JitPre{}; raws[0][u] = JitRaw{}; raws[1][u] = JitRaw{};
+    if (n > 0) {
+      const i64 p0 = row_of(t, u), p1 = row_of(t + tstride, u);
+      gpuq_jit_pre(P, p0 < n ? p0 : last, pres[0][u]);
+      gpuq_jit_pre(P, p1 < n ? p1 : last, pres[1][u]);
+    }
   }
+#pragma unroll
+  for (int u = 0; u < PU; ++u) if (n > 0) { const i64 p0 = row_of(t, u); gpuq_jit_load(P, p0 < n ? p0 : last, pres[0][u], raws[0][u]); }
+  while (t < nsteps) {
+#pragma unroll
+    for (int pj = 0; pj < 2; ++pj) {
+      // leaving through a jump (not by skipping the second half) keeps "which loads are pending" exact on the back edge
+      if (t >= nsteps) goto pipeline_done;
+      // issue order matters: vmcnt retires in order, so the roots of step t+2 go out first (their slot, the roots of step
+      // t, is dead), then the records of step t+1, which only wait for roots issued one step earlier
+      GPUQ_MARK("issue");
+#pragma unroll
+      for (int u = 0; u < PU; ++u) { const i64 pp = row_of(t + 2 * tstride, u); gpuq_jit_pre(P, pp < n ? pp : last, pres[pj][u]); }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) { const i64 pl = row_of(t + tstride, u); gpuq_jit_load(P, pl < n ? pl : last, pres[pj ^ 1][u], raws[pj ^ 1][u]); }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const i64 pos = row_of(t, u);
+        GPUQ_REGS_DECL;
+        // evaluated on every lane (clamped rows are real rows) so that the record is consumed on all paths
+        GPUQ_MARK("compute");
+        const bool pass = gpuq_jit_compute(P, pos < n ? pos : last, raws[pj][u], GPUQ_REGS);
+        accumulate_row(pos < n && pass, GPUQ_REGS);
+      }
+      GPUQ_MARK("end");
+      t += tstride;
+    }
+  }
+pipeline_done:
+#else
+  for (i64 w = (i64)blockIdx.x * WAVES + wave_id(); w < nwords; w += (i64)gridDim.x * WAVES) {
+    const i64 pos = (w << 6) + lane_id();
+    bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
+    accumulate_row(active, GPUQ_REGS);
+  }
+#endif
   __syncthreads();
   // block reduction: fold the per-lane partials of every live cell, add the wide spill cell
   __shared__ u64 red[WAVES * 2];
