@@ -86,9 +86,13 @@ struct gpuq_op {
   uint32_t nparts = 0;
   // scratch
   DevBuf ws[10];
+  // pinned host words for the small device->host reads (flags, counts): a pageable destination makes every such copy a
+  // staged, blocking transfer
+  uint32_t* pin = nullptr;
+  uint32_t* pinned() { if (!pin) { if (hipHostMalloc((void**)&pin, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pin = nullptr; } } return pin; }
   // profiling of the dominant kernel
   bool profile = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float kernel_ms = 0; int launches = 0; bool ev_pending = false;
-  ~gpuq_op() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
+  ~gpuq_op() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); if (pin) (void)hipHostFree(pin); }
 };
 
 struct gpuq_join_table {
@@ -160,12 +164,14 @@ DevProgram bind_program(const CompiledProgram& cp, const Schema& schema, const D
 }
 
 void reset_flags(gpuq_op* op, hipStream_t s) { HIPCHECK(hipMemsetAsync(op->flags_dev.p, 0, 4, s)); }
-uint32_t read_flags(gpuq_op* op, hipStream_t s) {
-  uint32_t f = 0;
-  HIPCHECK(hipMemcpyAsync(&f, op->flags_dev.p, 4, hipMemcpyDeviceToHost, s));
+// words [0, n) of the op's status block (flags, pad, n_groups, pad) -> host
+void read_status(gpuq_op* op, hipStream_t s, uint32_t* out, int n) {
+  uint32_t* h = op->pinned();
+  HIPCHECK(hipMemcpyAsync(h ? h : out, op->flags_dev.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));
-  return f;
+  if (h) for (int i = 0; i < n; ++i) out[i] = h[i];
 }
+uint32_t read_flags(gpuq_op* op, hipStream_t s) { uint32_t f = 0; read_status(op, s, &f, 1); return f; }
 void raise_flags(uint32_t f) {
   if (f & FLAG_STR_TRUNC) throw Unsupported("a Utf8 value longer than 15 bytes reached a device string comparison/key (PACKED15 limit)");
   if (f & FLAG_WIDE_MINMAX) throw Unsupported("MIN/MAX over a value outside the int64 range is not supported on device");
@@ -789,11 +795,45 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
       raw.n_groups = op->flags_dev.as<uint32_t>() + 2;     // next to the flags word: one copy reads both
       HIPCHECK(hipMemsetAsync(raw.n_groups, 0, 8, s));
     };
-    auto read_ng = [&]() { uint32_t v = 0; HIPCHECK(hipMemcpyAsync(&v, raw.n_groups, 4, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s)); return v; };
+    auto read_ng = [&]() { uint32_t v[3] = {0, 0, 0}; read_status(op, s, v, 3); return v[2]; };
+    if (n_outs != (int)op->out_fields.size()) throw std::runtime_error("expected " + std::to_string(op->out_fields.size()) + " output columns, got " + std::to_string(n_outs));
+    bool posted = false;
+    // AoS -> SoA, then the final projection into the caller's typed columns.  rows: host-side bound on the group count;
+    // rows_dev (optional): the device word holding the actual count.
+    auto run_post = [&](uint32_t rows, const uint32_t* rows_dev) {
+      const size_t colbytes = (size_t)std::max<uint32_t>(rows, 1) * 16, vbytes = ((size_t)rows + 63) / 64 * 8 + 8;
+      char* soa_mem = (char*)op->ws[6].ensure((size_t)(nk + na) * colbytes + (size_t)nk * vbytes);
+      AggSoA soa{};
+      std::vector<gpuq_column> pcols(nk + na);
+      for (int k = 0; k < nk; ++k) {
+        soa.key_col[k] = (ulonglong2*)(soa_mem + (size_t)k * colbytes);
+        soa.key_valid[k] = (u64*)(soa_mem + (size_t)(nk + na) * colbytes + (size_t)k * vbytes);
+        const DType& t = op->key_types[k];
+        pcols[k] = gpuq_column{t.id, t.p, t.s, 0, soa.key_col[k], nullptr, op->post_schema.fields[k].nullable ? (const uint8_t*)soa.key_valid[k] : nullptr, (int64_t)rows};
+      }
+      for (int a = 0; a < na; ++a) {
+        soa.acc_col[a] = (ulonglong2*)(soa_mem + (size_t)(nk + a) * colbytes);
+        const DType& t = op->acc_types[a];
+        pcols[nk + a] = gpuq_column{t.id, t.p, t.s, 0, soa.acc_col[a], nullptr, nullptr, (int64_t)rows};
+      }
+      launch_agg_emit(s, raw, nk, na, rows, soa, rows_dev);
+      gpuq_input pin{}; pin.cols = pcols.data(); pin.n_cols = nk + na; pin.n_rows = rows; pin.n_via = 0;
+      for (auto& pc : op->posts) {
+        DevProgram PP = bind_program(pc.prog, op->post_schema, pc.code.as<DevCode>(), op->flags_dev.as<uint32_t>(), &pin);
+        PP.n_dev = rows_dev;
+        const int no = (int)pc.prog.out_reg.size();
+        std::vector<gpuq_field_info> fi(op->out_fields.begin() + pc.first_out, op->out_fields.begin() + pc.first_out + no);
+        OutSpec O = make_outspec(pc.prog, outs + pc.first_out, no, fi);
+        launch_project(s, PP, rows, O);
+      }
+    };
     bool done = false;
     std::string strat = op->strategy;
     if (nk == 0) strat = "tiny";
-    else if (strat == "auto" && n <= 16384) strat = "hash";   // tiny input: a 2n-slot table beats the LDS kernel's fixed per-block cost
+    const int exact_gmax = 0;
+    // tiny input: a 2n-slot table beats the LDS kernel's fixed per-block cost (measured: 60 us for the five small hash-path
+    // launches against 83 us for one cold block of the 16-slot LDS kernel on a 4-row input)
+    if (strat == "auto" && n <= 16384) strat = "hash";
     if (strat == "auto" || strat == "tiny") {
       const int fit_big = agg_tiny_max_groups(na);
       if (fit_big < 1) { if (strat == "tiny") throw Unsupported("too many accumulators for the LDS aggregate"); }
@@ -801,6 +841,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         int fit_small = 0; for (int g = 1; g <= fit_big; ++g) { int nb; (void)nb; if ((size_t)g * na * 2048 + 4096 <= 64 * 1024) fit_small = g; }
         std::vector<int> tries;
         if (nk == 0) tries = {1};
+        else if (exact_gmax > 0) tries = {exact_gmax};
         else { if (fit_small > 4) { tries.push_back(4); } if (fit_small >= 2) tries.push_back(fit_small); if (fit_big > fit_small) tries.push_back(fit_big); }
         for (int gmax : tries) {
           int nb = 0; const size_t wsb = agg_tiny_workspace_bytes(gmax, nk, na, &nb);
@@ -809,14 +850,18 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
           reset_flags(op, s);
           // the LDS aggregate is specialised on its whole shape (keys, accumulators, group capacity)
           const std::string spec = agg_tiny_spec(op, gmax);
-          { JitScope js(op, op->prog, 3, n, spec); ProfScope ps(op, s); launch_agg_tiny(s, P, n, op->agg, gmax, wsp, raw); }
+          { JitScope js(op, op->prog, 3, n, spec); ProfScope ps(op, s); launch_agg_tiny(s, P, n, op->agg, gmax, wsp); }
+          launch_agg_tiny_merge(s, P, n, op->agg, gmax, wsp, raw);
           HIPCHECK(hipGetLastError());
+          // The result projection is queued before the host knows whether this try held all groups (it reads the group
+          // count on the device): one host round trip per aggregate instead of two.  An overflowing try is simply redone.
+          const bool ahead = (i64)raw.cap <= cap;
+          if (ahead) run_post((uint32_t)raw.cap, raw.n_groups);
           uint32_t fw[4] = {0, 0, 0, 0};
-          HIPCHECK(hipMemcpyAsync(fw, op->flags_dev.p, 16, hipMemcpyDeviceToHost, s));
-          HIPCHECK(hipStreamSynchronize(s));
+          read_status(op, s, fw, 4);
           const uint32_t f = fw[0];
           if (f & ~FLAG_GROUP_OVERFLOW) { reset_flags(op, s); raise_flags(f & ~FLAG_GROUP_OVERFLOW); }
-          if (!(f & FLAG_GROUP_OVERFLOW)) { ng = fw[2]; done = true; break; }
+          if (!(f & FLAG_GROUP_OVERFLOW)) { ng = fw[2]; done = true; posted = ahead; break; }
         }
         if (!done && strat == "tiny") throw Capacity("more groups than the LDS aggregate holds; use strategy hash/auto");
       }
@@ -864,35 +909,12 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
     }
     if (n_groups_out) *n_groups_out = ng;
     if ((i64)ng > cap) throw Capacity("aggregate produced " + std::to_string(ng) + " groups, output capacity is " + std::to_string(cap));
-    // AoS -> SoA, then the final projection into the caller's typed columns
-    const size_t colbytes = (size_t)std::max<uint32_t>(ng, 1) * 16, vbytes = ((size_t)ng + 63) / 64 * 8 + 8;
-    char* soa_mem = (char*)op->ws[6].ensure((size_t)(nk + na) * colbytes + (size_t)nk * vbytes);
-    AggSoA soa{};
-    std::vector<gpuq_column> pcols(nk + na);
-    for (int k = 0; k < nk; ++k) {
-      soa.key_col[k] = (ulonglong2*)(soa_mem + (size_t)k * colbytes);
-      soa.key_valid[k] = (u64*)(soa_mem + (size_t)(nk + na) * colbytes + (size_t)k * vbytes);
-      const DType& t = op->key_types[k];
-      pcols[k] = gpuq_column{t.id, t.p, t.s, 0, soa.key_col[k], nullptr, op->post_schema.fields[k].nullable ? (const uint8_t*)soa.key_valid[k] : nullptr, (int64_t)ng};
-    }
-    for (int a = 0; a < na; ++a) {
-      soa.acc_col[a] = (ulonglong2*)(soa_mem + (size_t)(nk + a) * colbytes);
-      const DType& t = op->acc_types[a];
-      pcols[nk + a] = gpuq_column{t.id, t.p, t.s, 0, soa.acc_col[a], nullptr, nullptr, (int64_t)ng};
-    }
-    launch_agg_emit(s, raw, nk, na, ng, soa);
-    gpuq_input pin{}; pin.cols = pcols.data(); pin.n_cols = nk + na; pin.n_rows = ng; pin.n_via = 0;
-    if (n_outs != (int)op->out_fields.size()) throw std::runtime_error("expected " + std::to_string(op->out_fields.size()) + " output columns, got " + std::to_string(n_outs));
     for (int i = 0; i < n_outs; ++i) outs[i].length = ng;
-    for (auto& pc : op->posts) {
-      DevProgram PP = bind_program(pc.prog, op->post_schema, pc.code.as<DevCode>(), op->flags_dev.as<uint32_t>(), &pin);
-      const int no = (int)pc.prog.out_reg.size();
-      std::vector<gpuq_field_info> fi(op->out_fields.begin() + pc.first_out, op->out_fields.begin() + pc.first_out + no);
-      OutSpec O = make_outspec(pc.prog, outs + pc.first_out, no, fi);
-      launch_project(s, PP, ng, O);
+    if (!posted) {
+      run_post(ng, nullptr);
+      HIPCHECK(hipGetLastError());
+      HIPCHECK(hipStreamSynchronize(s));
     }
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(s));
   });
 }
 
@@ -1064,6 +1086,11 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
     void* sws = op->ws[7].ensure(swb);
     ProfScope ps(op, s);
     { JitScope js(op, op->prog, 9, n); launch_sort_pack(s, P, n, S, K, klo, khi, ids); }
+    if (n <= sort_small_max()) {      // one block sorts it in LDS: no histogram / scan / scatter launches
+      launch_sort_small(s, klo, khi, ids, n, perm_out);
+      HIPCHECK(hipGetLastError());
+      return;
+    }
     auto run_passes = [&](int bits) {
       for (int sh = 0; sh < bits; sh += 8) {
         launch_radix_pass(s, klo, ids, n, sh, 0xFFu, klo2, ids2, hist, sws, swb);

@@ -90,6 +90,8 @@ struct DevProgram {
   const uint32_t* via[MAX_VIA];
   const DevCode* code;   // device memory
   uint32_t* flags;       // device status word (FLAG_* bits)
+  const uint32_t* n_dev; // k_project only: when set, the row count is min(*n_dev, n) -- lets the host queue the projection
+                         // of an aggregate's groups before it knows how many there are
 };
 
 // launcher-side dispatch over the column-slot template parameter

@@ -105,7 +105,8 @@ void launch_compact(hipStream_t s, const u64* bitmap, const uint32_t* block_offs
 void launch_project(hipStream_t s, const DevProgram& P, i64 n, const OutSpec& O);
 int agg_tiny_max_groups(int n_accs);
 size_t agg_tiny_workspace_bytes(int gmax, int n_keys, int n_accs, int* nblocks_out);
-void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace, const AggOut& out);
+void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace);
+void launch_agg_tiny_merge(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace, const AggOut& out);
 void launch_ht_init(hipStream_t s, const HashTable& T, const AggSpec* A);
 void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T);
 void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags);
@@ -126,11 +127,13 @@ void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec&
 void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, uint32_t nparts, u64* pid_out, uint32_t* ids);
 void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out);
 void launch_gather_u64(hipStream_t s, const u64* src, const uint32_t* idx, i64 n, u64* dst);
+int sort_small_max();
+void launch_sort_small(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, i64 n, uint32_t* out);
 void radix_geometry(i64 n, int* nblocks, i64* tile);
 size_t radix_hist_entries(int nblocks);
 void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, uint32_t mask, u64* keys_out, uint32_t* vals_out,
                        int32_t* hist, void* scan_ws, size_t scan_ws_bytes);
-void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa);
+void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa, const uint32_t* n_groups_dev = nullptr);
 void launch_concat_bitmap(hipStream_t s, u64* dst, i64 dst_bit_offset, const uint8_t* src, i64 n_bits);
 void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out);
 void launch_unpack_utf8_bytes(hipStream_t s, const ulonglong2* packed, i64 n, const int32_t* offsets, uint8_t* data_out);

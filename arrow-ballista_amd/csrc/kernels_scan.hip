@@ -126,7 +126,9 @@ __global__ void __launch_bounds__(BLOCK) k_compact(const u64* __restrict__ bitma
 
 // ------------------------------------------------------------------ project
 template <int MAXC>
-__device__ __forceinline__ void k_project_body(const DevProgram P, const i64 n, const OutSpec O) {
+__device__ __forceinline__ void k_project_body(const DevProgram P, const i64 n_arg, const OutSpec O) {
+  i64 n = n_arg;
+  if (P.n_dev) { const i64 nd = (i64)*P.n_dev; if (nd < n) n = nd; }
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * WAVES + wave_id(); w < nwords; w += (i64)gridDim.x * WAVES) {
     const i64 pos = (w << 6) + lane_id();
@@ -467,7 +469,11 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
         // evaluated on every lane (clamped rows are real rows) so that the record is consumed on all paths
         GPUQ_MARK("compute");
         const bool pass = gpuq_jit_compute(P, pos < n ? pos : last, raws[pj][u], GPUQ_REGS);
+#if defined(GPUQ_EXP_LOADS_ONLY)
+        if (pos < n && pass && rlo[3] == 0x123456789ull) atomicOr(P.flags, 1u << 30);     // experiment: loads + evaluation only
+#else
         accumulate_row(pos < n && pass, GPUQ_REGS);
+#endif
       }
       GPUQ_MARK("end");
       t += tstride;
@@ -557,7 +563,8 @@ extern "C" __global__ void __launch_bounds__(BLOCK) gpuq_jit_entry(const DevProg
 // Merge the per-block partial records into the final groups.  One block; the work is
 // nblocks*gmax records, a few thousand at most.
 #ifndef GPUQ_JIT
-__global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const int gmax, const char* __restrict__ workspace,
+constexpr int MERGE_BLOCK = 1024;   // one block; its serial chains of dependent loads are what the merge costs, so many threads
+__global__ void __launch_bounds__(MERGE_BLOCK) k_agg_tiny_merge(const AggSpec A, const int gmax, const char* __restrict__ workspace,
                                                           const size_t partial_stride, const int nblocks, const AggOut out,
                                                           uint32_t* __restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -573,13 +580,10 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const
   const int tid = threadIdx.x;
   if (tid == 0) { *fn = 0; *lock = 0; }
   __syncthreads();
-  volatile uint32_t* vfn = fn;
-  volatile u64* vk = fkeys;
-  volatile uint32_t* vnl = fnulls;
   const size_t keys_off = 8, nulls_off = 8 + (size_t)gmax * kstride * 16;
   const size_t cells_off = nulls_off + (size_t)gmax * 4 + ((gmax & 1) ? 4 : 0);
   // phase 1: map every (block, local group) to a final group id
-  for (int e = tid; e < nblocks * gmax; e += BLOCK) {
+  for (int e = tid; e < nblocks * gmax; e += MERGE_BLOCK) {
     const int b = e / gmax, g = e % gmax;
     const char* rec = workspace + (size_t)b * partial_stride;
     const uint32_t ng = ((const uint32_t*)rec)[0];
@@ -588,33 +592,33 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const
     const uint32_t kn = ((const uint32_t*)(rec + nulls_off))[g];
     int found = -1; uint32_t seen = 0;
     while (found < 0) {
-      const uint32_t nd = *vfn;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const uint32_t nd = lds_ld(fn);
+      LDS_ACQUIRE();
       for (uint32_t f = seen; f < nd && found < 0; ++f) {
-        bool eq = vnl[f] == kn;
-        for (int q = 0; q < n_keys; ++q) eq = eq && vk[(f * kstride + q) * 2] == k[2 * q] && vk[(f * kstride + q) * 2 + 1] == k[2 * q + 1];
+        bool eq = lds_ld(&fnulls[f]) == kn;
+        for (int q = 0; q < n_keys; ++q) eq = eq && lds_ld(&fkeys[(f * kstride + q) * 2]) == k[2 * q] && lds_ld(&fkeys[(f * kstride + q) * 2 + 1]) == k[2 * q + 1];
         if (eq) found = (int)f;
       }
       seen = nd;
       if (found >= 0) break;
       if (atomicCAS(lock, 0u, 1u) == 0u) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint32_t n2 = *vfn;
+        LDS_ACQUIRE();
+        const uint32_t n2 = lds_ld(fn);
         for (uint32_t f = seen; f < n2 && found < 0; ++f) {
-          bool eq = vnl[f] == kn;
-          for (int q = 0; q < n_keys; ++q) eq = eq && vk[(f * kstride + q) * 2] == k[2 * q] && vk[(f * kstride + q) * 2 + 1] == k[2 * q + 1];
+          bool eq = lds_ld(&fnulls[f]) == kn;
+          for (int q = 0; q < n_keys; ++q) eq = eq && lds_ld(&fkeys[(f * kstride + q) * 2]) == k[2 * q] && lds_ld(&fkeys[(f * kstride + q) * 2 + 1]) == k[2 * q + 1];
           if (eq) found = (int)f;
         }
         if (found < 0) {
           if (n2 < (uint32_t)cap) {
-            for (int q = 0; q < n_keys; ++q) { vk[(n2 * kstride + q) * 2] = k[2 * q]; vk[(n2 * kstride + q) * 2 + 1] = k[2 * q + 1]; }
-            vnl[n2] = kn;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            *vfn = n2 + 1;
+            for (int q = 0; q < n_keys; ++q) { lds_st(&fkeys[(n2 * kstride + q) * 2], k[2 * q]); lds_st(&fkeys[(n2 * kstride + q) * 2 + 1], k[2 * q + 1]); }
+            lds_st(&fnulls[n2], kn);
+            LDS_RELEASE();
+            lds_st(fn, n2 + 1);
             found = (int)n2;
           } else { atomicOr(flags, FLAG_GROUP_OVERFLOW); found = 0; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        LDS_RELEASE();
         atomicExch(lock, 0u);
       }
     }
@@ -625,7 +629,7 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const
   // phase 2: integer cells are folded with LDS atomics (any order gives the same bits); float sums
   // are folded by one thread per cell in block order so that results are reproducible run to run.
   u64* fcells = (u64*)(lock + 3);   // [cap][n_accs][2], 8-byte aligned by construction
-  for (int c = tid; c < nf * n_accs; c += BLOCK) {
+  for (int c = tid; c < nf * n_accs; c += MERGE_BLOCK) {
     const int kind = A.acc_kind[c % n_accs];
     fcells[2 * c] = acc_identity(kind);
     fcells[2 * c + 1] = (kind == ACC_MAX) ? ~0ull : 0;
@@ -633,7 +637,7 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const
   __syncthreads();
   bool has_float = false;
   for (int a = 0; a < n_accs; ++a) has_float = has_float || A.acc_kind[a] == ACC_FSUM;
-  for (int e = tid; e < nblocks * gmax; e += BLOCK) {
+  for (int e = tid; e < nblocks * gmax; e += MERGE_BLOCK) {
     const uint16_t f = map[e];
     if (f == 0xFFFF) continue;
     const int b = e / gmax, g = e % gmax;
@@ -652,7 +656,7 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const
         case ACC_MIN: atomicMin((long long*)dst, (long long)olo); break;
         case ACC_MAX: atomicMax((long long*)dst, (long long)olo); break;
         case ACC_FMIN: case ACC_FMAX: {
-          u64 cur = *(volatile u64*)dst;
+          u64 cur = lds_ld(dst);
           for (;;) {
             const bool better = (kind == ACC_FMIN) ? (f64_total_key(olo) < f64_total_key(cur)) : (f64_total_key(olo) > f64_total_key(cur));
             if (!better) break;
@@ -668,7 +672,7 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const
   }
   __syncthreads();
   if (has_float) {
-    for (int c = tid; c < nf * n_accs; c += BLOCK) {
+    for (int c = tid; c < nf * n_accs; c += MERGE_BLOCK) {
       const int f = c / n_accs, a = c % n_accs;
       if (A.acc_kind[a] != ACC_FSUM) continue;
       double acc = 0.0;
@@ -681,21 +685,24 @@ __global__ void __launch_bounds__(BLOCK) k_agg_tiny_merge(const AggSpec A, const
     }
     __syncthreads();
   }
-  for (int c = tid; c < nf * n_accs; c += BLOCK) {
+  for (int c = tid; c < nf * n_accs; c += MERGE_BLOCK) {
     const int kind = A.acc_kind[c % n_accs];
     u64 lo = fcells[2 * c], hi = fcells[2 * c + 1];
     if (kind == ACC_MIN || kind == ACC_MAX) hi = (u64)((i64)lo >> 63);
     out.cells[(size_t)c * 2] = lo; out.cells[(size_t)c * 2 + 1] = hi;
   }
-  for (int i = tid; i < nf * kstride * 2; i += BLOCK) out.keys[i] = fkeys[i];
-  for (int i = tid; i < nf; i += BLOCK) out.key_nulls[i] = fnulls[i];
+  for (int i = tid; i < nf * kstride * 2; i += MERGE_BLOCK) out.keys[i] = fkeys[i];
+  for (int i = tid; i < nf; i += MERGE_BLOCK) out.key_nulls[i] = fnulls[i];
   if (tid == 0) *out.n_groups = (uint32_t)nf;
 }
 #endif
 
 // ------------------------------------------------------------------ aggregate result AoS -> SoA
 #ifndef GPUQ_JIT
-__global__ void __launch_bounds__(BLOCK) k_agg_emit(const AggOut raw, const int n_keys, const int n_accs, const uint32_t ng, const AggSoA soa) {
+__global__ void __launch_bounds__(BLOCK) k_agg_emit(const AggOut raw, const int n_keys, const int n_accs, const uint32_t ng_arg, const AggSoA soa,
+                                                   const uint32_t* __restrict__ ng_dev) {
+  uint32_t ng = ng_arg;
+  if (ng_dev) { const uint32_t nd = *ng_dev; if (nd < ng) ng = nd; }
   const int kstride = n_keys > 0 ? n_keys : 1;
   const uint32_t nwords = (ng + 63) >> 6;
   for (uint32_t w = blockIdx.x * WAVES + wave_id(); w < nwords; w += gridDim.x * WAVES) {
@@ -755,7 +762,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles_serial(u64* __restrict__ ti
   const i64 a = (i64)t * per; i64 b = a + per; if (b > ntiles) b = ntiles;
   u64 s = 0; for (i64 i = a; i < b; ++i) s += tile_sums[i];
   part[t] = s; __syncthreads();
-  if (t == 0) { u64 run = 0; for (int k = 0; k < 1024; ++k) { const u64 v = part[k]; part[k] = run; run += v; } }
+  if (t == 0) { const int lim = (int)((ntiles + per - 1) / per); u64 run = 0; for (int k = 0; k < lim; ++k) { const u64 v = part[k]; part[k] = run; run += v; } }   // chunks past lim are empty
   __syncthreads();
   u64 run = part[t];
   for (i64 i = a; i < b; ++i) { const u64 v = tile_sums[i]; tile_sums[i] = run; run += v; }
@@ -840,7 +847,7 @@ size_t agg_tiny_workspace_bytes(int gmax, int n_keys, int n_accs, int* nblocks_o
   if (nblocks_out) *nblocks_out = nb;
   return (size_t)nb * ((tiny_partial_bytes(gmax, n_keys, n_accs) + 15) & ~(size_t)15);
 }
-void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace, const AggOut& out) {
+void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace) {
   const size_t stride = (tiny_partial_bytes(gmax, A.n_keys, A.n_accs) + 15) & ~(size_t)15;
   int nb_cap = g_num_cus * tiny_blocks_per_cu(gmax, A.n_keys, A.n_accs);
   int nb = grid_for(n, 64);
@@ -863,6 +870,13 @@ void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
   }
+}
+
+void launch_agg_tiny_merge(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace, const AggOut& out) {
+  const size_t stride = (tiny_partial_bytes(gmax, A.n_keys, A.n_accs) + 15) & ~(size_t)15;
+  int nb_cap = g_num_cus * tiny_blocks_per_cu(gmax, A.n_keys, A.n_accs);
+  int nb = grid_for(n, 64);
+  if (nb > nb_cap) nb = nb_cap;
   static size_t attr_merge = 0;
   const int kstride = A.n_keys > 0 ? A.n_keys : 1;
   const size_t mlds = (size_t)out.cap * kstride * 16 + (size_t)out.cap * 4 + (((size_t)nb * gmax * 2 + 15) & ~(size_t)15) + 32 + (size_t)out.cap * A.n_accs * 16;
@@ -870,14 +884,14 @@ void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A
     if (hipFuncSetAttribute((const void*)k_agg_tiny_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) == hipSuccess) attr_merge = mlds;
     else (void)hipGetLastError();
   }
-  hipLaunchKernelGGL(k_agg_tiny_merge, dim3(1), dim3(BLOCK), mlds, s, A, gmax, (const char*)workspace, stride, nb, out, P.flags);
+  hipLaunchKernelGGL(k_agg_tiny_merge, dim3(1), dim3(MERGE_BLOCK), mlds, s, A, gmax, (const char*)workspace, stride, nb, out, P.flags);
 }
 
-void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa) {
+void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa, const uint32_t* n_groups_dev) {
   if (n_groups == 0) return;
   const uint32_t nwords = (n_groups + 63) >> 6;
   uint32_t grid = (nwords + WAVES - 1) / WAVES; if (grid > (uint32_t)g_num_cus * 8) grid = g_num_cus * 8;
-  hipLaunchKernelGGL(k_agg_emit, dim3(grid), dim3(BLOCK), 0, s, raw, n_keys, n_accs, n_groups, soa);
+  hipLaunchKernelGGL(k_agg_emit, dim3(grid), dim3(BLOCK), 0, s, raw, n_keys, n_accs, n_groups, soa, n_groups_dev);
 }
 static int lin_grid(i64 n) { i64 need = (n + BLOCK - 1) / BLOCK; if (need < 1) need = 1; const i64 cap = (i64)g_num_cus * 16; return (int)(need < cap ? need : cap); }
 void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out) {

@@ -345,6 +345,43 @@ void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64
                      keys_out, vals_out);
 }
 
+// ------------------------------------------------------------------ small inputs: one block, bitonic network in LDS
+// Replaces the radix passes (5 launches per 8 key bits) when the whole input fits one block: the sort of a final
+// aggregate's handful of groups (q1: 4 rows) is pure launch latency otherwise.  Order = (composite key, row id): the row
+// id as the last tie-break makes the network's result the stable order the LSD radix produces.
+constexpr int SMALL_SORT_MAX = 2048;
+__global__ void __launch_bounds__(1024) k_sort_small(const u64* __restrict__ klo, const u64* __restrict__ khi, const uint32_t* __restrict__ ids,
+                                                     const int n, uint32_t* __restrict__ out) {
+  __shared__ u64 slo[SMALL_SORT_MAX], shi[SMALL_SORT_MAX];
+  __shared__ uint32_t sid[SMALL_SORT_MAX];
+  int m = 2; while (m < n) m <<= 1;
+  for (int i = threadIdx.x; i < m; i += 1024) {
+    if (i < n) { slo[i] = klo[i]; shi[i] = khi ? khi[i] : 0ull; sid[i] = ids[i]; }
+    else { slo[i] = ~0ull; shi[i] = ~0ull; sid[i] = 0xFFFFFFFFu; }          // padding sorts behind every real row
+  }
+  __syncthreads();
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < m; i += 1024) {
+        const int x = i ^ j;
+        if (x > i) {
+          const u64 ah = shi[i], al = slo[i], bh = shi[x], bl = slo[x];
+          const uint32_t ai = sid[i], bi = sid[x];
+          const bool a_gt_b = ah != bh ? ah > bh : (al != bl ? al > bl : ai > bi);
+          const bool up = (i & k) == 0;
+          if (a_gt_b == up) { shi[i] = bh; slo[i] = bl; sid[i] = bi; shi[x] = ah; slo[x] = al; sid[x] = ai; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += 1024) out[i] = sid[i];
+}
+int sort_small_max() { return SMALL_SORT_MAX; }
+void launch_sort_small(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, i64 n, uint32_t* out) {
+  if (n > 0) hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, s, klo, khi, ids, (int)n, out);
+}
+
 #endif  // GPUQ_JIT
 
 }  // namespace gpuq

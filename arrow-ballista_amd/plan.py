@@ -76,17 +76,29 @@ class Metrics:
 
 # ---------------------------------------------------------------------------------- helpers
 def _alloc_outputs(op, n, device):
-    """Allocate caller-side output columns for op.fields with capacity n rows."""
+    """Allocate caller-side output columns for op.fields with capacity n rows: one device allocation, sliced per buffer
+    (256-byte aligned pieces)."""
     torch = _torch()
-    cols, arr = [], (B.gpuq_column * max(1, len(op.fields)))()
-    for i, f in enumerate(op.fields):
-        tj = type_json(f["type"], f["precision"], f["scale"])
-        if f["type"] == B.T_BOOL:
-            data = torch.empty(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=device)
-        else:
-            data = torch.empty(max(1, n) * f["width"] + 16, dtype=torch.uint8, device=device)
-        validity = torch.empty(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=device) if f["nullable"] else None   # every word is written by the kernel
-        col = DeviceColumn(f["name"], tj, data, n, validity=validity, nullable=f["nullable"], repr=f["repr"])
+    nf = len(op.fields)
+    lay = op.__dict__.get("_out_layout")
+    if lay is None:
+        # per field: (type json, is_bool, width, nullable, repr, name)
+        lay = op._out_layout = [(type_json(f["type"], f["precision"], f["scale"]), f["type"] == B.T_BOOL, f["width"], f["nullable"], f["repr"], f["name"]) for f in op.fields]
+    bm = ((n + 63) // 64) * 8 + 8
+    sizes = []
+    for tj, is_bool, width, nullable, rp, name in lay:
+        sizes.append(bm if is_bool else max(1, n) * width + 16)
+        sizes.append(bm if nullable else 0)         # every validity word is written by the kernel
+    offs, total = [], 0
+    for sz in sizes:
+        offs.append(total)
+        total += (sz + 255) & ~255
+    buf = torch.empty(max(total, 256), dtype=torch.uint8, device=device)
+    cols, arr = [], (B.gpuq_column * max(1, nf))()
+    for i, (tj, is_bool, width, nullable, rp, name) in enumerate(lay):
+        data = buf[offs[2 * i]: offs[2 * i] + sizes[2 * i]]
+        validity = buf[offs[2 * i + 1]: offs[2 * i + 1] + sizes[2 * i + 1]] if nullable else None
+        col = DeviceColumn(name, tj, data, n, validity=validity, nullable=nullable, repr=rp)
         cols.append(col)
         arr[i] = col.to_c()
     return cols, arr
@@ -486,7 +498,7 @@ def aggregate_table(tc, table, descriptor, cap=None, op=None):
         tc.ctx.check(rc)
         break
     for c in cols:
-        c.length = ng.value
+        c.set_length(ng.value)
     return DeviceTable(cols, ng.value)
 
 

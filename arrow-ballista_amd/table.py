@@ -45,14 +45,22 @@ class DeviceColumn:
         return f
 
     def to_c(self):
-        tid, p, s = type_id(self.type)
-        c = B.gpuq_column()
-        c.type, c.precision, c.scale, c.repr = tid, p, s, self.repr
-        c.data = self.data.data_ptr() if self.data is not None and self.data.numel() > 0 else None
-        c.offsets = self.offsets.data_ptr() if self.offsets is not None else None
-        c.validity = self.validity.data_ptr() if self.validity is not None else None
+        """The C view of this column.  Built once: a column's buffers never change after construction (set_length only
+        narrows the row count), and building ctypes structs is what a small query's host time consists of."""
+        c = self.__dict__.get("_c")
+        if c is None:
+            tid, p, s = type_id(self.type)
+            c = B.gpuq_column()
+            c.type, c.precision, c.scale, c.repr = tid, p, s, self.repr
+            c.data = self.data.data_ptr() if self.data is not None and self.data.numel() > 0 else None
+            c.offsets = self.offsets.data_ptr() if self.offsets is not None else None
+            c.validity = self.validity.data_ptr() if self.validity is not None else None
+            self._c = c
         c.length = self.length
         return c
+
+    def set_length(self, n):
+        self.length = int(n)
 
     def nbytes(self):
         n = 0
@@ -88,7 +96,10 @@ class DeviceTable:
         return len(self.via) > 0
 
     def input_struct(self):
-        """(gpuq_input, keepalive) for a C call."""
+        """(gpuq_input, keepalive) for a C call.  Cached: a table is immutable once built."""
+        cached = self.__dict__.get("_inp")
+        if cached is not None and cached[2] == self.num_rows:
+            return cached[0], cached[1]
         arr = (B.gpuq_column * max(1, len(self.columns)))()
         for i, c in enumerate(self.columns):
             arr[i] = c.to_c()
@@ -99,6 +110,7 @@ class DeviceTable:
         inp.n_rows = self.num_rows
         for k, v in enumerate(self.via):
             inp.via[k] = v.data_ptr() if v.numel() > 0 else None
+        self._inp = (inp, arr, self.num_rows)
         return inp, arr
 
     def nbytes(self):

@@ -13,6 +13,7 @@ def walk(p,d=0,out=None):
     for c in p.children(): walk(c,d+1,out)
     return out
 for i in range(3): g.plan.materialize(tc, full.execute(0,tc))
+import gc; gc.collect(); gc.freeze(); gc.disable()
 nodes=walk(full)
 for d,p in nodes: p.metrics.elapsed_compute_ns=0
 torch.cuda.synchronize(); t0=time.perf_counter()
@@ -22,6 +23,10 @@ for i in range(K):
 torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/K*1e3
 print("ms/step %.3f"%dt)
 for d,p in nodes: print("  "*d+"%-22s %8.3f ms (own, excl. children's exec)"%(type(p).__name__+('/'+p.mode if hasattr(p,'mode') else ''), p.metrics.elapsed_compute_ns/K/1e6))
+# materialize cost
+torch.cuda.synchronize(); t0=time.perf_counter()
+for i in range(K): v=full.execute(0,tc)
+torch.cuda.synchronize(); print("execute only (no materialize): %.3f ms"%((time.perf_counter()-t0)/K*1e3))
 import cProfile, pstats
 pr=cProfile.Profile(); pr.enable()
 for i in range(K): out=g.plan.materialize(tc, full.execute(0,tc))
