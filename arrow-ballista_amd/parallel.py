@@ -37,6 +37,13 @@ def allgather_table(table, cap, group=None):
     n = table.num_rows
     if n > cap:
         raise ValueError("allgather_table: %d rows exceed cap %d" % (n, cap))
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        # gloo has no device all-gather: stage through host memory (CPU tests / several ranks sharing one GPU)
+        host = DeviceTable([DeviceColumn(c.name, c.type, c.data.cpu(), c.length, offsets=c.offsets, validity=c.validity.cpu() if c.validity is not None else None,
+                                         nullable=c.nullable, repr=c.repr) for c in table.columns], n)
+        out = allgather_table(host, cap, group=group)
+        return DeviceTable([DeviceColumn(c.name, c.type, c.data.to(dev), c.length, validity=c.validity.to(dev) if c.validity is not None else None,
+                                         nullable=c.nullable, repr=c.repr) for c in out.columns], out.num_rows)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
     dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
     counts = [int(c.item()) for c in counts]
@@ -72,10 +79,25 @@ def allgather_table(table, cap, group=None):
     return DeviceTable(cols, total)
 
 
-def exchange_partitions(parts, group=None):
+def _a2a(send, send_splits, recv_splits, dev, group=None):
+    """Variable-size all-to-all of a uint8 tensor.  RCCL moves device memory directly; under gloo (CPU tests, or several
+    ranks sharing one GPU in the 2-process GPU test) the bytes are staged through host memory."""
+    import torch
+    dist = _dist()
+    total = int(sum(recv_splits))
+    staged = send.is_cuda and dist.get_backend(group) == "gloo"
+    if staged:
+        send = send.cpu()
+    recv = torch.empty(total, dtype=torch.uint8, device=send.device)
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[int(x) for x in recv_splits], input_split_sizes=[int(x) for x in send_splits], group=group)
+    return recv.to(dev) if staged else recv
+
+
+def exchange_partitions(parts, group=None, tc=None):
     """Hash-repartition exchange.  parts[d] = materialised fixed-width DeviceTable destined for rank d
-    (len(parts) == world size, same schema).  Returns the concatenation of what every rank sent here.
-    Step 1: all-to-all of row counts.  Step 2: one all_to_all_single per column with split sizes."""
+    (len(parts) == world size, same schema).  Returns the concatenation (in rank order) of what every rank sent here.
+    Step 1: all-to-all of row counts.  Step 2: one variable-size all-to-all per column buffer.  Validity bitmaps travel as
+    whole bytes per piece and are re-joined at bit granularity with gpuq_concat_bitmap (needs `tc`)."""
     import torch
     dist = _dist()
     rank, ws = world()
@@ -84,19 +106,141 @@ def exchange_partitions(parts, group=None):
     if len(parts) != ws:
         raise ValueError("need one partition per rank")
     dev = parts[0].columns[0].data.device
-    send_counts = torch.tensor([p.num_rows for p in parts], dtype=torch.int64, device=dev)
-    recv_counts = torch.empty(ws, dtype=torch.int64, device=dev)
+    staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+    send_counts = torch.tensor([p.num_rows for p in parts], dtype=torch.int64, device="cpu" if staged else dev)
+    recv_counts = torch.empty(ws, dtype=torch.int64, device=send_counts.device)
     dist.all_to_all_single(recv_counts, send_counts, group=group)
     sc = [int(x) for x in send_counts.tolist()]
     rc = [int(x) for x in recv_counts.tolist()]
     total = sum(rc)
+    pad = torch.zeros(16, dtype=torch.uint8, device=dev)
+    vb = lambda k: (k + 7) // 8
+
+    def exchange_bitmap(pieces):
+        """pieces[d]: bit-packed uint8 tensor of parts[d].num_rows bits, or None (all ones).  Bitmaps travel as whole bytes
+        per piece and are re-joined at bit granularity on the device."""
+        if tc is None:
+            raise ValueError("exchange_partitions: nullable / Boolean columns need a TaskContext (bitmap re-join runs on the device)")
+        send = [pc[: vb(p.num_rows)] if pc is not None else torch.full((vb(p.num_rows),), 255, dtype=torch.uint8, device=dev) for pc, p in zip(pieces, parts)]
+        vrecv = _a2a(torch.cat(send) if send else torch.zeros(0, dtype=torch.uint8, device=dev), [vb(k) for k in sc], [vb(k) for k in rc], dev, group)
+        out = torch.zeros(((total + 63) // 64) * 8 + 8, dtype=torch.uint8, device=dev)
+        boff, bit = 0, 0
+        for k in rc:
+            if k > 0:
+                piece = torch.cat([vrecv[boff: boff + vb(k)], pad])           # own storage: 8-byte readable tail
+                tc.ctx.check(tc.ctx.L.gpuq_concat_bitmap(tc.ctx.h, tc.stream_ptr(), out.data_ptr(), bit, piece.data_ptr(), k))
+                tc.sync()                                                       # `piece` is released after this iteration
+            boff += vb(k); bit += k
+        return out
     cols = []
     for ci, c0 in enumerate(parts[0].columns):
-        if c0.offsets is not None or c0.validity is not None:
-            raise ValueError("exchange_partitions: fixed-width non-null columns only (materialise / PACKED15 first)")
+        pcs = [p.columns[ci] for p in parts]
+        if any(c.offsets is not None for c in pcs):
+            raise ValueError("exchange_partitions: fixed-width columns only (materialise Utf8 as PACKED15 first)")
         w = type_width(c0.type)
-        send = torch.cat([p.columns[ci].data[: p.num_rows * w] for p in parts]) if sum(sc) else torch.zeros(0, dtype=torch.uint8, device=dev)
-        recv = torch.empty(total * w + 16, dtype=torch.uint8, device=dev)
-        dist.all_to_all_single(recv[: total * w], send, output_split_sizes=[k * w for k in rc], input_split_sizes=[k * w for k in sc], group=group)
-        cols.append(DeviceColumn(c0.name, c0.type, recv, total, nullable=c0.nullable, repr=c0.repr))
+        if w == 0:       # Boolean: bit-packed values
+            data = exchange_bitmap([c.data for c in pcs])
+        else:
+            send = torch.cat([c.data[: p.num_rows * w] for c, p in zip(pcs, parts)]) if sum(sc) else torch.zeros(0, dtype=torch.uint8, device=dev)
+            data = torch.cat([_a2a(send, [k * w for k in sc], [k * w for k in rc], dev, group), pad])
+        # every rank must take the same branch: nullability is a property of the schema, not of the data
+        nullable = any(c.nullable for c in pcs)
+        validity = exchange_bitmap([c.validity for c in pcs]) if nullable else None
+        cols.append(DeviceColumn(c0.name, c0.type, data, total, validity=validity, nullable=nullable, repr=c0.repr))
     return DeviceTable(cols, total)
+
+
+def repartition_exchange(tc, table, hash_expr, group=None):
+    """RepartitionExec(Hash(hash_expr, world)) followed by the exchange: returns the rows of ALL ranks whose key hashes to
+    this rank (planner.rs:137-151 splits a stage here; the reference then writes/reads shuffle files over Flight)."""
+    from . import plan as PL
+    rank, ws = world()
+    if ws == 1:
+        return table
+    views = PL.partition_table(tc, table, hash_expr, ws)
+    parts = [PL.materialize(tc, v, force=True) for v in views]
+    return exchange_partitions(parts, group=group, tc=tc)
+
+
+def broadcast_table(tc, table, cap=None, group=None):
+    """Every rank receives all ranks' rows (CollectLeft build sides below the broadcast threshold, config.rs:198-200)."""
+    from . import plan as PL
+    rank, ws = world()
+    if ws == 1:
+        return table
+    t = PL.materialize(tc, table, force=True)
+    if cap is None:
+        import torch
+        dist = _dist()
+        dev = t.columns[0].data.device
+        staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+        m = torch.tensor([t.num_rows], dtype=torch.int64, device="cpu" if staged else dev)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+        cap = max(1, int(m.item()))
+    return allgather_table(t, cap, group=group)
+
+
+def partitioned_hash_join(tc, left, right, on, join_type="Inner", filter=None, group=None):
+    """HashJoinExec(PartitionMode::Partitioned) across ranks: both inputs are repartitioned on their join keys with the
+    SAME partition function, exchanged, and joined locally.  `on` = [(left_expr, right_expr)].  Returns this rank's share
+    of the join result (a view)."""
+    from . import plan as PL
+    lt = repartition_exchange(tc, left, [l for l, _ in on], group=group)
+    rt = repartition_exchange(tc, right, [r for _, r in on], group=group)
+    L, R = PL.MemoryExec([lt]), PL.MemoryExec([rt])
+    ls, rs = L.schema(), R.schema()
+    from . import expr as E
+    on2 = [(E.rebind(l, ls), E.rebind(r, rs)) for l, r in on]
+    return PL.HashJoinExec(L, R, on2, filter, join_type, "Partitioned", False).execute(0, tc)
+
+
+def distributed_sort(tc, table, sort_expr, samples_per_rank=1024, group=None):
+    """SortExec + SortPreservingMergeExec across ranks: range partitioning.
+      1. every rank contributes `samples_per_rank` strided sample rows; all ranks sort the gathered samples and take the
+         same world-1 splitters;
+      2. the local rows and the splitters are sorted TOGETHER (splitters tagged to sort after equal rows): the positions
+         of the splitters in the result are the range boundaries of the locally sorted run;
+      3. range r of every rank goes to rank r (one exchange); the received sorted runs are merged.
+    The result is this rank's range, sorted; ranks hold ascending, non-overlapping ranges (rank order = global order)."""
+    import torch
+    from . import plan as PL
+    from . import expr as E
+    rank, ws = world()
+    if ws == 1:
+        return PL.sort_table(tc, table, sort_expr)
+    t = PL.materialize(tc, table, force=True)
+    schema = t.plain_schema()
+    n = t.num_rows
+    dev = tc.device
+    # 1. samples -> splitters (identical on every rank: same gathered rows in rank order, same stable sort)
+    k = min(n, samples_per_rank)
+    idx = (torch.arange(k, dtype=torch.int64, device=dev) * max(1, n // max(k, 1))).to(torch.int32) if k > 0 else torch.zeros(1, dtype=torch.int32, device=dev)
+    samp = PL.materialize(tc, PL._select_view(tc, t, idx[:k], k), force=True)
+    allsamp = allgather_table(samp, cap=samples_per_rank, group=group)
+    ssorted = PL.materialize(tc, PL.sort_table(tc, allsamp, sort_expr), force=True)
+    m = ssorted.num_rows
+    cut = [min(m - 1, max(0, (j * m) // ws)) for j in range(1, ws)] if m > 0 else []
+    # 2. sort rows + splitters together; tag column: 0 = row, 1 = splitter
+    tag_name = "__gpuq_splitter"
+    def with_tag(tab, val):
+        tagcol = DeviceColumn(tag_name, "Int32", torch.full((max(1, tab.num_rows) + 4,), val, dtype=torch.int32, device=dev).view(torch.uint8), tab.num_rows, nullable=False)
+        return DeviceTable(list(tab.columns) + [tagcol], tab.num_rows)
+    if cut:
+        ci = torch.tensor(cut, dtype=torch.int32, device=dev)
+        spl = PL.materialize(tc, PL._select_view(tc, ssorted, ci, len(cut)), force=True)
+        both = PL.concat_tables(tc, [with_tag(t, 0), with_tag(spl, 1)])
+    else:
+        both = with_tag(t, 0)
+    bs = both.plain_schema()
+    keys = [dict(s, expr=E.rebind(s["expr"], bs)) for s in sort_expr] + [{"expr": E.col(tag_name, bs), "asc": True, "nulls_first": False}]
+    run = PL.sort_table(tc, both, keys)
+    tags = PL.materialize(tc, PL._select_view(tc, DeviceTable([both.columns[-1]], both.num_rows), run.via[0], run.num_rows), force=True)
+    is_spl = PL.filter_table(tc, tags, E.binary(E.col(tag_name, tags.plain_schema()), E.Operator.Eq, E.lit(1, "Int32")))
+    pos = is_spl.via[0][: is_spl.num_rows].tolist() if is_spl.num_rows else []      # positions of the splitters in the sorted run
+    bounds = [0] + [p - j for j, p in enumerate(pos)] + [n]    # boundaries in the run with the splitters removed
+    rows_only = PL.filter_table(tc, run, E.binary(E.col(tag_name, run.plain_schema()), E.Operator.Eq, E.lit(0, "Int32")))
+    rows_only = DeviceTable(rows_only.columns[:-1], rows_only.num_rows, via=rows_only.via, sides=rows_only.sides[:-1])
+    # 3. ranges -> owners, merge the received runs
+    parts = [PL.materialize(tc, PL.slice_table(tc, rows_only, bounds[r], bounds[r + 1] - bounds[r]), force=True) for r in range(ws)]
+    mine = exchange_partitions(parts, group=group, tc=tc)
+    return PL.sort_table(tc, mine, [dict(s, expr=E.rebind(s["expr"], schema)) for s in sort_expr])

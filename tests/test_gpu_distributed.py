@@ -1,0 +1,100 @@
+"""GPU, 2 processes sharing cuda:0: the multi-GPU legs of the path end to end -- hash repartition +
+exchange, partitioned hash join, range-partitioned distributed sort, broadcast -- with every operator running in libgpuq
+and the collectives over gloo (the one-GPU box cannot host two RCCL ranks).  Checked against the oracle on the union of
+the shards.  The RCCL transport itself is exercised by bench.py --gpus N on the driver's 8-GPU node."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pyarrow as pa
+import pytest
+
+from oracle import oracle_np as O
+from test_gpu_operators import norm, rand_table
+from arrow_ballista_amd.expr import col
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _dec(x):
+    if isinstance(x, dict):
+        return int(__import__("decimal").Decimal(x["d"]).scaleb(2)) if "d" in x else float.fromhex(x["f"])
+    return x
+
+
+def _run(world=2):
+    port = str(29700 + os.getpid() % 1500)
+    with tempfile.TemporaryDirectory() as d:
+        outs = [os.path.join(d, "r%d.json" % r) for r in range(world)]
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, outs[r]],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+        logs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=420)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                o, _ = p.communicate()
+            logs.append(o.decode(errors="replace")[-3000:])
+        assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
+        return [{k: [tuple(_dec(x) for x in r) for r in v] for k, v in json.load(open(f)).items()} for f in outs]
+
+
+@pytest.fixture(scope="module")
+def ranks():
+    return _run(2)
+
+
+def _shards():
+    lts = [rand_table(1000 + r, 3000 + 100 * r, 0.2) for r in range(2)]
+    rts = [rand_table(2000 + r, 5000, 0.2) for r in range(2)]
+    rts = [t.rename_columns(["r_" + c for c in t.schema.names]) for t in rts]
+    return lts, rts
+
+
+def _orows(t):
+    return [tuple(r) for r in t.rows()]
+
+
+def test_repartition_exchange_is_a_partition_of_the_union(ranks):
+    lts, _ = _shards()
+    allrows = _orows(O.Table.from_arrow(pa.concat_tables(lts)))
+    got = [r for rk in ranks for r in rk["exchange_rows"]]
+    assert norm(got) == norm(allrows)
+    # both ranks applied the same function of (k64, flag): no key value appears on two ranks
+    keys = [set((r[0], r[6]) for r in rk["exchange_rows"]) for rk in ranks]
+    assert not (keys[0] & keys[1])
+    assert all(len(k) > 0 for k in keys)
+
+
+@pytest.mark.parametrize("jt", ["Inner", "Left"])
+def test_partitioned_hash_join_equals_oracle_join_of_union(ranks, jt):
+    lts, rts = _shards()
+    ol, orr = O.Table.from_arrow(pa.concat_tables(lts)), O.Table.from_arrow(pa.concat_tables(rts))
+    s = [{"name": n} for n in ol.names]
+    pairs = O.hash_join(ol, orr, [({"column": {"name": "k64"}}, {"column": {"name": "r_k64"}})], jt)
+    lrows, rrows = _orows(ol), _orows(orr)
+    exp = [(lrows[i] if i is not None else (None,) * len(ol.names)) + (rrows[j] if j is not None else (None,) * len(orr.names)) for i, j in pairs]
+    got = [r for rk in ranks for r in rk["join_" + jt]]
+    assert len(got) == len(exp)
+    assert norm(got) == norm(exp)
+
+
+def test_distributed_sort_is_globally_ordered(ranks):
+    lts, _ = _shards()
+    ot = O.Table.from_arrow(pa.concat_tables(lts))
+    order = [{"expr": {"column": {"name": "flag"}}, "asc": True, "nulls_first": False}, {"expr": {"column": {"name": "dec"}}, "asc": False, "nulls_first": True}]
+    got = ranks[0]["sort_rows"] + ranks[1]["sort_rows"]            # rank order = global order
+    assert norm(got) == norm(_orows(ot))                            # a permutation of the union
+    gt = O.Table(ot.names, ot.types, [[r[c] for r in got] for c in range(len(ot.names))])
+    keys = O.sort_keys(gt, order)
+    assert all(keys[i] <= keys[i + 1] for i in range(len(keys) - 1))
+    assert len(ranks[0]["sort_rows"]) > 0 and len(ranks[1]["sort_rows"]) > 0     # both ranges are populated
+
+
+def test_broadcast_gives_every_rank_all_rows(ranks):
+    assert ranks[0]["bcast_rows"] == ranks[1]["bcast_rows"]
+    assert len(ranks[0]["bcast_rows"]) == 10 + 11
