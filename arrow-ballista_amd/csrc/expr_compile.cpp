@@ -94,7 +94,7 @@ Schema schema_from_json(const Json& j) {
   const Json& fs = j.is_obj() ? j.at("fields") : j;
   for (const Json& f : fs.a) {
     Field fd; fd.name = f.at("name").str(); fd.type = dtype_from_json(f.at("type"));
-    fd.nullable = f.get_bool("nullable", true); fd.side = (int)f.get_i64("side", 0); fd.raw128 = (int)f.get_i64("raw128", 0);
+    fd.nullable = f.get_bool("nullable", true); fd.side = (int)f.get_i64("side", 0); fd.raw128 = (int)f.get_i64("raw128", 0); fd.dense = (int)f.get_i64("dense", 0);
     s.fields.push_back(fd);
   }
   return s;
@@ -116,7 +116,7 @@ NodeP ExprCompiler::intern(NodeP n) {
 NodeP ExprCompiler::column(int fi) {
   if (fi < 0 || fi >= (int)schema_.fields.size()) throw std::runtime_error("column index " + std::to_string(fi) + " out of range");
   auto n = std::make_shared<Node>();
-  n->kind = Node::COL; n->col = fi; n->type = schema_.fields[fi].type; n->nullable = schema_.fields[fi].nullable || schema_.fields[fi].side > 0;
+  n->kind = Node::COL; n->col = fi; n->type = schema_.fields[fi].type; n->nullable = schema_.fields[fi].nullable || (schema_.fields[fi].side > 0 && !schema_.fields[fi].dense);
   n->bits = type_bits(n->type); n->key = "c" + std::to_string(fi);
   return intern(n);
 }
@@ -575,9 +575,9 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
     const Field& f = schema_.fields[n->col];
     const std::string cs = std::to_string(c);
     std::string nn = "false";
-    if (f.nullable || f.side > 0) {
+    if (f.nullable || (f.side > 0 && !f.dense)) {
       std::string e;
-      if (f.side > 0) e = "!ok" + cs;
+      if (f.side > 0 && !f.dense) e = "!ok" + cs;
       if (f.nullable) e += std::string(e.empty() ? "" : " || ") + "(col" + cs + ".validity && !((vb" + cs + " >> (r" + cs + " & 7)) & 1u))";
       L("const bool n_c" + cs + " = " + e + ";");
       nn = "n_c" + cs;

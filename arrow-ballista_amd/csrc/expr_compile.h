@@ -46,6 +46,7 @@ struct Field {
   bool nullable = true;
   int side = 0;        // 0: addressed by the driving position; k>0: through index vector k
   int raw128 = 0;      // 1: device column is a raw (lo,hi) pair array regardless of the logical type
+  int dense = 0;       // side > 0 only: the index vector never holds NULL_ROW, so going through it adds no nulls
 };
 struct Schema {
   std::vector<Field> fields;

@@ -26,9 +26,18 @@ def world():
 
 
 def allgather_table(table, cap, group=None):
-    """All-gather a small materialised fixed-width table (e.g. partial-aggregate states): every rank
-    receives the concatenation of all ranks' rows.  `cap` = per-rank row capacity (>= max rows)."""
+    """All-gather a small materialised fixed-width table (e.g. partial-aggregate states): every rank receives the
+    concatenation, in rank order, of all ranks' rows.  `cap` = per-rank row capacity (>= max rows on any rank, the SAME
+    value on every rank).
+
+    ONE collective: a rank's row count and all of its column buffers travel as a single fixed-layout record
+    (table.record_layout, a pure function of schema and cap).  An aggregate result produced with output capacity `cap`
+    already IS such a record and is shipped as it lies; anything else is packed into one first.  The received records are
+    not unpacked: the result is a late-materialised view whose columns point into the receive buffer and whose index
+    vectors (one per value width) enumerate the live rows, so q1's merge of partial states costs one all-gather, one
+    count read-back and the upload of the index vectors."""
     import torch
+    from .table import record_layout, RECORD_HEADER
     dist = _dist()
     rank, ws = world()
     if ws == 1:
@@ -41,42 +50,87 @@ def allgather_table(table, cap, group=None):
         # gloo has no device all-gather: stage through host memory (CPU tests / several ranks sharing one GPU)
         host = DeviceTable([DeviceColumn(c.name, c.type, c.data.cpu(), c.length, offsets=c.offsets, validity=c.validity.cpu() if c.validity is not None else None,
                                          nullable=c.nullable, repr=c.repr) for c in table.columns], n)
-        out = allgather_table(host, cap, group=group)
+        out = _materialize_gathered(allgather_table(host, cap, group=group))
         return DeviceTable([DeviceColumn(c.name, c.type, c.data.to(dev), c.length, validity=c.validity.to(dev) if c.validity is not None else None,
                                          nullable=c.nullable, repr=c.repr) for c in out.columns], out.num_rows)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
-    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
-    counts = [int(c.item()) for c in counts]
+    if any(c.offsets is not None for c in table.columns):
+        raise ValueError("allgather_table: materialise Utf8 as PACKED15 first")
+    widths = [type_width(c.type) for c in table.columns]
+    B, lay = record_layout([(w, c.nullable) for w, c in zip(widths, table.columns)], cap)
+    rec = getattr(table, "_record", None)
+    if rec is not None and rec[1] == cap and rec[0].numel() == B and not table.is_view():
+        send = rec[0]
+    else:
+        send = torch.zeros(B, dtype=torch.uint8, device=dev)
+        for c, w, (doff, dbytes, voff, vbytes) in zip(table.columns, widths, lay):
+            k = n * w if w else (n + 7) // 8
+            send[doff: doff + k] = c.data[:k]
+            if voff >= 0:
+                if c.validity is not None:
+                    send[voff: voff + (n + 7) // 8] = c.validity[: (n + 7) // 8]
+                else:
+                    send[voff: voff + (n + 7) // 8] = 255
+    send[:8] = torch.tensor([n], dtype=torch.int64).view(torch.uint8).to(dev, non_blocking=True)
+    recv = torch.empty(ws * B, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    counts = [int(x) for x in recv.view(ws, B)[:, :8].contiguous().view(torch.int64).flatten().tolist()]     # the one host round trip
+    return unpack_records(table.columns, recv, counts, cap)
+
+
+def unpack_records(columns, recv, counts, cap):
+    """Records of len(counts) ranks, back to back in `recv`, as one table of sum(counts) rows in rank order.  `columns`
+    supplies names / types / nullability (any rank's table).  Non-nullable 4/8/16-byte columns are not copied: the result
+    is a view into `recv`."""
+    import torch
+    from .table import record_layout
+    dev = recv.device
+    ws = len(counts)
+    widths = [type_width(c.type) for c in columns]
+    B, lay = record_layout([(w, c.nullable) for w, c in zip(widths, columns)], cap)
+    recs = recv.view(ws, B)
     total = sum(counts)
+    simple = all(w in (4, 8, 16) for w in widths) and not any(c.nullable for c in columns)
+    if simple:
+        # view: element (rank r, row i) of a w-byte column sits at index r * (B / w) + i from the column's first record
+        classes = sorted(set(widths))
+        vias = []
+        for w in classes:
+            idx = [r * (B // w) + i for r, k in enumerate(counts) for i in range(k)] or [0]
+            vias.append(torch.tensor(idx, dtype=torch.int32).to(dev, non_blocking=True))
+        cols = [DeviceColumn(c.name, c.type, recv[doff:], total, nullable=False, repr=c.repr) for c, (doff, _, _, _) in zip(columns, lay)]
+        out = DeviceTable(cols, total, via=vias, sides=[classes.index(w) + 1 for w in widths], dense=True)
+        out._keep = recv
+        return out
+    pad = torch.zeros(16, dtype=torch.uint8, device=dev)
+    shifts = torch.arange(8, dtype=torch.uint8, device=dev)
+    vb = (cap + 7) // 8
+
+    def join_bits(o):
+        # pieces are not byte aligned across ranks: unpack, concatenate, re-pack (tiny arrays)
+        bits = [((recs[r, o: o + vb][:, None] >> shifts[None, :]) & 1).reshape(-1)[:k] for r, k in enumerate(counts)]
+        allb = torch.cat(bits)
+        allb = torch.cat([allb, torch.zeros((-allb.numel()) % 64 + 64, dtype=torch.uint8, device=dev)])
+        return (allb.reshape(-1, 8) << shifts[None, :]).sum(dim=1).to(torch.uint8)
     cols = []
-    for c in table.columns:
-        if c.offsets is not None:
-            raise ValueError("allgather_table: materialise Utf8 as PACKED15 first")
-        w = type_width(c.type)
-        send = torch.zeros(cap * w, dtype=torch.uint8, device=dev)
-        send[: n * w] = c.data[: n * w]
-        recv = [torch.empty(cap * w, dtype=torch.uint8, device=dev) for _ in range(ws)]
-        dist.all_gather(recv, send, group=group)
-        data = torch.cat([r[: k * w] for r, k in zip(recv, counts)] + [torch.zeros(16, dtype=torch.uint8, device=dev)])
-        validity = None
-        if c.validity is not None:
-            # validity bitmaps are re-packed from per-rank bit arrays (rows are not byte aligned across ranks)
-            vb = (cap + 7) // 8
-            vsend = torch.zeros(vb, dtype=torch.uint8, device=dev)
-            vsend[: (n + 7) // 8] = c.validity[: (n + 7) // 8]
-            vrecv = [torch.empty(vb, dtype=torch.uint8, device=dev) for _ in range(ws)]
-            dist.all_gather(vrecv, vsend, group=group)
-            bits = []
-            shifts = torch.arange(8, dtype=torch.uint8, device=dev)
-            for r, k in zip(vrecv, counts):
-                b = ((r[:, None] >> shifts[None, :]) & 1).reshape(-1)[:k]
-                bits.append(b)
-            allb = torch.cat(bits)
-            pad = (-allb.numel()) % 64
-            allb = torch.cat([allb, torch.zeros(pad + 64, dtype=torch.uint8, device=dev)])
-            validity = (allb.reshape(-1, 8) << shifts[None, :]).sum(dim=1).to(torch.uint8)
+    for c, w, (doff, dbytes, voff, vbytes) in zip(columns, widths, lay):
+        data = torch.cat([recs[r, doff: doff + k * w] for r, k in enumerate(counts)] + [pad]) if w else join_bits(doff)
+        validity = join_bits(voff) if voff >= 0 else None
         cols.append(DeviceColumn(c.name, c.type, data, total, validity=validity, nullable=c.nullable, repr=c.repr))
     return DeviceTable(cols, total)
+
+
+def _materialize_gathered(t):
+    """Host-side (CPU tensors) flattening of the view allgather_table returns, for the gloo staging path."""
+    import torch
+    if not t.is_view():
+        return t
+    cols = []
+    for c, sd in zip(t.columns, t.sides):
+        w = type_width(c.type)
+        idx = t.via[sd - 1].to(torch.int64)
+        flat = c.data[: (c.data.numel() // w) * w].view(-1, w)[idx].reshape(-1)
+        cols.append(DeviceColumn(c.name, c.type, torch.cat([flat, torch.zeros(16, dtype=torch.uint8)]), t.num_rows, nullable=False, repr=c.repr))
+    return DeviceTable(cols, t.num_rows)
 
 
 def _a2a(send, send_splits, recv_splits, dev, group=None):

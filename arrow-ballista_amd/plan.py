@@ -19,7 +19,7 @@ import uuid
 
 from . import binding as B
 from . import expr as E
-from .table import DeviceColumn, DeviceTable, type_id, type_json, type_width
+from .table import DeviceColumn, DeviceTable, record_layout, type_id, type_json, type_width
 
 NULL_ROW = 0xFFFFFFFF
 
@@ -58,7 +58,7 @@ class TaskContext:
 
 def table_sig(table):
     """Cheap hashable signature of a table's layout (what a compiled operator depends on)."""
-    return (len(table.via),) + tuple((c.name, c.type if isinstance(c.type, str) else (c.type["Decimal128"][0], c.type["Decimal128"][1]),
+    return (len(table.via), table.dense) + tuple((c.name, c.type if isinstance(c.type, str) else (c.type["Decimal128"][0], c.type["Decimal128"][1]),
                                       c.nullable, sd, c.repr) for c, sd in zip(table.columns, table.sides))
 
 
@@ -76,32 +76,24 @@ class Metrics:
 
 # ---------------------------------------------------------------------------------- helpers
 def _alloc_outputs(op, n, device):
-    """Allocate caller-side output columns for op.fields with capacity n rows: one device allocation, sliced per buffer
-    (256-byte aligned pieces)."""
+    """Allocate caller-side output columns for op.fields with capacity n rows: one device allocation laid out by
+    table.record_layout.  Returns (columns, C array, record buffer)."""
     torch = _torch()
     nf = len(op.fields)
     lay = op.__dict__.get("_out_layout")
     if lay is None:
-        # per field: (type json, is_bool, width, nullable, repr, name)
-        lay = op._out_layout = [(type_json(f["type"], f["precision"], f["scale"]), f["type"] == B.T_BOOL, f["width"], f["nullable"], f["repr"], f["name"]) for f in op.fields]
-    bm = ((n + 63) // 64) * 8 + 8
-    sizes = []
-    for tj, is_bool, width, nullable, rp, name in lay:
-        sizes.append(bm if is_bool else max(1, n) * width + 16)
-        sizes.append(bm if nullable else 0)         # every validity word is written by the kernel
-    offs, total = [], 0
-    for sz in sizes:
-        offs.append(total)
-        total += (sz + 255) & ~255
-    buf = torch.empty(max(total, 256), dtype=torch.uint8, device=device)
+        # per field: (type json, width (0 = Boolean), nullable, repr, name)
+        lay = op._out_layout = [(type_json(f["type"], f["precision"], f["scale"]), 0 if f["type"] == B.T_BOOL else f["width"], f["nullable"], f["repr"], f["name"]) for f in op.fields]
+    total, pieces = record_layout([(w, nl) for _, w, nl, _, _ in lay], n)
+    buf = torch.empty(total, dtype=torch.uint8, device=device)
     cols, arr = [], (B.gpuq_column * max(1, nf))()
-    for i, (tj, is_bool, width, nullable, rp, name) in enumerate(lay):
-        data = buf[offs[2 * i]: offs[2 * i] + sizes[2 * i]]
-        validity = buf[offs[2 * i + 1]: offs[2 * i + 1] + sizes[2 * i + 1]] if nullable else None
+    for i, ((tj, width, nullable, rp, name), (doff, dbytes, voff, vbytes)) in enumerate(zip(lay, pieces)):
+        data = buf[doff: doff + dbytes]
+        validity = buf[voff: voff + vbytes] if nullable else None       # every validity word is written by the kernel
         col = DeviceColumn(name, tj, data, n, validity=validity, nullable=nullable, repr=rp)
         cols.append(col)
         arr[i] = col.to_c()
-    return cols, arr
+    return cols, arr, buf
 
 
 def _project(tc, table, exprs, names, memo_key=None, memo=None):
@@ -123,7 +115,7 @@ def _project(tc, table, exprs, names, memo_key=None, memo=None):
         if memo_key is not None:
             memo[mk] = op
     n = table.num_rows
-    cols, arr = _alloc_outputs(op, n, tc.device)
+    cols, arr, _ = _alloc_outputs(op, n, tc.device)
     inp, keep = table.input_struct()
     tc.ctx.check(tc.ctx.L.gpuq_project_run(op.h, tc.stream_ptr(), C.byref(inp), arr, len(cols)))
     return DeviceTable(cols, n)
@@ -166,7 +158,7 @@ def materialize(tc, table, force=False):
     out = []
     for a in range(0, len(sch), 12):
         idxs = list(range(a, min(a + 12, len(sch))))
-        sub = DeviceTable([table.columns[i] for i in idxs], table.num_rows, via=table.via, sides=[table.sides[i] for i in idxs])
+        sub = DeviceTable([table.columns[i] for i in idxs], table.num_rows, via=table.via, sides=[table.sides[i] for i in idxs], dense=table.dense)
         def mk(sub=sub):
             ss = sub.plain_schema()
             return [E.col(f["name"], index=i) for i, f in enumerate(ss)], [f["name"] for f in ss]
@@ -478,7 +470,7 @@ class AggregateExec(ExecutionPlan):
         op = self._memo.get(mk)
         if op is None:
             op = self._memo[mk] = context.op(self._descriptor(table.schema(), pred, m))
-        out = aggregate_table(context, table, op.descriptor, op=op)
+        out = aggregate_table(context, table, op.descriptor, cap=getattr(self, "output_capacity", None), op=op)
         return self._timed(t0, out)
 
 
@@ -489,7 +481,7 @@ def aggregate_table(tc, table, descriptor, cap=None, op=None):
         cap = 4096 if not descriptor["group_expr"] else max(4096, min(n, 1 << 22))
     inp, keep = table.input_struct()
     while True:
-        cols, arr = _alloc_outputs(op, cap, tc.device)
+        cols, arr, buf = _alloc_outputs(op, cap, tc.device)
         ng = C.c_int64(0)
         rc = tc.ctx.L.gpuq_aggregate_run(op.h, tc.stream_ptr(), C.byref(inp), arr, len(cols), cap, C.byref(ng))
         if rc == 4 and ng.value > cap:
@@ -499,7 +491,9 @@ def aggregate_table(tc, table, descriptor, cap=None, op=None):
         break
     for c in cols:
         c.set_length(ng.value)
-    return DeviceTable(cols, ng.value)
+    out = DeviceTable(cols, ng.value)
+    out._record = (buf, cap)          # all columns live in one allocation of known layout (parallel.allgather_table)
+    return out
 
 
 class HashJoinExec(ExecutionPlan):

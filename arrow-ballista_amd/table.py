@@ -25,6 +25,29 @@ def type_width(t):
     return {B.T_INT32: 4, B.T_DATE32: 4, B.T_UINT32: 4, B.T_INT64: 8, B.T_UINT64: 8, B.T_FLOAT64: 8, B.T_DECIMAL128: 16, B.T_UTF8: 16}.get(tid, 0)
 
 
+RECORD_HEADER = 256
+
+
+def record_layout(specs, n):
+    """Byte layout of `n`-row output columns inside ONE device allocation ("record"): a 256-byte header (word 0 = row
+    count, filled in by whoever ships the record), then per column its data and, when nullable, its validity bitmap, each
+    256-byte aligned.  specs: [(width_bytes or 0 for bit-packed Boolean, nullable)].  Pure function of (specs, n): every
+    rank computes the same layout, which is what lets parallel.allgather_table ship a whole result in one collective.
+    Returns (total_bytes, [(data_off, data_bytes, validity_off or -1, validity_bytes)])."""
+    bm = ((n + 63) // 64) * 8 + 8
+    out, off = [], RECORD_HEADER
+    for width, nullable in specs:
+        dbytes = bm if width == 0 else max(1, n) * width + 16
+        doff = off
+        off += (dbytes + 255) & ~255
+        voff = -1
+        if nullable:
+            voff = off
+            off += (bm + 255) & ~255
+        out.append((doff, dbytes, voff, bm if nullable else 0))
+    return off, out
+
+
 def _torch():
     import torch
     return torch
@@ -38,8 +61,10 @@ class DeviceColumn:
         self.offsets, self.validity, self.repr = offsets, validity, repr
         self.nullable = (validity is not None) if nullable is None else bool(nullable)
 
-    def field(self, side=0):
+    def field(self, side=0, dense=False):
         f = {"name": self.name, "type": self.type, "nullable": bool(self.nullable), "side": int(side)}
+        if side > 0 and dense:
+            f["dense"] = 1
         if self.repr == B.REPR_PACKED15:
             f["raw128"] = 1
         return f
@@ -73,18 +98,19 @@ class DeviceColumn:
 class DeviceTable:
     """Columns + optional index vectors (a late-materialised view: column i is read at via[side_i-1][pos])."""
 
-    def __init__(self, columns, num_rows, via=None, sides=None):
+    def __init__(self, columns, num_rows, via=None, sides=None, dense=False):
         self.columns = list(columns)
         self.num_rows = int(num_rows)
         self.via = list(via or [])            # uint32-as-int32 tensors of length num_rows
         self.sides = list(sides) if sides is not None else [0] * len(self.columns)
+        self.dense = bool(dense)              # no index vector holds NULL_ROW: reading through them adds no nulls
 
     # ---- schema
     def schema(self):
-        return [c.field(s) for c, s in zip(self.columns, self.sides)]
+        return [c.field(s, self.dense) for c, s in zip(self.columns, self.sides)]
 
     def plain_schema(self):
-        return [{"name": c.name, "type": c.type, "nullable": bool(c.nullable or s > 0)} for c, s in zip(self.columns, self.sides)]
+        return [{"name": c.name, "type": c.type, "nullable": bool(c.nullable or (s > 0 and not self.dense))} for c, s in zip(self.columns, self.sides)]
 
     def column(self, name):
         for c in self.columns:

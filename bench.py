@@ -61,23 +61,13 @@ def main():
     lineitem = T.gen_lineitem_device(tc, n, seed=T.SEED_LINEITEM, seed_orders=T.SEED_ORDERS, row0=rank * n)
 
     # ---- plans (built once; compiled operators are cached in the TaskContext)
-    full = T.q1_plan(g.MemoryExec([lineitem]), two_phase=True)
-    node = full
-    chain = []
-    while True:
-        chain.append(node)
-        if isinstance(node, g.AggregateExec) and node.mode == "Partial":
-            break
-        node = node.children()[0]
-    partial = node
-    final_agg = next(c for c in chain if isinstance(c, g.AggregateExec) and c.mode == "FinalPartitioned")
-    final_src = g.MemoryExec([None], schema=partial.schema())
-    final_agg.input = final_src
+    STATE_CAP = 64      # rows of partial-aggregate state a rank ships; the same on every rank (fixes the record layout)
+    partial, full, final_src = T.q1_split_plan(lineitem, STATE_CAP)
 
     def step():
         states = partial.execute(0, tc)                    # fused filter+project+partial aggregate
         if world > 1:
-            states = parallel.allgather_table(states, cap=64)
+            states = parallel.allgather_table(states, cap=STATE_CAP)
         final_src.partitions[0] = states
         return g.plan.materialize(tc, full.execute(0, tc))   # final aggregate + projection + sort
 

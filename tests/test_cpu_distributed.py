@@ -62,7 +62,17 @@ def _worker(rank, world, port, q):
         merged = O.aggregate(O.Table(["g", "s"], ["Int64", "Int64"], [ag, [s if b else None for s, b in zip(asum, bits)]]),
                              [({"column": {"name": "g"}}, "g")], [{"fn": "SUM", "expr": None, "name": "s"}], "Final")
         ok4 = sorted(merged.rows()) == [(10, 300), (11, 201), (12, 202)]
-        q.put((rank, ok1, ok2, ok3, ok4))
+        # ---- the zero-copy path: non-nullable columns come back as a view into the receive buffer
+        st2 = g.DeviceTable([g.DeviceColumn("g", "Int64", torch.cat([gkeys.view(torch.uint8), torch.zeros(16, dtype=torch.uint8)]), ng, nullable=False),
+                             g.DeviceColumn("c", "Int32", torch.cat([torch.arange(ng, dtype=torch.int32).view(torch.uint8) + 0, torch.zeros(16, dtype=torch.uint8)]), ng, nullable=False),
+                             g.DeviceColumn("d", {"Decimal128": [20, 2]}, torch.cat([torch.stack([sums, torch.zeros_like(sums)], 1).reshape(-1).view(torch.uint8), torch.zeros(16, dtype=torch.uint8)]), ng, nullable=False)], ng)
+        v = parallel.allgather_table(st2, cap=8)
+        ok5 = v.is_view() and len(v.via) == 3 and v.sides == [2, 1, 3]
+        flat = parallel._materialize_gathered(v)
+        ok5 = ok5 and flat.columns[0].data[: flat.num_rows * 8].view(torch.int64).tolist() == exp_g
+        ok5 = ok5 and flat.columns[1].data[: flat.num_rows * 4].view(torch.int32).tolist() == [0, 1, 0, 1, 2]
+        ok5 = ok5 and flat.columns[2].data[: flat.num_rows * 16].view(torch.int64)[0::2].tolist() == exp_s
+        q.put((rank, ok1, ok2, ok3, ok4 and ok5))
     finally:
         dist.destroy_process_group()
 

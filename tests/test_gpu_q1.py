@@ -36,3 +36,28 @@ def test_generator_matches_oracle_restatement(tc):
         assert d[:nb].tobytes() == h.view(np.uint8)[:nb].tobytes(), c.name
         if c.offsets is not None:
             assert (c.offsets.cpu().numpy()[: n + 1] == host[c.name + "_off"]).all()
+
+
+def test_q1_rank_records_merge_as_in_bench(tc):
+    """bench.py's N>1 step replayed on one GPU: the partial-aggregate results of two shards are fixed-layout records; laid
+    back to back (what RCCL's all-gather delivers) they are read in place by the final aggregate through a view."""
+    import torch
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd import parallel
+    n = 150_000
+    recs, counts, cols0 = [], [], None
+    for r in range(2):
+        li = T.gen_lineitem_device(tc, n, seed=T.SEED_LINEITEM, seed_orders=T.SEED_ORDERS, row0=r * n)
+        partial, full, final_src = T.q1_split_plan(li, 64)
+        st = partial.execute(0, tc)
+        buf, cap = st._record
+        assert cap == 64 and not st.is_view()
+        buf[:8] = torch.tensor([st.num_rows], dtype=torch.int64).view(torch.uint8).to(buf.device)    # header word written by allgather_table
+        recs.append(buf); counts.append(st.num_rows); cols0 = st.columns
+    recv = torch.cat(recs)
+    assert recv.view(2, -1)[:, :8].contiguous().view(torch.int64).flatten().tolist() == counts
+    merged = parallel.unpack_records(cols0, recv, counts, 64)
+    assert merged.is_view() and merged.num_rows == sum(counts)
+    final_src.partitions[0] = merged
+    got = T.q1_result_to_rows(tc, g.plan.materialize(tc, full.execute(0, tc)))
+    assert got == T.q1_oracle_rows(2 * n)

@@ -201,6 +201,27 @@ def q1_plan(source, two_phase=True, strategy="auto"):
                        {"expr": col("l_linestatus", so), "asc": True, "nulls_first": False}], out)
 
 
+def q1_split_plan(lineitem, state_capacity=64):
+    """q1 as bench.py drives it on N ranks: (partial, full, final_src).  partial = the per-rank stage (fused filter +
+    projection + partial aggregate) whose result is a fixed-layout record of `state_capacity` rows; full = the rest of the
+    plan (final aggregate, projection, sort) reading its input from final_src.partitions[0]."""
+    import arrow_ballista_amd as g
+    full = q1_plan(g.MemoryExec([lineitem]), two_phase=True)
+    node = full
+    chain = []
+    while True:
+        chain.append(node)
+        if isinstance(node, g.AggregateExec) and node.mode == "Partial":
+            break
+        node = node.children()[0]
+    partial = node
+    partial.output_capacity = state_capacity
+    final_agg = next(c for c in chain if isinstance(c, g.AggregateExec) and c.mode == "FinalPartitioned")
+    final_src = g.MemoryExec([None], schema=partial.schema())
+    final_agg.input = final_src
+    return partial, full, final_src
+
+
 def run_q1(tc, lineitem, two_phase=True, strategy="auto"):
     import arrow_ballista_amd as g
     plan = q1_plan(g.MemoryExec([lineitem]), two_phase, strategy)
