@@ -232,49 +232,103 @@ __global__ void __launch_bounds__(SBLOCK) k_radix_hist(const u64* __restrict__ k
 #endif
 
 #ifndef GPUQ_JIT
+// Scatter with the tile sorted by digit in LDS first, so that a block writes every digit's run as consecutive addresses
+// (a lane-per-key scatter sends each of a wave's 64 stores to a different cache line: 1.1 TB/s on 2^27 rows).
+// The block walks its range in sub-tiles of RTILE keys.  Per sub-tile: every wave owns a contiguous quarter and takes it
+// in RROUNDS steps of 64 keys held in registers; a match-any over the digit bits gives each key its stable rank inside
+// the step, per-(wave, digit) counters in LDS carry the ranks across steps; one 256-wide scan turns the counters into
+// tile-local positions; keys and values go to their sorted place in LDS and are written out position by position.
+// Order inside a digit = (block, sub-tile, wave, step, lane) = input order: the pass is stable.
+constexpr int RROUNDS = 16;
+constexpr int RTILE = SBLOCK * RROUNDS;            // 4096 keys: 32 KB keys + 16 KB values in LDS
 __global__ void __launch_bounds__(SBLOCK) k_radix_scatter(const u64* __restrict__ keys, const uint32_t* __restrict__ vals, const i64 n,
                                                           const int shift, const uint32_t mask, const i64 tile,
                                                           const int32_t* __restrict__ offsets, const int nblocks,
                                                           u64* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-  __shared__ uint32_t wcnt[SWAVES][RADIX];   // per-wave digit counts, then running bases
-  for (int i = threadIdx.x; i < SWAVES * RADIX; i += SBLOCK) (&wcnt[0][0])[i] = 0;
-  __syncthreads();
+  __shared__ u64 sk[RTILE];
+  __shared__ uint32_t sv[RTILE];
+  __shared__ uint32_t wcnt[SWAVES][RADIX];   // per-wave digit counts of the sub-tile, then the waves' start positions
+  __shared__ uint32_t dstart[RADIX];         // tile-local start of every digit
+  __shared__ uint32_t gbase[RADIX];          // global position of the next key of every digit
+  __shared__ uint32_t wsum[SWAVES];
+  const int t = threadIdx.x, w = swave(), l = slane();
+  const u64 lt = (1ull << l) - 1;
+  for (int d = t; d < RADIX; d += SBLOCK) gbase[d] = (uint32_t)offsets[(size_t)d * nblocks + blockIdx.x];
   const i64 a = (i64)blockIdx.x * tile;
   i64 b = a + tile; if (b > n) b = n;
-  const i64 span = b > a ? b - a : 0;
-  const i64 per = ((span + SWAVES - 1) / SWAVES + 63) & ~(i64)63;
-  const i64 wa = a + per * swave();
-  i64 wb = wa + per; if (wb > b) wb = b;
-  // pass A: per-wave digit counts
-  for (i64 i = wa + slane(); i < wb; i += 64) atomicAdd(&wcnt[swave()][(uint32_t)(keys[i] >> shift) & mask], 1u);
-  __syncthreads();
-  // bases: global offset of (digit, block) + counts of earlier waves
-  for (int d = threadIdx.x; d < RADIX; d += SBLOCK) {
-    uint32_t run = (uint32_t)offsets[(size_t)d * nblocks + blockIdx.x];
-    for (int q = 0; q < SWAVES; ++q) { const uint32_t c = wcnt[q][d]; wcnt[q][d] = run; run += c; }
-  }
-  __syncthreads();
-  // pass B: stable ranks inside each 64-key step through a match-any over the 8 digit bits
-  for (i64 i0 = wa; i0 < wb; i0 += 64) {
-    const i64 i = i0 + slane();
-    const bool act = i < wb;
-    u64 k = 0; uint32_t v = 0; uint32_t d = 0;
-    if (act) { k = keys[i]; v = vals[i]; d = (uint32_t)(k >> shift) & mask; }
-    u64 same = __ballot(act);
+  for (i64 s0 = a; s0 < b; s0 += RTILE) {
+    for (int i = t; i < SWAVES * RADIX; i += SBLOCK) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+    // 1. load the wave's quarter, rank every key inside its (wave, digit) sequence
+    const i64 w0 = s0 + (i64)w * (RTILE / SWAVES);
+    u64 k[RROUNDS]; uint32_t v[RROUNDS]; uint32_t pos[RROUNDS];
 #pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
-      const u64 m = __ballot((d >> bit) & 1);
-      same &= ((d >> bit) & 1) ? m : ~m;
+    for (int r = 0; r < RROUNDS; ++r) {
+      const i64 i = w0 + r * 64 + l;
+      const bool act = i < b;
+      k[r] = act ? keys[i] : 0; v[r] = act ? vals[i] : 0;
     }
-    if (act) {
-      const uint32_t rank = (uint32_t)__popcll(same & ((1ull << slane()) - 1));
-      const uint32_t base = wcnt[swave()][d];
-      keys_out[base + rank] = k; vals_out[base + rank] = v;
+#pragma unroll
+    for (int r = 0; r < RROUNDS; ++r) {
+      const i64 i = w0 + r * 64 + l;
+      const bool act = i < b;
+      const uint32_t d = (uint32_t)(k[r] >> shift) & mask;
+      u64 same = __ballot(act);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const u64 m = __ballot((d >> bit) & 1);
+        same &= ((d >> bit) & 1) ? m : ~m;
+      }
+      const uint32_t before = act ? wcnt[w][d] : 0;
+      pos[r] = before + (uint32_t)__popcll(same & lt);
+      __builtin_amdgcn_wave_barrier();
+      if (act && (same >> l) <= 1ull) wcnt[w][d] = before + (uint32_t)__popcll(same);   // highest lane of each digit group
+      __builtin_amdgcn_wave_barrier();
     }
-    // the wave is the only writer of its row: bump each digit once (highest lane of each group)
-    __builtin_amdgcn_wave_barrier();
-    if (act && (same >> slane()) <= 1ull) wcnt[swave()][d] += (uint32_t)__popcll(same);
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    // 2. tile-local layout: digit-major, wave-minor (t == digit)
+    {
+      uint32_t c[SWAVES]; uint32_t tot = 0;
+#pragma unroll
+      for (int q = 0; q < SWAVES; ++q) { c[q] = wcnt[q][t]; tot += c[q]; }
+      uint32_t x = tot;                           // inclusive scan over the block's 256 digits
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (l >= off) x += y; }
+      if (l == 63) wsum[w] = x;
+      __syncthreads();
+      uint32_t pre = 0;
+#pragma unroll
+      for (int q = 0; q < SWAVES; ++q) if (q < w) pre += wsum[q];
+      const uint32_t ds = pre + x - tot;
+      dstart[t] = ds;
+      uint32_t run = ds;
+#pragma unroll
+      for (int q = 0; q < SWAVES; ++q) { wcnt[q][t] = run; run += c[q]; }
+    }
+    __syncthreads();
+    // 3. keys to their sorted place in LDS
+#pragma unroll
+    for (int r = 0; r < RROUNDS; ++r) {
+      const i64 i = w0 + r * 64 + l;
+      if (i < b) { const uint32_t d = (uint32_t)(k[r] >> shift) & mask; const uint32_t j = wcnt[w][d] + pos[r]; sk[j] = k[r]; sv[j] = v[r]; }
+    }
+    __syncthreads();
+    // 4. out, position by position: neighbouring lanes hold neighbouring keys of the same digit
+    const int cnt = (int)((b - s0) < RTILE ? (b - s0) : RTILE);
+#pragma unroll 4
+    for (int j = t; j < cnt; j += SBLOCK) {
+      const u64 kk = sk[j];
+      const uint32_t d = (uint32_t)(kk >> shift) & mask;
+      const uint32_t dst = gbase[d] + ((uint32_t)j - dstart[d]);
+      keys_out[dst] = kk; vals_out[dst] = sv[j];
+    }
+    __syncthreads();
+    // 5. advance the global bases by the sub-tile's digit totals
+    {
+      const uint32_t nxt = (t + 1 < RADIX) ? dstart[t + 1] : (uint32_t)cnt;
+      gbase[t] += nxt - dstart[t];
+    }
+    __syncthreads();
   }
 }
 #endif
