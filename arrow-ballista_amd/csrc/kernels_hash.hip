@@ -159,20 +159,45 @@ template <int MAXC>
 __device__ __forceinline__ void k_agg_hash_body(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T) {
   const i64 nwords = (n + 63) >> 6;
   const int cell0 = 1 + T.key_words;
+  // Rows with equal keys in neighbouring lanes (clustered input: lineitem rows of one order, a join's probe-ordered
+  // output) are combined inside the wave by a segmented scan; only the last lane of each run touches the table.  Every
+  // table access is a device-scope transaction (~10 G/s on this part), so a run of r rows costs 1/r of the traffic.
+  bool combine = true;
+  for (int a = 0; a < A.n_accs; ++a) combine = combine && A.acc_kind[a] != ACC_FMIN && A.acc_kind[a] != ACC_FMAX;
+  const int lane = hlane();
   for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
-    const i64 pos = (w << 6) + hlane();
+    const i64 pos = (w << 6) + lane;
     bool active = pos < n;
     GPUQ_REGS_DECL;
     if (active) active = GPUQ_EVAL(MAXC, P, pos);
-    if (!active) continue;
-    u64 kw[MAX_KW]; u64 h;
+    if (__ballot(active) == 0) continue;
+    u64 kw[MAX_KW]; u64 h = 0;
 #pragma unroll
     for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
-    make_key(K, GPUQ_REGS, kw, h);
-    bool inserted;
-    const u64 s = ht_find_or_insert(T, kw, h, 0u, inserted);
-    if (s == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
-    u64* cells = T.slots + s * (u64)T.slot_words + cell0;
+    if (active) make_key(K, GPUQ_REGS, kw, h);
+    // head[i]: lane i starts a run (its key differs from lane i-1's, or lane i-1 is not an active row)
+    // every cross-lane read below is executed by ALL lanes and only then combined: a shuffle under a short-circuit
+    // (`lane > 0 && shfl(..)`) runs with some lanes masked off, and a masked-off source lane reads as 0
+    bool head = true;
+    if (combine) {
+      const int pa = __shfl_up((int)active, 1);
+      const u64 ph = __shfl_up(h, 1);
+      bool eq = (pa != 0) & (lane > 0) & (ph == h);
+#pragma unroll
+      for (int q = 0; q < MAX_KW; ++q) { const u64 pk = __shfl_up(kw[q], 1); if (q < T.key_words) eq = eq & (pk == kw[q]); }
+      head = !(active & eq);
+    }
+    const int nh = __shfl_down((int)head, 1);
+    const bool next_head = (lane == 63) | (nh != 0);
+    const bool tail = active & next_head;
+    u64 s = ~0ull;
+    if (tail) {
+      bool inserted;
+      s = ht_find_or_insert(T, kw, h, 0u, inserted);
+      if (s == ~0ull) atomicOr(P.flags, FLAG_TABLE_FULL);
+    }
+    u64* cells = T.slots + (s == ~0ull ? 0 : s) * (u64)T.slot_words + cell0;
+    const bool upd = tail && s != ~0ull;
     for (int a = 0; a < A.n_accs; ++a) {
       const int kind = A.acc_kind[a];
       u64 vlo = 1, vhi = 0; bool vnull = false;
@@ -180,25 +205,54 @@ __device__ __forceinline__ void k_agg_hash_body(const DevProgram P, const i64 n,
         const int r = __builtin_amdgcn_readfirstlane(A.acc_reg[a]);
         vlo = rlo[r]; vhi = rhi[r]; vnull = (rnulls >> r) & 1;
       }
-      if (vnull) continue;
+      if (!active) vnull = true;
+      bool wide = false;      // MIN/MAX over a value outside int64
+      // identity for rows that do not contribute
+      switch (kind) {
+        case ACC_COUNT: case ACC_COUNT_STAR: vlo = vnull ? 0 : 1; vhi = 0; break;
+        case ACC_SUM: if (vnull) { vlo = 0; vhi = 0; } break;
+        case ACC_MIN: wide = !vnull && (i64)vhi != ((i64)vlo >> 63); if (vnull) vlo = 0x7FFFFFFFFFFFFFFFull; break;
+        case ACC_MAX: wide = !vnull && (i64)vhi != ((i64)vlo >> 63); if (vnull) vlo = 0x8000000000000000ull; break;
+        case ACC_FSUM: if (vnull) vlo = 0; break;
+        default: break;
+      }
+      if (__ballot(wide)) { if (wide) atomicOr(P.flags, FLAG_WIDE_MINMAX); continue; }
+      bool any = !vnull;        // does the run hold at least one contributing row
+      if (combine) {
+        bool f = head;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const u64 ulo = __shfl_up(vlo, off), uhi = __shfl_up(vhi, off);
+          const bool uf = __shfl_up((int)f, off) != 0, uany = __shfl_up((int)any, off) != 0;
+          if (lane >= off && !f) {
+            switch (kind) {
+              case ACC_COUNT: case ACC_COUNT_STAR: vlo += ulo; break;
+              case ACC_SUM: { const u64 sl = vlo + ulo; vhi = vhi + uhi + (sl < vlo ? 1 : 0); vlo = sl; break; }
+              case ACC_MIN: if ((i64)ulo < (i64)vlo) vlo = ulo; break;
+              case ACC_MAX: if ((i64)ulo > (i64)vlo) vlo = ulo; break;
+              case ACC_FSUM: vlo = (u64)__double_as_longlong(__longlong_as_double((i64)ulo) + __longlong_as_double((i64)vlo)); break;
+              default: break;
+            }
+            any = any || uany;
+            f = uf;
+          }
+        }
+      }
+      if (!upd || !any) continue;
       u64* c = cells + 2 * a;
       switch (kind) {
-        case ACC_COUNT: case ACC_COUNT_STAR: a_add(c, 1); break;
+        case ACC_COUNT: case ACC_COUNT_STAR: a_add(c, vlo); break;
         case ACC_SUM: {
           const u64 old = a_add(c, vlo);
           const u64 carry = (old + vlo < old) ? 1 : 0;
           if (vhi + carry) a_add(c + 1, vhi + carry);
           break;
         }
-        case ACC_MIN: case ACC_MAX: {
-          if ((i64)vhi != ((i64)vlo >> 63)) { atomicOr(P.flags, FLAG_WIDE_MINMAX); break; }
-          if (kind == ACC_MIN) __hip_atomic_fetch_min((i64*)c, (i64)vlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else __hip_atomic_fetch_max((i64*)c, (i64)vlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
+        case ACC_MIN: __hip_atomic_fetch_min((i64*)c, (i64)vlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+        case ACC_MAX: __hip_atomic_fetch_max((i64*)c, (i64)vlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
         case ACC_FSUM: unsafeAtomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;
         case ACC_FMIN: case ACC_FMAX: {
-          // total-order min/max through a CAS loop on the bit pattern
+          // total-order min/max through a CAS loop on the bit pattern (never combined: every row is its own run)
           u64 cur = a_load(c);
           for (;;) {
             const bool better = (kind == ACC_FMIN) ? (f64_total_key(vlo) < f64_total_key(cur)) : (f64_total_key(vlo) > f64_total_key(cur));
@@ -226,37 +280,55 @@ extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevPro
 #ifndef GPUQ_JIT
 __global__ void __launch_bounds__(HBLOCK) k_agg_hash_extract(const KeySpec K, const AggSpec A, const HashTable T, const AggOut out,
                                                              uint32_t* __restrict__ flags) {
+  // A wave claims output rows for XSUB x 64 slots with ONE atomic on the group counter (one atomic per 64 slots made a
+  // 2^26-slot table cost 18 ms: ~17 ns per serialised device-scope atomic).  Output order is arbitrary anyway.
+  constexpr int XSUB = 16;
   const int cell0 = 1 + T.key_words;
   const int kstride = K.n_keys > 0 ? K.n_keys : 1;
-  const u64 rounds = (T.n_slots + (u64)gridDim.x * HBLOCK - 1) / ((u64)gridDim.x * HBLOCK);
-  for (u64 it = 0; it < rounds; ++it) {
-    const u64 s = (it * gridDim.x + blockIdx.x) * HBLOCK + threadIdx.x;
-    bool live = false;
-    const u64* slot = nullptr;
-    if (s < T.n_slots) { slot = T.slots + s * (u64)T.slot_words; live = ((uint32_t)slot[0]) >= 2u; }
-    const u64 m = __ballot(live);
-    if (m == 0) continue;
-    uint32_t base = 0;
-    if (hlane() == 0) base = atomicAdd(out.n_groups, (uint32_t)__popcll(m));
-    base = __shfl(base, 0);
-    if (!live) continue;
-    const uint32_t g = base + (uint32_t)__popcll(m & ((1ull << hlane()) - 1));
-    if (g >= (uint32_t)out.cap) { atomicOr(flags, FLAG_GROUP_OVERFLOW); continue; }
-    int w = 0;
-    for (int k = 0; k < K.n_keys; ++k) {
-      const u64 lo = slot[1 + w]; ++w;
-      u64 hi = (u64)((i64)lo >> 63);
-      if (K.key_wide[k]) { hi = slot[1 + w]; ++w; }
-      out.keys[((size_t)g * kstride + k) * 2] = lo;
-      out.keys[((size_t)g * kstride + k) * 2 + 1] = hi;
+  const u64 chunk_slots = 64ull * XSUB;
+  const u64 nchunks = (T.n_slots + chunk_slots - 1) / chunk_slots;
+  const u64 wave0 = (u64)blockIdx.x * HWAVES + hwave(), nwaves = (u64)gridDim.x * HWAVES;
+  const u64 ltmask = (1ull << hlane()) - 1;
+  for (u64 c = wave0; c < nchunks; c += nwaves) {
+    u64 masks[XSUB]; uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < XSUB; ++j) {
+      const u64 s = c * chunk_slots + (u64)j * 64 + hlane();
+      const bool live = s < T.n_slots && ((uint32_t)T.slots[s * (u64)T.slot_words]) >= 2u;
+      masks[j] = __ballot(live); total += (uint32_t)__popcll(masks[j]);
     }
-    out.key_nulls[g] = K.null_word ? (uint32_t)slot[1 + w] : 0u;
-    for (int a = 0; a < A.n_accs; ++a) {
-      u64 lo = slot[cell0 + 2 * a], hi = slot[cell0 + 2 * a + 1];
-      const int kind = A.acc_kind[a];
-      if (kind == ACC_MIN || kind == ACC_MAX) hi = (u64)((i64)lo >> 63);
-      out.cells[((size_t)g * A.n_accs + a) * 2] = lo;
-      out.cells[((size_t)g * A.n_accs + a) * 2 + 1] = hi;
+    if (total == 0) continue;
+    uint32_t base = 0;
+    if (hlane() == 0) base = atomicAdd(out.n_groups, total);
+    base = __shfl(base, 0);
+#pragma unroll
+    for (int j = 0; j < XSUB; ++j) {
+      const u64 m = masks[j];
+      if ((m >> hlane()) & 1) {
+        const u64 s = c * chunk_slots + (u64)j * 64 + hlane();
+        const u64* slot = T.slots + s * (u64)T.slot_words;
+        const uint32_t g = base + (uint32_t)__popcll(m & ltmask);
+        if (g >= (uint32_t)out.cap) { atomicOr(flags, FLAG_GROUP_OVERFLOW); }
+        else {
+          int w = 0;
+          for (int k = 0; k < K.n_keys; ++k) {
+            const u64 lo = slot[1 + w]; ++w;
+            u64 hi = (u64)((i64)lo >> 63);
+            if (K.key_wide[k]) { hi = slot[1 + w]; ++w; }
+            out.keys[((size_t)g * kstride + k) * 2] = lo;
+            out.keys[((size_t)g * kstride + k) * 2 + 1] = hi;
+          }
+          out.key_nulls[g] = K.null_word ? (uint32_t)slot[1 + w] : 0u;
+          for (int a = 0; a < A.n_accs; ++a) {
+            u64 lo = slot[cell0 + 2 * a], hi = slot[cell0 + 2 * a + 1];
+            const int kind = A.acc_kind[a];
+            if (kind == ACC_MIN || kind == ACC_MAX) hi = (u64)((i64)lo >> 63);
+            out.cells[((size_t)g * A.n_accs + a) * 2] = lo;
+            out.cells[((size_t)g * A.n_accs + a) * 2 + 1] = hi;
+          }
+        }
+      }
+      base += (uint32_t)__popcll(m);
     }
   }
 }
@@ -594,7 +666,7 @@ void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K
   }
 }
 void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags) {
-  u64 need = (T.n_slots + HBLOCK - 1) / HBLOCK;
+  u64 need = (T.n_slots + (u64)HBLOCK * 16 - 1) / ((u64)HBLOCK * 16);      // a wave takes 16 x 64 slots per step
   const u64 cap = (u64)num_cus() * 16;
   const int grid = (int)(need < cap ? (need ? need : 1) : cap);
   hipLaunchKernelGGL(k_agg_hash_extract, dim3(grid), dim3(HBLOCK), 0, s, K, A, T, out, flags);
