@@ -77,8 +77,15 @@ static std::string env_defines() {
   return r;
 }
 
+// the entry point carries the sink's name so that profiles tell the specialised kernels apart
+static const char* jit_entry_name(int kernel_id) {
+  static const char* n[] = {"gpuq_jit_entry", "gpuq_jit_filter_bitmap", "gpuq_jit_project", "gpuq_jit_agg_tiny", "gpuq_jit_agg_hash", "gpuq_jit_join_build",
+                            "gpuq_jit_join_probe", "gpuq_jit_join_probe_unique", "gpuq_jit_sort_minmax", "gpuq_jit_sort_pack", "gpuq_jit_part_pid"};
+  return (kernel_id >= 1 && kernel_id <= 10) ? n[kernel_id] : n[0];
+}
+
 std::string jit_full_source(const std::string& eval_src, int kernel_id) {
-  return env_defines() + "#define GPUQ_JIT 1\n#define GPUQ_JIT_KERNEL " + std::to_string(kernel_id) +
+  return env_defines() + "#define gpuq_jit_entry " + jit_entry_name(kernel_id) + "\n#define GPUQ_JIT 1\n#define GPUQ_JIT_KERNEL " + std::to_string(kernel_id) +
          "\n#include \"gpuq_kernels.h\"\nnamespace gpuq {\n" + eval_src + "}\n#include \"" + file_of(kernel_id) + "\"\n";
 }
 
@@ -108,7 +115,7 @@ const JitFn* jit_get(const std::string& eval_src, int kernel_id) {
   hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
   hipError_t e = hipModuleLoadData(&mod, code.data());
   if (e != hipSuccess) throw std::runtime_error(std::string("jit: hipModuleLoadData: ") + hipGetErrorString(e));
-  e = hipModuleGetFunction(&fn, mod, "gpuq_jit_entry");
+  e = hipModuleGetFunction(&fn, mod, jit_entry_name(kernel_id));
   if (e != hipSuccess) throw std::runtime_error(std::string("jit: hipModuleGetFunction: ") + hipGetErrorString(e));
   f.module = mod; f.fn = fn;
   return &(g_cache[key] = f);

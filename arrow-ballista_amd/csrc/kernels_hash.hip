@@ -509,16 +509,31 @@ __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, con
         hs[u] = hash_combine(0x243F6A8885A308D3ull, key[u], 0, isn[u]);
       }
     }
-    // stage 2: first slot of every row
+    // Neighbouring lanes with the same key (clustered foreign keys: the lines of one order) look the key up once: only the
+    // first lane of a run ("head") touches the table, the others copy its answer.  All cross-lane reads are executed by
+    // every lane (a masked-off source lane reads as 0).
+    bool probe[U], head[U]; int src[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      probe[u] = act[u] && !(isn[u] && !null_eq);
+      const int pp = __shfl_up((int)probe[u], 1);
+      const u64 pk = __shfl_up(key[u], 1);
+      const int pn = __shfl_up((int)isn[u], 1);
+      const bool same = (hlane() > 0) & (pp != 0) & (pk == key[u]) & ((pn != 0) == isn[u]);
+      head[u] = probe[u] & !same;
+      const u64 hm = __ballot(head[u]) & ((2ull << hlane()) - 1);          // heads at or below this lane
+      src[u] = (probe[u] && hm) ? (63 - __clzll((long long)hm)) : hlane();
+    }
+    // stage 2: first slot of every run
     ulonglong2 sv[U]; u64 si[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { si[u] = hs[u] & mask; sv[u] = make_ulonglong2(0, 0); if (act[u] && !(isn[u] && !null_eq)) sv[u] = slots[si[u]]; }
+    for (int u = 0; u < U; ++u) { si[u] = hs[u] & mask; sv[u] = make_ulonglong2(0, 0); if (head[u]) sv[u] = slots[si[u]]; }
     // stage 3: resolve (linear probing continues per row only on a tag/key mismatch)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const i64 pos = ((wb + u) << 6) + hlane();
       uint32_t hit = NIL;
-      if (act[u] && !(isn[u] && !null_eq)) {
+      if (head[u]) {
         const uint32_t tag = tag_of(hs[u]);
         ulonglong2 v = sv[u]; u64 sidx = si[u];
         for (u64 probes = 0; probes < T.n_slots; ++probes) {
@@ -529,6 +544,7 @@ __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, con
         }
         if (visited && hit != NIL) atomicOr(&visited[hit >> 5], 1u << (hit & 31));
       }
+      hit = (uint32_t)__shfl((int)hit, src[u]);      // run members take their head's answer (heads and idle lanes read themselves)
       bool emit;
       if (join_type == JT_RIGHT_SEMI) emit = act[u] && hit != NIL;
       else if (join_type == JT_RIGHT_ANTI) emit = act[u] && hit == NIL;

@@ -121,7 +121,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if n == T.LINEITEM_ROWS[10] and os.path.exists(tp):
             traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
-        line["roofline"] = {"bound": "hbm", "kernel": "k_agg_tiny (hiprtc-specialised: gpuq_jit_entry)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        line["roofline"] = {"bound": "hbm", "kernel": "k_agg_tiny (hiprtc-specialised: gpuq_jit_agg_tiny)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
                             "algorithmic_bytes_per_launch": Q1_BYTES_PER_ROW * n}
 

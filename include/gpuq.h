@@ -78,6 +78,9 @@ typedef struct gpuq_op gpuq_op;
 typedef struct gpuq_join_table gpuq_join_table;
 
 /* ---- context ----------------------------------------------------------------------------- */
+/* Streams: every call takes the HIP stream its work is queued on.  All calls made on one context (and on the operators /
+   join tables created from it) must be queued on ONE stream at a time, or be ordered by the caller: the library recycles
+   its workspaces and join tables through a pool without synchronising, relying on stream order. */
 int gpuq_abi_version(void);
 /* json_opts: NULL or {"device":N}.  Fails (returns NULL) when no HIP device is usable;
    gpuq_last_error(NULL) then holds the reason. */

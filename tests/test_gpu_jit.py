@@ -56,3 +56,41 @@ def test_tpch_jit(jit):
     import test_gpu_tpch as M
     M.test_q3(jit, 120_000)
     M.test_q5(jit, 120_000)
+
+
+@pytest.mark.parametrize("jt", ["Inner", "Left", "Right", "Full", "RightSemi", "RightAnti"])
+def test_clustered_probe_keys_jit(jit, jt):
+    """Foreign keys arrive clustered (the lines of one order are neighbours): the specialised unique-key probe looks a run
+    of equal keys up once and hands the answer to the run's other lanes.  Runs of 1..7 equal keys, NULL keys, runs that
+    cross wave boundaries, a fused probe-side filter, unique build keys (PK side), against the oracle."""
+    import numpy as np
+    import pyarrow as pa
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, binary, lit, Operator as Op
+    from oracle import oracle_np as O
+    import test_gpu_operators as M
+    r = np.random.default_rng(5)
+    nb = 5000
+    bkeys = r.permutation(np.arange(0, 3 * nb, 3))[:nb].astype(np.int64)          # unique, multiples of 3
+    build = pa.table({"bk": pa.array(bkeys), "bv": pa.array(np.arange(nb, dtype=np.int64))})
+    runs = r.integers(1, 8, 9000)
+    base = r.integers(0, 3 * nb, len(runs)).astype(np.int64)                        # ~1/3 of the runs hit
+    pk = np.repeat(base, runs)
+    mask = np.repeat(r.random(len(runs)) < 0.1, runs)                               # whole runs of NULL keys
+    flt = r.integers(0, 10, len(pk)).astype(np.int32)
+    probe = pa.table({"pk": pa.array(pk, mask=mask), "pf": pa.array(flt), "pid": pa.array(np.arange(len(pk), dtype=np.int64))})
+    L, R0 = g.MemoryExec([build]), g.MemoryExec([probe])
+    rs0 = R0.schema()
+    R = g.FilterExec(binary(col("pf", rs0), Op.Lt, lit(8, "Int32")), R0)            # breaks some runs
+    ls, rs = L.schema(), R.schema()
+    plan = g.HashJoinExec(L, R, [(col("bk", ls), col("pk", rs))], None, jt, "CollectLeft", False)
+    got = M.norm(M.dev_rows(jit, plan.execute(0, jit)))
+    ol = O.Table.from_arrow(build)
+    orr = O.Table.from_arrow(probe.filter(pa.compute.less(probe["pf"], 8)))
+    pairs = O.hash_join(ol, orr, [({"column": {"name": "bk"}}, {"column": {"name": "pk"}})], jt)
+    lrows, rrows = [tuple(x) for x in ol.rows()], [tuple(x) for x in orr.rows()]
+    if jt in ("RightSemi", "RightAnti"):
+        exp = [rrows[j] for _, j in pairs]
+    else:
+        exp = [(lrows[i] if i is not None else (None,) * 2) + (rrows[j] if j is not None else (None,) * 3) for i, j in pairs]
+    assert got == M.norm(exp)
