@@ -11,6 +11,7 @@ from .binding import (  # noqa: F401
     T_NULL, T_BOOL, T_INT32, T_INT64, T_DATE32, T_FLOAT64, T_DECIMAL128, T_UTF8, T_UINT32, T_UINT64,
 )
 from . import expr  # noqa: F401
+from .native import NativePlan, NativeResult  # noqa: F401
 from .table import DeviceColumn, DeviceTable  # noqa: F401
 from .plan import (  # noqa: F401
     MemoryExec, FilterExec, ProjectionExec, AggregateExec, HashJoinExec, SortExec, CoalesceBatchesExec,

@@ -109,6 +109,18 @@ def lib():
         "gpuq_op_check": (i32, [vp, vp]),
         "gpuq_unpack_utf8": (i32, [vp, vp, vp, i64, vp, vp, i64, C.POINTER(i64)]),
         "gpuq_concat_bitmap": (i32, [vp, vp, vp, i64, vp, i64]),
+        "gpuq_plan_create": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
+        "gpuq_plan_free": (None, [vp]),
+        "gpuq_plan_num_partitions": (i32, [vp]),
+        "gpuq_plan_execute": (i32, [vp, vp, i32, C.POINTER(gpuq_input), i32, C.POINTER(vp)]),
+        "gpuq_plan_metrics": (i32, [vp, C.c_char_p, C.c_size_t]),
+        "gpuq_plan_last_error": (C.c_char_p, []),
+        "gpuq_plan_profile": (i32, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+        "gpuq_result_num_rows": (i64, [vp]),
+        "gpuq_result_num_columns": (i32, [vp]),
+        "gpuq_result_column": (i32, [vp, i32, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info)]),
+        "gpuq_result_free": (None, [vp]),
+        "gpuq_result_record": (i32, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(i64)]),
         "gpuq_gen_lineitem": (i32, [vp, vp, u64, u64, i64, i64, i64, C.POINTER(gpuq_lineitem_cols)]),
         "gpuq_gen_orders": (i32, [vp, vp, u64, i64, i64, i64, C.POINTER(gpuq_orders_cols)]),
         "gpuq_gen_customer": (i32, [vp, vp, u64, i64, i64, C.POINTER(gpuq_customer_cols)]),

@@ -51,7 +51,7 @@ struct Json {
       case NUL: return "null";
       case BOOL: return b ? "true" : "false";
       case NUM: return s;
-      case STR: return "\"" + s + "\"";
+      case STR: { std::string r = "\""; for (char c : s) { if (c == '"' || c == '\\') { r += '\\'; r += c; } else if (c == '\n') r += "\\n"; else if (c == '\t') r += "\\t"; else r += c; } return r + "\""; }
       case ARR: { std::string r = "["; for (size_t i = 0; i < a.size(); ++i) { if (i) r += ","; r += a[i].dump(); } return r + "]"; }
       case OBJ: { std::string r = "{"; for (size_t i = 0; i < o.size(); ++i) { if (i) r += ","; r += "\"" + o[i].first + "\":" + o[i].second.dump(); } return r + "}"; }
     }

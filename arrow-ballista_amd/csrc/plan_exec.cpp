@@ -1,0 +1,680 @@
+// Native plan executor: the host side of the engine above the operator ABI, in C++.
+//
+// What it stands in for in the reference: the walk an ExecutionEngine makes over the stage plan it is
+// handed (ballista/executor/src/execution_engine.rs:34-60: create_query_stage_exec(plan) ->
+// QueryStageExecutor::execute_query_stage) -- DataFusion's ExecutionPlan::execute() calls down the tree
+// (shuffle_writer.rs:255 `plan.execute(0, ctx)`).  PNode names, fields and modes mirror the protobuf
+// (ballista/core/proto/datafusion.proto: FilterExecNode :1291, ProjectionExecNode :1399, AggregateExecNode
+// :1405, HashJoinExecNode :1346, SortExecNode :1465, CoalesceBatchesExecNode :1487, GlobalLimit/LocalLimit
+// :1453-1463, UnionExecNode :1319, CoalescePartitionsExecNode :1492), carried as JSON.
+//
+// This file is a CLIENT of the C ABI in include/gpuq.h (operators are created from descriptors and run
+// through gpuq_*_run exactly as a Rust shim would) plus the planning that keeps data on the device between
+// operators: Filter -> Projection -> consumer chains are fused into the consumer's descriptor, filters /
+// joins / sorts produce index vectors and downstream operators read columns through them (late
+// materialisation), outputs of one operator live in one pooled device allocation.
+// The Python classes of the same names in arrow-ballista_amd/plan.py are the test-side mirror of this logic.
+#include "../../include/gpuq.h"
+#include "devbuf.h"
+#include "expr_compile.h"
+#include "json.h"
+#include <algorithm>
+#include <chrono>
+#include <functional>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace gpuq;
+
+namespace {
+
+constexpr uint32_t NULL_ROW_ID = 0xFFFFFFFFu;
+typedef std::shared_ptr<DevBuf> BufP;
+
+// ---------------------------------------------------------------- JSON building
+Json jstr(const std::string& s) { Json j; j.kind = Json::STR; j.s = s; return j; }
+Json jnum(long long v) { Json j; j.kind = Json::NUM; j.s = std::to_string(v); return j; }
+Json jbool(bool b) { Json j; j.kind = Json::BOOL; j.b = b; return j; }
+Json jarr(std::vector<Json> a = {}) { Json j; j.kind = Json::ARR; j.a = std::move(a); return j; }
+Json jobj(std::vector<std::pair<std::string, Json>> o = {}) { Json j; j.kind = Json::OBJ; j.o = std::move(o); return j; }
+Json jcol(const std::string& name, int index) { return jobj({{"column", jobj({{"name", jstr(name)}, {"index", jnum(index)}})}}); }
+Json jand(const Json& l, const Json& r) { return jobj({{"binary_expr", jobj({{"l", l}, {"r", r}, {"op", jstr("AND")}})}}); }
+
+// ---------------------------------------------------------------- schema / tables
+struct PField { std::string name; Json type; bool nullable = true; };
+typedef std::vector<PField> PSchema;
+
+int type_id_of(const Json& t, int& p, int& s) { DType d = dtype_from_json(t); p = d.p; s = d.s; return d.id; }
+Json type_json_of(int tid, int p, int s) {
+  switch (tid) {
+    case T_BOOL: return jstr("Boolean"); case T_INT32: return jstr("Int32"); case T_INT64: return jstr("Int64"); case T_DATE32: return jstr("Date32");
+    case T_FLOAT64: return jstr("Float64"); case T_UTF8: return jstr("Utf8"); case T_UINT32: return jstr("UInt32"); case T_UINT64: return jstr("UInt64");
+    case T_DECIMAL128: return jobj({{"Decimal128", jarr({jnum(p), jnum(s)})}});
+  }
+  throw std::runtime_error("plan: type id " + std::to_string(tid) + " has no name");
+}
+
+struct PCol { std::string name; Json type; bool nullable = true; gpuq_column c{}; };
+struct PTable {
+  std::vector<PCol> cols; int64_t n = 0;
+  std::vector<const uint32_t*> via; std::vector<int> sides; bool dense = false;
+  std::vector<BufP> keep;          // owners of every buffer the table points into
+  int64_t record_cap = 0;          // > 0: all columns live in keep[0], laid out for this row capacity (alloc_outputs)
+  bool is_view() const { return !via.empty(); }
+  void own(const PTable& o) { keep.insert(keep.end(), o.keep.begin(), o.keep.end()); }
+};
+
+// field list of a table as an operator sees it (side / raw128 / dense annotations)
+Json table_fields(const PTable& t) {
+  Json f = jarr();
+  for (size_t i = 0; i < t.cols.size(); ++i) {
+    const PCol& c = t.cols[i];
+    std::vector<std::pair<std::string, Json>> o = {{"name", jstr(c.name)}, {"type", c.type}, {"nullable", jbool(c.nullable)}, {"side", jnum(t.sides[i])}};
+    if (c.c.repr == GPUQ_REPR_PACKED15) o.push_back({"raw128", jnum(1)});
+    if (t.sides[i] > 0 && t.dense) o.push_back({"dense", jnum(1)});
+    f.a.push_back(jobj(o));
+  }
+  return f;
+}
+PSchema plain_schema(const PTable& t) {
+  PSchema s;
+  for (size_t i = 0; i < t.cols.size(); ++i) s.push_back({t.cols[i].name, t.cols[i].type, t.cols[i].nullable || (t.sides[i] > 0 && !t.dense)});
+  return s;
+}
+std::string table_sig(const PTable& t) {
+  std::string r = std::to_string(t.via.size()) + (t.dense ? "d" : "s");
+  for (size_t i = 0; i < t.cols.size(); ++i)
+    r += "|" + t.cols[i].name + ":" + t.cols[i].type.dump() + (t.cols[i].nullable ? "?" : "") + std::to_string(t.sides[i]) + "r" + std::to_string(t.cols[i].c.repr);
+  return r;
+}
+
+// ---------------------------------------------------------------- expression trees (PhysicalExprNode mirror)
+Json rewrite_columns(const Json& e, const std::function<Json(const Json&)>& fn) {
+  if (e.is_obj()) {
+    if (e.o.size() == 1 && e.o[0].first == "column" && e.o[0].second.is_obj() && e.o[0].second.find("name")) return fn(e.o[0].second);
+    Json r = jobj();
+    for (auto& kv : e.o) r.o.emplace_back(kv.first, rewrite_columns(kv.second, fn));
+    return r;
+  }
+  if (e.is_arr()) { Json r = jarr(); for (auto& v : e.a) r.a.push_back(rewrite_columns(v, fn)); return r; }
+  return e;
+}
+typedef std::map<std::string, Json> ColMap;      // output column of a ProjectionExec -> expression over its input
+Json inline_projection(const Json& e, const ColMap* m) {
+  if (!m) return e;
+  return rewrite_columns(e, [&](const Json& c) { auto it = m->find(c.at("name").str()); return it != m->end() ? it->second : jobj({{"column", c}}); });
+}
+template <class Names> Json rebind(const Json& e, const Names& names) {
+  return rewrite_columns(e, [&](const Json& c) {
+    const std::string& n = c.at("name").str();
+    for (size_t i = 0; i < names.size(); ++i) if (names[i] == n) return jcol(n, (int)i);
+    throw std::runtime_error("plan: column '" + n + "' not found in the input schema");
+  });
+}
+std::vector<std::string> names_of(const PTable& t) { std::vector<std::string> v; for (auto& c : t.cols) v.push_back(c.name); return v; }
+
+// ---------------------------------------------------------------- execution context
+struct Exec {
+  gpuq_ctx* ctx = nullptr; void* stream = nullptr;
+  std::map<std::string, gpuq_op*>* ops = nullptr;        // compiled operators, keyed by descriptor text (owned by the plan)
+  const gpuq_input* inputs = nullptr; int n_inputs = 0;
+  uint64_t* pin = nullptr;                                // pinned host words for count read-backs
+};
+
+void check(Exec& x, int rc) {
+  if (rc == GPUQ_OK) return;
+  const char* m = gpuq_last_error(x.ctx);
+  const std::string msg = m ? m : "gpuq error";
+  if (rc == GPUQ_ERR_UNSUPPORTED) throw Unsupported(msg);
+  if (rc == GPUQ_ERR_CAPACITY) throw Capacity(msg);
+  if (rc == GPUQ_ERR_HIP) throw HipError(msg);
+  throw std::runtime_error(msg);
+}
+gpuq_op* get_op(Exec& x, const Json& desc) {
+  const std::string key = desc.dump();
+  auto it = x.ops->find(key);
+  if (it != x.ops->end()) return it->second;
+  gpuq_op* op = nullptr;
+  check(x, gpuq_op_create(x.ctx, key.c_str(), &op));
+  (*x.ops)[key] = op;
+  return op;
+}
+uint64_t read_u64(Exec& x, const void* dev) {
+  HIPCHECK(hipMemcpyAsync(x.pin, dev, 8, hipMemcpyDeviceToHost, (hipStream_t)x.stream));
+  HIPCHECK(hipStreamSynchronize((hipStream_t)x.stream));
+  return x.pin[0];
+}
+BufP dev_alloc(size_t bytes) { BufP b = std::make_shared<DevBuf>(); b->ensure(bytes ? bytes : 16); return b; }
+
+struct InputC { gpuq_input in{}; std::vector<gpuq_column> cols; };
+void make_input(const PTable& t, InputC& ic) {
+  ic.cols.clear();
+  for (auto& c : t.cols) ic.cols.push_back(c.c);
+  ic.in.cols = ic.cols.data(); ic.in.n_cols = (int)ic.cols.size(); ic.in.n_via = (int)t.via.size(); ic.in.n_rows = t.n;
+  for (int k = 0; k < 3; ++k) ic.in.via[k] = k < (int)t.via.size() ? t.via[k] : nullptr;
+}
+
+// one pooled allocation for all output columns of an operator (same layout as table.record_layout in the Python mirror)
+PTable alloc_outputs(gpuq_op* op, int64_t n, std::vector<gpuq_column>& carr) {
+  const int nf = gpuq_op_num_outputs(op);
+  std::vector<gpuq_field_info> f((size_t)nf);
+  for (int i = 0; i < nf; ++i) if (gpuq_op_output_field(op, i, &f[(size_t)i]) != GPUQ_OK) throw std::runtime_error("plan: output field query failed");
+  const size_t bm = (size_t)((n + 63) / 64) * 8 + 8;
+  std::vector<size_t> doff((size_t)nf), voff((size_t)nf);
+  size_t off = 256;
+  for (int i = 0; i < nf; ++i) {
+    const size_t dbytes = f[(size_t)i].type == T_BOOL ? bm : (size_t)std::max<int64_t>(n, 1) * (size_t)f[(size_t)i].width + 16;
+    doff[(size_t)i] = off; off += (dbytes + 255) & ~(size_t)255;
+    voff[(size_t)i] = 0;
+    if (f[(size_t)i].nullable) { voff[(size_t)i] = off; off += (bm + 255) & ~(size_t)255; }
+  }
+  BufP buf = dev_alloc(off);
+  PTable t; t.n = n; t.keep.push_back(buf); t.record_cap = std::max<int64_t>(n, 1);
+  carr.assign((size_t)nf, gpuq_column{});
+  for (int i = 0; i < nf; ++i) {
+    PCol c; c.name = f[(size_t)i].name; c.type = type_json_of(f[(size_t)i].type, f[(size_t)i].precision, f[(size_t)i].scale); c.nullable = f[(size_t)i].nullable != 0;
+    c.c.type = f[(size_t)i].type; c.c.precision = f[(size_t)i].precision; c.c.scale = f[(size_t)i].scale; c.c.repr = f[(size_t)i].repr;
+    c.c.data = (char*)buf->p + doff[(size_t)i]; c.c.offsets = nullptr;
+    c.c.validity = f[(size_t)i].nullable ? (const uint8_t*)buf->p + voff[(size_t)i] : nullptr;
+    c.c.length = n;
+    carr[(size_t)i] = c.c;
+    t.cols.push_back(c); t.sides.push_back(0);
+  }
+  return t;
+}
+
+PTable project(Exec& x, const PTable& t, const std::vector<Json>& exprs, const std::vector<std::string>& names) {
+  Json ex = jarr();
+  const auto nm = names_of(t);
+  for (size_t i = 0; i < exprs.size(); ++i) ex.a.push_back(jobj({{"expr", rebind(exprs[i], nm)}, {"name", jstr(names[i])}}));
+  gpuq_op* op = get_op(x, jobj({{"op", jstr("project")}, {"input", jobj({{"fields", table_fields(t)}})}, {"exprs", ex}}));
+  std::vector<gpuq_column> carr;
+  PTable out = alloc_outputs(op, t.n, carr);
+  InputC ic; make_input(t, ic);
+  check(x, gpuq_project_run(op, x.stream, &ic.in, carr.data(), (int)carr.size()));
+  return out;
+}
+
+// new[j] = vec[idx[j]] with NULL_ROW propagated
+const uint32_t* take_u32(Exec& x, const uint32_t* vec, int64_t vec_len, const uint32_t* idx, int64_t n, std::vector<BufP>& keep) {
+  PTable src; src.n = n; src.via.push_back(idx); src.sides.push_back(1);
+  PCol c; c.name = "v"; c.type = jstr("UInt32"); c.nullable = false; c.c.type = T_UINT32; c.c.data = vec; c.c.length = vec_len;
+  src.cols.push_back(c);
+  const Json v = jcol("v", 0);
+  const Json e = jobj({{"case_", jobj({{"expr", Json()}, {"when_then_expr", jarr({jobj({{"when_expr", jobj({{"is_null_expr", jobj({{"expr", v}})}})},
+                      {"then_expr", jobj({{"literal", jobj({{"type", jstr("UInt32")}, {"value", jstr(std::to_string(NULL_ROW_ID))}})}})}})})}, {"else_expr", v}})}});
+  PTable out = project(x, src, {e}, {"v"});
+  keep.insert(keep.end(), out.keep.begin(), out.keep.end());
+  return (const uint32_t*)out.cols[0].c.data;
+}
+
+PTable materialize(Exec& x, const PTable& t, bool force = false);
+
+// address `t`'s rows through idx[0..n): a view
+PTable select_view(Exec& x, const PTable& t, const uint32_t* idx, int64_t n, const BufP& idx_owner) {
+  PTable out; out.n = n; out.own(t); if (idx_owner) out.keep.push_back(idx_owner);
+  if (!t.is_view()) {
+    out.cols = t.cols; out.via = {idx}; out.sides.assign(t.cols.size(), 1);
+    return out;
+  }
+  bool has0 = false; for (int s : t.sides) has0 = has0 || s == 0;
+  if ((int)t.via.size() + (has0 ? 1 : 0) > 3) {
+    PTable m = materialize(x, t);
+    out.own(m); out.cols = m.cols; out.via = {idx}; out.sides.assign(m.cols.size(), 1);
+    return out;
+  }
+  out.cols = t.cols;
+  if (has0) out.via.push_back(idx);
+  for (const uint32_t* v : t.via) out.via.push_back(take_u32(x, v, t.n, idx, n, out.keep));
+  const int shift = has0 ? 1 : 0;
+  for (int s : t.sides) out.sides.push_back(s == 0 ? 1 : s + shift);
+  return out;
+}
+
+PTable materialize(Exec& x, const PTable& t, bool force) {
+  if (!t.is_view() && !force) return t;
+  PTable out; out.n = t.n;
+  for (size_t a = 0; a < t.cols.size(); a += 12) {
+    PTable sub; sub.n = t.n; sub.via = t.via; sub.dense = t.dense;
+    std::vector<Json> ex; std::vector<std::string> nm;
+    for (size_t i = a; i < std::min(a + 12, t.cols.size()); ++i) { sub.cols.push_back(t.cols[i]); sub.sides.push_back(t.sides[i]); }
+    for (size_t i = 0; i < sub.cols.size(); ++i) { ex.push_back(jcol(sub.cols[i].name, (int)i)); nm.push_back(sub.cols[i].name); }
+    // rebind by position, not by name: duplicate names (join outputs) must keep their own column
+    Json exj = jarr();
+    for (size_t i = 0; i < ex.size(); ++i) exj.a.push_back(jobj({{"expr", ex[i]}, {"name", jstr(nm[i])}}));
+    gpuq_op* op = get_op(x, jobj({{"op", jstr("project")}, {"input", jobj({{"fields", table_fields(sub)}})}, {"exprs", exj}}));
+    std::vector<gpuq_column> carr;
+    PTable part = alloc_outputs(op, sub.n, carr);
+    InputC ic; make_input(sub, ic);
+    check(x, gpuq_project_run(op, x.stream, &ic.in, carr.data(), (int)carr.size()));
+    for (auto& c : part.cols) { out.cols.push_back(c); out.sides.push_back(0); }
+    out.own(part);
+  }
+  // the kernels above read t's buffers asynchronously: keep them alive as long as the result
+  out.own(t);
+  return out;
+}
+
+PTable filter_table(Exec& x, const PTable& t, const Json& predicate) {
+  const auto nm = names_of(t);
+  gpuq_op* op = get_op(x, jobj({{"op", jstr("filter")}, {"input", jobj({{"fields", table_fields(t)}})}, {"predicate", rebind(predicate, nm)}}));
+  BufP sel = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 4 + 16), cnt = dev_alloc(16);
+  InputC ic; make_input(t, ic);
+  check(x, gpuq_filter_run(op, x.stream, &ic.in, 0, (uint32_t*)sel->p, (uint64_t*)cnt->p));
+  const int64_t k = (int64_t)read_u64(x, cnt->p);
+  check(x, gpuq_op_check(op, x.stream));
+  return select_view(x, t, (const uint32_t*)sel->p, k, sel);
+}
+
+PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetch) {
+  const auto nm = names_of(t);
+  Json ex = jarr();
+  for (auto& s : sort_exprs.a) {
+    const bool asc = s.get_bool("asc", true);
+    ex.a.push_back(jobj({{"expr", rebind(s.at("expr"), nm)}, {"asc", jbool(asc)}, {"nulls_first", jbool(s.get_bool("nulls_first", !asc))}}));
+  }
+  gpuq_op* op = get_op(x, jobj({{"op", jstr("sort")}, {"input", jobj({{"fields", table_fields(t)}})}, {"expr", ex}}));
+  BufP perm = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 4 + 16);
+  InputC ic; make_input(t, ic);
+  check(x, gpuq_sort_run(op, x.stream, &ic.in, (uint32_t*)perm->p));
+  const int64_t k = (fetch < 0 || fetch > t.n) ? t.n : fetch;
+  return select_view(x, t, (const uint32_t*)perm->p, k, perm);
+}
+
+// ---------------------------------------------------------------- plan nodes
+struct Metrics { int64_t output_rows = 0, elapsed_ns = 0; };
+struct PNode {
+  std::string kind; Metrics m;
+  virtual ~PNode() {}
+  virtual std::vector<PNode*> children() { return {}; }
+  virtual int partitions() { auto c = children(); return c.empty() ? 1 : c[0]->partitions(); }
+  virtual PTable execute(int part, Exec& x) = 0;
+  PTable timed(std::chrono::steady_clock::time_point t0, PTable t) {
+    m.elapsed_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    m.output_rows += t.n; return t;
+  }
+};
+typedef std::unique_ptr<PNode> PNodeP;
+PNodeP build_node(const Json& j);
+
+struct MemoryExec : PNode {        // leaf: partitions[p] = index into the inputs handed to gpuq_plan_execute
+  PSchema schema; std::vector<int> parts; bool dense = false;
+  int partitions() override { return (int)parts.size(); }
+  PTable execute(int part, Exec& x) override {
+    if (part < 0 || part >= (int)parts.size()) throw std::runtime_error("MemoryExec: partition out of range");
+    const int slot = parts[(size_t)part];
+    if (slot < 0 || slot >= x.n_inputs) throw std::runtime_error("MemoryExec: input " + std::to_string(slot) + " was not supplied");
+    const gpuq_input& in = x.inputs[slot];
+    if (in.n_cols != (int)schema.size()) throw std::runtime_error("MemoryExec: input has " + std::to_string(in.n_cols) + " columns, schema has " + std::to_string(schema.size()));
+    PTable t; t.n = in.n_rows; t.dense = dense;
+    for (int k = 0; k < in.n_via; ++k) t.via.push_back(in.via[k]);
+    for (int i = 0; i < in.n_cols; ++i) {
+      PCol c; c.name = schema[(size_t)i].name; c.type = schema[(size_t)i].type; c.nullable = schema[(size_t)i].nullable; c.c = in.cols[i];
+      int p, s; const int tid = type_id_of(c.type, p, s);
+      if (c.c.type != tid) throw std::runtime_error("MemoryExec: column '" + c.name + "' does not have the declared type");
+      t.cols.push_back(c);
+    }
+    t.sides = sides.empty() ? std::vector<int>(t.cols.size(), in.n_via > 0 ? 1 : 0) : sides;
+    m.output_rows += t.n;
+    return t;
+  }
+  std::vector<int> sides;       // per column: index vector it is read through (views handed in by the caller)
+};
+
+struct PassThrough : PNode {       // CoalesceBatchesExec: whole partitions are already single tables
+  PNodeP input;
+  std::vector<PNode*> children() override { return {input.get()}; }
+  PTable execute(int part, Exec& x) override { return input->execute(part, x); }
+};
+
+struct FilterExec : PNode {
+  PNodeP input; Json predicate;
+  std::vector<PNode*> children() override { return {input.get()}; }
+  PTable execute(int part, Exec& x) override;
+};
+struct ProjectionExec : PNode {
+  PNodeP input; std::vector<Json> exprs; std::vector<std::string> names;
+  std::vector<PNode*> children() override { return {input.get()}; }
+  PTable execute(int part, Exec& x) override;
+};
+
+// Walk down through Filter / Projection / CoalesceBatches: (source node, AND-ed predicate, column map)
+struct Fused { PNode* src = nullptr; bool has_pred = false; Json pred; bool has_map = false; ColMap map; };
+Fused fuse(PNode* n) {
+  if (auto* p = dynamic_cast<PassThrough*>(n)) return fuse(p->input.get());
+  if (auto* f = dynamic_cast<FilterExec*>(n)) {
+    Fused r = fuse(f->input.get());
+    const Json mine = inline_projection(f->predicate, r.has_map ? &r.map : nullptr);
+    r.pred = r.has_pred ? jand(r.pred, mine) : mine; r.has_pred = true;
+    return r;
+  }
+  if (auto* p = dynamic_cast<ProjectionExec*>(n)) {
+    Fused r = fuse(p->input.get());
+    ColMap nm;
+    for (size_t i = 0; i < p->exprs.size(); ++i) nm[p->names[i]] = inline_projection(p->exprs[i], r.has_map ? &r.map : nullptr);
+    r.map = std::move(nm); r.has_map = true;
+    return r;
+  }
+  Fused r; r.src = n; return r;
+}
+
+PTable FilterExec::execute(int part, Exec& x) {
+  Fused f = fuse(this);
+  PTable t = f.src->execute(part, x);
+  auto t0 = std::chrono::steady_clock::now();
+  if (!f.has_map) return timed(t0, filter_table(x, t, f.pred));
+  // a computed projection sits below: run it on the filtered rows
+  PTable v = filter_table(x, t, f.pred);
+  std::vector<Json> ex; std::vector<std::string> nm;
+  for (auto& kv : f.map) { nm.push_back(kv.first); ex.push_back(kv.second); }
+  return timed(t0, project(x, v, ex, nm));
+}
+PTable ProjectionExec::execute(int part, Exec& x) {
+  Fused f = fuse(input.get());
+  PTable t = f.src->execute(part, x);
+  auto t0 = std::chrono::steady_clock::now();
+  if (f.has_pred) t = filter_table(x, t, f.pred);
+  std::vector<Json> ex;
+  for (auto& e : exprs) ex.push_back(inline_projection(e, f.has_map ? &f.map : nullptr));
+  return timed(t0, project(x, t, ex, names));
+}
+
+struct AggregateExec : PNode {
+  PNodeP input; std::string mode, strategy = "auto"; Json group_expr, aggr_expr; int64_t expected_groups = 0, output_capacity = 0;
+  std::vector<PNode*> children() override { return {input.get()}; }
+  PTable execute(int part, Exec& x) override {
+    const bool final_ = mode == "Final" || mode == "FinalPartitioned";
+    Fused f; if (final_) f.src = input.get(); else f = fuse(input.get());
+    PTable t = f.src->execute(part, x);
+    auto t0 = std::chrono::steady_clock::now();
+    const auto nm = names_of(t);
+    const ColMap* cm = f.has_map ? &f.map : nullptr;
+    Json ge = jarr(), ae = jarr();
+    for (auto& g : group_expr.a) ge.a.push_back(jobj({{"expr", rebind(inline_projection(g.at("expr"), cm), nm)}, {"name", g.at("name")}}));
+    for (auto& a : aggr_expr.a) {
+      std::vector<std::pair<std::string, Json>> o = {{"fn", a.at("fn")}, {"name", a.at("name")}};
+      for (const char* k : {"expr", "expr2"}) if (a.has(k)) o.push_back({k, rebind(inline_projection(a.at(k), cm), nm)});
+      ae.a.push_back(jobj(o));
+    }
+    std::vector<std::pair<std::string, Json>> d = {{"op", jstr("aggregate")}, {"mode", jstr(mode)}, {"input", jobj({{"fields", table_fields(t)}})},
+                                                   {"strategy", jstr(strategy)}, {"group_expr", ge}, {"aggr_expr", ae}};
+    if (f.has_pred) d.push_back({"predicate", rebind(f.pred, nm)});
+    if (expected_groups) d.push_back({"expected_groups", jnum(expected_groups)});
+    gpuq_op* op = get_op(x, jobj(d));
+    int64_t cap = output_capacity > 0 ? output_capacity : (group_expr.a.empty() ? 4096 : std::max<int64_t>(4096, std::min<int64_t>(t.n, 1ll << 22)));
+    InputC ic; make_input(t, ic);
+    for (;;) {
+      std::vector<gpuq_column> carr;
+      PTable out = alloc_outputs(op, cap, carr);
+      int64_t ng = 0;
+      const int rc = gpuq_aggregate_run(op, x.stream, &ic.in, carr.data(), (int)carr.size(), cap, &ng);
+      if (rc == GPUQ_ERR_CAPACITY && ng > cap) { cap = ng; continue; }
+      check(x, rc);
+      out.n = ng; for (auto& c : out.cols) c.c.length = ng;
+      return timed(t0, out);       // synchronous call: the input buffers are no longer referenced
+    }
+  }
+};
+
+struct SortExec : PNode {
+  PNodeP input; Json expr; int64_t fetch = -1; bool merge_all = false;     // merge_all: SortPreservingMergeExec over a single partition
+  std::vector<PNode*> children() override { return {input.get()}; }
+  int partitions() override { return merge_all ? 1 : input->partitions(); }
+  PTable execute(int part, Exec& x) override {
+    if (merge_all && input->partitions() != 1) throw Unsupported("SortPreservingMergeExec over several partitions: coalesce them first");
+    PTable t = input->execute(part, x);
+    auto t0 = std::chrono::steady_clock::now();
+    return timed(t0, sort_table(x, t, expr, fetch));
+  }
+};
+
+struct HashJoinExec : PNode {
+  PNodeP left, right; Json on; std::string join_type = "Inner", partition_mode = "CollectLeft"; bool null_equals_null = false; bool has_filter = false; Json filter;
+  std::vector<PNode*> children() override { return {left.get(), right.get()}; }
+  int partitions() override { return right->partitions(); }
+  struct Side { PTable t; bool has_pred = false; Json pred; };
+  Side side(PNode* plan, int part, Exec& x) {
+    Fused f = fuse(plan);
+    Side s;
+    if (f.has_map) { s.t = plan->execute(part, x); return s; }      // computed projection below the join: materialised, not fused
+    s.t = f.src->execute(part, x); s.has_pred = f.has_pred; s.pred = f.pred;
+    return s;
+  }
+  PTable join_view(Exec& x, const PTable& lt, const PTable& rt, const uint32_t* ob, const uint32_t* opb, int64_t k, const BufP& ob_own, const BufP& opb_own) {
+    PTable lv = select_view(x, lt, ob, k, ob_own), rv = select_view(x, rt, opb, k, opb_own);
+    if (lv.via.size() + rv.via.size() > 3) {
+      if (lv.via.size() >= rv.via.size()) lv = materialize(x, lv); else rv = materialize(x, rv);
+    }
+    PTable out; out.n = k; out.own(lv); out.own(rv);
+    out.cols = lv.cols; out.via = lv.via; out.sides = lv.sides;
+    const int shift = (int)lv.via.size();
+    for (size_t i = 0; i < rv.cols.size(); ++i) { out.cols.push_back(rv.cols[i]); out.sides.push_back(rv.sides[i] == 0 ? 0 : rv.sides[i] + shift); }
+    for (auto v : rv.via) out.via.push_back(v);
+    return out;
+  }
+  PTable execute(int part, Exec& x) override {
+    const std::string& jt = join_type;
+    int lpart = partition_mode == "Partitioned" ? part : 0;
+    if (partition_mode != "Partitioned" && left->partitions() != 1) throw Unsupported("CollectLeft with a multi-partition build side: wrap the left input in a single partition");
+    Side L = side(left.get(), lpart, x), R = side(right.get(), part, x);
+    auto t0 = std::chrono::steady_clock::now();
+    const auto ln = names_of(L.t), rn = names_of(R.t);
+    Json lk = jarr(), rk = jarr();
+    for (auto& o : on.a) { lk.a.push_back(rebind(o.at("left"), ln)); rk.a.push_back(rebind(o.at("right"), rn)); }
+    std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(L.t)}})}, {"on", lk}, {"null_equals_null", jbool(null_equals_null)}};
+    if (L.has_pred) bd.push_back({"predicate", rebind(L.pred, ln)});
+    std::vector<std::pair<std::string, Json>> pd = {{"op", jstr("join_probe")}, {"input", jobj({{"fields", table_fields(R.t)}})}, {"on", rk}, {"join_type", jstr(jt)},
+                                                   {"null_equals_null", jbool(null_equals_null)}};
+    if (R.has_pred) pd.push_back({"predicate", rebind(R.pred, rn)});
+    gpuq_op* bop = get_op(x, jobj(bd)); gpuq_op* pop = get_op(x, jobj(pd));
+    InputC lic, ric; make_input(L.t, lic); make_input(R.t, ric);
+    gpuq_join_table* jtab = nullptr;
+    check(x, gpuq_join_build_run(bop, x.stream, &lic.in, 0, L.t.n, &jtab));
+    struct Guard { gpuq_join_table* t; ~Guard() { if (t) gpuq_join_table_free(t); } } guard{jtab};
+    const bool lout = jt == "Left" || jt == "Full";
+    const int64_t extra_cap = lout ? L.t.n : 0;
+    int64_t cap = std::max<int64_t>(R.t.n, 1) + extra_cap;
+    BufP cnt = dev_alloc(16), ob, opb; int64_t k = 0;
+    for (;;) {
+      ob = dev_alloc((size_t)cap * 4 + 16); opb = dev_alloc((size_t)cap * 4 + 16);
+      check(x, gpuq_join_probe_run(pop, x.stream, jtab, &ric.in, 0, (uint32_t*)ob->p, (uint32_t*)opb->p, (uint64_t)(cap - extra_cap), (uint64_t*)cnt->p));
+      k = (int64_t)read_u64(x, cnt->p);
+      const int rc = gpuq_op_check(pop, x.stream);
+      if (rc == GPUQ_ERR_CAPACITY) { cap = k + extra_cap + 1; continue; }
+      check(x, rc);
+      break;
+    }
+    if (jt == "LeftSemi" || jt == "LeftAnti" || lout) {
+      BufP extra = dev_alloc(16);
+      if (!lout) {
+        BufP rows = dev_alloc((size_t)std::max<int64_t>(L.t.n, 1) * 4 + 16);
+        check(x, gpuq_join_build_side_rows(jtab, x.stream, jt == "LeftSemi" ? 1 : 0, (uint32_t*)rows->p, (uint64_t*)extra->p));
+        const int64_t mrows = (int64_t)read_u64(x, extra->p);
+        return timed(t0, select_view(x, L.t, (const uint32_t*)rows->p, mrows, rows));
+      }
+      check(x, gpuq_join_build_side_rows(jtab, x.stream, 0, (uint32_t*)ob->p + k, (uint64_t*)extra->p));
+      const int64_t mrows = (int64_t)read_u64(x, extra->p);
+      if (mrows > 0) HIPCHECK(hipMemsetAsync((uint32_t*)opb->p + k, 0xFF, (size_t)mrows * 4, (hipStream_t)x.stream));     // NULL_ROW on the probe side
+      k += mrows;
+    }
+    if (jt == "RightSemi" || jt == "RightAnti") return timed(t0, select_view(x, R.t, (const uint32_t*)opb->p, k, opb));
+    PTable out = join_view(x, L.t, R.t, (const uint32_t*)ob->p, (const uint32_t*)opb->p, k, ob, opb);
+    if (has_filter) {
+      if (jt != "Inner") throw Unsupported("JoinFilter on a non-inner join is not supported on device yet");
+      out = filter_table(x, out, filter);
+    }
+    // the probe kernels read the build table asynchronously; results were read back (synchronised) above
+    return timed(t0, out);
+  }
+};
+
+struct LimitExec : PNode {       // LocalLimitExec: first `fetch` rows of each partition (a prefix needs no index vector for plain tables)
+  PNodeP input; int64_t fetch = 0;
+  std::vector<PNode*> children() override { return {input.get()}; }
+  PTable execute(int part, Exec& x) override {
+    PTable t = input->execute(part, x);
+    if (fetch < t.n) { t.n = fetch; for (auto& c : t.cols) if (!t.is_view() && c.c.length > fetch) c.c.length = fetch; }
+    m.output_rows += t.n;
+    return t;
+  }
+};
+
+PNodeP build_child(const Json& v, const char* key) { return build_node(v.at(key)); }
+
+PNodeP build_node(const Json& j) {
+  if (!j.is_obj() || j.o.size() != 1) throw std::runtime_error("plan: a node is an object with one key (the node type): " + j.dump().substr(0, 80));
+  const std::string& kind = j.o[0].first; const Json& v = j.o[0].second;
+  PNodeP out;
+  if (kind == "MemoryExec") {
+    auto n = std::make_unique<MemoryExec>();
+    for (auto& f : v.at("schema").a) n->schema.push_back({f.at("name").str(), f.at("type"), f.get_bool("nullable", true)});
+    for (auto& p : v.at("partitions").a) n->parts.push_back((int)p.i64());
+    n->dense = v.get_bool("dense", false);
+    if (v.has("sides")) for (auto& s : v.at("sides").a) n->sides.push_back((int)s.i64());
+    out = std::move(n);
+  } else if (kind == "CoalesceBatchesExec") {
+    auto n = std::make_unique<PassThrough>(); n->input = build_child(v, "input"); out = std::move(n);
+  } else if (kind == "FilterExec") {
+    auto n = std::make_unique<FilterExec>(); n->input = build_child(v, "input"); n->predicate = v.at("expr"); out = std::move(n);
+  } else if (kind == "ProjectionExec") {
+    auto n = std::make_unique<ProjectionExec>(); n->input = build_child(v, "input");
+    const Json& e = v.at("expr"); const Json& names = v.at("expr_name");
+    if (e.a.size() != names.a.size()) throw std::runtime_error("ProjectionExec: expr and expr_name differ in length");
+    for (size_t i = 0; i < e.a.size(); ++i) { n->exprs.push_back(e.a[i]); n->names.push_back(names.a[i].str()); }
+    out = std::move(n);
+  } else if (kind == "AggregateExec") {
+    auto n = std::make_unique<AggregateExec>(); n->input = build_child(v, "input"); n->mode = v.get_str("mode", "Single"); n->strategy = v.get_str("strategy", "auto");
+    n->group_expr = v.has("group_expr") ? v.at("group_expr") : jarr(); n->aggr_expr = v.at("aggr_expr");
+    n->expected_groups = v.get_i64("expected_groups", 0); n->output_capacity = v.get_i64("output_capacity", 0);
+    out = std::move(n);
+  } else if (kind == "SortExec" || kind == "SortPreservingMergeExec") {
+    auto n = std::make_unique<SortExec>(); n->input = build_child(v, "input"); n->expr = v.at("expr"); n->fetch = v.get_i64("fetch", -1); n->merge_all = kind != "SortExec";
+    out = std::move(n);
+  } else if (kind == "HashJoinExec") {
+    auto n = std::make_unique<HashJoinExec>(); n->left = build_child(v, "left"); n->right = build_child(v, "right"); n->on = v.at("on");
+    n->join_type = v.get_str("join_type", "Inner"); n->partition_mode = v.get_str("partition_mode", "CollectLeft"); n->null_equals_null = v.get_bool("null_equals_null", false);
+    if (v.has("filter")) { n->has_filter = true; n->filter = v.at("filter"); }
+    out = std::move(n);
+  } else if (kind == "LocalLimitExec") {
+    auto n = std::make_unique<LimitExec>(); n->input = build_child(v, "input"); n->fetch = v.at("fetch").i64(); out = std::move(n);
+  } else throw Unsupported("plan: node type '" + kind + "' is not executed natively");
+  out->kind = kind;
+  return out;
+}
+
+void collect(PNode* n, std::vector<PNode*>& out) { out.push_back(n); for (PNode* c : n->children()) collect(c, out); }
+
+thread_local std::string g_plan_error;
+
+}  // namespace
+
+struct gpuq_plan {
+  gpuq_ctx* ctx = nullptr; PNodeP root; std::map<std::string, gpuq_op*> ops; uint64_t* pin = nullptr;
+  ~gpuq_plan() { for (auto& kv : ops) gpuq_op_free(kv.second); if (pin) (void)hipHostFree(pin); }
+};
+struct gpuq_result { PTable t; std::vector<gpuq_field_info> fields; };
+
+namespace {
+template <class F> int plan_guarded(F&& f) {
+  try { f(); return GPUQ_OK; }
+  catch (const HipError& e) { g_plan_error = e.what(); return GPUQ_ERR_HIP; }
+  catch (const Unsupported& e) { g_plan_error = e.what(); return GPUQ_ERR_UNSUPPORTED; }
+  catch (const Capacity& e) { g_plan_error = e.what(); return GPUQ_ERR_CAPACITY; }
+  catch (const std::bad_alloc&) { g_plan_error = "out of host memory"; return GPUQ_ERR_INTERNAL; }
+  catch (const std::exception& e) { g_plan_error = e.what(); return GPUQ_ERR_INVALID; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* gpuq_plan_last_error(void) { return g_plan_error.c_str(); }
+
+int gpuq_plan_create(gpuq_ctx* ctx, const char* plan_json, gpuq_plan** out) {
+  if (!out) return GPUQ_ERR_INVALID;
+  *out = nullptr;
+  return plan_guarded([&]() {
+    if (!ctx) throw std::runtime_error("ctx is NULL");
+    if (!plan_json) throw std::runtime_error("plan_json is NULL");
+    std::unique_ptr<gpuq_plan> p(new gpuq_plan());
+    p->ctx = ctx;
+    p->root = build_node(JsonParser(plan_json).parse());
+    *out = p.release();
+  });
+}
+
+void gpuq_plan_free(gpuq_plan* p) { delete p; }
+
+int gpuq_plan_num_partitions(gpuq_plan* p) { return p ? p->root->partitions() : 0; }
+
+int gpuq_plan_execute(gpuq_plan* p, void* stream, int partition, const gpuq_input* inputs, int n_inputs, gpuq_result** out) {
+  if (!p || !out) return GPUQ_ERR_INVALID;
+  *out = nullptr;
+  return plan_guarded([&]() {
+    if (!p->pin) HIPCHECK(hipHostMalloc((void**)&p->pin, 64, hipHostMallocDefault));
+    Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin;
+    PTable t = materialize(x, p->root->execute(partition, x));
+    HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+    std::unique_ptr<gpuq_result> r(new gpuq_result());
+    for (auto& c : t.cols) {
+      gpuq_field_info f{};
+      std::snprintf(f.name, sizeof(f.name), "%s", c.name.c_str());
+      f.type = c.c.type; f.precision = c.c.precision; f.scale = c.c.scale; f.nullable = c.nullable; f.repr = c.c.repr;
+      DType dt; dt.id = c.c.type; dt.p = c.c.precision; dt.s = c.c.scale;
+      f.width = c.c.type == T_BOOL ? 0 : type_width(dt);
+      r->fields.push_back(f);
+    }
+    // inputs are the caller's: only library-owned buffers are kept
+    r->t = std::move(t);
+    *out = r.release();
+  });
+}
+
+int gpuq_result_record(const gpuq_result* r, void** base_out, size_t* bytes_out, int64_t* cap_out) {
+  if (!r || !base_out || !bytes_out || !cap_out) return GPUQ_ERR_INVALID;
+  *base_out = nullptr; *bytes_out = 0; *cap_out = 0;
+  if (r->t.record_cap > 0 && r->t.keep.size() == 1 && !r->t.is_view()) { *base_out = r->t.keep[0]->p; *bytes_out = r->t.keep[0]->cap; *cap_out = r->t.record_cap; }
+  return GPUQ_OK;
+}
+int64_t gpuq_result_num_rows(const gpuq_result* r) { return r ? r->t.n : 0; }
+int gpuq_result_num_columns(const gpuq_result* r) { return r ? (int)r->t.cols.size() : 0; }
+int gpuq_result_column(const gpuq_result* r, int i, gpuq_column* col_out, gpuq_field_info* field_out) {
+  if (!r || i < 0 || i >= (int)r->t.cols.size()) return GPUQ_ERR_INVALID;
+  if (col_out) { *col_out = r->t.cols[(size_t)i].c; col_out->length = r->t.n; }
+  if (field_out) *field_out = r->fields[(size_t)i];
+  return GPUQ_OK;
+}
+void gpuq_result_free(gpuq_result* r) { delete r; }
+
+// Device time of the dominant kernel of the plan's operators (gpuq_op_profile on every compiled operator): reports the
+// operator that accumulated the most kernel time since profiling was enabled.
+int gpuq_plan_profile(gpuq_plan* p, int enable, float* kernel_ms_out, int* launches_out, char* op_desc_out, size_t cap) {
+  if (!p) return GPUQ_ERR_INVALID;
+  float best = -1; int bl = 0; std::string bd;
+  for (auto& kv : p->ops) {
+    float ms = 0; int n = 0;
+    if (gpuq_op_profile(kv.second, enable, &ms, &n) != GPUQ_OK) continue;
+    if (ms > best) { best = ms; bl = n; bd = kv.first; }
+  }
+  if (kernel_ms_out) *kernel_ms_out = best < 0 ? 0 : best;
+  if (launches_out) *launches_out = bl;
+  if (op_desc_out && cap) { std::snprintf(op_desc_out, cap, "%s", bd.c_str()); }
+  return GPUQ_OK;
+}
+
+int gpuq_plan_metrics(gpuq_plan* p, char* buf, size_t cap) {
+  if (!p || !buf) return GPUQ_ERR_INVALID;
+  std::vector<PNode*> nodes; collect(p->root.get(), nodes);
+  std::string s = "[";
+  for (size_t i = 0; i < nodes.size(); ++i)
+    s += std::string(i ? "," : "") + "{\"node\":\"" + nodes[i]->kind + "\",\"output_rows\":" + std::to_string(nodes[i]->m.output_rows) + ",\"elapsed_compute\":" + std::to_string(nodes[i]->m.elapsed_ns) + "}";
+  s += "]";
+  if (s.size() + 1 > cap) return GPUQ_ERR_CAPACITY;
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return GPUQ_OK;
+}
+
+}  // extern "C"

@@ -58,8 +58,8 @@ def allgather_table(table, cap, group=None):
     widths = [type_width(c.type) for c in table.columns]
     B, lay = record_layout([(w, c.nullable) for w, c in zip(widths, table.columns)], cap)
     rec = getattr(table, "_record", None)
-    if rec is not None and rec[1] == cap and rec[0].numel() == B and not table.is_view():
-        send = rec[0]
+    if rec is not None and rec[1] == cap and rec[0].numel() >= B and not table.is_view():
+        send = rec[0][:B]        # the allocation may be larger than the record (pooled block)
     else:
         send = torch.zeros(B, dtype=torch.uint8, device=dev)
         for c, w, (doff, dbytes, voff, vbytes) in zip(table.columns, widths, lay):

@@ -50,9 +50,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GPUQ_BENCH_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, the
+    # collectives are staged through host memory); the measured configuration is always nccl = RCCL, one rank per GPU.
+    backend = os.environ.get("GPUQ_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     tc = g.TaskContext(device=local_rank)
@@ -60,21 +68,31 @@ def main():
     n = args.rows or T.LINEITEM_ROWS[10]
     lineitem = T.gen_lineitem_device(tc, n, seed=T.SEED_LINEITEM, seed_orders=T.SEED_ORDERS, row0=rank * n)
 
-    # ---- plans (built once; compiled operators are cached in the TaskContext)
+    # ---- plans (built once).  Both stages run in the native plan executor (csrc/plan_exec.cpp): one library call per stage,
+    # no Python between operators.
     STATE_CAP = 64      # rows of partial-aggregate state a rank ships; the same on every rank (fixes the record layout)
-    partial, full, final_src = T.q1_split_plan(lineitem, STATE_CAP)
+    partial_py, full_py, final_src = T.q1_split_plan(lineitem, STATE_CAP)
+    partial = g.NativePlan(partial_py, tc)            # fused filter + projection + partial aggregate over the rank's rows
+
+    def gather(res):
+        states = res.to_device_table(tc.device)
+        return parallel.allgather_table(states, cap=STATE_CAP)
+
+    res0 = partial.execute(0)
+    final_src.partitions[0] = gather(res0) if world > 1 else res0.to_device_table(tc.device)
+    final = g.NativePlan(full_py, tc)                 # final aggregate + projection + sort over the (gathered) states
 
     def step():
-        states = partial.execute(0, tc)                    # fused filter+project+partial aggregate
+        res = partial.execute(0)
         if world > 1:
-            states = parallel.allgather_table(states, cap=STATE_CAP)
-        final_src.partitions[0] = states
-        return g.plan.materialize(tc, full.execute(0, tc))   # final aggregate + projection + sort
+            final.set_input(0, gather(res))            # one all-gather of fixed-layout records, read in place through a view
+        else:
+            final.set_input_result(0, res)
+        return final.execute(0), res
 
     for _ in range(args.warmup):
-        out = step()
-    pop = [o for o in tc._ops.values() if o.descriptor.get("op") == "aggregate" and o.descriptor.get("mode") == "Partial"][0]
-    pop.profile(True)
+        out, _r = step()
+    partial.profile(True)
 
     def fence():
         torch.cuda.synchronize()
@@ -90,19 +108,19 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out, _r = step()
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
-    kernel_ms, launches = pop.profile(False)
+    kernel_ms, launches, _desc = partial.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=tc.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=tc.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     rows_total = n * world * args.steps
     value = rows_total / dt
-    result_rows = T.q1_result_to_rows(tc, out)
+    result_rows = out.to_arrow().to_pylist()
 
     line = {
         "metric": "tpch_q1_operator_rows_per_sec", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,

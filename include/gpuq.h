@@ -227,6 +227,45 @@ int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n,
    Fixed-width data buffers are concatenated with plain device copies.  Asynchronous on `stream`. */
 int gpuq_concat_bitmap(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src, int64_t n_bits);
 
+/* ---- native plan executor ------------------------------------------------------------------
+   The C++ host side above the operator calls: executes a physical plan tree, keeping data on the device between operators
+   (fused Filter -> Projection -> consumer chains, index-vector views, pooled allocations).  Stands in for the walk an
+   ExecutionEngine makes over the stage plan (ballista/executor/src/execution_engine.rs:34-60; `plan.execute(0, ctx)` at
+   ballista/core/src/execution_plans/shuffle_writer.rs:255).  plan_json mirrors the PhysicalPlanNode messages of
+   ballista/core/proto/datafusion.proto, one key per node:
+     {"MemoryExec": {"schema": [{"name","type","nullable"}], "partitions": [input_slot, ...], "dense"?: bool, "sides"?: [..]}}
+     {"FilterExec": {"input": node, "expr": expr}}                                   (:1291-1294)
+     {"ProjectionExec": {"input": node, "expr": [expr], "expr_name": [str]}}         (:1399-1403)
+     {"AggregateExec": {"input", "mode", "group_expr": [{"expr","name"}], "aggr_expr": [{"fn","expr","expr2"?,"name"}],
+                        "strategy"?, "expected_groups"?, "output_capacity"?}}        (:1405-1450)
+     {"HashJoinExec": {"left", "right", "on": [{"left": expr, "right": expr}], "join_type", "partition_mode",
+                       "null_equals_null", "filter"?}}                               (:1346-1360)
+     {"SortExec" | "SortPreservingMergeExec": {"input", "expr": [{"expr","asc","nulls_first"}], "fetch"?}}   (:1465-1478)
+     {"CoalesceBatchesExec": {"input"}}  {"LocalLimitExec": {"input","fetch"}}       (:1487-1490, :1460-1463)
+   Expressions are the PhysicalExprNode mirror of gpuq_op_create; columns are resolved by NAME against each operator's input.
+   gpuq_plan_execute runs one output partition: inputs[k] is the table MemoryExec leaves refer to as slot k (caller-owned device
+   memory, must stay valid until the call returns); *out is a materialised result owned by the library (gpuq_result_free).
+   Synchronous.  Errors: status code + gpuq_plan_last_error(). */
+typedef struct gpuq_plan gpuq_plan;
+typedef struct gpuq_result gpuq_result;
+int gpuq_plan_create(gpuq_ctx* ctx, const char* plan_json, gpuq_plan** out);
+void gpuq_plan_free(gpuq_plan* plan);
+int gpuq_plan_num_partitions(gpuq_plan* plan);
+int gpuq_plan_execute(gpuq_plan* plan, void* stream, int partition, const gpuq_input* inputs, int n_inputs, gpuq_result** out);
+int gpuq_plan_metrics(gpuq_plan* plan, char* json_out, size_t cap);     /* per node: output_rows, elapsed_compute (ns) -- utils.rs:470-481 */
+const char* gpuq_plan_last_error(void);
+/* gpuq_op_profile over every operator the plan has compiled: enable/disable the HIP-event bracket around each operator's
+   dominant kernel and report the operator with the most accumulated kernel time (its descriptor text in op_desc_out). */
+int gpuq_plan_profile(gpuq_plan* plan, int enable, float* kernel_ms_out, int* launches_out, char* op_desc_out, size_t cap);
+int64_t gpuq_result_num_rows(const gpuq_result* r);
+int gpuq_result_num_columns(const gpuq_result* r);
+int gpuq_result_column(const gpuq_result* r, int i, gpuq_column* col_out, gpuq_field_info* field_out);
+void gpuq_result_free(gpuq_result* r);
+/* When all columns of the result live in ONE device allocation of the fixed "record" layout (an aggregate's output: 256-byte
+   header, then per column data and validity, 256-byte aligned, for *cap_out rows), returns it: such a result can be shipped
+   between GPUs as it lies.  *base_out = NULL otherwise. */
+int gpuq_result_record(const gpuq_result* r, void** base_out, size_t* bytes_out, int64_t* cap_out);
+
 /* ---- synthetic TPC-H-shaped input (bench/test support) ------------------- */
 typedef struct gpuq_lineitem_cols {
   int64_t* l_orderkey; int64_t* l_suppkey;

@@ -1,0 +1,126 @@
+"""The native (C++) plan executor, csrc/plan_exec.cpp, driven through gpuq_plan_create / gpuq_plan_execute: the same plans as
+the operator tests, executed without any Python between operators, against the oracle (and against the Python mirror in
+plan.py, which must agree row for row)."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import arrow_ballista_amd as g
+import tpch_util as T
+from arrow_ballista_amd.expr import Operator as Op
+from arrow_ballista_amd.expr import and_, binary, col, is_not_null, lit
+from oracle import oracle_np as O
+from test_gpu_operators import JOIN_TYPES, agg_cases, close_rows, dev_rows, norm, ora_rows, rand_table
+
+pytestmark = pytest.mark.gpu
+
+
+def arrow_rows(t):
+    cols = []
+    for f, c in zip(t.schema, t.columns):
+        if pa.types.is_decimal128(f.type):
+            cols.append([None if v is None else int(v.scaleb(f.type.scale)) for v in c.to_pylist()])
+        elif pa.types.is_date32(f.type):
+            cols.append(c.cast(pa.int32()).to_pylist())
+        else:
+            cols.append(c.to_pylist())
+    return list(zip(*cols)) if cols else []
+
+
+def native_rows(tc, plan, partition=0):
+    np_ = g.NativePlan(plan, tc)
+    try:
+        r = np_.execute(partition)
+        return arrow_rows(r.to_arrow()), np_
+    finally:
+        pass
+
+
+@pytest.mark.parametrize("n", [1, 65, 200_000])
+@pytest.mark.parametrize("two_phase", [True, False])
+def test_native_q1(tc, n, two_phase):
+    li = T.gen_lineitem_device(tc, n, seed=T.SEED_LINEITEM, seed_orders=T.SEED_ORDERS)
+    plan = T.q1_plan(g.MemoryExec([li]), two_phase=two_phase)
+    got, np_ = native_rows(tc, plan)
+    assert [tuple(r) for r in got] == T.q1_oracle_rows(n)
+    m = np_.metrics()
+    assert m[0]["node"] == "SortExec" and m[0]["output_rows"] == len(got) and any(x["node"] == "AggregateExec" for x in m)
+
+
+def test_native_q3_q5(tc):
+    import test_gpu_tpch as M
+    (li, od, cu, su), (hl, ho, hc, hs) = M._tables(tc, 120_000, 1500, 100)
+    q3 = T.q3_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]))
+    got, _ = native_rows(tc, q3)
+    exp = T.q3_oracle(hc, ho, hl)
+    assert [(r[1], r[2]) for r in got] == [(r[1], r[2]) for r in exp] and sorted(got) == sorted(exp) and len(exp) > 0
+    nation, region = T.nation_region_arrow()
+    q5 = T.q5_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), g.MemoryExec([su]), g.MemoryExec([nation]), g.MemoryExec([region]))
+    got, _ = native_rows(tc, q5)
+    assert [tuple(r) for r in got] == [tuple(r) for r in T.q5_oracle(hc, ho, hl, hs)]
+
+
+@pytest.mark.parametrize("nulls", [0.0, 0.15])
+def test_native_filter_projection_aggregate(tc, nulls):
+    t = rand_table(900, 30_000, nulls)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    pred = and_(binary(col("d", s), Op.LtEq, lit(9800, "Date32")), binary(col("k32", s), Op.Gt, lit(-20, "Int32")))
+    f = g.FilterExec(pred, src)
+    exprs = [(binary(col("dec", s), Op.Multiply, col("dec", s)), "sq"), (col("flag", s), "flag"), (col("k64", s), "k64"), (col("f", s), "f")]
+    p = g.ProjectionExec(exprs, g.CoalesceBatchesExec(f))
+    got, _ = native_rows(tc, p)
+    exp = ora_rows(O.project(ot.take(O.filter_rows(ot, pred)), [e for e, _ in exprs], [n for _, n in exprs]))
+    close_rows(got, exp, rel=0.0)
+    assert got == dev_rows(tc, p.execute(0, tc))
+    ps = p.schema()
+    for groups, aggs in agg_cases(s):
+        a = g.AggregateExec("Single", groups, aggs, f)
+        got, _ = native_rows(tc, a)
+        close_rows(norm(got), norm(ora_rows(O.aggregate(ot, groups, aggs, "Single", predicate=pred))))
+    # two-phase, the projection fused below the partial aggregate
+    aggs = [{"fn": "SUM", "expr": col("sq", ps), "name": "s"}, {"fn": "COUNT", "expr": lit(1), "name": "c"}, {"fn": "AVG", "expr": col("f", ps), "name": "a"}]
+    part = g.AggregateExec("Partial", [(col("flag", ps), "flag")], aggs, p)
+    fs = part.schema()
+    fin = g.AggregateExec("FinalPartitioned", [(col("flag", fs), "flag")], [dict(x, expr=None) for x in aggs], part)
+    got, _ = native_rows(tc, fin)
+    exp = O.aggregate(O.project(ot.take(O.filter_rows(ot, pred)), [e for e, _ in exprs], [n for _, n in exprs]),
+                      [(col("flag", ps), "flag")], aggs, "Single")
+    close_rows(norm(got), norm(ora_rows(exp)))
+
+
+@pytest.mark.parametrize("jt", JOIN_TYPES)
+def test_native_hash_join_types(tc, jt):
+    nl, nr = 3000, 7000
+    lt = rand_table(21, nl, 0.2).append_column("lid", pa.array(np.arange(nl, dtype=np.int64)))
+    rt = rand_table(22, nr, 0.2).append_column("rid", pa.array(np.arange(nr, dtype=np.int64)))
+    rt = rt.rename_columns([c if c == "rid" else "r_" + c for c in rt.schema.names])
+    L, R = g.MemoryExec([lt]), g.MemoryExec([rt])
+    ls, rs = L.schema(), R.schema()
+    for on in ([(col("k64", ls), col("r_k64", rs))], [(col("k32", ls), col("r_k32", rs)), (col("flag", ls), col("r_flag", rs))]):
+        lf = g.FilterExec(is_not_null(col("d", ls)), L)        # fused into the build
+        rf = g.FilterExec(binary(col("r_k32", rs), Op.Lt, lit(40, "Int32")), R)   # fused into the probe
+        plan = g.HashJoinExec(lf, rf, on, None, jt, "CollectLeft", False)
+        got, _ = native_rows(tc, plan)
+        assert norm(got) == norm(dev_rows(tc, plan.execute(0, tc)))
+
+
+def test_native_sort_fetch_and_limit(tc):
+    t = rand_table(77, 50_000, 0.1)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    spec = [{"expr": col("flag", s), "asc": True, "nulls_first": False}, {"expr": col("dec", s), "asc": False, "nulls_first": True},
+            {"expr": col("k64", s), "asc": True, "nulls_first": True}]
+    got, _ = native_rows(tc, g.SortExec(spec, src, fetch=100))
+    exp = [tuple(c[i] for c in ot.cols) for i in O.sort_perm(ot, spec)[:100]]
+    close_rows(got, exp, rel=0.0)
+    got, _ = native_rows(tc, g.LocalLimitExec(g.SortExec(spec[:1], g.FilterExec(is_not_null(col("flag", s)), src)), 7))
+    assert len(got) == 7 and all(r[6] == got[0][6] for r in got)
+
+
+def test_native_unsupported_node_fails_loudly(tc):
+    t = rand_table(1, 10, 0.0)
+    with pytest.raises(g.GpuqError):
+        g.NativePlan(g.UnionExec([g.MemoryExec([t]), g.MemoryExec([t])]), tc)
