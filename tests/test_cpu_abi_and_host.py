@@ -124,3 +124,31 @@ def test_q1_plan_schema_matches_reference_answer_shape():
             break
         p = ch[0]
     assert names == ["SortExec", "ProjectionExec", "AggregateExec", "CoalesceBatchesExec", "AggregateExec", "ProjectionExec", "CoalesceBatchesExec", "FilterExec", "MemoryExec"]
+
+
+def test_native_plan_json_is_parsed_without_a_device():
+    """gpuq_plan_create only builds the node tree (operators are compiled at first execution): the plan grammar can be
+    validated on a host without a GPU.  Unknown node types are refused loudly (GPUQ_ERR_UNSUPPORTED), malformed plans are
+    GPUQ_ERR_INVALID."""
+    import ctypes as C
+    import json
+    from arrow_ballista_amd import binding as B
+    L = B.lib()
+    schema = [{"name": "k", "type": "Int64", "nullable": False}, {"name": "v", "type": {"Decimal128": [15, 2]}, "nullable": True}]
+    col = lambda n: {"column": {"name": n}}
+    plan = {"SortExec": {"expr": [{"expr": col("s"), "asc": False, "nulls_first": True}], "fetch": 10, "input":
+            {"AggregateExec": {"mode": "Single", "group_expr": [{"expr": col("k"), "name": "k"}], "aggr_expr": [{"fn": "SUM", "expr": col("v"), "name": "s"}], "input":
+             {"CoalesceBatchesExec": {"input": {"FilterExec": {"expr": {"is_not_null_expr": {"expr": col("v")}}, "input":
+              {"HashJoinExec": {"left": {"MemoryExec": {"schema": schema, "partitions": [0]}}, "right": {"MemoryExec": {"schema": schema, "partitions": [1, 2]}},
+                                "on": [{"left": col("k"), "right": col("k")}], "join_type": "LeftSemi", "partition_mode": "CollectLeft", "null_equals_null": False}}}}}}}}}}
+    h = C.c_void_p()
+    # a context handle is only dereferenced at execution time
+    fake_ctx = C.c_void_p(1)
+    assert L.gpuq_plan_create(fake_ctx, json.dumps(plan).encode(), C.byref(h)) == 0, L.gpuq_plan_last_error()
+    assert L.gpuq_plan_num_partitions(h) == 2            # the join follows its probe (right) side: 2 partitions, kept by Filter / Aggregate / Sort
+    L.gpuq_plan_free(h)
+    h = C.c_void_p()
+    assert L.gpuq_plan_create(fake_ctx, json.dumps({"WindowAggExec": {"input": plan}}).encode(), C.byref(h)) == 3
+    assert b"WindowAggExec" in L.gpuq_plan_last_error()
+    assert L.gpuq_plan_create(fake_ctx, b'{"FilterExec": {"input": 1}}', C.byref(h)) == 1
+    assert L.gpuq_plan_create(fake_ctx, b'not json', C.byref(h)) == 1
