@@ -100,6 +100,55 @@ def tpch_pipelines(tc, T, g, sf):
     return out
 
 
+def cpu_proxy_acero(T, sf):
+    """CPU PROXY for q3 / q5 (SURVEY.md section 8d fallback): pyarrow Acero (multi-threaded hash join / group-by / sort) on the
+    host cores over the same synthetic tables, money columns as int64 cents (cheaper for the CPU than the reference's Decimal128).
+    It is NOT the reference's DataFusion path -- that cannot be built here -- and is reported only to put the GPU numbers next
+    to a vectorised multi-core CPU engine on the same box.  Results are checked against the oracle's group counts."""
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    n_li = T.LINEITEM_ROWS.get(sf, int(6_000_000 * sf))
+    n_orders, n_cust, n_supp = (n_li + 3) // 4, int(150_000 * sf), int(10_000 * sf)
+    d = T.gen_lineitem_host(n_li, n_supp=n_supp)
+    li = pa.table({"l_orderkey": d["l_orderkey"], "l_suppkey": d["l_suppkey"], "l_extendedprice": d["l_extendedprice"][0::2].astype(np.int64),
+                   "l_discount": d["l_discount"][0::2].astype(np.int64), "l_shipdate": d["l_shipdate"]})
+    del d
+    orders, customer, supplier = T.gen_other_tables_host(n_orders, n_cust, n_supp)
+    orders = orders.set_column(2, "o_orderdate", orders["o_orderdate"].cast(pa.int32()))
+    nation, region = T.nation_region_arrow()
+
+    def q3():
+        c = customer.filter(pc.equal(customer["c_mktsegment"], "BUILDING")).select(["c_custkey"])
+        o = orders.filter(pc.less(orders["o_orderdate"], T.Q3_DATE))
+        co = o.join(c, keys="o_custkey", right_keys="c_custkey", join_type="inner").select(["o_orderkey", "o_orderdate", "o_shippriority"])
+        l = li.filter(pc.greater(li["l_shipdate"], T.Q3_DATE)).select(["l_orderkey", "l_extendedprice", "l_discount"])
+        j = l.join(co, keys="l_orderkey", right_keys="o_orderkey", join_type="inner")
+        j = j.append_column("rev", pc.multiply(j["l_extendedprice"], pc.subtract(100, j["l_discount"])))
+        g_ = j.group_by(["l_orderkey", "o_orderdate", "o_shippriority"]).aggregate([("rev", "sum")])
+        return g_.sort_by([("rev_sum", "descending"), ("o_orderdate", "ascending")])
+
+    def q5():
+        r = region.filter(pc.equal(region["r_name"], "ASIA"))
+        n_ = nation.join(r, keys="n_regionkey", right_keys="r_regionkey", join_type="inner").select(["n_nationkey", "n_name"])
+        c = customer.join(n_, keys="c_nationkey", right_keys="n_nationkey", join_type="inner").select(["c_custkey", "c_nationkey", "n_name"])
+        o = orders.filter(pc.and_(pc.greater_equal(orders["o_orderdate"], T.Q5_DATE_LO), pc.less(orders["o_orderdate"], T.Q5_DATE_HI)))
+        oc = o.join(c, keys="o_custkey", right_keys="c_custkey", join_type="inner").select(["o_orderkey", "c_nationkey", "n_name"])
+        l = li.select(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]).join(oc, keys="l_orderkey", right_keys="o_orderkey", join_type="inner")
+        ls = l.join(supplier, keys=["l_suppkey", "c_nationkey"], right_keys=["s_suppkey", "s_nationkey"], join_type="inner")
+        ls = ls.append_column("rev", pc.multiply(ls["l_extendedprice"], pc.subtract(100, ls["l_discount"])))
+        return ls.group_by(["n_name"]).aggregate([("rev", "sum")]).sort_by([("rev_sum", "descending")])
+    out = {"engine": "pyarrow %s Acero, %d threads" % (pa.__version__, pa.cpu_count()), "sf": sf, "lineitem_rows": n_li,
+           "note": "CPU proxy, not the reference's DataFusion path; int64 cents instead of Decimal128"}
+    for name, fn in (("q3", q3), ("q5", q5)):
+        best, rows = None, 0
+        for _ in range(2):
+            t0 = time.perf_counter(); res = fn(); dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best; rows = res.num_rows
+        out[name] = {"wall_ms_best": best * 1e3, "result_rows": rows, "lineitem_rows_per_s": n_li / best}
+    return out
+
+
 def run(tc, T, g, full=True):
     extra = {"join_probe": []}
     grid = [(20, 28, 1.0), (24, 28, 1.0), (27, 28, 1.0), (24, 28, 0.5), (24, 28, 0.1)] if full else [(20, 24, 1.0)]
@@ -117,6 +166,10 @@ if __name__ == "__main__":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import tpch_util as T
     import arrow_ballista_amd as g
+    if "--cpu-proxy" in sys.argv:
+        sf = 10 if "--sf10" in sys.argv else 1
+        print(json.dumps(cpu_proxy_acero(T, sf), indent=1))
+        sys.exit(0)
     tc = g.TaskContext(device=0)
     if "--sf100" in sys.argv:
         out = {"q1": q1_pipeline(tc, T, g, 100)}
