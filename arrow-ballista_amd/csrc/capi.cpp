@@ -865,11 +865,15 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         alloc_raw(std::max<i64>(n, 1));
         launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
         HIPCHECK(hipGetLastError());
+        // as on the LDS path: queue the result projection before the group count is known on the host (it reads the count on
+        // the device) when the caller's columns can hold any outcome -- one host round trip instead of two
+        const bool ahead = (i64)raw.cap <= cap;
+        if (ahead) run_post((uint32_t)raw.cap, raw.n_groups);
         uint32_t fw[4] = {0, 0, 0, 0};
-        HIPCHECK(hipMemcpyAsync(fw, op->flags_dev.p, 16, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
+        read_status(op, s, fw, 4);
         if (fw[0]) { reset_flags(op, s); raise_flags(fw[0]); }
         ng = fw[2];
+        posted = ahead;
       } else {
         // count live slots first so the raw buffers are sized exactly
         alloc_raw(1);
