@@ -123,6 +123,7 @@ struct Exec {
   std::map<std::string, gpuq_op*>* ops = nullptr;        // compiled operators, keyed by descriptor text (owned by the plan)
   const gpuq_input* inputs = nullptr; int n_inputs = 0;
   uint64_t* pin = nullptr;                                // pinned host words for count read-backs
+  std::map<std::string, gpuq_op*>* memo = nullptr;       // (call site, input layout) -> operator: skips rebuilding the descriptor
 };
 
 void check(Exec& x, int rc) {
@@ -141,6 +142,16 @@ gpuq_op* get_op(Exec& x, const Json& desc) {
   gpuq_op* op = nullptr;
   check(x, gpuq_op_create(x.ctx, key.c_str(), &op));
   (*x.ops)[key] = op;
+  return op;
+}
+// Operator for a call site and an input layout.  Building and serialising a descriptor costs tens of microseconds; a plan
+// that runs repeatedly (or over many partitions) sees the same layouts again, so the descriptor is only built on a miss.
+template <class MakeDesc> gpuq_op* cached_op(Exec& x, const void* site, int tag, const std::string& sig, MakeDesc&& mk) {
+  std::string key = std::to_string((uintptr_t)site); key += '#'; key += std::to_string(tag); key += '#'; key += sig;
+  auto it = x.memo->find(key);
+  if (it != x.memo->end()) return it->second;
+  gpuq_op* op = get_op(x, mk());
+  (*x.memo)[key] = op;
   return op;
 }
 uint64_t read_u64(Exec& x, const void* dev) {
@@ -187,11 +198,13 @@ PTable alloc_outputs(gpuq_op* op, int64_t n, std::vector<gpuq_column>& carr) {
   return t;
 }
 
-PTable project(Exec& x, const PTable& t, const std::vector<Json>& exprs, const std::vector<std::string>& names) {
-  Json ex = jarr();
-  const auto nm = names_of(t);
-  for (size_t i = 0; i < exprs.size(); ++i) ex.a.push_back(jobj({{"expr", rebind(exprs[i], nm)}, {"name", jstr(names[i])}}));
-  gpuq_op* op = get_op(x, jobj({{"op", jstr("project")}, {"input", jobj({{"fields", table_fields(t)}})}, {"exprs", ex}}));
+PTable project(Exec& x, const PTable& t, const std::vector<Json>& exprs, const std::vector<std::string>& names, const void* site, int tag) {
+  gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
+    Json ex = jarr();
+    const auto nm = names_of(t);
+    for (size_t i = 0; i < exprs.size(); ++i) ex.a.push_back(jobj({{"expr", rebind(exprs[i], nm)}, {"name", jstr(names[i])}}));
+    return jobj({{"op", jstr("project")}, {"input", jobj({{"fields", table_fields(t)}})}, {"exprs", ex}});
+  });
   std::vector<gpuq_column> carr;
   PTable out = alloc_outputs(op, t.n, carr);
   InputC ic; make_input(t, ic);
@@ -204,10 +217,11 @@ const uint32_t* take_u32(Exec& x, const uint32_t* vec, int64_t vec_len, const ui
   PTable src; src.n = n; src.via.push_back(idx); src.sides.push_back(1);
   PCol c; c.name = "v"; c.type = jstr("UInt32"); c.nullable = false; c.c.type = T_UINT32; c.c.data = vec; c.c.length = vec_len;
   src.cols.push_back(c);
+  static const int take_site = 0;
   const Json v = jcol("v", 0);
   const Json e = jobj({{"case_", jobj({{"expr", Json()}, {"when_then_expr", jarr({jobj({{"when_expr", jobj({{"is_null_expr", jobj({{"expr", v}})}})},
                       {"then_expr", jobj({{"literal", jobj({{"type", jstr("UInt32")}, {"value", jstr(std::to_string(NULL_ROW_ID))}})}})}})})}, {"else_expr", v}})}});
-  PTable out = project(x, src, {e}, {"v"});
+  PTable out = project(x, src, {e}, {"v"}, &take_site, 0);
   keep.insert(keep.end(), out.keep.begin(), out.keep.end());
   return (const uint32_t*)out.cols[0].c.data;
 }
@@ -244,9 +258,12 @@ PTable materialize(Exec& x, const PTable& t, bool force) {
     for (size_t i = a; i < std::min(a + 12, t.cols.size()); ++i) { sub.cols.push_back(t.cols[i]); sub.sides.push_back(t.sides[i]); }
     for (size_t i = 0; i < sub.cols.size(); ++i) { ex.push_back(jcol(sub.cols[i].name, (int)i)); nm.push_back(sub.cols[i].name); }
     // rebind by position, not by name: duplicate names (join outputs) must keep their own column
-    Json exj = jarr();
-    for (size_t i = 0; i < ex.size(); ++i) exj.a.push_back(jobj({{"expr", ex[i]}, {"name", jstr(nm[i])}}));
-    gpuq_op* op = get_op(x, jobj({{"op", jstr("project")}, {"input", jobj({{"fields", table_fields(sub)}})}, {"exprs", exj}}));
+    static const int mat_site = 0;
+    gpuq_op* op = cached_op(x, &mat_site, 0, table_sig(sub), [&]() {
+      Json exj = jarr();
+      for (size_t i = 0; i < ex.size(); ++i) exj.a.push_back(jobj({{"expr", ex[i]}, {"name", jstr(nm[i])}}));
+      return jobj({{"op", jstr("project")}, {"input", jobj({{"fields", table_fields(sub)}})}, {"exprs", exj}});
+    });
     std::vector<gpuq_column> carr;
     PTable part = alloc_outputs(op, sub.n, carr);
     InputC ic; make_input(sub, ic);
@@ -259,9 +276,10 @@ PTable materialize(Exec& x, const PTable& t, bool force) {
   return out;
 }
 
-PTable filter_table(Exec& x, const PTable& t, const Json& predicate) {
-  const auto nm = names_of(t);
-  gpuq_op* op = get_op(x, jobj({{"op", jstr("filter")}, {"input", jobj({{"fields", table_fields(t)}})}, {"predicate", rebind(predicate, nm)}}));
+PTable filter_table(Exec& x, const PTable& t, const Json& predicate, const void* site, int tag) {
+  gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
+    return jobj({{"op", jstr("filter")}, {"input", jobj({{"fields", table_fields(t)}})}, {"predicate", rebind(predicate, names_of(t))}});
+  });
   BufP sel = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 4 + 16), cnt = dev_alloc(16);
   InputC ic; make_input(t, ic);
   check(x, gpuq_filter_run(op, x.stream, &ic.in, 0, (uint32_t*)sel->p, (uint64_t*)cnt->p));
@@ -270,14 +288,16 @@ PTable filter_table(Exec& x, const PTable& t, const Json& predicate) {
   return select_view(x, t, (const uint32_t*)sel->p, k, sel);
 }
 
-PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetch) {
-  const auto nm = names_of(t);
-  Json ex = jarr();
-  for (auto& s : sort_exprs.a) {
-    const bool asc = s.get_bool("asc", true);
-    ex.a.push_back(jobj({{"expr", rebind(s.at("expr"), nm)}, {"asc", jbool(asc)}, {"nulls_first", jbool(s.get_bool("nulls_first", !asc))}}));
-  }
-  gpuq_op* op = get_op(x, jobj({{"op", jstr("sort")}, {"input", jobj({{"fields", table_fields(t)}})}, {"expr", ex}}));
+PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
+  gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
+    const auto nm = names_of(t);
+    Json ex = jarr();
+    for (auto& s : sort_exprs.a) {
+      const bool asc = s.get_bool("asc", true);
+      ex.a.push_back(jobj({{"expr", rebind(s.at("expr"), nm)}, {"asc", jbool(asc)}, {"nulls_first", jbool(s.get_bool("nulls_first", !asc))}}));
+    }
+    return jobj({{"op", jstr("sort")}, {"input", jobj({{"fields", table_fields(t)}})}, {"expr", ex}});
+  });
   BufP perm = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 4 + 16);
   InputC ic; make_input(t, ic);
   check(x, gpuq_sort_run(op, x.stream, &ic.in, (uint32_t*)perm->p));
@@ -366,21 +386,21 @@ PTable FilterExec::execute(int part, Exec& x) {
   Fused f = fuse(this);
   PTable t = f.src->execute(part, x);
   auto t0 = std::chrono::steady_clock::now();
-  if (!f.has_map) return timed(t0, filter_table(x, t, f.pred));
+  if (!f.has_map) return timed(t0, filter_table(x, t, f.pred, this, 0));
   // a computed projection sits below: run it on the filtered rows
-  PTable v = filter_table(x, t, f.pred);
+  PTable v = filter_table(x, t, f.pred, this, 0);
   std::vector<Json> ex; std::vector<std::string> nm;
   for (auto& kv : f.map) { nm.push_back(kv.first); ex.push_back(kv.second); }
-  return timed(t0, project(x, v, ex, nm));
+  return timed(t0, project(x, v, ex, nm, this, 1));
 }
 PTable ProjectionExec::execute(int part, Exec& x) {
   Fused f = fuse(input.get());
   PTable t = f.src->execute(part, x);
   auto t0 = std::chrono::steady_clock::now();
-  if (f.has_pred) t = filter_table(x, t, f.pred);
+  if (f.has_pred) t = filter_table(x, t, f.pred, this, 0);
   std::vector<Json> ex;
   for (auto& e : exprs) ex.push_back(inline_projection(e, f.has_map ? &f.map : nullptr));
-  return timed(t0, project(x, t, ex, names));
+  return timed(t0, project(x, t, ex, names, this, 1));
 }
 
 struct AggregateExec : PNode {
@@ -391,6 +411,7 @@ struct AggregateExec : PNode {
     Fused f; if (final_) f.src = input.get(); else f = fuse(input.get());
     PTable t = f.src->execute(part, x);
     auto t0 = std::chrono::steady_clock::now();
+    gpuq_op* op = cached_op(x, this, 0, table_sig(t), [&]() {
     const auto nm = names_of(t);
     const ColMap* cm = f.has_map ? &f.map : nullptr;
     Json ge = jarr(), ae = jarr();
@@ -404,7 +425,8 @@ struct AggregateExec : PNode {
                                                    {"strategy", jstr(strategy)}, {"group_expr", ge}, {"aggr_expr", ae}};
     if (f.has_pred) d.push_back({"predicate", rebind(f.pred, nm)});
     if (expected_groups) d.push_back({"expected_groups", jnum(expected_groups)});
-    gpuq_op* op = get_op(x, jobj(d));
+    return jobj(d);
+    });
     int64_t cap = output_capacity > 0 ? output_capacity : (group_expr.a.empty() ? 4096 : std::max<int64_t>(4096, std::min<int64_t>(t.n, 1ll << 22)));
     InputC ic; make_input(t, ic);
     for (;;) {
@@ -428,7 +450,7 @@ struct SortExec : PNode {
     if (merge_all && input->partitions() != 1) throw Unsupported("SortPreservingMergeExec over several partitions: coalesce them first");
     PTable t = input->execute(part, x);
     auto t0 = std::chrono::steady_clock::now();
-    return timed(t0, sort_table(x, t, expr, fetch));
+    return timed(t0, sort_table(x, t, expr, fetch, this, 0));
   }
 };
 
@@ -462,15 +484,23 @@ struct HashJoinExec : PNode {
     if (partition_mode != "Partitioned" && left->partitions() != 1) throw Unsupported("CollectLeft with a multi-partition build side: wrap the left input in a single partition");
     Side L = side(left.get(), lpart, x), R = side(right.get(), part, x);
     auto t0 = std::chrono::steady_clock::now();
-    const auto ln = names_of(L.t), rn = names_of(R.t);
-    Json lk = jarr(), rk = jarr();
-    for (auto& o : on.a) { lk.a.push_back(rebind(o.at("left"), ln)); rk.a.push_back(rebind(o.at("right"), rn)); }
-    std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(L.t)}})}, {"on", lk}, {"null_equals_null", jbool(null_equals_null)}};
-    if (L.has_pred) bd.push_back({"predicate", rebind(L.pred, ln)});
-    std::vector<std::pair<std::string, Json>> pd = {{"op", jstr("join_probe")}, {"input", jobj({{"fields", table_fields(R.t)}})}, {"on", rk}, {"join_type", jstr(jt)},
-                                                   {"null_equals_null", jbool(null_equals_null)}};
-    if (R.has_pred) pd.push_back({"predicate", rebind(R.pred, rn)});
-    gpuq_op* bop = get_op(x, jobj(bd)); gpuq_op* pop = get_op(x, jobj(pd));
+    gpuq_op* bop = cached_op(x, this, 0, table_sig(L.t), [&]() {
+      const auto ln = names_of(L.t);
+      Json lk = jarr();
+      for (auto& o : on.a) lk.a.push_back(rebind(o.at("left"), ln));
+      std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(L.t)}})}, {"on", lk}, {"null_equals_null", jbool(null_equals_null)}};
+      if (L.has_pred) bd.push_back({"predicate", rebind(L.pred, ln)});
+      return jobj(bd);
+    });
+    gpuq_op* pop = cached_op(x, this, 1, table_sig(R.t), [&]() {
+      const auto rn = names_of(R.t);
+      Json rk = jarr();
+      for (auto& o : on.a) rk.a.push_back(rebind(o.at("right"), rn));
+      std::vector<std::pair<std::string, Json>> pd = {{"op", jstr("join_probe")}, {"input", jobj({{"fields", table_fields(R.t)}})}, {"on", rk}, {"join_type", jstr(jt)},
+                                                     {"null_equals_null", jbool(null_equals_null)}};
+      if (R.has_pred) pd.push_back({"predicate", rebind(R.pred, rn)});
+      return jobj(pd);
+    });
     InputC lic, ric; make_input(L.t, lic); make_input(R.t, ric);
     gpuq_join_table* jtab = nullptr;
     check(x, gpuq_join_build_run(bop, x.stream, &lic.in, 0, L.t.n, &jtab));
@@ -505,7 +535,7 @@ struct HashJoinExec : PNode {
     PTable out = join_view(x, L.t, R.t, (const uint32_t*)ob->p, (const uint32_t*)opb->p, k, ob, opb);
     if (has_filter) {
       if (jt != "Inner") throw Unsupported("JoinFilter on a non-inner join is not supported on device yet");
-      out = filter_table(x, out, filter);
+      out = filter_table(x, out, filter, this, 2);
     }
     // the probe kernels read the build table asynchronously; results were read back (synchronised) above
     return timed(t0, out);
@@ -573,7 +603,7 @@ thread_local std::string g_plan_error;
 }  // namespace
 
 struct gpuq_plan {
-  gpuq_ctx* ctx = nullptr; PNodeP root; std::map<std::string, gpuq_op*> ops; uint64_t* pin = nullptr;
+  gpuq_ctx* ctx = nullptr; PNodeP root; std::map<std::string, gpuq_op*> ops, memo; uint64_t* pin = nullptr;
   ~gpuq_plan() { for (auto& kv : ops) gpuq_op_free(kv.second); if (pin) (void)hipHostFree(pin); }
 };
 struct gpuq_result { PTable t; std::vector<gpuq_field_info> fields; };
@@ -615,7 +645,7 @@ int gpuq_plan_execute(gpuq_plan* p, void* stream, int partition, const gpuq_inpu
   *out = nullptr;
   return plan_guarded([&]() {
     if (!p->pin) HIPCHECK(hipHostMalloc((void**)&p->pin, 64, hipHostMallocDefault));
-    Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin;
+    Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin; x.memo = &p->memo;
     PTable t = materialize(x, p->root->execute(partition, x));
     HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
     std::unique_ptr<gpuq_result> r(new gpuq_result());
