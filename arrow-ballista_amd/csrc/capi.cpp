@@ -1129,7 +1129,16 @@ int gpuq_concat_bitmap(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bi
     check_ctx(ctx);
     if (!dst || dst_bit_offset < 0 || n_bits < 0) throw std::runtime_error("bad arguments");
     if (((uintptr_t)dst & 7) != 0) throw std::runtime_error("dst bitmap must be 8-byte aligned");
-    launch_concat_bitmap((hipStream_t)stream, (u64*)dst, dst_bit_offset, src, n_bits);
+    launch_concat_bitmap((hipStream_t)stream, (u64*)dst, dst_bit_offset, src, 0, n_bits);
+    HIPCHECK(hipGetLastError());
+  });
+}
+int gpuq_copy_bits(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src, int64_t src_bit_offset, int64_t n_bits) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!dst || dst_bit_offset < 0 || src_bit_offset < 0 || n_bits < 0) throw std::runtime_error("bad arguments");
+    if (((uintptr_t)dst & 7) != 0) throw std::runtime_error("dst bitmap must be 8-byte aligned");
+    launch_concat_bitmap((hipStream_t)stream, (u64*)dst, dst_bit_offset, src, src_bit_offset, n_bits);
     HIPCHECK(hipGetLastError());
   });
 }

@@ -900,12 +900,12 @@ void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, 
 void launch_unpack_utf8_bytes(hipStream_t s, const ulonglong2* packed, i64 n, const int32_t* offsets, uint8_t* data_out) {
   if (n > 0) hipLaunchKernelGGL(k_unpack_bytes, dim3(lin_grid(n)), dim3(BLOCK), 0, s, packed, n, offsets, data_out);
 }
-// dst bits [off, off+n) <- src bits [0, n) (src == nullptr: all ones).  dst is zero-initialised by the caller; words shared
-// between neighbouring pieces are merged with atomicOr.  One thread per destination word.
-__global__ void __launch_bounds__(BLOCK) k_concat_bitmap(u64* dst, const i64 off, const uint8_t* __restrict__ src, const i64 n) {
+// dst bits [off, off+n) <- src bits [soff, soff+n) (src == nullptr: all ones).  dst is zero-initialised by the caller; words
+// shared between neighbouring pieces are merged with atomicOr.  One thread per destination word.
+__global__ void __launch_bounds__(BLOCK) k_concat_bitmap(u64* dst, const i64 off, const uint8_t* __restrict__ src, const i64 soff, const i64 n) {
   const i64 w0 = off >> 6, w1 = (off + n - 1) >> 6;
   for (i64 w = w0 + (i64)blockIdx.x * BLOCK + threadIdx.x; w <= w1; w += (i64)gridDim.x * BLOCK) {
-    const i64 s0 = w * 64 - off;           // source bit that lands on bit 0 of this word (may be negative / beyond n)
+    const i64 s0 = w * 64 - off;           // piece-relative bit that lands on bit 0 of this word (may be negative / beyond n)
     u64 v = 0;
     if (!src) {
       const i64 lo = s0 < 0 ? -s0 : 0, hi = (n - s0) < 64 ? (n - s0) : 64;
@@ -913,14 +913,14 @@ __global__ void __launch_bounds__(BLOCK) k_concat_bitmap(u64* dst, const i64 off
     } else {
       for (int b = 0; b < 64; ++b) {
         const i64 sb = s0 + b;
-        if (sb >= 0 && sb < n) v |= (u64)((src[sb >> 3] >> (sb & 7)) & 1) << b;
+        if (sb >= 0 && sb < n) { const i64 q = sb + soff; v |= (u64)((src[q >> 3] >> (q & 7)) & 1) << b; }
       }
     }
     if (v) atomicOr((unsigned long long*)(dst + w), (unsigned long long)v);
   }
 }
-void launch_concat_bitmap(hipStream_t s, u64* dst, i64 off, const uint8_t* src, i64 n) {
-  if (n > 0) hipLaunchKernelGGL(k_concat_bitmap, dim3(lin_grid((n + 127) / 64)), dim3(BLOCK), 0, s, dst, off, src, n);
+void launch_concat_bitmap(hipStream_t s, u64* dst, i64 off, const uint8_t* src, i64 src_off, i64 n) {
+  if (n > 0) hipLaunchKernelGGL(k_concat_bitmap, dim3(lin_grid((n + 127) / 64)), dim3(BLOCK), 0, s, dst, off, src, src_off, n);
 }
 size_t exclusive_scan_ws_bytes(i64 n) { return (size_t)((n + 1 + SCAN_TILE - 1) / SCAN_TILE + 1) * 8; }
 void launch_exclusive_scan_i32(hipStream_t s, int32_t* data, i64 n, void* workspace, size_t) {

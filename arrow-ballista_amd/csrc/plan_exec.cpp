@@ -305,6 +305,8 @@ PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetc
   return select_view(x, t, (const uint32_t*)perm->p, k, perm);
 }
 
+PTable concat_tables(Exec& x, std::vector<PTable> parts);
+
 // ---------------------------------------------------------------- plan nodes
 struct Metrics { int64_t output_rows = 0, elapsed_ns = 0; };
 struct PNode {
@@ -447,8 +449,11 @@ struct SortExec : PNode {
   std::vector<PNode*> children() override { return {input.get()}; }
   int partitions() override { return merge_all ? 1 : input->partitions(); }
   PTable execute(int part, Exec& x) override {
-    if (merge_all && input->partitions() != 1) throw Unsupported("SortPreservingMergeExec over several partitions: coalesce them first");
-    PTable t = input->execute(part, x);
+    PTable t;
+    if (merge_all && input->partitions() != 1) {
+      std::vector<PTable> in; for (int p = 0; p < input->partitions(); ++p) in.push_back(input->execute(p, x));
+      t = concat_tables(x, std::move(in));
+    } else t = input->execute(part, x);
     auto t0 = std::chrono::steady_clock::now();
     return timed(t0, sort_table(x, t, expr, fetch, this, 0));
   }
@@ -553,6 +558,127 @@ struct LimitExec : PNode {       // LocalLimitExec: first `fetch` rows of each p
   }
 };
 
+// ---------------------------------------------------------------- fan-in (coalesce_tasks.rs:130-229) and row ranges
+// Concatenation in partition order.  Pieces are first brought to the fixed-width layout (materialize(force): no views,
+// Utf8 as PACKED15); data buffers are joined with device copies, validity / Boolean bitmaps at bit granularity.
+PTable concat_tables(Exec& x, std::vector<PTable> parts) {
+  std::vector<PTable> live;
+  for (auto& p : parts) if (p.n > 0) live.push_back(p);
+  if (live.empty() && !parts.empty()) live.push_back(parts[0]);
+  if (live.empty()) throw std::runtime_error("concat: no input partitions");
+  auto needs = [](const PTable& t) { if (t.is_view()) return true; for (auto& c : t.cols) if (c.c.offsets) return true; return false; };
+  if (live.size() == 1 && !needs(live[0])) return live[0];
+  for (auto& p : live) p = materialize(x, p, true);
+  int64_t n = 0; for (auto& p : live) n += p.n;
+  const size_t nc = live[0].cols.size();
+  const size_t bm = (size_t)((n + 63) / 64) * 8 + 8;
+  std::vector<size_t> doff(nc), voff(nc, 0), dbytes(nc);
+  size_t off = 256;
+  for (size_t i = 0; i < nc; ++i) {
+    const PCol& c0 = live[0].cols[i];
+    for (auto& p : live) if (p.cols[i].c.type != c0.c.type || p.cols[i].c.repr != c0.c.repr) throw std::runtime_error("concat: column '" + c0.name + "' has different layouts across partitions");
+    DType dt; dt.id = c0.c.type; dt.p = c0.c.precision; dt.s = c0.c.scale;
+    dbytes[i] = c0.c.type == T_BOOL ? bm : (size_t)std::max<int64_t>(n, 1) * (size_t)type_width(dt) + 16;
+    doff[i] = off; off += (dbytes[i] + 255) & ~(size_t)255;
+    bool any_valid = false; for (auto& p : live) any_valid = any_valid || p.cols[i].c.validity != nullptr;
+    if (any_valid) { voff[i] = off; off += (bm + 255) & ~(size_t)255; }
+  }
+  BufP buf = dev_alloc(off);
+  hipStream_t s = (hipStream_t)x.stream;
+  PTable out; out.n = n; out.keep.push_back(buf); out.record_cap = std::max<int64_t>(n, 1);
+  for (size_t i = 0; i < nc; ++i) {
+    PCol c = live[0].cols[i];
+    DType dt; dt.id = c.c.type; dt.p = c.c.precision; dt.s = c.c.scale;
+    char* d = (char*)buf->p + doff[i];
+    uint8_t* v = voff[i] ? (uint8_t*)buf->p + voff[i] : nullptr;
+    if (c.c.type == T_BOOL) HIPCHECK(hipMemsetAsync(d, 0, bm, s));
+    if (v) HIPCHECK(hipMemsetAsync(v, 0, bm, s));
+    int64_t row = 0; bool nullable = false;
+    for (auto& p : live) {
+      const PCol& pc = p.cols[i];
+      nullable = nullable || pc.nullable;
+      if (p.n > 0) {
+        if (c.c.type == T_BOOL) check(x, gpuq_copy_bits(x.ctx, x.stream, (uint8_t*)d, row, (const uint8_t*)pc.c.data, 0, p.n));
+        else { const size_t w = (size_t)type_width(dt); HIPCHECK(hipMemcpyAsync(d + (size_t)row * w, pc.c.data, (size_t)p.n * w, hipMemcpyDeviceToDevice, s)); }
+        if (v) check(x, gpuq_copy_bits(x.ctx, x.stream, v, row, pc.c.validity, 0, p.n));      // NULL source = all valid
+      }
+      row += p.n;
+    }
+    c.nullable = nullable; c.c.data = d; c.c.validity = v; c.c.offsets = nullptr; c.c.length = n;
+    out.cols.push_back(c); out.sides.push_back(0);
+  }
+  for (auto& p : live) out.own(p);       // the copies above are asynchronous
+  return out;
+}
+
+// rows [skip, skip + count) of a table
+PTable slice_table(Exec& x, PTable t, int64_t skip, int64_t count) {
+  skip = std::min(std::max<int64_t>(skip, 0), t.n);
+  count = (count < 0 || skip + count > t.n) ? t.n - skip : count;
+  if (skip == 0) { t.n = count; if (!t.is_view()) for (auto& c : t.cols) c.c.length = count; return t; }
+  bool has0 = false; if (t.is_view()) for (int sd : t.sides) has0 = has0 || sd == 0;
+  if (t.is_view() && !has0) { for (auto& v : t.via) v += skip; t.n = count; return t; }      // every column goes through an index vector
+  t = materialize(x, t, true);
+  hipStream_t s = (hipStream_t)x.stream;
+  const size_t bm = (size_t)((count + 63) / 64) * 8 + 8;
+  for (auto& c : t.cols) {
+    DType dt; dt.id = c.c.type; dt.p = c.c.precision; dt.s = c.c.scale;
+    if (c.c.type == T_BOOL) {
+      BufP b = dev_alloc(bm); HIPCHECK(hipMemsetAsync(b->p, 0, bm, s));
+      check(x, gpuq_copy_bits(x.ctx, x.stream, (uint8_t*)b->p, 0, (const uint8_t*)c.c.data, skip, count));
+      c.c.data = b->p; t.keep.push_back(b);
+    } else c.c.data = (const char*)c.c.data + (size_t)skip * (size_t)type_width(dt);
+    if (c.c.validity) {
+      BufP b = dev_alloc(bm); HIPCHECK(hipMemsetAsync(b->p, 0, bm, s));
+      check(x, gpuq_copy_bits(x.ctx, x.stream, (uint8_t*)b->p, 0, c.c.validity, skip, count));
+      c.c.validity = (const uint8_t*)b->p; t.keep.push_back(b);
+    }
+    c.c.length = count;
+  }
+  t.n = count; t.record_cap = 0;
+  return t;
+}
+
+struct UnionExec : PNode {       // output partitions = the inputs' partitions, one input after another (UNION ALL)
+  std::vector<PNodeP> inputs;
+  std::vector<PNode*> children() override { std::vector<PNode*> v; for (auto& i : inputs) v.push_back(i.get()); return v; }
+  int partitions() override { int k = 0; for (auto& i : inputs) k += i->partitions(); return k; }
+  PTable execute(int part, Exec& x) override {
+    for (auto& i : inputs) { const int k = i->partitions(); if (part < k) { PTable t = i->execute(part, x); m.output_rows += t.n; return t; } part -= k; }
+    throw std::runtime_error("UnionExec: partition out of range");
+  }
+};
+
+struct CoalesceExec : PNode {    // CoalesceTasksExec / CoalescePartitionsExec: P partitions -> 1, optionally preserving an order
+  PNodeP input; std::vector<int> parts; bool all = false; bool ordered = false; Json order_by;
+  std::vector<PNode*> children() override { return {input.get()}; }
+  int partitions() override { return 1; }
+  PTable execute(int, Exec& x) override {
+    if (!all && parts.size() == 1) return input->execute(parts[0], x);          // coalesce_tasks.rs:143-145
+    std::vector<PTable> in;
+    // with an order the reference merges ALL input partitions (coalesce_tasks.rs:151), not only the listed ones
+    if (all || ordered) for (int p = 0; p < input->partitions(); ++p) in.push_back(input->execute(p, x));
+    else for (int p : parts) in.push_back(input->execute(p, x));
+    auto t0 = std::chrono::steady_clock::now();
+    PTable out = concat_tables(x, std::move(in));
+    // k-way merge = concatenation in partition order + the stable sort (ties keep (partition, row) order)
+    if (ordered) out = sort_table(x, out, order_by, -1, this, 0);
+    return timed(t0, out);
+  }
+};
+
+struct GlobalLimitExec : PNode {
+  PNodeP input; int64_t skip = 0, fetch = -1;
+  std::vector<PNode*> children() override { return {input.get()}; }
+  int partitions() override { return 1; }
+  PTable execute(int, Exec& x) override {
+    if (input->partitions() != 1) throw std::runtime_error("GlobalLimitExec requires a single input partition");
+    PTable t = input->execute(0, x);
+    auto t0 = std::chrono::steady_clock::now();
+    return timed(t0, slice_table(x, t, skip, fetch));
+  }
+};
+
 PNodeP build_child(const Json& v, const char* key) { return build_node(v.at(key)); }
 
 PNodeP build_node(const Json& j) {
@@ -589,6 +715,17 @@ PNodeP build_node(const Json& j) {
     n->join_type = v.get_str("join_type", "Inner"); n->partition_mode = v.get_str("partition_mode", "CollectLeft"); n->null_equals_null = v.get_bool("null_equals_null", false);
     if (v.has("filter")) { n->has_filter = true; n->filter = v.at("filter"); }
     out = std::move(n);
+  } else if (kind == "UnionExec") {
+    auto n = std::make_unique<UnionExec>(); for (auto& i : v.at("inputs").a) n->inputs.push_back(build_node(i)); out = std::move(n);
+  } else if (kind == "CoalescePartitionsExec") {
+    auto n = std::make_unique<CoalesceExec>(); n->input = build_child(v, "input"); n->all = true; out = std::move(n);
+  } else if (kind == "CoalesceTasksExec") {
+    auto n = std::make_unique<CoalesceExec>(); n->input = build_child(v, "input");
+    for (auto& p : v.at("partitions").a) n->parts.push_back((int)p.i64());
+    if (v.has("order_by")) { n->ordered = true; n->order_by = v.at("order_by"); }
+    out = std::move(n);
+  } else if (kind == "GlobalLimitExec") {
+    auto n = std::make_unique<GlobalLimitExec>(); n->input = build_child(v, "input"); n->skip = v.get_i64("skip", 0); n->fetch = v.get_i64("fetch", -1); out = std::move(n);
   } else if (kind == "LocalLimitExec") {
     auto n = std::make_unique<LimitExec>(); n->input = build_child(v, "input"); n->fetch = v.at("fetch").i64(); out = std::move(n);
   } else throw Unsupported("plan: node type '" + kind + "' is not executed natively");

@@ -73,6 +73,17 @@ def plan_to_json(node, tc, inputs):
         return {"SortPreservingMergeExec": {"input": sub(node.input), "expr": node.expr, "fetch": -1 if node.fetch is None else int(node.fetch)}}
     if isinstance(node, P.SortExec):
         return {"SortExec": {"input": sub(node.input), "expr": node.expr, "fetch": -1 if node.fetch is None else int(node.fetch)}}
+    if isinstance(node, P.UnionExec):
+        return {"UnionExec": {"inputs": [sub(i) for i in node.inputs]}}
+    if isinstance(node, P.CoalescePartitionsExec):
+        return {"CoalescePartitionsExec": {"input": sub(node.input)}}
+    if isinstance(node, P.CoalesceTasksExec):
+        d = {"input": sub(node.input), "partitions": [int(p) for p in node.partitions]}
+        if node.order_by:
+            d["order_by"] = node.order_by
+        return {"CoalesceTasksExec": d}
+    if isinstance(node, P.GlobalLimitExec):
+        return {"GlobalLimitExec": {"input": sub(node.input), "skip": int(node.skip), "fetch": -1 if node.fetch is None else int(node.fetch)}}
     if isinstance(node, P.LocalLimitExec):
         return {"LocalLimitExec": {"input": sub(node.input), "fetch": int(node.fetch)}}
     raise B.GpuqError(3, "plan node %s is not executed natively" % t)

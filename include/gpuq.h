@@ -226,6 +226,9 @@ int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n,
    (a piece without a validity buffer).  dst (8-byte aligned, padded to a multiple of 8 bytes) must be zeroed first.
    Fixed-width data buffers are concatenated with plain device copies.  Asynchronous on `stream`. */
 int gpuq_concat_bitmap(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src, int64_t n_bits);
+/* Same with a source bit offset: dst bits [dst_bit_offset, +n_bits) |= src bits [src_bit_offset, +n_bits).  Row ranges of a
+   bitmap (GlobalLimitExec skip, datafusion.proto:1453-1458). */
+int gpuq_copy_bits(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src, int64_t src_bit_offset, int64_t n_bits);
 
 /* ---- native plan executor ------------------------------------------------------------------
    The C++ host side above the operator calls: executes a physical plan tree, keeping data on the device between operators
@@ -242,6 +245,8 @@ int gpuq_concat_bitmap(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bi
                        "null_equals_null", "filter"?}}                               (:1346-1360)
      {"SortExec" | "SortPreservingMergeExec": {"input", "expr": [{"expr","asc","nulls_first"}], "fetch"?}}   (:1465-1478)
      {"CoalesceBatchesExec": {"input"}}  {"LocalLimitExec": {"input","fetch"}}       (:1487-1490, :1460-1463)
+     {"GlobalLimitExec": {"input","skip","fetch"}}  {"UnionExec": {"inputs": [node]}}  {"CoalescePartitionsExec": {"input"}}   (:1453, :1319, :1492)
+     {"CoalesceTasksExec": {"input","partitions": [p],"order_by"?: [sort expr]}}     (ballista coalesce_tasks.rs:46-70)
    Expressions are the PhysicalExprNode mirror of gpuq_op_create; columns are resolved by NAME against each operator's input.
    gpuq_plan_execute runs one output partition: inputs[k] is the table MemoryExec leaves refer to as slot k (caller-owned device
    memory, must stay valid until the call returns); *out is a materialised result owned by the library (gpuq_result_free).

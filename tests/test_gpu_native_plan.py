@@ -120,7 +120,35 @@ def test_native_sort_fetch_and_limit(tc):
     assert len(got) == 7 and all(r[6] == got[0][6] for r in got)
 
 
+@pytest.mark.parametrize("nulls", [0.0, 0.2])
+def test_native_fan_in_merge_limits_union(tc, nulls):
+    parts = [rand_table(500 + i, n, nulls) for i, n in enumerate([1000, 0, 77, 4099, 1])]
+    src = g.MemoryExec(parts)
+    s = src.schema()
+    for plan in (g.CoalesceTasksExec(src, [0, 1, 2, 3, 4]), g.CoalesceTasksExec(src, [3, 2]), g.CoalesceTasksExec(src, [2]), g.CoalescePartitionsExec(src),
+                 g.CoalescePartitionsExec(g.UnionExec([src, g.MemoryExec(parts[:2])]))):
+        got, _ = native_rows(tc, plan)
+        assert got == dev_rows(tc, plan.execute(0, tc))
+    order = [{"expr": col("flag", s), "asc": True, "nulls_first": False}, {"expr": col("dec", s), "asc": False, "nulls_first": True}]
+    sorted_src = g.SortExec(order, src, preserve_partitioning=True)
+    for plan in (g.CoalesceTasksExec(sorted_src, [0, 3], order_by=order), g.SortPreservingMergeExec(order, sorted_src, fetch=10)):
+        got, _ = native_rows(tc, plan)
+        assert got == dev_rows(tc, plan.execute(0, tc))
+    one = g.CoalescePartitionsExec(src)
+    f = g.FilterExec(binary(col("k32", s), Op.Gt, lit(0, "Int32")), src)
+    for plan in (g.GlobalLimitExec(one, skip=998, fetch=13), g.GlobalLimitExec(one, skip=3, fetch=None), g.GlobalLimitExec(one, skip=99999, fetch=4),
+                 g.GlobalLimitExec(g.CoalesceTasksExec(f, [0]), skip=5, fetch=70), g.GlobalLimitExec(g.CoalesceTasksExec(src, [3]), skip=0, fetch=9)):
+        got, _ = native_rows(tc, plan)
+        assert got == dev_rows(tc, plan.execute(0, tc))
+    # context.rs:691-733 through the native executor: UNION ALL keeps both rows, UNION (aggregate over all columns) one
+    a = pa.table({"NUMBER": pa.array([1], pa.int64())})
+    u = g.UnionExec([g.MemoryExec([a]), g.MemoryExec([a])])
+    assert native_rows(tc, g.CoalescePartitionsExec(u))[0] == [(1,), (1,)]
+    us = u.schema()
+    assert native_rows(tc, g.AggregateExec("Single", [(col("NUMBER", us), "NUMBER")], [], g.CoalescePartitionsExec(u)))[0] == [(1,)]
+
+
 def test_native_unsupported_node_fails_loudly(tc):
     t = rand_table(1, 10, 0.0)
     with pytest.raises(g.GpuqError):
-        g.NativePlan(g.UnionExec([g.MemoryExec([t]), g.MemoryExec([t])]), tc)
+        g.NativePlan(g.RepartitionExec(g.MemoryExec([t]), [col("k64", g.MemoryExec([t]).schema())], 4), tc)
