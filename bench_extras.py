@@ -11,7 +11,7 @@ def _sync(tc):
     tc.sync()
 
 
-def join_probe_micro(tc, g, log2_build, log2_probe, hit_rate, reps=3):
+def join_probe_micro(tc, g, log2_build, log2_probe, hit_rate, reps=3, zipf=None):
     """build: 2^b unique int64 keys (shuffled); probe: 2^p uniform keys, `hit_rate` of them present.
     Algorithmic bytes: 24 B per probe row (8 key + 16 slot touch) + 12 B per emitted pair."""
     import torch
@@ -21,7 +21,15 @@ def join_probe_micro(tc, g, log2_build, log2_probe, hit_rate, reps=3):
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + log2_build)
     bkeys = torch.randperm(nb, device=dev, generator=gen, dtype=torch.int64) * 2 + 1           # odd keys
     span = int(nb / max(hit_rate, 1e-9))
-    pkeys = torch.randint(0, span, (npb,), device=dev, generator=gen, dtype=torch.int64) * 2 + 1   # odd key < 2*nb exists
+    if zipf:
+        # Zipf(a) ranks over the build keys (skewed probe side), inverse-CDF of the continuous approximation
+        # P(rank > x) = x^(1-a); rank r probes the r-th build key, so the hit rate is 100 %
+        u = torch.rand(npb, device=dev, generator=gen, dtype=torch.float64)
+        ranks = torch.clamp((1.0 - u * (1.0 - float(nb) ** (1.0 - zipf))) ** (1.0 / (1.0 - zipf)), max=float(nb)).to(torch.int64) - 1
+        pkeys = bkeys[torch.clamp(ranks, 0, nb - 1)]
+        del u, ranks
+    else:
+        pkeys = torch.randint(0, span, (npb,), device=dev, generator=gen, dtype=torch.int64) * 2 + 1   # odd key < 2*nb exists
     btab = g.DeviceTable([g.DeviceColumn("k", "Int64", bkeys.view(torch.uint8), nb, nullable=False)], nb)
     ptab = g.DeviceTable([g.DeviceColumn("k", "Int64", pkeys.view(torch.uint8), npb, nullable=False)], npb)
     bs, ps = btab.schema(), ptab.schema()
@@ -52,7 +60,7 @@ def join_probe_micro(tc, g, log2_build, log2_probe, hit_rate, reps=3):
     ok = bool((bkeys[ob[:k].long()] == pkeys[opb[:k].long()]).all().item()) if k else True
     exp = int(((pkeys < 2 * nb)).sum().item())
     alg_bytes = 24 * npb + 12 * matches
-    return {"build_rows": nb, "probe_rows": npb, "hit_rate": hit_rate, "matches": matches, "matches_expected": exp, "pairs_valid": ok,
+    return {"build_rows": nb, "probe_rows": npb, "hit_rate": hit_rate, "probe_keys": ("zipf(%.2f)" % zipf) if zipf else "uniform", "matches": matches, "matches_expected": exp, "pairs_valid": ok,
             "probe_ms": best, "probe_rows_per_s": npb / (best * 1e-3), "algorithmic_GBs": alg_bytes / (best * 1e-3) / 1e9,
             "frac_hbm_peak": alg_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "build_ms": build_ms, "build_rows_per_s": nb / (build_ms * 1e-3)}
 
@@ -154,6 +162,8 @@ def run(tc, T, g, full=True):
     grid = [(20, 28, 1.0), (24, 28, 1.0), (27, 28, 1.0), (24, 28, 0.5), (24, 28, 0.1)] if full else [(20, 24, 1.0)]
     for b, p, h in grid:
         extra["join_probe"].append(join_probe_micro(tc, g, b, p, h))
+    if full:
+        extra["join_probe"].append(join_probe_micro(tc, g, 24, 28, 1.0, zipf=1.05))
     extra["tpch"] = tpch_pipelines(tc, T, g, 10 if full else 1)
     return extra
 
