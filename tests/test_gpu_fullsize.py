@@ -1,0 +1,103 @@
+"""Parity at BASELINE.json's full size (TPC-H SF10: 59,986,052 lineitem rows), where the oracle is too slow to run: the
+size-independent properties the domain offers -- linearity of the aggregate (whole == merge of halves, bit for bit), row
+conservation, sortedness + permutation of the sort, "same key -> same partition" + conservation of the hash partitioning,
+and the foreign-key identity of the join (every line finds exactly its order)."""
+import numpy as np
+import pytest
+import torch
+
+import arrow_ballista_amd as g
+import tpch_util as T
+from arrow_ballista_amd.expr import Operator as Op
+from arrow_ballista_amd.expr import binary, col, lit
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+N = T.LINEITEM_ROWS[10]
+
+
+def _i64(c, n):
+    return c.data[: n * 8].view(torch.int64)
+
+
+def test_q1_linearity_and_row_conservation_sf10(tc):
+    li = T.gen_lineitem_device(tc, N)
+    whole = g.NativePlan(T.q1_plan(g.MemoryExec([li]), two_phase=True), tc).execute(0).to_arrow().to_pylist()
+    # partial states of the two halves, merged by the final stage, must equal the whole (integer / decimal sums: bit exact)
+    half = N // 2 + 12_345
+    parts = []
+    for lo, cnt in ((0, half), (half, N - half)):
+        sub = T.gen_lineitem_device(tc, cnt, row0=lo)
+        partial, full, final_src = T.q1_split_plan(sub, 64)
+        parts.append(g.plan.materialize(tc, partial.execute(0, tc)))
+        del sub
+    partial, full, final_src = T.q1_split_plan(li, 64)
+    final_src.partitions[0] = g.plan.concat_tables(tc, parts)
+    merged = g.plan.materialize(tc, full.execute(0, tc)).to_arrow(tc.ctx).to_pylist()
+    assert merged == whole and len(whole) == 4
+    # rows are conserved: the groups' counts add up to the rows that pass the predicate (counted independently)
+    ship = li.column("l_shipdate").data[: N * 4].view(torch.int32)
+    assert sum(r["count_order"] for r in whole) == int((ship <= T.Q1_SHIPDATE_MAX).sum().item())
+    # AVG is SUM / COUNT with truncation at scale + 4, for every group
+    for r in whole:
+        assert int(r["avg_qty"].scaleb(6)) == int(r["sum_qty"].scaleb(2)) * 10_000 // r["count_order"]
+
+
+def test_sort_is_a_sorted_permutation_2p26(tc):
+    n = 1 << 26
+    li = T.gen_lineitem_device(tc, n, columns=("l_orderkey", "l_extendedprice"))
+    s = li.schema()
+    v = g.SortExec([{"expr": col("l_extendedprice", s), "asc": True, "nulls_first": False}, {"expr": col("l_orderkey", s), "asc": False, "nulls_first": False}],
+                   g.MemoryExec([li])).execute(0, tc)
+    perm = v.via[0][:n].to(torch.int64)
+    # permutation: every row id exactly once
+    assert int(perm.sum().item()) == n * (n - 1) // 2
+    seen = torch.zeros(n, dtype=torch.bool, device=tc.device); seen[perm] = True
+    assert bool(seen.all().item())
+    price = li.column("l_extendedprice").data[: n * 16].view(torch.int64)[0::2][perm]      # fits 64 bits
+    okey = _i64(li.column("l_orderkey"), n)[perm]
+    d = price[1:] - price[:-1]
+    assert bool((d >= 0).all().item())
+    assert bool(((d > 0) | (okey[1:] <= okey[:-1])).all().item())                       # ties: second key descending
+
+
+def test_hash_partition_conserves_rows_and_separates_keys_2p26(tc):
+    n, parts = 1 << 26, 16
+    li = T.gen_lineitem_device(tc, n, columns=("l_orderkey", "l_suppkey"))
+    s = li.schema()
+    views = g.RepartitionExec(g.MemoryExec([li]), [col("l_orderkey", s)], parts).execute_all(0, tc)
+    assert sum(v.num_rows for v in views) == n
+    keys = _i64(li.column("l_orderkey"), n)
+    marks = torch.full((int(keys.max().item()) + 1,), -1, dtype=torch.int8, device=tc.device)      # owner partition of every key value
+    for p, v in enumerate(views):
+        rows = v.via[0][: v.num_rows].to(torch.int64)
+        k = keys[rows]
+        # same key -> same partition: no key value has been claimed by another partition
+        prev = marks[k]
+        assert bool(((prev == -1) | (prev == p)).all().item())
+        marks[k] = p
+        # stable inside a partition: row order is input order
+        assert bool((rows[1:] > rows[:-1]).all().item())
+        # the partition function is the oracle's (checked on a sample)
+        sample = k[:: max(1, v.num_rows // 500)][:500].tolist()
+        tab = O.Table(["l_orderkey"], ["Int64"], [sample])
+        assert set(O.hash_partition(tab, [{"column": {"name": "l_orderkey"}}], parts)) == {p}
+
+
+def test_fk_join_finds_every_order_sf10(tc):
+    n_orders = (N + 3) // 4
+    li = T.gen_lineitem_device(tc, N, columns=("l_orderkey", "l_extendedprice"))
+    od = T.gen_orders_device(tc, n_orders, 1_500_000)
+    L, R = g.MemoryExec([od]), g.MemoryExec([li])
+    ls, rs = L.schema(), R.schema()
+    j = g.HashJoinExec(L, R, [(col("o_orderkey", ls), col("l_orderkey", rs))], None, "Inner", "CollectLeft", False).execute(0, tc)
+    assert j.num_rows == N                       # every line has exactly one order
+    # probe order is preserved and the matched build row carries the same key
+    sides = dict(zip([c.name for c in j.columns], j.sides))
+    opb = j.via[sides["l_orderkey"] - 1][:N].to(torch.int64)
+    ob = j.via[sides["o_orderkey"] - 1][:N].to(torch.int64)
+    assert bool((opb == torch.arange(N, device=tc.device)).all().item())
+    assert bool((_i64(od.column("o_orderkey"), n_orders)[ob] == _i64(li.column("l_orderkey"), N)).all().item())
+    # anti join of the same inputs is empty, semi join keeps everything
+    for jt, exp in (("RightAnti", 0), ("RightSemi", N)):
+        assert g.HashJoinExec(L, R, [(col("o_orderkey", ls), col("l_orderkey", rs))], None, jt, "CollectLeft", False).execute(0, tc).num_rows == exp
