@@ -61,3 +61,55 @@ def test_q1_rank_records_merge_as_in_bench(tc):
     final_src.partitions[0] = merged
     got = T.q1_result_to_rows(tc, g.plan.materialize(tc, full.execute(0, tc)))
     assert got == T.q1_oracle_rows(2 * n)
+
+
+def test_q1_on_the_reference_testdata_two_partitions(tc):
+    """The rows of ballista/scheduler/testdata/lineitem/partition{0,1}.tbl (dbgen output the reference's planner tests read,
+    planner.rs:376-392 -- the reference asserts the plan SHAPE over them, not values): q1 as that two-stage plan (Partial per
+    partition, FinalPartitioned over both) on the device, against plain `decimal` arithmetic on the .tbl text."""
+    import datetime
+    import decimal
+    import os
+    import pyarrow as pa
+    import arrow_ballista_amd as g
+    D = decimal.Decimal
+    gold = os.path.join(os.path.dirname(__file__), "golden", "tpch10")
+    parts, rows = [], []
+    for fn in ("lineitem.partition0.tbl", "lineitem.partition1.tbl"):
+        rs = [l.rstrip("\n").split("|") for l in open(os.path.join(gold, fn))]
+        rows += rs
+        day = lambda s: (datetime.date.fromisoformat(s) - datetime.date(1970, 1, 1)).days
+        parts.append(pa.table({
+            "l_quantity": pa.array([D(r[4]).quantize(D("0.01")) for r in rs], pa.decimal128(15, 2)),
+            "l_extendedprice": pa.array([D(r[5]) for r in rs], pa.decimal128(15, 2)),
+            "l_discount": pa.array([D(r[6]) for r in rs], pa.decimal128(15, 2)),
+            "l_tax": pa.array([D(r[7]) for r in rs], pa.decimal128(15, 2)),
+            "l_returnflag": pa.array([r[8] for r in rs]), "l_linestatus": pa.array([r[9] for r in rs]),
+            "l_shipdate": pa.array([day(r[10]) for r in rs], pa.int32()).cast(pa.date32())},
+            schema=pa.schema([pa.field(n, t, nullable=False) for n, t in [("l_quantity", pa.decimal128(15, 2)), ("l_extendedprice", pa.decimal128(15, 2)),
+                              ("l_discount", pa.decimal128(15, 2)), ("l_tax", pa.decimal128(15, 2)), ("l_returnflag", pa.string()), ("l_linestatus", pa.string()),
+                              ("l_shipdate", pa.date32())]])))
+    src = g.MemoryExec(parts)
+    plan = T.q1_plan(src, two_phase=True)
+    # the Final stage reads BOTH partial partitions: coalesce them below it, as the reference's stage boundary does
+    node = plan
+    while not (isinstance(node, g.AggregateExec) and node.mode == "FinalPartitioned"):
+        node = node.children()[0]
+    node.input = g.CoalescePartitionsExec(node.input)
+    got = T.q1_result_to_rows(tc, g.plan.materialize(tc, plan.execute(0, tc)))
+    native = [tuple(r.values()) for r in g.NativePlan(plan, tc).execute(0).to_arrow().to_pylist()]
+    exp = {}
+    cutoff = datetime.date(1998, 9, 2)
+    for r in rows:
+        if datetime.date.fromisoformat(r[10]) > cutoff:
+            continue
+        q, e, d, t = D(r[4]), D(r[5]), D(r[6]), D(r[7])
+        a = exp.setdefault((r[8], r[9]), [D(0), D(0), D(0), D(0), D(0), 0])
+        a[0] += q; a[1] += e; a[2] += e * (1 - d); a[3] += e * (1 - d) * (1 + t); a[4] += d; a[5] += 1
+    want = []
+    for k in sorted(exp):
+        q, e, dp, ch, ds, c = exp[k]
+        trunc = lambda x, s: int((x.scaleb(s)).to_integral_value(rounding=decimal.ROUND_DOWN))
+        want.append(k + (trunc(q, 2), trunc(e, 2), trunc(dp, 4), trunc(ch, 6), trunc(q / c, 6), trunc(e / c, 6), trunc(ds / c, 6), c))
+    assert got == want and len(want) >= 2
+    assert [tuple(int(x.scaleb(-x.as_tuple().exponent)) if isinstance(x, D) else x for x in r) for r in native] == want
