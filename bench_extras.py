@@ -2,6 +2,7 @@
 micro-benchmark of SURVEY.md §8(d) (the other half of BASELINE.json's metric) and the q3 / q5 operator
 pipelines.  Kernel times come from HIP events around the launch (gpuq_op_profile)."""
 import ctypes as C
+import os
 import time
 
 HBM_PEAK_GBS = 8000.0
@@ -157,6 +158,55 @@ def cpu_proxy_acero(T, sf):
     return out
 
 
+def dist_join(T, g, rows_per_rank, steps=5):
+    """Partitioned hash join across ranks (BASELINE configs[4] shape): every rank owns a lineitem shard and the matching
+    orders shard; both sides are hash-repartitioned on the join key (same partition function), exchanged with one
+    variable-size all-to-all per column buffer, and joined locally.  Launch with torch.distributed.run, one rank per GPU
+    (GPUQ_BENCH_BACKEND=gloo rehearses it with ranks sharing a GPU).  Weak scaling: rows per rank fixed."""
+    import torch
+    import torch.distributed as dist
+    from arrow_ballista_amd import parallel
+    from arrow_ballista_amd.expr import col
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("GPUQ_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
+    tc = g.TaskContext(device=local)
+    n_li = rows_per_rank
+    n_or = (n_li + 3) // 4
+    li = T.gen_lineitem_device(tc, n_li, row0=rank * n_li, columns=("l_orderkey", "l_extendedprice"))
+    od = T.gen_orders_device(tc, n_or, 1_500_000, row0=rank * n_or)
+    ls, os_ = li.schema(), od.schema()
+    on = [(col("o_orderkey", os_), col("l_orderkey", ls))]
+
+    def step():
+        return parallel.partitioned_hash_join(tc, od, li, on, "Inner")
+    out = step()
+    total = torch.tensor([out.num_rows], dtype=torch.int64, device=tc.device if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(total)
+    times = []
+    for _ in range(steps):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        times.append(time.perf_counter() - t0)
+    res = {"workload": "partitioned hash join lineitem x orders on orderkey, both sides exchanged", "n_gpus": world, "backend": backend,
+           "probe_rows_per_rank": n_li, "build_rows_per_rank": n_or, "joined_rows_total": int(total.item()), "every_line_found_its_order": int(total.item()) == n_li * world,
+           "ms_best": min(times) * 1e3, "probe_rows_per_s_all_ranks": n_li * world / min(times)}
+    if world > 1:
+        dist.destroy_process_group()
+    return res if rank == 0 else None
+
+
 def run(tc, T, g, full=True):
     extra = {"join_probe": []}
     grid = [(20, 28, 1.0), (24, 28, 1.0), (27, 28, 1.0), (24, 28, 0.5), (24, 28, 0.1)] if full else [(20, 24, 1.0)]
@@ -176,6 +226,12 @@ if __name__ == "__main__":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import tpch_util as T
     import arrow_ballista_amd as g
+    if "--dist-join" in sys.argv:
+        rows = int(sys.argv[sys.argv.index("--rows") + 1]) if "--rows" in sys.argv else T.LINEITEM_ROWS[10]
+        r = dist_join(T, g, rows)
+        if r is not None:
+            print(json.dumps(r, indent=1))
+        sys.exit(0)
     if "--cpu-proxy" in sys.argv:
         sf = 10 if "--sf10" in sys.argv else 1
         print(json.dumps(cpu_proxy_acero(T, sf), indent=1))
