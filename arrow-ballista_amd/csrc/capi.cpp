@@ -51,6 +51,7 @@ struct gpuq_op {
   std::string mode = "Single", strategy = "auto";
   AggSpec agg{}; KeySpec keys{};
   std::vector<DType> key_types, acc_types;
+  std::vector<int> acc_bits;        // |argument| < 2^bits per accumulator (type-derived): lets the specialised kernel drop range checks
   struct PostChunk { CompiledProgram prog; DevBuf code; int first_out = 0; };
   std::deque<PostChunk> posts; Schema post_schema;
   i64 expected_groups = 0;
@@ -376,6 +377,7 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
   for (size_t i = 0; i < accs.size(); ++i) {
     op->agg.acc_kind[i] = accs[i].kind; op->agg.acc_reg[i] = accs[i].arg ? op->prog.out_reg[acc_slots[i]] : 0;
     op->acc_types.push_back(accs[i].type);
+    op->acc_bits.push_back(accs[i].arg ? op->prog.out_bits[acc_slots[i]] : 1);
   }
   op->keys = make_keyspec(kregs, op->key_types, any_null_key);
 
@@ -494,7 +496,9 @@ std::string agg_tiny_spec(const gpuq_op* op, int gmax) {
                      ", JIT_GMAX = " + std::to_string(gmax) + ", JIT_NKC = " + std::to_string(nk > 0 ? nk : 1) + ";\n";
   auto arr = [](const char* name, const int32_t* v, int n_) { std::string r = std::string("constexpr int ") + name + "[" + std::to_string(n_) + "] = {";
                                                              for (int i = 0; i < n_; ++i) r += std::to_string(v[i]) + (i + 1 < n_ ? "," : ""); return r + "};\n"; };
-  return spec + arr("JIT_KEY_REG", op->agg.key_reg, MAX_KEYS) + arr("JIT_ACC_KIND", op->agg.acc_kind, MAX_ACCS) + arr("JIT_ACC_REG", op->agg.acc_reg, MAX_ACCS);
+  int32_t bits[MAX_ACCS]; for (int i = 0; i < MAX_ACCS; ++i) bits[i] = i < (int)op->acc_bits.size() ? op->acc_bits[(size_t)i] : 127;
+  return spec + arr("JIT_KEY_REG", op->agg.key_reg, MAX_KEYS) + arr("JIT_ACC_KIND", op->agg.acc_kind, MAX_ACCS) + arr("JIT_ACC_REG", op->agg.acc_reg, MAX_ACCS) +
+         arr("JIT_ACC_BITS", bits, MAX_ACCS);
 }
 
 void check_ctx(gpuq_ctx* c) { if (!c) throw std::runtime_error("ctx is NULL"); HIPCHECK(hipSetDevice(c->device)); }

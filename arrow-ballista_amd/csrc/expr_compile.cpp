@@ -455,7 +455,7 @@ CompiledProgram ExprCompiler::finish() {
   for (size_t i = 0; i < imms.size(); ++i) { C.code.imm_lo[i] = imms[i].first; C.code.imm_hi[i] = imms[i].second; }
   C.pred_reg = pred_ ? reg.at(rep(pred_.get())) : -1;
   for (auto& o : outs_) {
-    C.out_reg.push_back(reg.at(rep(o.get()))); C.out_type.push_back(o->type); C.out_nullable.push_back(o->nullable); C.out_key.push_back(o->key);
+    C.out_reg.push_back(reg.at(rep(o.get()))); C.out_type.push_back(o->type); C.out_nullable.push_back(o->nullable); C.out_key.push_back(o->key); C.out_bits.push_back((o->type.is_int() || o->type.is_decimal() || o->type.id == T_DATE32) ? o->bits : 127);
   }
   C.jit_src = jit_source(C, order, reg);
   return C;

@@ -78,6 +78,7 @@ struct CompiledProgram {
   std::vector<DType> out_type;
   std::vector<bool> out_nullable;
   std::vector<std::string> out_key;
+  std::vector<int> out_bits;    // |value| < 2^bits for every output (from the declared types; 127 = unknown)
   std::string jit_src;          // C++ source of gpuq_jit_eval() for this program (typed, straight-line)
 };
 

@@ -248,6 +248,7 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
 #define SPEC_KEY_REG(k) JIT_KEY_REG[k]
 #define SPEC_ACC_KIND(a) JIT_ACC_KIND[a]
 #define SPEC_ACC_REG(a) JIT_ACC_REG[a]
+#define SPEC_ACC_BITS(a) JIT_ACC_BITS[a]
 #define SPEC_UNROLL _Pragma("unroll")
 #else
   const int n_keys = A.n_keys, n_accs = A.n_accs;
@@ -255,14 +256,17 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
 #define SPEC_KEY_REG(k) __builtin_amdgcn_readfirstlane(A.key_reg[k])
 #define SPEC_ACC_KIND(a) A.acc_kind[a]
 #define SPEC_ACC_REG(a) __builtin_amdgcn_readfirstlane(A.acc_reg[a])
+#define SPEC_ACC_BITS(a) 127
 #define SPEC_UNROLL
 #endif
   const int kstride = n_keys > 0 ? n_keys : 1;
   const TinyLds L = tiny_carve(smem, gmax, n_keys, n_accs);
   const int cells = gmax * n_accs;
   const int tid = threadIdx.x;
+#ifndef GPUQ_EXP_LOADS_ONLY
   for (int c = 0; c < cells; ++c) L.lane_acc[c * BLOCK + tid] = acc_identity(SPEC_ACC_KIND(c % n_accs));
   for (int c = tid; c < cells * 2; c += BLOCK) L.wide[c] = 0;
+#endif
   // an aggregate without GROUP BY always has exactly one group, even over zero rows
   if (tid == 0) { *L.dict_n = (n_keys == 0) ? 1u : 0u; *L.lock = 0; L.dnulls[0] = 0; }
   __syncthreads();
@@ -296,6 +300,23 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
     GPUQ_MARK("lookup");
     int gid = -1;
     uint32_t seen = 0;
+#ifndef GPUQ_EXP_NO_LOOKUP
+#ifdef GPUQ_JIT_SPEC
+    // fast path: every active row finds its group among the entries already cached in registers -- no LDS access at all
+    // (the dictionary of a low-cardinality aggregate is complete after the first few steps)
+    if (active) {
+#pragma unroll
+      for (int g = 0; g < JIT_GMAX; ++g) {
+        if ((uint32_t)g < cached_n) {
+          bool eq = dc_nl[g] == knull;
+#pragma unroll
+          for (int k = 0; k < JIT_NKC; ++k) if (k < n_keys) eq = eq && dc_lo[g][k] == GPUQ_KLO(k) && dc_hi[g][k] == GPUQ_KHI(k);
+          if (eq) gid = g;
+        }
+      }
+    }
+    if (__ballot(active && gid < 0) != 0)
+#endif
     for (;;) {
       // lock-free lookup over the dictionary entries published so far.  Bit 31 of the counter = "this block ran out of
       // dictionary entries": the launch's result is discarded by the host, so the block stops working (without this every
@@ -380,8 +401,13 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
       }
       // other lanes with the same key find it in the next lookup round
     }
+#endif  // GPUQ_EXP_NO_LOOKUP
     GPUQ_MARK("accumulate");
+#ifdef GPUQ_EXP_NO_LOOKUP
+    gid = (int)(k0hi >> 56) & 3;     // experiment: no dictionary
+#endif
     // accumulate
+#ifndef GPUQ_EXP_NO_ACC
     if (active) {
       SPEC_UNROLL
       for (int a = 0; a < n_accs; ++a) {
@@ -398,6 +424,13 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
           case ACC_COUNT: case ACC_COUNT_STAR: *slot += 1; break;
           case ACC_SUM: {
             const i64 cur = (i64)*slot;
+            if (SPEC_ACC_BITS(a) <= 60) {
+              // the argument's declared type bounds |v| < 2^60: it always fits the 64-bit slot, only the running sum can leave
+              i64 nv = cur + (i64)vlo;
+              if (nv > (1ll << 62) || nv < -(1ll << 62)) { wide_add(L.wide, cell, (u64)nv, (u64)(nv >> 63)); nv = 0; }
+              *slot = (u64)nv;
+              break;
+            }
             const bool fits = (i64)vhi == ((i64)vlo >> 63);
             const i64 v = (i64)vlo;
             // keep |slot| < 2^62 so one more 64-bit add cannot overflow
@@ -425,6 +458,9 @@ __device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n,
         }
       }
     }
+#else
+    if (active && gid == 77) atomicOr(P.flags, 1u << 29);
+#endif
     return false;
   };
 #ifdef GPUQ_JIT
@@ -497,6 +533,9 @@ pipeline_done:
   }
 #endif
   __syncthreads();
+#ifdef GPUQ_EXP_LOADS_ONLY
+  return;      // experiment: no accumulators were kept
+#endif
   // block reduction: fold the per-lane partials of every live cell, add the wide spill cell
   __shared__ u64 red[WAVES * 2];
   const int ng = (int)(*L.dict_n & 0x7FFFFFFFu);
@@ -555,6 +594,7 @@ pipeline_done:
 #undef SPEC_KEY_REG
 #undef SPEC_ACC_KIND
 #undef SPEC_ACC_REG
+#undef SPEC_ACC_BITS
 #undef SPEC_UNROLL
 #ifndef GPUQ_JIT
 template <int MAXC>
@@ -859,7 +899,10 @@ void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A
   int nb_cap = g_num_cus * tiny_blocks_per_cu(gmax, A.n_keys, A.n_accs);
   int nb = grid_for(n, 64);
   if (nb > nb_cap) nb = nb_cap;
-  const size_t lds = tiny_lds_bytes(gmax, A.n_keys, A.n_accs);
+  size_t lds = tiny_lds_bytes(gmax, A.n_keys, A.n_accs);
+  if (const char* e = std::getenv("GPUQ_EXP_OCC")) {      // tuning experiment (with GPUQ_JIT_DEFINES=GPUQ_EXP_LOADS_ONLY=1 only): k blocks per CU
+    const int k = std::atoi(e); if (k > 0) { nb = g_num_cus * k; const size_t cap_ = (size_t)(160 * 1024) / (size_t)k - 1024; if (lds > cap_) lds = cap_; }
+  }
   // > 64 KiB of dynamic LDS needs an explicit opt-in (per template instantiation); the JIT'd function is
   // only used while the request stays within the default 64 KiB
   if (jit_override().fn && jit_override().kernel_id == 3 && lds <= 60 * 1024) {
