@@ -1156,11 +1156,15 @@ int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n,
     if (n < 0 || !offsets_out) throw std::runtime_error("bad arguments");
     if (n == 0) { HIPCHECK(hipMemsetAsync(offsets_out, 0, 4, s)); if (data_len_out) *data_len_out = 0; return; }
     DevBuf ws; ws.ensure(exclusive_scan_ws_bytes(n));
-    launch_unpack_utf8_lengths(s, (const ulonglong2*)packed, n, offsets_out);
+    DevBuf flag; flag.ensure(16);
+    HIPCHECK(hipMemsetAsync(flag.p, 0, 4, s));
+    launch_unpack_utf8_lengths(s, (const ulonglong2*)packed, n, offsets_out, (uint32_t*)flag.p);
     launch_exclusive_scan_i32(s, offsets_out, n, ws.p, ws.cap);
-    int32_t total = 0;
+    int32_t total = 0; uint32_t too_long = 0;
     HIPCHECK(hipMemcpyAsync(&total, offsets_out + n, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&too_long, flag.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+    if (too_long) throw Unsupported("a Utf8 value longer than 15 bytes went through a device-side materialisation (PACKED15 limit): project it away or keep it on the host side");
     if (data_len_out) *data_len_out = total;
     if (total > data_cap) throw Capacity("utf8 data needs " + std::to_string(total) + " bytes");
     if (total > 0) { if (!data_out) throw std::runtime_error("data_out is NULL"); launch_unpack_utf8_bytes(s, (const ulonglong2*)packed, n, offsets_out, data_out); }

@@ -769,8 +769,13 @@ __global__ void __launch_bounds__(BLOCK) k_agg_emit(const AggOut raw, const int 
 
 // ------------------------------------------------------------------ packed Utf8 -> Arrow Utf8
 #ifndef GPUQ_JIT
-__global__ void __launch_bounds__(BLOCK) k_unpack_lengths(const ulonglong2* __restrict__ packed, const i64 n, int32_t* __restrict__ lens) {
-  for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) lens[i] = (int32_t)(packed[i].x & 0xFF);
+__global__ void __launch_bounds__(BLOCK) k_unpack_lengths(const ulonglong2* __restrict__ packed, const i64 n, int32_t* __restrict__ lens, uint32_t* __restrict__ too_long) {
+  for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    const int32_t len = (int32_t)(packed[i].x & 0xFF);
+    // a value that did not fit the 15 packed bytes keeps its original length: it cannot be turned back into text
+    if (len > 15 && too_long) atomicOr(too_long, 1u);
+    lens[i] = len;
+  }
 }
 #endif
 #ifndef GPUQ_JIT
@@ -944,8 +949,8 @@ void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, u
   hipLaunchKernelGGL(k_agg_emit, dim3(grid), dim3(BLOCK), 0, s, raw, n_keys, n_accs, n_groups, soa, n_groups_dev);
 }
 static int lin_grid(i64 n) { i64 need = (n + BLOCK - 1) / BLOCK; if (need < 1) need = 1; const i64 cap = (i64)g_num_cus * 16; return (int)(need < cap ? need : cap); }
-void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out) {
-  if (n > 0) hipLaunchKernelGGL(k_unpack_lengths, dim3(lin_grid(n)), dim3(BLOCK), 0, s, packed, n, lens_out);
+void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out, uint32_t* too_long) {
+  if (n > 0) hipLaunchKernelGGL(k_unpack_lengths, dim3(lin_grid(n)), dim3(BLOCK), 0, s, packed, n, lens_out, too_long);
 }
 void launch_unpack_utf8_bytes(hipStream_t s, const ulonglong2* packed, i64 n, const int32_t* offsets, uint8_t* data_out) {
   if (n > 0) hipLaunchKernelGGL(k_unpack_bytes, dim3(lin_grid(n)), dim3(BLOCK), 0, s, packed, n, offsets, data_out);

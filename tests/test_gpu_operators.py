@@ -506,3 +506,36 @@ def test_limits_and_union_kat(tc):
     us = u.schema()
     dedup = g.AggregateExec("Single", [(col("NUMBER", us), "NUMBER")], [], g.CoalescePartitionsExec(u))
     assert dev_rows(tc, dedup.execute(0, tc)) == [(1,)]
+
+
+# ------------------------------------------------------------------------------------ run-time failures are loud
+def test_runtime_limits_fail_loudly(tc):
+    """What the device path cannot do is reported as an error (GPUQ_ERR_UNSUPPORTED / CAPACITY), never answered wrongly or
+    by a fallback: a Utf8 value longer than 15 bytes reaching a comparison or a group key, more groups than the LDS
+    strategy was asked to hold."""
+    t = pa.table({"s": pa.array(["short", "exactly15bytes!", "a string value longer than fifteen bytes", None]), "v": pa.array([1, 2, 3, 4], pa.int64())})
+    src = g.MemoryExec([t])
+    s = src.schema()
+    with pytest.raises(g.GpuqError) as e:
+        dev_rows(tc, g.FilterExec(binary(col("s", s), Op.Eq, lit("short")), src).execute(0, tc))
+    assert e.value.status == 3 and "15 bytes" in str(e.value)
+    with pytest.raises(g.GpuqError) as e:
+        dev_rows(tc, g.AggregateExec("Single", [(col("s", s), "s")], [{"fn": "SUM", "expr": col("v", s), "name": "x"}], src).execute(0, tc))
+    assert e.value.status == 3
+    # carried through a device-side materialisation the long value is refused as well (PACKED15 holds 15 bytes) ...
+    with pytest.raises(g.GpuqError) as e:
+        dev_rows(tc, g.FilterExec(binary(col("v", s), Op.Gt, lit(1)), src).execute(0, tc))
+    assert e.value.status == 3 and "15 bytes" in str(e.value)
+    # ... while rows that do not contain it, or plans that project the column away, are fine
+    assert dev_rows(tc, g.FilterExec(binary(col("v", s), Op.Lt, lit(3)), src).execute(0, tc)) == [("short", 1), ("exactly15bytes!", 2)]
+    assert dev_rows(tc, g.ProjectionExec([(col("v", s), "v")], g.FilterExec(binary(col("v", s), Op.Gt, lit(1)), src)).execute(0, tc)) == [(2,), (3,), (4,)]
+    # and after the failure the operators keep working (flags are reset)
+    ok = pa.table({"s": pa.array(["a", "b", "a"]), "v": pa.array([1, 2, 3], pa.int64())})
+    osrc = g.MemoryExec([ok])
+    os_ = osrc.schema()
+    assert sorted(dev_rows(tc, g.AggregateExec("Single", [(col("s", os_), "s")], [{"fn": "SUM", "expr": col("v", os_), "name": "x"}], osrc).execute(0, tc))) == [("a", 4), ("b", 2)]
+    big = rand_table(3, 5000, 0.0)
+    bs = g.MemoryExec([big]).schema()
+    with pytest.raises(g.GpuqError) as e:
+        g.AggregateExec("Single", [(col("k64", bs), "k")], [{"fn": "COUNT", "expr": lit(1), "name": "c"}], g.MemoryExec([big]), strategy="tiny").execute(0, tc)
+    assert e.value.status == 4
