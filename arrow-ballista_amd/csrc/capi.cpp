@@ -1147,6 +1147,32 @@ int gpuq_copy_bits(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_of
   });
 }
 
+// ---------------------------------------------------------------- utf8 take (payload strings of any length)
+int gpuq_take_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int32_t* offsets_out, uint8_t* validity_out,
+                   uint8_t* data_out, int64_t data_cap, int64_t* data_len_out) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    if (!col || n < 0 || !offsets_out) throw std::runtime_error("bad arguments");
+    if (col->type != T_UTF8 || col->repr != GPUQ_REPR_ARROW || (!col->offsets && col->length > 0)) throw std::runtime_error("gpuq_take_utf8 takes an Arrow-layout Utf8 column (offsets + bytes)");
+    if (validity_out && ((uintptr_t)validity_out & 7)) throw std::runtime_error("validity_out must be 8-byte aligned");
+    if (n == 0) { HIPCHECK(hipMemsetAsync(offsets_out, 0, 4, s)); if (data_len_out) *data_len_out = 0; return; }
+    DevBuf ws; ws.ensure(exclusive_scan_ws_bytes(n));
+    launch_take_utf8_lengths(s, col->offsets, col->validity, idx, n, offsets_out, (u64*)validity_out);
+    launch_exclusive_scan_i32(s, offsets_out, n, ws.p, ws.cap);
+    int32_t total = 0;
+    HIPCHECK(hipMemcpyAsync(&total, offsets_out + n, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (data_len_out) *data_len_out = total;
+    if (total > data_cap) throw Capacity("utf8 data needs " + std::to_string(total) + " bytes");
+    if (total > 0) {
+      if (!data_out) throw std::runtime_error("data_out is NULL");
+      launch_take_utf8_bytes(s, (const uint8_t*)col->data, col->offsets, idx, n, offsets_out, data_out);
+    }
+    HIPCHECK(hipGetLastError());
+  });
+}
+
 // ---------------------------------------------------------------- utf8 unpack
 int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n, int32_t* offsets_out, uint8_t* data_out, int64_t data_cap,
                      int64_t* data_len_out) {

@@ -790,6 +790,38 @@ __global__ void __launch_bounds__(BLOCK) k_unpack_bytes(const ulonglong2* __rest
 }
 #endif
 
+// ------------------------------------------------------------------ take of Arrow-layout Utf8 (strings of any length as payload)
+// lens[j] = byte length of source row idx[j] (0 for NULL_ROW / NULL values); validity word per 64 outputs
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(BLOCK) k_take_utf8_lengths(const int32_t* __restrict__ offsets, const uint8_t* __restrict__ validity, const uint32_t* __restrict__ idx,
+                                                             const i64 n, int32_t* __restrict__ lens, u64* __restrict__ valid_out) {
+  const i64 nwords = (n + 63) >> 6;
+  for (i64 w = (i64)blockIdx.x * WAVES + wave_id(); w < nwords; w += (i64)gridDim.x * WAVES) {
+    const i64 j = (w << 6) + lane_id();
+    bool ok = false; int32_t len = 0;
+    if (j < n) {
+      const uint32_t r = idx ? idx[j] : (uint32_t)j;
+      ok = r != 0xFFFFFFFFu && (!validity || ((validity[r >> 3] >> (r & 7)) & 1));
+      if (ok) len = offsets[r + 1] - offsets[r];
+      lens[j] = len;
+    }
+    const u64 m = __ballot(ok);
+    if (valid_out && lane_id() == 0) valid_out[w] = m;
+  }
+}
+// one wave per output string: lanes copy 64 bytes per step (long strings stay coalesced, short ones cost one step)
+__global__ void __launch_bounds__(BLOCK) k_take_utf8_bytes(const uint8_t* __restrict__ data, const int32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
+                                                           const i64 n, const int32_t* __restrict__ out_offsets, uint8_t* __restrict__ out) {
+  for (i64 j = (i64)blockIdx.x * WAVES + wave_id(); j < n; j += (i64)gridDim.x * WAVES) {
+    const int32_t o0 = out_offsets[j], len = out_offsets[j + 1] - o0;
+    if (len <= 0) continue;
+    const uint32_t r = idx ? idx[j] : (uint32_t)j;
+    const uint8_t* src = data + offsets[r];
+    for (int32_t k = lane_id(); k < len; k += 64) out[o0 + k] = src[k];
+  }
+}
+#endif
+
 // Exclusive scan of int32 lengths into offsets (n+1 entries, in place): three-kernel
 // reduce / scan-of-tiles / downsweep over tiles of 2048 elements.
 constexpr int SCAN_TILE = 2048;
@@ -951,6 +983,14 @@ void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, u
 static int lin_grid(i64 n) { i64 need = (n + BLOCK - 1) / BLOCK; if (need < 1) need = 1; const i64 cap = (i64)g_num_cus * 16; return (int)(need < cap ? need : cap); }
 void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out, uint32_t* too_long) {
   if (n > 0) hipLaunchKernelGGL(k_unpack_lengths, dim3(lin_grid(n)), dim3(BLOCK), 0, s, packed, n, lens_out, too_long);
+}
+void launch_take_utf8_lengths(hipStream_t s, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int32_t* lens, u64* valid_out) {
+  if (n > 0) hipLaunchKernelGGL(k_take_utf8_lengths, dim3(grid_for(n, 8)), dim3(BLOCK), 0, s, offsets, validity, idx, n, lens, valid_out);
+}
+void launch_take_utf8_bytes(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint32_t* idx, i64 n, const int32_t* out_offsets, uint8_t* out) {
+  if (n <= 0) return;
+  i64 need = (n + WAVES - 1) / WAVES; const i64 cap = (i64)g_num_cus * 16; if (need < 1) need = 1;
+  hipLaunchKernelGGL(k_take_utf8_bytes, dim3((int)(need < cap ? need : cap)), dim3(BLOCK), 0, s, data, offsets, idx, n, out_offsets, out);
 }
 void launch_unpack_utf8_bytes(hipStream_t s, const ulonglong2* packed, i64 n, const int32_t* offsets, uint8_t* data_out) {
   if (n > 0) hipLaunchKernelGGL(k_unpack_bytes, dim3(lin_grid(n)), dim3(BLOCK), 0, s, packed, n, offsets, data_out);

@@ -249,13 +249,41 @@ PTable select_view(Exec& x, const PTable& t, const uint32_t* idx, int64_t n, con
   return out;
 }
 
+// Arrow-layout Utf8 column read through an index vector (or as it lies) into a fresh Arrow-layout column: any string length
+PCol take_utf8(Exec& x, const PCol& c, const uint32_t* idx, int64_t n, bool nullable, std::vector<BufP>& keep) {
+  BufP offs = dev_alloc((size_t)(n + 4) * 4), valid = dev_alloc((size_t)((n + 63) / 64) * 8 + 8);
+  int64_t dl = 0;
+  int rc = gpuq_take_utf8(x.ctx, x.stream, &c.c, idx, n, (int32_t*)offs->p, (uint8_t*)valid->p, nullptr, 0, &dl);
+  if (rc != GPUQ_OK && rc != GPUQ_ERR_CAPACITY) check(x, rc);
+  BufP data = dev_alloc((size_t)dl + 16);
+  if (dl > 0) check(x, gpuq_take_utf8(x.ctx, x.stream, &c.c, idx, n, (int32_t*)offs->p, (uint8_t*)valid->p, (uint8_t*)data->p, dl + 16, &dl));
+  PCol o = c;
+  o.nullable = nullable; o.c.repr = GPUQ_REPR_ARROW; o.c.data = data->p; o.c.offsets = (const int32_t*)offs->p;
+  o.c.validity = nullable ? (const uint8_t*)valid->p : nullptr; o.c.length = n;
+  keep.push_back(offs); keep.push_back(data); keep.push_back(valid);
+  return o;
+}
+
+// force: also re-encode a plain table; strings then become fixed-width PACKED15 (concat / row ranges need fixed widths),
+// which holds 15 bytes.  Otherwise Utf8 columns in Arrow layout are taken as they are, whatever their length.
 PTable materialize(Exec& x, const PTable& t, bool force) {
   if (!t.is_view() && !force) return t;
+  const bool pack_strings = force;
   PTable out; out.n = t.n;
-  for (size_t a = 0; a < t.cols.size(); a += 12) {
+  out.cols.resize(t.cols.size()); out.sides.assign(t.cols.size(), 0);
+  std::vector<size_t> fixed;
+  for (size_t i = 0; i < t.cols.size(); ++i) {
+    const PCol& c = t.cols[i];
+    if (c.c.offsets && !pack_strings) {
+      if (!t.is_view()) out.cols[i] = c;
+      else out.cols[i] = take_utf8(x, c, t.sides[i] > 0 ? t.via[(size_t)t.sides[i] - 1] : nullptr, t.n, c.nullable || (t.sides[i] > 0 && !t.dense), out.keep);
+    } else fixed.push_back(i);
+  }
+  for (size_t a = 0; a < fixed.size(); a += 12) {
     PTable sub; sub.n = t.n; sub.via = t.via; sub.dense = t.dense;
     std::vector<Json> ex; std::vector<std::string> nm;
-    for (size_t i = a; i < std::min(a + 12, t.cols.size()); ++i) { sub.cols.push_back(t.cols[i]); sub.sides.push_back(t.sides[i]); }
+    const size_t hi = std::min(a + 12, fixed.size());
+    for (size_t k = a; k < hi; ++k) { sub.cols.push_back(t.cols[fixed[k]]); sub.sides.push_back(t.sides[fixed[k]]); }
     for (size_t i = 0; i < sub.cols.size(); ++i) { ex.push_back(jcol(sub.cols[i].name, (int)i)); nm.push_back(sub.cols[i].name); }
     // rebind by position, not by name: duplicate names (join outputs) must keep their own column
     static const int mat_site = 0;
@@ -268,7 +296,7 @@ PTable materialize(Exec& x, const PTable& t, bool force) {
     PTable part = alloc_outputs(op, sub.n, carr);
     InputC ic; make_input(sub, ic);
     check(x, gpuq_project_run(op, x.stream, &ic.in, carr.data(), (int)carr.size()));
-    for (auto& c : part.cols) { out.cols.push_back(c); out.sides.push_back(0); }
+    for (size_t k = a; k < hi; ++k) out.cols[fixed[k]] = part.cols[k - a];
     out.own(part);
   }
   // the kernels above read t's buffers asynchronously: keep them alive as long as the result

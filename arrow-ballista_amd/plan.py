@@ -149,20 +149,51 @@ def _select_view(tc, table, idx, n):
     return DeviceTable(cols, n, via=vias, sides=sides)
 
 
-def materialize(tc, table, force=False):
-    """Gather a late-materialised view into plain columns (<= 12 columns per kernel call).  force=True also
-    re-encodes a plain table (Utf8 offsets+bytes -> fixed-width PACKED15), which concat_tables needs."""
+def _take_utf8(tc, col, idx, n, nullable):
+    """Arrow-layout Utf8 column read through idx (None: identity) into a fresh Arrow-layout column: strings of any length."""
+    torch = _torch()
+    L = tc.ctx.L
+    offs = torch.empty(n + 4, dtype=torch.int32, device=tc.device)
+    valid = torch.empty(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=tc.device)
+    cc = col.to_c()
+    dl = C.c_int64(0)
+    ip = idx.data_ptr() if idx is not None and idx.numel() > 0 else None
+    rc = L.gpuq_take_utf8(tc.ctx.h, tc.stream_ptr(), C.byref(cc), ip, n, offs.data_ptr(), valid.data_ptr(), None, 0, C.byref(dl))
+    if rc not in (0, 4):
+        tc.ctx.check(rc)
+    data = torch.empty(dl.value + 16, dtype=torch.uint8, device=tc.device)
+    if dl.value > 0:
+        tc.ctx.check(L.gpuq_take_utf8(tc.ctx.h, tc.stream_ptr(), C.byref(cc), ip, n, offs.data_ptr(), valid.data_ptr(), data.data_ptr(), dl.value + 16, C.byref(dl)))
+    return DeviceColumn(col.name, "Utf8", data, n, offsets=offs, validity=valid if nullable else None, nullable=nullable, repr=B.REPR_ARROW)
+
+
+def materialize(tc, table, force=False, pack_strings=None):
+    """Gather a late-materialised view into plain columns (<= 12 columns per kernel call).
+    Utf8 columns in Arrow layout (offsets + bytes) are taken as they are, whatever their length (gpuq_take_utf8); with
+    pack_strings (the default under force=True: concat / exchange need fixed-width columns) every string is re-encoded as
+    PACKED15, which holds 15 bytes and refuses longer values."""
+    if pack_strings is None:
+        pack_strings = force
     if not table.is_view() and not force:
         return table
-    sch = table.plain_schema()
-    out = []
-    for a in range(0, len(sch), 12):
-        idxs = list(range(a, min(a + 12, len(sch))))
+    out = [None] * len(table.columns)
+    fixed = []
+    for i, (c, sd) in enumerate(zip(table.columns, table.sides)):
+        if c.offsets is not None and not pack_strings:
+            if not table.is_view():
+                out[i] = c
+            else:
+                out[i] = _take_utf8(tc, c, table.via[sd - 1] if sd > 0 else None, table.num_rows, bool(c.nullable or (sd > 0 and not table.dense)))
+        else:
+            fixed.append(i)
+    for a in range(0, len(fixed), 12):
+        idxs = fixed[a: a + 12]
         sub = DeviceTable([table.columns[i] for i in idxs], table.num_rows, via=table.via, sides=[table.sides[i] for i in idxs], dense=table.dense)
         def mk(sub=sub):
             ss = sub.plain_schema()
             return [E.col(f["name"], index=i) for i, f in enumerate(ss)], [f["name"] for f in ss]
-        out += _project(tc, sub, mk, None, memo_key="materialize").columns
+        for i, c in zip(idxs, _project(tc, sub, mk, None, memo_key="materialize").columns):
+            out[i] = c
     return DeviceTable(out, table.num_rows)
 
 

@@ -216,6 +216,15 @@ int gpuq_op_check(gpuq_op* op, void* stream);
    4 aggregate-hash, 5 join build, 6 probe chained, 7 probe unique, 8 sort min/max, 9 sort pack, 10 partition). */
 int gpuq_op_jit_source(gpuq_op* op, int kernel_id, char* buf, size_t cap);
 
+/* arrow `take` for Utf8 payload columns of ANY string length (datafusion's materialisation of a join / filter / sort output):
+   out[j] = col[idx[j]] (idx == NULL: identity; 0xFFFFFFFF or a NULL value -> NULL, length 0).  col must be Arrow layout
+   (offsets + bytes).  offsets_out: n+1 int32; validity_out (optional, 8-byte aligned, ((n+63)/64)*8 bytes): written in full;
+   data_out capacity data_cap bytes.  Two-call protocol: with data_cap too small (e.g. 0) the call computes offsets and
+   validity, reports the required size in *data_len_out and returns GPUQ_ERR_CAPACITY; call again with a large enough
+   buffer.  Synchronous up to the size read-back; the byte copy is queued on `stream`. */
+int gpuq_take_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int32_t* offsets_out, uint8_t* validity_out,
+                   uint8_t* data_out, int64_t data_cap, int64_t* data_len_out);
+
 /* Utf8 PACKED15 -> Arrow offsets+bytes.  offsets_out: n+1 int32; data_out capacity data_cap bytes.
    Synchronous; *data_len_out (host) = bytes written. */
 int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n, int32_t* offsets_out, uint8_t* data_out,

@@ -152,3 +152,30 @@ def test_native_unsupported_node_fails_loudly(tc):
     t = rand_table(1, 10, 0.0)
     with pytest.raises(g.GpuqError):
         g.NativePlan(g.RepartitionExec(g.MemoryExec([t]), [col("k64", g.MemoryExec([t]).schema())], 4), tc)
+
+
+def test_long_strings_travel_as_payload(tc):
+    """Utf8 values of any length pass through filters, joins, sorts and materialisation as payload (gpuq_take_utf8); only
+    comparisons / keys are limited to 15 bytes."""
+    n = 3000
+    r = np.random.default_rng(8)
+    words = ["", "x", "exactly15bytes!", "a comment that is clearly longer than fifteen bytes", "δοκιμή utf-8 ✓ multibyte text that is long"]
+    comment = pa.array([words[i] if r.random() > 0.1 else None for i in r.integers(0, len(words), n)])
+    lt = pa.table({"k": pa.array(r.integers(0, 500, n), pa.int64()), "comment": comment, "v": pa.array(np.arange(n, dtype=np.int64))})
+    rt = pa.table({"rk": pa.array(np.arange(500, dtype=np.int64)), "name": pa.array(["supplier#%09d of somewhere far away" % i for i in range(500)])})
+    L, R = g.MemoryExec([rt]), g.MemoryExec([lt])
+    ls, rs = L.schema(), R.schema()
+    f = g.FilterExec(binary(col("v", rs), Op.Gt, lit(99)), R)
+    j = g.HashJoinExec(L, f, [(col("rk", ls), col("k", rs))], None, "Inner", "CollectLeft", False)
+    js = j.schema()
+    plan = g.SortExec([{"expr": col("v", js), "asc": False, "nulls_first": False}], j, fetch=200)
+    exp = []
+    lk, lc, lv = lt["k"].to_pylist(), lt["comment"].to_pylist(), lt["v"].to_pylist()
+    names = rt["name"].to_pylist()
+    for i in sorted(range(n), key=lambda i: -lv[i]):
+        if lv[i] > 99:
+            exp.append((lk[i], names[lk[i]], lk[i], lc[i], lv[i]))
+    exp = exp[:200]
+    assert dev_rows(tc, plan.execute(0, tc)) == exp
+    got, _ = native_rows(tc, plan)
+    assert got == exp
