@@ -108,6 +108,7 @@ def lib():
         "gpuq_partition_run": (i32, [vp, vp, C.POINTER(gpuq_input), vp, vp]),
         "gpuq_op_check": (i32, [vp, vp]),
         "gpuq_unpack_utf8": (i32, [vp, vp, vp, i64, vp, vp, i64, C.POINTER(i64)]),
+        "gpuq_offsets_rebase": (i32, [vp, vp, vp, i64, i32, vp]),
         "gpuq_take_utf8": (i32, [vp, vp, C.POINTER(gpuq_column), vp, i64, vp, vp, vp, i64, C.POINTER(i64)]),
         "gpuq_concat_bitmap": (i32, [vp, vp, vp, i64, vp, i64]),
         "gpuq_copy_bits": (i32, [vp, vp, vp, i64, vp, i64, i64]),

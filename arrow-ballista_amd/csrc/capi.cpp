@@ -1173,6 +1173,15 @@ int gpuq_take_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const ui
   });
 }
 
+int gpuq_offsets_rebase(gpuq_ctx* ctx, void* stream, const int32_t* src, int64_t n, int32_t delta, int32_t* dst) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (n < 0 || (n > 0 && (!src || !dst))) throw std::runtime_error("bad arguments");
+    launch_offsets_rebase((hipStream_t)stream, src, n, delta, dst);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
 // ---------------------------------------------------------------- utf8 unpack
 int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n, int32_t* offsets_out, uint8_t* data_out, int64_t data_cap,
                      int64_t* data_len_out) {

@@ -984,6 +984,12 @@ static int lin_grid(i64 n) { i64 need = (n + BLOCK - 1) / BLOCK; if (need < 1) n
 void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out, uint32_t* too_long) {
   if (n > 0) hipLaunchKernelGGL(k_unpack_lengths, dim3(lin_grid(n)), dim3(BLOCK), 0, s, packed, n, lens_out, too_long);
 }
+__global__ void __launch_bounds__(BLOCK) k_offsets_rebase(const int32_t* __restrict__ src, const i64 n, const int32_t delta, int32_t* __restrict__ dst) {
+  for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) dst[i] = src[i] + delta;
+}
+void launch_offsets_rebase(hipStream_t s, const int32_t* src, i64 n, int32_t delta, int32_t* dst) {
+  if (n > 0) hipLaunchKernelGGL(k_offsets_rebase, dim3(lin_grid(n)), dim3(BLOCK), 0, s, src, n, delta, dst);
+}
 void launch_take_utf8_lengths(hipStream_t s, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int32_t* lens, u64* valid_out) {
   if (n > 0) hipLaunchKernelGGL(k_take_utf8_lengths, dim3(grid_for(n, 8)), dim3(BLOCK), 0, s, offsets, validity, idx, n, lens, valid_out);
 }

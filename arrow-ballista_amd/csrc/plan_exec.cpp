@@ -594,9 +594,8 @@ PTable concat_tables(Exec& x, std::vector<PTable> parts) {
   for (auto& p : parts) if (p.n > 0) live.push_back(p);
   if (live.empty() && !parts.empty()) live.push_back(parts[0]);
   if (live.empty()) throw std::runtime_error("concat: no input partitions");
-  auto needs = [](const PTable& t) { if (t.is_view()) return true; for (auto& c : t.cols) if (c.c.offsets) return true; return false; };
-  if (live.size() == 1 && !needs(live[0])) return live[0];
-  for (auto& p : live) p = materialize(x, p, true);
+  if (live.size() == 1 && !live[0].is_view()) return live[0];
+  for (auto& p : live) p = materialize(x, p);        // views -> plain columns; Arrow-layout strings stay as they are
   int64_t n = 0; for (auto& p : live) n += p.n;
   const size_t nc = live[0].cols.size();
   const size_t bm = (size_t)((n + 63) / 64) * 8 + 8;
@@ -606,7 +605,9 @@ PTable concat_tables(Exec& x, std::vector<PTable> parts) {
     const PCol& c0 = live[0].cols[i];
     for (auto& p : live) if (p.cols[i].c.type != c0.c.type || p.cols[i].c.repr != c0.c.repr) throw std::runtime_error("concat: column '" + c0.name + "' has different layouts across partitions");
     DType dt; dt.id = c0.c.type; dt.p = c0.c.precision; dt.s = c0.c.scale;
-    dbytes[i] = c0.c.type == T_BOOL ? bm : (size_t)std::max<int64_t>(n, 1) * (size_t)type_width(dt) + 16;
+    for (auto& p : live) if ((p.cols[i].c.offsets != nullptr) != (c0.c.offsets != nullptr)) throw std::runtime_error("concat: column '" + c0.name + "' has different layouts across partitions");
+    if (c0.c.offsets) dbytes[i] = (size_t)(n + 4) * 4;          // Arrow-layout Utf8: this slot holds the joined offsets, the bytes get their own buffer
+    else dbytes[i] = c0.c.type == T_BOOL ? bm : (size_t)std::max<int64_t>(n, 1) * (size_t)type_width(dt) + 16;
     doff[i] = off; off += (dbytes[i] + 255) & ~(size_t)255;
     bool any_valid = false; for (auto& p : live) any_valid = any_valid || p.cols[i].c.validity != nullptr;
     if (any_valid) { voff[i] = off; off += (bm + 255) & ~(size_t)255; }
@@ -622,6 +623,32 @@ PTable concat_tables(Exec& x, std::vector<PTable> parts) {
     if (c.c.type == T_BOOL) HIPCHECK(hipMemsetAsync(d, 0, bm, s));
     if (v) HIPCHECK(hipMemsetAsync(v, 0, bm, s));
     int64_t row = 0; bool nullable = false;
+    if (c.c.offsets) {
+      // first / last offset of every piece (one small read-back per piece), then re-based offsets and joined bytes
+      std::vector<int32_t> first(live.size()), last(live.size()); int64_t total = 0;
+      for (size_t q = 0; q < live.size(); ++q) {
+        const PCol& pc = live[q].cols[i];
+        HIPCHECK(hipMemcpyAsync(&x.pin[0], pc.c.offsets, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync((char*)&x.pin[0] + 4, pc.c.offsets + live[q].n, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        std::memcpy(&first[q], &x.pin[0], 4); std::memcpy(&last[q], (char*)&x.pin[0] + 4, 4);
+        total += last[q] - first[q];
+      }
+      BufP bytes = dev_alloc((size_t)total + 16);
+      int64_t base = 0;
+      for (size_t q = 0; q < live.size(); ++q) {
+        const PCol& pc = live[q].cols[i];
+        nullable = nullable || pc.nullable;
+        check(x, gpuq_offsets_rebase(x.ctx, x.stream, pc.c.offsets, live[q].n + 1, (int32_t)(base - first[q]), (int32_t*)d + row));
+        if (last[q] > first[q]) HIPCHECK(hipMemcpyAsync((char*)bytes->p + base, (const char*)pc.c.data + first[q], (size_t)(last[q] - first[q]), hipMemcpyDeviceToDevice, s));
+        if (v && live[q].n > 0) check(x, gpuq_copy_bits(x.ctx, x.stream, v, row, pc.c.validity, 0, live[q].n));
+        row += live[q].n; base += last[q] - first[q];
+      }
+      c.nullable = nullable; c.c.offsets = (const int32_t*)d; c.c.data = bytes->p; c.c.validity = v; c.c.length = n;
+      out.keep.push_back(bytes);
+      out.cols.push_back(c); out.sides.push_back(0);
+      continue;
+    }
     for (auto& p : live) {
       const PCol& pc = p.cols[i];
       nullable = nullable || pc.nullable;

@@ -199,8 +199,9 @@ def materialize(tc, table, force=False, pack_strings=None):
 
 def concat_tables(tc, tables):
     """Fan-in of partitions into one table (row order = partition order, then row order inside a partition).
-    Every piece is first brought to the fixed-width device layout; data buffers are joined with device copies
-    (torch.cat) and validity / Boolean bitmaps with gpuq_concat_bitmap."""
+    Views are materialised first; fixed-width data buffers are joined with device copies (torch.cat), validity / Boolean
+    bitmaps with gpuq_concat_bitmap, Arrow-layout strings by re-basing their offsets (gpuq_offsets_rebase) and joining
+    their bytes."""
     torch = _torch()
     tables = list(tables)
     live = [t for t in tables if t.num_rows > 0]
@@ -208,7 +209,7 @@ def concat_tables(tc, tables):
         return live[0]
     if not live:
         live = tables[:1]
-    parts = [materialize(tc, t, force=any(c.offsets is not None for c in t.columns)) for t in live]
+    parts = [materialize(tc, t) for t in live]
     n = sum(p.num_rows for p in parts)
     cols = []
     L = tc.ctx.L
@@ -226,13 +227,26 @@ def concat_tables(tc, tables):
         if any(c.repr != c0.repr or c.type != c0.type for c in pcs):
             raise B.GpuqError(2, "concat: column %r has different layouts across partitions" % c0.name)
         w = type_width(c0.type)
-        if w == 0:           # Boolean: bit-packed
+        offsets = None
+        if c0.offsets is not None:      # Utf8 in Arrow layout: any string length
+            if any(c.offsets is None for c in pcs):
+                raise B.GpuqError(2, "concat: column %r has different layouts across partitions" % c0.name)
+            ends = torch.stack([torch.stack([c.offsets[0], c.offsets[p.num_rows]]) for c, p in zip(pcs, parts)]).tolist()
+            offsets = torch.empty(n + 4, dtype=torch.int32, device=tc.device)
+            row, base, chunks = 0, 0, []
+            for (first, last), c, p in zip(ends, pcs, parts):
+                tc.ctx.check(L.gpuq_offsets_rebase(tc.ctx.h, tc.stream_ptr(), c.offsets.data_ptr(), p.num_rows + 1, base - first, offsets.data_ptr() + 4 * row))
+                chunks.append(c.data[first:last])
+                row += p.num_rows
+                base += last - first
+            data = torch.cat(chunks + [torch.zeros(16, dtype=torch.uint8, device=tc.device)])
+        elif w == 0:           # Boolean: bit-packed
             data = bitmap([(c.data, p.num_rows) for c, p in zip(pcs, parts)])
         else:
             data = torch.cat([c.data[: p.num_rows * w] for c, p in zip(pcs, parts)] + [torch.zeros(16, dtype=torch.uint8, device=tc.device)])
         nullable = any(c.nullable for c in pcs)
         validity = bitmap([(c.validity, p.num_rows) for c, p in zip(pcs, parts)]) if any(c.validity is not None for c in pcs) else None
-        cols.append(DeviceColumn(c0.name, c0.type, data, n, validity=validity, nullable=nullable, repr=c0.repr))
+        cols.append(DeviceColumn(c0.name, c0.type, data, n, offsets=offsets, validity=validity, nullable=nullable, repr=c0.repr))
     return DeviceTable(cols, n)
 
 
@@ -884,11 +898,17 @@ class ShuffleWriterExec(ExecutionPlan):
         parts = list(input_partitions) if input_partitions is not None else (self.partitions or range(self.plan.output_partition_count()))
         out = []
         opts = pa.ipc.IpcWriteOptions(compression="lz4")
+        # the reference's ShuffleWriteMetrics (shuffle_writer.rs:139-160): write_time, repart_time (ns), input_rows, output_rows
+        mx = self.metrics.extra
+        for k in ("write_time", "repart_time", "input_rows"):
+            mx.setdefault(k, 0)
         for p in parts:
             table = self.plan.execute(p, context)
+            mx["input_rows"] += table.num_rows
             base = os.path.join(self.work_dir, self.job_id, str(self.stage_id))
             if self.shuffle_output_partitioning is None:
                 path = os.path.join(base, str(uuid.uuid4()), "data.arrow")
+                tw = time.perf_counter()
                 host = materialize(context, table).to_arrow(context.ctx)
                 os.makedirs(os.path.dirname(path), exist_ok=True)
                 nb = 0
@@ -897,10 +917,14 @@ class ShuffleWriterExec(ExecutionPlan):
                         if b.num_rows:
                             w.write_batch(b)
                             nb += 1
+                mx["write_time"] += int((time.perf_counter() - tw) * 1e9)
                 out.append(ShuffleWritePartition(partition_id=p, path=path, num_batches=nb, num_rows=host.num_rows, num_bytes=host.nbytes))
             else:
                 exprs, n = self.shuffle_output_partitioning
+                tr = time.perf_counter()
                 views = partition_table(context, table, exprs, n)
+                mx["repart_time"] += int((time.perf_counter() - tr) * 1e9)
+                tw = time.perf_counter()
                 for q, v in enumerate(views):
                     if v.num_rows == 0:
                         continue    # lazily created writers: empty partitions produce no file (shuffle_writer.rs:329-334)
@@ -914,6 +938,7 @@ class ShuffleWriterExec(ExecutionPlan):
                             nb += 1
                     out.append(ShuffleWritePartition(partition_id=q, path=path, num_batches=nb, num_rows=host.num_rows,
                                                      num_bytes=os.path.getsize(path)))
+                mx["write_time"] += int((time.perf_counter() - tw) * 1e9)
         self.metrics.elapsed_compute_ns += int((time.perf_counter() - t0) * 1e9)
         self.metrics.output_rows += sum(o["num_rows"] for o in out)
         return out

@@ -225,6 +225,9 @@ int gpuq_op_jit_source(gpuq_op* op, int kernel_id, char* buf, size_t cap);
 int gpuq_take_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int32_t* offsets_out, uint8_t* validity_out,
                    uint8_t* data_out, int64_t data_cap, int64_t* data_len_out);
 
+/* dst[i] = src[i] + delta for n Utf8 offsets: joining the offset arrays of partitions that are concatenated (fan-in). */
+int gpuq_offsets_rebase(gpuq_ctx* ctx, void* stream, const int32_t* src, int64_t n, int32_t delta, int32_t* dst);
+
 /* Utf8 PACKED15 -> Arrow offsets+bytes.  offsets_out: n+1 int32; data_out capacity data_cap bytes.
    Synchronous; *data_len_out (host) = bytes written. */
 int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n, int32_t* offsets_out, uint8_t* data_out,

@@ -179,3 +179,8 @@ def test_long_strings_travel_as_payload(tc):
     assert dev_rows(tc, plan.execute(0, tc)) == exp
     got, _ = native_rows(tc, plan)
     assert got == exp
+    # fan-in of partitions that carry long strings (filtered views and plain tables mixed)
+    fan = g.CoalescePartitionsExec(g.UnionExec([g.MemoryExec([lt.slice(0, 700), lt.slice(700, 1)]), g.FilterExec(binary(col("v", rs), Op.Lt, lit(50)), g.MemoryExec([lt]))]))
+    want = [tuple(r.values()) for r in lt.slice(0, 701).to_pylist()] + [tuple(r.values()) for r in lt.slice(0, 50).to_pylist()]
+    assert dev_rows(tc, fan.execute(0, tc)) == want
+    assert native_rows(tc, fan)[0] == want
