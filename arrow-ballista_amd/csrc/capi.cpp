@@ -1028,6 +1028,11 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
     if (n >= (1ll << 31)) throw Unsupported("sort of >= 2^31 rows in one call");
     if (!perm_out) throw std::runtime_error("perm_out is NULL");
     const SortSpec& S = op->sort;
+    if (n <= sort_direct_max()) {      // one block, no min/max read-back
+      launch_sort_direct(s, P, n, S, perm_out);
+      HIPCHECK(hipGetLastError());
+      return;
+    }
     // 1. per-key min/max in the ordered view
     const int mb = sort_minmax_blocks(n);
     u64* mm = (u64*)op->ws[0].ensure((size_t)mb * MAX_SORT_KEYS * 5 * 8);

@@ -128,6 +128,8 @@ void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K
 void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out);
 void launch_gather_u64(hipStream_t s, const u64* src, const uint32_t* idx, i64 n, u64* dst);
 int sort_small_max();
+int sort_direct_max();
+void launch_sort_direct(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, uint32_t* perm);
 void launch_sort_small(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, i64 n, uint32_t* out);
 void radix_geometry(i64 n, int* nblocks, i64* tile);
 size_t radix_hist_entries(int nblocks);

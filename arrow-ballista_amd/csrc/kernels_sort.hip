@@ -143,6 +143,86 @@ extern "C" __global__ void __launch_bounds__(SBLOCK) gpuq_jit_entry(const DevPro
                                                       u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids) { k_sort_pack_body<0>(P, n, S, K, key_lo, key_hi, ids); }
 #endif
 
+// ------------------------------------------------------------------ small inputs, end to end in one block
+// <= SORT_DIRECT_MAX rows: evaluate the keys, normalise each to an unsigned 128-bit value whose order is the requested
+// order (ASC / DESC), keep a 2-bit rank per key for NULL placement, and run a bitonic network over (rank, value) x keys
+// with the row id as the last tie-break (= the stable order).  No per-key min/max, hence no host round trip: sorting the
+// handful of groups a final aggregate produces is otherwise one synchronisation and three launches.
+constexpr int SORT_DIRECT_MAX = 512;
+template <int MAXC>
+__device__ __forceinline__ void k_sort_direct_body(const DevProgram P, const int n, const SortSpec S, uint32_t* __restrict__ perm) {
+  __shared__ u64 vlo[MAX_SORT_KEYS][SORT_DIRECT_MAX], vhi[MAX_SORT_KEYS][SORT_DIRECT_MAX];
+  __shared__ uint32_t rk[SORT_DIRECT_MAX], sid[SORT_DIRECT_MAX];      // rk: 2 bits per key (0 NULL first, 1 value, 2 NULL last, 3 padding)
+  int m = 2; while (m < n) m <<= 1;
+  const int i = threadIdx.x;
+  if (i < m) {
+    uint32_t ranks = 0xFFu; uint32_t id = 0xFFFFFFFFu;
+    u64 lo[MAX_SORT_KEYS], hi[MAX_SORT_KEYS];
+#pragma unroll
+    for (int k = 0; k < MAX_SORT_KEYS; ++k) { lo[k] = 0; hi[k] = 0; }
+    const bool act = i < n;
+    GPUQ_REGS_DECL;
+    if (act) (void)GPUQ_EVAL(MAXC, P, (i64)i);
+    if (act) {
+      ranks = 0; id = (uint32_t)i;
+#pragma unroll
+      for (int k = 0; k < MAX_SORT_KEYS; ++k) {
+        if (k < S.n_keys) {
+          const int r = __builtin_amdgcn_readfirstlane(S.reg[k]);
+          const bool isn = (rnulls >> r) & 1;
+          u128 u = 0;
+          if (!isn) {
+            u = (u128)sort_view(rlo[r], rhi[r], S.kind[k]) ^ ((u128)1 << 127);     // signed order -> unsigned order
+            if (S.desc[k]) u = ~u;
+          }
+          lo[k] = (u64)u; hi[k] = (u64)(u >> 64);
+          ranks |= (isn ? (S.nulls_first[k] ? 0u : 2u) : 1u) << (2 * k);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAX_SORT_KEYS; ++k) { vlo[k][i] = lo[k]; vhi[k][i] = hi[k]; }
+    rk[i] = ranks; sid[i] = id;
+  }
+  __syncthreads();
+  for (int kk = 2; kk <= m; kk <<= 1) {
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      const int x = i ^ j;
+      if (i < m && x > i) {
+        // a > b in (rank_0, value_0, rank_1, value_1, ..., id) order
+        bool gt = false, decided = false;
+        const uint32_t ra = rk[i], rb = rk[x];
+#pragma unroll
+        for (int k = 0; k < MAX_SORT_KEYS; ++k) {
+          if (k < S.n_keys && !decided) {
+            const uint32_t a2 = (ra >> (2 * k)) & 3u, b2 = (rb >> (2 * k)) & 3u;
+            if (a2 != b2) { gt = a2 > b2; decided = true; }
+            else if (a2 == 1u) {
+              const u64 ah = vhi[k][i], bh = vhi[k][x];
+              if (ah != bh) { gt = ah > bh; decided = true; }
+              else { const u64 al = vlo[k][i], bl = vlo[k][x]; if (al != bl) { gt = al > bl; decided = true; } }
+            }
+          }
+        }
+        if (!decided) gt = sid[i] > sid[x];
+        const bool up = (i & kk) == 0;
+        if (gt == up) {
+#pragma unroll
+          for (int k = 0; k < MAX_SORT_KEYS; ++k) { const u64 tl = vlo[k][i], th = vhi[k][i]; vlo[k][i] = vlo[k][x]; vhi[k][i] = vhi[k][x]; vlo[k][x] = tl; vhi[k][x] = th; }
+          const uint32_t tr = rk[i]; rk[i] = rk[x]; rk[x] = tr;
+          const uint32_t ti = sid[i]; sid[i] = sid[x]; sid[x] = ti;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (i < n) perm[i] = sid[i];
+}
+#ifndef GPUQ_JIT
+template <int MAXC>
+__global__ void __launch_bounds__(SORT_DIRECT_MAX) k_sort_direct(const DevProgram P, const int n, const SortSpec S, uint32_t* __restrict__ perm) { k_sort_direct_body<MAXC>(P, n, S, perm); }
+#endif
+
 // ------------------------------------------------------------------ partition ids
 template <int MAXC>
 __device__ __forceinline__ void k_part_pid_body(const DevProgram P, const i64 n, const KeySpec K, const uint32_t nparts,
@@ -432,6 +512,13 @@ __global__ void __launch_bounds__(1024) k_sort_small(const u64* __restrict__ klo
   for (int i = threadIdx.x; i < n; i += 1024) out[i] = sid[i];
 }
 int sort_small_max() { return SMALL_SORT_MAX; }
+int sort_direct_max() { return SORT_DIRECT_MAX; }
+void launch_sort_direct(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, uint32_t* perm) {
+  if (n <= 0) return;
+#define CALL(M) hipLaunchKernelGGL(k_sort_direct<M>, dim3(1), dim3(SORT_DIRECT_MAX), 0, s, P, (int)n, S, perm)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
+}
 void launch_sort_small(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, i64 n, uint32_t* out) {
   if (n > 0) hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, s, klo, khi, ids, (int)n, out);
 }
