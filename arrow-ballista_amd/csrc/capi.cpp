@@ -846,6 +846,43 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         if (!done && strat == "tiny") throw Capacity("more groups than the LDS aggregate holds; use strategy hash/auto");
       }
     }
+    if (!done && (strat == "radix" || (strat == "auto" && n >= (1ll << 22) && op->expected_groups >= (1ll << 20)))) {
+      // High cardinality: partition the rows by key hash into buckets whose groups fit an LDS table, aggregate every bucket
+      // inside one block (kernels_hash.hip).  Falls through to the global table when a bucket overflows (skew, or more
+      // groups than the hint promised).
+      const int slot_words = 1 + op->keys.key_words + 2 * na;
+      uint32_t capslots = 64; while ((size_t)capslots * 2 * slot_words * 8 <= 60 * 1024) capslots *= 2;
+      if ((size_t)capslots * slot_words * 8 <= 60 * 1024 && n < (1ll << 31)) {
+        const u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (u64)n;
+        const u64 per_bucket = std::max<u64>(1, (u64)capslots * 3 / 8);          // load factor <= 0.5 with headroom for uneven buckets
+        u64 nbk = next_pow2(std::max<u64>(1, (est + per_bucket - 1) / per_bucket)); if (nbk > (1ull << 24)) nbk = 1ull << 24;
+        int bits = 0; while ((1ull << bits) < nbk) ++bits;
+        DevBuf b_bid, b_bid2, b_ids, b_ids2, b_hist, b_scan, b_bounds;
+        u64* bid = (u64*)b_bid.ensure((size_t)n * 8); u64* bid2 = (u64*)b_bid2.ensure((size_t)n * 8);
+        uint32_t* ids = (uint32_t*)b_ids.ensure((size_t)n * 4 + 16); uint32_t* ids2 = (uint32_t*)b_ids2.ensure((size_t)n * 4 + 16);
+        int nblocks; i64 tile; radix_geometry(n, &nblocks, &tile);
+        int32_t* hist = (int32_t*)b_hist.ensure(radix_hist_entries(nblocks) * 4 + 16);
+        const size_t swb = exclusive_scan_ws_bytes((i64)radix_hist_entries(nblocks));
+        void* sws = b_scan.ensure(swb);
+        uint32_t* bounds = (uint32_t*)b_bounds.ensure((size_t)(nbk + 2) * 4);
+        reset_flags(op, s);
+        { JitScope js(op, op->prog, 11, n); launch_agg_bucket_id(s, P, n, op->keys, nbk - 1, bid, ids); }
+        for (int sh = 0; sh < bits; sh += 8) {
+          launch_radix_pass(s, bid, ids, n, sh, 0xFFu, bid2, ids2, hist, sws, swb);
+          std::swap(bid, bid2); std::swap(ids, ids2);
+        }
+        launch_bucket_bounds(s, bid, n, nbk, bounds);
+        alloc_raw((i64)std::min<u64>((u64)std::max<i64>(n, 1), std::max<u64>(est + est / 4, 1ull << 20)));
+        { JitScope js(op, op->prog, 12, n); ProfScope ps(op, s); launch_agg_bucket(s, P, op->keys, op->agg, ids, bounds, (uint32_t)nbk, capslots, slot_words, raw); }
+        HIPCHECK(hipGetLastError());
+        uint32_t fw[4] = {0, 0, 0, 0};
+        read_status(op, s, fw, 4);
+        if (fw[0] & ~(FLAG_TABLE_FULL | FLAG_GROUP_OVERFLOW)) { reset_flags(op, s); raise_flags(fw[0] & ~(FLAG_TABLE_FULL | FLAG_GROUP_OVERFLOW)); }
+        if (!(fw[0] & (FLAG_TABLE_FULL | FLAG_GROUP_OVERFLOW))) { ng = fw[2]; done = true; }
+        else if (strat == "radix" && op->expected_groups > 0 && est < (u64)n) throw Capacity("radix aggregate: a bucket overflowed; raise expected_groups or use strategy hash/auto");
+        else reset_flags(op, s);
+      } else if (strat == "radix") throw Unsupported("radix aggregate: the group state does not fit an LDS table");
+    }
     if (!done) {
       // global hash table; grow on FLAG_TABLE_FULL
       u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (u64)std::min<i64>(std::max<i64>(n, 1), 1ll << 24);

@@ -334,6 +334,216 @@ __global__ void __launch_bounds__(HBLOCK) k_agg_hash_extract(const KeySpec K, co
 }
 #endif
 
+// ------------------------------------------------------------------ radix-partitioned aggregate (high cardinality)
+// The global-table aggregate is bound by device-scope transactions (~10 G/s: every probe, CAS and accumulate of every row
+// is one).  For tens of millions of groups the rows are first partitioned by key hash into buckets small enough for an LDS
+// hash table (bucket id + row id through the coalesced radix passes of kernels_sort.hip); one block then aggregates a bucket
+// entirely in LDS -- workgroup-scope atomics only -- and appends its groups to the result.  Three kernels:
+//   k_agg_bucket_id     rows -> (bucket = hash & mask, row id | NIL for rows the predicate drops)
+//   k_bucket_bounds     lower bound of every bucket in the sorted bucket-id array
+//   k_agg_bucket        per bucket: LDS find-or-insert + accumulate over the bucket's rows (re-evaluated by row id), extract
+template <int MAXC>
+__device__ __forceinline__ void k_agg_bucket_id_body(const DevProgram P, const i64 n, const KeySpec K, const u64 bucket_mask,
+                                                         u64* __restrict__ bid, uint32_t* __restrict__ ids) {
+  const i64 nwords = (n + 63) >> 6;
+  for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
+    const i64 pos = (w << 6) + hlane();
+    if (pos >= n) continue;
+    GPUQ_REGS_DECL;
+    const bool pass = GPUQ_EVAL(MAXC, P, pos);
+    u64 kw[MAX_KW]; u64 h = 0;
+#pragma unroll
+    for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
+    if (pass) make_key(K, GPUQ_REGS, kw, h);
+    bid[pos] = h & bucket_mask;
+    ids[pos] = pass ? (uint32_t)pos : NIL;
+  }
+}
+#ifndef GPUQ_JIT
+template <int MAXC>
+__global__ void __launch_bounds__(HBLOCK) k_agg_bucket_id(const DevProgram P, const i64 n, const KeySpec K, const u64 bucket_mask,
+                                                          u64* __restrict__ bid, uint32_t* __restrict__ ids) { k_agg_bucket_id_body<MAXC>(P, n, K, bucket_mask, bid, ids); }
+__global__ void __launch_bounds__(HBLOCK) k_bucket_bounds(const u64* __restrict__ sorted_bid, const i64 n, const u64 nbuckets, uint32_t* __restrict__ bounds) {
+  for (u64 b = (u64)blockIdx.x * HBLOCK + threadIdx.x; b <= nbuckets; b += (u64)gridDim.x * HBLOCK) {
+    i64 lo = 0, hi = n;                     // first position whose bucket id is >= b
+    while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (sorted_bid[mid] < b) lo = mid + 1; else hi = mid; }
+    bounds[b] = (uint32_t)lo;
+  }
+}
+#elif GPUQ_JIT_KERNEL == 11
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const u64 bucket_mask,
+                                                          u64* __restrict__ bid, uint32_t* __restrict__ ids) { k_agg_bucket_id_body<0>(P, n, K, bucket_mask, bid, ids); }
+#endif
+
+// LDS table slot: word 0 = state (0 empty, 1 being written, else tag), then key words, then 2 words per accumulator
+__device__ __forceinline__ uint32_t lds_slot_find_or_insert(u64* slots, const uint32_t cap, const int slot_words, const int key_words, const u64 (&kw)[MAX_KW], const u64 h) {
+  const uint32_t mask = cap - 1;
+  uint32_t s = (uint32_t)(h >> 20) & mask;          // bits the bucket id did not use
+  const u64 tag = (u64)tag_of(h);
+  for (uint32_t probes = 0; probes < cap;) {
+    u64* slot = slots + (size_t)s * slot_words;
+    u64 st = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (st == 0) {
+      u64 expected = 0;
+      if (__hip_atomic_compare_exchange_strong(slot, &expected, 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+#pragma unroll
+        for (int q = 0; q < MAX_KW; ++q) if (q < key_words) __hip_atomic_store(slot + 1 + q, kw[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __hip_atomic_store(slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return s;
+      }
+      st = expected;
+    }
+    if (st == 1) continue;                           // being published by another lane: look again
+    if (st == tag) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      bool eq = true;
+#pragma unroll
+      for (int q = 0; q < MAX_KW; ++q) if (q < key_words) eq = eq && (__hip_atomic_load(slot + 1 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kw[q]);
+      if (eq) return s;
+    }
+    s = (s + 1) & mask; ++probes;
+  }
+  return 0xFFFFFFFFu;
+}
+
+template <int MAXC>
+__device__ __forceinline__ void k_agg_bucket_body(const DevProgram P, const KeySpec K, const AggSpec A, const uint32_t* __restrict__ ids,
+                                                      const uint32_t* __restrict__ bounds, const uint32_t nbuckets, const uint32_t cap, const int slot_words,
+                                                      const AggOut out) {
+  extern __shared__ __attribute__((aligned(16))) u64 bslots[];
+  __shared__ uint32_t cnt[2]; __shared__ uint32_t gbase;
+  const int key_words = K.key_words;
+  const int cell0 = 1 + key_words;
+  const int kstride = K.n_keys > 0 ? K.n_keys : 1;
+  for (uint32_t bk = blockIdx.x; bk < nbuckets; bk += gridDim.x) {
+    const uint32_t b0 = bounds[bk], b1 = bounds[bk + 1];
+    if (b0 == b1) continue;                          // uniform for the block
+    // table init
+    for (uint32_t i = threadIdx.x; i < cap * (uint32_t)slot_words; i += HBLOCK) {
+      const int w = (int)(i % (uint32_t)slot_words);
+      u64 v = 0;
+      if (w >= cell0) {
+        const int a = (w - cell0) >> 1, half = (w - cell0) & 1;
+        if (a < A.n_accs) {
+          switch (A.acc_kind[a]) {
+            case ACC_MIN: v = half ? 0 : 0x7FFFFFFFFFFFFFFFull; break;
+            case ACC_MAX: v = half ? ~0ull : 0x8000000000000000ull; break;
+            case ACC_FMIN: v = half ? 0 : 0x7FF0000000000000ull; break;
+            case ACC_FMAX: v = half ? 0 : 0xFFF0000000000000ull; break;
+            default: break;
+          }
+        }
+      }
+      bslots[i] = v;
+    }
+    if (threadIdx.x == 0) { cnt[0] = 0; cnt[1] = 0; }
+    __syncthreads();
+    // aggregate the bucket's rows
+    for (uint32_t i0 = b0; i0 < b1; i0 += HBLOCK) {
+      const uint32_t i = i0 + threadIdx.x;
+      uint32_t row = NIL;
+      if (i < b1) row = ids[i];
+      bool active = row != NIL;
+      GPUQ_REGS_DECL;
+      if (active) active = GPUQ_EVAL(MAXC, P, (i64)row);
+      if (!active) continue;
+      u64 kw[MAX_KW]; u64 h;
+#pragma unroll
+      for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
+      make_key(K, GPUQ_REGS, kw, h);
+      const uint32_t s = lds_slot_find_or_insert(bslots, cap, slot_words, key_words, kw, h);
+      if (s == 0xFFFFFFFFu) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
+      u64* cells = bslots + (size_t)s * slot_words + cell0;
+      for (int a = 0; a < A.n_accs; ++a) {
+        const int kind = A.acc_kind[a];
+        u64 vlo = 1, vhi = 0; bool vnull = false;
+        if (kind != ACC_COUNT_STAR) {
+          const int r = __builtin_amdgcn_readfirstlane(A.acc_reg[a]);
+          vlo = rlo[r]; vhi = rhi[r]; vnull = (rnulls >> r) & 1;
+        }
+        if (vnull) continue;
+        u64* c = cells + 2 * a;
+        switch (kind) {
+          case ACC_COUNT: case ACC_COUNT_STAR: atomicAdd((unsigned long long*)c, 1ull); break;
+          case ACC_SUM: {
+            const u64 old = atomicAdd((unsigned long long*)c, (unsigned long long)vlo);
+            const u64 carry = (old + vlo < old) ? 1 : 0;
+            if (vhi + carry) atomicAdd((unsigned long long*)(c + 1), (unsigned long long)(vhi + carry));
+            break;
+          }
+          case ACC_MIN: case ACC_MAX: {
+            if ((i64)vhi != ((i64)vlo >> 63)) { atomicOr(P.flags, FLAG_WIDE_MINMAX); break; }
+            if (kind == ACC_MIN) atomicMin((long long*)c, (long long)vlo); else atomicMax((long long*)c, (long long)vlo);
+            break;
+          }
+          case ACC_FSUM: atomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;
+          case ACC_FMIN: case ACC_FMAX: {
+            u64 cur = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (;;) {
+              const bool better = (kind == ACC_FMIN) ? (f64_total_key(vlo) < f64_total_key(cur)) : (f64_total_key(vlo) > f64_total_key(cur));
+              if (!better) break;
+              const u64 seen = atomicCAS((unsigned long long*)c, (unsigned long long)cur, (unsigned long long)vlo);
+              if (seen == cur) break;
+              cur = seen;
+            }
+            break;
+          }
+          default: break;
+        }
+      }
+    }
+    __syncthreads();
+    // extract: count, claim a range of the result with one device atomic per bucket, write
+    for (int pass = 0; pass < 2; ++pass) {
+      for (uint32_t s0 = 0; s0 < cap; s0 += HBLOCK) {
+        const uint32_t s = s0 + threadIdx.x;
+        const u64* slot = bslots + (size_t)s * slot_words;
+        const bool live = s < cap && (uint32_t)slot[0] >= 2u;
+        const u64 m = __ballot(live);
+        uint32_t wbase = 0;
+        if (hlane() == 0 && m) wbase = atomicAdd(&cnt[pass], (uint32_t)__popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (pass == 1 && live) {
+          const uint32_t g = gbase + wbase + (uint32_t)__popcll(m & ((1ull << hlane()) - 1));
+          if (g >= (uint32_t)out.cap) atomicOr(P.flags, FLAG_GROUP_OVERFLOW);
+          else {
+            int w = 0;
+            for (int k = 0; k < K.n_keys; ++k) {
+              const u64 lo = slot[1 + w]; ++w;
+              u64 hi = (u64)((i64)lo >> 63);
+              if (K.key_wide[k]) { hi = slot[1 + w]; ++w; }
+              out.keys[((size_t)g * kstride + k) * 2] = lo; out.keys[((size_t)g * kstride + k) * 2 + 1] = hi;
+            }
+            out.key_nulls[g] = K.null_word ? (uint32_t)slot[1 + w] : 0u;
+            for (int a = 0; a < A.n_accs; ++a) {
+              u64 lo = slot[cell0 + 2 * a], hi = slot[cell0 + 2 * a + 1];
+              const int kind = A.acc_kind[a];
+              if (kind == ACC_MIN || kind == ACC_MAX) hi = (u64)((i64)lo >> 63);
+              out.cells[((size_t)g * A.n_accs + a) * 2] = lo; out.cells[((size_t)g * A.n_accs + a) * 2 + 1] = hi;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (pass == 0) {
+        if (threadIdx.x == 0) gbase = atomicAdd(out.n_groups, cnt[0]);
+        __syncthreads();
+      }
+    }
+  }
+}
+#ifndef GPUQ_JIT
+template <int MAXC>
+__global__ void __launch_bounds__(HBLOCK) k_agg_bucket(const DevProgram P, const KeySpec K, const AggSpec A, const uint32_t* __restrict__ ids,
+                                                       const uint32_t* __restrict__ bounds, const uint32_t nbuckets, const uint32_t cap, const int slot_words,
+                                                       const AggOut out) { k_agg_bucket_body<MAXC>(P, K, A, ids, bounds, nbuckets, cap, slot_words, out); }
+#elif GPUQ_JIT_KERNEL == 12
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const KeySpec K, const AggSpec A, const uint32_t* __restrict__ ids,
+                                                       const uint32_t* __restrict__ bounds, const uint32_t nbuckets, const uint32_t cap, const int slot_words,
+                                                       const AggOut out) { k_agg_bucket_body<0>(P, K, A, ids, bounds, nbuckets, cap, slot_words, out); }
+#endif
+
 // ------------------------------------------------------------------ join build
 template <int MAXC>
 __device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
@@ -686,6 +896,32 @@ void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, 
   const u64 cap = (u64)num_cus() * 16;
   const int grid = (int)(need < cap ? (need ? need : 1) : cap);
   hipLaunchKernelGGL(k_agg_hash_extract, dim3(grid), dim3(HBLOCK), 0, s, K, A, T, out, flags);
+}
+void launch_agg_bucket_id(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, u64 bucket_mask, u64* bid, uint32_t* ids) {
+  if (n <= 0) return;
+  if (jit_override().fn && jit_override().kernel_id == 11) {
+    (void)jit_launch(jit_override().fn, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, bucket_mask, bid, ids);
+  } else {
+#define CALL(M) hipLaunchKernelGGL(k_agg_bucket_id<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, bucket_mask, bid, ids)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
+  }
+}
+void launch_bucket_bounds(hipStream_t s, const u64* sorted_bid, i64 n, u64 nbuckets, uint32_t* bounds) {
+  const u64 need = (nbuckets + 1 + HBLOCK - 1) / HBLOCK;
+  hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)(need < 4096 ? need : 4096)), dim3(HBLOCK), 0, s, sorted_bid, n, nbuckets, bounds);
+}
+void launch_agg_bucket(hipStream_t s, const DevProgram& P, const KeySpec& K, const AggSpec& A, const uint32_t* ids, const uint32_t* bounds, uint32_t nbuckets,
+                       uint32_t cap, int slot_words, const AggOut& out) {
+  const size_t lds = (size_t)cap * slot_words * 8;
+  u64 grid = nbuckets; const u64 gcap = (u64)num_cus() * 8; if (grid > gcap) grid = gcap; if (grid < 1) grid = 1;
+  if (jit_override().fn && jit_override().kernel_id == 12) {
+    (void)jit_launch(jit_override().fn, dim3((unsigned)grid), dim3(HBLOCK), lds, s, P, K, A, ids, bounds, nbuckets, cap, slot_words, out);
+  } else {
+#define CALL(M) hipLaunchKernelGGL(k_agg_bucket<M>, dim3((unsigned)grid), dim3(HBLOCK), lds, s, P, K, A, ids, bounds, nbuckets, cap, slot_words, out)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
+  }
 }
 void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
                        int payload_via, int null_equals_null) {

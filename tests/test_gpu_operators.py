@@ -164,6 +164,39 @@ def test_aggregate_single(tc, n, nulls):
         close_rows(got, exp)
 
 
+@pytest.mark.parametrize("nulls", [0.0, 0.15])
+@pytest.mark.parametrize("n", [0, 1, 700, 60_000])
+def test_aggregate_radix_strategy(tc, n, nulls):
+    """The radix-partitioned, LDS-resident aggregate (high-cardinality path) on every aggregate shape, forced at small sizes:
+    several buckets, string and multi-column keys, NULL keys, all accumulator kinds, a fused predicate."""
+    t = rand_table(4100 + n, n, nulls)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    pred = binary(col("k32", s), Op.Gt, lit(-30, "Int32"))
+    for groups, aggs in agg_cases(s):
+        if not groups:
+            continue                       # ungrouped aggregates always take the LDS kernel
+        plan = g.AggregateExec("Single", groups, aggs, g.FilterExec(pred, src), strategy="radix", expected_groups=max(1, n // 3))
+        got = norm(dev_rows(tc, plan.execute(0, tc)))
+        exp = norm(ora_rows(O.aggregate(ot, groups, aggs, "Single", predicate=pred)))
+        close_rows(got, exp)
+        close_rows(norm(native_rows_of(tc, plan)), exp)          # float sums: atomic order differs run to run
+
+
+def native_rows_of(tc, plan):
+    t = g.NativePlan(plan, tc).execute(0).to_arrow()
+    cols = []
+    for f, c in zip(t.schema, t.columns):
+        if pa.types.is_decimal128(f.type):
+            cols.append([None if v is None else int(v.scaleb(f.type.scale)) for v in c.to_pylist()])
+        elif pa.types.is_date32(f.type):
+            cols.append(c.cast(pa.int32()).to_pylist())
+        else:
+            cols.append(c.to_pylist())
+    return list(zip(*cols)) if cols else []
+
+
 @pytest.mark.parametrize("strategy", ["tiny", "hash"])
 def test_aggregate_partial_final_and_strategies(tc, strategy):
     parts = [rand_table(7 + i, 20_000, 0.1) for i in range(3)]

@@ -30,3 +30,6 @@ rev=binary(col("l_extendedprice",s),Op.Multiply,binary(lit(1,("Decimal128",20,0)
 agg=g.AggregateExec("Single",[(col("l_orderkey",s),"k")],[{"fn":"SUM","expr":rev,"name":"rev"}],g.MemoryExec([li]),strategy="hash",expected_groups=n//4)
 ms,r=timeit(lambda: agg.execute(0,tc))
 print("hash aggregate %d rows -> %d groups: %.2f ms  %.2f Grows/s"%(n,r.num_rows,ms,n/ms/1e6))
+agg2=g.AggregateExec("Single",[(col("l_orderkey",s),"k")],[{"fn":"SUM","expr":rev,"name":"rev"}],g.MemoryExec([li]),strategy="radix",expected_groups=n//4)
+ms,r=timeit(lambda: agg2.execute(0,tc))
+print("radix aggregate %d rows -> %d groups: %.2f ms  %.2f Grows/s"%(n,r.num_rows,ms,n/ms/1e6))
