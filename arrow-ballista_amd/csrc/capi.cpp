@@ -854,7 +854,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
       uint32_t capslots = 64; while ((size_t)capslots * 2 * slot_words * 8 <= 60 * 1024) capslots *= 2;
       if ((size_t)capslots * slot_words * 8 <= 60 * 1024 && n < (1ll << 31)) {
         const u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (u64)n;
-        const u64 per_bucket = std::max<u64>(1, (u64)capslots * 3 / 8);          // load factor <= 0.5 with headroom for uneven buckets
+        const u64 per_bucket = std::max<u64>(1, (u64)capslots / 2);             // mean load 0.5: buckets are Poisson-even (hash bits), sqrt(mean) of spread
         u64 nbk = next_pow2(std::max<u64>(1, (est + per_bucket - 1) / per_bucket)); if (nbk > (1ull << 24)) nbk = 1ull << 24;
         int bits = 0; while ((1ull << bits) < nbk) ++bits;
         DevBuf b_bid, b_bid2, b_ids, b_ids2, b_hist, b_scan, b_bounds;

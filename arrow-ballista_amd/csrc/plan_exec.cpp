@@ -458,6 +458,7 @@ struct AggregateExec : PNode {
     return jobj(d);
     });
     int64_t cap = output_capacity > 0 ? output_capacity : (group_expr.a.empty() ? 4096 : std::max<int64_t>(4096, std::min<int64_t>(t.n, 1ll << 22)));
+    if (output_capacity <= 0 && expected_groups > 0) cap = std::max<int64_t>(cap, std::min<int64_t>(t.n, expected_groups + expected_groups / 4));   // a too-small capacity costs a second run
     InputC ic; make_input(t, ic);
     for (;;) {
       std::vector<gpuq_column> carr;

@@ -524,6 +524,9 @@ def aggregate_table(tc, table, descriptor, cap=None, op=None):
     n = table.num_rows
     if cap is None:
         cap = 4096 if not descriptor["group_expr"] else max(4096, min(n, 1 << 22))
+        eg = int(descriptor.get("expected_groups", 0) or 0)
+        if eg > 0:          # a cardinality hint also sizes the output: a too-small capacity costs a second run of the aggregate
+            cap = max(cap, min(n, eg + eg // 4))
     inp, keep = table.input_struct()
     while True:
         cols, arr, buf = _alloc_outputs(op, cap, tc.device)
