@@ -1209,7 +1209,7 @@ int gpuq_take_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const ui
     if (total > data_cap) throw Capacity("utf8 data needs " + std::to_string(total) + " bytes");
     if (total > 0) {
       if (!data_out) throw std::runtime_error("data_out is NULL");
-      launch_take_utf8_bytes(s, (const uint8_t*)col->data, col->offsets, idx, n, offsets_out, data_out);
+      launch_take_utf8_bytes(s, (const uint8_t*)col->data, col->offsets, idx, n, offsets_out, data_out, (i64)total);
     }
     HIPCHECK(hipGetLastError());
   });

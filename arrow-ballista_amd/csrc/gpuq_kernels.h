@@ -144,7 +144,7 @@ void launch_concat_bitmap(hipStream_t s, u64* dst, i64 dst_bit_offset, const uin
 void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out, uint32_t* too_long);
 void launch_offsets_rebase(hipStream_t s, const int32_t* src, i64 n, int32_t delta, int32_t* dst);
 void launch_take_utf8_lengths(hipStream_t s, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int32_t* lens, u64* valid_out);
-void launch_take_utf8_bytes(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint32_t* idx, i64 n, const int32_t* out_offsets, uint8_t* out);
+void launch_take_utf8_bytes(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint32_t* idx, i64 n, const int32_t* out_offsets, uint8_t* out, i64 total_bytes);
 void launch_unpack_utf8_bytes(hipStream_t s, const ulonglong2* packed, i64 n, const int32_t* offsets, uint8_t* data_out);
 void launch_exclusive_scan_i32(hipStream_t s, int32_t* data, i64 n, void* workspace, size_t ws_bytes);   // in place, n+1 entries out
 size_t exclusive_scan_ws_bytes(i64 n);

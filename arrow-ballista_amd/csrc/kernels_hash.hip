@@ -693,7 +693,10 @@ __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, con
                                                               const int join_type, const int null_eq, uint32_t* __restrict__ match,
                                                               u64* __restrict__ bitmap, uint32_t* __restrict__ block_counts, const i64 wpb,
                                                               uint32_t* __restrict__ visited) {
-  constexpr int U = 4;
+#ifndef GPUQ_PROBE_ROWS
+#define GPUQ_PROBE_ROWS 4
+#endif
+  constexpr int U = GPUQ_PROBE_ROWS;
   __shared__ uint32_t wave_cnt[HWAVES];
   const i64 nwords = (n + 63) >> 6;
   const i64 w0 = (i64)blockIdx.x * wpb;

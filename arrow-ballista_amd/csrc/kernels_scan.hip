@@ -820,6 +820,17 @@ __global__ void __launch_bounds__(BLOCK) k_take_utf8_bytes(const uint8_t* __rest
     for (int32_t k = lane_id(); k < len; k += 64) out[o0 + k] = src[k];
   }
 }
+// short strings (names, flags: a few bytes each): one lane per string -- a whole wave per 8-byte string leaves 56 lanes idle
+__global__ void __launch_bounds__(BLOCK) k_take_utf8_bytes_short(const uint8_t* __restrict__ data, const int32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
+                                                                 const i64 n, const int32_t* __restrict__ out_offsets, uint8_t* __restrict__ out) {
+  for (i64 j = (i64)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (i64)gridDim.x * BLOCK) {
+    const int32_t o0 = out_offsets[j], len = out_offsets[j + 1] - o0;
+    if (len <= 0) continue;
+    const uint32_t r = idx ? idx[j] : (uint32_t)j;
+    const uint8_t* src = data + offsets[r];
+    for (int32_t k = 0; k < len; ++k) out[o0 + k] = src[k];
+  }
+}
 #endif
 
 // Exclusive scan of int32 lengths into offsets (n+1 entries, in place): three-kernel
@@ -993,8 +1004,12 @@ void launch_offsets_rebase(hipStream_t s, const int32_t* src, i64 n, int32_t del
 void launch_take_utf8_lengths(hipStream_t s, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int32_t* lens, u64* valid_out) {
   if (n > 0) hipLaunchKernelGGL(k_take_utf8_lengths, dim3(grid_for(n, 8)), dim3(BLOCK), 0, s, offsets, validity, idx, n, lens, valid_out);
 }
-void launch_take_utf8_bytes(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint32_t* idx, i64 n, const int32_t* out_offsets, uint8_t* out) {
+void launch_take_utf8_bytes(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint32_t* idx, i64 n, const int32_t* out_offsets, uint8_t* out, i64 total_bytes) {
   if (n <= 0) return;
+  if (total_bytes <= n * 24) {       // average string of <= 24 bytes
+    hipLaunchKernelGGL(k_take_utf8_bytes_short, dim3(lin_grid(n)), dim3(BLOCK), 0, s, data, offsets, idx, n, out_offsets, out);
+    return;
+  }
   i64 need = (n + WAVES - 1) / WAVES; const i64 cap = (i64)g_num_cus * 16; if (need < 1) need = 1;
   hipLaunchKernelGGL(k_take_utf8_bytes, dim3((int)(need < cap ? need : cap)), dim3(BLOCK), 0, s, data, offsets, idx, n, out_offsets, out);
 }
