@@ -124,6 +124,14 @@ def lib():
         "gpuq_result_column": (i32, [vp, i32, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info)]),
         "gpuq_result_free": (None, [vp]),
         "gpuq_result_record": (i32, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(i64)]),
+        "gpuq_ipc_peek": (i32, [vp, i64, vp]),
+        "gpuq_ipc_encode_batch": (i32, [vp, vp, C.POINTER(gpuq_column), i32, i64, i32, vp, i64, C.POINTER(i64)]),
+        "gpuq_ipc_decode_batch": (i32, [vp, vp, vp, i64, C.POINTER(gpuq_field_info), i32, C.POINTER(vp)]),
+        "gpuq_ipc_batch_num_rows": (i64, [vp]),
+        "gpuq_ipc_batch_num_columns": (i32, [vp]),
+        "gpuq_ipc_batch_column": (i32, [vp, i32, C.POINTER(gpuq_column)]),
+        "gpuq_ipc_batch_free": (None, [vp]),
+        "gpuq_ipc_last_error": (C.c_char_p, []),
         "gpuq_gen_lineitem": (i32, [vp, vp, u64, u64, i64, i64, i64, C.POINTER(gpuq_lineitem_cols)]),
         "gpuq_gen_orders": (i32, [vp, vp, u64, i64, i64, i64, C.POINTER(gpuq_orders_cols)]),
         "gpuq_gen_customer": (i32, [vp, vp, u64, i64, i64, C.POINTER(gpuq_customer_cols)]),

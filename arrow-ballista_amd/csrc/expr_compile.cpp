@@ -283,6 +283,20 @@ NodeP ExprCompiler::binary(const std::string& op_in, NodeP l, NodeP r) {
       const int o = (a->bits <= 63 && b->bits <= 63) ? OP_MULW : OP_MUL;
       return raw(o, rt, nullable, a->bits + b->bits, {a, b});
     }
+    // arrow-arith 49 numeric.rs decimal_op [UPSTREAM-KNOWLEDGE]: Div -> scale s1+4, precision p1+(4+s2), l*10^(4+s2) / r
+    // truncated toward zero; Rem -> scale max(s1,s2), precision min(p1-s1,p2-s2)+scale.  x/0 -> NULL (see the integer case).
+    if (op == "/") {
+      const int rs = std::min(38, dl.s + 4), k = rs - dl.s + dr.s;
+      NodeP a = rescale(l, dl.s + k), b = rescale(r, dr.s);
+      if (a->bits > 127) throw std::runtime_error("decimal division " + l->type.to_string() + " / " + r->type.to_string() + " can overflow 128 bits on device");
+      return raw(OP_DIV, dec_type(std::min(38, dl.p + k), rs), true, a->bits, {a, b});
+    }
+    if (op == "%") {
+      const int s = std::max(dl.s, dr.s);
+      NodeP a = rescale(l, s), b = rescale(r, s);
+      if (a->bits > 127 || b->bits > 127) throw std::runtime_error("decimal modulo operands can overflow 128 bits on device");
+      return raw(OP_MOD, dec_type(std::min(38, std::min(dl.p - dl.s, dr.p - dr.s) + s), s), true, b->bits, {a, b});
+    }
     throw std::runtime_error("decimal operator '" + op + "' is not supported on device yet");
   }
   if ((l->type.is_int() || l->type.id == T_DATE32) && (r->type.is_int() || r->type.id == T_DATE32)) {

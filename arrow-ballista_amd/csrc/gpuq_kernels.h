@@ -148,6 +148,20 @@ void launch_take_utf8_bytes(hipStream_t s, const uint8_t* data, const int32_t* o
 void launch_unpack_utf8_bytes(hipStream_t s, const ulonglong2* packed, i64 n, const int32_t* offsets, uint8_t* data_out);
 void launch_exclusive_scan_i32(hipStream_t s, int32_t* data, i64 n, void* workspace, size_t ws_bytes);   // in place, n+1 entries out
 size_t exclusive_scan_ws_bytes(i64 n);
+// ----- LZ4 block codec (shuffle sink / source, kernels_lz4.hip)
+struct Lz4Block { int64_t src; int64_t slot; int32_t len; int32_t pad; };     // compress: one <= 64 KiB input block and its worst-case output slot
+constexpr int LZ4_UNIT_BLOCK = 0, LZ4_UNIT_STORED = 1, LZ4_UNIT_FRAME_BLOCKS = 2;
+constexpr int LZ4_UNIT_BLOCK_CHECKSUM = 1;
+struct Lz4Unit { int64_t src, dst, src_len, dst_len; int32_t mode, flags; };  // decompress: one independent block, or the blocks of one linked frame
+constexpr int64_t LZ4_BLOCK_BYTES = 65536;
+inline int64_t lz4_slot_bytes(int64_t len) { return ((len + len / 255 + 16) + 15) & ~(int64_t)15; }
+void launch_lz4_compress(hipStream_t s, const uint8_t* src, uint8_t* slots, const Lz4Block* blocks, int n_blocks, int32_t* csize);
+void launch_lz4_layout(hipStream_t s, const Lz4Block* blocks, const int32_t* csize, const int32_t* buf_first_block, int n_buffers, int64_t* buf_off, int64_t* buf_len,
+                       int64_t* blk_dst);
+void launch_lz4_pack(hipStream_t s, const uint8_t* src, const uint8_t* slots, const Lz4Block* blocks, int n_blocks, const int32_t* csize, const int32_t* blk_buffer,
+                     const int32_t* buf_first_block, const int64_t* buf_off, const int64_t* buf_len, const int64_t* blk_dst, uint8_t* body);
+void launch_lz4_decode(hipStream_t s, const uint8_t* src, int64_t src_bytes, uint8_t* dst, const Lz4Unit* units, int n_units, uint32_t* status);
+void launch_popcount_bits(hipStream_t s, const uint8_t* bits, int64_t n_bits, unsigned long long* out);
 void launch_gen_lineitem(hipStream_t s, u64 seed, u64 seed_orders, i64 row0, i64 n, i64 n_supp, const LineitemCols& c);
 void launch_gen_orders(hipStream_t s, u64 seed, i64 row0, i64 n, i64 n_cust, const OrdersCols& c);
 void launch_gen_customer(hipStream_t s, u64 seed, i64 row0, i64 n, const CustomerCols& c);

@@ -1,0 +1,332 @@
+// LZ4 block codec for the shuffle sink / source: the reference writes its shuffle partitions as Arrow
+// IPC streams whose buffers are LZ4 frames (ballista/core/src/execution_plans/shuffle_writer.rs:365-378,
+// ballista/core/src/utils.rs:179-219; the codec itself is the `lz4_flex` crate behind arrow-ipc 49 -- not in the tree, the
+// format is the public LZ4 block / frame specification).  One WAVE per unit of independent work:
+//   * compress: one 64 KiB block (frames are written with independent blocks, so every block is a unit);
+//   * decompress: one independent block, or one whole frame with linked blocks (what Arrow C++ writes).
+// Everything is byte / integer work bound by dependent-latency chains, not by MFMA or even HBM; the parallelism is across
+// blocks (a 1 GB shuffle partition has 16 Ki of them).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+#include "gpuq_kernels.h"
+
+namespace gpuq {
+
+typedef unsigned long long u64;
+
+constexpr int LZ4_HASH_BITS = 12;
+constexpr int LZ4_MFLIMIT = 12;        // a match must start at least 12 bytes before the end of the block
+constexpr int LZ4_LASTLITERALS = 5;    // the last 5 bytes of a block are literals
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// n bytes, all lanes of the wave; src and dst do not overlap
+__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, int n) {
+  const int lane = lane_id();
+  if (n >= 512) {           // long runs: 4 bytes per lane through unaligned dword loads, stores aligned after a byte head
+    const int head = (int)((4 - ((uintptr_t)dst & 3)) & 3);
+    if (lane < head) dst[lane] = src[lane];
+    const int words = (n - head) >> 2;
+    for (int w = lane; w < words; w += 64) *(uint32_t*)(dst + head + 4 * w) = ld32u(src + head + 4 * w);
+    const int done = head + 4 * words;
+    if (lane < n - done) dst[done + lane] = src[done + lane];
+    return;
+  }
+  for (int i = lane; i < n; i += 64) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------- compress
+// length field continuation: v >= 15 -> bytes of 255 then the remainder
+__device__ __forceinline__ int put_len_ext(uint8_t* out, int o, int v /* value - 15, >= 0 */) {
+  const int nb = v / 255 + 1, lane = lane_id();
+  for (int i = lane; i < nb; i += 64) out[o + i] = (uint8_t)((i < nb - 1) ? 255 : (v % 255));
+  return o + nb;
+}
+
+__global__ __launch_bounds__(64) void k_lz4_compress(const uint8_t* __restrict__ src_base, uint8_t* __restrict__ dst_base, const Lz4Block* __restrict__ blocks,
+                                                     int n_blocks, int32_t* __restrict__ csize_out) {
+  __shared__ uint16_t ht[1 << LZ4_HASH_BITS];
+  const int b = (int)blockIdx.x;
+  if (b >= n_blocks) return;
+  const int lane = lane_id();
+  const uint8_t* src = src_base + blocks[b].src;
+  uint8_t* out = dst_base + blocks[b].slot;
+  const int len = blocks[b].len;
+  for (int i = lane; i < (1 << LZ4_HASH_BITS); i += 64) ht[i] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  int o = 0, anchor = 0;
+  const int mlast = len - LZ4_MFLIMIT;            // last position a match may start at
+  const int mend = len - LZ4_LASTLITERALS;        // matches end at or before this
+  int base = 1;                                    // position 0 can never be a match start's candidate target < p anyway
+  int cur = 0;                                     // first position not yet covered by an emitted sequence
+  while (base <= mlast) {
+    const int p = base + lane;
+    const bool valid = p <= mlast;
+    const uint32_t v = valid ? ld32u(src + p) : 0u;
+    const uint32_t h = (v * 2654435761u) >> (32 - LZ4_HASH_BITS);
+    int cand = valid ? (int)ht[h] : 0;
+    bool ok = valid && cand < p && ld32u(src + cand) == v;
+    // columnar data repeats with the period of its element width: look there before giving up (the hash table only
+    // knows positions of EARLIER windows)
+    if (__ballot(valid && !ok)) {
+#pragma unroll
+      for (int k = 16; k >= 1; k >>= 1) {
+        if (k == 2) continue;
+        if (valid && !ok && p >= k && ld32u(src + p - k) == v) { ok = true; cand = p - k; }
+      }
+    }
+    if (valid) ht[h] = (uint16_t)p;
+    u64 m = __ballot(ok);
+    while (m) {
+      const int L = __builtin_ctzll(m);
+      const int pL = base + L;
+      if (pL < cur) { m &= m - 1; continue; }
+      const int cL = __builtin_amdgcn_readlane(cand, L);
+      // extend: 4 bytes per lane, 256 per round
+      int mlen = 4;
+      {
+        const int limit = mend - (pL + 4);          // bytes that may still be added
+        int done = 0;
+        while (done < limit) {
+          const int off = done + 4 * lane;
+          const int rem = limit - off;               // bytes this lane may compare (<=0: none)
+          uint32_t x = 0; bool stop = rem < 4;
+          if (rem > 0) {
+            x = ld32u(src + pL + 4 + off) ^ ld32u(src + cL + 4 + off);
+            if (rem < 4) x |= 0xFFFFFFFFu << (8 * rem);   // bytes past the limit count as mismatches
+          } else x = 0xFFFFFFFFu;
+          stop = x != 0;
+          const u64 sm = __ballot(stop);
+          if (sm) {
+            const int S = __builtin_ctzll(sm);
+            const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)x, S);
+            done += 4 * S + (__builtin_ctz(xs) >> 3);
+            break;
+          }
+          done += 256;
+        }
+        if (done > limit) done = limit;
+        if (done < 0) done = 0;
+        mlen += done;
+      }
+      // emit: token, literal length, literals, offset, match length
+      const int lit = pL - anchor, ml = mlen - 4;
+      if (lane == 0) out[o] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (ml < 15 ? ml : 15));
+      o += 1;
+      if (lit >= 15) o = put_len_ext(out, o, lit - 15);
+      wave_copy(out + o, src + anchor, lit);
+      o += lit;
+      if (lane == 0) { const int d = pL - cL; out[o] = (uint8_t)d; out[o + 1] = (uint8_t)(d >> 8); }
+      o += 2;
+      if (ml >= 15) o = put_len_ext(out, o, ml - 15);
+      cur = pL + mlen; anchor = cur;
+      const int rel = cur - base;
+      m = rel >= 64 ? 0ull : (m & ~((1ull << rel) - 1ull));
+    }
+    base = (base + 64 > cur) ? base + 64 : cur;
+  }
+  // last sequence: literals only
+  {
+    const int lit = len - anchor;
+    if (lane == 0) out[o] = (uint8_t)((lit < 15 ? lit : 15) << 4);
+    o += 1;
+    if (lit >= 15) o = put_len_ext(out, o, lit - 15);
+    wave_copy(out + o, src + anchor, lit);
+    o += lit;
+  }
+  if (lane == 0) csize_out[b] = o;
+}
+
+// ---------------------------------------------------------------- frame layout + pack
+// frame = [u64 uncompressed length][magic FLG BD HC][u32 block size | data]...[u32 0]; a block that did not shrink is stored raw
+// with bit 31 of its size set.  A buffer whose frame would not be smaller than the data is written as [-1][raw bytes]
+// (arrow-ipc's LENGTH_NO_COMPRESSED_DATA); an empty buffer has no bytes at all.
+__global__ void k_lz4_layout(const Lz4Block* __restrict__ blocks, const int32_t* __restrict__ csize, const int32_t* __restrict__ buf_first_block /* n_buffers+1 */,
+                             int n_buffers, int64_t* __restrict__ buf_off /* n_buffers+1: body offsets, 8-aligned; [n] = body length */,
+                             int64_t* __restrict__ buf_len /* n_buffers */, int64_t* __restrict__ blk_dst /* per block: body offset of its 4-byte header, <0: buffer stored raw */) {
+  // pass 1: each thread sizes one buffer
+  for (int b = (int)threadIdx.x; b < n_buffers; b += (int)blockDim.x) {
+    const int f = buf_first_block[b], l = buf_first_block[b + 1];
+    int64_t raw = 0, fr = 8 + 7 + 4;
+    for (int k = f; k < l; ++k) { raw += blocks[k].len; fr += 4 + (csize[k] < blocks[k].len ? csize[k] : blocks[k].len); }
+    buf_len[b] = (raw == 0) ? 0 : (fr < raw + 8 ? fr : -(raw + 8));     // negative: stored raw
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t off = 0;
+    for (int b = 0; b < n_buffers; ++b) { buf_off[b] = off; const int64_t l = buf_len[b] < 0 ? -buf_len[b] : buf_len[b]; off += (l + 7) & ~(int64_t)7; }
+    buf_off[n_buffers] = off;
+  }
+  __syncthreads();
+  for (int b = (int)threadIdx.x; b < n_buffers; b += (int)blockDim.x) {
+    const int f = buf_first_block[b], l = buf_first_block[b + 1];
+    if (buf_len[b] < 0) {
+      int64_t pos = buf_off[b] + 8;
+      for (int k = f; k < l; ++k) { blk_dst[k] = -(pos + 1); pos += blocks[k].len; }     // raw: -(destination of the bytes + 1)
+    } else {
+      int64_t pos = buf_off[b] + 8 + 7;
+      for (int k = f; k < l; ++k) { blk_dst[k] = pos; pos += 4 + (csize[k] < blocks[k].len ? csize[k] : blocks[k].len); }
+    }
+  }
+}
+
+__device__ __forceinline__ void block_copy(uint8_t* dst, const uint8_t* src, int n) {
+  const int t = (int)threadIdx.x, T = (int)blockDim.x;
+  const int head = (int)((4 - ((uintptr_t)dst & 3)) & 3) < n ? (int)((4 - ((uintptr_t)dst & 3)) & 3) : n;
+  if (t < head) dst[t] = src[t];
+  const int words = (n - head) >> 2;
+  for (int w = t; w < words; w += T) *(uint32_t*)(dst + head + 4 * w) = ld32u(src + head + 4 * w);
+  const int done = head + 4 * words;
+  if (t < n - done) dst[done + t] = src[done + t];
+}
+
+__global__ __launch_bounds__(256) void k_lz4_pack(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ slots, const Lz4Block* __restrict__ blocks,
+                                                  const int32_t* __restrict__ csize, const int32_t* __restrict__ blk_buffer, const int32_t* __restrict__ buf_first_block,
+                                                  const int64_t* __restrict__ buf_off, const int64_t* __restrict__ buf_len, const int64_t* __restrict__ blk_dst,
+                                                  uint8_t* __restrict__ body) {
+  const int k = (int)blockIdx.x, t = (int)threadIdx.x;
+  const int b = blk_buffer[k];
+  const bool first = buf_first_block[b] == k, last = buf_first_block[b + 1] == k + 1;
+  const int len = blocks[k].len;
+  const int64_t bl = buf_len[b];
+  const int64_t total = bl < 0 ? -bl : bl;
+  uint8_t* const bufp = body + buf_off[b];
+  if (first && t < 8) {
+    int64_t raw = 0;
+    if (bl < 0) raw = -1; else for (int j = buf_first_block[b]; j < buf_first_block[b + 1]; ++j) raw += blocks[j].len;
+    bufp[t] = (uint8_t)((u64)raw >> (8 * t));
+  }
+  if (last) { const int64_t padded = (total + 7) & ~(int64_t)7; if (t < (int)(padded - total)) bufp[total + t] = 0; }
+  if (bl < 0) { block_copy(body + (-blk_dst[k] - 1), src_base + blocks[k].src, len); return; }
+  if (first && t == 0) { uint8_t* h = bufp + 8; h[0] = 0x04; h[1] = 0x22; h[2] = 0x4D; h[3] = 0x18; h[4] = 0x60; h[5] = 0x40; h[6] = 0x82; }
+  uint8_t* d = body + blk_dst[k];
+  const int cs = csize[k];
+  const bool stored = cs >= len;
+  const uint32_t hdr = stored ? ((uint32_t)len | 0x80000000u) : (uint32_t)cs;
+  if (t < 4) d[t] = (uint8_t)(hdr >> (8 * t));
+  block_copy(d + 4, stored ? src_base + blocks[k].src : slots + blocks[k].slot, stored ? len : cs);
+  if (last && t < 4) d[4 + (stored ? len : cs) + t] = 0;      // EndMark
+}
+
+// ---------------------------------------------------------------- decompress
+struct InWin {      // 256-byte window of the compressed stream held in registers (one dword per lane)
+  const uint32_t* base; int64_t w0; int64_t wend; uint32_t w;
+};
+__device__ __forceinline__ void win_load(InWin& W, int64_t dw) {
+  W.w0 = dw;
+  const int64_t i = dw + lane_id();
+  W.w = (i < W.wend) ? W.base[i] : 0u;
+}
+__device__ __forceinline__ int win_byte(InWin& W, int64_t a /* byte address relative to W.base */) {
+  const int64_t dw = a >> 2;
+  if (dw < W.w0 || dw >= W.w0 + 64) win_load(W, dw);
+  const int l = rfl((int)(dw - W.w0));
+  return (int)((((uint32_t)__builtin_amdgcn_readlane((int)W.w, l)) >> (8 * (int)(a & 3))) & 0xFF);
+}
+
+// one LZ4 block: in [ip, iend) -> out at op; returns the new op or -1 on a malformed stream
+__device__ __forceinline__ int64_t lz4_decode_block(InWin& W, const uint8_t* in8, int64_t ip, int64_t iend, uint8_t* out, int64_t op, int64_t out_lo, int64_t out_hi) {
+  const int lane = lane_id();
+  while (ip < iend) {
+    const int token = win_byte(W, ip); ip += 1;
+    int lit = token >> 4;
+    if (lit == 15) { int x; do { if (ip >= iend) return -1; x = win_byte(W, ip); ip += 1; lit += x; } while (x == 255); }
+    if (lit > iend - ip || lit > out_hi - op) return -1;
+    if (lit) { wave_copy(out + op, in8 + ip, lit); ip += lit; op += lit; }
+    if (ip >= iend) break;                            // the last sequence has no match
+    if (ip + 2 > iend) return -1;
+    const int offset = win_byte(W, ip) | (win_byte(W, ip + 1) << 8); ip += 2;
+    int ml = token & 15;
+    if (ml == 15) { int x; do { if (ip >= iend) return -1; x = win_byte(W, ip); ip += 1; ml += x; } while (x == 255); }
+    ml += 4;
+    if (offset == 0 || offset > op - out_lo || ml > out_hi - op) return -1;
+    // the source lies entirely before op (bytes of a period shorter than the match repeat): every byte is independent
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const uint8_t* s = out + op - offset;
+    if (offset >= ml) { for (int i = lane; i < ml; i += 64) out[op + i] = s[i]; }
+    else { for (int i = lane; i < ml; i += 64) out[op + i] = s[i % offset]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    op += ml;
+  }
+  return op;
+}
+
+__global__ __launch_bounds__(64) void k_lz4_decode(const uint8_t* __restrict__ src_base, uint8_t* dst_base, const Lz4Unit* __restrict__ units, int n_units,
+                                                   int64_t src_bytes, uint32_t* __restrict__ status) {
+  const int u = (int)blockIdx.x;
+  if (u >= n_units) return;
+  const Lz4Unit U = units[u];
+  InWin W; W.base = (const uint32_t*)src_base; W.wend = (src_bytes + 3) >> 2; W.w0 = -1000; W.w = 0;
+  uint8_t* out = dst_base + U.dst;
+  bool bad = false;
+  if (U.mode == LZ4_UNIT_BLOCK) {
+    const int64_t end = lz4_decode_block(W, src_base, U.src, U.src + U.src_len, out, 0, 0, U.dst_len);
+    bad = end != U.dst_len;
+  } else if (U.mode == LZ4_UNIT_STORED) {
+    if (U.src_len != U.dst_len) bad = true; else wave_copy(out, src_base + U.src, (int)U.dst_len);
+  } else {      // LZ4_UNIT_FRAME_BLOCKS: walk the block headers of one frame (linked blocks: matches reach into earlier blocks)
+    int64_t ip = U.src, op = 0;
+    const int64_t iend = U.src + U.src_len;
+    while (true) {
+      if (ip + 4 > iend) { bad = true; break; }
+      const uint32_t hdr = (uint32_t)win_byte(W, ip) | ((uint32_t)win_byte(W, ip + 1) << 8) | ((uint32_t)win_byte(W, ip + 2) << 16) | ((uint32_t)win_byte(W, ip + 3) << 24);
+      ip += 4;
+      if (hdr == 0) break;                                         // EndMark
+      const int64_t bs = (int64_t)(hdr & 0x7FFFFFFFu);
+      if (bs > iend - ip) { bad = true; break; }
+      if (hdr & 0x80000000u) {
+        if (bs > U.dst_len - op) { bad = true; break; }
+        wave_copy(out + op, src_base + ip, (int)bs); op += bs;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      } else {
+        // the window a match may reach back into is the 64 KiB before op, across block boundaries
+        op = lz4_decode_block(W, src_base, ip, ip + bs, out, op, 0, U.dst_len);
+        if (op < 0) { bad = true; break; }
+      }
+      ip += bs + ((U.flags & LZ4_UNIT_BLOCK_CHECKSUM) ? 4 : 0);
+    }
+    if (!bad && op != U.dst_len) bad = true;
+  }
+  if (bad && lane_id() == 0) atomicOr(status, 1u);
+}
+
+__global__ void k_popcount_bits(const u64* __restrict__ bits, int64_t n_bits, unsigned long long* __restrict__ out) {
+  const int64_t words = (n_bits + 63) >> 6;
+  unsigned long long c = 0;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x) {
+    u64 x = bits[w];
+    if (w == words - 1 && (n_bits & 63)) x &= (1ull << (n_bits & 63)) - 1ull;
+    c += (unsigned long long)__popcll(x);
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// ---------------------------------------------------------------- launchers
+void launch_lz4_compress(hipStream_t s, const uint8_t* src, uint8_t* slots, const Lz4Block* blocks, int n_blocks, int32_t* csize) {
+  if (n_blocks > 0) hipLaunchKernelGGL(k_lz4_compress, dim3((unsigned)n_blocks), dim3(64), 0, s, src, slots, blocks, n_blocks, csize);
+}
+void launch_lz4_layout(hipStream_t s, const Lz4Block* blocks, const int32_t* csize, const int32_t* buf_first_block, int n_buffers, int64_t* buf_off, int64_t* buf_len,
+                       int64_t* blk_dst) {
+  hipLaunchKernelGGL(k_lz4_layout, dim3(1), dim3(256), 0, s, blocks, csize, buf_first_block, n_buffers, buf_off, buf_len, blk_dst);
+}
+void launch_lz4_pack(hipStream_t s, const uint8_t* src, const uint8_t* slots, const Lz4Block* blocks, int n_blocks, const int32_t* csize, const int32_t* blk_buffer,
+                     const int32_t* buf_first_block, const int64_t* buf_off, const int64_t* buf_len, const int64_t* blk_dst, uint8_t* body) {
+  if (n_blocks > 0)
+    hipLaunchKernelGGL(k_lz4_pack, dim3((unsigned)n_blocks), dim3(256), 0, s, src, slots, blocks, csize, blk_buffer, buf_first_block, buf_off, buf_len, blk_dst, body);
+}
+void launch_lz4_decode(hipStream_t s, const uint8_t* src, int64_t src_bytes, uint8_t* dst, const Lz4Unit* units, int n_units, uint32_t* status) {
+  if (n_units > 0) hipLaunchKernelGGL(k_lz4_decode, dim3((unsigned)n_units), dim3(64), 0, s, src, dst, units, n_units, src_bytes, status);
+}
+void launch_popcount_bits(hipStream_t s, const uint8_t* bits, int64_t n_bits, unsigned long long* out) {
+  const int64_t words = (n_bits + 63) >> 6;
+  if (words <= 0) return;
+  const int blocks = (int)std::min<int64_t>(1024, (words + 255) / 256);
+  hipLaunchKernelGGL(k_popcount_bits, dim3((unsigned)blocks), dim3(256), 0, s, (const u64*)bits, n_bits, out);
+}
+
+}  // namespace gpuq

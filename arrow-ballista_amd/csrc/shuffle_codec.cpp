@@ -1,0 +1,453 @@
+// Shuffle sink / source codec: one Arrow IPC RecordBatch message <-> device columns, buffers compressed as
+// LZ4 frames on the device.  What it stands in for in the reference:
+//   * write: `StreamWriter::try_new_with_options(file, schema, IpcWriteOptions.try_with_compression(Some(LZ4_FRAME)))` + `write(&batch)`
+//     -- ballista/core/src/execution_plans/shuffle_writer.rs:365-378 (hash-partitioned), ballista/core/src/utils.rs:179-219 (unpartitioned);
+//   * read: `StreamReader` / `read_record_batch` -- ballista/core/src/execution_plans/shuffle_reader.rs, ballista/core/src/client.rs,
+//     ballista/executor/.../async_reader/mod.rs:168-258.
+// The codec itself lives in third-party crates (arrow-ipc 49.0.0 `compression.rs` over lz4_flex; not in the tree): the formats
+// restated here are the public ones -- Arrow columnar IPC (Message.fbs / Schema.fbs: encapsulated message = 0xFFFFFFFF, int32
+// metadata length, flatbuffer, body; BodyCompression: every buffer = int64 uncompressed length (-1 = stored raw) + codec frame)
+// and the LZ4 frame format 1.6.x.  This file is a client of devbuf.h and the launchers in kernels_lz4.hip; no CPU (de)compressor exists
+// here: the host only frames (headers, flatbuffer metadata, block index walk).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/gpuq.h"
+#include "devbuf.h"
+#include "gpuq_kernels.h"
+
+using namespace gpuq;
+
+namespace {
+thread_local std::string g_ipc_error;
+
+template <class F> int guarded_ipc(F&& f) {
+  try { f(); return GPUQ_OK; }
+  catch (const HipError& e) { g_ipc_error = e.what(); return GPUQ_ERR_HIP; }
+  catch (const Unsupported& e) { g_ipc_error = e.what(); return GPUQ_ERR_UNSUPPORTED; }
+  catch (const Capacity& e) { g_ipc_error = e.what(); return GPUQ_ERR_CAPACITY; }
+  catch (const std::bad_alloc&) { g_ipc_error = "out of host memory"; return GPUQ_ERR_INTERNAL; }
+  catch (const std::exception& e) { g_ipc_error = e.what(); return GPUQ_ERR_INVALID; }
+}
+
+// ---------------------------------------------------------------- flatbuffer access (read side: generic; write side: one fixed layout)
+struct FbView {
+  const uint8_t* b; size_t n;
+  void need(size_t at, size_t k) const { if (at > n || k > n - at) throw std::runtime_error("IPC metadata: offset outside the flatbuffer"); }
+  uint16_t u16(size_t at) const { need(at, 2); uint16_t v; std::memcpy(&v, b + at, 2); return v; }
+  uint32_t u32(size_t at) const { need(at, 4); uint32_t v; std::memcpy(&v, b + at, 4); return v; }
+  int32_t i32(size_t at) const { return (int32_t)u32(at); }
+  int64_t i64(size_t at) const { need(at, 8); int64_t v; std::memcpy(&v, b + at, 8); return v; }
+  uint8_t u8(size_t at) const { need(at, 1); return b[at]; }
+  size_t field(size_t table, int k) const {      // absolute position of field k of a table, 0 when absent
+    const int64_t vt = (int64_t)table - (int64_t)i32(table);
+    if (vt < 0) throw std::runtime_error("IPC metadata: bad vtable offset");
+    const uint16_t vsize = u16((size_t)vt);
+    const size_t slot = 4 + 2 * (size_t)k;
+    if (slot + 2 > vsize) return 0;
+    const uint16_t off = u16((size_t)vt + slot);
+    return off ? table + off : 0;
+  }
+  size_t indirect(size_t at) const { return at + u32(at); }
+};
+
+struct BatchMeta {
+  int header_type = 0, codec = -1; int64_t body_len = 0, n_rows = 0;
+  std::vector<std::pair<int64_t, int64_t>> nodes, buffers;      // (length, null_count), (offset, length)
+};
+
+BatchMeta parse_message(const uint8_t* fb, size_t n) {
+  FbView v{fb, n};
+  BatchMeta m;
+  const size_t msg = v.indirect(0);
+  if (size_t p = v.field(msg, 1)) m.header_type = v.u8(p);
+  if (size_t p = v.field(msg, 3)) m.body_len = v.i64(p);
+  if (m.header_type != 3) return m;
+  size_t hp = v.field(msg, 2);
+  if (!hp) throw std::runtime_error("IPC metadata: RecordBatch message without a header");
+  const size_t rb = v.indirect(hp);
+  if (size_t p = v.field(rb, 0)) m.n_rows = v.i64(p);
+  if (size_t p = v.field(rb, 1)) {
+    const size_t vec = v.indirect(p); const uint32_t cnt = v.u32(vec);
+    for (uint32_t i = 0; i < cnt; ++i) m.nodes.push_back({v.i64(vec + 4 + 16 * (size_t)i), v.i64(vec + 12 + 16 * (size_t)i)});
+  }
+  if (size_t p = v.field(rb, 2)) {
+    const size_t vec = v.indirect(p); const uint32_t cnt = v.u32(vec);
+    for (uint32_t i = 0; i < cnt; ++i) m.buffers.push_back({v.i64(vec + 4 + 16 * (size_t)i), v.i64(vec + 12 + 16 * (size_t)i)});
+  }
+  if (size_t p = v.field(rb, 3)) {
+    const size_t bc = v.indirect(p);
+    m.codec = 0;
+    if (size_t c = v.field(bc, 0)) m.codec = (int8_t)v.u8(c);
+    if (size_t c = v.field(bc, 1)) if (v.u8(c) != 0) throw Unsupported("IPC BodyCompression method other than BUFFER");
+  }
+  return m;
+}
+
+// One RecordBatch message as a flatbuffer (Message{version V5, header RecordBatch{length, nodes, buffers, compression?}, bodyLength}).
+std::vector<uint8_t> build_batch_metadata(const BatchMeta& m) {
+  const size_t nn = m.nodes.size(), nb = m.buffers.size();
+  const size_t nodes_cnt = 92, nodes_dat = 96, bufs_cnt = nodes_dat + 16 * nn + 4, bufs_dat = bufs_cnt + 4, total = bufs_dat + 16 * nb;
+  std::vector<uint8_t> b(total, 0);
+  auto p16 = [&](size_t at, uint16_t x) { std::memcpy(&b[at], &x, 2); };
+  auto p32 = [&](size_t at, uint32_t x) { std::memcpy(&b[at], &x, 4); };
+  auto p64 = [&](size_t at, int64_t x) { std::memcpy(&b[at], &x, 8); };
+  p32(0, 16);
+  // Message vtable @4, table @16
+  p16(4, 12); p16(6, 20); p16(8, 16); p16(10, 18); p16(12, 4); p16(14, 8);
+  p32(16, 12); p32(20, 48 - 20); p64(24, m.body_len); p16(32, 4 /* MetadataVersion V5 */); b[34] = 3 /* MessageHeader RecordBatch */;
+  // RecordBatch vtable @36, table @48
+  p16(36, 12); p16(38, 24); p16(40, 8); p16(42, 4); p16(44, 16); p16(46, m.codec >= 0 ? 20 : 0);
+  p32(48, 12); p32(52, (uint32_t)(nodes_cnt - 52)); p64(56, m.n_rows); p32(64, (uint32_t)(bufs_cnt - 64)); p32(68, m.codec >= 0 ? 80 - 68 : 0);
+  // BodyCompression vtable @72, table @80
+  p16(72, 8); p16(74, 8); p16(76, 4); p16(78, 5);
+  p32(80, 8); b[84] = (uint8_t)(m.codec >= 0 ? m.codec : 0); b[85] = 0;
+  p32(nodes_cnt, (uint32_t)nn);
+  for (size_t i = 0; i < nn; ++i) { p64(nodes_dat + 16 * i, m.nodes[i].first); p64(nodes_dat + 16 * i + 8, m.nodes[i].second); }
+  p32(bufs_cnt, (uint32_t)nb);
+  for (size_t i = 0; i < nb; ++i) { p64(bufs_dat + 16 * i, m.buffers[i].first); p64(bufs_dat + 16 * i + 8, m.buffers[i].second); }
+  return b;
+}
+
+int type_width_of(int type) {
+  switch (type) {
+    case GPUQ_INT32: case GPUQ_DATE32: case GPUQ_UINT32: return 4;
+    case GPUQ_INT64: case GPUQ_FLOAT64: case GPUQ_UINT64: return 8;
+    case GPUQ_DECIMAL128: return 16;
+    default: return 0;
+  }
+}
+
+struct SrcBuf { const uint8_t* p; int64_t len; };
+
+struct PinnedScratch {      // small pinned area for the descriptor upload / size read-back of one call
+  void* p = nullptr; size_t cap = 0;
+  ~PinnedScratch() { if (p) (void)hipHostFree(p); }
+  void* ensure(size_t n) { if (n > cap) { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; HIPCHECK(hipHostMalloc(&p, n, hipHostMallocDefault)); cap = n; } return p; }
+};
+thread_local PinnedScratch g_pin_up, g_pin_down;
+
+}  // namespace
+
+struct gpuq_ipc_batch {
+  int64_t n_rows = 0;
+  struct Col { gpuq_column col{}; DevBuf data, offsets, validity; };
+  std::vector<std::unique_ptr<Col>> cols;
+};
+
+extern "C" {
+
+const char* gpuq_ipc_last_error(void) { return g_ipc_error.c_str(); }
+
+int gpuq_ipc_peek(const uint8_t* bytes, int64_t avail, gpuq_ipc_info* out) {
+  return guarded_ipc([&]() {
+    if (!bytes || !out) throw std::runtime_error("bytes/out is NULL");
+    std::memset(out, 0, sizeof(*out)); out->codec = -1;
+    if (avail < 8) throw Capacity("need at least 8 bytes of an encapsulated IPC message");
+    uint32_t cont; int32_t mlen; std::memcpy(&cont, bytes, 4); std::memcpy(&mlen, bytes + 4, 4);
+    if (cont != 0xFFFFFFFFu) throw std::runtime_error("IPC message does not start with the continuation marker (pre-0.15 framing is not supported)");
+    if (mlen == 0) { out->header_type = 0; out->metadata_bytes = 8; return; }      // end-of-stream
+    if (mlen < 0) throw std::runtime_error("negative IPC metadata length");
+    out->metadata_bytes = 8 + (int64_t)mlen;
+    if (avail < out->metadata_bytes) throw Capacity("IPC metadata is " + std::to_string(out->metadata_bytes) + " bytes");
+    const BatchMeta m = parse_message(bytes + 8, (size_t)mlen);
+    out->header_type = m.header_type; out->codec = m.codec; out->body_bytes = m.body_len; out->n_rows = m.n_rows;
+    out->n_nodes = (int32_t)m.nodes.size(); out->n_buffers = (int32_t)m.buffers.size();
+  });
+}
+
+int gpuq_ipc_encode_batch(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, int n_cols, int64_t n_rows, int codec, uint8_t* out_host, int64_t cap,
+                          int64_t* len_out) {
+  return guarded_ipc([&]() {
+    if (!ctx) throw std::runtime_error("ctx is NULL");
+    if (!cols && n_cols > 0) throw std::runtime_error("cols is NULL");
+    if (codec != -1 && codec != 0) throw Unsupported("IPC body compression codec " + std::to_string(codec) + " (only LZ4_FRAME = 0 or none = -1)");
+    hipStream_t s = (hipStream_t)stream;
+    BatchMeta meta; meta.header_type = 3; meta.codec = codec; meta.n_rows = n_rows;
+    // ---- the Arrow buffers of every column, in IPC order (validity, [offsets], data)
+    std::vector<SrcBuf> bufs;
+    DevBuf counts; counts.ensure(8 * (size_t)(n_cols + 1) + 16 * (size_t)n_cols);
+    HIPCHECK(hipMemsetAsync(counts.p, 0, 8 * (size_t)(n_cols + 1), s));
+    std::vector<std::unique_ptr<DevBuf>> temps;
+    int32_t* ends_dev = (int32_t*)((char*)counts.p + 8 * (size_t)(n_cols + 1));      // per column: first and last Utf8 offset
+    bool any_utf8 = false;
+    for (int c = 0; c < n_cols; ++c) {
+      const gpuq_column& k = cols[c];
+      if (k.length != n_rows) throw std::runtime_error("column " + std::to_string(c) + " has " + std::to_string(k.length) + " rows, batch has " + std::to_string(n_rows));
+      if (k.repr != GPUQ_REPR_ARROW) throw Unsupported("IPC encode needs Arrow-layout columns (unpack PACKED15 strings with gpuq_unpack_utf8 first)");
+      if (k.validity && n_rows > 0) launch_popcount_bits(s, k.validity, n_rows, (unsigned long long*)counts.p + c);
+      if (k.type == GPUQ_UTF8 && n_rows > 0) {
+        any_utf8 = true;
+        HIPCHECK(hipMemcpyAsync(ends_dev + 2 * c, k.offsets, 4, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(ends_dev + 2 * c + 1, k.offsets + n_rows, 4, hipMemcpyDeviceToDevice, s));
+      }
+    }
+    std::vector<unsigned long long> valid_counts((size_t)n_cols + 1, 0);
+    std::vector<int32_t> ends(2 * (size_t)n_cols + 2, 0);
+    {
+      char* pd = (char*)g_pin_down.ensure(counts.cap);
+      HIPCHECK(hipMemcpyAsync(pd, counts.p, 8 * (size_t)(n_cols + 1) + 8 * (size_t)n_cols, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      std::memcpy(valid_counts.data(), pd, 8 * (size_t)n_cols);
+      if (any_utf8) std::memcpy(ends.data(), pd + 8 * (size_t)(n_cols + 1), 8 * (size_t)n_cols);
+    }
+    for (int c = 0; c < n_cols; ++c) {
+      const gpuq_column& k = cols[c];
+      const int64_t nulls = (k.validity && n_rows > 0) ? n_rows - (int64_t)valid_counts[(size_t)c] : 0;
+      meta.nodes.push_back({n_rows, nulls});
+      bufs.push_back({nulls > 0 ? k.validity : nullptr, nulls > 0 ? (n_rows + 7) / 8 : 0});
+      if (k.type == GPUQ_UTF8) {
+        const int32_t first = ends[2 * (size_t)c], last = ends[2 * (size_t)c + 1];
+        const int32_t* offs = k.offsets;
+        if (first != 0 && n_rows > 0) {       // a sliced column: offsets are rebased so that the data buffer starts at the first string
+          temps.push_back(std::make_unique<DevBuf>()); temps.back()->ensure((size_t)(n_rows + 1) * 4);
+          launch_offsets_rebase(s, k.offsets, n_rows + 1, -first, temps.back()->as<int32_t>());
+          offs = temps.back()->as<int32_t>();
+        }
+        if (n_rows == 0) {                     // one zero offset
+          temps.push_back(std::make_unique<DevBuf>()); temps.back()->ensure(16); HIPCHECK(hipMemsetAsync(temps.back()->p, 0, 16, s));
+          offs = temps.back()->as<int32_t>();
+        }
+        bufs.push_back({(const uint8_t*)offs, (n_rows + 1) * 4});
+        bufs.push_back({(const uint8_t*)k.data + first, (int64_t)last - first});
+      } else if (k.type == GPUQ_BOOL) {
+        bufs.push_back({(const uint8_t*)k.data, (n_rows + 7) / 8});
+      } else {
+        const int w = type_width_of(k.type);
+        if (!w) throw Unsupported("IPC encode of column type " + std::to_string(k.type));
+        bufs.push_back({(const uint8_t*)k.data, n_rows * w});
+      }
+    }
+    const int nb = (int)bufs.size();
+    std::vector<int64_t> boff((size_t)nb + 1, 0), blen((size_t)nb, 0);
+    DevBuf body, slots, desc, sizes;
+    if (codec < 0) {
+      int64_t off = 0;
+      for (int j = 0; j < nb; ++j) { boff[(size_t)j] = off; blen[(size_t)j] = bufs[(size_t)j].len; off += (bufs[(size_t)j].len + 7) & ~(int64_t)7; }
+      boff[(size_t)nb] = off;
+    } else {
+      // ---- blocks of <= 64 KiB, one wave each
+      std::vector<Lz4Block> blocks; std::vector<int32_t> blk_buffer, first((size_t)nb + 1, 0);
+      int64_t slot = 0, worst = 0;
+      for (int j = 0; j < nb; ++j) {
+        first[(size_t)j] = (int32_t)blocks.size();
+        for (int64_t at = 0; at < bufs[(size_t)j].len; at += LZ4_BLOCK_BYTES) {
+          const int64_t l = std::min<int64_t>(LZ4_BLOCK_BYTES, bufs[(size_t)j].len - at);
+          blocks.push_back({(int64_t)(uintptr_t)(bufs[(size_t)j].p + at), slot, (int32_t)l, 0});
+          blk_buffer.push_back(j); slot += lz4_slot_bytes(l);
+        }
+        if (bufs[(size_t)j].len > 0) worst += (bufs[(size_t)j].len + 8 + 7) & ~(int64_t)7;
+      }
+      first[(size_t)nb] = (int32_t)blocks.size();
+      const int nblk = (int)blocks.size();
+      if (nblk > 0) {
+        const size_t b_blocks = sizeof(Lz4Block) * (size_t)nblk, b_bb = 4 * (size_t)nblk, b_first = 4 * ((size_t)nb + 1);
+        const size_t o_bb = (b_blocks + 15) & ~(size_t)15, o_first = (o_bb + b_bb + 15) & ~(size_t)15, up_total = o_first + b_first;
+        char* up = (char*)g_pin_up.ensure(up_total);
+        std::memcpy(up, blocks.data(), b_blocks); std::memcpy(up + o_bb, blk_buffer.data(), b_bb); std::memcpy(up + o_first, first.data(), b_first);
+        desc.ensure(up_total);
+        HIPCHECK(hipMemcpyAsync(desc.p, up, up_total, hipMemcpyHostToDevice, s));
+        // sizes: csize[nblk] i32 | blk_dst[nblk] i64 | buf_off[nb+1] i64 | buf_len[nb] i64
+        const size_t o_dst = (4 * (size_t)nblk + 15) & ~(size_t)15, o_off = o_dst + 8 * (size_t)nblk, o_len = o_off + 8 * ((size_t)nb + 1), sz_total = o_len + 8 * (size_t)nb;
+        sizes.ensure(sz_total);
+        slots.ensure((size_t)slot + 16);
+        body.ensure((size_t)worst + 16);
+        const Lz4Block* d_blocks = (const Lz4Block*)desc.p;
+        const int32_t* d_bb = (const int32_t*)((char*)desc.p + o_bb); const int32_t* d_first = (const int32_t*)((char*)desc.p + o_first);
+        int32_t* d_csize = (int32_t*)sizes.p; int64_t* d_dst = (int64_t*)((char*)sizes.p + o_dst);
+        int64_t* d_off = (int64_t*)((char*)sizes.p + o_off); int64_t* d_len = (int64_t*)((char*)sizes.p + o_len);
+        launch_lz4_compress(s, nullptr, slots.as<uint8_t>(), d_blocks, nblk, d_csize);
+        launch_lz4_layout(s, d_blocks, d_csize, d_first, nb, d_off, d_len, d_dst);
+        launch_lz4_pack(s, nullptr, slots.as<uint8_t>(), d_blocks, nblk, d_csize, d_bb, d_first, d_off, d_len, d_dst, body.as<uint8_t>());
+        char* pd = (char*)g_pin_down.ensure(8 * (2 * (size_t)nb + 1));
+        HIPCHECK(hipMemcpyAsync(pd, d_off, 8 * (2 * (size_t)nb + 1), hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        std::memcpy(boff.data(), pd, 8 * ((size_t)nb + 1));
+        std::memcpy(blen.data(), pd + 8 * ((size_t)nb + 1), 8 * (size_t)nb);
+        for (auto& l : blen) if (l < 0) l = -l;
+        if (boff[(size_t)nb] > worst) throw std::runtime_error("internal: compressed body larger than its bound");
+      }
+    }
+    meta.body_len = boff[(size_t)nb];
+    for (int j = 0; j < nb; ++j) meta.buffers.push_back({boff[(size_t)j], blen[(size_t)j]});
+    const std::vector<uint8_t> fb = build_batch_metadata(meta);
+    const int64_t total = 8 + (int64_t)fb.size() + meta.body_len;
+    if (len_out) *len_out = total;
+    if (!out_host || cap < total) {
+      if (!out_host && cap == 0) return;      // size query
+      throw Capacity("IPC message needs " + std::to_string(total) + " bytes");
+    }
+    const uint32_t cont = 0xFFFFFFFFu; const int32_t mlen = (int32_t)fb.size();
+    std::memcpy(out_host, &cont, 4); std::memcpy(out_host + 4, &mlen, 4); std::memcpy(out_host + 8, fb.data(), fb.size());
+    uint8_t* hb = out_host + 8 + fb.size();
+    if (codec < 0) {
+      for (int j = 0; j < nb; ++j) {
+        const int64_t l = bufs[(size_t)j].len;
+        if (l > 0) HIPCHECK(hipMemcpyAsync(hb + boff[(size_t)j], bufs[(size_t)j].p, (size_t)l, hipMemcpyDeviceToHost, s));
+        std::memset(hb + boff[(size_t)j] + l, 0, (size_t)(((l + 7) & ~(int64_t)7) - l));
+      }
+    } else if (meta.body_len > 0) {
+      HIPCHECK(hipMemcpyAsync(hb, body.p, (size_t)meta.body_len, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+  });
+}
+
+int gpuq_ipc_decode_batch(gpuq_ctx* ctx, void* stream, const uint8_t* msg, int64_t msg_bytes, const gpuq_field_info* fields, int n_cols, gpuq_ipc_batch** out) {
+  gpuq_ipc_batch* B = nullptr;
+  int rc = guarded_ipc([&]() {
+    if (!ctx) throw std::runtime_error("ctx is NULL");
+    if (!msg || !out || (!fields && n_cols > 0)) throw std::runtime_error("msg/fields/out is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    if (msg_bytes < 8) throw std::runtime_error("truncated IPC message");
+    uint32_t cont; int32_t mlen; std::memcpy(&cont, msg, 4); std::memcpy(&mlen, msg + 4, 4);
+    if (cont != 0xFFFFFFFFu || mlen <= 0 || 8 + (int64_t)mlen > msg_bytes) throw std::runtime_error("not an encapsulated IPC message");
+    const BatchMeta m = parse_message(msg + 8, (size_t)mlen);
+    if (m.header_type != 3) throw std::runtime_error("IPC message is not a RecordBatch (header type " + std::to_string(m.header_type) + ")");
+    if (m.codec > 0) throw Unsupported("IPC body compression codec " + std::to_string(m.codec) + " (ZSTD) is not supported on device");
+    const uint8_t* hb = msg + 8 + mlen;
+    if (m.body_len < 0 || 8 + (int64_t)mlen + m.body_len > msg_bytes) throw std::runtime_error("truncated IPC body");
+    if ((int)m.nodes.size() != n_cols) throw std::runtime_error("IPC batch has " + std::to_string(m.nodes.size()) + " field nodes, schema has " + std::to_string(n_cols));
+    size_t want = 0;
+    for (int c = 0; c < n_cols; ++c) want += fields[c].type == GPUQ_UTF8 ? 3 : 2;
+    if (m.buffers.size() != want) throw std::runtime_error("IPC batch has " + std::to_string(m.buffers.size()) + " buffers, schema needs " + std::to_string(want));
+    for (auto& b : m.buffers) if (b.first < 0 || b.second < 0 || b.first + b.second > m.body_len) throw std::runtime_error("IPC buffer outside the body");
+    const int64_t n = m.n_rows;
+    B = new gpuq_ipc_batch(); B->n_rows = n;
+    DevBuf dbody;
+    dbody.ensure((size_t)m.body_len + 16);
+    if (m.body_len > 0) HIPCHECK(hipMemcpyAsync(dbody.p, hb, (size_t)m.body_len, hipMemcpyHostToDevice, s));
+    const uint8_t* db = dbody.as<uint8_t>();
+    std::vector<Lz4Unit> units, units_seq;      // fast path (independent blocks assumed full) and the always-valid per-frame walk
+    bool split_any = false;
+    // decode buffer j (body range) into dst (capacity dst_cap bytes); returns the uncompressed length
+    auto emit = [&](size_t j, uint8_t* dst, int64_t dst_cap) -> int64_t {
+      const int64_t off = m.buffers[j].first, len = m.buffers[j].second;
+      if (len == 0) return 0;
+      if (m.codec < 0) {
+        if (len > dst_cap) throw std::runtime_error("IPC buffer " + std::to_string(j) + " is larger than its column allows");
+        HIPCHECK(hipMemcpyAsync(dst, db + off, (size_t)len, hipMemcpyDeviceToDevice, s));
+        return len;
+      }
+      if (len < 8) throw std::runtime_error("compressed IPC buffer shorter than its length prefix");
+      int64_t ulen; std::memcpy(&ulen, hb + off, 8);
+      if (ulen == -1) {
+        if (len - 8 > dst_cap) throw std::runtime_error("IPC buffer " + std::to_string(j) + " is larger than its column allows");
+        if (len > 8) HIPCHECK(hipMemcpyAsync(dst, db + off + 8, (size_t)(len - 8), hipMemcpyDeviceToDevice, s));
+        return len - 8;
+      }
+      if (ulen < 0 || ulen > dst_cap) throw std::runtime_error("IPC buffer " + std::to_string(j) + " decompresses to " + std::to_string(ulen) + " bytes, its column allows " + std::to_string(dst_cap));
+      if (ulen == 0) return 0;
+      // LZ4 frame header
+      const uint8_t* f = hb + off + 8; const int64_t flen = len - 8;
+      if (flen < 7 + 4) throw std::runtime_error("truncated LZ4 frame");
+      uint32_t magic; std::memcpy(&magic, f, 4);
+      if (magic != 0x184D2204u) throw std::runtime_error("IPC buffer is not an LZ4 frame (magic " + std::to_string(magic) + ")");
+      const uint8_t flg = f[4], bd = f[5];
+      if ((flg >> 6) != 1) throw std::runtime_error("unsupported LZ4 frame version");
+      const bool indep = (flg >> 5) & 1, bchk = (flg >> 4) & 1, has_size = (flg >> 3) & 1, has_dict = flg & 1;
+      if (has_dict) throw Unsupported("LZ4 frame with a dictionary id");
+      const int bmax_id = (bd >> 4) & 7;
+      if (bmax_id < 4) throw std::runtime_error("bad LZ4 frame block size id");
+      const int64_t bmax = (int64_t)1 << (8 + 2 * bmax_id);
+      int64_t hp = 6 + (has_size ? 8 : 0) + 1;
+      if (hp + 4 > flen) throw std::runtime_error("truncated LZ4 frame");
+      const int64_t fsrc = off + 8 + hp;                      // first block header, relative to the body
+      Lz4Unit whole{fsrc, (int64_t)(uintptr_t)dst, flen - hp, ulen, LZ4_UNIT_FRAME_BLOCKS, bchk ? LZ4_UNIT_BLOCK_CHECKSUM : 0};
+      units_seq.push_back(whole);
+      if (!indep) { units.push_back(whole); return ulen; }
+      // independent blocks: walk the block index on the host, one unit per block (all but the last assumed full; verified on the device)
+      int64_t ip = hp, op = 0; size_t first_unit = units.size(); bool okw = true;
+      while (true) {
+        if (ip + 4 > flen) { okw = false; break; }
+        uint32_t h; std::memcpy(&h, f + ip, 4); ip += 4;
+        if (h == 0) break;
+        const int64_t bs = h & 0x7FFFFFFFu;
+        if (bs > flen - ip || op >= ulen) { okw = false; break; }
+        const int64_t dl = std::min(bmax, ulen - op);
+        units.push_back({off + 8 + ip, (int64_t)(uintptr_t)dst + op, bs, dl, (h & 0x80000000u) ? LZ4_UNIT_STORED : LZ4_UNIT_BLOCK, 0});
+        ip += bs + (bchk ? 4 : 0); op += dl;
+      }
+      if (!okw || op != ulen) { units.resize(first_unit); units.push_back(whole); }
+      else if (units.size() - first_unit > 1) split_any = true;
+      return ulen;
+    };
+    size_t j = 0;
+    for (int c = 0; c < n_cols; ++c) {
+      auto col = std::make_unique<gpuq_ipc_batch::Col>();
+      const gpuq_field_info& f = fields[c];
+      col->col.type = f.type; col->col.precision = f.precision; col->col.scale = f.scale; col->col.repr = GPUQ_REPR_ARROW; col->col.length = n;
+      if (m.nodes[(size_t)c].first != n) throw std::runtime_error("IPC field node length differs from the batch length");
+      const int64_t nulls = m.nodes[(size_t)c].second;
+      const size_t vbytes = (size_t)((n + 63) / 64) * 8;
+      if (nulls > 0 && m.buffers[j].second > 0) {
+        col->validity.ensure(vbytes + 80); HIPCHECK(hipMemsetAsync(col->validity.p, 0, vbytes + 80, s));
+        emit(j, col->validity.as<uint8_t>(), (int64_t)vbytes + 64);      // producers may pad their bitmaps (64-byte allocation granules)
+        col->col.validity = col->validity.as<uint8_t>();
+      }
+      ++j;
+      if (f.type == GPUQ_UTF8) {
+        col->offsets.ensure((size_t)(n + 1) * 4 + 80);
+        HIPCHECK(hipMemsetAsync(col->offsets.p, 0, (size_t)(n + 1) * 4 + 80, s));
+        emit(j, col->offsets.as<uint8_t>(), (n + 1) * 4 + 64); ++j;
+        // the data length is the frame's uncompressed length (or the raw length)
+        int64_t dlen = m.buffers[j].second;
+        if (m.codec >= 0 && dlen >= 8) { int64_t u; std::memcpy(&u, hb + m.buffers[j].first, 8); dlen = (u == -1) ? dlen - 8 : u; }
+        if (dlen < 0) throw std::runtime_error("bad Utf8 data buffer length");
+        col->data.ensure((size_t)dlen + 16);
+        emit(j, col->data.as<uint8_t>(), dlen); ++j;
+        col->col.offsets = col->offsets.as<int32_t>();
+      } else if (f.type == GPUQ_BOOL) {
+        col->data.ensure(vbytes + 80); HIPCHECK(hipMemsetAsync(col->data.p, 0, vbytes + 80, s));
+        emit(j, col->data.as<uint8_t>(), (int64_t)vbytes + 64); ++j;
+      } else {
+        const int w = type_width_of(f.type);
+        if (!w) throw Unsupported("IPC decode of column type " + std::to_string(f.type));
+        col->data.ensure((size_t)n * w + 80);
+        const int64_t got = emit(j, col->data.as<uint8_t>(), n * w + 64); ++j;
+        if (got < n * w) throw std::runtime_error("IPC data buffer of column " + std::to_string(c) + " has " + std::to_string(got) + " bytes, expected " + std::to_string(n * w));
+      }
+      col->col.data = col->data.p;
+      B->cols.push_back(std::move(col));
+    }
+    if (!units.empty()) {
+      DevBuf dunits, dstatus; dstatus.ensure(16);
+      auto run = [&](const std::vector<Lz4Unit>& us) -> uint32_t {
+        char* up = (char*)g_pin_up.ensure(sizeof(Lz4Unit) * us.size());
+        std::memcpy(up, us.data(), sizeof(Lz4Unit) * us.size());
+        dunits.ensure(sizeof(Lz4Unit) * us.size());
+        HIPCHECK(hipMemcpyAsync(dunits.p, up, sizeof(Lz4Unit) * us.size(), hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemsetAsync(dstatus.p, 0, 4, s));
+        launch_lz4_decode(s, db, m.body_len, nullptr, (const Lz4Unit*)dunits.p, (int)us.size(), dstatus.as<uint32_t>());
+        uint32_t* pd = (uint32_t*)g_pin_down.ensure(16);
+        HIPCHECK(hipMemcpyAsync(pd, dstatus.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        return *pd;
+      };
+      uint32_t st = run(units);
+      if (st && split_any) st = run(units_seq);      // a frame whose inner blocks are not full-size: decode frame by frame
+      if (st) throw std::runtime_error("malformed LZ4 data in an IPC buffer");
+    } else {
+      HIPCHECK(hipStreamSynchronize(s));
+    }
+    *out = B;
+  });
+  if (rc != GPUQ_OK) { delete B; if (out) *out = nullptr; }
+  return rc;
+}
+
+int64_t gpuq_ipc_batch_num_rows(const gpuq_ipc_batch* b) { return b ? b->n_rows : 0; }
+int gpuq_ipc_batch_num_columns(const gpuq_ipc_batch* b) { return b ? (int)b->cols.size() : 0; }
+int gpuq_ipc_batch_column(const gpuq_ipc_batch* b, int i, gpuq_column* col_out) {
+  if (!b || !col_out || i < 0 || i >= (int)b->cols.size()) return GPUQ_ERR_INVALID;
+  *col_out = b->cols[(size_t)i]->col;
+  return GPUQ_OK;
+}
+void gpuq_ipc_batch_free(gpuq_ipc_batch* b) { delete b; }
+
+}  // extern "C"

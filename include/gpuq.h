@@ -283,6 +283,42 @@ void gpuq_result_free(gpuq_result* r);
    between GPUs as it lies.  *base_out = NULL otherwise. */
 int gpuq_result_record(const gpuq_result* r, void** base_out, size_t* bytes_out, int64_t* cap_out);
 
+/* ---- shuffle codec: Arrow IPC stream messages with LZ4_FRAME buffers, device side -------------------
+   Stands in for the reference's shuffle sink and source: `StreamWriter::try_new_with_options(.., LZ4_FRAME)` + `write(&batch)`
+   (ballista/core/src/execution_plans/shuffle_writer.rs:365-378, ballista/core/src/utils.rs:179-219) and the IPC stream reader
+   behind ShuffleReaderExec / the Flight client (ballista/core/src/execution_plans/shuffle_reader.rs, ballista/core/src/client.rs).
+   A shuffle file is: the Schema message (the caller's Arrow library serialises it -- arrow-rs `IpcDataGenerator::schema_to_bytes`,
+   pyarrow `Schema.serialize()`), RecordBatch messages, then the end-of-stream marker FF FF FF FF 00 00 00 00.  These entry points
+   encode / decode ONE encapsulated RecordBatch message; the buffers are (de)compressed on the device (one wave per 64 KiB block),
+   the host only frames.  Frames are written with independent 64 KiB blocks, no checksums (what lz4_flex writes for arrow-ipc);
+   frames with linked blocks (Arrow C++), stored blocks, block checksums and content size are read.  ZSTD is GPUQ_ERR_UNSUPPORTED.
+   Errors: status code + gpuq_ipc_last_error(). */
+typedef struct gpuq_ipc_info {
+  int32_t header_type;     /* Message.fbs MessageHeader: 1 Schema, 2 DictionaryBatch, 3 RecordBatch; 0 = end-of-stream marker */
+  int32_t codec;           /* -1 none, 0 LZ4_FRAME, 1 ZSTD */
+  int64_t metadata_bytes;  /* from the start of the message to the start of its body (8 + flatbuffer incl. padding) */
+  int64_t body_bytes;
+  int64_t n_rows;
+  int32_t n_nodes, n_buffers;
+} gpuq_ipc_info;
+typedef struct gpuq_ipc_batch gpuq_ipc_batch;
+/* Host only: parses the message that starts at `bytes`.  GPUQ_ERR_CAPACITY when `avail` does not cover the metadata yet
+   (out->metadata_bytes is set once the first 8 bytes are there). */
+int gpuq_ipc_peek(const uint8_t* bytes, int64_t avail, gpuq_ipc_info* out);
+/* cols: device columns in GPUQ_REPR_ARROW layout, all of n_rows rows.  codec: 0 = LZ4_FRAME, -1 = uncompressed.  Writes the
+   message to out_host (host memory, cap bytes) and its length to *len_out.  out_host == NULL && cap == 0: size query (the
+   compression runs, nothing is copied).  GPUQ_ERR_CAPACITY (with *len_out set) when cap is too small.  Synchronous. */
+int gpuq_ipc_encode_batch(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, int n_cols, int64_t n_rows, int codec, uint8_t* out_host, int64_t cap,
+                          int64_t* len_out);
+/* msg: one whole encapsulated RecordBatch message in host memory; fields: the stream's schema (type / precision / scale are
+   read).  The decoded columns live in device memory owned by *out (gpuq_ipc_batch_free).  Synchronous. */
+int gpuq_ipc_decode_batch(gpuq_ctx* ctx, void* stream, const uint8_t* msg, int64_t msg_bytes, const gpuq_field_info* fields, int n_cols, gpuq_ipc_batch** out);
+int64_t gpuq_ipc_batch_num_rows(const gpuq_ipc_batch* b);
+int gpuq_ipc_batch_num_columns(const gpuq_ipc_batch* b);
+int gpuq_ipc_batch_column(const gpuq_ipc_batch* b, int i, gpuq_column* col_out);
+void gpuq_ipc_batch_free(gpuq_ipc_batch* b);
+const char* gpuq_ipc_last_error(void);
+
 /* ---- synthetic TPC-H-shaped input (bench/test support) ------------------- */
 typedef struct gpuq_lineitem_cols {
   int64_t* l_orderkey; int64_t* l_suppkey;

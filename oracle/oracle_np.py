@@ -299,6 +299,19 @@ def _binary(op, lt, lv, rt, rv):
             return t, [None if (x is None or y is None) else (x + y if op == "+" else x - y) for x, y in zip(a, b)]
         if op == "*":
             return dec(min(38, p1 + p2 + 1), min(38, s1 + s2)), [None if (x is None or y is None) else x * y for x, y in zip(lv, rv)]
+        # arrow-arith 49 numeric.rs decimal_op [UPSTREAM-KNOWLEDGE]: Div -> scale s1+4 ("follow postgres and MySQL adding a
+        # fixed scale increment of 4"), precision p1 + (4 + s2), value = l*10^(4+s2) / r truncated toward zero;
+        # Rem -> scale max(s1,s2), precision min(p1-s1, p2-s2) + scale, sign of the dividend.  x/0 raises DivideByZero in
+        # arrow; here (as for integers) the slot becomes NULL -- the device cannot raise per row.
+        if op == "/":
+            rs = min(38, s1 + 4)
+            k = rs - s1 + s2
+            a = _rescale(lv, lt, s1)[0]; b = _rescale(rv, rt, s2)[0]
+            return dec(min(38, p1 + k), rs), [None if (x is None or y is None or y == 0) else trunc_div(x * 10 ** k, y) for x, y in zip(a, b)]
+        if op == "%":
+            s = max(s1, s2)
+            a, b = _rescale(lv, lt, s)[0], _rescale(rv, rt, s)[0]
+            return dec(min(38, min(p1 - s1, p2 - s2) + s), s), [None if (x is None or y is None or y == 0) else x - trunc_div(x, y) * y for x, y in zip(a, b)]
         raise NotImplementedError("decimal %s" % op)
     # integers / dates
     if lt == "Date32" and rt == "Date32" and op == "-":

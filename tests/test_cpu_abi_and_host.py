@@ -152,3 +152,41 @@ def test_native_plan_json_is_parsed_without_a_device():
     assert b"WindowAggExec" in L.gpuq_plan_last_error()
     assert L.gpuq_plan_create(fake_ctx, b'{"FilterExec": {"input": 1}}', C.byref(h)) == 1
     assert L.gpuq_plan_create(fake_ctx, b'not json', C.byref(h)) == 1
+
+
+def test_ipc_peek_walks_an_arrow_cpp_stream_on_the_host():
+    """gpuq_ipc_peek (host-only flatbuffer reader) against a stream written by Arrow C++: message kinds, body sizes, row
+    and buffer counts, compression codec; the walk lands exactly on the end-of-stream marker."""
+    import ctypes as C
+    import io
+    import numpy as np
+    import pyarrow as pa
+    from arrow_ballista_amd import binding as B
+    from arrow_ballista_amd.shuffle import gpuq_ipc_info
+    L = B.lib()
+    t = pa.table({"a": pa.array(np.arange(5000, dtype=np.int64)), "s": pa.array(["x%d" % (i % 7) for i in range(5000)]),
+                  "d": pa.array([None if i % 5 == 0 else i for i in range(5000)], type=pa.int32())})
+    for comp, codec in (("lz4", 0), ("zstd", 1), (None, -1)):
+        sink = io.BytesIO()
+        with pa.ipc.new_stream(sink, t.schema, options=pa.ipc.IpcWriteOptions(compression=comp)) as w:
+            for b in t.to_batches(max_chunksize=2000):
+                w.write_batch(b)
+        raw = sink.getvalue()
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        pos, kinds, rows = 0, [], 0
+        info = gpuq_ipc_info()
+        while True:
+            rc = L.gpuq_ipc_peek(C.c_void_p(C.addressof(buf) + pos), len(raw) - pos, C.byref(info))
+            assert rc == 0, L.gpuq_ipc_last_error()
+            kinds.append(info.header_type)
+            if info.header_type == 0:
+                break
+            if info.header_type == 3:
+                assert info.codec == codec and info.n_nodes == 3 and info.n_buffers == 7
+                rows += info.n_rows
+            pos += info.metadata_bytes + info.body_bytes
+        assert kinds == [1, 3, 3, 3, 0] and rows == 5000 and pos + 8 == len(raw)
+    # too few bytes: CAPACITY with the size needed; garbage: INVALID
+    assert L.gpuq_ipc_peek(C.c_void_p(C.addressof(buf)), 12, C.byref(info)) == 4 and info.metadata_bytes > 12
+    junk = (C.c_uint8 * 64)(*([7] * 64))
+    assert L.gpuq_ipc_peek(C.c_void_p(C.addressof(junk)), 64, C.byref(info)) == 1

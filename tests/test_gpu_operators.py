@@ -134,6 +134,26 @@ def test_projection_decimal_types_and_cast(tc):
     assert ty["a"] == {"Decimal128": [23, 2]} and ty["c"] == {"Decimal128": [38, 6]} and ty["up"] == {"Decimal128": [20, 4]}
 
 
+def test_decimal_division_and_modulo(tc):
+    """Decimal `/` and `%` (arrow-arith 49 decimal_op: Div -> scale s1+4, precision p1+4+s2; Rem -> scale max(s1,s2)); x/0 -> NULL."""
+    t = rand_table(19, 4000, 0.1)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    exprs = [(binary(col("dec", s), Op.Divide, lit(7, D152)), "dq"), (binary(col("dec", s), Op.Divide, col("k32", s)), "di"),
+             (binary(col("k64", s), Op.Divide, col("dec", s)), "id"), (binary(col("dec", s), Op.Modulo, lit(333, D152)), "dm"),
+             (binary(col("dec", s), Op.Modulo, col("k32", s)), "dmi"),
+             (binary(binary(lit(10000, ("Decimal128", 5, 2)), Op.Multiply, col("dec", s)), Op.Divide, cast(col("k64", s), ("Decimal128", 20, 2))), "q14")]
+    plan = g.ProjectionExec(exprs, src)
+    got = dev_rows(tc, plan.execute(0, tc))
+    exp = ora_rows(O.project(ot, [e for e, _ in exprs], [n for _, n in exprs]))
+    assert got == exp
+    assert any(r[1] is None for r in got) and any(r[1] is not None and r[1] < 0 for r in got)
+    ty = {f["name"]: f["type"] for f in plan.schema()}
+    assert ty["dq"] == {"Decimal128": [21, 6]} and ty["di"] == {"Decimal128": [19, 6]} and ty["id"] == {"Decimal128": [26, 4]}
+    assert ty["dm"] == {"Decimal128": [15, 2]} and ty["dmi"] == {"Decimal128": [12, 2]}
+
+
 # ------------------------------------------------------------------------------------ aggregate
 def agg_cases(s):
     return [

@@ -88,3 +88,24 @@ def test_q1_shape_on_reference_testdata():
     assert dict(out.rows()) == exp
     # l_extendedprice(15,2) * Int64 -> Decimal(15,2)*Decimal(20,0) = (36,2); SUM -> (38,2)
     assert out.types[1] == O.dec(38, 2)
+
+
+def test_decimal_division_rules_by_hand():
+    """Decimal `/` and `%` as arrow-arith 49 computes them (hand-worked): 1.00/3.00 -> 0.333333 (15,2)/(15,2) -> (21,6);
+    -7.50 / 2 (Int32 -> Decimal(10,0)) -> -3.750000 (19,6); truncation toward zero; % keeps the dividend's sign; x/0 -> NULL."""
+    from oracle import oracle_np as O
+    import decimal
+    D = decimal.Decimal
+    t = O.Table(["a", "b", "i"], [{"Decimal128": [15, 2]}, {"Decimal128": [15, 2]}, "Int32"],
+                [[100, -750, 200, -1, None], [300, 200, 0, 3, 5], [3, 2, 7, -2, 1]])
+    from arrow_ballista_amd.expr import Operator as Op, binary, col
+    sch = [{"name": n, "type": ty} for n, ty in zip(t.names, t.types)]
+    ca, cb, ci = col("a", sch), col("b", sch), col("i", sch)
+    ty, v = O.eval_expr(binary(ca, Op.Divide, cb), t)
+    assert ty == {"Decimal128": [21, 6]} and v == [333333, -3750000, None, -333333, None]
+    ty, v = O.eval_expr(binary(ca, Op.Divide, ci), t)
+    assert ty == {"Decimal128": [19, 6]} and v == [333333, -3750000, 285714, 5000, None]
+    ty, v = O.eval_expr(binary(ca, Op.Modulo, cb), t)
+    assert ty == {"Decimal128": [15, 2]} and v == [100, -150, None, -1, None]
+    ty, v = O.eval_expr(binary(ca, Op.Modulo, ci), t)
+    assert ty == {"Decimal128": [12, 2]} and v == [100, -150, 200, -1, None]
