@@ -15,14 +15,14 @@ from .native import NativePlan, NativeResult  # noqa: F401
 from .table import DeviceColumn, DeviceTable  # noqa: F401
 from .plan import (  # noqa: F401
     MemoryExec, FilterExec, ProjectionExec, AggregateExec, HashJoinExec, SortExec, CoalesceBatchesExec,
-    RepartitionExec, ShuffleWriterExec, DefaultExecutionEngine, TaskContext,
+    RepartitionExec, ShuffleWriterExec, ShuffleReaderExec, DefaultExecutionEngine, TaskContext,
     CoalesceTasksExec, CoalescePartitionsExec, SortPreservingMergeExec, UnionExec, LocalLimitExec, GlobalLimitExec,
 )
 
 __all__ = [
     "GpuqError", "Context", "Op", "JoinTable", "lib", "lib_path", "compile_check", "expr",
     "DeviceColumn", "DeviceTable", "MemoryExec", "FilterExec", "ProjectionExec", "AggregateExec",
-    "HashJoinExec", "SortExec", "CoalesceBatchesExec", "RepartitionExec", "ShuffleWriterExec",
+    "HashJoinExec", "SortExec", "CoalesceBatchesExec", "RepartitionExec", "ShuffleWriterExec", "ShuffleReaderExec",
     "DefaultExecutionEngine", "TaskContext", "CoalesceTasksExec", "CoalescePartitionsExec", "SortPreservingMergeExec",
     "UnionExec", "LocalLimitExec", "GlobalLimitExec",
 ]

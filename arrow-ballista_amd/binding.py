@@ -127,6 +127,7 @@ def lib():
         "gpuq_ipc_peek": (i32, [vp, i64, vp]),
         "gpuq_ipc_encode_batch": (i32, [vp, vp, C.POINTER(gpuq_column), i32, i64, i32, vp, i64, C.POINTER(i64)]),
         "gpuq_ipc_decode_batch": (i32, [vp, vp, vp, i64, C.POINTER(gpuq_field_info), i32, C.POINTER(vp)]),
+        "gpuq_ipc_decode_stream": (i32, [vp, vp, vp, i64, C.POINTER(gpuq_field_info), i32, C.POINTER(vp)]),
         "gpuq_ipc_batch_num_rows": (i64, [vp]),
         "gpuq_ipc_batch_num_columns": (i32, [vp]),
         "gpuq_ipc_batch_column": (i32, [vp, i32, C.POINTER(gpuq_column)]),

@@ -161,6 +161,10 @@ void launch_lz4_layout(hipStream_t s, const Lz4Block* blocks, const int32_t* csi
 void launch_lz4_pack(hipStream_t s, const uint8_t* src, const uint8_t* slots, const Lz4Block* blocks, int n_blocks, const int32_t* csize, const int32_t* blk_buffer,
                      const int32_t* buf_first_block, const int64_t* buf_off, const int64_t* buf_len, const int64_t* blk_dst, uint8_t* body);
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, int64_t src_bytes, uint8_t* dst, const Lz4Unit* units, int n_units, uint32_t* status);
+struct Utf8Piece { const int32_t* tmp; int64_t n; int32_t* dst; int64_t at, dl, start, used; int32_t first, pad; };   // one batch of a Utf8 column (kernels_lz4.hip)
+void launch_utf8_piece_starts(hipStream_t s, Utf8Piece* pieces, int n_pieces, uint32_t* gap);
+void launch_utf8_piece_offsets(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_rows);
+void launch_utf8_piece_compact(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_bytes, const uint8_t* from, uint8_t* to);
 void launch_popcount_bits(hipStream_t s, const uint8_t* bits, int64_t n_bits, unsigned long long* out);
 void launch_gen_lineitem(hipStream_t s, u64 seed, u64 seed_orders, i64 row0, i64 n, i64 n_supp, const LineitemCols& c);
 void launch_gen_orders(hipStream_t s, u64 seed, i64 row0, i64 n, i64 n_cust, const OrdersCols& c);

@@ -306,7 +306,54 @@ __global__ void k_popcount_bits(const u64* __restrict__ bits, int64_t n_bits, un
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+// ---------------------------------------------------------------- Utf8 columns of a multi-batch stream
+// Every batch brings its own offsets (decoded into a temp) and its own data buffer (decoded at a host-known position `at`,
+// the sum of the buffers before it).  Producers may pad a data buffer beyond the bytes its offsets use (Arrow C++ rounds a
+// sliced buffer up to 8 bytes) or leave the offsets un-rebased: the merged column needs `start` = the bytes really used before
+// the batch.  k_utf8_piece_starts computes that and raises `gap` when the data is not already contiguous (then
+// k_utf8_piece_compact moves it); k_utf8_piece_offsets writes the merged offsets.
+__global__ void k_utf8_piece_starts(Utf8Piece* __restrict__ pieces, int n_pieces, uint32_t* __restrict__ gap) {
+  for (int k = (int)threadIdx.x; k < n_pieces; k += (int)blockDim.x) {
+    const int32_t a = pieces[k].tmp[0], b = pieces[k].tmp[pieces[k].n];
+    pieces[k].first = a; pieces[k].used = (int64_t)b - a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t start = 0; bool g = false;
+    for (int k = 0; k < n_pieces; ++k) {
+      pieces[k].start = start;
+      g |= (start != pieces[k].at + pieces[k].first) || pieces[k].used < 0 || pieces[k].used + pieces[k].first > pieces[k].dl;
+      start += pieces[k].used;
+    }
+    if (g) atomicOr(gap, 2u);
+  }
+}
+__global__ __launch_bounds__(256) void k_utf8_piece_offsets(const Utf8Piece* __restrict__ pieces) {
+  const Utf8Piece P = pieces[blockIdx.y];
+  const int32_t delta = (int32_t)(P.start - P.first);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= P.n; i += (int64_t)gridDim.x * 256) P.dst[i] = P.tmp[i] + delta;
+}
+__global__ __launch_bounds__(256) void k_utf8_piece_compact(const Utf8Piece* __restrict__ pieces, const uint8_t* __restrict__ from, uint8_t* __restrict__ to) {
+  const Utf8Piece P = pieces[blockIdx.y];
+  if (P.used <= 0 || P.used + P.first > P.dl) return;
+  const uint8_t* s = from + P.at + P.first; uint8_t* d = to + P.start;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.used; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+}
+
 // ---------------------------------------------------------------- launchers
+void launch_utf8_piece_starts(hipStream_t s, Utf8Piece* pieces, int n_pieces, uint32_t* gap) {
+  if (n_pieces > 0) hipLaunchKernelGGL(k_utf8_piece_starts, dim3(1), dim3(256), 0, s, pieces, n_pieces, gap);
+}
+void launch_utf8_piece_offsets(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_rows) {
+  if (n_pieces <= 0) return;
+  const unsigned gx = (unsigned)std::min<int64_t>(64, (max_rows + 256) / 256);
+  hipLaunchKernelGGL(k_utf8_piece_offsets, dim3(gx, (unsigned)n_pieces), dim3(256), 0, s, pieces);
+}
+void launch_utf8_piece_compact(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_bytes, const uint8_t* from, uint8_t* to) {
+  if (n_pieces <= 0) return;
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (max_bytes + 4095) / 4096));
+  hipLaunchKernelGGL(k_utf8_piece_compact, dim3(gx, (unsigned)n_pieces), dim3(256), 0, s, pieces, from, to);
+}
 void launch_lz4_compress(hipStream_t s, const uint8_t* src, uint8_t* slots, const Lz4Block* blocks, int n_blocks, int32_t* csize) {
   if (n_blocks > 0) hipLaunchKernelGGL(k_lz4_compress, dim3((unsigned)n_blocks), dim3(64), 0, s, src, slots, blocks, n_blocks, csize);
 }

@@ -298,53 +298,68 @@ int gpuq_ipc_encode_batch(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, 
   });
 }
 
-int gpuq_ipc_decode_batch(gpuq_ctx* ctx, void* stream, const uint8_t* msg, int64_t msg_bytes, const gpuq_field_info* fields, int n_cols, gpuq_ipc_batch** out) {
+// All RecordBatch messages of a byte range decoded in ONE pass: every LZ4 block (independent frames) or frame (linked blocks)
+// of every buffer of every batch is a unit of the same launch, and each lands at its final place in the concatenated column.
+// That is what makes the reference's 8192-row batches (one or two blocks per buffer) fill the chip.
+int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, int64_t n_bytes, const gpuq_field_info* fields, int n_cols, gpuq_ipc_batch** out) {
   gpuq_ipc_batch* B = nullptr;
   int rc = guarded_ipc([&]() {
     if (!ctx) throw std::runtime_error("ctx is NULL");
-    if (!msg || !out || (!fields && n_cols > 0)) throw std::runtime_error("msg/fields/out is NULL");
+    if (!bytes || !out || (!fields && n_cols > 0)) throw std::runtime_error("bytes/fields/out is NULL");
     hipStream_t s = (hipStream_t)stream;
-    if (msg_bytes < 8) throw std::runtime_error("truncated IPC message");
-    uint32_t cont; int32_t mlen; std::memcpy(&cont, msg, 4); std::memcpy(&mlen, msg + 4, 4);
-    if (cont != 0xFFFFFFFFu || mlen <= 0 || 8 + (int64_t)mlen > msg_bytes) throw std::runtime_error("not an encapsulated IPC message");
-    const BatchMeta m = parse_message(msg + 8, (size_t)mlen);
-    if (m.header_type != 3) throw std::runtime_error("IPC message is not a RecordBatch (header type " + std::to_string(m.header_type) + ")");
-    if (m.codec > 0) throw Unsupported("IPC body compression codec " + std::to_string(m.codec) + " (ZSTD) is not supported on device");
-    const uint8_t* hb = msg + 8 + mlen;
-    if (m.body_len < 0 || 8 + (int64_t)mlen + m.body_len > msg_bytes) throw std::runtime_error("truncated IPC body");
-    if ((int)m.nodes.size() != n_cols) throw std::runtime_error("IPC batch has " + std::to_string(m.nodes.size()) + " field nodes, schema has " + std::to_string(n_cols));
+    // ---- host pass over the message headers
+    struct Msg { BatchMeta m; int64_t body; int64_t row0; };
+    std::vector<Msg> msgs;
     size_t want = 0;
     for (int c = 0; c < n_cols; ++c) want += fields[c].type == GPUQ_UTF8 ? 3 : 2;
-    if (m.buffers.size() != want) throw std::runtime_error("IPC batch has " + std::to_string(m.buffers.size()) + " buffers, schema needs " + std::to_string(want));
-    for (auto& b : m.buffers) if (b.first < 0 || b.second < 0 || b.first + b.second > m.body_len) throw std::runtime_error("IPC buffer outside the body");
-    const int64_t n = m.n_rows;
-    B = new gpuq_ipc_batch(); B->n_rows = n;
-    DevBuf dbody;
-    dbody.ensure((size_t)m.body_len + 16);
-    if (m.body_len > 0) HIPCHECK(hipMemcpyAsync(dbody.p, hb, (size_t)m.body_len, hipMemcpyHostToDevice, s));
-    const uint8_t* db = dbody.as<uint8_t>();
+    int64_t pos = 0, N = 0;
+    while (pos + 8 <= n_bytes) {
+      uint32_t cont; int32_t mlen; std::memcpy(&cont, bytes + pos, 4); std::memcpy(&mlen, bytes + pos + 4, 4);
+      if (cont != 0xFFFFFFFFu) throw std::runtime_error("IPC stream: message at byte " + std::to_string(pos) + " does not start with the continuation marker");
+      if (mlen == 0) break;                                          // end-of-stream marker
+      if (mlen < 0 || pos + 8 + (int64_t)mlen > n_bytes) throw std::runtime_error("truncated IPC message metadata");
+      Msg g; g.m = parse_message(bytes + pos + 8, (size_t)mlen); g.body = pos + 8 + mlen; g.row0 = N;
+      if (g.m.body_len < 0 || g.body + g.m.body_len > n_bytes) throw std::runtime_error("truncated IPC body");
+      pos = g.body + g.m.body_len;
+      if (g.m.header_type == 1) continue;                            // Schema: the caller passed the fields
+      if (g.m.header_type != 3) throw Unsupported("IPC message type " + std::to_string(g.m.header_type) + " (dictionary batches are not supported on device)");
+      if (g.m.codec > 0) throw Unsupported("IPC body compression codec " + std::to_string(g.m.codec) + " (ZSTD) is not supported on device");
+      if ((int)g.m.nodes.size() != n_cols) throw std::runtime_error("IPC batch has " + std::to_string(g.m.nodes.size()) + " field nodes, schema has " + std::to_string(n_cols));
+      if (g.m.buffers.size() != want) throw std::runtime_error("IPC batch has " + std::to_string(g.m.buffers.size()) + " buffers, schema needs " + std::to_string(want));
+      for (auto& bf : g.m.buffers) if (bf.first < 0 || bf.second < 0 || bf.first + bf.second > g.m.body_len) throw std::runtime_error("IPC buffer outside the body");
+      for (auto& nd : g.m.nodes) if (nd.first != g.m.n_rows) throw std::runtime_error("IPC field node length differs from the batch length");
+      N += g.m.n_rows;
+      msgs.push_back(std::move(g));
+    }
+    B = new gpuq_ipc_batch(); B->n_rows = N;
+    DevBuf dsrc;
+    dsrc.ensure((size_t)pos + 16);
+    if (pos > 0) HIPCHECK(hipMemcpyAsync(dsrc.p, bytes, (size_t)pos, hipMemcpyHostToDevice, s));
+    const uint8_t* db = dsrc.as<uint8_t>();
     std::vector<Lz4Unit> units, units_seq;      // fast path (independent blocks assumed full) and the always-valid per-frame walk
     bool split_any = false;
-    // decode buffer j (body range) into dst (capacity dst_cap bytes); returns the uncompressed length
-    auto emit = [&](size_t j, uint8_t* dst, int64_t dst_cap) -> int64_t {
-      const int64_t off = m.buffers[j].first, len = m.buffers[j].second;
-      if (len == 0) return 0;
-      if (m.codec < 0) {
-        if (len > dst_cap) throw std::runtime_error("IPC buffer " + std::to_string(j) + " is larger than its column allows");
-        HIPCHECK(hipMemcpyAsync(dst, db + off, (size_t)len, hipMemcpyDeviceToDevice, s));
-        return len;
-      }
+    // uncompressed length of buffer j of message g (host only)
+    auto ulen_of = [&](const Msg& g, size_t j) -> int64_t {
+      const int64_t len = g.m.buffers[j].second;
+      if (len == 0 || g.m.codec < 0) return len;
       if (len < 8) throw std::runtime_error("compressed IPC buffer shorter than its length prefix");
-      int64_t ulen; std::memcpy(&ulen, hb + off, 8);
-      if (ulen == -1) {
-        if (len - 8 > dst_cap) throw std::runtime_error("IPC buffer " + std::to_string(j) + " is larger than its column allows");
-        if (len > 8) HIPCHECK(hipMemcpyAsync(dst, db + off + 8, (size_t)(len - 8), hipMemcpyDeviceToDevice, s));
-        return len - 8;
-      }
-      if (ulen < 0 || ulen > dst_cap) throw std::runtime_error("IPC buffer " + std::to_string(j) + " decompresses to " + std::to_string(ulen) + " bytes, its column allows " + std::to_string(dst_cap));
-      if (ulen == 0) return 0;
+      int64_t u; std::memcpy(&u, bytes + g.body + g.m.buffers[j].first, 8);
+      if (u == -1) return len - 8;
+      if (u < 0) throw std::runtime_error("bad uncompressed length in an IPC buffer");
+      return u;
+    };
+    // queue the decode of buffer j of message g into dst (capacity dst_cap bytes)
+    auto emit = [&](const Msg& g, size_t j, uint8_t* dst, int64_t dst_cap) {
+      const int64_t off = g.body + g.m.buffers[j].first, len = g.m.buffers[j].second;
+      if (len == 0) return;
+      const int64_t ulen = ulen_of(g, j);
+      if (ulen > dst_cap) throw std::runtime_error("IPC buffer " + std::to_string(j) + " holds " + std::to_string(ulen) + " bytes, its column allows " + std::to_string(dst_cap));
+      if (ulen == 0) return;
+      if (g.m.codec < 0) { HIPCHECK(hipMemcpyAsync(dst, db + off, (size_t)len, hipMemcpyDeviceToDevice, s)); return; }
+      int64_t pre; std::memcpy(&pre, bytes + off, 8);
+      if (pre == -1) { HIPCHECK(hipMemcpyAsync(dst, db + off + 8, (size_t)(len - 8), hipMemcpyDeviceToDevice, s)); return; }
       // LZ4 frame header
-      const uint8_t* f = hb + off + 8; const int64_t flen = len - 8;
+      const uint8_t* f = bytes + off + 8; const int64_t flen = len - 8;
       if (flen < 7 + 4) throw std::runtime_error("truncated LZ4 frame");
       uint32_t magic; std::memcpy(&magic, f, 4);
       if (magic != 0x184D2204u) throw std::runtime_error("IPC buffer is not an LZ4 frame (magic " + std::to_string(magic) + ")");
@@ -355,14 +370,13 @@ int gpuq_ipc_decode_batch(gpuq_ctx* ctx, void* stream, const uint8_t* msg, int64
       const int bmax_id = (bd >> 4) & 7;
       if (bmax_id < 4) throw std::runtime_error("bad LZ4 frame block size id");
       const int64_t bmax = (int64_t)1 << (8 + 2 * bmax_id);
-      int64_t hp = 6 + (has_size ? 8 : 0) + 1;
+      const int64_t hp = 6 + (has_size ? 8 : 0) + 1;
       if (hp + 4 > flen) throw std::runtime_error("truncated LZ4 frame");
-      const int64_t fsrc = off + 8 + hp;                      // first block header, relative to the body
-      Lz4Unit whole{fsrc, (int64_t)(uintptr_t)dst, flen - hp, ulen, LZ4_UNIT_FRAME_BLOCKS, bchk ? LZ4_UNIT_BLOCK_CHECKSUM : 0};
+      Lz4Unit whole{off + 8 + hp, (int64_t)(uintptr_t)dst, flen - hp, ulen, LZ4_UNIT_FRAME_BLOCKS, bchk ? LZ4_UNIT_BLOCK_CHECKSUM : 0};
       units_seq.push_back(whole);
-      if (!indep) { units.push_back(whole); return ulen; }
+      if (!indep) { units.push_back(whole); return; }
       // independent blocks: walk the block index on the host, one unit per block (all but the last assumed full; verified on the device)
-      int64_t ip = hp, op = 0; size_t first_unit = units.size(); bool okw = true;
+      int64_t ip = hp, op = 0; const size_t first_unit = units.size(); bool okw = true;
       while (true) {
         if (ip + 4 > flen) { okw = false; break; }
         uint32_t h; std::memcpy(&h, f + ip, 4); ip += 4;
@@ -375,70 +389,168 @@ int gpuq_ipc_decode_batch(gpuq_ctx* ctx, void* stream, const uint8_t* msg, int64
       }
       if (!okw || op != ulen) { units.resize(first_unit); units.push_back(whole); }
       else if (units.size() - first_unit > 1) split_any = true;
-      return ulen;
     };
-    size_t j = 0;
+    struct BitFix { uint8_t* dst; int64_t bit0; const uint8_t* src; int64_t n; };          // after the decode: dst bits [bit0, +n) |= src (NULL: ones)
+    struct CopyFix { uint8_t* dst; const uint8_t* src; int64_t n; };
+    struct Utf8Col { int col; std::vector<Utf8Piece> pieces; int64_t max_rows, total; };
+    std::vector<Utf8Col> utf8_cols;
+    std::vector<BitFix> bitfix; std::vector<CopyFix> copyfix;
+    std::vector<std::unique_ptr<DevBuf>> temps;
+    auto temp = [&](size_t nbytes) -> uint8_t* { temps.push_back(std::make_unique<DevBuf>()); temps.back()->ensure(nbytes + 80); return temps.back()->as<uint8_t>(); };
+    // one temp area per kind, carved per batch (a DevBuf per batch would be thousands of pool round trips)
+    const size_t vbytes = (size_t)((N + 63) / 64) * 8;
+    // a bitmap piece lands in place when it starts on a byte and either ends on one or is the last piece; everything else goes
+    // through a temp and an OR-merge (which also masks the producer's padding bits)
+    auto bitmap_piece = [&](const Msg& g, size_t j, uint8_t* dst, bool last, uint8_t*& scratch) {
+      const int64_t n = g.m.n_rows;
+      if (n == 0) return;
+      if (g.m.buffers[j].second == 0) { bitfix.push_back({dst, g.row0, nullptr, n}); return; }       // no buffer: all ones
+      const int64_t cap = (n + 7) / 8 + 64;
+      (void)last;
+      if ((g.row0 & 7) == 0 && (n & 7) == 0 && ulen_of(g, j) == n / 8) { emit(g, j, dst + g.row0 / 8, n / 8); return; }      // exact fit: concurrent pieces never overlap
+      uint8_t* t = scratch; scratch += (cap + 15) & ~(int64_t)15;
+      emit(g, j, t, cap);
+      bitfix.push_back({dst, g.row0, t, n});
+    };
+    size_t bit_scratch = 0, off_scratch = 0;
+    for (auto& g : msgs) { bit_scratch += (size_t)(((g.m.n_rows + 7) / 8 + 64 + 15) & ~(int64_t)15); off_scratch += (size_t)((g.m.n_rows + 1) * 4 + 64 + 15) & ~(size_t)15; }
+    size_t j0 = 0;
     for (int c = 0; c < n_cols; ++c) {
       auto col = std::make_unique<gpuq_ipc_batch::Col>();
       const gpuq_field_info& f = fields[c];
-      col->col.type = f.type; col->col.precision = f.precision; col->col.scale = f.scale; col->col.repr = GPUQ_REPR_ARROW; col->col.length = n;
-      if (m.nodes[(size_t)c].first != n) throw std::runtime_error("IPC field node length differs from the batch length");
-      const int64_t nulls = m.nodes[(size_t)c].second;
-      const size_t vbytes = (size_t)((n + 63) / 64) * 8;
-      if (nulls > 0 && m.buffers[j].second > 0) {
+      col->col.type = f.type; col->col.precision = f.precision; col->col.scale = f.scale; col->col.repr = GPUQ_REPR_ARROW; col->col.length = N;
+      bool any_nulls = false;
+      for (auto& g : msgs) any_nulls |= g.m.nodes[(size_t)c].second > 0 && g.m.buffers[j0].second > 0;
+      if (any_nulls) {
         col->validity.ensure(vbytes + 80); HIPCHECK(hipMemsetAsync(col->validity.p, 0, vbytes + 80, s));
-        emit(j, col->validity.as<uint8_t>(), (int64_t)vbytes + 64);      // producers may pad their bitmaps (64-byte allocation granules)
+        uint8_t* scratch = temp(bit_scratch); HIPCHECK(hipMemsetAsync(scratch, 0, bit_scratch, s));
+        for (size_t k = 0; k < msgs.size(); ++k) {
+          const Msg& g = msgs[k];
+          if (g.m.nodes[(size_t)c].second > 0 && g.m.buffers[j0].second > 0) bitmap_piece(g, j0, col->validity.as<uint8_t>(), k + 1 == msgs.size(), scratch);
+          else if (g.m.n_rows > 0) bitfix.push_back({col->validity.as<uint8_t>(), g.row0, nullptr, g.m.n_rows});
+        }
         col->col.validity = col->validity.as<uint8_t>();
       }
-      ++j;
       if (f.type == GPUQ_UTF8) {
-        col->offsets.ensure((size_t)(n + 1) * 4 + 80);
-        HIPCHECK(hipMemsetAsync(col->offsets.p, 0, (size_t)(n + 1) * 4 + 80, s));
-        emit(j, col->offsets.as<uint8_t>(), (n + 1) * 4 + 64); ++j;
-        // the data length is the frame's uncompressed length (or the raw length)
-        int64_t dlen = m.buffers[j].second;
-        if (m.codec >= 0 && dlen >= 8) { int64_t u; std::memcpy(&u, hb + m.buffers[j].first, 8); dlen = (u == -1) ? dlen - 8 : u; }
-        if (dlen < 0) throw std::runtime_error("bad Utf8 data buffer length");
-        col->data.ensure((size_t)dlen + 16);
-        emit(j, col->data.as<uint8_t>(), dlen); ++j;
+        int64_t total = 0;
+        for (auto& g : msgs) total += ulen_of(g, j0 + 2);
+        if (total > 0x7FFFFFFF) throw Unsupported("Utf8 column of more than 2 GiB in one shuffle partition (int32 offsets)");
+        col->offsets.ensure((size_t)(N + 1) * 4 + 80); HIPCHECK(hipMemsetAsync(col->offsets.p, 0, (size_t)(N + 1) * 4 + 80, s));
+        col->data.ensure((size_t)total + 80);
+        uint8_t* scratch = msgs.size() > 1 ? temp(off_scratch) : nullptr;
+        if (scratch) HIPCHECK(hipMemsetAsync(scratch, 0, off_scratch, s));
+        int64_t at = 0, max_piece_rows = 0;
+        std::vector<Utf8Piece> pieces;
+        for (auto& g : msgs) {
+          const int64_t n = g.m.n_rows, cap = (n + 1) * 4 + 64;
+          if (msgs.size() == 1) emit(g, j0 + 1, col->offsets.as<uint8_t>(), cap);
+          else if (n > 0) {
+            uint8_t* t = scratch; scratch += (cap + 15) & ~(int64_t)15;
+            emit(g, j0 + 1, t, cap);
+            pieces.push_back({(const int32_t*)t, n, col->offsets.as<int32_t>() + g.row0, at, ulen_of(g, j0 + 2), 0, 0, 0, 0});
+            max_piece_rows = std::max(max_piece_rows, n);
+          }
+          const int64_t dl = ulen_of(g, j0 + 2);
+          emit(g, j0 + 2, col->data.as<uint8_t>() + at, dl);
+          at += dl;
+        }
         col->col.offsets = col->offsets.as<int32_t>();
+        if (!pieces.empty()) { utf8_cols.push_back({(int)B->cols.size(), std::move(pieces), max_piece_rows, total}); }
+        j0 += 3;
       } else if (f.type == GPUQ_BOOL) {
         col->data.ensure(vbytes + 80); HIPCHECK(hipMemsetAsync(col->data.p, 0, vbytes + 80, s));
-        emit(j, col->data.as<uint8_t>(), (int64_t)vbytes + 64); ++j;
+        uint8_t* scratch = temp(bit_scratch); HIPCHECK(hipMemsetAsync(scratch, 0, bit_scratch, s));
+        for (size_t k = 0; k < msgs.size(); ++k) bitmap_piece(msgs[k], j0 + 1, col->data.as<uint8_t>(), k + 1 == msgs.size(), scratch);
+        j0 += 2;
       } else {
         const int w = type_width_of(f.type);
         if (!w) throw Unsupported("IPC decode of column type " + std::to_string(f.type));
-        col->data.ensure((size_t)n * w + 80);
-        const int64_t got = emit(j, col->data.as<uint8_t>(), n * w + 64); ++j;
-        if (got < n * w) throw std::runtime_error("IPC data buffer of column " + std::to_string(c) + " has " + std::to_string(got) + " bytes, expected " + std::to_string(n * w));
+        col->data.ensure((size_t)N * w + 80);
+        for (size_t k = 0; k < msgs.size(); ++k) {
+          const Msg& g = msgs[k];
+          const int64_t need = g.m.n_rows * w;
+          if (ulen_of(g, j0 + 1) < need) throw std::runtime_error("IPC data buffer of column " + std::to_string(c) + " has " + std::to_string(ulen_of(g, j0 + 1)) + " bytes, expected " + std::to_string(need));
+          const int64_t ul = ulen_of(g, j0 + 1);
+          // a producer's padding beyond the rows may only spill into the slack at the end of the column; elsewhere the pieces of
+          // one launch must not overlap: a padded piece is decoded aside and its rows copied in afterwards
+          if (ul == need || (k + 1 == msgs.size() && ul <= need + 64)) emit(g, j0 + 1, col->data.as<uint8_t>() + g.row0 * w, ul);
+          else if (need > 0) { uint8_t* t = temp((size_t)ul); emit(g, j0 + 1, t, ul); copyfix.push_back({col->data.as<uint8_t>() + g.row0 * w, t, need}); }
+        }
+        j0 += 2;
       }
       col->col.data = col->data.p;
       B->cols.push_back(std::move(col));
     }
-    if (!units.empty()) {
-      DevBuf dunits, dstatus; dstatus.ensure(16);
-      auto run = [&](const std::vector<Lz4Unit>& us) -> uint32_t {
+    DevBuf dunits, dstatus, dpieces; dstatus.ensure(16);
+    // Utf8 piece descriptors of all columns in one upload
+    size_t n_pieces = 0; for (auto& u : utf8_cols) n_pieces += u.pieces.size();
+    std::vector<size_t> piece0;
+    if (n_pieces) {
+      dpieces.ensure(sizeof(Utf8Piece) * n_pieces);
+      std::vector<Utf8Piece> all; all.reserve(n_pieces);
+      for (auto& u : utf8_cols) { piece0.push_back(all.size()); all.insert(all.end(), u.pieces.begin(), u.pieces.end()); }
+      // (pageable source: the copy is staged before the call returns)
+      HIPCHECK(hipMemcpyAsync(dpieces.p, all.data(), sizeof(Utf8Piece) * n_pieces, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipStreamSynchronize(s));
+    }
+    bool gap = false;
+    auto run = [&](const std::vector<Lz4Unit>& us) -> uint32_t {
+      HIPCHECK(hipMemsetAsync(dstatus.p, 0, 8, s));
+      if (!us.empty()) {
         char* up = (char*)g_pin_up.ensure(sizeof(Lz4Unit) * us.size());
         std::memcpy(up, us.data(), sizeof(Lz4Unit) * us.size());
         dunits.ensure(sizeof(Lz4Unit) * us.size());
         HIPCHECK(hipMemcpyAsync(dunits.p, up, sizeof(Lz4Unit) * us.size(), hipMemcpyHostToDevice, s));
-        HIPCHECK(hipMemsetAsync(dstatus.p, 0, 4, s));
-        launch_lz4_decode(s, db, m.body_len, nullptr, (const Lz4Unit*)dunits.p, (int)us.size(), dstatus.as<uint32_t>());
-        uint32_t* pd = (uint32_t*)g_pin_down.ensure(16);
-        HIPCHECK(hipMemcpyAsync(pd, dstatus.p, 4, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
-        return *pd;
-      };
-      uint32_t st = run(units);
-      if (st && split_any) st = run(units_seq);      // a frame whose inner blocks are not full-size: decode frame by frame
-      if (st) throw std::runtime_error("malformed LZ4 data in an IPC buffer");
-    } else {
+        launch_lz4_decode(s, db, pos, nullptr, (const Lz4Unit*)dunits.p, (int)us.size(), dstatus.as<uint32_t>());
+      }
+      for (auto& x : copyfix) HIPCHECK(hipMemcpyAsync(x.dst, x.src, (size_t)x.n, hipMemcpyDeviceToDevice, s));
+      for (auto& x : bitfix) launch_concat_bitmap(s, (u64*)x.dst, x.bit0, x.src, 0, x.n);
+      for (size_t k = 0; k < utf8_cols.size(); ++k) {
+        Utf8Piece* dp = (Utf8Piece*)dpieces.p + piece0[k];
+        launch_utf8_piece_starts(s, dp, (int)utf8_cols[k].pieces.size(), dstatus.as<uint32_t>() + 1);
+        launch_utf8_piece_offsets(s, dp, (int)utf8_cols[k].pieces.size(), utf8_cols[k].max_rows);
+      }
+      uint32_t* pd = (uint32_t*)g_pin_down.ensure(16);
+      HIPCHECK(hipMemcpyAsync(pd, dstatus.p, 8, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      gap = pd[1] != 0;
+      return pd[0];
+    };
+    HIPCHECK(hipMemsetAsync(dstatus.p, 0, 16, s));
+    uint32_t st = run(units);
+    if (st && split_any) {       // a frame whose inner blocks are not full-size: decode frame by frame (bitmaps are OR-merged: clear them first)
+      for (auto& c : B->cols) {
+        if (c->col.validity) HIPCHECK(hipMemsetAsync(c->validity.p, 0, vbytes + 80, s));
+        if (c->col.type == GPUQ_BOOL) HIPCHECK(hipMemsetAsync(c->data.p, 0, vbytes + 80, s));
+      }
+      HIPCHECK(hipMemsetAsync(dstatus.p, 0, 16, s));
+      st = run(units_seq);
+    }
+    if (st) throw std::runtime_error("malformed LZ4 data in an IPC buffer");
+    if (gap) {                   // some producer padded its string data: move every column's bytes to where the merged offsets point
+      for (size_t k = 0; k < utf8_cols.size(); ++k) {
+        auto& col = *B->cols[(size_t)utf8_cols[k].col];
+        DevBuf packed; packed.ensure((size_t)utf8_cols[k].total + 80);
+        int64_t max_bytes = 0; for (auto& pc : utf8_cols[k].pieces) max_bytes = std::max(max_bytes, pc.dl);
+        launch_utf8_piece_compact(s, (const Utf8Piece*)dpieces.p + piece0[k], (int)utf8_cols[k].pieces.size(), max_bytes, col.data.as<uint8_t>(), packed.as<uint8_t>());
+        std::swap(col.data.p, packed.p); std::swap(col.data.cap, packed.cap);
+        col.col.data = col.data.p;
+      }
       HIPCHECK(hipStreamSynchronize(s));
     }
     *out = B;
   });
   if (rc != GPUQ_OK) { delete B; if (out) *out = nullptr; }
   return rc;
+}
+
+int gpuq_ipc_decode_batch(gpuq_ctx* ctx, void* stream, const uint8_t* msg, int64_t msg_bytes, const gpuq_field_info* fields, int n_cols, gpuq_ipc_batch** out) {
+  gpuq_ipc_info info;
+  int rc = gpuq_ipc_peek(msg, msg_bytes, &info);
+  if (rc != GPUQ_OK) return rc;
+  if (info.header_type != 3) { g_ipc_error = "IPC message is not a RecordBatch (header type " + std::to_string(info.header_type) + ")"; return GPUQ_ERR_INVALID; }
+  if (info.metadata_bytes + info.body_bytes > msg_bytes) { g_ipc_error = "truncated IPC body"; return GPUQ_ERR_INVALID; }
+  return gpuq_ipc_decode_stream(ctx, stream, msg, info.metadata_bytes + info.body_bytes, fields, n_cols, out);
 }
 
 int64_t gpuq_ipc_batch_num_rows(const gpuq_ipc_batch* b) { return b ? b->n_rows : 0; }

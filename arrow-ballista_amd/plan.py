@@ -896,15 +896,19 @@ class ShuffleWriterExec(ExecutionPlan):
         return self.plan.schema()
 
     def execute_shuffle_write(self, input_partitions, context):
-        import pyarrow as pa
+        from . import shuffle as S
         t0 = time.perf_counter()
         parts = list(input_partitions) if input_partitions is not None else (self.partitions or range(self.plan.output_partition_count()))
         out = []
-        opts = pa.ipc.IpcWriteOptions(compression="lz4")
         # the reference's ShuffleWriteMetrics (shuffle_writer.rs:139-160): write_time, repart_time (ns), input_rows, output_rows
         mx = self.metrics.extra
         for k in ("write_time", "repart_time", "input_rows"):
             mx.setdefault(k, 0)
+
+        def sink(path, table):
+            # IPC stream, LZ4_FRAME buffers compressed on the device (csrc/kernels_lz4.hip); batches of the session's batch size
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            return S.write_ipc_stream(context, path, table, batch_size=max(context.batch_size, S.SHUFFLE_BATCH_ROWS), codec=0)
         for p in parts:
             table = self.plan.execute(p, context)
             mx["input_rows"] += table.num_rows
@@ -912,16 +916,9 @@ class ShuffleWriterExec(ExecutionPlan):
             if self.shuffle_output_partitioning is None:
                 path = os.path.join(base, str(uuid.uuid4()), "data.arrow")
                 tw = time.perf_counter()
-                host = materialize(context, table).to_arrow(context.ctx)
-                os.makedirs(os.path.dirname(path), exist_ok=True)
-                nb = 0
-                with pa.OSFile(path, "wb") as f, pa.ipc.new_stream(f, host.schema, options=opts) as w:
-                    for b in host.to_batches(max_chunksize=context.batch_size):
-                        if b.num_rows:
-                            w.write_batch(b)
-                            nb += 1
+                nb, rows, nbytes = sink(path, table)
                 mx["write_time"] += int((time.perf_counter() - tw) * 1e9)
-                out.append(ShuffleWritePartition(partition_id=p, path=path, num_batches=nb, num_rows=host.num_rows, num_bytes=host.nbytes))
+                out.append(ShuffleWritePartition(partition_id=p, path=path, num_batches=nb, num_rows=rows, num_bytes=nbytes))
             else:
                 exprs, n = self.shuffle_output_partitioning
                 tr = time.perf_counter()
@@ -932,18 +929,47 @@ class ShuffleWriterExec(ExecutionPlan):
                     if v.num_rows == 0:
                         continue    # lazily created writers: empty partitions produce no file (shuffle_writer.rs:329-334)
                     path = os.path.join(base, str(q), "%s.arrow" % uuid.uuid4())
-                    host = materialize(context, v).to_arrow(context.ctx)
-                    os.makedirs(os.path.dirname(path), exist_ok=True)
-                    nb = 0
-                    with pa.OSFile(path, "wb") as f, pa.ipc.new_stream(f, host.schema, options=opts) as w:
-                        for b in host.to_batches(max_chunksize=context.batch_size):
-                            w.write_batch(b)
-                            nb += 1
-                    out.append(ShuffleWritePartition(partition_id=q, path=path, num_batches=nb, num_rows=host.num_rows,
-                                                     num_bytes=os.path.getsize(path)))
+                    nb, rows, nbytes = sink(path, v)
+                    out.append(ShuffleWritePartition(partition_id=q, path=path, num_batches=nb, num_rows=rows, num_bytes=nbytes))
                 mx["write_time"] += int((time.perf_counter() - tw) * 1e9)
         self.metrics.elapsed_compute_ns += int((time.perf_counter() - t0) * 1e9)
         self.metrics.output_rows += sum(o["num_rows"] for o in out)
+        return out
+
+
+class ShuffleReaderExec(ExecutionPlan):
+    """ShuffleReaderExec(partition: Vec<Vec<PartitionLocation>>, schema) -- ballista/core/src/execution_plans/shuffle_reader.rs:149-177.
+    Output partition p is the concatenation of its locations' IPC streams, decoded on the device (gpuq_ipc_decode_batch).
+    Locations are dicts with a "path" (the PartitionLocation field, serde/scheduler/mod.rs:47-55); only local files are read
+    here -- fetching from a remote executor over Flight is the control plane's job (out of scope)."""
+
+    def __init__(self, partition, schema):
+        super().__init__()
+        self.partition, self._schema = [list(p) for p in partition], schema
+
+    def schema(self):
+        return self._schema
+
+    def output_partition_count(self):
+        return len(self.partition)
+
+    def execute(self, partition, context):
+        from . import shuffle as S
+        t0 = time.perf_counter()
+        tables = []
+        for loc in self.partition[partition]:
+            path = loc["path"] if isinstance(loc, dict) else loc
+            if not os.path.exists(path):
+                # shuffle_reader.rs:654: a missing map output is a FetchFailed, which makes the scheduler re-run the map stage
+                raise B.GpuqError(1, "FetchFailed: shuffle partition file %s does not exist" % path)
+            t, _ = S.read_ipc_stream(context, path)
+            tables.append(t)
+        if not tables:
+            out = S.empty_table(context, self._schema)
+        else:
+            out = tables[0] if len(tables) == 1 else concat_tables(context, tables)
+        self.metrics.elapsed_compute_ns += int((time.perf_counter() - t0) * 1e9)
+        self.metrics.output_rows += out.num_rows
         return out
 
 

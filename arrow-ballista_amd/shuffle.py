@@ -13,6 +13,9 @@ from . import binding as B
 from .table import DeviceColumn, DeviceTable, type_id, type_json
 
 EOS = b"\xff\xff\xff\xff\x00\x00\x00\x00"
+# Rows per RecordBatch the device sink writes: the reference cuts its stream at the session batch size (8192) because that is
+# what flows through its operators; a GPU partition is whole columns, and every IPC reader accepts any batch length.
+SHUFFLE_BATCH_ROWS = 1 << 20
 
 
 class gpuq_ipc_info(C.Structure):
@@ -25,15 +28,23 @@ def _check(L, rc):
         raise B.GpuqError(rc, L.gpuq_ipc_last_error().decode())
 
 
+def _arrow_type(t):
+    import pyarrow as pa
+    tid, p, s = type_id(t)
+    return {B.T_INT32: pa.int32(), B.T_INT64: pa.int64(), B.T_DATE32: pa.date32(), B.T_FLOAT64: pa.float64(), B.T_UINT32: pa.uint32(),
+            B.T_UINT64: pa.uint64(), B.T_UTF8: pa.string(), B.T_BOOL: pa.bool_()}.get(tid) or pa.decimal128(p, s)
+
+
 def _arrow_schema(table):
     import pyarrow as pa
-    fields = []
-    for c in table.columns:
-        tid, p, s = type_id(c.type)
-        pt = {B.T_INT32: pa.int32(), B.T_INT64: pa.int64(), B.T_DATE32: pa.date32(), B.T_FLOAT64: pa.float64(), B.T_UINT32: pa.uint32(),
-              B.T_UINT64: pa.uint64(), B.T_UTF8: pa.string(), B.T_BOOL: pa.bool_()}.get(tid) or pa.decimal128(p, s)
-        fields.append(pa.field(c.name, pt, nullable=bool(c.nullable)))
-    return pa.schema(fields)
+    return pa.schema([pa.field(c.name, _arrow_type(c.type), nullable=bool(c.nullable)) for c in table.columns])
+
+
+def empty_table(tc, schema):
+    """Zero-row device table for a list of field dicts ({"name","type","nullable"})."""
+    import pyarrow as pa
+    fields = [pa.field(f["name"], _arrow_type(f["type"]), nullable=bool(f.get("nullable", True))) for f in schema]
+    return DeviceTable.from_arrow(pa.Table.from_batches([], schema=pa.schema(fields)), tc.device)
 
 
 def _arrow_layout(tc, table):
@@ -173,73 +184,55 @@ class _Batch:
             pass
 
 
-def read_ipc_stream(tc, source):
-    """Read an Arrow IPC stream (path, bytes or memoryview) into ONE device table (batches concatenated in stream order,
-    as ShuffleReaderExec's consumer sees them).  Returns (DeviceTable, pyarrow schema)."""
-    import pyarrow as pa
+def _wrap_batch(tc, L, h, schema, fields, types):
     import torch
-    from . import plan as P
-    L = tc.ctx.L
-    if isinstance(source, str):
-        import numpy as np
-        data = memoryview(np.fromfile(source, dtype=np.uint8))
-    else:
-        data = memoryview(source)
-    base = (C.c_uint8 * len(data)).from_buffer_copy(data) if data.readonly else (C.c_uint8 * len(data)).from_buffer(data)
-    addr = C.addressof(base)
-    pos, total = 0, len(data)
-    schema, fields, types, parts = None, None, None, []
-    info = gpuq_ipc_info()
-    while pos < total:
-        _check(L, L.gpuq_ipc_peek(C.c_void_p(addr + pos), total - pos, C.byref(info)))
-        if info.header_type == 0:
-            break
-        mlen = info.metadata_bytes + info.body_bytes
-        if pos + mlen > total:
-            raise B.GpuqError(1, "truncated IPC stream")
-        if info.header_type == 1:
-            schema = pa.ipc.read_schema(pa.py_buffer(bytes(data[pos: pos + mlen])))
-            fields, types = _fields_of(schema)
-        elif info.header_type == 3:
-            if schema is None:
-                raise B.GpuqError(1, "RecordBatch message before the Schema message")
-            h = C.c_void_p()
-            _check(L, L.gpuq_ipc_decode_batch(tc.ctx.h, tc.stream_ptr(), C.c_void_p(addr + pos), mlen, fields, len(schema), C.byref(h)))
-            owner = _Batch(L, h)
-            n = int(L.gpuq_ipc_batch_num_rows(h))
-            cols = []
-            for i, fl in enumerate(schema):
-                c = B.gpuq_column()
-                L.gpuq_ipc_batch_column(h, i, C.byref(c))
+    owner = _Batch(L, h)
+    n = int(L.gpuq_ipc_batch_num_rows(h))
+    cols = []
 
-                def alias(ptr, nb):
-                    class _A:
-                        pass
-                    a = _A()
-                    a.__cuda_array_interface__ = {"shape": (int(nb),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-                    a.owner = owner
-                    return torch.as_tensor(a, device=tc.device)
-                tid = fields[i].type
-                vb = ((n + 63) // 64) * 8 + 8
-                validity = alias(c.validity, vb) if c.validity else None
-                if tid == B.T_UTF8:
-                    offs = alias(c.offsets, (n + 1) * 4).view(torch.int32)
-                    dlen = int(offs[n].item()) if n else 0
-                    cols.append(DeviceColumn(fl.name, "Utf8", alias(c.data, max(16, dlen)), n, offsets=offs, validity=validity, nullable=fl.nullable))
-                elif tid == B.T_BOOL:
-                    cols.append(DeviceColumn(fl.name, "Boolean", alias(c.data, vb), n, validity=validity, nullable=fl.nullable))
-                else:
-                    w = {B.T_INT32: 4, B.T_DATE32: 4, B.T_UINT32: 4, B.T_INT64: 8, B.T_UINT64: 8, B.T_FLOAT64: 8, B.T_DECIMAL128: 16}[tid]
-                    cols.append(DeviceColumn(fl.name, types[i], alias(c.data, max(1, n) * w + 16), n, validity=validity, nullable=fl.nullable))
-            t = DeviceTable(cols, n)
-            t._keep = owner
-            parts.append(t)
+    def alias(ptr, nb):
+        class _A:
+            pass
+        a = _A()
+        a.__cuda_array_interface__ = {"shape": (int(nb),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+        a.owner = owner
+        return torch.as_tensor(a, device=tc.device)
+    for i, fl in enumerate(schema):
+        c = B.gpuq_column()
+        L.gpuq_ipc_batch_column(h, i, C.byref(c))
+        tid = fields[i].type
+        vb = ((n + 63) // 64) * 8 + 8
+        validity = alias(c.validity, vb) if c.validity else None
+        if tid == B.T_UTF8:
+            offs = alias(c.offsets, (n + 1) * 4).view(torch.int32)
+            dlen = int(offs[n].item()) if n else 0
+            cols.append(DeviceColumn(fl.name, "Utf8", alias(c.data, max(16, dlen)), n, offsets=offs, validity=validity, nullable=fl.nullable))
+        elif tid == B.T_BOOL:
+            cols.append(DeviceColumn(fl.name, "Boolean", alias(c.data, vb), n, validity=validity, nullable=fl.nullable))
         else:
-            raise B.GpuqError(3, "IPC message type %d (dictionary batches are not supported on device)" % info.header_type)
-        pos += mlen
-    if schema is None:
-        raise B.GpuqError(1, "IPC stream without a Schema message")
-    if not parts:
-        empty = pa.Table.from_batches([], schema=schema)
-        return DeviceTable.from_arrow(empty, tc.device), schema
-    return (parts[0] if len(parts) == 1 else P.concat_tables(tc, parts)), schema
+            w = {B.T_INT32: 4, B.T_DATE32: 4, B.T_UINT32: 4, B.T_INT64: 8, B.T_UINT64: 8, B.T_FLOAT64: 8, B.T_DECIMAL128: 16}[tid]
+            cols.append(DeviceColumn(fl.name, types[i], alias(c.data, max(1, n) * w + 16), n, validity=validity, nullable=fl.nullable))
+    t = DeviceTable(cols, n)
+    t._keep = owner
+    return t
+
+
+def read_ipc_stream(tc, source):
+    """Read an Arrow IPC stream (path, bytes or memoryview) into ONE device table: every batch of the stream is decoded in a
+    single library call (gpuq_ipc_decode_stream), in stream order, as ShuffleReaderExec's consumer sees them.
+    Returns (DeviceTable, pyarrow schema)."""
+    import numpy as np
+    import pyarrow as pa
+    L = tc.ctx.L
+    data = np.fromfile(source, dtype=np.uint8) if isinstance(source, str) else np.frombuffer(source, dtype=np.uint8)
+    addr, total = data.ctypes.data, int(data.size)
+    info = gpuq_ipc_info()
+    _check(L, L.gpuq_ipc_peek(C.c_void_p(addr), total, C.byref(info)))
+    if info.header_type != 1:
+        raise B.GpuqError(1, "IPC stream does not start with a Schema message")
+    first = info.metadata_bytes + info.body_bytes
+    schema = pa.ipc.read_schema(pa.py_buffer(data[:first].tobytes()))
+    fields, types = _fields_of(schema)
+    h = C.c_void_p()
+    _check(L, L.gpuq_ipc_decode_stream(tc.ctx.h, tc.stream_ptr(), C.c_void_p(addr + first), total - first, fields, len(schema), C.byref(h)))
+    return _wrap_batch(tc, L, h, schema, fields, types), schema

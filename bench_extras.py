@@ -207,6 +207,63 @@ def dist_join(T, g, rows_per_rank, steps=5):
     return res if rank == 0 else None
 
 
+def shuffle_codec(tc, T, g, rows, reps=3):
+    """Shuffle sink / source codec on the q3 stage-0 shuffle columns of lineitem (l_orderkey Int64,
+    l_extendedprice / l_discount Decimal128(15,2), l_shipdate Date32 = 44 B/row): one IPC RecordBatch message, LZ4_FRAME buffers.
+    encode_kernels = compress + layout + pack on the device (size query: nothing copied back); encode_to_host adds the D2H of
+    the body into pinned memory; decode = H2D of the message + device decompress.  CPU proxy: pyarrow (Arrow C++ + liblz4,
+    its own thread pool) writing / reading the same batch in host memory."""
+    import io
+    import pyarrow as pa
+    import torch
+    from arrow_ballista_amd import shuffle as S
+    t = T.gen_lineitem_device(tc, rows, columns=("l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"))
+    raw = rows * 44
+    out = {"rows": rows, "raw_bytes": raw}
+
+    def best(fn):
+        b = None
+        for _ in range(reps):
+            _sync(tc); t0 = time.perf_counter(); r = fn(); _sync(tc); dt = time.perf_counter() - t0
+            b = dt if b is None or dt < b else b
+        return b, r
+    S.encoded_size(tc, t)                                   # warm-up (pool, pinned scratch)
+    dt, size = best(lambda: S.encoded_size(tc, t))
+    out["encoded_bytes"] = size
+    out["ratio"] = raw / size
+    out["encode_kernels_ms"] = dt * 1e3
+    out["encode_kernels_GBps_in"] = raw / dt / 1e9
+    buf = torch.empty(size + 4096, dtype=torch.uint8, pin_memory=True)
+    dt, (msg, buf) = best(lambda: S.encode_batch(tc, t, 0, buf))
+    out["encode_to_host_ms"] = dt * 1e3
+    out["encode_to_host_GBps_in"] = raw / dt / 1e9
+    stream = io.BytesIO()
+    stream.write(S._arrow_schema(t).serialize().to_pybytes()); stream.write(msg); stream.write(S.EOS)
+    data = stream.getvalue()
+    S.read_ipc_stream(tc, data)
+    dt, _ = best(lambda: S.read_ipc_stream(tc, data))
+    out["decode_from_host_ms"] = dt * 1e3
+    out["decode_from_host_GBps_out"] = raw / dt / 1e9
+    # CPU proxy: the same rows in the reference's configuration (8192-row batches, shuffle_writer.rs + IpcWriteOptions LZ4_FRAME)
+    host = pa.ipc.open_stream(data).read_all()
+    def cpu_write():
+        sink = pa.BufferOutputStream()
+        with pa.ipc.new_stream(sink, host.schema, options=pa.ipc.IpcWriteOptions(compression="lz4")) as w:
+            w.write_table(host, max_chunksize=8192)
+        return sink.getvalue()
+    dt, cbuf = best(cpu_write)
+    out["cpu_proxy_arrow_cpp"] = {"threads": pa.cpu_count(), "batch_rows": 8192, "write_ms": dt * 1e3, "write_GBps_in": raw / dt / 1e9, "encoded_bytes": cbuf.size}
+    dt, _ = best(lambda: pa.ipc.open_stream(cbuf).read_all())
+    out["cpu_proxy_arrow_cpp"].update({"read_ms": dt * 1e3, "read_GBps_out": raw / dt / 1e9})
+    # the CPU-written file (2048 batches x 4 columns, linked-block frames: one wave per buffer) decoded on the device in one call
+    cb = cbuf.to_pybytes()
+    S.read_ipc_stream(tc, cb)
+    dt, _ = best(lambda: S.read_ipc_stream(tc, cb))
+    out["decode_cpu_written_file_ms"] = dt * 1e3
+    out["decode_cpu_written_file_GBps_out"] = raw / dt / 1e9
+    return out
+
+
 def run(tc, T, g, full=True):
     extra = {"join_probe": []}
     grid = [(20, 28, 1.0), (24, 28, 1.0), (27, 28, 1.0), (24, 28, 0.5), (24, 28, 0.1)] if full else [(20, 24, 1.0)]
@@ -237,6 +294,10 @@ if __name__ == "__main__":
         print(json.dumps(cpu_proxy_acero(T, sf), indent=1))
         sys.exit(0)
     tc = g.TaskContext(device=0)
+    if "--shuffle-codec" in sys.argv:
+        rows = int(sys.argv[sys.argv.index("--rows") + 1]) if "--rows" in sys.argv else 1 << 24
+        print(json.dumps(shuffle_codec(tc, T, g, rows), indent=1))
+        sys.exit(0)
     if "--sf100" in sys.argv:
         out = {"q1": q1_pipeline(tc, T, g, 100)}
         out.update(tpch_pipelines(tc, T, g, 100))

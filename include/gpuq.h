@@ -313,6 +313,11 @@ int gpuq_ipc_encode_batch(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, 
 /* msg: one whole encapsulated RecordBatch message in host memory; fields: the stream's schema (type / precision / scale are
    read).  The decoded columns live in device memory owned by *out (gpuq_ipc_batch_free).  Synchronous. */
 int gpuq_ipc_decode_batch(gpuq_ctx* ctx, void* stream, const uint8_t* msg, int64_t msg_bytes, const gpuq_field_info* fields, int n_cols, gpuq_ipc_batch** out);
+/* The same for a whole byte range of encapsulated messages (a shuffle file after -- or including -- its Schema message, up to
+   the end-of-stream marker or n_bytes): every RecordBatch is decoded in ONE launch (a unit of work per LZ4 block of every
+   buffer of every batch) straight into the concatenated columns.  This is the call for files written with the reference's
+   8192-row batches, whose buffers hold one or two blocks each. */
+int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, int64_t n_bytes, const gpuq_field_info* fields, int n_cols, gpuq_ipc_batch** out);
 int64_t gpuq_ipc_batch_num_rows(const gpuq_ipc_batch* b);
 int gpuq_ipc_batch_num_columns(const gpuq_ipc_batch* b);
 int gpuq_ipc_batch_column(const gpuq_ipc_batch* b, int i, gpuq_column* col_out);

@@ -120,3 +120,39 @@ def test_malformed_streams_fail_loudly(tc):
     with pytest.raises(g.GpuqError) as e:
         S.read_ipc_stream(tc, zs.getvalue())
     assert e.value.status == 3
+
+
+def test_two_stages_through_shuffle_files(tc, tmp_path):
+    """Map stage: ShuffleWriterExec hash-partitions its input into files (device LZ4).  Reduce stage: ShuffleReaderExec reads
+    output partition q of every map task (device decode) and a FinalPartitioned-style aggregate runs on it -- the file-based
+    shuffle of the reference (shuffle_writer.rs:234-456 -> shuffle_reader.rs:149-177), result identical to the one-stage oracle."""
+    import os
+    from arrow_ballista_amd.expr import Operator as Op, binary, col, lit
+    from oracle import oracle_np as O
+    import test_gpu_operators as TO
+    parts = [TO.rand_table(900 + i, 6000, 0.1) for i in range(3)]
+    src = g.MemoryExec(parts)
+    s = src.schema()
+    nred = 4
+    writer = g.ShuffleWriterExec("jobS", 1, g.FilterExec(binary(col("k32", s), Op.GtEq, lit(-40, "Int32")), src), str(tmp_path), ([col("k64", s)], nred))
+    stage = g.DefaultExecutionEngine().create_query_stage_exec("jobS", 1, writer, str(tmp_path))
+    locs = []
+    for p in range(3):                                    # one map task per input partition
+        locs += stage.execute_query_stage([p], tc)
+    assert all(os.path.getsize(o["path"]) == o["num_bytes"] for o in locs)
+    reader = g.ShuffleReaderExec([[o for o in locs if o["partition_id"] == q] for q in range(nred)], s)
+    rs = reader.schema()
+    aggs = [{"fn": "SUM", "expr": col("dec", rs), "name": "sd"}, {"fn": "COUNT", "expr": lit(1), "name": "c"}, {"fn": "COUNT", "expr": col("s", rs), "name": "cs"},
+            {"fn": "MIN", "expr": col("d", rs), "name": "md"}]
+    plan = g.AggregateExec("Single", [(col("k64", rs), "k64")], aggs, reader)
+    got = []
+    for q in range(nred):
+        got += TO.dev_rows(tc, plan.execute(q, tc))
+    ot = O.Table.from_arrow(pa.concat_tables(parts))
+    keep = O.filter_rows(ot, binary(col("k32", s), Op.GtEq, lit(-40, "Int32")))
+    exp = TO.ora_rows(O.aggregate(ot.take(keep), [(col("k64", s), "k64")], aggs, "Single"))
+    assert TO.norm(got) == TO.norm(exp)
+    assert reader.metrics.output_rows == len(keep)
+    with pytest.raises(g.GpuqError, match="FetchFailed"):
+        g.ShuffleReaderExec([[{"path": str(tmp_path / "missing.arrow")}]], s).execute(0, tc)
+    assert g.ShuffleReaderExec([[]], s).execute(0, tc).num_rows == 0
