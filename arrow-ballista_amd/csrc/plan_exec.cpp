@@ -19,7 +19,10 @@
 #include "expr_compile.h"
 #include "json.h"
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
+#include <random>
+#include <sys/stat.h>
 #include <functional>
 #include <cstdio>
 #include <cstring>
@@ -737,6 +740,228 @@ struct GlobalLimitExec : PNode {
 
 PNodeP build_child(const Json& v, const char* key) { return build_node(v.at(key)); }
 
+// ---------------------------------------------------------------- stage driver: shuffle sink and source
+// ShuffleWriterExec (ballista/core/src/execution_plans/shuffle_writer.rs:234-456): runs the child for one input partition,
+// optionally hash-partitions its output (BatchPartitioner call site :336-391) and writes one Arrow IPC stream with LZ4_FRAME
+// buffers per non-empty output partition (:358-378; lazily created writers: an empty partition gets no file, :329-334), in the
+// reference's path layout: <work_dir>/<job_id>/<stage_id>/<output partition>/<uuid>.arrow, or .../<stage_id>/<uuid>/data.arrow
+// when the stage is not repartitioned (utils.rs:179-219).  The node's result is the reference's result batch
+// (shuffle_writer.rs:470-520): one row per file -- partition, path, num_rows, num_batches, num_bytes.
+void mkdirs(const std::string& path) {
+  for (size_t i = 1; i <= path.size(); ++i)
+    if (i == path.size() || path[i] == '/') {
+      const std::string d = path.substr(0, i);
+      if (::mkdir(d.c_str(), 0777) != 0 && errno != EEXIST) throw std::runtime_error("cannot create directory " + d + ": " + std::strerror(errno));
+    }
+}
+std::string uuid4() {
+  static thread_local std::mt19937_64 rng{std::random_device{}()};
+  uint64_t a = rng(), b = rng();
+  a = (a & 0xFFFFFFFFFFFF0FFFull) | 0x0000000000004000ull; b = (b & 0x3FFFFFFFFFFFFFFFull) | 0x8000000000000000ull;
+  char buf[40];
+  std::snprintf(buf, sizeof(buf), "%08x-%04x-%04x-%04x-%012llx", (unsigned)(a >> 32), (unsigned)((a >> 16) & 0xFFFF), (unsigned)(a & 0xFFFF), (unsigned)(b >> 48),
+                (unsigned long long)(b & 0xFFFFFFFFFFFFull));
+  return buf;
+}
+void ipc_check(int rc) {
+  if (rc == GPUQ_OK) return;
+  const std::string msg = gpuq_ipc_last_error();
+  if (rc == GPUQ_ERR_UNSUPPORTED) throw Unsupported(msg);
+  if (rc == GPUQ_ERR_CAPACITY) throw Capacity(msg);
+  if (rc == GPUQ_ERR_HIP) throw HipError(msg);
+  throw std::runtime_error(msg);
+}
+struct PinnedBuf {
+  uint8_t* p = nullptr; size_t cap = 0;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  uint8_t* ensure(size_t n) { if (n > cap) { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; HIPCHECK(hipHostMalloc((void**)&p, n, hipHostMallocDefault)); cap = n; } return p; }
+};
+thread_local PinnedBuf g_sink_buf;
+
+// plain table with every Utf8 column in Arrow layout (PACKED15 columns are unpacked)
+PTable arrow_layout(Exec& x, const PTable& in) {
+  PTable t = materialize(x, in);
+  for (auto& c : t.cols) {
+    if (c.c.repr != GPUQ_REPR_PACKED15) continue;
+    const int64_t n = t.n;
+    BufP offs = dev_alloc((size_t)(n + 4) * 4), data = dev_alloc((size_t)n * 15 + 16);
+    int64_t dl = 0;
+    check(x, gpuq_unpack_utf8(x.ctx, x.stream, c.c.data, n, (int32_t*)offs->p, (uint8_t*)data->p, n * 15 + 16, &dl));
+    c.c.repr = GPUQ_REPR_ARROW; c.c.data = data->p; c.c.offsets = (const int32_t*)offs->p;
+    t.keep.push_back(offs); t.keep.push_back(data);
+  }
+  return t;
+}
+
+struct ShuffleFile { int64_t partition; std::string path; int64_t rows, batches, bytes; };
+
+struct ShuffleWriterExec : PNode {
+  PNodeP input; std::string job_id, work_dir; int64_t stage_id = 0; bool hashed = false; Json hash_expr; int64_t partition_count = 0; int64_t batch_rows = 1 << 20;
+  int64_t write_ns = 0, repart_ns = 0, input_rows = 0;      // ShuffleWriteMetrics, shuffle_writer.rs:139-160
+  std::vector<PNode*> children() override { return {input.get()}; }
+
+  ShuffleFile write_file(Exec& x, const PTable& view, int64_t partition, const std::string& path) {
+    PTable t = arrow_layout(x, view);
+    std::vector<gpuq_field_info> fields(t.cols.size());
+    size_t raw = 0;
+    for (size_t i = 0; i < t.cols.size(); ++i) {
+      gpuq_field_info& f = fields[i]; f = gpuq_field_info{};
+      std::snprintf(f.name, sizeof(f.name), "%s", t.cols[i].name.c_str());
+      f.type = t.cols[i].c.type; f.precision = t.cols[i].c.precision; f.scale = t.cols[i].c.scale; f.nullable = t.cols[i].nullable; f.repr = GPUQ_REPR_ARROW;
+    }
+    mkdirs(path.substr(0, path.rfind('/')));
+    FILE* fp = std::fopen(path.c_str(), "wb");
+    if (!fp) throw std::runtime_error("cannot create " + path + ": " + std::strerror(errno));
+    ShuffleFile sf{partition, path, t.n, 0, 0};
+    try {
+      auto put = [&](const void* p, size_t n) { if (n && std::fwrite(p, 1, n, fp) != n) throw std::runtime_error("short write to " + path); sf.bytes += (int64_t)n; };
+      int64_t len = 0;
+      ipc_check(gpuq_ipc_schema_message(fields.data(), (int)fields.size(), nullptr, 0, &len));
+      std::vector<uint8_t> sm((size_t)len);
+      ipc_check(gpuq_ipc_schema_message(fields.data(), (int)fields.size(), sm.data(), len, &len));
+      put(sm.data(), sm.size());
+      const int64_t step = std::max<int64_t>(64, (batch_rows + 63) / 64 * 64);      // batches start on bitmap words: row ranges are pointer arithmetic
+      // Utf8 byte counts of the whole partition, for the output bound of a batch
+      for (int64_t lo = 0; lo < t.n; lo += step) {
+        const int64_t k = std::min(step, t.n - lo);
+        std::vector<gpuq_column> cols;
+        raw = 4096;
+        for (auto& c : t.cols) {
+          gpuq_column v = c.c; v.length = k;
+          DType dt; dt.id = v.type; dt.p = v.precision; dt.s = v.scale;
+          if (v.validity) v.validity += lo / 8;
+          if (v.type == T_UTF8) { v.offsets += lo; raw += (size_t)(k + 1) * 4 + 64; }
+          else if (v.type == T_BOOL) { v.data = (const uint8_t*)v.data + lo / 8; raw += (size_t)k / 8 + 64; }
+          else { v.data = (const char*)v.data + (size_t)lo * (size_t)type_width(dt); raw += (size_t)k * (size_t)type_width(dt) + 64; }
+          raw += (size_t)k / 8 + 64;
+          cols.push_back(v);
+        }
+        // string bytes: not known on the host; ask for the size only when the first guess (32 B per string) is too small
+        size_t guess = raw; for (auto& c : t.cols) if (c.c.type == T_UTF8) guess += (size_t)k * 32;
+        uint8_t* hb = g_sink_buf.ensure(guess);
+        int rc = gpuq_ipc_encode_batch(x.ctx, x.stream, cols.data(), (int)cols.size(), k, 0, hb, (int64_t)g_sink_buf.cap, &len);
+        if (rc == GPUQ_ERR_CAPACITY) { hb = g_sink_buf.ensure((size_t)len); rc = gpuq_ipc_encode_batch(x.ctx, x.stream, cols.data(), (int)cols.size(), k, 0, hb, (int64_t)g_sink_buf.cap, &len); }
+        ipc_check(rc);
+        put(hb, (size_t)len);
+        sf.batches += 1;
+      }
+      static const uint8_t eos[8] = {0xFF, 0xFF, 0xFF, 0xFF, 0, 0, 0, 0};
+      put(eos, 8);
+    } catch (...) { std::fclose(fp); throw; }
+    if (std::fclose(fp) != 0) throw std::runtime_error("cannot close " + path);
+    return sf;
+  }
+
+  PTable execute(int part, Exec& x) override {
+    auto t0 = std::chrono::steady_clock::now();
+    PTable t = input->execute(part, x);
+    input_rows += t.n;
+    const std::string base = work_dir + "/" + job_id + "/" + std::to_string(stage_id);
+    std::vector<ShuffleFile> files;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ns = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
+    if (!hashed) {
+      auto tw = now();
+      files.push_back(write_file(x, t, part, base + "/" + uuid4() + "/data.arrow"));
+      write_ns += ns(tw, now());
+    } else {
+      auto tr = now();
+      PSchema ps = plain_schema(t);
+      std::vector<std::string> names; for (auto& f : ps) names.push_back(f.name);
+      gpuq_op* op = cached_op(x, this, 0, table_sig(t), [&]() {
+        Json he = jarr(); for (auto& e : hash_expr.a) he.a.push_back(rebind(e, names));
+        return jobj({{"op", jstr("partition")}, {"input", jobj({{"fields", table_fields(t)}})}, {"hash_expr", he}, {"partition_count", jnum(partition_count)}});
+      });
+      BufP perm = dev_alloc((size_t)std::max<int64_t>(1, t.n) * 4), offs = dev_alloc((size_t)(partition_count + 2) * 8);
+      InputC ic; make_input(t, ic);
+      check(x, gpuq_partition_run(op, x.stream, &ic.in, (uint32_t*)perm->p, (uint64_t*)offs->p));
+      std::vector<uint64_t> o((size_t)partition_count + 1);
+      HIPCHECK(hipMemcpyAsync(o.data(), offs->p, o.size() * 8, hipMemcpyDeviceToHost, (hipStream_t)x.stream));
+      HIPCHECK(hipStreamSynchronize((hipStream_t)x.stream));
+      repart_ns += ns(tr, now());
+      auto tw = now();
+      for (int64_t q = 0; q < partition_count; ++q) {
+        const int64_t cnt = (int64_t)(o[(size_t)q + 1] - o[(size_t)q]);
+        if (cnt == 0) continue;
+        PTable v = select_view(x, t, (const uint32_t*)perm->p + o[(size_t)q], cnt, perm);
+        files.push_back(write_file(x, v, q, base + "/" + std::to_string(q) + "/" + uuid4() + ".arrow"));
+      }
+      write_ns += ns(tw, now());
+    }
+    // the result batch: partition, path, num_rows, num_batches, num_bytes
+    const int64_t n = (int64_t)files.size();
+    std::vector<uint32_t> pid; std::vector<int32_t> poff{0}; std::string pdata; std::vector<uint64_t> rows, batches, bytes;
+    for (auto& f : files) { pid.push_back((uint32_t)f.partition); pdata += f.path; poff.push_back((int32_t)pdata.size()); rows.push_back((uint64_t)f.rows); batches.push_back((uint64_t)f.batches); bytes.push_back((uint64_t)f.bytes); }
+    PTable out; out.n = n;
+    auto up = [&](const void* src, size_t nbytes) -> BufP {
+      BufP b = dev_alloc(nbytes + 16);
+      if (nbytes) HIPCHECK(hipMemcpyAsync(b->p, src, nbytes, hipMemcpyHostToDevice, (hipStream_t)x.stream));
+      out.keep.push_back(b); return b;
+    };
+    auto fixed = [&](const char* name, int tid, const void* src, size_t w) {
+      PCol c; c.name = name; c.type = type_json_of(tid, 0, 0); c.nullable = false; c.c.type = tid; c.c.repr = GPUQ_REPR_ARROW; c.c.length = n; c.c.data = up(src, (size_t)n * w)->p;
+      out.cols.push_back(c); out.sides.push_back(0);
+    };
+    fixed("partition", T_UINT32, pid.data(), 4);
+    { PCol c; c.name = "path"; c.type = jstr("Utf8"); c.nullable = false; c.c.type = T_UTF8; c.c.repr = GPUQ_REPR_ARROW; c.c.length = n;
+      c.c.offsets = (const int32_t*)up(poff.data(), poff.size() * 4)->p; c.c.data = up(pdata.data(), pdata.size())->p; out.cols.push_back(c); out.sides.push_back(0); }
+    fixed("num_rows", T_UINT64, rows.data(), 8); fixed("num_batches", T_UINT64, batches.data(), 8); fixed("num_bytes", T_UINT64, bytes.data(), 8);
+    HIPCHECK(hipStreamSynchronize((hipStream_t)x.stream));      // the uploads read host vectors that die with this frame
+    m.elapsed_ns += ns(t0, now());
+    for (auto& f : files) m.output_rows += f.rows;
+    return out;
+  }
+};
+
+// ShuffleReaderExec (ballista/core/src/execution_plans/shuffle_reader.rs:149-177): output partition p = the IPC streams of its
+// locations, decoded on the device in one launch per file.  Local files only (a remote location is the Flight client's job);
+// a missing file is the reference's FetchFailed (:654), which makes the scheduler re-run the map stage.
+struct ShuffleReaderExec : PNode {
+  PSchema schema; std::vector<std::vector<std::string>> locations;
+  int partitions() override { return (int)locations.size(); }
+  PTable execute(int part, Exec& x) override {
+    auto t0 = std::chrono::steady_clock::now();
+    if (part < 0 || part >= (int)locations.size()) throw std::runtime_error("ShuffleReaderExec: partition out of range");
+    std::vector<gpuq_field_info> fields(schema.size());
+    for (size_t i = 0; i < schema.size(); ++i) {
+      gpuq_field_info& f = fields[i]; f = gpuq_field_info{};
+      std::snprintf(f.name, sizeof(f.name), "%s", schema[i].name.c_str());
+      int p, s; f.type = type_id_of(schema[i].type, p, s); f.precision = p; f.scale = s; f.nullable = schema[i].nullable; f.repr = GPUQ_REPR_ARROW;
+    }
+    std::vector<PTable> parts;
+    std::vector<uint8_t> bytes;
+    auto wrap = [&](gpuq_ipc_batch* b) {
+      PTable t; t.n = gpuq_ipc_batch_num_rows(b);
+      t.keep.push_back(BufP(new DevBuf(), [b](DevBuf* d) { delete d; gpuq_ipc_batch_free(b); }));
+      for (size_t i = 0; i < schema.size(); ++i) {
+        PCol c; c.name = schema[i].name; c.type = schema[i].type; c.nullable = schema[i].nullable;
+        gpuq_ipc_batch_column(b, (int)i, &c.c);
+        t.cols.push_back(c); t.sides.push_back(0);
+      }
+      return t;
+    };
+    for (auto& path : locations[(size_t)part]) {
+      FILE* fp = std::fopen(path.c_str(), "rb");
+      if (!fp) throw std::runtime_error("FetchFailed: shuffle partition file " + path + " cannot be opened: " + std::strerror(errno));
+      std::fseek(fp, 0, SEEK_END); const long sz = std::ftell(fp); std::fseek(fp, 0, SEEK_SET);
+      bytes.resize((size_t)std::max<long>(sz, 0));
+      const size_t got = bytes.empty() ? 0 : std::fread(bytes.data(), 1, bytes.size(), fp);
+      std::fclose(fp);
+      if (got != bytes.size()) throw std::runtime_error("short read from " + path);
+      gpuq_ipc_batch* b = nullptr;
+      ipc_check(gpuq_ipc_decode_stream(x.ctx, x.stream, bytes.data(), (int64_t)bytes.size(), fields.data(), (int)fields.size(), &b));
+      parts.push_back(wrap(b));
+    }
+    if (parts.empty()) {
+      static const uint8_t eos[8] = {0xFF, 0xFF, 0xFF, 0xFF, 0, 0, 0, 0};
+      gpuq_ipc_batch* b = nullptr;
+      ipc_check(gpuq_ipc_decode_stream(x.ctx, x.stream, eos, 8, fields.data(), (int)fields.size(), &b));
+      parts.push_back(wrap(b));
+    }
+    return timed(t0, parts.size() == 1 ? parts[0] : concat_tables(x, std::move(parts)));
+  }
+};
+
 PNodeP build_node(const Json& j) {
   if (!j.is_obj() || j.o.size() != 1) throw std::runtime_error("plan: a node is an object with one key (the node type): " + j.dump().substr(0, 80));
   const std::string& kind = j.o[0].first; const Json& v = j.o[0].second;
@@ -784,6 +1009,21 @@ PNodeP build_node(const Json& j) {
     auto n = std::make_unique<GlobalLimitExec>(); n->input = build_child(v, "input"); n->skip = v.get_i64("skip", 0); n->fetch = v.get_i64("fetch", -1); out = std::move(n);
   } else if (kind == "LocalLimitExec") {
     auto n = std::make_unique<LimitExec>(); n->input = build_child(v, "input"); n->fetch = v.at("fetch").i64(); out = std::move(n);
+  } else if (kind == "ShuffleWriterExec") {
+    auto n = std::make_unique<ShuffleWriterExec>(); n->input = build_child(v, "input");
+    n->job_id = v.at("job_id").str(); n->stage_id = v.at("stage_id").i64(); n->work_dir = v.at("work_dir").str(); n->batch_rows = v.get_i64("batch_rows", 1 << 20);
+    if (n->work_dir.empty()) throw std::runtime_error("ShuffleWriterExec: work_dir is empty (the decoded plan carries \"\"; the engine sets the executor's, serde/mod.rs:191)");
+    if (v.has("output_partitioning")) {
+      const Json& op = v.at("output_partitioning");
+      n->hashed = true; n->hash_expr = op.at("hash_expr"); n->partition_count = op.at("partition_count").i64();
+      if (n->partition_count < 1) throw std::runtime_error("ShuffleWriterExec: partition_count must be >= 1");
+    }
+    out = std::move(n);
+  } else if (kind == "ShuffleReaderExec") {
+    auto n = std::make_unique<ShuffleReaderExec>();
+    for (auto& f : v.at("schema").a) n->schema.push_back({f.at("name").str(), f.at("type"), f.get_bool("nullable", true)});
+    for (auto& p : v.at("partition").a) { n->locations.emplace_back(); for (auto& l : p.a) n->locations.back().push_back(l.is_obj() ? l.at("path").str() : l.str()); }
+    out = std::move(n);
   } else throw Unsupported("plan: node type '" + kind + "' is not executed natively");
   out->kind = kind;
   return out;
@@ -893,7 +1133,12 @@ int gpuq_plan_metrics(gpuq_plan* p, char* buf, size_t cap) {
   std::vector<PNode*> nodes; collect(p->root.get(), nodes);
   std::string s = "[";
   for (size_t i = 0; i < nodes.size(); ++i)
-    s += std::string(i ? "," : "") + "{\"node\":\"" + nodes[i]->kind + "\",\"output_rows\":" + std::to_string(nodes[i]->m.output_rows) + ",\"elapsed_compute\":" + std::to_string(nodes[i]->m.elapsed_ns) + "}";
+  {
+    s += std::string(i ? "," : "") + "{\"node\":\"" + nodes[i]->kind + "\",\"output_rows\":" + std::to_string(nodes[i]->m.output_rows) + ",\"elapsed_compute\":" + std::to_string(nodes[i]->m.elapsed_ns);
+    if (auto* w = dynamic_cast<ShuffleWriterExec*>(nodes[i]))
+      s += ",\"write_time\":" + std::to_string(w->write_ns) + ",\"repart_time\":" + std::to_string(w->repart_ns) + ",\"input_rows\":" + std::to_string(w->input_rows);
+    s += "}";
+  }
   s += "]";
   if (s.size() + 1 > cap) return GPUQ_ERR_CAPACITY;
   std::memcpy(buf, s.c_str(), s.size() + 1);

@@ -114,6 +114,99 @@ std::vector<uint8_t> build_batch_metadata(const BatchMeta& m) {
   return b;
 }
 
+// ---- Schema message (Schema.fbs): Message{V5, Schema{endianness Little, fields:[Field{name, nullable, type, children:[]}]}, bodyLength 0}.
+// A small front-to-back flatbuffer writer: a table is written with its vtable in front of it and zeroed offset slots; whatever
+// a slot refers to is appended later and the slot patched (uoffsets point forward, as the format requires).
+struct FbWriter {
+  std::vector<uint8_t> b;
+  struct Slot { int id; int size; uint64_t value; };
+  void align(size_t a) { while (b.size() % a) b.push_back(0); }
+  void put(size_t at, const void* p, size_t n) { std::memcpy(&b[at], p, n); }
+  size_t grow(size_t n) { const size_t at = b.size(); b.resize(at + n, 0); return at; }
+  // returns the table position; where[id] = absolute position of the field
+  size_t table(int n_ids, const std::vector<Slot>& slots, std::vector<size_t>& where) {
+    align(4);
+    const size_t vsize = 4 + 2 * (size_t)n_ids;
+    size_t vt = grow(vsize); align(4);
+    // 8-byte fields need absolute 8-byte alignment: start the table so that (table + 4) is 8-aligned when one is present
+    bool wide = false; for (auto& sl : slots) wide |= sl.size == 8;
+    if (wide) while ((b.size() + 4) % 8) b.push_back(0);
+    const size_t t = grow(4);
+    where.assign((size_t)n_ids, 0);
+    for (auto& sl : slots) {
+      while ((b.size()) % (size_t)sl.size) b.push_back(0);
+      const size_t at = grow((size_t)sl.size);
+      put(at, &sl.value, (size_t)sl.size);
+      where[(size_t)sl.id] = at;
+    }
+    align(4);
+    const uint16_t vs = (uint16_t)vsize, ts = (uint16_t)(b.size() - t);
+    put(vt, &vs, 2); put(vt + 2, &ts, 2);
+    for (auto& sl : slots) { const uint16_t off = (uint16_t)(where[(size_t)sl.id] - t); put(vt + 4 + 2 * (size_t)sl.id, &off, 2); }
+    const int32_t so = (int32_t)(t - vt); put(t, &so, 4);
+    return t;
+  }
+  void point(size_t slot_at, size_t target) { const uint32_t u = (uint32_t)(target - slot_at); put(slot_at, &u, 4); }
+  size_t string(const std::string& x) {
+    align(4);
+    const size_t at = grow(4 + x.size() + 1);
+    const uint32_t n = (uint32_t)x.size(); put(at, &n, 4); if (n) put(at + 4, x.data(), n);
+    align(4);
+    return at;
+  }
+};
+
+std::vector<uint8_t> build_schema_metadata(const gpuq_field_info* fields, int n_cols) {
+  FbWriter w;
+  std::vector<size_t> at;
+  w.grow(4);                                                                        // root uoffset
+  const size_t msg = w.table(4, {{3, 8, 0}, {2, 4, 0}, {0, 2, 4 /* V5 */}, {1, 1, 1 /* MessageHeader Schema */}}, at);
+  w.point(0, msg);
+  const size_t msg_header = at[2];
+  const size_t sch = w.table(4, {{1, 4, 0}, {0, 2, 0 /* Endianness Little */}}, at);
+  w.point(msg_header, sch);
+  const size_t sch_fields = at[1];
+  w.align(4);
+  const size_t vec = w.grow(4 + 4 * (size_t)n_cols);
+  { const uint32_t n = (uint32_t)n_cols; w.put(vec, &n, 4); }
+  w.point(sch_fields, vec);
+  for (int c = 0; c < n_cols; ++c) {
+    const gpuq_field_info& f = fields[c];
+    int type_type = 0;
+    switch (f.type) {
+      case GPUQ_INT32: case GPUQ_INT64: case GPUQ_UINT32: case GPUQ_UINT64: type_type = 2; break;
+      case GPUQ_FLOAT64: type_type = 3; break;
+      case GPUQ_UTF8: type_type = 5; break;
+      case GPUQ_BOOL: type_type = 6; break;
+      case GPUQ_DECIMAL128: type_type = 7; break;
+      case GPUQ_DATE32: type_type = 8; break;
+      default: throw Unsupported("IPC schema for column type " + std::to_string(f.type));
+    }
+    const size_t ft = w.table(6, {{0, 4, 0}, {3, 4, 0}, {5, 4, 0}, {1, 1, (uint64_t)(f.nullable ? 1 : 0)}, {2, 1, (uint64_t)type_type}}, at);
+    w.point(vec + 4 + 4 * (size_t)c, ft);
+    const size_t a_name = at[0], a_type = at[3], a_children = at[5];
+    w.point(a_name, w.string(std::string(f.name, strnlen(f.name, sizeof(f.name)))));
+    std::vector<size_t> ta;
+    size_t tt = 0;
+    switch (f.type) {
+      case GPUQ_INT32: tt = w.table(2, {{0, 4, 32}, {1, 1, 1}}, ta); break;
+      case GPUQ_INT64: tt = w.table(2, {{0, 4, 64}, {1, 1, 1}}, ta); break;
+      case GPUQ_UINT32: tt = w.table(2, {{0, 4, 32}, {1, 1, 0}}, ta); break;
+      case GPUQ_UINT64: tt = w.table(2, {{0, 4, 64}, {1, 1, 0}}, ta); break;
+      case GPUQ_FLOAT64: tt = w.table(1, {{0, 2, 2 /* DOUBLE */}}, ta); break;
+      case GPUQ_UTF8: case GPUQ_BOOL: tt = w.table(0, {}, ta); break;
+      case GPUQ_DECIMAL128: tt = w.table(3, {{0, 4, (uint64_t)f.precision}, {1, 4, (uint64_t)f.scale}, {2, 4, 128}}, ta); break;
+      case GPUQ_DATE32: tt = w.table(1, {{0, 2, 0 /* DateUnit DAY */}}, ta); break;
+    }
+    w.point(a_type, tt);
+    w.align(4);
+    const size_t kids = w.grow(4);                                                 // empty children vector (Arrow C++ insists on its presence)
+    w.point(a_children, kids);
+  }
+  w.align(8);
+  return w.b;
+}
+
 int type_width_of(int type) {
   switch (type) {
     case GPUQ_INT32: case GPUQ_DATE32: case GPUQ_UINT32: return 4;
@@ -158,6 +251,18 @@ int gpuq_ipc_peek(const uint8_t* bytes, int64_t avail, gpuq_ipc_info* out) {
     const BatchMeta m = parse_message(bytes + 8, (size_t)mlen);
     out->header_type = m.header_type; out->codec = m.codec; out->body_bytes = m.body_len; out->n_rows = m.n_rows;
     out->n_nodes = (int32_t)m.nodes.size(); out->n_buffers = (int32_t)m.buffers.size();
+  });
+}
+
+int gpuq_ipc_schema_message(const gpuq_field_info* fields, int n_cols, uint8_t* out, int64_t cap, int64_t* len_out) {
+  return guarded_ipc([&]() {
+    if (!fields && n_cols > 0) throw std::runtime_error("fields is NULL");
+    const std::vector<uint8_t> fb = build_schema_metadata(fields, n_cols);
+    const int64_t total = 8 + (int64_t)fb.size();
+    if (len_out) *len_out = total;
+    if (!out || cap < total) { if (!out && cap == 0) return; throw Capacity("IPC schema message needs " + std::to_string(total) + " bytes"); }
+    const uint32_t cont = 0xFFFFFFFFu; const int32_t mlen = (int32_t)fb.size();
+    std::memcpy(out, &cont, 4); std::memcpy(out + 4, &mlen, 4); std::memcpy(out + 8, fb.data(), fb.size());
   });
 }
 

@@ -86,6 +86,15 @@ def plan_to_json(node, tc, inputs):
         return {"GlobalLimitExec": {"input": sub(node.input), "skip": int(node.skip), "fetch": -1 if node.fetch is None else int(node.fetch)}}
     if isinstance(node, P.LocalLimitExec):
         return {"LocalLimitExec": {"input": sub(node.input), "fetch": int(node.fetch)}}
+    if isinstance(node, P.ShuffleWriterExec):
+        d = {"input": sub(node.plan), "job_id": node.job_id, "stage_id": int(node.stage_id), "work_dir": node.work_dir}
+        if node.shuffle_output_partitioning is not None:
+            exprs, n = node.shuffle_output_partitioning
+            d["output_partitioning"] = {"hash_expr": list(exprs), "partition_count": int(n)}
+        return {"ShuffleWriterExec": d}
+    if isinstance(node, P.ShuffleReaderExec):
+        return {"ShuffleReaderExec": {"schema": [{"name": f["name"], "type": f["type"], "nullable": bool(f.get("nullable", True))} for f in node.schema()],
+                                      "partition": [[{"path": (l["path"] if isinstance(l, dict) else l)} for l in p] for p in node.partition]}}
     raise B.GpuqError(3, "plan node %s is not executed natively" % t)
 
 

@@ -259,6 +259,13 @@ int gpuq_copy_bits(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_of
      {"CoalesceBatchesExec": {"input"}}  {"LocalLimitExec": {"input","fetch"}}       (:1487-1490, :1460-1463)
      {"GlobalLimitExec": {"input","skip","fetch"}}  {"UnionExec": {"inputs": [node]}}  {"CoalescePartitionsExec": {"input"}}   (:1453, :1319, :1492)
      {"CoalesceTasksExec": {"input","partitions": [p],"order_by"?: [sort expr]}}     (ballista coalesce_tasks.rs:46-70)
+     {"ShuffleWriterExec": {"input","job_id","stage_id","work_dir","output_partitioning"?: {"hash_expr": [expr], "partition_count": n},
+                            "batch_rows"?: rows per RecordBatch, default 2^20}}      (ballista shuffle_writer.rs:234-456: the stage root)
+         writes <work_dir>/<job_id>/<stage_id>/<q>/<uuid>.arrow per non-empty output partition q (unpartitioned:
+         .../<stage_id>/<uuid>/data.arrow), Arrow IPC stream + LZ4_FRAME; result = one row per file:
+         partition UInt32, path Utf8, num_rows / num_batches / num_bytes UInt64 (shuffle_writer.rs:470-520)
+     {"ShuffleReaderExec": {"schema": [{"name","type","nullable"}], "partition": [[{"path"} | path, ...], ...]}}   (shuffle_reader.rs:149-177;
+         local files; a file that cannot be opened is reported as "FetchFailed: ...")
    Expressions are the PhysicalExprNode mirror of gpuq_op_create; columns are resolved by NAME against each operator's input.
    gpuq_plan_execute runs one output partition: inputs[k] is the table MemoryExec leaves refer to as slot k (caller-owned device
    memory, must stay valid until the call returns); *out is a materialised result owned by the library (gpuq_result_free).
@@ -269,7 +276,7 @@ int gpuq_plan_create(gpuq_ctx* ctx, const char* plan_json, gpuq_plan** out);
 void gpuq_plan_free(gpuq_plan* plan);
 int gpuq_plan_num_partitions(gpuq_plan* plan);
 int gpuq_plan_execute(gpuq_plan* plan, void* stream, int partition, const gpuq_input* inputs, int n_inputs, gpuq_result** out);
-int gpuq_plan_metrics(gpuq_plan* plan, char* json_out, size_t cap);     /* per node: output_rows, elapsed_compute (ns) -- utils.rs:470-481 */
+int gpuq_plan_metrics(gpuq_plan* plan, char* json_out, size_t cap);     /* per node: output_rows, elapsed_compute (ns) -- utils.rs:470-481; ShuffleWriterExec adds write_time, repart_time, input_rows (shuffle_writer.rs:139-160) */
 const char* gpuq_plan_last_error(void);
 /* gpuq_op_profile over every operator the plan has compiled: enable/disable the HIP-event bracket around each operator's
    dominant kernel and report the operator with the most accumulated kernel time (its descriptor text in op_desc_out). */
@@ -305,6 +312,9 @@ typedef struct gpuq_ipc_batch gpuq_ipc_batch;
 /* Host only: parses the message that starts at `bytes`.  GPUQ_ERR_CAPACITY when `avail` does not cover the metadata yet
    (out->metadata_bytes is set once the first 8 bytes are there). */
 int gpuq_ipc_peek(const uint8_t* bytes, int64_t avail, gpuq_ipc_info* out);
+/* Host only: the encapsulated Schema message that opens a stream of these fields (name, type, precision, scale, nullable are
+   read) -- what `IpcDataGenerator::schema_to_bytes` / `Schema.serialize()` produce.  Size query with out == NULL && cap == 0. */
+int gpuq_ipc_schema_message(const gpuq_field_info* fields, int n_cols, uint8_t* out, int64_t cap, int64_t* len_out);
 /* cols: device columns in GPUQ_REPR_ARROW layout, all of n_rows rows.  codec: 0 = LZ4_FRAME, -1 = uncompressed.  Writes the
    message to out_host (host memory, cap bytes) and its length to *len_out.  out_host == NULL && cap == 0: size query (the
    compression runs, nothing is copied).  GPUQ_ERR_CAPACITY (with *len_out set) when cap is too small.  Synchronous. */

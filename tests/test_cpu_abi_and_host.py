@@ -190,3 +190,46 @@ def test_ipc_peek_walks_an_arrow_cpp_stream_on_the_host():
     assert L.gpuq_ipc_peek(C.c_void_p(C.addressof(buf)), 12, C.byref(info)) == 4 and info.metadata_bytes > 12
     junk = (C.c_uint8 * 64)(*([7] * 64))
     assert L.gpuq_ipc_peek(C.c_void_p(C.addressof(junk)), 64, C.byref(info)) == 1
+
+
+def test_ipc_schema_message_is_read_by_arrow_cpp():
+    """gpuq_ipc_schema_message (hand-written Schema.fbs flatbuffer) parsed by Arrow C++: every supported type, nullability,
+    empty and non-ASCII names; schema + end-of-stream marker is a valid empty stream."""
+    import ctypes as C
+    import pyarrow as pa
+    from arrow_ballista_amd import binding as B
+    from arrow_ballista_amd.shuffle import EOS, _fields_of
+    L = B.lib()
+    sch = pa.schema([pa.field("a", pa.int64(), False), pa.field("b", pa.int32()), pa.field("u32", pa.uint32()), pa.field("u64", pa.uint64(), False),
+                     pa.field("f", pa.float64()), pa.field("s", pa.string()), pa.field("flag", pa.bool_(), False), pa.field("dec", pa.decimal128(15, 2)),
+                     pa.field("d", pa.date32()), pa.field("", pa.decimal128(38, 10)), pa.field("ünï", pa.string(), False)])
+    for s in (sch, pa.schema([]), pa.schema([pa.field("x" * 200, pa.date32())])):
+        fields, _ = _fields_of(s)
+        ln = C.c_int64(0)
+        assert L.gpuq_ipc_schema_message(fields, len(s), None, 0, C.byref(ln)) == 0 and ln.value % 8 == 0
+        buf = (C.c_uint8 * ln.value)()
+        assert L.gpuq_ipc_schema_message(fields, len(s), buf, ln.value - 1, C.byref(ln)) == 4          # CAPACITY
+        assert L.gpuq_ipc_schema_message(fields, len(s), buf, ln.value, C.byref(ln)) == 0
+        raw = bytes(buf)
+        assert pa.ipc.read_schema(pa.py_buffer(raw)).equals(s)
+        t = pa.ipc.open_stream(raw + EOS).read_all()
+        assert t.num_rows == 0 and t.schema.equals(s)
+
+
+def test_native_plan_parses_the_stage_driver_nodes():
+    """ShuffleWriterExec / ShuffleReaderExec in the native plan grammar: parsed and validated on the host (no device)."""
+    import ctypes as C
+    import json
+    from arrow_ballista_amd import binding as B
+    L = B.lib()
+    leaf = {"ShuffleReaderExec": {"schema": [{"name": "k", "type": "Int64", "nullable": False}, {"name": "v", "type": {"Decimal128": [15, 2]}, "nullable": True}],
+                                  "partition": [[{"path": "/tmp/a.arrow"}, {"path": "/tmp/b.arrow"}], [], ["/tmp/c.arrow"]]}}
+    col = {"column": {"name": "k", "index": 0}}
+    plan = {"ShuffleWriterExec": {"input": leaf, "job_id": "j", "stage_id": 4, "work_dir": "/tmp/w", "output_partitioning": {"hash_expr": [col], "partition_count": 8}}}
+    h = C.c_void_p()
+    ctx = C.c_void_p(1)       # never dereferenced by gpuq_plan_create
+    assert L.gpuq_plan_create(ctx, json.dumps(plan).encode(), C.byref(h)) == 0, L.gpuq_plan_last_error()
+    assert L.gpuq_plan_num_partitions(h) == 3
+    L.gpuq_plan_free(h)
+    plan["ShuffleWriterExec"]["work_dir"] = ""
+    assert L.gpuq_plan_create(ctx, json.dumps(plan).encode(), C.byref(h)) == 1 and b"work_dir" in L.gpuq_plan_last_error()
