@@ -110,6 +110,7 @@ def lib():
         "gpuq_unpack_utf8": (i32, [vp, vp, vp, i64, vp, vp, i64, C.POINTER(i64)]),
         "gpuq_offsets_rebase": (i32, [vp, vp, vp, i64, i32, vp]),
         "gpuq_take_utf8": (i32, [vp, vp, C.POINTER(gpuq_column), vp, i64, vp, vp, vp, i64, C.POINTER(i64)]),
+        "gpuq_like_utf8": (i32, [vp, vp, C.POINTER(gpuq_column), vp, i64, C.c_char_p, i32, i32, vp, vp]),
         "gpuq_concat_bitmap": (i32, [vp, vp, vp, i64, vp, i64]),
         "gpuq_copy_bits": (i32, [vp, vp, vp, i64, vp, i64, i64]),
         "gpuq_plan_create": (i32, [vp, C.c_char_p, C.POINTER(vp)]),

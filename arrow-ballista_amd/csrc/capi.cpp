@@ -1224,6 +1224,39 @@ int gpuq_offsets_rebase(gpuq_ctx* ctx, void* stream, const int32_t* src, int64_t
   });
 }
 
+// ---------------------------------------------------------------- LIKE
+int gpuq_like_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, const char* pattern, int negated, int case_insensitive,
+                   uint8_t* bits_out, uint8_t* validity_out) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!col || !pattern || (n > 0 && !bits_out)) throw std::runtime_error("col/pattern/bits_out is NULL");
+    if (col->type != T_UTF8 || col->repr != GPUQ_REPR_ARROW || (n > 0 && !col->offsets)) throw Unsupported("LIKE needs a Utf8 column in Arrow layout (offsets + bytes)");
+    if (case_insensitive) throw Unsupported("ILIKE (case_insensitive) is not supported on device: arrow upper-cases both sides with full Unicode case mapping");
+    const std::string r = pattern;
+    auto wild = [](char c) { return c == '%' || c == '_'; };
+    auto has_wild = [&](size_t a, size_t b) { for (size_t i = a; i < b; ++i) if (wild(r[i])) return true; return false; };
+    auto ends_with_esc = [&]() { return r.size() >= 2 && r[r.size() - 2] == '\\' && r.back() == '%'; };
+    // arrow-string 49 like.rs op_scalar: the shapes served without a regex [UPSTREAM-KNOWLEDGE]
+    bool fast = false;
+    const size_t L = r.size();
+    if (!has_wild(0, L)) fast = true;                                                                            // equality
+    else if (r.back() == '%' && !ends_with_esc() && !has_wild(0, L - 1)) fast = true;                            // starts_with
+    else if (r.front() == '%' && !has_wild(1, L)) fast = true;                                                   // ends_with
+    else if (L >= 2 && r.front() == '%' && r.back() == '%' && !ends_with_esc() && !has_wild(1, L - 1)) fast = true;   // contains
+    LikePattern pat{}; pat.regex_mode = fast ? 0 : 1;
+    auto push = [&](int t) { if (pat.n >= LIKE_MAX_TOKENS) throw Unsupported("LIKE pattern longer than 256 tokens"); pat.tok[pat.n++] = (uint16_t)t; };
+    for (size_t i = 0; i < L; ++i) {
+      const char c = r[i];
+      if (c == '\\' && i + 1 < L && wild(r[i + 1])) { push((uint8_t)r[i + 1]); ++i; }      // \% and \_ are literals; any other backslash is itself
+      else if (c == '%') { if (!(pat.n > 0 && pat.tok[pat.n - 1] == 257)) push(257); }
+      else if (c == '_') push(256);
+      else push((uint8_t)c);
+    }
+    launch_like_utf8((hipStream_t)stream, (const uint8_t*)col->data, col->offsets, col->validity, idx, n, pat, negated ? 1 : 0, (u64*)bits_out, (u64*)validity_out);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
 // ---------------------------------------------------------------- utf8 unpack
 int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n, int32_t* offsets_out, uint8_t* data_out, int64_t data_cap,
                      int64_t* data_len_out) {

@@ -142,6 +142,10 @@ void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64
 void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa, const uint32_t* n_groups_dev = nullptr);
 void launch_concat_bitmap(hipStream_t s, u64* dst, i64 dst_bit_offset, const uint8_t* src, i64 src_bit_offset, i64 n_bits);
 void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out, uint32_t* too_long);
+constexpr int LIKE_MAX_TOKENS = 256;
+struct LikePattern { int32_t n; int32_t regex_mode; uint16_t tok[LIKE_MAX_TOKENS]; };     // 0..255 literal byte, 256 '_', 257 '%'
+void launch_like_utf8(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, const LikePattern& pat, int negated,
+                      u64* bits_out, u64* valid_out);
 void launch_offsets_rebase(hipStream_t s, const int32_t* src, i64 n, int32_t delta, int32_t* dst);
 void launch_take_utf8_lengths(hipStream_t s, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int32_t* lens, u64* valid_out);
 void launch_take_utf8_bytes(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint32_t* idx, i64 n, const int32_t* out_offsets, uint8_t* out, i64 total_bytes);

@@ -1038,6 +1038,54 @@ __global__ void __launch_bounds__(BLOCK) k_concat_bitmap(u64* dst, const i64 off
 void launch_concat_bitmap(hipStream_t s, u64* dst, i64 off, const uint8_t* src, i64 src_off, i64 n) {
   if (n > 0) hipLaunchKernelGGL(k_concat_bitmap, dim3(lin_grid((n + 127) / 64)), dim3(BLOCK), 0, s, dst, off, src, src_off, n);
 }
+// SQL LIKE of an Arrow-layout Utf8 column against a literal pattern (DataFusion LikeExpr -> arrow-string 49 `like` / `nlike`
+// with a scalar pattern).  One lane per string; a wave's ballot is one word of the result bitmap.  Pattern tokens: 0..255 a
+// literal byte, 256 = '_' (one UTF-8 character), 257 = '%' (any run).  Greedy matching with one backtrack point (the last '%').
+// regex_mode: the pattern is none of arrow's fast shapes (equality, prefix%, %suffix, %infix%) and goes through its regex
+// translation, where '.' does not match a newline: '_' and '%' then refuse '\n' [UPSTREAM-KNOWLEDGE, arrow-string 49 like.rs].
+__device__ __forceinline__ int utf8_len(uint8_t b) { return b < 0x80 ? 1 : (b < 0xE0 ? 2 : (b < 0xF0 ? 3 : 4)); }
+__global__ void __launch_bounds__(BLOCK) k_like_utf8(const uint8_t* __restrict__ data, const int32_t* __restrict__ offsets, const uint8_t* __restrict__ validity,
+                                                     const uint32_t* __restrict__ idx, const i64 n, const LikePattern pat, const int negated,
+                                                     u64* __restrict__ bits_out, u64* __restrict__ valid_out) {
+  __shared__ uint16_t tok[LIKE_MAX_TOKENS];
+  for (int i = (int)threadIdx.x; i < pat.n; i += BLOCK) tok[i] = pat.tok[i];
+  __syncthreads();
+  const i64 words = (n + 63) >> 6;
+  for (i64 w = (i64)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); w < words; w += (i64)gridDim.x * (BLOCK / 64)) {
+    const i64 i = w * 64 + (threadIdx.x & 63);
+    bool valid = false, m = false;
+    if (i < n) {
+      const uint32_t r = idx ? idx[i] : (uint32_t)i;
+      valid = r != 0xFFFFFFFFu && (!validity || ((validity[r >> 3] >> (r & 7)) & 1));
+      if (valid) {
+        const uint8_t* str = data + offsets[r];
+        const int len = offsets[r + 1] - offsets[r], plen = pat.n;
+        int s = 0, p = 0, star_p = -1, star_s = 0;
+        bool fail = false;
+        while (s < len) {
+          const int t = p < plen ? (int)tok[p] : -1;
+          if (t >= 0 && t < 256 && str[s] == (uint8_t)t) { ++s; ++p; }
+          else if (t == 256 && !(pat.regex_mode && str[s] == '\n')) { s += utf8_len(str[s]); ++p; }
+          else if (t == 257) { star_p = p; star_s = s; ++p; }
+          else if (star_p >= 0) {
+            if (pat.regex_mode && str[star_s] == '\n') { fail = true; break; }
+            star_s += utf8_len(str[star_s]); s = star_s; p = star_p + 1;
+          } else { fail = true; break; }
+        }
+        if (!fail && s > len) fail = true;                 // a truncated multi-byte character
+        while (!fail && p < plen && tok[p] == 257) ++p;
+        m = !fail && p == plen;
+        if (negated) m = !m;
+      }
+    }
+    const u64 mb = __ballot(valid && m), vb = __ballot(valid);
+    if ((threadIdx.x & 63) == 0) { bits_out[w] = mb; if (valid_out) valid_out[w] = vb; }
+  }
+}
+void launch_like_utf8(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, const LikePattern& pat, int negated,
+                      u64* bits_out, u64* valid_out) {
+  if (n > 0) hipLaunchKernelGGL(k_like_utf8, dim3(lin_grid(n)), dim3(BLOCK), 0, s, data, offsets, validity, idx, n, pat, negated, bits_out, valid_out);
+}
 size_t exclusive_scan_ws_bytes(i64 n) { return (size_t)((n + 1 + SCAN_TILE - 1) / SCAN_TILE + 1) * 8; }
 void launch_exclusive_scan_i32(hipStream_t s, int32_t* data, i64 n, void* workspace, size_t) {
   // data holds n lengths (entry n is scratch); afterwards data[0..n] are the offsets

@@ -119,6 +119,21 @@ template <class Names> Json rebind(const Json& e, const Names& names) {
   });
 }
 std::vector<std::string> names_of(const PTable& t) { std::vector<std::string> v; for (auto& c : t.cols) v.push_back(c.name); return v; }
+bool has_like(const Json& e) {
+  if (e.is_obj()) { for (auto& kv : e.o) if (kv.first == "like_expr" || has_like(kv.second)) return true; return false; }
+  if (e.is_arr()) { for (auto& v : e.a) if (has_like(v)) return true; }
+  return false;
+}
+Json rewrite_like(const Json& e, const std::function<Json(const Json&)>& fn) {
+  if (e.is_obj()) {
+    if (e.o.size() == 1 && e.o[0].first == "like_expr") return fn(e.o[0].second);
+    Json r = jobj();
+    for (auto& kv : e.o) r.o.emplace_back(kv.first, rewrite_like(kv.second, fn));
+    return r;
+  }
+  if (e.is_arr()) { Json r = jarr(); for (auto& v : e.a) r.a.push_back(rewrite_like(v, fn)); return r; }
+  return e;
+}
 
 // ---------------------------------------------------------------- execution context
 struct Exec {
@@ -201,7 +216,54 @@ PTable alloc_outputs(gpuq_op* op, int64_t n, std::vector<gpuq_column>& carr) {
   return t;
 }
 
-PTable project(Exec& x, const PTable& t, const std::vector<Json>& exprs, const std::vector<std::string>& names, const void* site, int tag) {
+// LIKE runs as its own kernel over the Arrow-layout bytes (gpuq_like_utf8): every like_expr node becomes a reference to a Boolean
+// column appended to a copy of the table.  The operand must be a column of `t`, the pattern a Utf8 literal.
+PTable lower_like(Exec& x, const PTable& t, std::vector<Json>& exprs) {
+  bool any = false; for (auto& e : exprs) any = any || has_like(e);
+  if (!any) return t;
+  struct Found { std::string col, pattern; bool negated, ci; };
+  std::vector<Found> found;
+  for (auto& e : exprs)
+    e = rewrite_like(e, [&](const Json& v) {
+      const Json& operand = v.at("expr"); const Json& pat = v.at("pattern");
+      if (!(operand.is_obj() && operand.o.size() == 1 && operand.o[0].first == "column")) throw Unsupported("LIKE over a computed expression is not supported on device (operand must be a column)");
+      if (!(pat.is_obj() && pat.find("literal") && pat.at("literal").get_str("type", "") == "Utf8" && pat.at("literal").find("value") && !pat.at("literal").at("value").is_null()))
+        throw Unsupported("LIKE needs a non-NULL Utf8 literal pattern");
+      found.push_back({operand.o[0].second.at("name").str(), pat.at("literal").at("value").str(), v.get_bool("negated", false), v.get_bool("case_insensitive", false)});
+      return jobj({{"column", jobj({{"name", jstr("__like_" + std::to_string(found.size() - 1))}})}});
+    });
+  PTable out = t;
+  hipStream_t s = (hipStream_t)x.stream;
+  for (size_t k = 0; k < found.size(); ++k) {
+    size_t i = 0; while (i < t.cols.size() && t.cols[i].name != found[k].col) ++i;
+    if (i == t.cols.size()) throw std::runtime_error("plan: column '" + found[k].col + "' not found in the input schema");
+    PCol c = t.cols[i]; const int sd = t.sides[i];
+    if (c.c.type != T_UTF8) throw std::runtime_error("LIKE over a non-Utf8 column '" + c.name + "'");
+    if (c.c.repr == GPUQ_REPR_PACKED15) {      // a string produced by an operator: back to offsets + bytes first
+      const int64_t m = c.c.length;
+      BufP offs = dev_alloc((size_t)(m + 4) * 4), data = dev_alloc((size_t)m * 15 + 16);
+      int64_t dl = 0;
+      check(x, gpuq_unpack_utf8(x.ctx, x.stream, c.c.data, m, (int32_t*)offs->p, (uint8_t*)data->p, m * 15 + 16, &dl));
+      c.c.repr = GPUQ_REPR_ARROW; c.c.data = data->p; c.c.offsets = (const int32_t*)offs->p;
+      out.keep.push_back(offs); out.keep.push_back(data);
+    }
+    const size_t nb = (size_t)((t.n + 63) / 64) * 8 + 8;
+    const bool nullable = c.nullable || (sd > 0 && !t.dense);
+    BufP bits = dev_alloc(nb), valid = nullable ? dev_alloc(nb) : nullptr;
+    HIPCHECK(hipMemsetAsync(bits->p, 0, nb, s)); if (valid) HIPCHECK(hipMemsetAsync(valid->p, 0, nb, s));
+    check(x, gpuq_like_utf8(x.ctx, x.stream, &c.c, sd > 0 ? t.via[(size_t)sd - 1] : nullptr, t.n, found[k].pattern.c_str(), found[k].negated, found[k].ci,
+                            (uint8_t*)bits->p, valid ? (uint8_t*)valid->p : nullptr));
+    PCol b; b.name = "__like_" + std::to_string(k); b.type = jstr("Boolean"); b.nullable = nullable;
+    b.c.type = T_BOOL; b.c.repr = GPUQ_REPR_ARROW; b.c.data = bits->p; b.c.validity = valid ? (const uint8_t*)valid->p : nullptr; b.c.length = t.n;
+    out.cols.push_back(b); out.sides.push_back(0);
+    out.keep.push_back(bits); if (valid) out.keep.push_back(valid);
+  }
+  return out;
+}
+
+PTable project(Exec& x, const PTable& t_in, const std::vector<Json>& exprs_in, const std::vector<std::string>& names, const void* site, int tag) {
+  std::vector<Json> exprs = exprs_in;
+  const PTable t = lower_like(x, t_in, exprs);
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     Json ex = jarr();
     const auto nm = names_of(t);
@@ -307,7 +369,10 @@ PTable materialize(Exec& x, const PTable& t, bool force) {
   return out;
 }
 
-PTable filter_table(Exec& x, const PTable& t, const Json& predicate, const void* site, int tag) {
+PTable filter_table(Exec& x, const PTable& source, const Json& predicate_in, const void* site, int tag) {
+  std::vector<Json> pe{predicate_in};
+  const PTable t = lower_like(x, source, pe);          // helper columns are visible to the predicate only: the view is over `source`
+  const Json& predicate = pe[0];
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     return jobj({{"op", jstr("filter")}, {"input", jobj({{"fields", table_fields(t)}})}, {"predicate", rebind(predicate, names_of(t))}});
   });
@@ -316,7 +381,7 @@ PTable filter_table(Exec& x, const PTable& t, const Json& predicate, const void*
   check(x, gpuq_filter_run(op, x.stream, &ic.in, 0, (uint32_t*)sel->p, (uint64_t*)cnt->p));
   const int64_t k = (int64_t)read_u64(x, cnt->p);
   check(x, gpuq_op_check(op, x.stream));
-  return select_view(x, t, (const uint32_t*)sel->p, k, sel);
+  return select_view(x, source, (const uint32_t*)sel->p, k, sel);
 }
 
 PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
@@ -400,12 +465,14 @@ struct Fused { PNode* src = nullptr; bool has_pred = false; Json pred; bool has_
 Fused fuse(PNode* n) {
   if (auto* p = dynamic_cast<PassThrough*>(n)) return fuse(p->input.get());
   if (auto* f = dynamic_cast<FilterExec*>(n)) {
+    if (has_like(f->predicate)) { Fused r; r.src = n; return r; }      // LIKE is its own kernel over this filter's input: not inlined into consumers
     Fused r = fuse(f->input.get());
     const Json mine = inline_projection(f->predicate, r.has_map ? &r.map : nullptr);
     r.pred = r.has_pred ? jand(r.pred, mine) : mine; r.has_pred = true;
     return r;
   }
   if (auto* p = dynamic_cast<ProjectionExec*>(n)) {
+    for (auto& e : p->exprs) if (has_like(e)) { Fused r; r.src = n; return r; }
     Fused r = fuse(p->input.get());
     ColMap nm;
     for (size_t i = 0; i < p->exprs.size(); ++i) nm[p->names[i]] = inline_projection(p->exprs[i], r.has_map ? &r.map : nullptr);
@@ -416,7 +483,12 @@ Fused fuse(PNode* n) {
 }
 
 PTable FilterExec::execute(int part, Exec& x) {
-  Fused f = fuse(this);
+  Fused f;
+  if (has_like(predicate)) {       // fuse what lies below, evaluate this predicate (with its LIKE kernel) here
+    f = fuse(input.get());
+    const Json mine = inline_projection(predicate, f.has_map ? &f.map : nullptr);
+    f.pred = f.has_pred ? jand(f.pred, mine) : mine; f.has_pred = true;
+  } else f = fuse(this);
   PTable t = f.src->execute(part, x);
   auto t0 = std::chrono::steady_clock::now();
   if (!f.has_map) return timed(t0, filter_table(x, t, f.pred, this, 0));

@@ -99,6 +99,12 @@ def in_list(e, values, negated=False):
     return {"in_list": {"expr": e, "list": list(values), "negated": bool(negated)}}
 
 
+def like(e, pattern, negated=False, case_insensitive=False):
+    """PhysicalLikeExprNode (datafusion.proto:1240-1245): expr [NOT] LIKE pattern; pattern is a Utf8 literal."""
+    return {"like_expr": {"negated": bool(negated), "case_insensitive": bool(case_insensitive), "expr": e,
+                          "pattern": pattern if isinstance(pattern, dict) else lit(pattern)}}
+
+
 def case(when_then, else_expr=None, expr=None):
     return {"case_": {"expr": expr, "when_then_expr": [{"when_expr": w, "then_expr": t} for w, t in when_then],
                       "else_expr": else_expr}}
@@ -145,3 +151,27 @@ def rebind(e, schema):
             raise KeyError("column '%s' not in schema %s" % (c["name"], names))
         return {"column": {"name": c["name"], "index": names.index(c["name"])}}
     return rewrite_columns(e, fix)
+
+
+def has_like(e):
+    if isinstance(e, dict):
+        return "like_expr" in e or any(has_like(v) for v in e.values())
+    if isinstance(e, list):
+        return any(has_like(v) for v in e)
+    return False
+
+
+def rewrite_like(e, fn):
+    """Copy of `e` with every like_expr node replaced by fn(node_body)."""
+    if isinstance(e, dict):
+        if "like_expr" in e and len(e) == 1:
+            return fn(e["like_expr"])
+        return {k: rewrite_like(v, fn) for k, v in e.items()}
+    if isinstance(e, list):
+        return [rewrite_like(v, fn) for v in e]
+    return copy.deepcopy(e)
+
+
+def like_placeholder(e):
+    """For type inference only: LIKE is Boolean and NULL exactly where its operand is -- as `operand = operand`."""
+    return rewrite_like(e, lambda v: {"binary_expr": {"l": v["expr"], "r": copy.deepcopy(v["expr"]), "op": "Eq"}})

@@ -96,10 +96,58 @@ def _alloc_outputs(op, n, device):
     return cols, arr, buf
 
 
+def lower_like(tc, table, exprs):
+    """LIKE is evaluated by its own kernel over the Arrow-layout bytes (gpuq_like_utf8), not inside the register-based
+    expression programs: every like_expr node of `exprs` becomes a reference to a Boolean column appended to (a copy of)
+    the table.  The operand must be a column of `table`; the pattern a Utf8 literal.  Returns (table, exprs)."""
+    if not any(E.has_like(e) for e in exprs):
+        return table, exprs
+    torch = _torch()
+    found = []
+
+    def repl(v):
+        operand, pat = v["expr"], v["pattern"]
+        if not (isinstance(operand, dict) and "column" in operand):
+            raise B.GpuqError(3, "LIKE over a computed expression is not supported on device (operand must be a column)")
+        if not (isinstance(pat, dict) and "literal" in pat and pat["literal"].get("type") == "Utf8" and pat["literal"].get("value") is not None):
+            raise B.GpuqError(3, "LIKE needs a non-NULL Utf8 literal pattern")
+        found.append((operand["column"]["name"], pat["literal"]["value"], bool(v.get("negated")), bool(v.get("case_insensitive"))))
+        return {"column": {"name": "__like_%d" % (len(found) - 1)}}
+    new_exprs = [E.rewrite_like(e, repl) for e in exprs]
+    cols, sides = list(table.columns), list(table.sides)
+    n = table.num_rows
+    names = [c.name for c in table.columns]
+    for k, (name, pattern, negated, ci) in enumerate(found):
+        if name not in names:
+            raise KeyError("column '%s' not in schema %s" % (name, names))
+        i = names.index(name)
+        c, sd = table.columns[i], table.sides[i]
+        if c.repr == B.REPR_PACKED15:      # a string produced by an operator: back to offsets + bytes first
+            m = c.length
+            off = torch.zeros(m + 4, dtype=torch.int32, device=tc.device)
+            dat = torch.zeros(max(16, m * 15), dtype=torch.uint8, device=tc.device)
+            dl = C.c_int64(0)
+            tc.ctx.check(tc.ctx.L.gpuq_unpack_utf8(tc.ctx.h, tc.stream_ptr(), c.data.data_ptr() if m else None, m, off.data_ptr(), dat.data_ptr(),
+                                                   dat.numel(), C.byref(dl)))
+            c = DeviceColumn(c.name, c.type, dat, m, offsets=off, validity=c.validity, nullable=c.nullable)
+        nb = ((n + 63) // 64) * 8 + 8
+        bits = torch.zeros(nb, dtype=torch.uint8, device=tc.device)
+        nullable = bool(c.nullable or (sd > 0 and not table.dense))
+        valid = torch.zeros(nb, dtype=torch.uint8, device=tc.device) if nullable else None
+        idx = table.via[sd - 1] if sd > 0 else None
+        tc.ctx.check(tc.ctx.L.gpuq_like_utf8(tc.ctx.h, tc.stream_ptr(), C.byref(c.to_c()), idx.data_ptr() if idx is not None else None, n,
+                                             pattern.encode(), int(negated), int(ci), bits.data_ptr(), valid.data_ptr() if valid is not None else None))
+        cols.append(DeviceColumn("__like_%d" % k, "Boolean", bits, n, validity=valid, nullable=nullable))
+        sides.append(0)
+    return DeviceTable(cols, n, via=table.via, sides=sides, dense=table.dense), new_exprs
+
+
 def _project(tc, table, exprs, names, memo_key=None, memo=None):
     """ProjectionExec kernel call: evaluate `exprs` over (a view of) `table` into a materialised table.
     memo_key: hashable identity of (exprs, names) so the compiled operator is found without rebuilding the descriptor."""
     op = None
+    if not callable(exprs):
+        table, exprs = lower_like(tc, table, exprs)
     if memo is None:
         memo = tc._memo
     if memo_key is not None:
@@ -288,10 +336,14 @@ def _fuse(plan):
     if isinstance(plan, CoalesceBatchesExec):
         return _fuse(plan.input)
     if isinstance(plan, FilterExec):
+        if E.has_like(plan.predicate):
+            return plan, None, None          # LIKE runs as its own kernel over the filter's input: not inlined into consumers
         src, p, m = _fuse(plan.input)
         mine = E.inline_projection(plan.predicate, m) if m else plan.predicate
         return src, (E.and_(p, mine) if p is not None else mine), m
     if isinstance(plan, ProjectionExec):
+        if any(E.has_like(e) for e, _ in plan.expr):
+            return plan, None, None
         src, p, m = _fuse(plan.input)
         new = {name: (E.inline_projection(e, m) if m else e) for e, name in plan.expr}
         return src, p, new
@@ -418,6 +470,8 @@ class FilterExec(ExecutionPlan):
 def filter_table(tc, table, predicate, memo_key=None, memo=None):
     torch = _torch()
     op = None
+    source = table
+    table, (predicate,) = lower_like(tc, table, [predicate])
     if memo is None:
         memo = tc._memo
     if memo_key is not None:
@@ -435,7 +489,7 @@ def filter_table(tc, table, predicate, memo_key=None, memo=None):
     tc.ctx.check(tc.ctx.L.gpuq_filter_run(op.h, tc.stream_ptr(), C.byref(inp), 0, sel.data_ptr(), cnt.data_ptr()))
     k = int(cnt[0].item())
     op.check(tc.stream_ptr())
-    return _select_view(tc, table, sel[:k], k)
+    return _select_view(tc, source, sel[:k], k)
 
 
 class ProjectionExec(ExecutionPlan):
@@ -450,17 +504,23 @@ class ProjectionExec(ExecutionPlan):
 
     def schema(self):
         d = B.compile_check({"op": "project", "input": {"fields": self.input.schema()},
-                             "exprs": [{"expr": E.rebind(e, self.input.schema()), "name": n} for e, n in self.expr]})
+                             "exprs": [{"expr": E.rebind(E.like_placeholder(e), self.input.schema()), "name": n} for e, n in self.expr]})
         return [_field_from_desc(o) for o in d["outputs"]]
 
     def execute(self, partition, context):
         if not hasattr(self, "_fused"):
             self._fused = _fuse(self)          # plan nodes are immutable once built: fuse once
+            self._like = self._fused[0] is self
+            if self._like:                      # own expressions hold a LIKE: fuse what lies below, evaluate this node by itself
+                s2, p2, m2 = _fuse(self.input)
+                self._fused = (s2, p2, {name: (E.inline_projection(e, m2) if m2 else e) for e, name in self.expr})
         src, pred, m = self._fused
         table = src.execute(partition, context)
         t0 = time.perf_counter()
         if pred is not None:
             table = filter_table(context, table, pred, memo_key="pf", memo=self._memo)
+        if self._like:
+            return self._timed(t0, _project(context, table, [m[name] for _, name in self.expr], [name for _, name in self.expr], memo_key="pl", memo=self._memo))
         out = _project(context, table, lambda: ([m[name] for _, name in self.expr], [name for _, name in self.expr]), None, memo_key="pe", memo=self._memo)
         return self._timed(t0, out)
 

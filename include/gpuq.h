@@ -132,7 +132,8 @@ int gpuq_export_arrow(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, cons
 /* ---- compiled operators ------------------------------------------------------------------ */
 /* Descriptor JSON (see INTEGRATION.md for the grammar).  Expression nodes mirror PhysicalExprNode
    (datafusion.proto:1142-1180): column, literal, binary_expr, cast, try_cast, not_expr, is_null_expr,
-   is_not_null_expr, negative, in_list, case_.  "op" is one of
+   is_not_null_expr, negative, in_list, case_ (like_expr is evaluated by gpuq_like_utf8 and lowered to a Boolean column by the plan
+   executor).  "op" is one of
      "filter"      FilterExec        {input, predicate}
      "project"     ProjectionExec    {input, exprs:[{expr,name}]}
      "aggregate"   AggregateExec     {input, mode:Partial|Final|FinalPartitioned|Single, group_expr:[{expr,name}],
@@ -224,6 +225,15 @@ int gpuq_op_jit_source(gpuq_op* op, int kernel_id, char* buf, size_t cap);
    buffer.  Synchronous up to the size read-back; the byte copy is queued on `stream`. */
 int gpuq_take_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int32_t* offsets_out, uint8_t* validity_out,
                    uint8_t* data_out, int64_t data_cap, int64_t* data_len_out);
+
+/* LikeExpr (PhysicalLikeExprNode, datafusion.proto:1240-1245: negated, case_insensitive, expr, pattern) of a Utf8 column in Arrow
+   layout against a literal pattern: '%' any run of characters, '_' one character, "\\%" / "\\_" the literal characters (arrow-string's
+   `like` / `nlike` with a scalar pattern).  idx (optional) addresses the column through an index vector; 0xFFFFFFFF or a NULL
+   value gives NULL.  bits_out / validity_out: bitmaps of ((n+63)/64)*8 bytes, 8-byte aligned, written in full (validity_out may
+   be NULL).  case_insensitive != 0 is GPUQ_ERR_UNSUPPORTED.  Asynchronous.  The result is a Boolean column an operator's
+   expression can read like any other. */
+int gpuq_like_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, const char* pattern, int negated, int case_insensitive,
+                   uint8_t* bits_out, uint8_t* validity_out);
 
 /* dst[i] = src[i] + delta for n Utf8 offsets: joining the offset arrays of partitions that are concatenated (fan-in). */
 int gpuq_offsets_rebase(gpuq_ctx* ctx, void* stream, const int32_t* src, int64_t n, int32_t delta, int32_t* dst);

@@ -152,6 +152,30 @@ def _to_float(vals, t):
     return [None if v is None else float(v) for v in vals]
 
 
+def like_match(s, pat):
+    """arrow-string 49 like.rs with a scalar pattern [UPSTREAM-KNOWLEDGE]: equality / starts_with / ends_with / contains for
+    the four wildcard-free shapes, else the regex ^...$ built by replace_like_wildcards ('%' -> '.*', '_' -> '.', "\\%" and
+    "\\_" literal, every other character literal; '.' does not match a newline)."""
+    import re
+    wild = lambda t: any(c in "%_" for c in t)
+    if not wild(pat):
+        return s == pat
+    if pat.endswith("%") and not pat.endswith("\\%") and not wild(pat[:-1]):
+        return s.startswith(pat[:-1])
+    if pat.startswith("%") and not wild(pat[1:]):
+        return s.endswith(pat[1:])
+    if pat.startswith("%") and pat.endswith("%") and not pat.endswith("\\%") and not wild(pat[1:-1]):
+        return pat[1:-1] in s
+    out, i = [], 0
+    while i < len(pat):
+        c = pat[i]
+        if c == "\\" and i + 1 < len(pat) and pat[i + 1] in "%_":
+            out.append(re.escape(pat[i + 1])); i += 2; continue
+        out.append(".*" if c == "%" else ("." if c == "_" else re.escape(c)))
+        i += 1
+    return re.fullmatch("".join(out), s) is not None
+
+
 def eval_expr(e, tab):
     """-> (type, values)."""
     (kind, v), = e.items()
@@ -186,6 +210,13 @@ def eval_expr(e, tab):
     if kind == "negative":
         t, vals = eval_expr(v["expr"], tab)
         return t, [None if x is None else -x for x in vals]
+    if kind == "like_expr":
+        _, vals = eval_expr(v["expr"], tab)
+        pat = v["pattern"]["literal"]["value"]
+        if v.get("case_insensitive"):
+            raise NotImplementedError("ILIKE")
+        neg = bool(v.get("negated"))
+        return "Boolean", [None if x is None else (like_match(x, pat) != neg) for x in vals]
     if kind == "in_list":
         acc = None
         for it in v["list"]:

@@ -8,7 +8,7 @@ import pytest
 import arrow_ballista_amd as g
 import tpch_util as T
 from arrow_ballista_amd.expr import Operator as Op
-from arrow_ballista_amd.expr import and_, binary, col, is_not_null, lit
+from arrow_ballista_amd.expr import and_, binary, col, is_not_null, like, lit, or_
 from oracle import oracle_np as O
 from test_gpu_operators import JOIN_TYPES, agg_cases, close_rows, dev_rows, norm, ora_rows, rand_table
 
@@ -236,3 +236,29 @@ def test_native_stage_driver_writes_and_reads_shuffle_files(tc, tmp_path):
     with pytest.raises(g.GpuqError, match="FetchFailed"):
         bad.execute(0)
     assert g.NativePlan(g.ShuffleReaderExec([[]], s), tc).execute(0).num_rows == 0
+
+
+def test_native_like(tc):
+    """LIKE in the native executor: FilterExec (alone, over a view, under an aggregate that fuses its input) and ProjectionExec,
+    row for row against the oracle."""
+    from test_gpu_operators import LIKE_PATTERNS, like_table
+    t = like_table(78, 4000, 0.15)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    for pat in LIKE_PATTERNS[::2]:
+        e = like(col("s", s), pat, negated=(len(pat) % 2 == 1))
+        got, _ = native_rows(tc, g.FilterExec(e, src))
+        assert got == ora_rows(ot.take(O.filter_rows(ot, e))), pat
+    inner = g.FilterExec(binary(col("k", s), Op.Gt, lit(10)), src)
+    pred = or_(like(col("s", s), "%ING"), like(col("s", s), "%special%requests%"))
+    outer = g.FilterExec(pred, inner)
+    keep = O.filter_rows(ot, and_(binary(col("k", s), Op.Gt, lit(10)), pred))
+    assert native_rows(tc, outer)[0] == ora_rows(ot.take(keep))
+    aggs = [{"fn": "COUNT", "expr": lit(1), "name": "c"}, {"fn": "SUM", "expr": col("k", s), "name": "sk"}]
+    got, _ = native_rows(tc, g.AggregateExec("Single", [(col("k", s), "k")], aggs, outer))
+    assert norm(got) == norm(ora_rows(O.aggregate(ot.take(keep), [(col("k", s), "k")], aggs, "Single")))
+    exprs = [(like(col("s", s), "B%G"), "l"), (binary(col("k", s), Op.Multiply, lit(2)), "k2")]
+    got, _ = native_rows(tc, g.ProjectionExec(exprs, inner))
+    sub = ot.take(O.filter_rows(ot, binary(col("k", s), Op.Gt, lit(10))))
+    assert got == ora_rows(O.project(sub, [e for e, _ in exprs], [n for _, n in exprs]))

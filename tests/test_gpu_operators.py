@@ -12,7 +12,7 @@ import pytest
 
 import arrow_ballista_amd as g
 from arrow_ballista_amd.expr import Operator as Op
-from arrow_ballista_amd.expr import (and_, binary, case, cast, col, in_list, is_not_null, is_null, lit, negative, not_, or_)
+from arrow_ballista_amd.expr import (and_, binary, case, cast, col, in_list, is_not_null, is_null, like, lit, negative, not_, or_)
 from oracle import oracle_np as O
 
 pytestmark = pytest.mark.gpu
@@ -152,6 +152,61 @@ def test_decimal_division_and_modulo(tc):
     ty = {f["name"]: f["type"] for f in plan.schema()}
     assert ty["dq"] == {"Decimal128": [21, 6]} and ty["di"] == {"Decimal128": [19, 6]} and ty["id"] == {"Decimal128": [26, 4]}
     assert ty["dm"] == {"Decimal128": [15, 2]} and ty["dmi"] == {"Decimal128": [12, 2]}
+
+
+LIKE_PATTERNS = ["BUILDING", "%", "", "MACH%", "%ING", "%U%", "%special%requests%", "_UILDING", "B%G", "%_", "__", "a\\%b", "%\\_%", "50\\%", "é_%", "%o_ %",
+                 "%fox%dog%", "x", "%x", "%%", "_%_", "%D__G", "line%two"]
+
+
+def like_table(seed, n, nulls):
+    r = np.random.default_rng(seed)
+    words = np.array(["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY", "", "x", "a%b", "a_b", "50%", "50x", "é", "éa", "日本語", "ab",
+                      "the quick brown fox jumps over the lazy dog", "special deposits requests", "no special pending requests here", "line one\nline two",
+                      "GUILDING", "B\nG", "_", "%", "fox dog"])
+    mask = (r.random(n) < nulls) if nulls > 0 else None
+    return pa.table({"s": pa.array(words[r.integers(0, len(words), n)], type=pa.string(), mask=mask), "k": pa.array(r.integers(0, 50, n), type=pa.int64())})
+
+
+@pytest.mark.parametrize("nulls", [0.0, 0.2])
+def test_like_expr(tc, nulls):
+    """LikeExpr (PhysicalLikeExprNode): every pattern shape of arrow's scalar `like` (equality, prefix, suffix, infix, general
+    with '_' / inner '%' / escapes; multi-byte characters; the regex path's newline rule), LIKE and NOT LIKE, NULL operands,
+    in FilterExec (alone, under another filter = through an index vector, fused under an aggregate) and in ProjectionExec."""
+    t = like_table(77, 5000, nulls)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    for pat in LIKE_PATTERNS:
+        for neg in (False, True):
+            e = like(col("s", s), pat, negated=neg)
+            got = dev_rows(tc, g.FilterExec(e, src).execute(0, tc))
+            exp = ora_rows(ot.take(O.filter_rows(ot, e)))
+            assert got == exp, (pat, neg)
+    # as a projected value (NULL where the operand is NULL), next to other expressions
+    exprs = [(like(col("s", s), "%requests%"), "l1"), (like(col("s", s), "_", negated=True), "l2"), (binary(col("k", s), Op.Plus, lit(1)), "k1"),
+             (and_(like(col("s", s), "%o%"), binary(col("k", s), Op.Lt, lit(25))), "both")]
+    plan = g.ProjectionExec(exprs, src)
+    assert dev_rows(tc, plan.execute(0, tc)) == ora_rows(O.project(ot, [e for e, _ in exprs], [n for _, n in exprs]))
+    assert [f["type"] for f in plan.schema()] == ["Boolean", "Boolean", "Int64", "Boolean"]
+    # through a view (filter over a filter), then fused under an aggregate
+    inner = g.FilterExec(binary(col("k", s), Op.Gt, lit(10)), src)
+    outer = g.FilterExec(or_(like(col("s", s), "%ING"), like(col("s", s), "50_")), inner)
+    keep = O.filter_rows(ot, and_(binary(col("k", s), Op.Gt, lit(10)), or_(like(col("s", s), "%ING"), like(col("s", s), "50_"))))
+    assert dev_rows(tc, outer.execute(0, tc)) == ora_rows(ot.take(keep))
+    aggs = [{"fn": "COUNT", "expr": lit(1), "name": "c"}]
+    agg = g.AggregateExec("Single", [(col("s", s), "s")], aggs, outer)
+    assert norm(dev_rows(tc, agg.execute(0, tc))) == norm(ora_rows(O.aggregate(ot.take(keep), [(col("s", s), "s")], aggs, "Single")))
+    # a string produced by an operator (PACKED15) as the operand
+    grouped = g.AggregateExec("Single", [(col("s", s), "s")], aggs, g.FilterExec(binary(col("k", s), Op.Lt, lit(40)), src))
+    gs = grouped.schema()
+    sub = O.aggregate(ot.take(O.filter_rows(ot, binary(col("k", s), Op.Lt, lit(40)))), [(col("s", s), "s")], aggs, "Single")
+    short = [r for r in ora_rows(sub) if r[0] is None or len(r[0].encode()) <= 15]
+    if len(short) == len(ora_rows(sub)):
+        got = dev_rows(tc, g.FilterExec(like(col("s", gs), "%I%"), grouped).execute(0, tc))
+        assert norm(got) == norm([r for r in short if r[0] is not None and "I" in r[0]])
+    with pytest.raises(g.GpuqError) as ei:
+        g.FilterExec(like(col("s", s), "abc", case_insensitive=True), src).execute(0, tc)
+    assert ei.value.status == 3
 
 
 # ------------------------------------------------------------------------------------ aggregate

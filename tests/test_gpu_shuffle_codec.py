@@ -156,3 +156,72 @@ def test_two_stages_through_shuffle_files(tc, tmp_path):
     with pytest.raises(g.GpuqError, match="FetchFailed"):
         g.ShuffleReaderExec([[{"path": str(tmp_path / "missing.arrow")}]], s).execute(0, tc)
     assert g.ShuffleReaderExec([[]], s).execute(0, tc).num_rows == 0
+
+
+def _pattern_cases():
+    """Byte strings that walk the LZ4 block format's boundaries: literal / match length fields at 14, 15, 16, 269, 270, 271
+    (token nibble, one and two extension bytes), periods shorter than the match (overlapping copies), the end-of-block rules
+    (no match in the last 12 bytes, 5 literal bytes at the end), blocks of exactly 64 KiB and one byte either side, long
+    single matches spanning blocks, incompressible data (stored blocks / raw buffers)."""
+    r = np.random.default_rng(5)
+    cases = []
+    for L in list(range(0, 40)) + [63, 64, 65, 254, 255, 256, 269, 270, 271, 272, 510, 511, 512, 513, 4095, 4096, 4097]:
+        cases.append(bytes([65]) * L)                                              # one long run
+        cases.append(r.integers(0, 256, L, dtype=np.uint8).tobytes())              # incompressible
+        cases.append((b"abcdefghijklmnopqrstuvwxyz0123456789" * (L // 36 + 1))[:L])   # period 36
+    for lit in (0, 1, 14, 15, 16, 17, 269, 270, 271, 525):
+        for ml in (4, 5, 18, 19, 20, 273, 274, 275, 530):
+            head = r.integers(0, 256, lit, dtype=np.uint8).tobytes()
+            word = r.integers(0, 256, max(ml, 8), dtype=np.uint8).tobytes()
+            cases.append(word + head + word[:ml] + r.integers(0, 256, 13, dtype=np.uint8).tobytes())
+    for period in (1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 63, 64, 65):
+        unit = r.integers(0, 256, period, dtype=np.uint8).tobytes()
+        for total in (period + 4, 100, 1000):
+            cases.append((unit * (total // period + 1))[:total] + b"tail-bytes-xyz")
+    for L in (65535, 65536, 65537, 131072, 131073, 200_000):
+        cases.append(bytes(L))                                                     # zeros across block boundaries
+        cases.append((r.integers(0, 4, L, dtype=np.uint8) + 48).tobytes())        # low entropy
+        cases.append(r.integers(0, 256, L, dtype=np.uint8).tobytes())
+    return cases
+
+
+def test_lz4_format_boundaries_both_directions(tc):
+    """Each case's bytes (padded to a multiple of 4) ride as the data buffer of an Int32 column, one batch per case: the codec
+    sees exactly those bytes.  Arrow C++ is the writer for one direction and the reader for the other."""
+    cases = _pattern_cases()
+    batches, expect = [], []
+    for c in cases:
+        pad = (-len(c)) % 4
+        arr = np.frombuffer(c + bytes(pad), dtype=np.int32)
+        expect.append(arr)
+        batches.append(pa.record_batch([pa.array(arr, type=pa.int32())], names=["x"]))
+    schema = batches[0].schema
+    # 1. Arrow C++ writes (linked frames), the device reads the whole stream in one launch
+    sink = io.BytesIO()
+    with pa.ipc.new_stream(sink, schema, options=pa.ipc.IpcWriteOptions(compression="lz4")) as w:
+        for b in batches:
+            w.write_batch(b)
+    got, _ = S.read_ipc_stream(tc, sink.getvalue())
+    want = np.concatenate(expect)
+    assert np.array_equal(got.to_arrow(tc.ctx).column("x").to_numpy(), want)
+    # 2. the device writes every case as its own batch, Arrow C++ and the device read them back
+    out = io.BytesIO()
+    out.write(schema.serialize().to_pybytes())
+    buf = None
+    for b in batches:
+        dt = g.DeviceTable.from_arrow(pa.Table.from_batches([b]), tc.device)
+        msg, buf = S.encode_batch(tc, dt, 0, buf)
+        out.write(bytes(msg))
+    out.write(S.EOS)
+    raw = out.getvalue()
+    back = pa.ipc.open_stream(raw)
+    n = 0
+    for b, e in zip(back, expect):
+        assert np.array_equal(b.column(0).to_numpy(), e), n
+        n += 1
+    assert n == len(cases)
+    got, _ = S.read_ipc_stream(tc, raw)
+    assert np.array_equal(got.to_arrow(tc.ctx).column("x").to_numpy(), want)
+    # compressible cases must actually shrink: 200,000 zero bytes fit in a few hundred
+    dt = g.DeviceTable.from_arrow(pa.table({"x": pa.array(np.zeros(50_000, dtype=np.int32))}), tc.device)
+    assert S.encoded_size(tc, dt) < 2000

@@ -109,3 +109,16 @@ def test_decimal_division_rules_by_hand():
     assert ty == {"Decimal128": [15, 2]} and v == [100, -150, None, -1, None]
     ty, v = O.eval_expr(binary(ca, Op.Modulo, ci), t)
     assert ty == {"Decimal128": [12, 2]} and v == [100, -150, 200, -1, None]
+
+
+def test_like_rules_by_hand():
+    """LIKE as arrow-string 49 evaluates a scalar pattern (hand-worked): the four regex-free shapes, '_' = one character (not one
+    byte), escapes, and the regex path's '.'-does-not-match-newline rule that only general patterns are subject to."""
+    from oracle.oracle_np import like_match as L
+    cases = [("abc", "abc", True), ("abc", "ab", False), ("abcdef", "abc%", True), ("abcdef", "%def", True), ("abcdef", "%cd%", True), ("abcdef", "a_c%f", True),
+             ("abcdef", "a%c_e%", True), ("50%", "50\\%", True), ("50x", "50\\%", False), ("a_b", "a\\_b", True), ("axb", "a\\_b", False),
+             ("a\nb", "a%b", False), ("a\nb", "a%", True), ("a\nb", "%b", True), ("a\nb", "%\n%", True), ("", "%", True), ("", "_", False), ("é", "_", True),
+             ("日本語", "___", True), ("日本語", "__", False), ("special requests", "%special%requests%", True), ("abc", "___", True), ("abc", "____", False),
+             ("a\\b", "a\\b", True), ("a.c", "a.c", True), ("abc", "a.c", False), ("a+c", "a+_", True)]
+    for s_, p_, e_ in cases:
+        assert L(s_, p_) == e_, (s_, p_)
