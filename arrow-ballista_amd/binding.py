@@ -104,6 +104,7 @@ def lib():
         "gpuq_join_table_free": (None, [vp]),
         "gpuq_join_probe_run": (i32, [vp, vp, vp, C.POINTER(gpuq_input), i32, vp, vp, u64, vp]),
         "gpuq_join_build_side_rows": (i32, [vp, vp, i32, vp, vp]),
+        "gpuq_mark_rows": (i32, [vp, vp, vp, i64, vp]),
         "gpuq_sort_run": (i32, [vp, vp, C.POINTER(gpuq_input), vp]),
         "gpuq_partition_run": (i32, [vp, vp, C.POINTER(gpuq_input), vp, vp]),
         "gpuq_op_check": (i32, [vp, vp]),

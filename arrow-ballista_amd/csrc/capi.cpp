@@ -1224,6 +1224,15 @@ int gpuq_offsets_rebase(gpuq_ctx* ctx, void* stream, const int32_t* src, int64_t
   });
 }
 
+int gpuq_mark_rows(gpuq_ctx* ctx, void* stream, const uint32_t* rows, int64_t n, uint8_t* bitmap) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (n < 0 || (n > 0 && (!rows || !bitmap))) throw std::runtime_error("bad arguments");
+    launch_mark_rows((hipStream_t)stream, rows, n, bitmap);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
 // ---------------------------------------------------------------- LIKE
 int gpuq_like_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, const char* pattern, int negated, int case_insensitive,
                    uint8_t* bits_out, uint8_t* validity_out) {

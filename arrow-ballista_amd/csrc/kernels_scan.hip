@@ -1086,6 +1086,16 @@ void launch_like_utf8(hipStream_t s, const uint8_t* data, const int32_t* offsets
                       u64* bits_out, u64* valid_out) {
   if (n > 0) hipLaunchKernelGGL(k_like_utf8, dim3(lin_grid(n)), dim3(BLOCK), 0, s, data, offsets, validity, idx, n, pat, negated, bits_out, valid_out);
 }
+// bitmap[rows[i]] = 1 for every i (0xFFFFFFFF skipped): which rows of a join side survive in the filtered pair list
+__global__ void __launch_bounds__(BLOCK) k_mark_rows(const uint32_t* __restrict__ rows, const i64 n, unsigned int* __restrict__ bitmap) {
+  for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    const uint32_t r = rows[i];
+    if (r != 0xFFFFFFFFu) atomicOr(bitmap + (r >> 5), 1u << (r & 31));
+  }
+}
+void launch_mark_rows(hipStream_t s, const uint32_t* rows, i64 n, uint8_t* bitmap) {
+  if (n > 0) hipLaunchKernelGGL(k_mark_rows, dim3(lin_grid(n)), dim3(BLOCK), 0, s, rows, n, (unsigned int*)bitmap);
+}
 size_t exclusive_scan_ws_bytes(i64 n) { return (size_t)((n + 1 + SCAN_TILE - 1) / SCAN_TILE + 1) * 8; }
 void launch_exclusive_scan_i32(hipStream_t s, int32_t* data, i64 n, void* workspace, size_t) {
   // data holds n lengths (entry n is scratch); afterwards data[0..n] are the offsets

@@ -369,6 +369,23 @@ PTable materialize(Exec& x, const PTable& t, bool force) {
   return out;
 }
 
+// the passing driving positions of `source` (in order) and their number
+int64_t filter_sel(Exec& x, const PTable& source, const Json& predicate_in, const void* site, int tag, BufP& sel_out) {
+  std::vector<Json> pe{predicate_in};
+  const PTable t = lower_like(x, source, pe);
+  const Json& predicate = pe[0];
+  gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
+    return jobj({{"op", jstr("filter")}, {"input", jobj({{"fields", table_fields(t)}})}, {"predicate", rebind(predicate, names_of(t))}});
+  });
+  sel_out = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 4 + 16);
+  BufP cnt = dev_alloc(16);
+  InputC ic; make_input(t, ic);
+  check(x, gpuq_filter_run(op, x.stream, &ic.in, 0, (uint32_t*)sel_out->p, (uint64_t*)cnt->p));
+  const int64_t k = (int64_t)read_u64(x, cnt->p);
+  check(x, gpuq_op_check(op, x.stream));
+  return k;
+}
+
 PTable filter_table(Exec& x, const PTable& source, const Json& predicate_in, const void* site, int tag) {
   std::vector<Json> pe{predicate_in};
   const PTable t = lower_like(x, source, pe);          // helper columns are visible to the predicate only: the view is over `source`
@@ -587,12 +604,52 @@ struct HashJoinExec : PNode {
     for (auto v : rv.via) out.via.push_back(v);
     return out;
   }
-  PTable execute(int part, Exec& x) override {
+  // positions of [0, n) that occur (want_marked) / do not occur in rows[0..k)
+  int64_t marked_rows(Exec& x, const uint32_t* rows, int64_t k, int64_t n, bool want_marked, int tag, BufP& out) {
+    const size_t nb = (size_t)((n + 63) / 64) * 8 + 8;
+    BufP bits = dev_alloc(nb);
+    HIPCHECK(hipMemsetAsync(bits->p, 0, nb, (hipStream_t)x.stream));
+    check(x, gpuq_mark_rows(x.ctx, x.stream, rows, k, (uint8_t*)bits->p));
+    PTable t; t.n = n; t.keep.push_back(bits);
+    PCol c; c.name = "m"; c.type = jstr("Boolean"); c.nullable = false; c.c.type = T_BOOL; c.c.repr = GPUQ_REPR_ARROW; c.c.data = bits->p; c.c.length = n;
+    t.cols.push_back(c); t.sides.push_back(0);
+    const Json m = jcol("m", 0);
+    return filter_sel(x, t, want_marked ? m : jobj({{"not_expr", jobj({{"expr", m}})}}), this, tag, out);
+  }
+  // JoinFilter on a non-inner join: `pairs` are the Inner matches; a pair that fails the filter is no match
+  PTable residual_join(Exec& x, const PTable& lt, const PTable& rt, const PTable& pairs, const BufP& ob, const BufP& opb, int64_t k) {
+    hipStream_t s = (hipStream_t)x.stream;
+    BufP sel; const int64_t k2 = filter_sel(x, pairs, filter, this, 2, sel);
+    std::vector<BufP> keep{ob, opb, sel};
+    const uint32_t* ob2 = k2 ? take_u32(x, (const uint32_t*)ob->p, k, (const uint32_t*)sel->p, k2, keep) : (const uint32_t*)ob->p;
+    const uint32_t* opb2 = k2 ? take_u32(x, (const uint32_t*)opb->p, k, (const uint32_t*)sel->p, k2, keep) : (const uint32_t*)opb->p;
     const std::string& jt = join_type;
+    auto with_keep = [&](PTable t) { for (auto& b : keep) t.keep.push_back(b); return t; };
+    if (jt == "LeftSemi" || jt == "LeftAnti") { BufP rows; const int64_t m = marked_rows(x, ob2, k2, lt.n, jt == "LeftSemi", 5, rows); return with_keep(select_view(x, lt, (const uint32_t*)rows->p, m, rows)); }
+    if (jt == "RightSemi" || jt == "RightAnti") { BufP rows; const int64_t m = marked_rows(x, opb2, k2, rt.n, jt == "RightSemi", 6, rows); return with_keep(select_view(x, rt, (const uint32_t*)rows->p, m, rows)); }
+    BufP lrows, rrows; int64_t ml = 0, mr = 0;
+    if (jt == "Left" || jt == "Full") ml = marked_rows(x, ob2, k2, lt.n, false, 5, lrows);
+    if (jt == "Right" || jt == "Full") mr = marked_rows(x, opb2, k2, rt.n, false, 6, rrows);
+    const int64_t k3 = k2 + ml + mr;
+    BufP ob3 = dev_alloc((size_t)std::max<int64_t>(k3, 1) * 4 + 16), opb3 = dev_alloc((size_t)std::max<int64_t>(k3, 1) * 4 + 16);
+    uint32_t* a = (uint32_t*)ob3->p; uint32_t* b = (uint32_t*)opb3->p;
+    if (k2) { HIPCHECK(hipMemcpyAsync(a, ob2, (size_t)k2 * 4, hipMemcpyDeviceToDevice, s)); HIPCHECK(hipMemcpyAsync(b, opb2, (size_t)k2 * 4, hipMemcpyDeviceToDevice, s)); }
+    if (ml) { HIPCHECK(hipMemcpyAsync(a + k2, lrows->p, (size_t)ml * 4, hipMemcpyDeviceToDevice, s)); HIPCHECK(hipMemsetAsync(b + k2, 0xFF, (size_t)ml * 4, s)); }
+    if (mr) { HIPCHECK(hipMemsetAsync(a + k2 + ml, 0xFF, (size_t)mr * 4, s)); HIPCHECK(hipMemcpyAsync(b + k2 + ml, rrows->p, (size_t)mr * 4, hipMemcpyDeviceToDevice, s)); }
+    HIPCHECK(hipStreamSynchronize(s));      // the sources of the copies die with this frame
+    return join_view(x, lt, rt, a, b, k3, ob3, opb3);
+  }
+  PTable execute(int part, Exec& x) override {
+    const bool residual = has_filter && join_type != "Inner";
+    const std::string jt = residual ? std::string("Inner") : join_type;
     int lpart = partition_mode == "Partitioned" ? part : 0;
     if (partition_mode != "Partitioned" && left->partitions() != 1) throw Unsupported("CollectLeft with a multi-partition build side: wrap the left input in a single partition");
     Side L = side(left.get(), lpart, x), R = side(right.get(), part, x);
     auto t0 = std::chrono::steady_clock::now();
+    if (residual) {      // rows that fail a side's own predicate are not part of the join at all: apply those first
+      if (L.has_pred) { L.t = filter_table(x, L.t, L.pred, this, 3); L.has_pred = false; }
+      if (R.has_pred) { R.t = filter_table(x, R.t, R.pred, this, 4); R.has_pred = false; }
+    }
     gpuq_op* bop = cached_op(x, this, 0, table_sig(L.t), [&]() {
       const auto ln = names_of(L.t);
       Json lk = jarr();
@@ -642,10 +699,8 @@ struct HashJoinExec : PNode {
     }
     if (jt == "RightSemi" || jt == "RightAnti") return timed(t0, select_view(x, R.t, (const uint32_t*)opb->p, k, opb));
     PTable out = join_view(x, L.t, R.t, (const uint32_t*)ob->p, (const uint32_t*)opb->p, k, ob, opb);
-    if (has_filter) {
-      if (jt != "Inner") throw Unsupported("JoinFilter on a non-inner join is not supported on device yet");
-      out = filter_table(x, out, filter, this, 2);
-    }
+    if (residual) return timed(t0, residual_join(x, L.t, R.t, out, ob, opb, k));
+    if (has_filter) out = filter_table(x, out, filter, this, 2);
     // the probe kernels read the build table asynchronously; results were read back (synchronised) above
     return timed(t0, out);
   }

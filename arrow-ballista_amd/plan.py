@@ -467,7 +467,7 @@ class FilterExec(ExecutionPlan):
         return self._timed(t0, filter_table(context, table, self.predicate, memo_key="self", memo=self._memo))
 
 
-def filter_table(tc, table, predicate, memo_key=None, memo=None):
+def filter_table(tc, table, predicate, memo_key=None, memo=None, return_sel=False):
     torch = _torch()
     op = None
     source = table
@@ -489,6 +489,8 @@ def filter_table(tc, table, predicate, memo_key=None, memo=None):
     tc.ctx.check(tc.ctx.L.gpuq_filter_run(op.h, tc.stream_ptr(), C.byref(inp), 0, sel.data_ptr(), cnt.data_ptr()))
     k = int(cnt[0].item())
     op.check(tc.stream_ptr())
+    if return_sel:
+        return sel[:k], k
     return _select_view(tc, source, sel[:k], k)
 
 
@@ -605,6 +607,7 @@ def aggregate_table(tc, table, descriptor, cap=None, op=None):
 
 
 class HashJoinExec(ExecutionPlan):
+
     """HashJoinExec(left, right, on: [(left_col, right_col)], filter, join_type, partition_mode, null_equals_null)
     -- ctor surface of ballista/core/src/physical_optimizer/task_group.rs:306-315, datafusion.proto:1346-1360.
     The LEFT input is the build side.  Output columns = left columns then right columns (a view)."""
@@ -619,6 +622,9 @@ class HashJoinExec(ExecutionPlan):
 
     def output_partition_count(self):
         return self.right.output_partition_count()
+
+    def _residual_join(self, tc, ltab, rtab, pairs, ob, opb, k):
+        return _residual_join_impl(tc, self.join_type, self.filter, ltab, rtab, pairs, ob, opb, k)
 
     def schema(self):
         ls, rs = self.left.schema(), self.right.schema()
@@ -660,7 +666,16 @@ class HashJoinExec(ExecutionPlan):
             ltab, lpred, _ = self._side(self.left, lpart, tc, lkeys)
         rtab, rpred, _ = self._side(self.right, partition, tc, rkeys)
         t0 = time.perf_counter()
-        mk = ("join", id(tc), table_sig(ltab), table_sig(rtab))
+        residual = self.filter is not None and jt != "Inner"
+        if residual:
+            # a pair that fails the JoinFilter is no match: probe as Inner over the rows that pass the sides' own predicates,
+            # filter the pairs, derive the outer / semi / anti parts from the surviving pairs (_residual_join)
+            if lpred is not None:
+                ltab, lpred = filter_table(tc, ltab, lpred), None
+            if rpred is not None:
+                rtab, rpred = filter_table(tc, rtab, rpred), None
+            jt = "Inner"
+        mk = ("join", id(tc), table_sig(ltab), table_sig(rtab), jt)
         ops = self._memo.get(mk)
         lschema, rschema = (None, None) if ops else (ltab.schema(), rtab.schema())
         bdesc = None if ops else {"op": "join_build", "input": {"fields": lschema}, "on": [E.rebind(k, lschema) for k in lkeys],
@@ -711,13 +726,46 @@ class HashJoinExec(ExecutionPlan):
             if jt in ("RightSemi", "RightAnti"):
                 return self._timed(t0, _select_view(tc, rtab, opb[:k], k))
             out = _join_view(tc, ltab, rtab, ob[:k], opb[:k], k)
+            if residual:
+                return self._timed(t0, self._residual_join(tc, ltab, rtab, out, ob[:k], opb[:k], k))
             if self.filter is not None:
-                if jt != "Inner":
-                    raise B.GpuqError(3, "JoinFilter on a non-inner join is not supported on device yet")
                 out = filter_table(tc, out, self.filter)
             return self._timed(t0, out)
         finally:
             jtab.close()
+
+
+def _marked_rows(tc, rows, k, n, want_marked):
+    """Positions of [0, n) that occur (want_marked) / do not occur in rows[0..k): (int32 tensor, count)."""
+    torch = _torch()
+    bits = torch.zeros(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=tc.device)
+    tc.ctx.check(tc.ctx.L.gpuq_mark_rows(tc.ctx.h, tc.stream_ptr(), rows.data_ptr() if k else None, k, bits.data_ptr()))
+    t = DeviceTable([DeviceColumn("m", "Boolean", bits, n, nullable=False)], n)
+    m = E.col("m", index=0)
+    return filter_table(tc, t, m if want_marked else E.not_(m), return_sel=True)
+
+
+def _residual_join_impl(tc, jt, flt, ltab, rtab, pairs, ob, opb, k):
+    torch = _torch()
+    sel, k2 = filter_table(tc, pairs, flt, return_sel=True)
+    ob2 = _take_u32(tc, ob, sel, k2) if k else ob[:0]
+    opb2 = _take_u32(tc, opb, sel, k2) if k else opb[:0]
+    nl, nr = ltab.num_rows, rtab.num_rows
+    if jt in ("LeftSemi", "LeftAnti"):
+        rows, m = _marked_rows(tc, ob2, k2, nl, jt == "LeftSemi")
+        return _select_view(tc, ltab, rows, m)
+    if jt in ("RightSemi", "RightAnti"):
+        rows, m = _marked_rows(tc, opb2, k2, nr, jt == "RightSemi")
+        return _select_view(tc, rtab, rows, m)
+    lparts, rparts = [ob2], [opb2]
+    if jt in ("Left", "Full"):
+        rows, m = _marked_rows(tc, ob2, k2, nl, False)
+        lparts.append(rows); rparts.append(torch.full((m,), -1, dtype=torch.int32, device=tc.device))
+    if jt in ("Right", "Full"):
+        rows, m = _marked_rows(tc, opb2, k2, nr, False)
+        lparts.append(torch.full((m,), -1, dtype=torch.int32, device=tc.device)); rparts.append(rows)
+    ob3, opb3 = torch.cat(lparts), torch.cat(rparts)
+    return _join_view(tc, ltab, rtab, ob3, opb3, int(ob3.numel()))
 
 
 def _join_view(tc, ltab, rtab, ob, opb, k):

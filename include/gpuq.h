@@ -199,6 +199,13 @@ int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpu
    (Left/Full outer remainder, LeftAnti).  Ordered.  Asynchronous. */
 int gpuq_join_build_side_rows(gpuq_join_table* t, void* stream, int matched, uint32_t* rows_out, uint64_t* count_out);
 
+/* HashJoinExec with a JoinFilter on a non-inner join (datafusion.proto:1346-1360 `filter`): a pair that fails the filter does not
+   count as a match.  The executors probe as Inner, filter the pairs, and derive the outer / semi / anti parts from the pairs
+   that survive: gpuq_mark_rows sets bitmap bit rows[i] for every surviving pair (0xFFFFFFFF skipped; bitmap zeroed by the
+   caller, 8-byte aligned, one bit per row of that side); the unmarked / marked rows are then selected with an ordinary filter
+   over that Boolean column.  Asynchronous. */
+int gpuq_mark_rows(gpuq_ctx* ctx, void* stream, const uint32_t* rows, int64_t n, uint8_t* bitmap);
+
 /* SortExec: writes the permutation (driving positions in sorted order; stable) to perm_out (n_rows).
    Asynchronous. */
 int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out);

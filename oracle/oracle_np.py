@@ -595,8 +595,10 @@ def _avg_final(st, sums, cnts, at):
     return "Float64", [None if (c == 0 or v is None) else v / c for v, c in zip(sums, cnts)]
 
 
-def hash_join(left, right, on, join_type="Inner", null_equals_null=False, left_pred=None, right_pred=None):
-    """HashJoinExec: list of (left_row | None, right_row | None).  Build = LEFT input.  Pair order unspecified."""
+def hash_join(left, right, on, join_type="Inner", null_equals_null=False, left_pred=None, right_pred=None, pair_filter=None):
+    """HashJoinExec: list of (left_row | None, right_row | None).  Build = LEFT input.  Pair order unspecified.
+    pair_filter(i, j) -> True/False/None: the JoinFilter; a key match it does not accept (False or NULL) is no match, for the
+    outer / semi / anti bookkeeping as well (datafusion HashJoinExec applies the filter before it marks rows visited)."""
     lrows = filter_rows(left, left_pred) if left_pred is not None else list(range(left.n))
     rrows = filter_rows(right, right_pred) if right_pred is not None else list(range(right.n))
     lk = [eval_expr(l, left)[1] for l, _ in on]
@@ -612,6 +614,8 @@ def hash_join(left, right, on, join_type="Inner", null_equals_null=False, left_p
     for j in rrows:
         k = tuple(c[j] for c in rk)
         ms = [] if (any(x is None for x in k) and not null_equals_null) else table.get(k, [])
+        if pair_filter is not None:
+            ms = [i for i in ms if pair_filter(i, j) is True]
         for i in ms:
             pairs.append((i, j)); visited.add(i)
         matched_right.append((j, bool(ms)))

@@ -431,6 +431,48 @@ def test_hash_join_null_equals_null_and_fused_filters(tc):
     assert got2 == exp2
 
 
+@pytest.mark.parametrize("jt", JOIN_TYPES[1:])
+def test_hash_join_filter_on_outer_semi_anti(tc, jt):
+    """JoinFilter on the non-inner join types (q21 / q22 shape: semi / anti join with a residual predicate): a key match the
+    filter rejects -- False or NULL -- is no match; sides' own predicates apply before the join."""
+    nl, nr = 1500, 4000
+    lt = rand_table(41, nl, 0.15).append_column("lid", pa.array(np.arange(nl, dtype=np.int64)))
+    rt = rand_table(42, nr, 0.15).append_column("rid", pa.array(np.arange(nr, dtype=np.int64)))
+    rt = rt.rename_columns([c if c == "rid" else "r_" + c for c in rt.schema.names])
+    L, R = g.MemoryExec([lt]), g.MemoryExec([rt])
+    ls, rs = L.schema(), R.schema()
+    ol, orr = O.Table.from_arrow(lt), O.Table.from_arrow(rt)
+    on = [(col("k32", ls), col("r_k32", rs))]
+    both = ls + rs
+    jf = and_(binary(col("dec", both), Op.Lt, col("r_dec", both)), binary(col("flag", both), Op.NotEq, col("r_flag", both)))
+
+    def pf(i, j):
+        a, b, c, d = ol.col("dec")[i], orr.col("r_dec")[j], ol.col("flag")[i], orr.col("r_flag")[j]
+        x = None if a is None or b is None else a < b
+        y = None if c is None or d is None else c != d
+        return False if (x is False or y is False) else (None if (x is None or y is None) else True)
+    lp = binary(col("k64", ls), Op.Gt, lit(20))
+    rp = binary(col("r_d", rs), Op.Lt, lit(10200, "Date32"))
+    for left, right, lpred, rpred in ((L, R, None, None), (g.FilterExec(lp, L), g.CoalesceBatchesExec(g.FilterExec(rp, R)), lp, rp)):
+        plan = g.HashJoinExec(left, right, on, jf, jt, "CollectLeft", False)
+        exp_pairs = O.hash_join(ol, orr, on, jt, left_pred=lpred, right_pred=rpred, pair_filter=pf)
+        for runner in ("mirror", "native"):
+            def rows(p):
+                return dev_rows(tc, p.execute(0, tc)) if runner == "mirror" else __import__("test_gpu_native_plan").native_rows(tc, p)[0]
+            if jt in ("LeftSemi", "LeftAnti"):
+                got = sorted(r[0] for r in rows(g.ProjectionExec([(col("lid", ls), "lid")], plan)))
+                exp = sorted(i for i, _ in exp_pairs)
+            elif jt in ("RightSemi", "RightAnti"):
+                got = sorted(r[0] for r in rows(g.ProjectionExec([(col("rid", rs), "rid")], plan)))
+                exp = sorted(j for _, j in exp_pairs)
+            else:
+                js = plan.schema()
+                got = norm(rows(g.ProjectionExec([(col("lid", js), "lid"), (col("rid", js), "rid"), (col("s", js), "s"), (col("r_f", js), "r_f")], plan)))
+                exp = norm([(i, j, None if i is None else ol.col("s")[i], None if j is None else orr.col("r_f")[j]) for i, j in exp_pairs])
+            assert got == exp, (jt, runner, lpred is not None)
+            assert len(exp) > 0
+
+
 def test_join_then_aggregate_then_sort_pipeline(tc):
     """q3-shaped: filter -> join -> join -> group-by -> sort, all through late-materialised views."""
     r = np.random.default_rng(3)
