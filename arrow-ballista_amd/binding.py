@@ -52,7 +52,8 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "libgpuq.so")
+    # GPUQ_LIB: another build of the same library (A/B measurements of a kernel change on one box)
+    return os.environ.get("GPUQ_LIB") or os.path.join(_HERE, "libgpuq.so")
 
 
 def lib():
@@ -89,6 +90,7 @@ def lib():
         "gpuq_table_free": (None, [vp]),
         "gpuq_export_arrow": (i32, [vp, vp, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info), i32, i64, vp, vp]),
         "gpuq_ctx_set_jit": (i32, [vp, C.c_char_p, i64]),
+        "gpuq_ctx_jit_wait": (i32, [vp]),
         "gpuq_ctx_jit_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]),
         "gpuq_op_jit_source": (i32, [vp, i32, C.c_char_p, C.c_size_t]),
         "gpuq_op_create": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
@@ -192,6 +194,10 @@ class Context:
 
     def set_jit(self, mode, min_rows=-1):
         self.check(self.L.gpuq_ctx_set_jit(self.h, mode.encode(), int(min_rows)))
+
+    def jit_wait(self):
+        """Wait for the background specialisation of hot small-input programs requested so far."""
+        self.check(self.L.gpuq_ctx_jit_wait(self.h))
 
     def jit_stats(self):
         a, n = C.c_int(0), C.c_int(0)

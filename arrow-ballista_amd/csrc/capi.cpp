@@ -52,6 +52,7 @@ struct gpuq_op {
   AggSpec agg{}; KeySpec keys{};
   std::vector<DType> key_types, acc_types;
   std::vector<int> acc_bits;        // |argument| < 2^bits per accumulator (type-derived): lets the specialised kernel drop range checks
+  std::map<std::pair<const void*, int>, int> jit_runs;      // (program, sink kernel) -> small-input runs so far (background tier)
   struct PostChunk { CompiledProgram prog; DevBuf code; int first_out = 0; };
   std::deque<PostChunk> posts; Schema post_schema;
   i64 expected_groups = 0;
@@ -176,10 +177,14 @@ struct JitScope {
   bool active = false;
   JitScope(gpuq_op* op, const CompiledProgram& cp, int kernel_id, i64 n, const std::string& spec = std::string()) {
     gpuq_ctx* c = op->ctx;
+    if (cp.jit_src.empty() || c->jit_mode == 0) return;
     const bool use = c->jit_mode == 2 || (c->jit_mode == 1 && n >= c->jit_min_rows);
-    if (!use || cp.jit_src.empty()) return;
+    // auto mode, small input: only a program that keeps coming back (third run on) is worth a compile, and nobody waits for it
+    const bool hot = !use && ++op->jit_runs[{(const void*)&cp, kernel_id}] > 2;
+    if (!use && !hot) return;
     try {
-      const JitFn* f = jit_get(cp.jit_src + spec, kernel_id);
+      const JitFn* f = use ? jit_get(cp.jit_src + spec, kernel_id) : jit_try_get(cp.jit_src + spec, kernel_id);
+      if (!f) return;
       jit_override().fn = f->fn; jit_override().kernel_id = kernel_id; active = true; c->jit_launches++;
     } catch (const std::exception& e) {
       if (c->jit_mode == 2) throw Unsupported(e.what());
@@ -804,7 +809,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         const int no = (int)pc.prog.out_reg.size();
         std::vector<gpuq_field_info> fi(op->out_fields.begin() + pc.first_out, op->out_fields.begin() + pc.first_out + no);
         OutSpec O = make_outspec(pc.prog, outs + pc.first_out, no, fi);
-        launch_project(s, PP, rows, O);
+        { JitScope js(op, pc.prog, 2, rows); launch_project(s, PP, rows, O); }
       }
     };
     bool done = false;
@@ -1534,6 +1539,7 @@ int gpuq_ctx_set_jit(gpuq_ctx* ctx, const char* mode, int64_t min_rows) {
     if (min_rows >= 0) ctx->jit_min_rows = min_rows;
   });
 }
+int gpuq_ctx_jit_wait(gpuq_ctx* ctx) { return guarded(ctx, [&]() { check_ctx(ctx); jit_drain(); }); }
 int gpuq_ctx_jit_stats(gpuq_ctx* ctx, int* available, int* launches, char* last_error, size_t cap) {
   if (!ctx) return GPUQ_ERR_INVALID;
   if (available) *available = jit_available() ? 1 : 0;

@@ -8,9 +8,15 @@
 #include "jit_runtime.h"
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
+#include <set>
+#include <thread>
 #include <stdexcept>
 #include <vector>
 
@@ -90,11 +96,8 @@ std::string jit_full_source(const std::string& eval_src, int kernel_id) {
          "\n#include \"gpuq_kernels.h\"\nnamespace gpuq {\n" + eval_src + "}\n#include \"" + file_of(kernel_id) + "\"\n";
 }
 
-const JitFn* jit_get(const std::string& eval_src, int kernel_id) {
-  const std::string key = std::to_string(kernel_id) + "|" + eval_src;
-  std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_cache.find(key);
-  if (it != g_cache.end()) return &it->second;
+// hiprtc compile + module load of one (front-end source, sink) pair; no lock held
+static JitFn compile_and_load(const std::string& eval_src, int kernel_id) {
   Rtc& r = rtc();
   if (!r.ok) throw std::runtime_error("jit: hiprtc is not available on this host");
   const std::string src = jit_full_source(eval_src, kernel_id);
@@ -119,7 +122,87 @@ const JitFn* jit_get(const std::string& eval_src, int kernel_id) {
   e = hipModuleGetFunction(&fn, mod, jit_entry_name(kernel_id));
   if (e != hipSuccess) throw std::runtime_error(std::string("jit: hipModuleGetFunction: ") + hipGetErrorString(e));
   f.module = mod; f.fn = fn;
-  return &(g_cache[key] = f);
+  return f;
+}
+
+const JitFn* jit_get(const std::string& eval_src, int kernel_id) {
+  const std::string key = std::to_string(kernel_id) + "|" + eval_src;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) return &it->second;
+  }
+  const JitFn f = compile_and_load(eval_src, kernel_id);      // two threads may compile the same key; the first insert wins
+  std::lock_guard<std::mutex> lk(g_mu);
+  return &g_cache.emplace(key, f).first->second;
+}
+
+// ---- background tier: operators that run again and again on small inputs (a stage's many small partitions, the final stage
+// of a two-phase aggregate) are worth specialising too -- a lone wave interprets ~100 instructions in ~20 us, the generated
+// code runs them in ~3 -- but nobody should wait for the compiler: the request is queued, a worker thread compiles, callers
+// keep using the interpreter kernels until the function is there.
+namespace {
+struct BgJob { std::string key, src; int kernel_id; int device; };
+struct Bg {
+  std::mutex mu; std::condition_variable cv, idle;
+  std::deque<BgJob> queue; std::set<std::string> known;      // queued, running, done or failed: never requested twice
+  bool running = false, started = false, stop = false;
+};
+Bg& bg() { static Bg* b = new Bg(); return *b; }      // leaked on purpose: the worker may outlive static destruction
+void bg_worker() {
+  Bg& B = bg();
+  for (;;) {
+    BgJob job;
+    {
+      std::unique_lock<std::mutex> lk(B.mu);
+      B.cv.wait(lk, [&] { return B.stop || !B.queue.empty(); });
+      if (B.stop) { B.running = false; B.idle.notify_all(); return; }
+      job = std::move(B.queue.front()); B.queue.pop_front(); B.running = true;
+    }
+    try {
+      (void)hipSetDevice(job.device);
+      const JitFn f = compile_and_load(job.src, job.kernel_id);
+      std::lock_guard<std::mutex> lk(g_mu);
+      g_cache.emplace(job.key, f);
+    } catch (const std::exception&) { /* stays on the interpreter kernels */ }
+    {
+      std::lock_guard<std::mutex> lk(B.mu);
+      B.running = false;
+      if (B.queue.empty()) B.idle.notify_all();
+    }
+  }
+}
+void bg_stop_at_exit() {
+  Bg& B = bg();
+  std::unique_lock<std::mutex> lk(B.mu);
+  B.queue.clear(); B.stop = true; B.cv.notify_all();
+  B.idle.wait_for(lk, std::chrono::seconds(20), [&] { return !B.running; });      // do not tear the runtime down under a compile
+}
+}  // namespace
+
+const JitFn* jit_try_get(const std::string& eval_src, int kernel_id) {
+  const std::string key = std::to_string(kernel_id) + "|" + eval_src;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) return &it->second;
+  }
+  if (!rtc().ok) return nullptr;
+  Bg& B = bg();
+  std::lock_guard<std::mutex> lk(B.mu);
+  if (B.stop || !B.known.insert(key).second) return nullptr;
+  int dev = 0; (void)hipGetDevice(&dev);
+  B.queue.push_back({key, eval_src, kernel_id, dev});
+  if (!B.started) { B.started = true; std::thread(bg_worker).detach(); std::atexit(bg_stop_at_exit); }
+  B.cv.notify_one();
+  return nullptr;
+}
+
+void jit_drain() {
+  Bg& B = bg();
+  std::unique_lock<std::mutex> lk(B.mu);
+  if (!B.started) return;
+  B.idle.wait(lk, [&] { return B.queue.empty() && !B.running; });
 }
 
 }  // namespace gpuq

@@ -97,6 +97,10 @@ int gpuq_ctx_device_info(gpuq_ctx* ctx, char* buf, size_t cap); /* JSON: name, a
    | "force" (errors are reported).  Default "auto", 2^21 rows; env GPUQ_JIT overrides at ctx creation. */
 int gpuq_ctx_set_jit(gpuq_ctx* ctx, const char* mode, int64_t min_rows /* <0 = keep */);
 int gpuq_ctx_jit_stats(gpuq_ctx* ctx, int* available, int* launches, char* last_error, size_t cap);
+/* In "auto" mode a program that runs for the third time on inputs below min_rows is handed to a background thread for
+   specialisation; its callers keep running the interpreter kernels until the compiled function is there.  This call waits
+   until every compile requested so far has finished (benchmarks call it at the end of their warm-up). */
+int gpuq_ctx_jit_wait(gpuq_ctx* ctx);
 
 /* ---- device memory + Arrow C Data Interface ingest/egress ---------------------------------- */
 /* A host that owns Arrow RecordBatches (arrow-rs `arrow::ffi`, pyarrow `_export_to_c`) hands them over
