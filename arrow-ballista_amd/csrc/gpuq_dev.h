@@ -278,22 +278,10 @@ typedef const DevCode __attribute__((address_space(4))) * ConstCode;
 __device__ __forceinline__ ConstCode const_code(const DevProgram& P) {
   return (ConstCode)(unsigned long long)(const void*)P.code;
 }
-// Small inputs turn an interpreter kernel into one latency chain: the scalar cache starts cold at every launch, and after a
-// multi-GB scan so does L2, so each 64-byte line of the instruction stream (8 instructions) costs a trip to HBM -- ~24 us for a
-// 96-instruction post program over 4 rows.  Kernels that run on such inputs copy the whole DevCode (1 KiB) into LDS with one
-// wave-wide load at entry (GPUQ_STAGE_CODE) and interpret from there (LDS = true).
-__device__ __forceinline__ void stage_code(const DevProgram& P, DevCode* s) {
-  const ulonglong2* src = (const ulonglong2*)P.code; ulonglong2* dst = (ulonglong2*)s;
-  for (int i = (int)threadIdx.x; i < (int)(sizeof(DevCode) / 16); i += (int)blockDim.x) dst[i] = src[i];
-  __syncthreads();
-}
-template <bool LDS = false>
-__device__ __forceinline__ void run_program(const DevProgram& P, GPUQ_REGS_PARAM, const DevCode* sc = nullptr) {
+__device__ __forceinline__ void run_program(const DevProgram& P, GPUQ_REGS_PARAM) {
   ConstCode code = const_code(P);
   for (int p = 0; p < P.n_insns; ++p) {
-    unsigned long long raw;
-    if (LDS) raw = *(const unsigned long long*)&sc->insns[p];
-    else raw = *(const unsigned long long __attribute__((address_space(4)))*)&code->insns[p];
+    const unsigned long long raw = *(const unsigned long long __attribute__((address_space(4)))*)&code->insns[p];
     DevInsn in;
     in.op = (uint8_t)raw; in.dst = (uint8_t)(raw >> 8); in.a = (uint8_t)(raw >> 16); in.b = (uint8_t)(raw >> 24); in.imm = (uint32_t)(raw >> 32);
     const int op = __builtin_amdgcn_readfirstlane((int)in.op);
@@ -306,7 +294,7 @@ __device__ __forceinline__ void run_program(const DevProgram& P, GPUQ_REGS_PARAM
     u64 zlo = 0, zhi = 0;
     bool zn = an || bn;  // default null propagation for binary ops
     switch (op) {
-      case OP_IMM: if (LDS) { zlo = sc->imm_lo[imm]; zhi = sc->imm_hi[imm]; } else { zlo = code->imm_lo[imm]; zhi = code->imm_hi[imm]; } zn = false; break;
+      case OP_IMM: zlo = code->imm_lo[imm]; zhi = code->imm_hi[imm]; zn = false; break;
       case OP_MOV: zlo = alo; zhi = ahi; zn = an; break;
       case OP_ADD: { i128 z = mk128(alo, ahi) + mk128(blo, bhi); zlo = (u64)z; zhi = (u64)((u128)z >> 64); break; }
       case OP_SUB: { i128 z = mk128(alo, ahi) - mk128(blo, bhi); zlo = (u64)z; zhi = (u64)((u128)z >> 64); break; }
@@ -381,16 +369,11 @@ __device__ __forceinline__ bool row_passes(const DevProgram& P, GPUQ_REGS_CPARAM
 }
 
 #define GPUQ_EVAL(MAXC, P, pos) (load_columns<MAXC>(P, pos, GPUQ_REGS), run_program(P, GPUQ_REGS), row_passes(P, GPUQ_REGS))
-// at the top of a kernel body, before any thread can leave: the instruction stream goes to LDS; GPUQ_EVAL_S then reads it there
-#define GPUQ_STAGE_CODE(P) __shared__ ::gpuq::DevCode gpuq_scode_; ::gpuq::stage_code(P, &gpuq_scode_)
-#define GPUQ_EVAL_S(MAXC, P, pos) (load_columns<MAXC>(P, pos, GPUQ_REGS), run_program<true>(P, GPUQ_REGS, &gpuq_scode_), row_passes(P, GPUQ_REGS))
 #else
 // JIT build: the row front-end is a generated, typed, straight-line function (jit_codegen.cpp) with the
 // same contract: fills the registers the sink reads and returns the row predicate.
 __device__ __forceinline__ bool gpuq_jit_eval(const DevProgram& P, i64 pos, GPUQ_REGS_PARAM);
 #define GPUQ_EVAL(MAXC, P, pos) gpuq_jit_eval(P, pos, GPUQ_REGS)
-#define GPUQ_STAGE_CODE(P) do {} while (0)
-#define GPUQ_EVAL_S(MAXC, P, pos) gpuq_jit_eval(P, pos, GPUQ_REGS)
 #endif
 
 // ---------------------------------------------------------------- hashing

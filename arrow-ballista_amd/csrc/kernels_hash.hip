@@ -157,7 +157,6 @@ __global__ void __launch_bounds__(HBLOCK) k_ht_init(const HashTable T, const Agg
 // ------------------------------------------------------------------ hash aggregate
 template <int MAXC>
 __device__ __forceinline__ void k_agg_hash_body(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T) {
-  GPUQ_STAGE_CODE(P);
   const i64 nwords = (n + 63) >> 6;
   const int cell0 = 1 + T.key_words;
   // Rows with equal keys in neighbouring lanes (clustered input: lineitem rows of one order, a join's probe-ordered
@@ -170,7 +169,7 @@ __device__ __forceinline__ void k_agg_hash_body(const DevProgram P, const i64 n,
     const i64 pos = (w << 6) + lane;
     bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) active = GPUQ_EVAL_S(MAXC, P, pos);
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
     if (__ballot(active) == 0) continue;
     u64 kw[MAX_KW]; u64 h = 0;
 #pragma unroll

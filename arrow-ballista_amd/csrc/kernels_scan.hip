@@ -127,7 +127,6 @@ __global__ void __launch_bounds__(BLOCK) k_compact(const u64* __restrict__ bitma
 // ------------------------------------------------------------------ project
 template <int MAXC>
 __device__ __forceinline__ void k_project_body(const DevProgram P, const i64 n_arg, const OutSpec O) {
-  GPUQ_STAGE_CODE(P);
   i64 n = n_arg;
   if (P.n_dev) { const i64 nd = (i64)*P.n_dev; if (nd < n) n = nd; }
   const i64 nwords = (n + 63) >> 6;
@@ -135,7 +134,7 @@ __device__ __forceinline__ void k_project_body(const DevProgram P, const i64 n_a
     const i64 pos = (w << 6) + lane_id();
     const bool active = pos < n;
     GPUQ_REGS_DECL;
-    if (active) (void)GPUQ_EVAL_S(MAXC, P, pos);
+    if (active) (void)GPUQ_EVAL(MAXC, P, pos);
 #pragma unroll
     for (int k = 0; k < MAX_OUTS; ++k) {
       if (k < O.n_out) {
