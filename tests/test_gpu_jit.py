@@ -94,3 +94,34 @@ def test_clustered_probe_keys_jit(jit, jt):
     else:
         exp = [(lrows[i] if i is not None else (None,) * 2) + (rrows[j] if j is not None else (None,) * 3) for i, j in pairs]
     assert got == M.norm(exp)
+
+
+def test_background_tier_switches_without_changing_results(tc):
+    """auto mode: a plan that keeps running on a small input is specialised by the worker thread from its third run on; the
+    rows before, while and after the switch are the oracle's, and the specialised kernels do get launched afterwards."""
+    st = tc.ctx.jit_stats()
+    if not st["available"]:
+        pytest.skip("hiprtc not available")
+    import arrow_ballista_amd as g
+    from test_gpu_native_plan import arrow_rows
+
+    def rows(res):
+        return [tuple(r) for r in arrow_rows(res.to_arrow())]
+    tc.ctx.set_jit("auto")
+    n = 3000
+    li = T.gen_lineitem_device(tc, n, seed=23)
+    exp = T.q1_oracle_rows(n, seed=23)
+    plan = g.NativePlan(T.q1_plan(g.MemoryExec([li]), two_phase=True), tc)
+    before = tc.ctx.jit_stats()["launches"]
+    for _ in range(4):
+        assert rows(plan.execute(0)) == exp
+    tc.ctx.jit_wait()
+    mid = tc.ctx.jit_stats()["launches"]
+    for _ in range(3):
+        assert rows(plan.execute(0)) == exp
+    assert tc.ctx.jit_stats()["launches"] > mid >= before
+    # switched off: the counters stand still and the interpreter kernels give the same rows
+    tc.ctx.set_jit("off")
+    off = tc.ctx.jit_stats()["launches"]
+    assert rows(plan.execute(0)) == exp and tc.ctx.jit_stats()["launches"] == off
+    tc.ctx.set_jit("auto")
