@@ -56,6 +56,7 @@ struct gpuq_op {
   struct PostChunk { CompiledProgram prog; DevBuf code; int first_out = 0; };
   std::deque<PostChunk> posts; Schema post_schema;
   i64 expected_groups = 0;
+  i64 last_groups = -1;             // groups of this operator's previous run
   // join
   int join_type = JT_INNER; int null_eq = 0;
   // sort
@@ -819,7 +820,12 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
     // tiny input: a 2n-slot table beats the LDS kernel's fixed per-block cost (measured: 60 us for the five small hash-path
     // launches against 83 us for one cold block of the 16-slot LDS kernel on a 4-row input)
     if (strat == "auto" && n <= 16384) strat = "hash";
-    if (strat == "auto" || strat == "tiny") {
+    // groups this operator is expected to produce: the caller's hint, else what its previous run produced (another partition
+    // of the same stage, the same query again)
+    const i64 known_groups = op->expected_groups > 0 ? op->expected_groups : op->last_groups;
+    if (strat == "auto" && nk > 0 && known_groups > (i64)agg_tiny_max_groups(na)) {
+      // more groups than the LDS dictionary holds: do not even try it
+    } else if (strat == "auto" || strat == "tiny") {
       const int fit_big = agg_tiny_max_groups(na);
       if (fit_big < 1) { if (strat == "tiny") throw Unsupported("too many accumulators for the LDS aggregate"); }
       else {
@@ -828,6 +834,8 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         if (nk == 0) tries = {1};
         else if (exact_gmax > 0) tries = {exact_gmax};
         else { if (fit_small > 4) { tries.push_back(4); } if (fit_small >= 2) tries.push_back(fit_small); if (fit_big > fit_small) tries.push_back(fit_big); }
+        // a known group count goes straight to the smallest capacity that holds it
+        if (nk > 0 && known_groups > 0) while (tries.size() > 1 && (i64)tries.front() < known_groups) tries.erase(tries.begin());
         for (int gmax : tries) {
           int nb = 0; const size_t wsb = agg_tiny_workspace_bytes(gmax, nk, na, &nb);
           void* wsp = op->ws[4].ensure(wsb);
@@ -851,16 +859,18 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         if (!done && strat == "tiny") throw Capacity("more groups than the LDS aggregate holds; use strategy hash/auto");
       }
     }
-    if (!done && (strat == "radix" || (strat == "auto" && n >= (1ll << 22) && op->expected_groups >= (1ll << 20)))) {
+    if (!done && (strat == "radix" || (strat == "auto" && ((n >= (1ll << 22) && op->expected_groups >= (1ll << 20)) ||
+                                                            (n >= (1ll << 20) && known_groups >= 4096))))) {
       // High cardinality: partition the rows by key hash into buckets whose groups fit an LDS table, aggregate every bucket
       // inside one block (kernels_hash.hip).  Falls through to the global table when a bucket overflows (skew, or more
       // groups than the hint promised).
       const int slot_words = 1 + op->keys.key_words + 2 * na;
       uint32_t capslots = 64; while ((size_t)capslots * 2 * slot_words * 8 <= 60 * 1024) capslots *= 2;
       if ((size_t)capslots * slot_words * 8 <= 60 * 1024 && n < (1ll << 31)) {
-        const u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (u64)n;
+        const u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (op->last_groups > 0 ? (u64)op->last_groups + (u64)op->last_groups / 4 : (u64)n);
         const u64 per_bucket = std::max<u64>(1, (u64)capslots / 2);             // mean load 0.5: buckets are Poisson-even (hash bits), sqrt(mean) of spread
         u64 nbk = next_pow2(std::max<u64>(1, (est + per_bucket - 1) / per_bucket)); if (nbk > (1ull << 24)) nbk = 1ull << 24;
+        if (n >= (1ll << 20) && nbk < 2048) nbk = 2048;                          // one block per bucket: enough of them to fill the chip
         int bits = 0; while ((1ull << bits) < nbk) ++bits;
         DevBuf b_bid, b_bid2, b_ids, b_ids2, b_hist, b_scan, b_bounds;
         u64* bid = (u64*)b_bid.ensure((size_t)n * 8); u64* bid2 = (u64*)b_bid2.ensure((size_t)n * 8);
@@ -890,16 +900,24 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
     }
     if (!done) {
       // global hash table; grow on FLAG_TABLE_FULL
-      u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (u64)std::min<i64>(std::max<i64>(n, 1), 1ll << 24);
+      // the group count this operator produced last time (another partition of the same stage, the same query again) stands in
+      // for a missing expected_groups: it sizes the table and decides on block-local pre-aggregation
+      const i64 known = known_groups >= 0 ? (op->expected_groups > 0 ? known_groups : std::max<i64>(known_groups * 2, 64)) : -1;
+      u64 est = known > 0 ? (u64)std::min<i64>(known, std::max<i64>(n, 1)) : (u64)std::min<i64>(std::max<i64>(n, 1), 1ll << 24);
       if (est < 64) est = 64;
       HashTable T{};
       T.key_words = op->keys.key_words; T.slot_words = 1 + T.key_words + 2 * na;
+      // medium cardinality (known, and a block's LDS table holds a good share of the groups): fold rows inside the block first
+      const uint32_t lslots = agg_lds_slots(T);
+      const bool use_lds = strat == "lds" || (strat == "auto" && lslots > 0 && n >= (1ll << 17) && known > 0 && known <= (i64)lslots * 4);
+      if (strat == "lds" && !lslots) throw Unsupported("lds aggregate: the group state does not fit an LDS table");
       for (;;) {
         T.n_slots = next_pow2(est * 2);
         T.slots = (u64*)op->ws[5].ensure((size_t)T.n_slots * T.slot_words * 8);
         launch_ht_init(s, T, &op->agg);
         reset_flags(op, s);
-        { JitScope js(op, op->prog, 4, n); ProfScope ps(op, s); launch_agg_hash(s, P, n, op->keys, op->agg, T); }
+        if (use_lds) { JitScope js(op, op->prog, 13, n); ProfScope ps(op, s); launch_agg_lds(s, P, n, op->keys, op->agg, T); }
+        else { JitScope js(op, op->prog, 4, n); ProfScope ps(op, s); launch_agg_hash(s, P, n, op->keys, op->agg, T); }
         HIPCHECK(hipGetLastError());
         const uint32_t f = (n <= (1ll << 20) && est >= (u64)n) ? 0u : read_flags(op, s);   // a 2n-slot table cannot fill up; other flags surface after extract
         if (f & FLAG_TABLE_FULL) { if (est >= (u64)std::max<i64>(n, 1024)) throw std::runtime_error("hash aggregate: table full at maximum size"); est = std::min<u64>(est * 4, (u64)std::max<i64>(n, 1024)); continue; }
@@ -933,6 +951,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         ng = read_ng();
       }
     }
+    op->last_groups = (i64)ng;
     if (n_groups_out) *n_groups_out = ng;
     if ((i64)ng > cap) throw Capacity("aggregate produced " + std::to_string(ng) + " groups, output capacity is " + std::to_string(cap));
     for (int i = 0; i < n_outs; ++i) outs[i].length = ng;

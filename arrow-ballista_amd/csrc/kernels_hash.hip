@@ -407,6 +407,184 @@ __device__ __forceinline__ uint32_t lds_slot_find_or_insert(u64* slots, const ui
   return 0xFFFFFFFFu;
 }
 
+// ------------------------------------------------------------------ block-local pre-aggregation (medium cardinality)
+// A group-by with a few hundred to a few thousand groups (too many for k_agg_tiny's register-cached dictionary, few enough
+// that every row of a 10 M-row input hits one of a handful of hot slots) makes the global table a contention point: device-
+// scope atomics run at ~10 G/s spread over addresses, far less on a hundred hot ones (h2o q1: 14 ms for 10 M rows; three
+// float sums per row: 540 ms).  Here every block folds its rows into an LDS table first (LDS atomics are per-CU) and only
+// the table's entries go to the global table: #blocks x #groups global operations instead of #rows.  LDS slot = [state/tag,
+// hash, key words, 2 words per accumulator]; a block whose table runs full sends its remaining rows straight to the global
+// table, so the kernel is correct for any cardinality -- the host only picks it when the group count is known to be small.
+constexpr uint32_t LDS_PROBES = 32;
+__device__ __forceinline__ uint32_t lds_group_slot(u64* slots, const uint32_t cap, const int lw, const int key_words, const u64 (&kw)[MAX_KW], const u64 h) {
+  const uint32_t mask = cap - 1;
+  uint32_t s = (uint32_t)(h >> 17) & mask;
+  const u64 tag = (u64)tag_of(h);
+  for (uint32_t probes = 0; probes < LDS_PROBES;) {
+    u64* slot = slots + (size_t)s * lw;
+    u64 st = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (st == 0) {
+      u64 expected = 0;
+      if (__hip_atomic_compare_exchange_strong(slot, &expected, 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        __hip_atomic_store(slot + 1, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int q = 0; q < MAX_KW; ++q) if (q < key_words) __hip_atomic_store(slot + 2 + q, kw[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __hip_atomic_store(slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return s;
+      }
+      st = expected;
+    }
+    if (st == 1) continue;                           // being published by another lane: look again
+    if (st == tag) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      bool eq = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == h;
+#pragma unroll
+      for (int q = 0; q < MAX_KW; ++q) if (q < key_words) eq = eq && (__hip_atomic_load(slot + 2 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kw[q]);
+      if (eq) return s;
+    }
+    s = (s + 1) & mask; ++probes;
+  }
+  return NIL;
+}
+// one accumulator value folded into a GLOBAL cell (device-scope atomics); FMIN/FMAX through a CAS loop on the total order
+__device__ __forceinline__ void global_fold(u64* c, const int kind, const u64 vlo, const u64 vhi) {
+  switch (kind) {
+    case ACC_COUNT: case ACC_COUNT_STAR: if (vlo) a_add(c, vlo); break;
+    case ACC_SUM: {
+      if (!(vlo | vhi)) break;
+      const u64 old = a_add(c, vlo);
+      const u64 carry = (old + vlo < old) ? 1 : 0;
+      if (vhi + carry) a_add(c + 1, vhi + carry);
+      break;
+    }
+    case ACC_MIN: __hip_atomic_fetch_min((i64*)c, (i64)vlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+    case ACC_MAX: __hip_atomic_fetch_max((i64*)c, (i64)vlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+    case ACC_FSUM: unsafeAtomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;
+    case ACC_FMIN: case ACC_FMAX: {
+      u64 cur = a_load(c);
+      for (;;) {
+        const bool better = (kind == ACC_FMIN) ? (f64_total_key(vlo) < f64_total_key(cur)) : (f64_total_key(vlo) > f64_total_key(cur));
+        if (!better) break;
+        const u64 seen = a_cas(c, cur, vlo);
+        if (seen == cur) break;
+        cur = seen;
+      }
+      break;
+    }
+    default: break;
+  }
+}
+
+template <int MAXC>
+__device__ __forceinline__ void k_agg_lds_body(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap) {
+  extern __shared__ __attribute__((aligned(16))) u64 lslots[];
+  __shared__ uint32_t lfull;
+  const int key_words = K.key_words;
+  const int lw = T.slot_words + 1, lcell0 = 2 + key_words, gcell0 = 1 + key_words;
+  for (uint32_t i = threadIdx.x; i < lcap * (uint32_t)lw; i += HBLOCK) {
+    const int w = (int)(i % (uint32_t)lw);
+    u64 v = 0;
+    if (w >= lcell0) {
+      const int a = (w - lcell0) >> 1, half = (w - lcell0) & 1;
+      if (a < A.n_accs) {
+        switch (A.acc_kind[a]) {
+          case ACC_MIN: v = half ? 0 : 0x7FFFFFFFFFFFFFFFull; break;
+          case ACC_MAX: v = half ? ~0ull : 0x8000000000000000ull; break;
+          case ACC_FMIN: v = half ? 0 : 0x7FF0000000000000ull; break;
+          case ACC_FMAX: v = half ? 0 : 0xFFF0000000000000ull; break;
+          default: break;
+        }
+      }
+    }
+    lslots[i] = v;
+  }
+  if (threadIdx.x == 0) lfull = 0;
+  __syncthreads();
+  const i64 nwords = (n + 63) >> 6;
+  for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
+    const i64 pos = (w << 6) + hlane();
+    bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
+    if (!active) continue;
+    u64 kw[MAX_KW]; u64 h = 0;
+#pragma unroll
+    for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
+    make_key(K, GPUQ_REGS, kw, h);
+    uint32_t ls = NIL;
+    if (!__hip_atomic_load(&lfull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+      ls = lds_group_slot(lslots, lcap, lw, key_words, kw, h);
+      if (ls == NIL) __hip_atomic_store(&lfull, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    u64* gcells = nullptr;
+    if (ls == NIL) {                                  // this block's table is full: the row goes to the global table directly
+      bool inserted;
+      const u64 gs = ht_find_or_insert(T, kw, h, 0u, inserted);
+      if (gs == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
+      gcells = T.slots + gs * (u64)T.slot_words + gcell0;
+    }
+    u64* cells = lslots + (size_t)(ls == NIL ? 0 : ls) * lw + lcell0;
+    for (int a = 0; a < A.n_accs; ++a) {
+      const int kind = A.acc_kind[a];
+      u64 vlo = 1, vhi = 0; bool vnull = false;
+      if (kind != ACC_COUNT_STAR) {
+        const int r = __builtin_amdgcn_readfirstlane(A.acc_reg[a]);
+        vlo = rlo[r]; vhi = rhi[r]; vnull = (rnulls >> r) & 1;
+      }
+      if (vnull) continue;
+      if (kind == ACC_COUNT) { vlo = 1; vhi = 0; }
+      if ((kind == ACC_MIN || kind == ACC_MAX) && (i64)vhi != ((i64)vlo >> 63)) { atomicOr(P.flags, FLAG_WIDE_MINMAX); continue; }
+      if (gcells) { global_fold(gcells + 2 * a, kind, vlo, vhi); continue; }
+      u64* c = cells + 2 * a;
+      switch (kind) {
+        case ACC_COUNT: case ACC_COUNT_STAR: atomicAdd((unsigned long long*)c, 1ull); break;
+        case ACC_SUM: {
+          const u64 old = atomicAdd((unsigned long long*)c, (unsigned long long)vlo);
+          const u64 carry = (old + vlo < old) ? 1 : 0;
+          if (vhi + carry) atomicAdd((unsigned long long*)(c + 1), (unsigned long long)(vhi + carry));
+          break;
+        }
+        case ACC_MIN: atomicMin((long long*)c, (long long)vlo); break;
+        case ACC_MAX: atomicMax((long long*)c, (long long)vlo); break;
+        case ACC_FSUM: atomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;
+        case ACC_FMIN: case ACC_FMAX: {
+          u64 cur = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (;;) {
+            const bool better = (kind == ACC_FMIN) ? (f64_total_key(vlo) < f64_total_key(cur)) : (f64_total_key(vlo) > f64_total_key(cur));
+            if (!better) break;
+            const u64 seen = atomicCAS((unsigned long long*)c, (unsigned long long)cur, (unsigned long long)vlo);
+            if (seen == cur) break;
+            cur = seen;
+          }
+          break;
+        }
+        default: break;
+      }
+    }
+  }
+  __syncthreads();
+  // flush: every live LDS slot is folded into the global table
+  for (uint32_t sl = threadIdx.x; sl < lcap; sl += HBLOCK) {
+    const u64* slot = lslots + (size_t)sl * lw;
+    if (slot[0] < 2) continue;
+    u64 kw[MAX_KW];
+#pragma unroll
+    for (int q = 0; q < MAX_KW; ++q) kw[q] = (q < key_words) ? slot[2 + q] : 0;
+    bool inserted;
+    const u64 gs = ht_find_or_insert(T, kw, slot[1], 0u, inserted);
+    if (gs == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
+    u64* g = T.slots + gs * (u64)T.slot_words + gcell0;
+    for (int a = 0; a < A.n_accs; ++a) global_fold(g + 2 * a, A.acc_kind[a], slot[lcell0 + 2 * a], slot[lcell0 + 2 * a + 1]);
+  }
+}
+#ifndef GPUQ_JIT
+template <int MAXC>
+__global__ void __launch_bounds__(HBLOCK) k_agg_lds(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap) { k_agg_lds_body<MAXC>(P, n, K, A, T, lcap); }
+#elif GPUQ_JIT_KERNEL == 13
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap) { k_agg_lds_body<0>(P, n, K, A, T, lcap); }
+#endif
+
 template <int MAXC>
 __device__ __forceinline__ void k_agg_bucket_body(const DevProgram P, const KeySpec K, const AggSpec A, const uint32_t* __restrict__ ids,
                                                       const uint32_t* __restrict__ bounds, const uint32_t nbuckets, const uint32_t cap, const int slot_words,
@@ -890,6 +1068,24 @@ void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K
     (void)jit_launch(jit_override().fn, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, A, T);
   } else {
 #define CALL(M) hipLaunchKernelGGL(k_agg_hash<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, A, T)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
+  }
+}
+uint32_t agg_lds_slots(const HashTable& T) {      // LDS table size (slots) of the pre-aggregating kernel, 0 = a slot is too wide for it
+  const size_t bytes = (size_t)(T.slot_words + 1) * 8;
+  uint32_t cap = 1; while ((size_t)cap * 2 * bytes <= 32768) cap *= 2;
+  return cap >= 128 ? cap : 0;
+}
+void launch_agg_lds(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T) {
+  if (n <= 0) return;
+  const uint32_t lcap = agg_lds_slots(T);
+  const size_t lds = (size_t)lcap * (T.slot_words + 1) * 8;
+  const int grid = hgrid(n, 4);
+  if (jit_override().fn && jit_override().kernel_id == 13) {
+    (void)jit_launch(jit_override().fn, dim3(grid), dim3(HBLOCK), lds, s, P, n, K, A, T, lcap);
+  } else {
+#define CALL(M) hipLaunchKernelGGL(k_agg_lds<M>, dim3(grid), dim3(HBLOCK), lds, s, P, n, K, A, T, lcap)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
   }

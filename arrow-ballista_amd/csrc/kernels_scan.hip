@@ -615,6 +615,9 @@ __global__ void __launch_bounds__(MERGE_BLOCK) k_agg_tiny_merge(const AggSpec A,
                                                           const size_t partial_stride, const int nblocks, const AggOut out,
                                                           uint32_t* __restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // some block ran out of dictionary slots: the attempt is void (the host retries with a bigger capacity or another strategy),
+  // and merging thousands of full partial dictionaries under one lock would cost milliseconds for nothing
+  if (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_GROUP_OVERFLOW) return;
   const int n_keys = A.n_keys, n_accs = A.n_accs;
   const int kstride = n_keys > 0 ? n_keys : 1;
   const int cap = out.cap;

@@ -141,7 +141,7 @@ int gpuq_export_arrow(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, cons
      "filter"      FilterExec        {input, predicate}
      "project"     ProjectionExec    {input, exprs:[{expr,name}]}
      "aggregate"   AggregateExec     {input, mode:Partial|Final|FinalPartitioned|Single, group_expr:[{expr,name}],
-                                      aggr_expr:[{fn:SUM|AVG|COUNT|MIN|MAX, expr, name}], predicate?, strategy?:auto|tiny|hash}
+                                      aggr_expr:[{fn:SUM|AVG|COUNT|MIN|MAX, expr, name}], predicate?, strategy?:auto|tiny|hash|lds|radix, expected_groups?}
      "join_build"  HashJoinExec build (left) side  {input, on:[expr], predicate?, null_equals_null?}
      "join_probe"  HashJoinExec probe (right) side {input, on:[expr], predicate?, join_type, null_equals_null?}
      "sort"        SortExec          {input, expr:[{expr, asc, nulls_first}], fetch?}

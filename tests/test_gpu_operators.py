@@ -259,6 +259,34 @@ def test_aggregate_radix_strategy(tc, n, nulls):
         close_rows(norm(native_rows_of(tc, plan)), exp)          # float sums: atomic order differs run to run
 
 
+@pytest.mark.parametrize("nulls", [0.0, 0.15])
+@pytest.mark.parametrize("n", [1, 700, 60_000, 300_000])
+def test_aggregate_lds_strategy(tc, n, nulls):
+    """Block-local pre-aggregation (k_agg_lds: every block folds its rows into an LDS table, the table's entries go to the
+    global one), forced with strategy "lds" on every aggregate shape: few groups (everything stays in LDS), more groups than
+    an LDS table holds (k64 at 300,000 rows: 100,000 groups -- blocks run full and send rows to the global table directly),
+    string / multi-column / NULL keys, all accumulator kinds, a fused predicate.  Then the way "auto" reaches it: the second
+    run of an operator whose first run produced few groups."""
+    t = rand_table(5100 + n, n, nulls)
+    ot = O.Table.from_arrow(t)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    pred = binary(col("k32", s), Op.Gt, lit(-30, "Int32"))
+    for groups, aggs in agg_cases(s):
+        if not groups:
+            continue
+        plan = g.AggregateExec("Single", groups, aggs, g.FilterExec(pred, src), strategy="lds")
+        exp = norm(ora_rows(O.aggregate(ot, groups, aggs, "Single", predicate=pred)))
+        close_rows(norm(dev_rows(tc, plan.execute(0, tc))), exp)
+        close_rows(norm(native_rows_of(tc, plan)), exp)
+    if n >= 300_000:
+        groups, aggs = agg_cases(s)[1]                  # (flag, s): ~28 groups, more accumulators than the register-cached kernel takes
+        plan = g.AggregateExec("Single", groups, aggs + [{"fn": "MAX", "expr": col("k64", s), "name": "xk"}, {"fn": "MIN", "expr": col("d", s), "name": "nd"}], src)
+        exp = norm(ora_rows(O.aggregate(ot, groups, plan.aggr_expr, "Single")))
+        for _ in range(3):                               # run 1: global table; from run 2 on the operator knows its group count
+            close_rows(norm(dev_rows(tc, plan.execute(0, tc))), exp)
+
+
 def native_rows_of(tc, plan):
     t = g.NativePlan(plan, tc).execute(0).to_arrow()
     cols = []
