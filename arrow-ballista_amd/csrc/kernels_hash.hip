@@ -547,7 +547,7 @@ __device__ __forceinline__ void k_agg_lds_body(const DevProgram P, const i64 n, 
         }
         case ACC_MIN: atomicMin((long long*)c, (long long)vlo); break;
         case ACC_MAX: atomicMax((long long*)c, (long long)vlo); break;
-        case ACC_FSUM: atomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;
+        case ACC_FSUM: unsafeAtomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;
         case ACC_FMIN: case ACC_FMAX: {
           u64 cur = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           for (;;) {
@@ -655,7 +655,7 @@ __device__ __forceinline__ void k_agg_bucket_body(const DevProgram P, const KeyS
             if (kind == ACC_MIN) atomicMin((long long*)c, (long long)vlo); else atomicMax((long long*)c, (long long)vlo);
             break;
           }
-          case ACC_FSUM: atomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;
+          case ACC_FSUM: unsafeAtomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;
           case ACC_FMIN: case ACC_FMAX: {
             u64 cur = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             for (;;) {
