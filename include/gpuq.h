@@ -179,7 +179,11 @@ int gpuq_filter_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload
    NULL).  Asynchronous. */
 int gpuq_project_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs);
 
-/* AggregateExec.  outs: caller-allocated columns of capacity `cap` rows in output-schema order.
+/* AggregateExec.  Strategy "auto" picks the kernel by cardinality: <= 64 groups an LDS dictionary with per-lane accumulators;
+   a few hundred to a few thousand, block-local LDS tables flushed to a global one ("lds"); >= 4096 known groups on >= 2^20
+   rows, radix partitioning + one LDS table per bucket ("radix"); otherwise / unknown a global hash table ("hash").  The
+   group count is taken from expected_groups, else from this operator's previous run -- keep operators alive across the
+   partitions of a stage.  outs: caller-allocated columns of capacity `cap` rows in output-schema order.
    Synchronous (the group count decides the strategy and the result length); *n_groups_out (host)
    receives the number of groups.  GPUQ_ERR_CAPACITY when cap is too small. */
 int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs, int64_t cap,
