@@ -822,8 +822,30 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
     if (strat == "auto" && n <= 16384) strat = "hash";
     // groups this operator is expected to produce: the caller's hint, else what its previous run produced (another partition
     // of the same stage, the same query again)
-    const i64 known_groups = op->expected_groups > 0 ? op->expected_groups : op->last_groups;
-    if (strat == "auto" && nk > 0 && known_groups > (i64)agg_tiny_max_groups(na)) {
+    i64 known_groups = op->expected_groups > 0 ? op->expected_groups : op->last_groups;
+    bool many_groups = false;          // the sample says: far more groups than an LDS dictionary, count unknown
+    if (strat == "auto" && nk > 0 && known_groups < 0 && n >= (1ll << 20)) {
+      // a first run over a large input: estimate the cardinality from a strided sample of 2^20 rows (linear counting into 2^24
+      // bits), 20-40 us against the milliseconds a wrong strategy costs
+      const i64 nsample = 1ll << 20, stride = std::max<i64>(1, n / nsample);
+      const u64 nbits = 1ull << 24;
+      uint32_t* bm = (uint32_t*)op->ws[7].ensure(nbits / 8 + 64);
+      unsigned long long* cnt = (unsigned long long*)((char*)bm + nbits / 8);
+      HIPCHECK(hipMemsetAsync(bm, 0, nbits / 8 + 64, s));
+      launch_key_sample(s, P, n, op->keys, stride, nsample, bm, nbits, cnt + 1);
+      launch_popcount_bits(s, (const uint8_t*)bm, (i64)nbits, cnt);
+      unsigned long long* pd = (unsigned long long*)op->pinned();
+      unsigned long long host2[2] = {0, 0};
+      unsigned long long* dst = pd ? pd : host2;
+      HIPCHECK(hipMemcpyAsync(dst, cnt, 16, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      const i64 distinct = (i64)dst[0], passed = (i64)dst[1];
+      if (passed >= 4096) {
+        if (distinct * 4 <= passed) known_groups = std::max<i64>(1, distinct + distinct / 4);      // every group seen several times: the sample covers the key domain
+        else many_groups = true;
+      }
+    }
+    if (strat == "auto" && nk > 0 && (many_groups || known_groups > (i64)agg_tiny_max_groups(na))) {
       // more groups than the LDS dictionary holds: do not even try it
     } else if (strat == "auto" || strat == "tiny") {
       const int fit_big = agg_tiny_max_groups(na);
@@ -867,7 +889,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
       const int slot_words = 1 + op->keys.key_words + 2 * na;
       uint32_t capslots = 64; while ((size_t)capslots * 2 * slot_words * 8 <= 60 * 1024) capslots *= 2;
       if ((size_t)capslots * slot_words * 8 <= 60 * 1024 && n < (1ll << 31)) {
-        const u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (op->last_groups > 0 ? (u64)op->last_groups + (u64)op->last_groups / 4 : (u64)n);
+        const u64 est = op->expected_groups > 0 ? (u64)op->expected_groups : (known_groups > 0 ? (u64)known_groups + (u64)known_groups / 4 : (u64)n);
         const u64 per_bucket = std::max<u64>(1, (u64)capslots / 2);             // mean load 0.5: buckets are Poisson-even (hash bits), sqrt(mean) of spread
         u64 nbk = next_pow2(std::max<u64>(1, (est + per_bucket - 1) / per_bucket)); if (nbk > (1ull << 24)) nbk = 1ull << 24;
         if (n >= (1ll << 20) && nbk < 2048) nbk = 2048;                          // one block per bucket: enough of them to fill the chip

@@ -109,6 +109,7 @@ void launch_agg_tiny(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A
 void launch_agg_tiny_merge(hipStream_t s, const DevProgram& P, i64 n, const AggSpec& A, int gmax, void* workspace, const AggOut& out);
 void launch_ht_init(hipStream_t s, const HashTable& T, const AggSpec* A);
 void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T);
+void launch_key_sample(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, i64 stride, i64 nsample, uint32_t* bitmap, u64 nbits, unsigned long long* passed);
 uint32_t agg_lds_slots(const HashTable& T);
 void launch_agg_lds(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T);
 void launch_agg_bucket_id(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, u64 bucket_mask, u64* bid, uint32_t* ids);

@@ -407,6 +407,34 @@ __device__ __forceinline__ uint32_t lds_slot_find_or_insert(u64* slots, const ui
   return 0xFFFFFFFFu;
 }
 
+// ------------------------------------------------------------------ cardinality estimate
+// Which aggregate kernel is right depends on the number of groups, which nobody tells a first run.  A strided sample of the
+// input (every stride-th row, so clustered keys do not fool it) is hashed into a bitmap (linear counting: with far more bits
+// than samples the popcount IS the number of distinct keys seen); `passed` counts the sampled rows the predicate kept.
+#ifndef GPUQ_JIT
+template <int MAXC>
+__global__ void __launch_bounds__(HBLOCK) k_key_sample(const DevProgram P, const i64 n, const KeySpec K, const i64 stride, const i64 nsample,
+                                                       unsigned int* __restrict__ bitmap, const u64 bit_mask, unsigned long long* __restrict__ passed) {
+  const i64 nwords = (nsample + 63) >> 6;
+  for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
+    const i64 i = (w << 6) + hlane();
+    i64 pos = i * stride; if (pos >= n) pos = n - 1;
+    bool active = i < nsample;
+    GPUQ_REGS_DECL;
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
+    const u64 m = __ballot(active);
+    if (m && hlane() == 0) atomicAdd(passed, (unsigned long long)__popcll(m));
+    if (!active) continue;
+    u64 kw[MAX_KW]; u64 h = 0;
+#pragma unroll
+    for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
+    make_key(K, GPUQ_REGS, kw, h);
+    const u64 bit = mix64(h) & bit_mask;
+    atomicOr(bitmap + (bit >> 5), 1u << (bit & 31));
+  }
+}
+#endif
+
 // ------------------------------------------------------------------ block-local pre-aggregation (medium cardinality)
 // A group-by with a few hundred to a few thousand groups (too many for k_agg_tiny's register-cached dictionary, few enough
 // that every row of a 10 M-row input hits one of a handful of hot slots) makes the global table a contention point: device-
@@ -1071,6 +1099,12 @@ void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
   }
+}
+void launch_key_sample(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, i64 stride, i64 nsample, uint32_t* bitmap, u64 nbits, unsigned long long* passed) {
+  if (n <= 0 || nsample <= 0) return;
+#define CALL(M) hipLaunchKernelGGL(k_key_sample<M>, dim3(hgrid(nsample, 8)), dim3(HBLOCK), 0, s, P, n, K, stride, nsample, bitmap, nbits - 1, passed)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
 }
 uint32_t agg_lds_slots(const HashTable& T) {      // LDS table size (slots) of the pre-aggregating kernel, 0 = a slot is too wide for it
   const size_t bytes = (size_t)(T.slot_words + 1) * 8;

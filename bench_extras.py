@@ -305,9 +305,15 @@ def h2o(tc, T, g, n=10_000_000, k=100, reps=3):
             best = dt if best is None or dt < best else best
         return best, res
     for name, (keys, aggs, host_aggs) in questions.items():
-        plan = g.NativePlan(g.AggregateExec("Single", [(col(c, s), c) for c in keys], aggs, dx, expected_groups=0), tc)
+        mk = lambda: g.NativePlan(g.AggregateExec("Single", [(col(c, s), c) for c in keys], aggs, dx, expected_groups=0), tc)
+        plan = mk()
         dt, res = timed(lambda: plan.execute(0))
-        e = {"device_ms": dt * 1e3, "groups": res.num_rows, "rows_per_s": n / dt}
+        # an operator that has never run (no remembered group count): the first execution of a fresh plan, kernels already compiled
+        cold = None
+        for _ in range(2):
+            fresh = mk(); _sync(tc); t0 = time.perf_counter(); fresh.execute(0); _sync(tc); c = time.perf_counter() - t0
+            cold = c if cold is None or c < cold else cold
+        e = {"device_ms": dt * 1e3, "first_run_ms": cold * 1e3, "groups": res.num_rows, "rows_per_s": n / dt}
         if host_aggs is not None:
             t0 = time.perf_counter(); h = x.group_by(keys).aggregate(host_aggs); e["cpu_proxy_acero_ms"] = (time.perf_counter() - t0) * 1e3
             e["cpu_threads"] = pa.cpu_count()
