@@ -841,7 +841,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
       HIPCHECK(hipStreamSynchronize(s));
       const i64 distinct = (i64)dst[0], passed = (i64)dst[1];
       if (passed >= 4096) {
-        if (distinct * 4 <= passed) known_groups = std::max<i64>(1, distinct + distinct / 4);      // every group seen several times: the sample covers the key domain
+        if (distinct * 4 <= passed) known_groups = std::max<i64>(1, distinct);      // every group seen several times: the sample covers the key domain (users of the number add their own margin)
         else many_groups = true;
       }
     }
