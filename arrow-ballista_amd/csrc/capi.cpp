@@ -938,7 +938,14 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         T.slots = (u64*)op->ws[5].ensure((size_t)T.n_slots * T.slot_words * 8);
         launch_ht_init(s, T, &op->agg);
         reset_flags(op, s);
-        if (use_lds) { JitScope js(op, op->prog, 13, n); ProfScope ps(op, s); launch_agg_lds(s, P, n, op->keys, op->agg, T); }
+        if (use_lds) {
+          // float partial sums are parked per (table slot, sum, block) and added up in block order afterwards
+          int n_fsum = 0; for (int a = 0; a < na; ++a) n_fsum += op->agg.acc_kind[a] == ACC_FSUM;
+          u64* fstage = nullptr;
+          const size_t fbytes = (size_t)T.n_slots * (size_t)n_fsum * (size_t)agg_lds_grid(n) * 8;
+          if (n_fsum > 0 && fbytes <= ((size_t)256 << 20)) { fstage = (u64*)op->ws[8].ensure(fbytes); HIPCHECK(hipMemsetAsync(fstage, 0, fbytes, s)); }
+          JitScope js(op, op->prog, 13, n); ProfScope ps(op, s); launch_agg_lds(s, P, n, op->keys, op->agg, T, fstage, n_fsum);
+        }
         else { JitScope js(op, op->prog, 4, n); ProfScope ps(op, s); launch_agg_hash(s, P, n, op->keys, op->agg, T); }
         HIPCHECK(hipGetLastError());
         const uint32_t f = (n <= (1ll << 20) && est >= (u64)n) ? 0u : read_flags(op, s);   // a 2n-slot table cannot fill up; other flags surface after extract

@@ -111,7 +111,8 @@ void launch_ht_init(hipStream_t s, const HashTable& T, const AggSpec* A);
 void launch_agg_hash(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T);
 void launch_key_sample(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, i64 stride, i64 nsample, uint32_t* bitmap, u64 nbits, unsigned long long* passed);
 uint32_t agg_lds_slots(const HashTable& T);
-void launch_agg_lds(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T);
+int agg_lds_grid(i64 n);
+void launch_agg_lds(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T, u64* fstage, int n_fsum);
 void launch_agg_bucket_id(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, u64 bucket_mask, u64* bid, uint32_t* ids);
 void launch_bucket_bounds(hipStream_t s, const u64* sorted_bid, i64 n, u64 nbuckets, uint32_t* bounds);
 void launch_agg_bucket(hipStream_t s, const DevProgram& P, const KeySpec& K, const AggSpec& A, const uint32_t* ids, const uint32_t* bounds, uint32_t nbuckets,

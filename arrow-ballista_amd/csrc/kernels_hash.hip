@@ -505,7 +505,8 @@ __device__ __forceinline__ void global_fold(u64* c, const int kind, const u64 vl
 }
 
 template <int MAXC>
-__device__ __forceinline__ void k_agg_lds_body(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap) {
+__device__ __forceinline__ void k_agg_lds_body(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap,
+                                               u64* __restrict__ fstage, const int n_fsum) {
   extern __shared__ __attribute__((aligned(16))) u64 lslots[];
   __shared__ uint32_t lfull;
   const int key_words = K.key_words;
@@ -575,7 +576,7 @@ __device__ __forceinline__ void k_agg_lds_body(const DevProgram P, const i64 n, 
         }
         case ACC_MIN: atomicMin((long long*)c, (long long)vlo); break;
         case ACC_MAX: atomicMax((long long*)c, (long long)vlo); break;
-        case ACC_FSUM: unsafeAtomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;
+        case ACC_FSUM: unsafeAtomicAdd((double*)c, __longlong_as_double((i64)vlo)); break;      // (a CAS loop or a fetch_add cost the same: measured)
         case ACC_FMIN: case ACC_FMAX: {
           u64 cur = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           for (;;) {
@@ -603,14 +604,52 @@ __device__ __forceinline__ void k_agg_lds_body(const DevProgram P, const i64 n, 
     const u64 gs = ht_find_or_insert(T, kw, slot[1], 0u, inserted);
     if (gs == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
     u64* g = T.slots + gs * (u64)T.slot_words + gcell0;
-    for (int a = 0; a < A.n_accs; ++a) global_fold(g + 2 * a, A.acc_kind[a], slot[lcell0 + 2 * a], slot[lcell0 + 2 * a + 1]);
+    int kf = 0;
+    for (int a = 0; a < A.n_accs; ++a) {
+      const int kind = A.acc_kind[a];
+      // A float partial sum does not go to the table cell: thousands of blocks adding doubles to the same hundred addresses
+      // serialise at 2-7 us per add (that alone was 6 of q4's 6.5 ms).  It is parked in its own word [slot][sum][block]
+      // and k_fsum_stage_reduce adds the blocks up in block order afterwards -- which also makes the sum reproducible.
+      if (kind == ACC_FSUM && fstage) { fstage[((gs * (u64)n_fsum + (u64)kf) * gridDim.x) + blockIdx.x] = slot[lcell0 + 2 * a]; ++kf; continue; }
+      if (kind == ACC_FSUM) ++kf;
+      global_fold(g + 2 * a, kind, slot[lcell0 + 2 * a], slot[lcell0 + 2 * a + 1]);
+    }
   }
 }
 #ifndef GPUQ_JIT
+// one wave per (table slot, float sum): the blocks' partial sums in block order
+__global__ void __launch_bounds__(HBLOCK) k_fsum_stage_reduce(const HashTable T, const AggSpec A, const u64* __restrict__ fstage, const int n_fsum, const uint32_t nblk) {
+  const int gcell0 = 1 + T.key_words;
+  const u64 items = T.n_slots * (u64)n_fsum;
+  for (u64 it = (u64)blockIdx.x * HWAVES + hwave(); it < items; it += (u64)gridDim.x * HWAVES) {
+    const u64 gs = it / (u64)n_fsum; const int kf = (int)(it % (u64)n_fsum);
+    if ((uint32_t)T.slots[gs * (u64)T.slot_words] < 2u) continue;
+    const u64* src = fstage + it * nblk;
+    double acc = 0.0;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
+      const uint32_t b = b0 + hlane();
+      double v = b < nblk ? __longlong_as_double((i64)src[b]) : 0.0;
+      // fixed tree inside the 64 blocks, then in order across groups of 64
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      acc += v;
+    }
+    if (hlane() == 0) {
+      int k = 0, a = 0;
+      for (; a < A.n_accs; ++a) if (A.acc_kind[a] == ACC_FSUM) { if (k == kf) break; ++k; }
+      double* cell = (double*)(T.slots + gs * (u64)T.slot_words + gcell0 + 2 * a);
+      *cell += acc;          // rows that bypassed a full LDS table have already added theirs here
+    }
+  }
+}
+#endif
+#ifndef GPUQ_JIT
 template <int MAXC>
-__global__ void __launch_bounds__(HBLOCK) k_agg_lds(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap) { k_agg_lds_body<MAXC>(P, n, K, A, T, lcap); }
+__global__ void __launch_bounds__(HBLOCK) k_agg_lds(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap,
+                                                    u64* fstage, const int n_fsum) { k_agg_lds_body<MAXC>(P, n, K, A, T, lcap, fstage, n_fsum); }
 #elif GPUQ_JIT_KERNEL == 13
-extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap) { k_agg_lds_body<0>(P, n, K, A, T, lcap); }
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap,
+                                                                     u64* fstage, const int n_fsum) { k_agg_lds_body<0>(P, n, K, A, T, lcap, fstage, n_fsum); }
 #endif
 
 template <int MAXC>
@@ -1111,17 +1150,24 @@ uint32_t agg_lds_slots(const HashTable& T) {      // LDS table size (slots) of t
   uint32_t cap = 1; while ((size_t)cap * 2 * bytes <= 32768) cap *= 2;
   return cap >= 128 ? cap : 0;
 }
-void launch_agg_lds(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T) {
+int agg_lds_grid(i64 n) { return hgrid(n, 4); }
+// fstage: nullptr, or T.n_slots * n_fsum * agg_lds_grid(n) zeroed words for the blocks' float partial sums
+void launch_agg_lds(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T, u64* fstage, int n_fsum) {
   if (n <= 0) return;
   const uint32_t lcap = agg_lds_slots(T);
   const size_t lds = (size_t)lcap * (T.slot_words + 1) * 8;
-  const int grid = hgrid(n, 4);
+  const int grid = agg_lds_grid(n);
   if (jit_override().fn && jit_override().kernel_id == 13) {
-    (void)jit_launch(jit_override().fn, dim3(grid), dim3(HBLOCK), lds, s, P, n, K, A, T, lcap);
+    (void)jit_launch(jit_override().fn, dim3(grid), dim3(HBLOCK), lds, s, P, n, K, A, T, lcap, fstage, n_fsum);
   } else {
-#define CALL(M) hipLaunchKernelGGL(k_agg_lds<M>, dim3(grid), dim3(HBLOCK), lds, s, P, n, K, A, T, lcap)
+#define CALL(M) hipLaunchKernelGGL(k_agg_lds<M>, dim3(grid), dim3(HBLOCK), lds, s, P, n, K, A, T, lcap, fstage, n_fsum)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
+  }
+  if (fstage && n_fsum > 0) {
+    const u64 items = T.n_slots * (u64)n_fsum;
+    const u64 need = (items + HWAVES - 1) / HWAVES, cap = (u64)num_cus() * 8;
+    hipLaunchKernelGGL(k_fsum_stage_reduce, dim3((unsigned)(need < cap ? (need ? need : 1) : cap)), dim3(HBLOCK), 0, s, T, A, (const u64*)fstage, n_fsum, (uint32_t)grid);
   }
 }
 void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags) {
