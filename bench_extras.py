@@ -355,6 +355,42 @@ def h2o(tc, T, g, n=10_000_000, k=100, reps=3):
     return out
 
 
+def like_micro(tc, T, g, n=1 << 23, reps=5):
+    """LikeExpr throughput (q13's `o_comment NOT LIKE '%special%requests%'` shape): n comment-like strings of 19-78 bytes built
+    from a word list, Arrow layout in HBM; one gpuq_like_utf8 launch per pattern.  Bytes = offsets + string bytes read."""
+    import ctypes as C
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    import torch
+    r = np.random.default_rng(5)
+    words = np.array(["special", "requests", "deposits", "pending", "furiously", "carefully", "packages", "accounts", "blithely", "ironic", "final", "express", "regular", "quickly"])
+    k = 6
+    parts = words[r.integers(0, len(words), (n, k))]
+    col = parts[:, 0]
+    for j in range(1, k):
+        col = np.char.add(np.char.add(col, " "), parts[:, j])
+    arr = pa.array(col, type=pa.string())
+    if isinstance(arr, pa.ChunkedArray):
+        arr = pa.concat_arrays(arr.chunks)
+    t = g.DeviceTable.from_arrow(pa.table({"c": arr}), tc.device)
+    c = t.columns[0]
+    nbytes = int(arr.buffers()[2].size) + 4 * (n + 1)
+    out = {"rows": n, "bytes": nbytes, "patterns": {}}
+    bits = torch.zeros(((n + 63) // 64) * 8 + 8, dtype=torch.uint8, device=tc.device)
+    for pat in ("%special%requests%", "furiously%", "%accounts", "%ironic%", "_pecial%"):
+        best = None
+        for _ in range(reps):
+            _sync(tc); t0 = time.perf_counter()
+            tc.ctx.check(tc.ctx.L.gpuq_like_utf8(tc.ctx.h, tc.stream_ptr(), C.byref(c.to_c()), None, n, pat.encode(), 0, 0, bits.data_ptr(), None))
+            _sync(tc); dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        got = int(np.unpackbits(bits.cpu().numpy()[: (n + 7) // 8], bitorder="little")[:n].sum())
+        t0 = time.perf_counter(); exp = pc.sum(pc.match_like(arr, pat)).as_py(); cpu = time.perf_counter() - t0
+        out["patterns"][pat] = {"device_ms": best * 1e3, "GBps": nbytes / best / 1e9, "matches": got, "matches_cpu": bool(got == exp), "cpu_proxy_arrow_cpp_ms": cpu * 1e3}
+    return out
+
+
 def run(tc, T, g, full=True):
     extra = {"join_probe": []}
     grid = [(20, 28, 1.0), (24, 28, 1.0), (27, 28, 1.0), (24, 28, 0.5), (24, 28, 0.1)] if full else [(20, 24, 1.0)]
@@ -385,6 +421,9 @@ if __name__ == "__main__":
         print(json.dumps(cpu_proxy_acero(T, sf), indent=1))
         sys.exit(0)
     tc = g.TaskContext(device=0)
+    if "--like" in sys.argv:
+        print(json.dumps(like_micro(tc, T, g), indent=1))
+        sys.exit(0)
     if "--h2o" in sys.argv:
         rows = int(sys.argv[sys.argv.index("--rows") + 1]) if "--rows" in sys.argv else 10_000_000
         print(json.dumps(h2o(tc, T, g, rows), indent=1))
