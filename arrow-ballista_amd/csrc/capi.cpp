@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <tuple>
+#include <map>
 #include <deque>
 #include <functional>
 #include <vector>
@@ -53,6 +55,7 @@ struct gpuq_op {
   std::vector<DType> key_types, acc_types;
   std::vector<int> acc_bits;        // |argument| < 2^bits per accumulator (type-derived): lets the specialised kernel drop range checks
   std::map<std::pair<const void*, int>, int> jit_runs;      // (program, sink kernel) -> small-input runs so far (background tier)
+  std::map<std::tuple<const void*, int, size_t>, const JitFn*> jit_fns;      // (program, sink kernel, specialisation) -> compiled function
   struct PostChunk { CompiledProgram prog; DevBuf code; int first_out = 0; };
   std::deque<PostChunk> posts; Schema post_schema;
   i64 expected_groups = 0;
@@ -184,7 +187,16 @@ struct JitScope {
     const bool hot = !use && ++op->jit_runs[{(const void*)&cp, kernel_id}] > 2;
     if (!use && !hot) return;
     try {
-      const JitFn* f = use ? jit_get(cp.jit_src + spec, kernel_id) : jit_try_get(cp.jit_src + spec, kernel_id);
+      // the process-wide cache is keyed by the whole generated source (kilobytes of text to concatenate and compare): an
+      // operator remembers the functions it has resolved
+      const auto fkey = std::make_tuple((const void*)&cp, kernel_id, std::hash<std::string>()(spec));
+      const JitFn* f = nullptr;
+      auto hit = op->jit_fns.find(fkey);
+      if (hit != op->jit_fns.end()) f = hit->second;
+      else {
+        f = use ? jit_get(cp.jit_src + spec, kernel_id) : jit_try_get(cp.jit_src + spec, kernel_id);
+        if (f) op->jit_fns[fkey] = f;
+      }
       if (!f) return;
       jit_override().fn = f->fn; jit_override().kernel_id = kernel_id; active = true; c->jit_launches++;
     } catch (const std::exception& e) {
