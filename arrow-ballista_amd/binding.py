@@ -123,6 +123,7 @@ def lib():
         "gpuq_plan_metrics": (i32, [vp, C.c_char_p, C.c_size_t]),
         "gpuq_plan_last_error": (C.c_char_p, []),
         "gpuq_plan_profile": (i32, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+        "gpuq_plan_profile_all": (i32, [vp, C.c_char_p, C.c_size_t]),
         "gpuq_result_num_rows": (i64, [vp]),
         "gpuq_result_num_columns": (i32, [vp]),
         "gpuq_result_column": (i32, [vp, i32, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info)]),

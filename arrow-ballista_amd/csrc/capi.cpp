@@ -729,7 +729,7 @@ int gpuq_op_profile(gpuq_op* op, int enable, float* kernel_ms_out, int* launches
     if (op->ev_pending) { float ms = 0; HIPCHECK(hipEventSynchronize(op->ev1)); HIPCHECK(hipEventElapsedTime(&ms, op->ev0, op->ev1)); op->kernel_ms += ms; op->ev_pending = false; }
     if (kernel_ms_out) *kernel_ms_out = op->kernel_ms;
     if (launches_out) *launches_out = op->launches;
-    op->kernel_ms = 0; op->launches = 0; op->profile = enable != 0;
+    op->kernel_ms = 0; op->launches = 0; if (enable >= 0) op->profile = enable != 0;
   });
 }
 

@@ -1255,6 +1255,23 @@ int gpuq_plan_profile(gpuq_plan* p, int enable, float* kernel_ms_out, int* launc
   return GPUQ_OK;
 }
 
+int gpuq_plan_profile_all(gpuq_plan* p, char* json_out, size_t cap) {
+  if (!p || !json_out || !cap) return GPUQ_ERR_INVALID;
+  Json arr = jarr();
+  for (auto& kv : p->ops) {
+    float ms = 0; int n = 0;
+    if (gpuq_op_profile(kv.second, -1, &ms, &n) != GPUQ_OK) continue;
+    std::string kind;
+    try { kind = JsonParser(kv.first.c_str()).parse().get_str("op", ""); } catch (const std::exception&) {}
+    Json num; num.kind = Json::NUM; { char b[64]; std::snprintf(b, sizeof(b), "%.6f", (double)ms); num.s = b; }
+    arr.a.push_back(jobj({{"op", jstr(kind)}, {"kernel_ms", num}, {"launches", jnum(n)}, {"desc", jstr(kv.first)}}));
+  }
+  const std::string s = arr.dump();
+  if (s.size() + 1 > cap) return GPUQ_ERR_CAPACITY;
+  std::memcpy(json_out, s.c_str(), s.size() + 1);
+  return GPUQ_OK;
+}
+
 int gpuq_plan_metrics(gpuq_plan* p, char* buf, size_t cap) {
   if (!p || !buf) return GPUQ_ERR_INVALID;
   std::vector<PNode*> nodes; collect(p->root.get(), nodes);

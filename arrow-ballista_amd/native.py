@@ -233,6 +233,12 @@ class NativePlan:
         _check(self.tc.ctx.L, self.tc.ctx.L.gpuq_plan_profile(self.h, 1 if enable else 0, C.byref(ms), C.byref(n), buf, len(buf)))
         return ms.value, n.value, buf.value.decode()
 
+    def profile_all(self):
+        """[{op, kernel_ms, launches, desc}] for every operator the plan has compiled (accumulators are reset)."""
+        buf = C.create_string_buffer(1 << 20)
+        _check(self.tc.ctx.L, self.tc.ctx.L.gpuq_plan_profile_all(self.h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
     def metrics(self):
         buf = C.create_string_buffer(1 << 16)
         _check(self.tc.ctx.L, self.tc.ctx.L.gpuq_plan_metrics(self.h, buf, len(buf)))

@@ -306,6 +306,9 @@ const char* gpuq_plan_last_error(void);
 /* gpuq_op_profile over every operator the plan has compiled: enable/disable the HIP-event bracket around each operator's
    dominant kernel and report the operator with the most accumulated kernel time (its descriptor text in op_desc_out). */
 int gpuq_plan_profile(gpuq_plan* plan, int enable, float* kernel_ms_out, int* launches_out, char* op_desc_out, size_t cap);
+/* Every operator the plan has compiled, as a JSON array [{"op": kind, "kernel_ms": accumulated ms, "launches": n, "desc": descriptor}]
+   (reads and resets the accumulators; profiling stays as it was set by gpuq_plan_profile).  GPUQ_ERR_CAPACITY when cap is too small. */
+int gpuq_plan_profile_all(gpuq_plan* plan, char* json_out, size_t cap);
 int64_t gpuq_result_num_rows(const gpuq_result* r);
 int gpuq_result_num_columns(const gpuq_result* r);
 int gpuq_result_column(const gpuq_result* r, int i, gpuq_column* col_out, gpuq_field_info* field_out);
@@ -385,7 +388,7 @@ int gpuq_timer_stop(gpuq_timer* t, void* stream);
 int gpuq_timer_elapsed_ms(gpuq_timer* t, float* ms_out); /* synchronises on the stop event */
 void gpuq_timer_free(gpuq_timer* t);
 /* Per-op device time of the last call(s): the op brackets its dominant kernel with HIP events when
-   enabled; returns the accumulated ms and launch count since the last reset. */
+   enabled; returns the accumulated ms and launch count since the last reset.  enable < 0 keeps the current setting. */
 int gpuq_op_profile(gpuq_op* op, int enable, float* kernel_ms_out, int* launches_out);
 
 #ifdef __cplusplus

@@ -247,3 +247,126 @@ void oracle_partition_ids_i64(const i64* keys, i64 n, uint32_t nparts, uint32_t*
 #pragma omp parallel for schedule(static)
   for (i64 i = 0; i < n; ++i) pid_out[i] = (uint32_t)(hash_combine1(0x243F6A8885A308D3ull, (u64)keys[i]) % nparts);
 }
+
+/* ---------------------------------------------------------------- q3: filter + 2 hash joins + group-by + sort
+ * reference benchmarks/queries/q3.sql (physical shape: benchmarks/src/bin/tpch.rs:286-351 runs it through DataFusion's
+ * HashJoinExec(CollectLeft) x 2 -> AggregateExec -> SortExec) over Arrow-physical columns:
+ *   customer(c_custkey i64, c_mktsegment Utf8)  orders(o_orderkey, o_custkey i64, o_orderdate date32, o_shippriority i32)
+ *   lineitem(l_orderkey i64, l_extendedprice / l_discount Decimal128(15,2), l_shipdate date32)
+ * J1 build: customers of `segment`; J1 probe: orders with o_orderdate < date; J2 build: the J1 output keyed by o_orderkey;
+ * J2 probe: lineitem with l_shipdate > date; aggregate: SUM(l_extendedprice * (1 - l_discount)) as Decimal128(38,4) by
+ * (l_orderkey, o_orderdate, o_shippriority); order by revenue DESC, o_orderdate ASC (ties: l_orderkey ASC, so that the
+ * output is a pure function of the input).  Executed the way a vectorised multi-core CPU engine does it: chained hash
+ * tables with key re-verification [UPSTREAM-KNOWLEDGE], the probe side split over threads, per-thread partial aggregates
+ * merged at the end.  Returns the number of groups; the first `cap` of them are written. */
+typedef struct { i64 okey; int32_t odate, oprio; i128 rev; int used; } q3_group;
+typedef struct { q3_group* g; u64 mask; i64 n; } q3_table;
+static void q3_table_init(q3_table* t, u64 slots) { t->g = (q3_group*)calloc(slots, sizeof(q3_group)); t->mask = slots - 1; t->n = 0; }
+static void q3_table_add(q3_table* t, i64 okey, int32_t odate, int32_t oprio, i128 rev);
+static void q3_table_grow(q3_table* t) {
+  q3_table b; q3_table_init(&b, (t->mask + 1) * 2);
+  for (u64 s = 0; s <= t->mask; ++s) if (t->g[s].used) q3_table_add(&b, t->g[s].okey, t->g[s].odate, t->g[s].oprio, t->g[s].rev);
+  free(t->g); *t = b;
+}
+static void q3_table_add(q3_table* t, i64 okey, int32_t odate, int32_t oprio, i128 rev) {
+  if ((u64)t->n * 2 > t->mask) q3_table_grow(t);
+  u64 s = mix64((u64)okey ^ ((u64)(uint32_t)odate << 32) ^ (u64)(uint32_t)oprio * 0x9E3779B97F4A7C15ull) & t->mask;
+  for (;; s = (s + 1) & t->mask) {
+    q3_group* q = &t->g[s];
+    if (!q->used) { q->used = 1; q->okey = okey; q->odate = odate; q->oprio = oprio; q->rev = rev; t->n++; return; }
+    if (q->okey == okey && q->odate == odate && q->oprio == oprio) { q->rev += rev; return; }
+  }
+}
+static int q3_cmp(const void* a, const void* b) {
+  const q3_group* x = (const q3_group*)a; const q3_group* y = (const q3_group*)b;
+  if (x->rev != y->rev) return x->rev > y->rev ? -1 : 1;
+  if (x->odate != y->odate) return x->odate < y->odate ? -1 : 1;
+  return x->okey < y->okey ? -1 : (x->okey > y->okey ? 1 : 0);
+}
+
+i64 oracle_q3(i64 n_cust, const i64* c_custkey, const uint8_t* c_mktsegment, const int32_t* c_seg_off, const char* segment,
+              i64 n_orders, const i64* o_orderkey, const i64* o_custkey, const int32_t* o_orderdate, const int32_t* o_shippriority,
+              i64 n_line, const i64* l_orderkey, const u64* l_extendedprice, const u64* l_discount, const int32_t* l_shipdate, int32_t date,
+              i64 cap, i64* out_orderkey, u64* out_revenue /*[cap][2]*/, int32_t* out_orderdate, int32_t* out_shippriority,
+              i64* stats /* optional [4]: J1 build rows, J1 output rows, J2 probe rows (pass the filter), J2 matches */) {
+  const int nthreads = oracle_num_threads();
+  const size_t seglen = strlen(segment);
+  /* J1 build side: FilterExec(c_mktsegment = segment) -> keys */
+  i64* ck = (i64*)malloc((size_t)(n_cust > 0 ? n_cust : 1) * 8); i64 nck = 0;
+  for (i64 i = 0; i < n_cust; ++i) {
+    const int32_t a = c_seg_off[i], b = c_seg_off[i + 1];
+    if ((size_t)(b - a) == seglen && memcmp(c_mktsegment + a, segment, seglen) == 0) ck[nck++] = c_custkey[i];
+  }
+  void* t1 = oracle_join_build(ck, nck);
+  const oracle_join_table* T1 = (const oracle_join_table*)t1;
+  /* J1 probe: FilterExec(o_orderdate < date) -> inner join on custkey; output rows keep the probe (orders) order */
+  i64* cnt = (i64*)calloc((size_t)nthreads + 1, 8);
+  i64* jk = NULL; int32_t* jd = NULL; int32_t* jp = NULL; i64 nj = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma omp parallel
+    {
+      int tid = 0;
+#ifdef _OPENMP
+      tid = omp_get_thread_num();
+#endif
+      const i64 a = n_orders * tid / nthreads, b = n_orders * (tid + 1) / nthreads;
+      i64 w = pass ? cnt[tid] : 0;
+      for (i64 j = a; j < b; ++j) {
+        if (!(o_orderdate[j] < date)) continue;
+        const i64 k = o_custkey[j];
+        for (uint32_t r = T1->head[mix64((u64)k) & T1->mask]; r != 0xFFFFFFFFu; r = T1->next[r])
+          if (T1->keys[r] == k) { if (pass) { jk[w] = o_orderkey[j]; jd[w] = o_orderdate[j]; jp[w] = o_shippriority[j]; } ++w; }
+      }
+      if (!pass) cnt[tid + 1] = w;
+    }
+    if (!pass) {
+      cnt[0] = 0; for (int t = 0; t < nthreads; ++t) cnt[t + 1] += cnt[t];
+      nj = cnt[nthreads];
+      jk = (i64*)malloc((size_t)(nj > 0 ? nj : 1) * 8); jd = (int32_t*)malloc((size_t)(nj > 0 ? nj : 1) * 4); jp = (int32_t*)malloc((size_t)(nj > 0 ? nj : 1) * 4);
+    }
+  }
+  oracle_join_free(t1);
+  /* J2: build on o_orderkey of the J1 output, probe FilterExec(l_shipdate > date), aggregate per thread */
+  void* t2 = oracle_join_build(jk, nj);
+  const oracle_join_table* T2 = (const oracle_join_table*)t2;
+  q3_table* parts = (q3_table*)calloc((size_t)nthreads, sizeof(q3_table));
+  i64 probes = 0, matches = 0;
+#pragma omp parallel reduction(+ : probes, matches)
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    q3_table* pt = &parts[tid]; q3_table_init(pt, 1024);
+    const i64 a = n_line * tid / nthreads, b = n_line * (tid + 1) / nthreads;
+    for (i64 i = a; i < b; ++i) {
+      if (!(l_shipdate[i] > date)) continue;
+      ++probes;
+      const i64 k = l_orderkey[i];
+      for (uint32_t r = T2->head[mix64((u64)k) & T2->mask]; r != 0xFFFFFFFFu; r = T2->next[r]) {
+        if (T2->keys[r] != k) continue;
+        const i128 ext = (i128)(((u128)l_extendedprice[2 * i + 1] << 64) | l_extendedprice[2 * i]);
+        const i128 disc = (i128)(((u128)l_discount[2 * i + 1] << 64) | l_discount[2 * i]);
+        q3_table_add(pt, k, jd[r], jp[r], ext * (100 - disc));      /* Decimal(15,2) * (Decimal(20,0) - Decimal(15,2)) -> scale 4 */
+        ++matches;
+      }
+    }
+  }
+  oracle_join_free(t2);
+  q3_table all; q3_table_init(&all, 1024);
+  for (int t = 0; t < nthreads; ++t) {
+    for (u64 s = 0; s <= parts[t].mask; ++s) if (parts[t].g[s].used) q3_table_add(&all, parts[t].g[s].okey, parts[t].g[s].odate, parts[t].g[s].oprio, parts[t].g[s].rev);
+    free(parts[t].g);
+  }
+  free(parts);
+  q3_group* out = (q3_group*)malloc((size_t)(all.n > 0 ? all.n : 1) * sizeof(q3_group)); i64 ng = 0;
+  for (u64 s = 0; s <= all.mask; ++s) if (all.g[s].used) out[ng++] = all.g[s];
+  qsort(out, (size_t)ng, sizeof(q3_group), q3_cmp);
+  for (i64 g = 0; g < ng && g < cap; ++g) {
+    out_orderkey[g] = out[g].okey; out_revenue[2 * g] = (u64)out[g].rev; out_revenue[2 * g + 1] = (u64)((u128)out[g].rev >> 64);
+    out_orderdate[g] = out[g].odate; out_shippriority[g] = out[g].oprio;
+  }
+  if (stats) { stats[0] = nck; stats[1] = nj; stats[2] = probes; stats[3] = matches; }
+  free(out); free(all.g); free(ck); free(cnt); free(jk); free(jd); free(jp);
+  return ng;
+}

@@ -46,3 +46,17 @@ def test_join_sort_partition_c_equals_python_oracle():
     pid = np.zeros(len(build), np.uint32)
     L.oracle_partition_ids_i64(build.ctypes.data, C.c_int64(len(build)), C.c_uint32(16), pid.ctypes.data)
     assert pid.tolist() == O.hash_partition(lt, [c("k")], 16)
+
+
+def test_q3_c_equals_python_oracle():
+    """oracle_q3 (bench.py's cpu_baseline at N=1) against the numpy restatement of q3 on the same generated tables."""
+    import pyarrow as pa
+    n_li, n_cust = 60_000, 1500
+    h = T.gen_q3_tables_host(n_li, n_cust)
+    rows, st = T.q3_oracle_c(h)
+    hl = T.lineitem_host_to_arrow(T.gen_lineitem_host(n_li), n_li)
+    ho, hc, _hs = T.gen_other_tables_host(h["n_orders"], n_cust, 100)
+    exp = T.q3_oracle(hc, ho, hl)
+    assert st["groups"] == len(exp) > 0 and st["j2_matches"] >= len(exp)
+    assert [(r[1], r[2]) for r in rows] == [(r[1], r[2]) for r in exp]          # ORDER BY revenue desc, o_orderdate
+    assert sorted(rows) == sorted(exp)

@@ -45,6 +45,8 @@ def oracle_lib():
         L.oracle_gen_customer.argtypes = [u64, i64, i64] + [vp] * 4
         L.oracle_gen_supplier.argtypes = [u64, i64, i64] + [vp] * 2
         L.oracle_q1.argtypes = [i64] + [vp] * 9 + [i32] + [vp] * 3
+        L.oracle_q3.restype = i64
+        L.oracle_q3.argtypes = [i64, vp, vp, vp, C.c_char_p, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp]
         _ORACLE = L
     return _ORACLE
 
@@ -411,3 +413,35 @@ def q5_oracle(customer, orders, lineitem, supplier):
         if nk is not None and sn[int(lsup[i])] == nk:
             groups[NATIONS[nk][0]] = groups.get(NATIONS[nk][0], 0) + ext[i] * (100 - disc[i])
     return sorted(groups.items(), key=lambda r: -r[1])
+
+
+def gen_q3_tables_host(n_li, n_cust):
+    """numpy columns (Arrow physical layout) of the three q3 tables from the oracle's generator: the inputs of q3_oracle_c."""
+    L = oracle_lib()
+    n_orders = (n_li + 3) // 4
+    li = gen_lineitem_host(n_li)
+    ok, oc, od, osp = np.empty(n_orders, np.int64), np.empty(n_orders, np.int64), np.empty(n_orders, np.int32), np.empty(n_orders, np.int32)
+    L.oracle_gen_orders(SEED_ORDERS, 0, n_orders, n_cust, _p(ok), _p(oc), _p(od), _p(osp))
+    ck, cn, cm, co = np.empty(n_cust, np.int64), np.empty(n_cust, np.int64), np.empty(n_cust * 9 + 16, np.uint8), np.empty(n_cust + 1, np.int32)
+    L.oracle_gen_customer(SEED_CUSTOMER, 0, n_cust, _p(ck), _p(cn), _p(cm), _p(co))
+    return dict(n_li=n_li, n_orders=n_orders, n_cust=n_cust, l_orderkey=li["l_orderkey"], l_extendedprice=li["l_extendedprice"], l_discount=li["l_discount"],
+                l_shipdate=li["l_shipdate"], o_orderkey=ok, o_custkey=oc, o_orderdate=od, o_shippriority=osp, c_custkey=ck, c_mktsegment=cm, c_mktsegment_off=co)
+
+
+def q3_oracle_c(h, cap=None):
+    """C oracle q3 over gen_q3_tables_host columns -> (rows [(l_orderkey, revenue, o_orderdate, o_shippriority)] ordered by
+    (revenue desc, o_orderdate, l_orderkey), stats dict)."""
+    L = oracle_lib()
+    cap = cap if cap is not None else h["n_orders"]
+    ok, rev, od, sp = np.empty(max(cap, 1), np.int64), np.empty(2 * max(cap, 1), np.uint64), np.empty(max(cap, 1), np.int32), np.empty(max(cap, 1), np.int32)
+    st = np.zeros(4, np.int64)
+    ng = L.oracle_q3(h["n_cust"], _p(h["c_custkey"]), _p(h["c_mktsegment"]), _p(h["c_mktsegment_off"]), b"BUILDING",
+                     h["n_orders"], _p(h["o_orderkey"]), _p(h["o_custkey"]), _p(h["o_orderdate"]), _p(h["o_shippriority"]),
+                     h["n_li"], _p(h["l_orderkey"]), _p(h["l_extendedprice"]), _p(h["l_discount"]), _p(h["l_shipdate"]), Q3_DATE,
+                     cap, _p(ok), _p(rev), _p(od), _p(sp), _p(st))
+    k = min(ng, cap)
+    rows = []
+    for g_ in range(k):
+        v = (int(rev[2 * g_ + 1]) << 64) | int(rev[2 * g_])
+        rows.append((int(ok[g_]), v - (1 << 128) if v >> 127 else v, int(od[g_]), int(sp[g_])))
+    return rows, dict(groups=int(ng), j1_build_rows=int(st[0]), j1_output_rows=int(st[1]), j2_probe_rows=int(st[2]), j2_matches=int(st[3]))
