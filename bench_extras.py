@@ -421,6 +421,11 @@ if __name__ == "__main__":
         print(json.dumps(cpu_proxy_acero(T, sf), indent=1))
         sys.exit(0)
     tc = g.TaskContext(device=0)
+    if "--probe-micro" in sys.argv:      # the probe kernels alone (for rocprofv3 --pmc passes): --probe-micro 24 27
+        i = sys.argv.index("--probe-micro")
+        bits = [int(a) for a in sys.argv[i + 1:] if a.isdigit()] or [24]
+        print(json.dumps([join_probe_micro(tc, g, b, 28, 1.0, reps=2) for b in bits], indent=1))
+        sys.exit(0)
     if "--like" in sys.argv:
         print(json.dumps(like_micro(tc, T, g), indent=1))
         sys.exit(0)
