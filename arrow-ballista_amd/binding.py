@@ -89,6 +89,7 @@ def lib():
         "gpuq_table_column": (i32, [vp, i32, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info)]),
         "gpuq_table_free": (None, [vp]),
         "gpuq_export_arrow": (i32, [vp, vp, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info), i32, i64, vp, vp]),
+        "gpuq_ctx_set_option": (i32, [vp, C.c_char_p, C.c_char_p]),
         "gpuq_ctx_set_jit": (i32, [vp, C.c_char_p, i64]),
         "gpuq_ctx_jit_wait": (i32, [vp]),
         "gpuq_ctx_jit_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]),
@@ -195,6 +196,9 @@ class Context:
 
     def set_jit(self, mode, min_rows=-1):
         self.check(self.L.gpuq_ctx_set_jit(self.h, mode.encode(), int(min_rows)))
+
+    def set_option(self, key, value):
+        self.check(self.L.gpuq_ctx_set_option(self.h, key.encode(), str(value).encode()))
 
     def jit_wait(self):
         """Wait for the background specialisation of hot small-input programs requested so far."""

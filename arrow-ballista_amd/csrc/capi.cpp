@@ -36,6 +36,8 @@ struct gpuq_ctx {
   i64 jit_min_rows = 1ll << 21;
   std::string last_jit_error;       // auto mode: why the last specialisation fell back to the interpreter kernels
   int jit_launches = 0;
+  int join_dense = 1;               // direct-addressed join tables for one narrow key of bounded range (gpuq_ctx_set_option "join_dense")
+  i64 join_dense_ratio = 128;       // ... while range <= ratio x keys
 };
 
 struct gpuq_timer { hipEvent_t a = nullptr, b = nullptr; };
@@ -80,7 +82,7 @@ struct gpuq_op {
 struct gpuq_join_table {
   gpuq_ctx* ctx = nullptr;
   KeySpec keys{}; HashTable T{}; int null_eq = 0;
-  DevBuf slots, next, visited, present, ws_bitmap, ws_counts;
+  DevBuf slots, dense, next, visited, present, ws_bitmap, ws_counts;
   i64 bound = 0;
   bool visited_ready = false;
   bool has_dups = false;   // some key occurs on more than one build row -> chained probe
@@ -546,6 +548,7 @@ gpuq_ctx* gpuq_ctx_create(int device_ordinal, const char* json_opts) {
     if (json_opts && *json_opts) { Json o = JsonParser(json_opts).parse(); jm = o.get_str("jit", jm); c->jit_min_rows = o.get_i64("jit_min_rows", c->jit_min_rows); }
     if (jm == "off" || jm == "0") c->jit_mode = 0; else if (jm == "force" || jm == "2") c->jit_mode = 2; else c->jit_mode = 1;
     if (!jit_available() && c->jit_mode == 1) c->jit_mode = 0;
+    if (const char* e = std::getenv("GPUQ_JOIN_DENSE")) c->join_dense = std::atoi(e) != 0;
   });
   if (rc != GPUQ_OK) { delete c; return nullptr; }
   return c;
@@ -1020,13 +1023,41 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     if (build_rows_bound < 0 || build_rows_bound > 0xFFFFFFFEll) throw std::runtime_error("build_rows_bound out of range");
     t = new gpuq_join_table(); t->ctx = op->ctx; t->keys = op->keys; t->null_eq = op->null_eq; t->bound = build_rows_bound;
     t->T.key_words = op->keys.key_words; t->T.slot_words = 1 + t->T.key_words;
-    t->T.n_slots = next_pow2(std::max<u64>((u64)n * 3, 1024));   // load factor in (0.17, 0.33]: a miss ends after ~1.5 slot visits (2.5 at 0.5)
-    t->T.slots = (u64*)t->slots.ensure((size_t)t->T.n_slots * t->T.slot_words * 8);
+    // One narrow key whose values span a bounded range: direct addressing (dense[key - min] = chain head).  The range of the rows
+    // that will be inserted is measured first (one more pass over the build input; the build is synchronous anyway).  Direct
+    // addressing wins while initialising `range` words costs less than hashing `count` keys (~700 B of memset per key measured),
+    // i.e. up to a range of ~128 x count (gpuq_ctx_set_option "join_dense" / "join_dense_ratio").
+    bool dense = false; i64 kmin = 0; u64 krange = 0;
+    const int dense_mode = op->ctx->join_dense; const i64 dense_ratio = op->ctx->join_dense_ratio;
+    if (dense_mode && n > 0 && op->keys.n_keys == 1 && !op->keys.key_wide[0] && !op->keys.null_word) {
+      u64* kr = (u64*)op->ws[0].ensure(32);
+      const u64 init[3] = {0x7FFFFFFFFFFFFFFFull, 0x8000000000000000ull, 0};
+      HIPCHECK(hipMemcpyAsync(kr, init, sizeof(init), hipMemcpyHostToDevice, s));
+      { JitScope js(op, op->prog, 14, n); launch_join_keyrange(s, P, n, op->keys, op->null_eq, kr); }
+      HIPCHECK(hipGetLastError());
+      u64 got[3];
+      HIPCHECK(hipMemcpyAsync(got, kr, sizeof(got), hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      const u64 cnt = got[2];
+      if (cnt > 0) {
+        const u64 span = got[1] - got[0];      // unsigned difference of two's complement values: exact for max >= min
+        const u64 lim = std::max<u64>((u64)cnt * (u64)dense_ratio, 1ull << 16);
+        if (span < (1ull << 31) && span < lim && (span + 1) * 4 <= op->ctx->hbm / 8) { dense = true; kmin = (i64)got[0]; krange = span + 1; }
+      }
+    }
+    if (dense) {
+      t->T.n_slots = 0; t->T.slots = nullptr;
+      t->T.dense = (uint32_t*)t->dense.ensure((size_t)krange * 4 + 16); t->T.dense_min = kmin; t->T.dense_range = krange;
+      HIPCHECK(hipMemsetAsync(t->T.dense, 0xFF, (size_t)krange * 4, s));
+    } else {
+      t->T.n_slots = next_pow2(std::max<u64>((u64)n * 3, 1024));   // load factor in (0.17, 0.33]: a miss ends after ~1.5 slot visits (2.5 at 0.5)
+      t->T.slots = (u64*)t->slots.ensure((size_t)t->T.n_slots * t->T.slot_words * 8);
+    }
     uint32_t* next = (uint32_t*)t->next.ensure((size_t)std::max<i64>(build_rows_bound, 1) * 4);
     const size_t bm = ((size_t)build_rows_bound + 63) / 64 * 8 + 8;
     uint32_t* present = (uint32_t*)t->present.ensure(bm);
     HIPCHECK(hipMemsetAsync(present, 0, bm, s));
-    launch_ht_init(s, t->T, nullptr);
+    if (!dense) launch_ht_init(s, t->T, nullptr);
     reset_flags(op, s);
     { JitScope js(op, op->prog, 5, n); ProfScope ps(op, s); launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq); }
     HIPCHECK(hipGetLastError());
@@ -1068,20 +1099,23 @@ int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpu
       const i64 n = in->n_rows;
       if (n == 0) { HIPCHECK(hipMemsetAsync(count_out, 0, 8, s)); return; }
       const i64 nwords = (n + 63) >> 6;
-      const i64 maxb = (i64)op->ctx->cus * 8;
-      i64 wpb = (nwords + maxb - 1) / maxb; if (wpb < 16) wpb = 16;
-      const int nblocks = (int)((nwords + wpb - 1) / wpb);
-      uint32_t* match = (uint32_t*)op->ws[0].ensure((size_t)n * 4 + 16);
-      u64* bitmap = (u64*)op->ws[1].ensure((size_t)nwords * 8);
-      uint32_t* counts = (uint32_t*)op->ws[2].ensure((size_t)nblocks * 4 + 16);
+      // segments: one wave each, small enough that the scheduler evens out waves that finish early (>= 32 segments per resident
+      // wave slot would be wasted scan work; 4 per slot keeps the tail short)
+      const i64 target = (i64)op->ctx->cus * 8 * 4 * 4;
+      i64 wpw = (nwords + target - 1) / target; if (wpw < 16) wpw = 16;
+      wpw = (wpw + 3) & ~(i64)3;
+      const int nsegs = (int)((nwords + wpw - 1) / wpw);
+      const bool want_build = out_build != nullptr;
+      uint32_t* seg_build = want_build ? (uint32_t*)op->ws[0].ensure((size_t)nwords * 256 + 16) : nullptr;
+      uint32_t* seg_probe = (uint32_t*)op->ws[1].ensure((size_t)nwords * 256 + 16);
+      uint32_t* counts = (uint32_t*)op->ws[2].ensure((size_t)nsegs * 4 + 16);
       std::string spec;
-      if (op->keys.n_keys == 1 && op->keys.key_words == 1 && t->T.slot_words == 2)     // one narrow key, 16-byte slots
+      if (op->keys.n_keys == 1 && op->keys.key_words == 1 && (t->T.slot_words == 2 || t->T.dense))     // one narrow key: 16-byte slots or direct addressing
         spec = "#define GPUQ_JIT_PROBE1 1\nconstexpr int JIT_KEY_REG0 = " + std::to_string(op->keys.key_reg[0]) + ";\n";
       { JitScope js(op, op->prog, 7, n, spec); ProfScope ps(op, s);
-        launch_join_probe_unique(s, P, n, op->keys, t->T, jt, op->null_eq, match, bitmap, counts, nblocks, wpb, visited); }
-      launch_scan_block_counts(s, counts, nblocks, (u64*)count_out);
-      if (out_probe) launch_compact_pairs(s, bitmap, counts, nblocks, wpb, n, match, payload_via > 0 ? in->via[payload_via - 1] : nullptr,
-                                          out_build, out_probe, out_cap, op->flags_dev.as<uint32_t>());
+        launch_join_probe_unique(s, P, n, op->keys, t->T, jt, op->null_eq, payload_via, seg_build, seg_probe, counts, nsegs, wpw, visited);
+        launch_scan_block_counts(s, counts, nsegs, (u64*)count_out);
+        if (out_probe) launch_copy_segments(s, seg_build, seg_probe, counts, nsegs, wpw, n, (const u64*)count_out, out_build, out_probe, out_cap, op->flags_dev.as<uint32_t>()); }
       HIPCHECK(hipGetLastError());
       return;
     }
@@ -1597,6 +1631,15 @@ int gpuq_ctx_set_jit(gpuq_ctx* ctx, const char* mode, int64_t min_rows) {
     if (m == "off") ctx->jit_mode = 0; else if (m == "auto") ctx->jit_mode = jit_available() ? 1 : 0; else if (m == "force") ctx->jit_mode = 2;
     else throw std::runtime_error("jit mode must be off|auto|force");
     if (min_rows >= 0) ctx->jit_min_rows = min_rows;
+  });
+}
+int gpuq_ctx_set_option(gpuq_ctx* ctx, const char* key, const char* value) {
+  return guarded(ctx, [&]() {
+    if (!ctx || !key || !value) throw std::runtime_error("ctx/key/value is NULL");
+    const std::string k = key;
+    if (k == "join_dense") ctx->join_dense = std::atoi(value) != 0;
+    else if (k == "join_dense_ratio") { const long long r = std::atoll(value); if (r < 1) throw std::runtime_error("join_dense_ratio must be >= 1"); ctx->join_dense_ratio = r; }
+    else throw std::runtime_error("unknown option '" + k + "'");
   });
 }
 int gpuq_ctx_jit_wait(gpuq_ctx* ctx) { return guarded(ctx, [&]() { check_ctx(ctx); jit_drain(); }); }

@@ -50,11 +50,17 @@ struct KeySpec {
 //   [0]            low 32 bits state (0 empty, 1 locked, else hash tag|2); high 32 bits payload (join: chain head row)
 //   [1..key_words] key words
 //   [1+key_words..] aggregate cells, two u64 (lo,hi) per accumulator
+// Join tables over ONE narrow (<= 64-bit) integer key whose values span a bounded range use direct addressing instead:
+// dense[key - dense_min] = chain head row (0xFFFFFFFF = no such key), dense_range entries.  One load per probe, no probing
+// loop, and a probe side that is clustered / sorted by the key (fact-table foreign keys) walks the table sequentially.
 struct HashTable {
   u64* slots;
   u64 n_slots;         // power of two
   int32_t slot_words;
   int32_t key_words;
+  uint32_t* dense;     // nullptr = open addressing (slots)
+  i64 dense_min;
+  u64 dense_range;
 };
 enum JoinType : int32_t { JT_INNER = 0, JT_LEFT = 1, JT_RIGHT = 2, JT_FULL = 3, JT_LEFT_SEMI = 4, JT_LEFT_ANTI = 5, JT_RIGHT_SEMI = 6, JT_RIGHT_ANTI = 7 };
 
@@ -120,10 +126,15 @@ void launch_agg_bucket(hipStream_t s, const DevProgram& P, const KeySpec& K, con
 void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags);
 void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
                        int payload_via, int null_equals_null);
-void launch_join_probe_unique(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int join_type, int null_equals_null,
-                              uint32_t* match, u64* bitmap, uint32_t* block_counts, int nblocks, i64 wpb, uint32_t* visited);
-void launch_compact_pairs(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 wpb, i64 n, const uint32_t* match,
-                          const uint32_t* probe_via, uint32_t* out_build, uint32_t* out_probe, u64 out_cap, uint32_t* flags);
+// key range of the rows a join build would insert: out = {min (i64), max (i64), count (u64)}, pre-set by the caller to {INT64_MAX, INT64_MIN, 0}
+void launch_join_keyrange(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, int null_equals_null, u64* out);
+// unique build keys: every wave owns `wpw` consecutive 64-row words (segment g = words [g*wpw, (g+1)*wpw)) and writes its pairs, in probe
+// order, to seg_build / seg_probe starting at row g*wpw*64; seg_counts[g] = pairs of the segment.  launch_copy_segments then moves
+// the segments to their final places (seg_counts already scanned to exclusive offsets).
+void launch_join_probe_unique(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int join_type, int null_equals_null, int payload_via,
+                              uint32_t* seg_build, uint32_t* seg_probe, uint32_t* seg_counts, int nsegs, i64 wpw, uint32_t* visited);
+void launch_copy_segments(hipStream_t s, const uint32_t* seg_build, const uint32_t* seg_probe, const uint32_t* seg_offsets, int nsegs, i64 wpw, i64 n,
+                          const u64* total, uint32_t* out_build, uint32_t* out_probe, u64 out_cap, uint32_t* flags);
 void launch_bitmap_select(hipStream_t s, const u64* present, const u64* visited, int matched, i64 nwords, i64 n, u64* bitmap,
                           uint32_t* block_counts, int nblocks, i64 wpb);
 void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, const uint32_t* next,

@@ -798,6 +798,44 @@ extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevPro
 #endif
 
 // ------------------------------------------------------------------ join build
+// Key range of the rows the build would insert (single narrow key): decides between the direct-addressed table and
+// open addressing.  out = {min, max, count}, pre-set by the host to {INT64_MAX, INT64_MIN, 0}.
+template <int MAXC>
+__device__ __forceinline__ void k_join_keyrange_body(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out) {
+  __shared__ i64 smn[HWAVES], smx[HWAVES]; __shared__ u64 scn[HWAVES];
+  i64 mn = 0x7FFFFFFFFFFFFFFFll, mx = (i64)0x8000000000000000ull; u64 cn = 0;
+  const i64 nwords = (n + 63) >> 6;
+  const int kr = __builtin_amdgcn_readfirstlane(K.key_reg[0]);
+  for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
+    const i64 pos = (w << 6) + hlane();
+    bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
+    if (active && !((rnulls >> kr) & 1)) {
+      const i64 v = (i64)rlo[kr];
+      mn = v < mn ? v : mn; mx = v > mx ? v : mx; ++cn;
+    }
+  }
+  (void)null_eq;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const i64 a = __shfl_xor(mn, o), b = __shfl_xor(mx, o); const u64 c = __shfl_xor(cn, o);
+    mn = a < mn ? a : mn; mx = b > mx ? b : mx; cn += c;
+  }
+  if (hlane() == 0) { smn[hwave()] = mn; smx[hwave()] = mx; scn[hwave()] = cn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < HWAVES; ++k) { mn = smn[k] < mn ? smn[k] : mn; mx = smx[k] > mx ? smx[k] : mx; cn += scn[k]; }
+    if (cn) { atomicMin((long long*)out, (long long)mn); atomicMax((long long*)out + 1, (long long)mx); atomicAdd((unsigned long long*)out + 2, (unsigned long long)cn); }
+  }
+}
+#ifndef GPUQ_JIT
+template <int MAXC>
+__global__ void __launch_bounds__(HBLOCK) k_join_keyrange(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out) { k_join_keyrange_body<MAXC>(P, n, K, null_eq, out); }
+#elif GPUQ_JIT_KERNEL == 14
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out) { k_join_keyrange_body<0>(P, n, K, null_eq, out); }
+#endif
+
 template <int MAXC>
 __device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
                                                        uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
@@ -817,34 +855,47 @@ __device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 
     if (payload_via > 0) row = P.via[payload_via - 1][pos];
     if (present) atomicOr(&present[row >> 5], 1u << (row & 31));   // every build-side row, NULL keys included (outer joins emit them)
     if (any_null && !null_eq) continue;   // a NULL key never matches (SQL equi-join)
-    bool inserted;
-    const u64 s = ht_find_or_insert(T, kw, h, row, inserted);
-    if (s == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
+    bool inserted; uint32_t old = NIL;
+    if (T.dense) {
+      // direct addressing: the table word is the chain head; an exchange both claims the key and links a duplicate
+      const u64 idx = kw[0] - (u64)T.dense_min;
+      if (idx >= T.dense_range) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }      // cannot happen: the range was measured on these rows
+      old = __hip_atomic_exchange(T.dense + idx, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      inserted = old == NIL;
+    } else {
+      const u64 s = ht_find_or_insert(T, kw, h, row, inserted);
+      if (s == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
+      if (!inserted && next) {
+        uint32_t* head = (uint32_t*)(T.slots + s * (u64)T.slot_words) + 1;   // high half of word 0
+        old = __hip_atomic_exchange(head, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     if (inserted) {
       if (next) next[row] = NIL;
     } else {
       // duplicate key: remember it (the host then uses the chained probe) -- test first, one word must not be hammered
       if (!(__hip_atomic_load(P.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_DUP_BUILD_KEY)) atomicOr(P.flags, FLAG_DUP_BUILD_KEY);
-      if (next) {
-        uint32_t* head = (uint32_t*)(T.slots + s * (u64)T.slot_words) + 1;   // high half of word 0
-        const uint32_t old = __hip_atomic_exchange(head, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        next[row] = old;
-      }
+      if (next) next[row] = old;
     }
   }
 }
 #ifndef GPUQ_JIT
 template <int MAXC>
-#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
                                                        uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
                                                        const int null_eq) { k_join_build_body<MAXC>(P, n, K, T, next, present, payload_via, null_eq); }
-#endif
 #elif GPUQ_JIT_KERNEL == 5
 extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
                                                        uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
                                                        const int null_eq) { k_join_build_body<0>(P, n, K, T, next, present, payload_via, null_eq); }
 #endif
+
+// key lookup shared by the probes: chain head row of the key, or NIL
+__device__ __forceinline__ uint32_t join_lookup(const HashTable& T, const u64 (&kw)[MAX_KW], const u64 h) {
+  if (T.dense) { const u64 idx = kw[0] - (u64)T.dense_min; return idx < T.dense_range ? T.dense[idx] : NIL; }
+  uint32_t payload;
+  return ht_find(T, kw, h, payload) ? payload : NIL;
+}
 
 // ------------------------------------------------------------------ join probe
 // Emits (build_row, probe_row) pairs with wave-ballot compaction: one global atomic per wave per
@@ -872,10 +923,7 @@ __device__ __forceinline__ void k_join_probe_body(const DevProgram P, const i64 
 #pragma unroll
       for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
       const bool any_null = make_key(K, GPUQ_REGS, kw, h);
-      if (!(any_null && !null_eq)) {
-        uint32_t payload;
-        if (ht_find(T, kw, h, payload)) cur = payload;
-      }
+      if (!(any_null && !null_eq)) cur = join_lookup(T, kw, h);
     }
     if (join_type == JT_RIGHT_SEMI || join_type == JT_RIGHT_ANTI) {
       const bool emit = active && ((join_type == JT_RIGHT_SEMI) == (cur != NIL));
@@ -932,189 +980,198 @@ extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevPro
 #endif
 
 // ------------------------------------------------------------------ join probe, unique build keys
-// No output atomics: pass 1 writes one match word per probe position (build row or NIL) plus the
-// emit bitmap and per-block counts; pass 2 (k_compact_pairs) turns them into dense, PROBE-ORDERED
-// (build_row, probe_row) pairs.  A single global counter would serialise the whole probe
-// (measured: 51 ms for 2^28 probes whatever the table size -- one device-scope atomic per wave step).
+// No output atomics and no per-row match vector: every wave owns a SEGMENT of `wpw` consecutive 64-row words, probes it in
+// order and appends its (build_row, probe_row) pairs to seg_build / seg_probe starting at the segment's first row (a segment
+// of r rows emits at most r pairs, so segments never collide); seg_counts[g] = pairs of segment g.  A scan of the counts and
+// k_copy_segments then move the segments to their final, PROBE-ORDERED places.  A selective join (TPC-H q3: 14.6 M pairs
+// from 600 M probe rows) writes and re-reads only its pairs; the first version wrote a 4-byte match word per probe ROW and
+// read all of them back in the compaction pass (4.8 GB of the kernel pair's 14 GB at SF100).  A single global counter would
+// serialise the whole probe (measured: 51 ms for 2^28 probes whatever the table size -- one device-scope atomic per wave step).
+__device__ __forceinline__ uint32_t emit_pairs(const bool emit, const uint32_t hit, const uint32_t prow, const u64 seg_base, const uint32_t cnt,
+                                               uint32_t* __restrict__ seg_build, uint32_t* __restrict__ seg_probe) {
+  const u64 m = __ballot(emit);
+  if (emit) {
+    const u64 j = seg_base + cnt + (u64)__popcll(m & ((1ull << hlane()) - 1));
+    if (seg_build) seg_build[j] = hit;
+    seg_probe[j] = prow;
+  }
+  return (uint32_t)__popcll(m);
+}
 #ifdef GPUQ_JIT_PROBE1
-// JIT specialisation for the common PK/FK shape: ONE narrow (<= 64-bit) non-null-word key, 16-byte slots.
-// Each lane keeps U probe rows in flight: U key evaluations, then U slot loads issued back to back, then U
-// resolutions -- the random slot access is the long pole of a probe, and one outstanding access per
-// lane cannot cover its latency (measured: 26-38 G probes/s with U = 1 whatever the table size).
+// JIT specialisation for the common PK/FK shape: ONE narrow (<= 64-bit) non-null-word key (16-byte slots, or the
+// direct-addressed table).  Each lane keeps U probe rows in flight: U key evaluations, then U table loads issued back to back,
+// then U resolutions -- the random table access is the long pole of a probe, and one outstanding access per lane cannot
+// cover its latency (measured: 26-38 G probes/s with U = 1 whatever the table size).
 template <int MAXC>
 __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
-                                                              const int join_type, const int null_eq, uint32_t* __restrict__ match,
-                                                              u64* __restrict__ bitmap, uint32_t* __restrict__ block_counts, const i64 wpb,
+                                                              const int join_type, const int null_eq, const int payload_via,
+                                                              uint32_t* __restrict__ seg_build, uint32_t* __restrict__ seg_probe,
+                                                              uint32_t* __restrict__ seg_counts, const int nsegs, const i64 wpw,
                                                               uint32_t* __restrict__ visited) {
 #ifndef GPUQ_PROBE_ROWS
 #define GPUQ_PROBE_ROWS 4
 #endif
   constexpr int U = GPUQ_PROBE_ROWS;
-  __shared__ uint32_t wave_cnt[HWAVES];
+  const i64 seg = (i64)blockIdx.x * HWAVES + hwave();
+  if (seg >= nsegs) return;
   const i64 nwords = (n + 63) >> 6;
-  const i64 w0 = (i64)blockIdx.x * wpb;
-  i64 w1 = w0 + wpb; if (w1 > nwords) w1 = nwords;
+  const i64 w0 = seg * wpw;
+  i64 w1 = w0 + wpw; if (w1 > nwords) w1 = nwords;
+  const u64 seg_base = (u64)w0 << 6;
   const bool probe_outer = (join_type == JT_RIGHT || join_type == JT_FULL);
   const bool want_pairs = (join_type == JT_INNER || join_type == JT_LEFT || join_type == JT_RIGHT || join_type == JT_FULL);
   const u64 mask = T.n_slots - 1;
   const ulonglong2* __restrict__ slots = (const ulonglong2*)T.slots;
+  const uint32_t* __restrict__ dense = T.dense;
   uint32_t cnt = 0;
-  for (i64 wb = w0 + (i64)hwave() * U; wb < w1; wb += (i64)HWAVES * U) {
-    bool act[U]; u64 key[U]; u64 hs[U]; bool isn[U];
+  for (i64 wb = w0; wb < w1; wb += U) {
+    bool act[U]; u64 key[U]; u64 hs[U]; bool isn[U]; uint32_t prow[U];
     // stage 1: evaluate U rows (column loads of all U rows are independent -> in flight together)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const i64 pos = ((wb + u) << 6) + hlane();
       act[u] = (wb + u) < w1 && pos < n;
-      key[u] = 0; hs[u] = 0; isn[u] = false;
+      key[u] = 0; hs[u] = 0; isn[u] = false; prow[u] = (uint32_t)pos;
       if (act[u]) {
         GPUQ_REGS_DECL;
         act[u] = GPUQ_EVAL(MAXC, P, pos);
         isn[u] = (rnulls >> JIT_KEY_REG0) & 1;
         key[u] = isn[u] ? 0 : rlo[JIT_KEY_REG0];
+        if (payload_via > 0) prow[u] = P.via[payload_via - 1][pos];
+      }
+    }
+    uint32_t hit[U];
+    if (dense) {
+      // direct addressing: one load per row, all U in flight; neighbouring lanes with equal or adjacent keys share cache lines
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const u64 idx = key[u] - (u64)T.dense_min;
+        hit[u] = NIL;
+        if (act[u] && !isn[u] && idx < T.dense_range) hit[u] = dense[idx];
+      }
+    } else {
+      // Neighbouring lanes with the same key (clustered foreign keys: the lines of one order) look the key up once: only the
+      // first lane of a run ("head") touches the table, the others copy its answer.  All cross-lane reads are executed by
+      // every lane (a masked-off source lane reads as 0).
+      bool head[U]; int src[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
         hs[u] = hash_combine(0x243F6A8885A308D3ull, key[u], 0, isn[u]);
+        const bool probe = act[u] && !(isn[u] && !null_eq);
+        const int pp = __shfl_up((int)probe, 1);
+        const u64 pk = __shfl_up(key[u], 1);
+        const int pn = __shfl_up((int)isn[u], 1);
+        const bool same = (hlane() > 0) & (pp != 0) & (pk == key[u]) & ((pn != 0) == isn[u]);
+        head[u] = probe & !same;
+        const u64 hm = __ballot(head[u]) & ((2ull << hlane()) - 1);          // heads at or below this lane
+        src[u] = (probe && hm) ? (63 - __clzll((long long)hm)) : hlane();
       }
-    }
-    // Neighbouring lanes with the same key (clustered foreign keys: the lines of one order) look the key up once: only the
-    // first lane of a run ("head") touches the table, the others copy its answer.  All cross-lane reads are executed by
-    // every lane (a masked-off source lane reads as 0).
-    bool probe[U], head[U]; int src[U];
+      // stage 2: first slot of every run
+      ulonglong2 sv[U]; u64 si[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      probe[u] = act[u] && !(isn[u] && !null_eq);
-      const int pp = __shfl_up((int)probe[u], 1);
-      const u64 pk = __shfl_up(key[u], 1);
-      const int pn = __shfl_up((int)isn[u], 1);
-      const bool same = (hlane() > 0) & (pp != 0) & (pk == key[u]) & ((pn != 0) == isn[u]);
-      head[u] = probe[u] & !same;
-      const u64 hm = __ballot(head[u]) & ((2ull << hlane()) - 1);          // heads at or below this lane
-      src[u] = (probe[u] && hm) ? (63 - __clzll((long long)hm)) : hlane();
-    }
-    // stage 2: first slot of every run
-    ulonglong2 sv[U]; u64 si[U];
+      for (int u = 0; u < U; ++u) { si[u] = hs[u] & mask; sv[u] = make_ulonglong2(0, 0); if (head[u]) sv[u] = slots[si[u]]; }
+      // stage 3: resolve (linear probing continues per row only on a tag/key mismatch)
 #pragma unroll
-    for (int u = 0; u < U; ++u) { si[u] = hs[u] & mask; sv[u] = make_ulonglong2(0, 0); if (head[u]) sv[u] = slots[si[u]]; }
-    // stage 3: resolve (linear probing continues per row only on a tag/key mismatch)
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const i64 pos = ((wb + u) << 6) + hlane();
-      uint32_t hit = NIL;
-      if (head[u]) {
-        const uint32_t tag = tag_of(hs[u]);
-        ulonglong2 v = sv[u]; u64 sidx = si[u];
-        for (u64 probes = 0; probes < T.n_slots; ++probes) {
-          const uint32_t st = (uint32_t)v.x;
-          if (st == 0u) break;
-          if (st == tag && v.y == key[u]) { hit = (uint32_t)(v.x >> 32); break; }
-          sidx = (sidx + 1) & mask; v = slots[sidx];
+      for (int u = 0; u < U; ++u) {
+        uint32_t h_ = NIL;
+        if (head[u]) {
+          const uint32_t tag = tag_of(hs[u]);
+          ulonglong2 v = sv[u]; u64 sidx = si[u];
+          for (u64 probes = 0; probes < T.n_slots; ++probes) {
+            const uint32_t st = (uint32_t)v.x;
+            if (st == 0u) break;
+            if (st == tag && v.y == key[u]) { h_ = (uint32_t)(v.x >> 32); break; }
+            sidx = (sidx + 1) & mask; v = slots[sidx];
+          }
         }
-        if (visited && hit != NIL) atomicOr(&visited[hit >> 5], 1u << (hit & 31));
+        hit[u] = (uint32_t)__shfl((int)h_, src[u]);      // run members take their head's answer (heads and idle lanes read themselves)
+        if (!act[u]) hit[u] = NIL;
       }
-      hit = (uint32_t)__shfl((int)hit, src[u]);      // run members take their head's answer (heads and idle lanes read themselves)
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (visited && hit[u] != NIL) atomicOr(&visited[hit[u] >> 5], 1u << (hit[u] & 31));
       bool emit;
-      if (join_type == JT_RIGHT_SEMI) emit = act[u] && hit != NIL;
-      else if (join_type == JT_RIGHT_ANTI) emit = act[u] && hit == NIL;
-      else emit = want_pairs && act[u] && (hit != NIL || probe_outer);
-      if ((wb + u) < w1) {
-        if (pos < n) match[pos] = hit;
-        const u64 m = __ballot(emit);
-        if (hlane() == 0) bitmap[wb + u] = m;
-        cnt += (uint32_t)__popcll(m);
-      }
+      if (join_type == JT_RIGHT_SEMI) emit = act[u] && hit[u] != NIL;
+      else if (join_type == JT_RIGHT_ANTI) emit = act[u] && hit[u] == NIL;
+      else emit = want_pairs && act[u] && (hit[u] != NIL || probe_outer);
+      cnt += emit_pairs(emit, hit[u], prow[u], seg_base, cnt, seg_build, seg_probe);
     }
   }
-  if (hlane() == 0) wave_cnt[hwave()] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < HWAVES; ++k) t += wave_cnt[k]; block_counts[blockIdx.x] = t; }
+  if (hlane() == 0) seg_counts[seg] = cnt;
 }
 #else
 template <int MAXC>
 __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
-                                                              const int join_type, const int null_eq, uint32_t* __restrict__ match,
-                                                              u64* __restrict__ bitmap, uint32_t* __restrict__ block_counts, const i64 wpb,
+                                                              const int join_type, const int null_eq, const int payload_via,
+                                                              uint32_t* __restrict__ seg_build, uint32_t* __restrict__ seg_probe,
+                                                              uint32_t* __restrict__ seg_counts, const int nsegs, const i64 wpw,
                                                               uint32_t* __restrict__ visited) {
-  __shared__ uint32_t wave_cnt[HWAVES];
+  const i64 seg = (i64)blockIdx.x * HWAVES + hwave();
+  if (seg >= nsegs) return;
   const i64 nwords = (n + 63) >> 6;
-  const i64 w0 = (i64)blockIdx.x * wpb;
-  i64 w1 = w0 + wpb; if (w1 > nwords) w1 = nwords;
+  const i64 w0 = seg * wpw;
+  i64 w1 = w0 + wpw; if (w1 > nwords) w1 = nwords;
+  const u64 seg_base = (u64)w0 << 6;
   const bool probe_outer = (join_type == JT_RIGHT || join_type == JT_FULL);
   const bool want_pairs = (join_type == JT_INNER || join_type == JT_LEFT || join_type == JT_RIGHT || join_type == JT_FULL);
   uint32_t cnt = 0;
-  for (i64 w = w0 + hwave(); w < w1; w += HWAVES) {
+  for (i64 w = w0; w < w1; ++w) {
     const i64 pos = (w << 6) + hlane();
     bool active = pos < n;
     GPUQ_REGS_DECL;
     if (active) active = GPUQ_EVAL(MAXC, P, pos);
-    uint32_t hit = NIL;
+    uint32_t hit = NIL, prow = (uint32_t)pos;
     if (active) {
+      if (payload_via > 0) prow = P.via[payload_via - 1][pos];
       u64 kw[MAX_KW]; u64 h;
 #pragma unroll
       for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
       const bool any_null = make_key(K, GPUQ_REGS, kw, h);
-      if (!(any_null && !null_eq)) { uint32_t payload; if (ht_find(T, kw, h, payload)) hit = payload; }
+      if (!(any_null && !null_eq)) hit = join_lookup(T, kw, h);
       if (visited && hit != NIL) atomicOr(&visited[hit >> 5], 1u << (hit & 31));
     }
     bool emit;
     if (join_type == JT_RIGHT_SEMI) emit = active && hit != NIL;
     else if (join_type == JT_RIGHT_ANTI) emit = active && hit == NIL;
     else emit = want_pairs && active && (hit != NIL || probe_outer);
-    if (pos < n) match[pos] = hit;
-    const u64 m = __ballot(emit);
-    if (hlane() == 0) bitmap[w] = m;
-    cnt += (uint32_t)__popcll(m);
+    cnt += emit_pairs(emit, hit, prow, seg_base, cnt, seg_build, seg_probe);
   }
-  if (hlane() == 0) wave_cnt[hwave()] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < HWAVES; ++k) t += wave_cnt[k]; block_counts[blockIdx.x] = t; }
+  if (hlane() == 0) seg_counts[seg] = cnt;
 }
 #endif  // GPUQ_JIT_PROBE1
 #ifndef GPUQ_JIT
 template <int MAXC>
-#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(HBLOCK) k_join_probe_unique(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
-                                                              const int join_type, const int null_eq, uint32_t* __restrict__ match,
-                                                              u64* __restrict__ bitmap, uint32_t* __restrict__ block_counts, const i64 wpb,
-                                                              uint32_t* __restrict__ visited) { k_join_probe_unique_body<MAXC>(P, n, K, T, join_type, null_eq, match, bitmap, block_counts, wpb, visited); }
-#endif
+                                                              const int join_type, const int null_eq, const int payload_via,
+                                                              uint32_t* __restrict__ seg_build, uint32_t* __restrict__ seg_probe,
+                                                              uint32_t* __restrict__ seg_counts, const int nsegs, const i64 wpw,
+                                                              uint32_t* __restrict__ visited) { k_join_probe_unique_body<MAXC>(P, n, K, T, join_type, null_eq, payload_via, seg_build, seg_probe, seg_counts, nsegs, wpw, visited); }
 #elif GPUQ_JIT_KERNEL == 7
 extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
-                                                              const int join_type, const int null_eq, uint32_t* __restrict__ match,
-                                                              u64* __restrict__ bitmap, uint32_t* __restrict__ block_counts, const i64 wpb,
-                                                              uint32_t* __restrict__ visited) { k_join_probe_unique_body<0>(P, n, K, T, join_type, null_eq, match, bitmap, block_counts, wpb, visited); }
+                                                              const int join_type, const int null_eq, const int payload_via,
+                                                              uint32_t* __restrict__ seg_build, uint32_t* __restrict__ seg_probe,
+                                                              uint32_t* __restrict__ seg_counts, const int nsegs, const i64 wpw,
+                                                              uint32_t* __restrict__ visited) { k_join_probe_unique_body<0>(P, n, K, T, join_type, null_eq, payload_via, seg_build, seg_probe, seg_counts, nsegs, wpw, visited); }
 #endif
 
 #ifndef GPUQ_JIT
-__global__ void __launch_bounds__(HBLOCK) k_compact_pairs(const u64* __restrict__ bitmap, const uint32_t* __restrict__ block_offsets, const i64 wpb,
-                                                          const i64 n, const uint32_t* __restrict__ match, const uint32_t* __restrict__ probe_via,
+// one wave per segment: its pairs from the segment's scratch place to their final place (offsets = exclusive scan of the counts)
+__global__ void __launch_bounds__(HBLOCK) k_copy_segments(const uint32_t* __restrict__ seg_build, const uint32_t* __restrict__ seg_probe,
+                                                          const uint32_t* __restrict__ seg_offsets, const int nsegs, const i64 wpw, const u64* __restrict__ total,
                                                           uint32_t* __restrict__ out_build, uint32_t* __restrict__ out_probe, const u64 out_cap,
                                                           uint32_t* __restrict__ flags) {
-  __shared__ uint32_t wave_cnt[HWAVES];
-  const i64 nwords = (n + 63) >> 6;
-  const i64 w0 = (i64)blockIdx.x * wpb;
-  i64 w1 = w0 + wpb; if (w1 > nwords) w1 = nwords;
-  const i64 span = w1 > w0 ? (w1 - w0) : 0;
-  const i64 per = (span + HWAVES - 1) / HWAVES;
-  const i64 a = w0 + per * hwave();
-  i64 b = a + per; if (b > w1) b = w1;
-  uint32_t cnt = 0;
-  for (i64 w = a + hlane(); w < b; w += 64) cnt += (uint32_t)__popcll(bitmap[w]);
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-  if (hlane() == 0) wave_cnt[hwave()] = cnt;
-  __syncthreads();
-  u64 out = block_offsets[blockIdx.x];
-  for (int k = 0; k < hwave(); ++k) out += wave_cnt[k];
-  for (i64 w = a; w < b; ++w) {
-    const u64 m = bitmap[w];
-    const int l = hlane();
-    if ((m >> l) & 1) {
-      const u64 idx = out + (u64)__popcll(m & ((1ull << l) - 1));
-      const i64 pos = (w << 6) + l;
-      if (idx < out_cap) {
-        if (out_build) out_build[idx] = match[pos];
-        out_probe[idx] = probe_via ? probe_via[pos] : (uint32_t)pos;
-      } else atomicOr(flags, FLAG_OUT_OVERFLOW);
+  const u64 tot = *total;
+  for (i64 seg = (i64)blockIdx.x * HWAVES + hwave(); seg < nsegs; seg += (i64)gridDim.x * HWAVES) {
+    const u64 off = seg_offsets[seg];
+    const u64 end = (seg + 1 < nsegs) ? (u64)seg_offsets[seg + 1] : tot;
+    const u64 src = (u64)(seg * wpw) << 6;
+    for (u64 i = hlane(); off + i < end; i += 64) {
+      if (off + i < out_cap) {
+        if (out_build) out_build[off + i] = seg_build[src + i];
+        out_probe[off + i] = seg_probe[src + i];
+      } else { atomicOr(flags, FLAG_OUT_OVERFLOW); break; }
     }
-    out += (u64)__popcll(m);
   }
 }
 #endif
@@ -1259,19 +1316,33 @@ void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec&
   }
 }
 
-void launch_join_probe_unique(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int join_type, int null_equals_null,
-                              uint32_t* match, u64* bitmap, uint32_t* block_counts, int nblocks, i64 wpb, uint32_t* visited) {
-  if (jit_override().fn && jit_override().kernel_id == 7) {
-    (void)jit_launch(jit_override().fn, dim3(nblocks), dim3(HBLOCK), 0, s, P, n, K, T, join_type, null_equals_null, match, bitmap, block_counts, wpb, visited);
+void launch_join_keyrange(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, int null_equals_null, u64* out) {
+  if (n <= 0) return;
+  if (jit_override().fn && jit_override().kernel_id == 14) {
+    (void)jit_launch(jit_override().fn, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, null_equals_null, out);
   } else {
-#define CALL(M) hipLaunchKernelGGL(k_join_probe_unique<M>, dim3(nblocks), dim3(HBLOCK), 0, s, P, n, K, T, join_type, null_equals_null, match, bitmap, block_counts, wpb, visited)
+#define CALL(M) hipLaunchKernelGGL(k_join_keyrange<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, null_equals_null, out)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
   }
 }
-void launch_compact_pairs(hipStream_t s, const u64* bitmap, const uint32_t* block_offsets, int nblocks, i64 wpb, i64 n, const uint32_t* match,
-                          const uint32_t* probe_via, uint32_t* out_build, uint32_t* out_probe, u64 out_cap, uint32_t* flags) {
-  hipLaunchKernelGGL(k_compact_pairs, dim3(nblocks), dim3(HBLOCK), 0, s, bitmap, block_offsets, wpb, n, match, probe_via, out_build, out_probe, out_cap, flags);
+void launch_join_probe_unique(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int join_type, int null_equals_null, int payload_via,
+                              uint32_t* seg_build, uint32_t* seg_probe, uint32_t* seg_counts, int nsegs, i64 wpw, uint32_t* visited) {
+  const int nblocks = (nsegs + HWAVES - 1) / HWAVES;
+  if (jit_override().fn && jit_override().kernel_id == 7) {
+    (void)jit_launch(jit_override().fn, dim3(nblocks), dim3(HBLOCK), 0, s, P, n, K, T, join_type, null_equals_null, payload_via, seg_build, seg_probe, seg_counts, nsegs, wpw, visited);
+  } else {
+#define CALL(M) hipLaunchKernelGGL(k_join_probe_unique<M>, dim3(nblocks), dim3(HBLOCK), 0, s, P, n, K, T, join_type, null_equals_null, payload_via, seg_build, seg_probe, seg_counts, nsegs, wpw, visited)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
+  }
+}
+void launch_copy_segments(hipStream_t s, const uint32_t* seg_build, const uint32_t* seg_probe, const uint32_t* seg_offsets, int nsegs, i64 wpw, i64 n,
+                          const u64* total, uint32_t* out_build, uint32_t* out_probe, u64 out_cap, uint32_t* flags) {
+  (void)n;
+  i64 need = ((i64)nsegs + HWAVES - 1) / HWAVES; const i64 cap = (i64)num_cus() * 8;
+  hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)(need < cap ? (need ? need : 1) : cap)), dim3(HBLOCK), 0, s, seg_build, seg_probe, seg_offsets, nsegs, wpw, total,
+                     out_build, out_probe, out_cap, flags);
 }
 
 #endif  // GPUQ_JIT

@@ -88,6 +88,10 @@ gpuq_ctx* gpuq_ctx_create(int device_ordinal, const char* json_opts);
 void gpuq_ctx_free(gpuq_ctx* ctx);
 const char* gpuq_last_error(gpuq_ctx* ctx);
 int gpuq_ctx_device_info(gpuq_ctx* ctx, char* buf, size_t cap); /* JSON: name, arch, cus, hbm_bytes */
+/* Tuning switches (strings): "join_dense" = "0" | "1" (default 1; env GPUQ_JOIN_DENSE at ctx creation): join tables over ONE
+   Int32 / Int64 / Date32 key whose build values span a bounded range are direct-addressed arrays instead of hash tables;
+   "join_dense_ratio" = largest range / key-count ratio that still takes the array (default 128). */
+int gpuq_ctx_set_option(gpuq_ctx* ctx, const char* key, const char* value);
 
 /* ---- runtime specialisation (JIT) ---------------------------------------------------------- */
 /* The row front-end (column loads + expressions) of every operator exists twice: as interpreter kernels
@@ -229,7 +233,7 @@ int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t
    check (string longer than 15 bytes in a packed comparison, output capacity overflow, ...). */
 int gpuq_op_check(gpuq_op* op, void* stream);
 /* Debug: the full source handed to hiprtc for sink kernel `kernel_id` (1 filter, 2 project, 3 aggregate-LDS,
-   4 aggregate-hash, 5 join build, 6 probe chained, 7 probe unique, 8 sort min/max, 9 sort pack, 10 partition). */
+   4 aggregate-hash, 5 join build, 6 probe chained, 7 probe unique, 8 sort min/max, 9 sort pack, 10 partition, 14 join key range). */
 int gpuq_op_jit_source(gpuq_op* op, int kernel_id, char* buf, size_t cap);
 
 /* arrow `take` for Utf8 payload columns of ANY string length (datafusion's materialisation of a join / filter / sort output):

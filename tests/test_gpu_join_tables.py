@@ -1,0 +1,169 @@
+"""HashJoinExec (datafusion.proto:1346-1360) over the two join-table layouts of the device path -- the direct-addressed
+array (one narrow integer key of bounded range) and the open-addressing hash table -- and the segmented, probe-ordered pair
+emission of the unique-key probe, against the oracle.  The operator suite (test_gpu_operators.py) runs with the default
+policy; here every join type runs under both layouts, interpreter and hiprtc-specialised kernels."""
+import ctypes as C
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import arrow_ballista_amd as g
+from arrow_ballista_amd.expr import Operator as Op
+from arrow_ballista_amd.expr import binary, col, lit
+from oracle import oracle_np as O
+import test_gpu_operators as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["dense", "hash"])
+def layout(tc, request):
+    tc.ctx.set_option("join_dense", 1 if request.param == "dense" else 0)
+    yield request.param
+    tc.ctx.set_option("join_dense", 1)
+
+
+@pytest.fixture(params=["off", "force"])
+def jitmode(tc, request):
+    if request.param == "force" and not tc.ctx.jit_stats()["available"]:
+        pytest.skip("hiprtc not available")
+    tc.ctx.set_jit(request.param)
+    yield request.param
+    tc.ctx.set_jit("auto")
+
+
+@pytest.mark.parametrize("jt", M.JOIN_TYPES)
+def test_join_types_under_both_layouts(tc, layout, jitmode, jt):
+    M.test_hash_join_types(tc, jt, 0.2)
+
+
+def _join_rows(tc, build, probe, jt, on=("bk", "pk"), probe_pred=None):
+    L, R0 = g.MemoryExec([build]), g.MemoryExec([probe])
+    R = g.FilterExec(probe_pred(R0.schema()), R0) if probe_pred else R0
+    ls, rs = L.schema(), R.schema()
+    plan = g.HashJoinExec(L, R, [(col(on[0], ls), col(on[1], rs))], None, jt, "CollectLeft", False)
+    return M.norm(M.dev_rows(tc, plan.execute(0, tc)))
+
+
+def _oracle_rows(build, probe, jt, on=("bk", "pk")):
+    ol, orr = O.Table.from_arrow(build), O.Table.from_arrow(probe)
+    pairs = O.hash_join(ol, orr, [({"column": {"name": on[0]}}, {"column": {"name": on[1]}})], jt)
+    lrows, rrows = [tuple(x) for x in ol.rows()], [tuple(x) for x in orr.rows()]
+    nl, nr = len(build.schema.names), len(probe.schema.names)
+    if jt in ("LeftSemi", "LeftAnti"):
+        return M.norm([lrows[i] for i, _ in pairs])
+    if jt in ("RightSemi", "RightAnti"):
+        return M.norm([rrows[j] for _, j in pairs])
+    return M.norm([(lrows[i] if i is not None else (None,) * nl) + (rrows[j] if j is not None else (None,) * nr) for i, j in pairs])
+
+
+KEYSETS = {
+    # name: (build keys, probe keys, arrow type)
+    "negative_and_positive": (lambda r: r.permutation(np.arange(-700, 900))[:1100], lambda r: r.integers(-1000, 1200, 6000), pa.int64()),
+    "int64_extremes": (lambda r: np.array([np.iinfo(np.int64).min, -1, 0, 1, np.iinfo(np.int64).max, 42], dtype=np.int64),
+                       lambda r: np.array([np.iinfo(np.int64).min, np.iinfo(np.int64).max, 0, 7, 42, -1, -2] * 40, dtype=np.int64), pa.int64()),      # range too wide: hash table
+    "sparse_beyond_ratio": (lambda r: (r.permutation(4000)[:900].astype(np.int64) * 1_000_003), lambda r: (r.integers(0, 4200, 5000).astype(np.int64) * 1_000_003), pa.int64()),
+    "single_key": (lambda r: np.array([123456789], dtype=np.int64), lambda r: np.array([123456789, 5, 123456789, 123456790, 123456788], dtype=np.int64), pa.int64()),
+    "int32_keys": (lambda r: r.permutation(np.arange(-300, 300)).astype(np.int32)[:400], lambda r: r.integers(-400, 400, 3000).astype(np.int32), pa.int32()),
+    "duplicate_build_keys": (lambda r: r.integers(100, 400, 1500), lambda r: r.integers(0, 500, 4000), pa.int64()),                # chained probe over either layout
+}
+
+
+@pytest.mark.parametrize("jt", ["Inner", "Left", "Right", "Full", "LeftSemi", "LeftAnti", "RightSemi", "RightAnti"])
+@pytest.mark.parametrize("keyset", sorted(KEYSETS))
+def test_key_domains(tc, layout, keyset, jt):
+    """Key domains that steer the layout choice or sit at its edges: negative keys (index = key - min), the int64 extremes
+    (range does not fit: hash table even when direct addressing is on), a sparse domain beyond the range / count ratio, a single
+    key, Int32 keys, duplicate build keys (chains), probe keys below min and above max, NULL keys on both sides."""
+    r = np.random.default_rng(hash(keyset) % 1000)
+    mk_b, mk_p, ty = KEYSETS[keyset]
+    bk, pk = np.asarray(mk_b(r)), np.asarray(mk_p(r))
+    bmask = r.random(len(bk)) < 0.05 if len(bk) > 10 else None
+    pmask = r.random(len(pk)) < 0.1
+    build = pa.table({"bk": pa.array(bk, type=ty, mask=bmask), "bv": pa.array(np.arange(len(bk), dtype=np.int64))})
+    probe = pa.table({"pk": pa.array(pk, type=ty, mask=pmask), "pid": pa.array(np.arange(len(pk), dtype=np.int64))})
+    assert _join_rows(tc, build, probe, jt) == _oracle_rows(build, probe, jt)
+
+
+@pytest.mark.parametrize("jt", ["Inner", "Right", "RightSemi", "RightAnti"])
+def test_segments_keep_probe_order_and_cover_ragged_tails(tc, layout, jitmode, jt):
+    """The unique-key probe emits its pairs in probe order through per-wave segments.  2^20 + 77 probe rows (segments of
+    several waves, a ragged last word and a last segment shorter than the others), match density that varies along the input
+    (empty segments, full segments), a fused probe-side filter; the C entry points directly: pair list == the oracle's
+    probe-ordered list, element by element."""
+    import torch
+    r = np.random.default_rng(9)
+    nb, n = 50_000, (1 << 20) + 77
+    bkeys = r.permutation(np.arange(0, 2 * nb, 2))[:nb].astype(np.int64) + 1000          # unique even keys from 1000
+    pk = r.integers(900, 2 * nb + 1200, n).astype(np.int64)
+    pk[: n // 4] = 7                                                                       # a long stretch without any match
+    pk[n // 4: n // 2] = np.repeat(bkeys, 8)[: n // 2 - n // 4]                            # a stretch where every row matches, clustered
+    flt = r.integers(0, 10, n).astype(np.int32)
+    dev = tc.device
+    bt = g.DeviceTable([g.DeviceColumn("k", "Int64", torch.from_numpy(bkeys).to(dev).view(torch.uint8), nb, nullable=False)], nb)
+    pt = g.DeviceTable([g.DeviceColumn("k", "Int64", torch.from_numpy(pk).to(dev).view(torch.uint8), n, nullable=False),
+                        g.DeviceColumn("f", "Int32", torch.from_numpy(flt).to(dev).view(torch.uint8), n, nullable=False)], n)
+    bs, ps = bt.schema(), pt.schema()
+    bop = tc.op({"op": "join_build", "input": {"fields": bs}, "on": [col("k", bs)]})
+    pop = tc.op({"op": "join_probe", "input": {"fields": ps}, "on": [col("k", ps)], "join_type": jt, "predicate": binary(col("f", ps), Op.Lt, lit(8, "Int32"))})
+    binp, _k1 = bt.input_struct()
+    pinp, _k2 = pt.input_struct()
+    h = C.c_void_p()
+    tc.ctx.check(tc.ctx.L.gpuq_join_build_run(bop.h, tc.stream_ptr(), C.byref(binp), 0, nb, C.byref(h)))
+    ob = torch.full((n,), -2, dtype=torch.int32, device=dev)
+    opb = torch.full((n,), -2, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    tc.ctx.check(tc.ctx.L.gpuq_join_probe_run(pop.h, tc.stream_ptr(), h, C.byref(pinp), 0, ob.data_ptr(), opb.data_ptr(), n, cnt.data_ptr()))
+    tc.sync()
+    pop.check(tc.stream_ptr())
+    k = int(cnt[0].item())
+    tc.ctx.L.gpuq_join_table_free(h)
+    # oracle: probe-ordered pairs
+    where = {int(v): i for i, v in enumerate(bkeys)}
+    passing = np.nonzero(flt < 8)[0]
+    hit = np.array([where.get(int(v), -1) for v in pk[passing]])
+    if jt == "Inner":
+        sel = hit >= 0; exp_b, exp_p = hit[sel], passing[sel]
+    elif jt == "Right":
+        exp_b, exp_p = hit, passing
+    elif jt == "RightSemi":
+        sel = hit >= 0; exp_b, exp_p = None, passing[sel]
+    else:
+        sel = hit < 0; exp_b, exp_p = None, passing[sel]
+    assert k == len(exp_p)
+    assert np.array_equal(opb[:k].cpu().numpy().astype(np.int64), exp_p)
+    if exp_b is not None:
+        assert np.array_equal(ob[:k].cpu().numpy().astype(np.int64), exp_b)          # -1 == NULL_ROW (0xFFFFFFFF) for unmatched outer rows
+    assert int(opb[k:].max().item() if k < n else -2) == -2                           # nothing written past the count
+
+
+def test_capacity_overflow_is_reported(tc, layout):
+    """out_cap smaller than the pair count: the count is still exact, the check reports GPUQ_ERR_CAPACITY, nothing is written past out_cap."""
+    import torch
+    nb, n = 1000, 100_000
+    dev = tc.device
+    bk = torch.arange(nb, dtype=torch.int64, device=dev)
+    pk = torch.arange(n, dtype=torch.int64, device=dev) % nb
+    bt = g.DeviceTable([g.DeviceColumn("k", "Int64", bk.view(torch.uint8), nb, nullable=False)], nb)
+    pt = g.DeviceTable([g.DeviceColumn("k", "Int64", pk.view(torch.uint8), n, nullable=False)], n)
+    bs, ps = bt.schema(), pt.schema()
+    bop = tc.op({"op": "join_build", "input": {"fields": bs}, "on": [col("k", bs)]})
+    pop = tc.op({"op": "join_probe", "input": {"fields": ps}, "on": [col("k", ps)], "join_type": "Inner"})
+    binp, _k1 = bt.input_struct()
+    pinp, _k2 = pt.input_struct()
+    h = C.c_void_p()
+    tc.ctx.check(tc.ctx.L.gpuq_join_build_run(bop.h, tc.stream_ptr(), C.byref(binp), 0, nb, C.byref(h)))
+    cap = 5000
+    ob = torch.full((cap + 64,), -2, dtype=torch.int32, device=dev)
+    opb = torch.full((cap + 64,), -2, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    tc.ctx.check(tc.ctx.L.gpuq_join_probe_run(pop.h, tc.stream_ptr(), h, C.byref(pinp), 0, ob.data_ptr(), opb.data_ptr(), cap, cnt.data_ptr()))
+    tc.sync()
+    assert int(cnt[0].item()) == n
+    with pytest.raises(g.GpuqError) as e:
+        pop.check(tc.stream_ptr())
+    assert e.value.status == 4
+    assert int(ob[cap:].max().item()) == -2 and int(opb[cap:].max().item()) == -2
+    assert np.array_equal(opb[:cap].cpu().numpy(), np.arange(cap, dtype=np.int32))
+    tc.ctx.L.gpuq_join_table_free(h)
