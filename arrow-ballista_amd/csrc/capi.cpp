@@ -82,7 +82,7 @@ struct gpuq_op {
 struct gpuq_join_table {
   gpuq_ctx* ctx = nullptr;
   KeySpec keys{}; HashTable T{}; int null_eq = 0;
-  DevBuf slots, dense, next, visited, present, ws_bitmap, ws_counts;
+  DevBuf slots, dense, dense_bits, next, visited, present, ws_bitmap, ws_counts;
   i64 bound = 0;
   bool visited_ready = false;
   bool has_dups = false;   // some key occurs on more than one build row -> chained probe
@@ -983,16 +983,32 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         ng = fw[2];
         posted = ahead;
       } else {
-        // count live slots first so the raw buffers are sized exactly
-        alloc_raw(1);
-        raw.cap = 0;
-        launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
-        ng = read_ng();
-        reset_flags(op, s);
-        alloc_raw(std::max<i64>(ng, 1));
-        launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
-        HIPCHECK(hipGetLastError());
-        ng = read_ng();
+        // Size the raw result from what this operator produced last time (the partitions of a stage, or the same query again,
+        // have similar cardinalities) and extract once; an unknown or outgrown count costs a counting pass first.
+        bool done = false;
+        if (op->last_groups > 0) {
+          alloc_raw(op->last_groups + op->last_groups / 4 + 1024);
+          launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
+          HIPCHECK(hipGetLastError());
+          uint32_t fw[4] = {0, 0, 0, 0};
+          read_status(op, s, fw, 4);
+          ng = fw[2];
+          if (fw[0] & ~FLAG_GROUP_OVERFLOW) { reset_flags(op, s); raise_flags(fw[0]); }
+          done = !(fw[0] & FLAG_GROUP_OVERFLOW);
+          if (!done) { reset_flags(op, s); HIPCHECK(hipMemsetAsync(raw.n_groups, 0, 4, s)); }
+        } else {
+          alloc_raw(1);
+          raw.cap = 0;      // counting pass
+          launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
+          ng = read_ng();
+          reset_flags(op, s);
+        }
+        if (!done) {
+          alloc_raw(std::max<i64>(ng, 1));
+          launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
+          HIPCHECK(hipGetLastError());
+          ng = read_ng();
+        }
       }
     }
     op->last_groups = (i64)ng;
@@ -1027,7 +1043,7 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     // that will be inserted is measured first (one more pass over the build input; the build is synchronous anyway).  Direct
     // addressing wins while initialising `range` words costs less than hashing `count` keys (~700 B of memset per key measured),
     // i.e. up to a range of ~128 x count (gpuq_ctx_set_option "join_dense" / "join_dense_ratio").
-    bool dense = false; i64 kmin = 0; u64 krange = 0;
+    bool dense = false; i64 kmin = 0; u64 krange = 0, kcount = 0;
     const int dense_mode = op->ctx->join_dense; const i64 dense_ratio = op->ctx->join_dense_ratio;
     if (dense_mode && n > 0 && op->keys.n_keys == 1 && !op->keys.key_wide[0] && !op->keys.null_word) {
       u64* kr = (u64*)op->ws[0].ensure(32);
@@ -1042,13 +1058,20 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
       if (cnt > 0) {
         const u64 span = got[1] - got[0];      // unsigned difference of two's complement values: exact for max >= min
         const u64 lim = std::max<u64>((u64)cnt * (u64)dense_ratio, 1ull << 16);
-        if (span < (1ull << 31) && span < lim && (span + 1) * 4 <= op->ctx->hbm / 8) { dense = true; kmin = (i64)got[0]; krange = span + 1; }
+        if (span < (1ull << 31) && span < lim && (span + 1) * 4 <= op->ctx->hbm / 8) { dense = true; kmin = (i64)got[0]; krange = span + 1; kcount = cnt; }
       }
     }
+    bool sparse_bits = false;
     if (dense) {
       t->T.n_slots = 0; t->T.slots = nullptr;
       t->T.dense = (uint32_t*)t->dense.ensure((size_t)krange * 4 + 16); t->T.dense_min = kmin; t->T.dense_range = krange;
-      HIPCHECK(hipMemsetAsync(t->T.dense, 0xFF, (size_t)krange * 4, s));
+      // sparse domain (fewer than one value in four is a key): presence bitmap + uninitialised row array (gpuq_kernels.h)
+      sparse_bits = kcount * 4 < krange;
+      if (sparse_bits) {
+        const size_t bb = ((size_t)krange + 63) / 64 * 8 + 8;
+        t->T.dense_bits = (uint32_t*)t->dense_bits.ensure(bb);
+        HIPCHECK(hipMemsetAsync(t->T.dense_bits, 0, bb, s));
+      } else HIPCHECK(hipMemsetAsync(t->T.dense, 0xFF, (size_t)krange * 4, s));
     } else {
       t->T.n_slots = next_pow2(std::max<u64>((u64)n * 3, 1024));   // load factor in (0.17, 0.33]: a miss ends after ~1.5 slot visits (2.5 at 0.5)
       t->T.slots = (u64*)t->slots.ensure((size_t)t->T.n_slots * t->T.slot_words * 8);
@@ -1061,7 +1084,17 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     reset_flags(op, s);
     { JitScope js(op, op->prog, 5, n); ProfScope ps(op, s); launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq); }
     HIPCHECK(hipGetLastError());
-    const uint32_t f = read_flags(op, s);
+    uint32_t f = read_flags(op, s);
+    if (sparse_bits && (f & FLAG_DUP_BUILD_KEY)) {
+      // duplicate keys: chains need defined heads -- rebuild over the initialised array
+      t->T.dense_bits = nullptr;
+      HIPCHECK(hipMemsetAsync(t->T.dense, 0xFF, (size_t)krange * 4, s));
+      HIPCHECK(hipMemsetAsync(present, 0, bm, s));
+      reset_flags(op, s);
+      { JitScope js(op, op->prog, 5, n); ProfScope ps(op, s); launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq); }
+      HIPCHECK(hipGetLastError());
+      f = read_flags(op, s);
+    }
     if (f & ~FLAG_DUP_BUILD_KEY) { reset_flags(op, s); raise_flags(f & ~FLAG_DUP_BUILD_KEY); }
     if (f) reset_flags(op, s);
     t->has_dups = (f & FLAG_DUP_BUILD_KEY) != 0;

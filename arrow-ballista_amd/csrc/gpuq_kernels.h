@@ -61,6 +61,11 @@ struct HashTable {
   uint32_t* dense;     // nullptr = open addressing (slots)
   i64 dense_min;
   u64 dense_range;
+  // Sparse domains (few keys in a wide range: a filtered dimension table) add a presence bitmap, one bit per key value, and leave
+  // the row array uninitialised: only bits are cleared at build time (range / 8 bytes instead of 4 x range), a probe that misses
+  // touches the bitmap alone (32 x denser than the array: L2- or Infinity-Cache-resident), a hit reads bitmap + array.
+  // Only for unique build keys (duplicates need the chain heads initialised).  nullptr = the array alone (NIL = no key).
+  uint32_t* dense_bits;
 };
 enum JoinType : int32_t { JT_INNER = 0, JT_LEFT = 1, JT_RIGHT = 2, JT_FULL = 3, JT_LEFT_SEMI = 4, JT_LEFT_ANTI = 5, JT_RIGHT_SEMI = 6, JT_RIGHT_ANTI = 7 };
 

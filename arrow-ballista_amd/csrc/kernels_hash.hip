@@ -301,6 +301,8 @@ __global__ void __launch_bounds__(HBLOCK) k_agg_hash_extract(const KeySpec K, co
     uint32_t base = 0;
     if (hlane() == 0) base = atomicAdd(out.n_groups, total);
     base = __shfl(base, 0);
+    if (out.cap == 0) continue;           // counting pass (the caller sizes the result from n_groups): nothing to write, nothing to flag
+    if (base + total > (uint32_t)out.cap && hlane() == 0) atomicOr(flags, FLAG_GROUP_OVERFLOW);      // once per wave, not once per row
 #pragma unroll
     for (int j = 0; j < XSUB; ++j) {
       const u64 m = masks[j];
@@ -308,8 +310,7 @@ __global__ void __launch_bounds__(HBLOCK) k_agg_hash_extract(const KeySpec K, co
         const u64 s = c * chunk_slots + (u64)j * 64 + hlane();
         const u64* slot = T.slots + s * (u64)T.slot_words;
         const uint32_t g = base + (uint32_t)__popcll(m & ltmask);
-        if (g >= (uint32_t)out.cap) { atomicOr(flags, FLAG_GROUP_OVERFLOW); }
-        else {
+        if (g < (uint32_t)out.cap) {
           int w = 0;
           for (int k = 0; k < K.n_keys; ++k) {
             const u64 lo = slot[1 + w]; ++w;
@@ -860,8 +861,17 @@ __device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 
       // direct addressing: the table word is the chain head; an exchange both claims the key and links a duplicate
       const u64 idx = kw[0] - (u64)T.dense_min;
       if (idx >= T.dense_range) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }      // cannot happen: the range was measured on these rows
-      old = __hip_atomic_exchange(T.dense + idx, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      inserted = old == NIL;
+      if (T.dense_bits) {
+        // presence bitmap + uninitialised row array: valid for unique keys only; a duplicate raises the flag and the host rebuilds
+        // with the initialised array (chains need a defined head)
+        const uint32_t bit = 1u << (idx & 31);
+        const uint32_t was = atomicOr(T.dense_bits + (idx >> 5), bit);
+        T.dense[idx] = row;
+        inserted = !(was & bit);
+      } else {
+        old = __hip_atomic_exchange(T.dense + idx, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        inserted = old == NIL;
+      }
     } else {
       const u64 s = ht_find_or_insert(T, kw, h, row, inserted);
       if (s == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
@@ -892,7 +902,12 @@ extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevPro
 
 // key lookup shared by the probes: chain head row of the key, or NIL
 __device__ __forceinline__ uint32_t join_lookup(const HashTable& T, const u64 (&kw)[MAX_KW], const u64 h) {
-  if (T.dense) { const u64 idx = kw[0] - (u64)T.dense_min; return idx < T.dense_range ? T.dense[idx] : NIL; }
+  if (T.dense) {
+    const u64 idx = kw[0] - (u64)T.dense_min;
+    if (idx >= T.dense_range) return NIL;
+    if (T.dense_bits && !((T.dense_bits[idx >> 5] >> (idx & 31)) & 1u)) return NIL;
+    return T.dense[idx];
+  }
   uint32_t payload;
   return ht_find(T, kw, h, payload) ? payload : NIL;
 }
@@ -1043,11 +1058,30 @@ __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, con
     uint32_t hit[U];
     if (dense) {
       // direct addressing: one load per row, all U in flight; neighbouring lanes with equal or adjacent keys share cache lines
+      const uint32_t* __restrict__ dbits = T.dense_bits;
+      if (dbits) {
+        // sparse domain: presence bits first (all U loads in flight), the row array only for the hits
+        uint32_t bw[U]; bool in[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const u64 idx = key[u] - (u64)T.dense_min;
-        hit[u] = NIL;
-        if (act[u] && !isn[u] && idx < T.dense_range) hit[u] = dense[idx];
+        for (int u = 0; u < U; ++u) {
+          const u64 idx = key[u] - (u64)T.dense_min;
+          in[u] = act[u] && !isn[u] && idx < T.dense_range;
+          bw[u] = 0;
+          if (in[u]) bw[u] = dbits[idx >> 5];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const u64 idx = key[u] - (u64)T.dense_min;
+          hit[u] = NIL;
+          if (in[u] && ((bw[u] >> (idx & 31)) & 1u)) hit[u] = dense[idx];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const u64 idx = key[u] - (u64)T.dense_min;
+          hit[u] = NIL;
+          if (act[u] && !isn[u] && idx < T.dense_range) hit[u] = dense[idx];
+        }
       }
     } else {
       // Neighbouring lanes with the same key (clustered foreign keys: the lines of one order) look the key up once: only the

@@ -67,6 +67,8 @@ KEYSETS = {
     "single_key": (lambda r: np.array([123456789], dtype=np.int64), lambda r: np.array([123456789, 5, 123456789, 123456790, 123456788], dtype=np.int64), pa.int64()),
     "int32_keys": (lambda r: r.permutation(np.arange(-300, 300)).astype(np.int32)[:400], lambda r: r.integers(-400, 400, 3000).astype(np.int32), pa.int32()),
     "duplicate_build_keys": (lambda r: r.integers(100, 400, 1500), lambda r: r.integers(0, 500, 4000), pa.int64()),                # chained probe over either layout
+    "sparse_domain_presence_bitmap": (lambda r: r.permutation(60_000)[:1500].astype(np.int64) - 30_000, lambda r: r.integers(-31_000, 31_000, 9000), pa.int64()),   # 1 value in 40 is a key
+    "sparse_domain_with_duplicates": (lambda r: r.integers(0, 60_000, 3000), lambda r: r.integers(-100, 60_100, 9000), pa.int64()),  # bitmap build finds duplicates -> rebuilt with chains
 }
 
 
