@@ -31,13 +31,16 @@ u64 next_pow2(u64 v) { u64 r = 1; while (r < v) r <<= 1; return r; }
 }  // namespace
 
 struct gpuq_ctx {
-  int device = 0; int cus = 256; size_t hbm = 0; std::string name, arch, last_error;
+  int device = 0; int cus = 256; size_t hbm = 0; std::string name, arch;
   int jit_mode = 1;                 // 0 off, 1 auto (inputs >= jit_min_rows), 2 force
   i64 jit_min_rows = 1ll << 21;
   std::string last_jit_error;       // auto mode: why the last specialisation fell back to the interpreter kernels
   int jit_launches = 0;
   int join_dense = 1;               // direct-addressed join tables for one narrow key of bounded range (gpuq_ctx_set_option "join_dense")
   i64 join_dense_ratio = 128;       // ... while range <= ratio x keys
+  int join_radix = 0;               // partitioned probe over a direct-addressed table: 0 off (default: measured 1.0-1.16x, pairs
+                                    // leave probe order -- DESIGN.md section 3), 1 auto, 2 force ("join_radix")
+  int join_radix_slice_log2 = 18;   // table entries per partition slice (2^18 x 4 B = 1 MiB: an XCD's L2 holds a few)
 };
 
 struct gpuq_timer { hipEvent_t a = nullptr, b = nullptr; };
@@ -90,7 +93,7 @@ struct gpuq_join_table {
 
 namespace {
 
-void set_err(gpuq_ctx* c, const std::string& m) { g_last_error = m; if (c) c->last_error = m; }
+void set_err(gpuq_ctx*, const std::string& m) { g_last_error = m; }      // per calling thread, like errno: contexts are shared between task threads
 
 template <class F> int guarded(gpuq_ctx* ctx, F&& f) {
   try { f(); return GPUQ_OK; }
@@ -554,7 +557,7 @@ gpuq_ctx* gpuq_ctx_create(int device_ordinal, const char* json_opts) {
   return c;
 }
 void gpuq_ctx_free(gpuq_ctx* ctx) { delete ctx; }
-const char* gpuq_last_error(gpuq_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+const char* gpuq_last_error(gpuq_ctx*) { return g_last_error.c_str(); }
 int gpuq_ctx_device_info(gpuq_ctx* ctx, char* buf, size_t cap) {
   return guarded(ctx, [&]() {
     check_ctx(ctx);
@@ -724,7 +727,7 @@ int gpuq_op_output_field(gpuq_op* op, int i, gpuq_field_info* out) {
 }
 int gpuq_op_check(gpuq_op* op, void* stream) {
   if (!op) return GPUQ_ERR_INVALID;
-  return guarded(op->ctx, [&]() { check_ctx(op->ctx); const uint32_t f = read_flags(op, (hipStream_t)stream); if (f) { reset_flags(op, (hipStream_t)stream); raise_flags(f); } });
+  return guarded(op->ctx, [&]() { check_ctx(op->ctx); const uint32_t f = read_flags(op, use_stream(stream)); if (f) { reset_flags(op, use_stream(stream)); raise_flags(f); } });
 }
 int gpuq_op_profile(gpuq_op* op, int enable, float* kernel_ms_out, int* launches_out) {
   if (!op) return GPUQ_ERR_INVALID;
@@ -742,7 +745,7 @@ int gpuq_filter_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload
   return guarded(op->ctx, [&]() {
     check_ctx(op->ctx);
     if (op->kind != K_FILTER) throw std::runtime_error("not a filter operator");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     if (payload_via < 0 || payload_via > in->n_via) throw std::runtime_error("payload_via out of range");
     const i64 n = in->n_rows;
@@ -767,7 +770,7 @@ int gpuq_project_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_colum
   return guarded(op->ctx, [&]() {
     check_ctx(op->ctx);
     if (op->kind != K_PROJECT) throw std::runtime_error("not a project operator");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     OutSpec O = make_outspec(op->prog, outs, n_outs, op->out_fields);
     for (int i = 0; i < n_outs; ++i) outs[i].length = in->n_rows;
@@ -782,7 +785,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
   return guarded(op->ctx, [&]() {
     check_ctx(op->ctx);
     if (op->kind != K_AGG) throw std::runtime_error("not an aggregate operator");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     const i64 n = in->n_rows;
     const int nk = op->agg.n_keys, na = op->agg.n_accs, kstride = nk > 0 ? nk : 1;
@@ -1024,6 +1027,22 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
 }
 
 // ---------------------------------------------------------------- join
+namespace {
+// Do neighbouring probe rows hit neighbouring table entries?  A strided sample of 64-row words; "local" when most adjacent
+// pairs of live rows are within 2^14 entries (64 KiB of table) of each other -- clustered / sorted foreign keys.
+bool probe_keys_local(gpuq_op* op, hipStream_t s, const DevProgram& P, i64 n, const HashTable& T) {
+  u64* c = (u64*)op->ws[7].ensure(32);
+  HIPCHECK(hipMemsetAsync(c, 0, 16, s));
+  const i64 nwords = (n + 63) >> 6;
+  const i64 nsample = std::min<i64>(nwords, 4096);
+  launch_join_locality(s, P, n, op->keys, T, nwords / nsample, nsample, c);
+  HIPCHECK(hipGetLastError());
+  u64 got[2] = {0, 0};
+  HIPCHECK(hipMemcpyAsync(got, c, 16, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  return got[0] == 0 || got[1] * 2 >= got[0];
+}
+}  // namespace
 int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, int64_t build_rows_bound, gpuq_join_table** out) {
   if (!op) return GPUQ_ERR_INVALID;
   gpuq_join_table* t = nullptr;
@@ -1031,7 +1050,7 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     check_ctx(op->ctx);
     if (op->kind != K_JOIN_BUILD) throw std::runtime_error("not a join_build operator");
     if (!out) throw std::runtime_error("out is NULL");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     if (payload_via < 0 || payload_via > in->n_via) throw std::runtime_error("payload_via out of range");
     const i64 n = in->n_rows;
@@ -1114,7 +1133,7 @@ int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpu
     if (!t || !count_out) throw std::runtime_error("table/count_out is NULL");
     if (op->keys.n_keys != t->keys.n_keys || op->keys.key_words != t->keys.key_words) throw std::runtime_error("probe keys do not match the build keys (count / width)");
     for (int k = 0; k < op->keys.n_keys; ++k) if (op->keys.key_wide[k] != t->keys.key_wide[k]) throw std::runtime_error("probe key " + std::to_string(k) + " width class differs from the build key; cast one side");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     if (payload_via < 0 || payload_via > in->n_via) throw std::runtime_error("payload_via out of range");
     const int jt = op->join_type;
@@ -1142,6 +1161,31 @@ int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpu
       uint32_t* seg_build = want_build ? (uint32_t*)op->ws[0].ensure((size_t)nwords * 256 + 16) : nullptr;
       uint32_t* seg_probe = (uint32_t*)op->ws[1].ensure((size_t)nwords * 256 + 16);
       uint32_t* counts = (uint32_t*)op->ws[2].ensure((size_t)nsegs * 4 + 16);
+      // Partitioned probe (kernels_hash.hip): pays when the table is beyond the caches AND the probe keys arrive in random
+      // order; the pairs then come out in partition order, so whatever reads probe-side columns through them gathers at random
+      // -- "auto" therefore asks for a big table, a big probe side and keys without locality (sampled), "force" is for measurements.
+      const int rjm = op->ctx->join_radix;
+      bool use_rj = rjm != 0 && t->T.dense && (jt == JT_INNER || jt == JT_RIGHT_SEMI) && n < (1ll << 31) && out_probe;
+      if (use_rj && rjm == 1) use_rj = n >= (1ll << 24) && t->T.dense_range * 4 >= ((u64)64 << 20) && !probe_keys_local(op, s, P, n, t->T);
+      if (use_rj) {
+        RjGeomHost g; rj_geometry(n, t->T.dense_range, op->ctx->join_radix_slice_log2, &g);
+        u64* rec = (u64*)op->ws[3].ensure((size_t)n * 8 + 16);
+        u64* rec2 = (u64*)op->ws[4].ensure((size_t)n * 8 + 16);
+        int32_t* hist = (int32_t*)op->ws[5].ensure(rj_hist_entries(g) * 4 + 16);
+        const size_t swb = exclusive_scan_ws_bytes((i64)rj_hist_entries(g));
+        void* sws = op->ws[6].ensure(swb);
+        i64 rwpw = 0; const int rblocks = rj_probe_geometry(n, &rwpw); const int rsegs = rblocks * 4;
+        if (want_build) seg_build = (uint32_t*)op->ws[0].ensure((size_t)rsegs * rwpw * 256 + 16);
+        seg_probe = (uint32_t*)op->ws[1].ensure((size_t)rsegs * rwpw * 256 + 16);
+        counts = (uint32_t*)op->ws[2].ensure((size_t)rsegs * 4 + 16);
+        JitScope js(op, op->prog, 15, n); ProfScope ps(op, s);
+        launch_rj_partition(s, P, n, op->keys, t->T, payload_via, g, rec, rec2, hist, sws, swb);
+        launch_rj_probe(s, rec2, hist + (size_t)g.nparts * g.nblocks, t->T, jt, seg_build, seg_probe, counts, rblocks, rwpw);
+        launch_scan_block_counts(s, counts, rsegs, (u64*)count_out);
+        launch_copy_segments(s, seg_build, seg_probe, counts, rsegs, rwpw, n, (const u64*)count_out, out_build, out_probe, out_cap, op->flags_dev.as<uint32_t>());
+        HIPCHECK(hipGetLastError());
+        return;
+      }
       std::string spec;
       if (op->keys.n_keys == 1 && op->keys.key_words == 1 && (t->T.slot_words == 2 || t->T.dense))     // one narrow key: 16-byte slots or direct addressing
         spec = "#define GPUQ_JIT_PROBE1 1\nconstexpr int JIT_KEY_REG0 = " + std::to_string(op->keys.key_reg[0]) + ";\n";
@@ -1163,7 +1207,7 @@ int gpuq_join_build_side_rows(gpuq_join_table* t, void* stream, int matched, uin
   if (!t) return GPUQ_ERR_INVALID;
   return guarded(t->ctx, [&]() {
     check_ctx(t->ctx);
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     const i64 n = t->bound;
     if (n == 0) { if (count_out) HIPCHECK(hipMemsetAsync(count_out, 0, 8, s)); return; }
     const size_t bm = ((size_t)n + 63) / 64 * 8 + 8;
@@ -1190,7 +1234,7 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
   return guarded(op->ctx, [&]() {
     check_ctx(op->ctx);
     if (op->kind != K_SORT) throw std::runtime_error("not a sort operator");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     const i64 n = in->n_rows;
     if (n == 0) return;
@@ -1271,7 +1315,7 @@ int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t
   return guarded(op->ctx, [&]() {
     check_ctx(op->ctx);
     if (op->kind != K_PARTITION) throw std::runtime_error("not a partition operator");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     const i64 n = in->n_rows;
     const uint32_t np = op->nparts;
@@ -1307,7 +1351,7 @@ int gpuq_concat_bitmap(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bi
     check_ctx(ctx);
     if (!dst || dst_bit_offset < 0 || n_bits < 0) throw std::runtime_error("bad arguments");
     if (((uintptr_t)dst & 7) != 0) throw std::runtime_error("dst bitmap must be 8-byte aligned");
-    launch_concat_bitmap((hipStream_t)stream, (u64*)dst, dst_bit_offset, src, 0, n_bits);
+    launch_concat_bitmap(use_stream(stream), (u64*)dst, dst_bit_offset, src, 0, n_bits);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -1316,7 +1360,7 @@ int gpuq_copy_bits(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_of
     check_ctx(ctx);
     if (!dst || dst_bit_offset < 0 || src_bit_offset < 0 || n_bits < 0) throw std::runtime_error("bad arguments");
     if (((uintptr_t)dst & 7) != 0) throw std::runtime_error("dst bitmap must be 8-byte aligned");
-    launch_concat_bitmap((hipStream_t)stream, (u64*)dst, dst_bit_offset, src, src_bit_offset, n_bits);
+    launch_concat_bitmap(use_stream(stream), (u64*)dst, dst_bit_offset, src, src_bit_offset, n_bits);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -1326,7 +1370,7 @@ int gpuq_take_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const ui
                    uint8_t* data_out, int64_t data_cap, int64_t* data_len_out) {
   return guarded(ctx, [&]() {
     check_ctx(ctx);
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     if (!col || n < 0 || !offsets_out) throw std::runtime_error("bad arguments");
     if (col->type != T_UTF8 || col->repr != GPUQ_REPR_ARROW || (!col->offsets && col->length > 0)) throw std::runtime_error("gpuq_take_utf8 takes an Arrow-layout Utf8 column (offsets + bytes)");
     if (validity_out && ((uintptr_t)validity_out & 7)) throw std::runtime_error("validity_out must be 8-byte aligned");
@@ -1351,7 +1395,7 @@ int gpuq_offsets_rebase(gpuq_ctx* ctx, void* stream, const int32_t* src, int64_t
   return guarded(ctx, [&]() {
     check_ctx(ctx);
     if (n < 0 || (n > 0 && (!src || !dst))) throw std::runtime_error("bad arguments");
-    launch_offsets_rebase((hipStream_t)stream, src, n, delta, dst);
+    launch_offsets_rebase(use_stream(stream), src, n, delta, dst);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -1360,7 +1404,7 @@ int gpuq_mark_rows(gpuq_ctx* ctx, void* stream, const uint32_t* rows, int64_t n,
   return guarded(ctx, [&]() {
     check_ctx(ctx);
     if (n < 0 || (n > 0 && (!rows || !bitmap))) throw std::runtime_error("bad arguments");
-    launch_mark_rows((hipStream_t)stream, rows, n, bitmap);
+    launch_mark_rows(use_stream(stream), rows, n, bitmap);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -1393,7 +1437,7 @@ int gpuq_like_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const ui
       else if (c == '_') push(256);
       else push((uint8_t)c);
     }
-    launch_like_utf8((hipStream_t)stream, (const uint8_t*)col->data, col->offsets, col->validity, idx, n, pat, negated ? 1 : 0, (u64*)bits_out, (u64*)validity_out);
+    launch_like_utf8(use_stream(stream), (const uint8_t*)col->data, col->offsets, col->validity, idx, n, pat, negated ? 1 : 0, (u64*)bits_out, (u64*)validity_out);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -1403,7 +1447,7 @@ int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n,
                      int64_t* data_len_out) {
   return guarded(ctx, [&]() {
     check_ctx(ctx);
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     if (n < 0 || !offsets_out) throw std::runtime_error("bad arguments");
     if (n == 0) { HIPCHECK(hipMemsetAsync(offsets_out, 0, 4, s)); if (data_len_out) *data_len_out = 0; return; }
     DevBuf ws; ws.ensure(exclusive_scan_ws_bytes(n));
@@ -1431,7 +1475,7 @@ int gpuq_gen_lineitem(gpuq_ctx* ctx, void* stream, uint64_t seed, uint64_t seed_
     if (!c || n < 0 || n_supp < 1) throw std::runtime_error("bad arguments");
     LineitemCols d{c->l_orderkey ? (i64*)c->l_orderkey : nullptr, (i64*)c->l_suppkey, (u64*)c->l_quantity, (u64*)c->l_extendedprice, (u64*)c->l_discount,
                    (u64*)c->l_tax, c->l_shipdate, c->l_returnflag, c->l_returnflag_off, c->l_linestatus, c->l_linestatus_off};
-    launch_gen_lineitem((hipStream_t)stream, seed, seed_orders, row0, n, n_supp, d);
+    launch_gen_lineitem(use_stream(stream), seed, seed_orders, row0, n, n_supp, d);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -1440,7 +1484,7 @@ int gpuq_gen_orders(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, in
     check_ctx(ctx);
     if (!c || n < 0 || n_cust < 3) throw std::runtime_error("bad arguments");
     OrdersCols d{(i64*)c->o_orderkey, (i64*)c->o_custkey, c->o_orderdate, c->o_shippriority};
-    launch_gen_orders((hipStream_t)stream, seed, row0, n, n_cust, d);
+    launch_gen_orders(use_stream(stream), seed, row0, n, n_cust, d);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -1449,7 +1493,7 @@ int gpuq_gen_customer(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, 
     check_ctx(ctx);
     if (!c || n < 0 || row0 % 5 != 0) throw std::runtime_error("bad arguments (row0 must be a multiple of 5)");
     CustomerCols d{(i64*)c->c_custkey, (i64*)c->c_nationkey, c->c_mktsegment, c->c_mktsegment_off};
-    launch_gen_customer((hipStream_t)stream, seed, row0, n, d);
+    launch_gen_customer(use_stream(stream), seed, row0, n, d);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -1458,7 +1502,7 @@ int gpuq_gen_supplier(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, 
     check_ctx(ctx);
     if (!c || n < 0) throw std::runtime_error("bad arguments");
     SupplierCols d{(i64*)c->s_suppkey, (i64*)c->s_nationkey};
-    launch_gen_supplier((hipStream_t)stream, seed, row0, n, d);
+    launch_gen_supplier(use_stream(stream), seed, row0, n, d);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -1528,10 +1572,10 @@ int gpuq_buffer_alloc(gpuq_ctx* ctx, size_t bytes, void** dev_out) {
 }
 int gpuq_buffer_free(gpuq_ctx* ctx, void* dev) { return guarded(ctx, [&]() { check_ctx(ctx); if (dev) HIPCHECK(hipFree(dev)); }); }
 int gpuq_copy_h2d(gpuq_ctx* ctx, void* stream, void* dst_dev, const void* src_host, size_t bytes) {
-  return guarded(ctx, [&]() { check_ctx(ctx); if (bytes) { g_staging.h2d((hipStream_t)stream, dst_dev, src_host, bytes); g_staging.drain(); } });
+  return guarded(ctx, [&]() { check_ctx(ctx); if (bytes) { g_staging.h2d(use_stream(stream), dst_dev, src_host, bytes); g_staging.drain(); } });
 }
 int gpuq_copy_d2h(gpuq_ctx* ctx, void* stream, void* dst_host, const void* src_dev, size_t bytes) {
-  return guarded(ctx, [&]() { check_ctx(ctx); if (bytes) { HIPCHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); HIPCHECK(hipStreamSynchronize((hipStream_t)stream)); } });
+  return guarded(ctx, [&]() { check_ctx(ctx); if (bytes) { HIPCHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, use_stream(stream))); HIPCHECK(hipStreamSynchronize(use_stream(stream))); } });
 }
 
 int gpuq_table_import_arrow(gpuq_ctx* ctx, void* stream, const struct ArrowArray* batch, const struct ArrowSchema* schema, gpuq_table** out) {
@@ -1541,7 +1585,7 @@ int gpuq_table_import_arrow(gpuq_ctx* ctx, void* stream, const struct ArrowArray
     if (!batch || !schema || !out) throw std::runtime_error("batch/schema/out is NULL");
     if (std::string(schema->format ? schema->format : "") != "+s") throw std::runtime_error("expected a struct-typed ArrowArray (RecordBatch)");
     if (batch->n_children != schema->n_children) throw std::runtime_error("array/schema children mismatch");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     t = new gpuq_table(); t->ctx = ctx; t->n_rows = batch->length;
     for (int64_t c = 0; c < batch->n_children; ++c) {
       const ArrowArray* a = batch->children[c]; const ArrowSchema* f = schema->children[c];
@@ -1604,7 +1648,7 @@ int gpuq_export_arrow(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, cons
   return guarded(ctx, [&]() {
     check_ctx(ctx);
     if (!cols || !fields || !out || !out_schema || n_cols < 0 || n_rows < 0) throw std::runtime_error("bad arguments");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     auto* P = new ExportPriv(); auto* S = new ExportSchemaPriv();
     std::unique_ptr<ExportPriv> gp(P); std::unique_ptr<ExportSchemaPriv> gs(S);
     P->kids.resize(n_cols); P->kid_bufs.resize(n_cols); S->kids.resize(n_cols); S->strs.reserve((size_t)n_cols * 2 + 2);
@@ -1625,7 +1669,7 @@ int gpuq_export_arrow(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, cons
           DevBuf offs, data; offs.ensure((size_t)(n_rows + 1) * 4 + 16); data.ensure((size_t)n_rows * 15 + 16);
           int64_t dl = 0;
           int rc2 = gpuq_unpack_utf8(ctx, stream, col.data, n_rows, (int32_t*)offs.p, (uint8_t*)data.p, n_rows * 15 + 16, &dl);
-          if (rc2 != GPUQ_OK) throw std::runtime_error(ctx->last_error);
+          if (rc2 != GPUQ_OK) throw std::runtime_error(g_last_error);
           b.push_back(fetch(offs.p, (size_t)(n_rows + 1) * 4)); b.push_back(fetch(data.p, (size_t)dl));
           HIPCHECK(hipStreamSynchronize(s));
         } else {
@@ -1671,6 +1715,8 @@ int gpuq_ctx_set_option(gpuq_ctx* ctx, const char* key, const char* value) {
     if (!ctx || !key || !value) throw std::runtime_error("ctx/key/value is NULL");
     const std::string k = key;
     if (k == "join_dense") ctx->join_dense = std::atoi(value) != 0;
+    else if (k == "join_radix") { const std::string v = value; ctx->join_radix = v == "off" || v == "0" ? 0 : (v == "force" || v == "2" ? 2 : 1); }
+    else if (k == "join_radix_slice_log2") { const int b = std::atoi(value); if (b < 10 || b > 26) throw std::runtime_error("join_radix_slice_log2 must be in [10, 26]"); ctx->join_radix_slice_log2 = b; }
     else if (k == "join_dense_ratio") { const long long r = std::atoll(value); if (r < 1) throw std::runtime_error("join_dense_ratio must be >= 1"); ctx->join_dense_ratio = r; }
     else throw std::runtime_error("unknown option '" + k + "'");
   });
@@ -1696,8 +1742,8 @@ int gpuq_op_jit_source(gpuq_op* op, int kernel_id, char* buf, size_t cap) {
 int gpuq_timer_create(gpuq_ctx* ctx, gpuq_timer** out) {
   return guarded(ctx, [&]() { check_ctx(ctx); auto* t = new gpuq_timer(); HIPCHECK(hipEventCreate(&t->a)); HIPCHECK(hipEventCreate(&t->b)); *out = t; });
 }
-int gpuq_timer_start(gpuq_timer* t, void* stream) { return guarded(nullptr, [&]() { HIPCHECK(hipEventRecord(t->a, (hipStream_t)stream)); }); }
-int gpuq_timer_stop(gpuq_timer* t, void* stream) { return guarded(nullptr, [&]() { HIPCHECK(hipEventRecord(t->b, (hipStream_t)stream)); }); }
+int gpuq_timer_start(gpuq_timer* t, void* stream) { return guarded(nullptr, [&]() { HIPCHECK(hipEventRecord(t->a, use_stream(stream))); }); }
+int gpuq_timer_stop(gpuq_timer* t, void* stream) { return guarded(nullptr, [&]() { HIPCHECK(hipEventRecord(t->b, use_stream(stream))); }); }
 int gpuq_timer_elapsed_ms(gpuq_timer* t, float* ms_out) {
   return guarded(nullptr, [&]() { HIPCHECK(hipEventSynchronize(t->b)); HIPCHECK(hipEventElapsedTime(ms_out, t->a, t->b)); });
 }

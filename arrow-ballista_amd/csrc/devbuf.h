@@ -19,43 +19,73 @@ struct Capacity : std::runtime_error { using std::runtime_error::runtime_error; 
     if (_e != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e));             \
   } while (0)
 
+// The stream the calling thread is currently queueing work on.  Every C entry point that takes a stream sets it first
+// (use_stream); DevBuf remembers the stream it was last (re)allocated under, and the pool orders a block's next user behind
+// its previous one when the two differ.
+inline hipStream_t& tls_stream() { thread_local hipStream_t s = nullptr; return s; }
+inline hipStream_t use_stream(void* s) { tls_stream() = (hipStream_t)s; return (hipStream_t)s; }
+
 // Device allocations are recycled through a process-wide pool: hipMalloc + hipFree of a join table cost ~0.55 ms per join
 // (a q5 run builds five), more than most of the kernels around them.  A released block is handed to the next request it
-// fits (cap within 2x).  Reuse relies on stream order: all calls of a context are issued on one stream (or are ordered
-// by the caller), so whoever reuses a block is queued behind the kernels that last touched it.
+// fits (cap within 2x).  A block released under stream A carries an event recorded on A at release time; a taker on the same
+// stream relies on stream order, a taker on ANY OTHER stream (another host thread running its own task on the device, as the
+// reference's task-runner pool does: cpu_bound_executor.rs:94-131) first makes its stream wait for that event, so kernels of
+// the previous owner that are still in flight finish before the new owner's first kernel touches the block.
 struct DevPool {
-  struct Blk { void* p; size_t cap; int dev; };
-  std::mutex mu; std::vector<Blk> free_; size_t held = 0;
+  struct Blk { void* p; size_t cap; int dev; hipStream_t st; hipEvent_t ev; };
+  std::mutex mu; std::vector<Blk> free_; std::vector<hipEvent_t> events_; size_t held = 0;
   static DevPool& get() { static DevPool* P = new DevPool(); return *P; }      // leaked on purpose: no hipFree at process exit
   void* take(size_t bytes, size_t* cap_out) {
     int dev = 0; (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(mu);
-    int best = -1;
-    for (size_t i = 0; i < free_.size(); ++i)
-      if (free_[i].dev == dev && free_[i].cap >= bytes && free_[i].cap <= 2 * bytes + (1u << 20) && (best < 0 || free_[i].cap < free_[(size_t)best].cap)) best = (int)i;
-    if (best < 0) return nullptr;
-    Blk b = free_[(size_t)best]; free_.erase(free_.begin() + best); held -= b.cap; *cap_out = b.cap; return b.p;
+    Blk b{};
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      int best = -1;
+      for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i].dev == dev && free_[i].cap >= bytes && free_[i].cap <= 2 * bytes + (1u << 20) && (best < 0 || free_[i].cap < free_[(size_t)best].cap)) best = (int)i;
+      if (best < 0) return nullptr;
+      b = free_[(size_t)best]; free_.erase(free_.begin() + best); held -= b.cap;
+    }
+    if (b.ev) {
+      const hipStream_t cur = tls_stream();
+      if (b.st != cur && hipEventQuery(b.ev) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipStreamWaitEvent(cur, b.ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(b.ev); }
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      events_.push_back(b.ev);      // an event that is waited on keeps the recorded state until it is recorded again
+    }
+    *cap_out = b.cap; return b.p;
   }
-  void give(void* p, size_t cap) {
+  void give(void* p, size_t cap, hipStream_t st) {
     int dev = 0; (void)hipGetDevice(&dev);
+    hipEvent_t ev = nullptr;
+    { std::lock_guard<std::mutex> lk(mu); if (!events_.empty()) { ev = events_.back(); events_.pop_back(); } }
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+    if (ev && hipEventRecord(ev, st) != hipSuccess) {      // e.g. the caller destroyed the stream: nothing can be in flight on it any more
+      (void)hipGetLastError();
+      std::lock_guard<std::mutex> lk(mu); events_.push_back(ev); ev = nullptr;
+    }
     { std::lock_guard<std::mutex> lk(mu);
-      if (held + cap <= (size_t)24 << 30 && free_.size() < 256) { free_.push_back({p, cap, dev}); held += cap; return; } }
-    (void)hipFree(p);
+      if (held + cap <= (size_t)24 << 30 && free_.size() < 256) { free_.push_back({p, cap, dev, st, ev}); held += cap; return; }
+      if (ev) events_.push_back(ev); }
+    (void)hipFree(p);      // synchronises with the device
   }
   void trim() {      // out of memory somewhere: give everything back and let the caller retry
-    std::vector<Blk> v; { std::lock_guard<std::mutex> lk(mu); v.swap(free_); held = 0; }
+    std::vector<Blk> v; { std::lock_guard<std::mutex> lk(mu); v.swap(free_); held = 0; for (auto& b : v) if (b.ev) events_.push_back(b.ev); }
     for (auto& b : v) (void)hipFree(b.p);
   }
 };
 
 struct DevBuf {
-  void* p = nullptr; size_t cap = 0;
+  void* p = nullptr; size_t cap = 0; hipStream_t st = nullptr;      // st: the stream of the thread that last (re)allocated or touched the buffer
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) DevPool::get().give(p, cap); }
+  ~DevBuf() { if (p) DevPool::get().give(p, cap, st); }
   void* ensure(size_t bytes) {
+    st = tls_stream();
     if (bytes > cap) {
-      if (p) { DevPool::get().give(p, cap); p = nullptr; cap = 0; }
+      if (p) { DevPool::get().give(p, cap, st); p = nullptr; cap = 0; }
       size_t want = bytes < 256 ? 256 : bytes;
       p = DevPool::get().take(want, &cap);
       if (!p) {

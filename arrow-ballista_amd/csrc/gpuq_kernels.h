@@ -140,6 +140,17 @@ void launch_join_probe_unique(hipStream_t s, const DevProgram& P, i64 n, const K
                               uint32_t* seg_build, uint32_t* seg_probe, uint32_t* seg_counts, int nsegs, i64 wpw, uint32_t* visited);
 void launch_copy_segments(hipStream_t s, const uint32_t* seg_build, const uint32_t* seg_probe, const uint32_t* seg_offsets, int nsegs, i64 wpw, i64 n,
                           const u64* total, uint32_t* out_build, uint32_t* out_probe, u64 out_cap, uint32_t* flags);
+// partitioned probe over a direct-addressed table (kernels_hash.hip): records = (table index << 32 | probe row), one scatter pass on
+// the high index bits; offsets of the dropped-rows digit (hist[nparts * nblocks]) = number of live records after the scan
+void launch_join_locality(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, i64 stride, i64 nsample, u64* out);
+struct RjGeomHost { uint32_t nparts, shift; i64 tile; int32_t nblocks; };
+void rj_geometry(i64 n, u64 range, int slice_log2, RjGeomHost* g);
+size_t rj_hist_entries(const RjGeomHost& g);
+void launch_rj_partition(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int payload_via, const RjGeomHost& g,
+                         u64* rec, u64* rec_out, int32_t* hist, void* scan_ws, size_t scan_ws_bytes);
+int rj_probe_geometry(i64 n, i64* wpw_out);
+void launch_rj_probe(hipStream_t s, const u64* rec, const int32_t* n_live, const HashTable& T, int join_type, uint32_t* seg_build, uint32_t* seg_probe,
+                     uint32_t* seg_counts, int nblocks, i64 wpw);
 void launch_bitmap_select(hipStream_t s, const u64* present, const u64* visited, int matched, i64 nwords, i64 n, u64* bitmap,
                           uint32_t* block_counts, int nblocks, i64 wpb);
 void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, const uint32_t* next,

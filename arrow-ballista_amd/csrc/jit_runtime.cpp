@@ -59,7 +59,7 @@ Rtc& rtc() {
 }
 const char* file_of(int kernel_id) {
   if (kernel_id >= 1 && kernel_id <= 3) return "kernels_scan.hip";
-  if ((kernel_id >= 4 && kernel_id <= 7) || (kernel_id >= 11 && kernel_id <= 14)) return "kernels_hash.hip";
+  if ((kernel_id >= 4 && kernel_id <= 7) || (kernel_id >= 11 && kernel_id <= 15)) return "kernels_hash.hip";
   if (kernel_id >= 8 && kernel_id <= 10) return "kernels_sort.hip";
   throw std::runtime_error("jit: bad kernel id");
 }
@@ -87,8 +87,8 @@ static std::string env_defines() {
 static const char* jit_entry_name(int kernel_id) {
   static const char* n[] = {"gpuq_jit_entry", "gpuq_jit_filter_bitmap", "gpuq_jit_project", "gpuq_jit_agg_tiny", "gpuq_jit_agg_hash", "gpuq_jit_join_build",
                             "gpuq_jit_join_probe", "gpuq_jit_join_probe_unique", "gpuq_jit_sort_minmax", "gpuq_jit_sort_pack", "gpuq_jit_part_pid",
-                            "gpuq_jit_agg_bucket_id", "gpuq_jit_agg_bucket", "gpuq_jit_agg_lds", "gpuq_jit_join_keyrange"};
-  return (kernel_id >= 1 && kernel_id <= 14) ? n[kernel_id] : n[0];
+                            "gpuq_jit_agg_bucket_id", "gpuq_jit_agg_bucket", "gpuq_jit_agg_lds", "gpuq_jit_join_keyrange", "gpuq_jit_rj_pack"};
+  return (kernel_id >= 1 && kernel_id <= 15) ? n[kernel_id] : n[0];
 }
 
 std::string jit_full_source(const std::string& eval_src, int kernel_id) {

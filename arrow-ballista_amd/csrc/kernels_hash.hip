@@ -847,14 +847,17 @@ __device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 
     bool active = pos < n;
     GPUQ_REGS_DECL;
     if (active) active = GPUQ_EVAL(MAXC, P, pos);
+    // `present` = every build-side row that passes the side's predicate, NULL keys included (outer joins emit them).  When rows
+    // are positions, the 64 rows of this step ARE word w of the bitmap: one plain 8-byte store (64 lanes OR-ing into two words
+    // serialise in the L2's atomic unit -- it was most of the build's time: 1.4 ms for 14.6 M rows)
+    if (present && payload_via == 0) { const u64 am = __ballot(active); if (hlane() == 0) ((u64*)present)[w] = am; }
     if (!active) continue;
     u64 kw[MAX_KW]; u64 h;
 #pragma unroll
     for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
     const bool any_null = make_key(K, GPUQ_REGS, kw, h);
     uint32_t row = (uint32_t)pos;
-    if (payload_via > 0) row = P.via[payload_via - 1][pos];
-    if (present) atomicOr(&present[row >> 5], 1u << (row & 31));   // every build-side row, NULL keys included (outer joins emit them)
+    if (payload_via > 0) { row = P.via[payload_via - 1][pos]; if (present) atomicOr(&present[row >> 5], 1u << (row & 31)); }
     if (any_null && !null_eq) continue;   // a NULL key never matches (SQL equi-join)
     bool inserted; uint32_t old = NIL;
     if (T.dense) {
@@ -1210,6 +1213,184 @@ __global__ void __launch_bounds__(HBLOCK) k_copy_segments(const uint32_t* __rest
 }
 #endif
 
+// ------------------------------------------------------------------ partitioned probe (radix join over a direct-addressed table)
+// A probe side whose keys arrive in random order touches one random cache line of the table per row; beyond the Infinity
+// Cache every such touch moves a whole line across the fabric (measured: 2^28 probes of a 2^24-key table = 19.8 GB of fetches
+// for 9.7 GB of algorithmic traffic, 42 G probes/s whatever the table layout).  The partitioned probe makes the accesses
+// local instead: the probe rows are range-partitioned on the HIGH bits of (key - min) with ONE LDS-staged scatter pass
+// (records of 8 bytes: table index << 32 | probe row), so that the records of one partition hit one slice of the table
+// small enough for an XCD's L2; the lookups then run over the partition-ordered records with the segments dealt to the
+// XCDs in contiguous runs (blocks that share an XCD work on neighbouring records, i.e. on the same slice).  The build side
+// needs no partitioning at all: slice p of the direct-addressed table IS partition p's table.
+//   k_rj_pack      rows -> records (front-end: predicate, key, range check) + per-block histogram of the partition digits
+//   k_rj_scatter   one pass: tile sorted by digit in LDS (LDS atomics give the ranks; order inside a partition is free),
+//                  runs written to consecutive addresses
+//   k_rj_probe     records -> pairs, per-wave segments as in the direct probe
+// Pair order is partition order, not probe order (DataFusion's is unspecified across batches); Inner / RightSemi only.
+constexpr uint32_t RJ_MAX_PARTS = 1024;
+constexpr int RJ_TILE = 4096;                 // records sorted in LDS per step: 32 KB
+constexpr int RJ_ROUNDS = RJ_TILE / HBLOCK;
+constexpr u64 RJ_DROPPED = ~0ull;             // a row that cannot match (predicate, NULL key, key outside the table's range)
+struct RjGeom { uint32_t nparts; uint32_t shift; i64 tile; int32_t nblocks; int32_t pad; };      // digit = index >> shift; digit nparts = dropped rows
+
+template <int MAXC>
+__device__ __forceinline__ void k_rj_pack_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T, const int payload_via, const RjGeom G,
+                                                   u64* __restrict__ rec, int32_t* __restrict__ hist) {
+  __shared__ uint32_t lcnt[RJ_MAX_PARTS + 1];
+  for (uint32_t d = threadIdx.x; d <= G.nparts; d += HBLOCK) lcnt[d] = 0;
+  __syncthreads();
+  const int kr = __builtin_amdgcn_readfirstlane(K.key_reg[0]);
+  const i64 a = (i64)blockIdx.x * G.tile;
+  i64 b = a + G.tile; if (b > n) b = n;
+  for (i64 p0 = a + (i64)hwave() * 64; p0 < b; p0 += HBLOCK) {
+    const i64 pos = p0 + hlane();
+    bool active = pos < b;
+    GPUQ_REGS_DECL;
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
+    u64 r = RJ_DROPPED; uint32_t d = G.nparts;
+    if (active && !((rnulls >> kr) & 1)) {
+      const u64 idx = rlo[kr] - (u64)T.dense_min;
+      if (idx < T.dense_range) {
+        uint32_t prow = (uint32_t)pos;
+        if (payload_via > 0) prow = P.via[payload_via - 1][pos];
+        r = (idx << 32) | prow; d = (uint32_t)(idx >> G.shift);
+      }
+    }
+    if (pos < b) { rec[pos] = r; atomicAdd(&lcnt[d], 1u); }
+  }
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d <= G.nparts; d += HBLOCK) hist[(size_t)d * G.nblocks + blockIdx.x] = (int32_t)lcnt[d];
+}
+#ifndef GPUQ_JIT
+template <int MAXC>
+__global__ void __launch_bounds__(HBLOCK) k_rj_pack(const DevProgram P, const i64 n, const KeySpec K, const HashTable T, const int payload_via, const RjGeom G,
+                                                    u64* __restrict__ rec, int32_t* __restrict__ hist) { k_rj_pack_body<MAXC>(P, n, K, T, payload_via, G, rec, hist); }
+#elif GPUQ_JIT_KERNEL == 15
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const HashTable T, const int payload_via, const RjGeom G,
+                                                    u64* __restrict__ rec, int32_t* __restrict__ hist) { k_rj_pack_body<0>(P, n, K, T, payload_via, G, rec, hist); }
+#endif
+
+#ifndef GPUQ_JIT
+__device__ __forceinline__ uint32_t rj_digit(const u64 r, const RjGeom& G) { return r == RJ_DROPPED ? G.nparts : (uint32_t)(r >> (32 + G.shift)); }
+// offsets: exclusive scan of hist ([digit][block]); dropped rows (digit nparts) are not written
+__global__ void __launch_bounds__(HBLOCK) k_rj_scatter(const u64* __restrict__ rec, const i64 n, const RjGeom G, const int32_t* __restrict__ offsets, u64* __restrict__ out) {
+  __shared__ u64 sk[RJ_TILE];
+  __shared__ uint32_t lcnt[RJ_MAX_PARTS + 1];     // records of the digit in this step, then the digit's first slot in sk
+  __shared__ uint32_t gbase[RJ_MAX_PARTS + 1];    // global position of the digit's next record
+  __shared__ uint32_t wsum[HWAVES];
+  const int t = threadIdx.x, l = hlane(), w = hwave();
+  const uint32_t D = G.nparts;                    // digits 0..D-1 are written; digit D (dropped) is counted and skipped
+  for (uint32_t d = t; d <= D; d += HBLOCK) gbase[d] = (uint32_t)offsets[(size_t)d * G.nblocks + blockIdx.x];
+  const uint32_t per = (D + 1 + HBLOCK - 1) / HBLOCK;       // digits per thread in the scan (<= 5)
+  const i64 a = (i64)blockIdx.x * G.tile;
+  i64 b = a + G.tile; if (b > n) b = n;
+  for (i64 s0 = a; s0 < b; s0 += RJ_TILE) {
+    for (uint32_t d = t; d <= D; d += HBLOCK) lcnt[d] = 0;
+    __syncthreads();
+    u64 r[RJ_ROUNDS]; uint32_t rank[RJ_ROUNDS];
+#pragma unroll
+    for (int q = 0; q < RJ_ROUNDS; ++q) { const i64 i = s0 + q * HBLOCK + t; r[q] = i < b ? rec[i] : RJ_DROPPED; }
+#pragma unroll
+    for (int q = 0; q < RJ_ROUNDS; ++q) { const i64 i = s0 + q * HBLOCK + t; rank[q] = 0; if (i < b) rank[q] = atomicAdd(&lcnt[rj_digit(r[q], G)], 1u); }
+    __syncthreads();
+    // exclusive scan of the digit counts (thread t owns digits [t*per, t*per + per))
+    uint32_t c[5]; uint32_t tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 5; ++k) { const uint32_t d = t * per + k; c[k] = (k < per && d <= D) ? lcnt[d] : 0; tot += c[k]; }
+    uint32_t x = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (l >= off) x += y; }
+    if (l == 63) wsum[w] = x;
+    __syncthreads();
+    uint32_t pre = 0;
+#pragma unroll
+    for (int q = 0; q < HWAVES; ++q) if (q < w) pre += wsum[q];
+    uint32_t run = pre + x - tot;
+#pragma unroll
+    for (uint32_t k = 0; k < 5; ++k) { const uint32_t d = t * per + k; if (k < per && d <= D) { lcnt[d] = run; run += c[k]; } }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RJ_ROUNDS; ++q) { const i64 i = s0 + q * HBLOCK + t; if (i < b) sk[lcnt[rj_digit(r[q], G)] + rank[q]] = r[q]; }
+    __syncthreads();
+    const uint32_t cnt = (uint32_t)((b - s0) < RJ_TILE ? (b - s0) : RJ_TILE);
+    const uint32_t live = lcnt[D];                // dropped records sort last: slots [live, cnt) are skipped
+    for (uint32_t j = t; j < live; j += HBLOCK) {
+      const u64 v = sk[j];
+      const uint32_t d = rj_digit(v, G);
+      out[gbase[d] + (j - lcnt[d])] = v;
+    }
+    __syncthreads();
+    for (uint32_t d = t; d <= D; d += HBLOCK) { const uint32_t nxt = d < D ? lcnt[d + 1] : cnt; gbase[d] += nxt - lcnt[d]; }
+    __syncthreads();
+  }
+}
+
+// XCD-aware work order.  Blocks b, b+8, b+16, ... share an XCD (observed round-robin placement; speed only, any placement is
+// correct).  Group x = blockIdx % 8 owns the x-th eighth of the records, and ALL waves of the group stride through that
+// eighth together, 256 records per wave and step, so that at any moment the group's waves read neighbouring records, i.e. hit
+// the same table slice, and the slice stays in the group's L2.  (Giving every wave its own contiguous segment, as the direct
+// probe does, puts ~1000 segments = tens of slices in flight per XCD: 2.3 / 4.3 ms for 2^28 records over 2^24 / 2^27 keys.)
+// The grid is sized to what is resident at once (host side); a wave's pairs go to its own scratch segment of `wpw` words.
+__global__ void __launch_bounds__(HBLOCK) k_rj_probe(const u64* __restrict__ rec, const int32_t* __restrict__ n_live_p, const HashTable T, const int join_type,
+                                                     uint32_t* __restrict__ seg_build, uint32_t* __restrict__ seg_probe, uint32_t* __restrict__ seg_counts,
+                                                     const int nsegs, const i64 wpw) {
+  constexpr int U = 4;
+  const i64 seg = (i64)blockIdx.x * HWAVES + hwave();
+  if (seg >= nsegs) return;
+  const i64 n = (i64)*n_live_p;
+  const i64 nwords = (n + 63) >> 6;
+  const i64 x = blockIdx.x % 8, nbx = ((i64)gridDim.x - x + 7) / 8;          // blocks of this group
+  const i64 g0 = nwords * x / 8, g1 = nwords * (x + 1) / 8;                   // the group's words
+  const i64 nwx = nbx * HWAVES, wl = (i64)(blockIdx.x / 8) * HWAVES + hwave();  // waves of the group, this wave's index among them
+  const u64 seg_base = (u64)(seg * wpw) << 6;
+  const uint32_t* __restrict__ dense = T.dense; const uint32_t* __restrict__ dbits = T.dense_bits;
+  uint32_t cnt = 0;
+  for (i64 wb = g0 + wl * U; wb < g1; wb += nwx * U) {
+    u64 r[U]; bool act[U]; uint32_t hit[U]; uint32_t bw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const i64 pos = ((wb + u) << 6) + hlane(); act[u] = (wb + u) < g1 && pos < n; r[u] = act[u] ? rec[pos] : 0; }
+    if (dbits) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const u64 idx = r[u] >> 32; bw[u] = act[u] ? dbits[idx >> 5] : 0u; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const u64 idx = r[u] >> 32; hit[u] = NIL; if (act[u] && ((bw[u] >> (idx & 31)) & 1u)) hit[u] = dense[idx]; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) { hit[u] = NIL; if (act[u]) hit[u] = dense[r[u] >> 32]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) cnt += emit_pairs(act[u] && hit[u] != NIL, hit[u], (uint32_t)r[u], seg_base, cnt, join_type == JT_RIGHT_SEMI ? nullptr : seg_build, seg_probe);
+  }
+  if (hlane() == 0) seg_counts[seg] = cnt;
+}
+#endif
+
+#ifndef GPUQ_JIT
+// sample of the probe side's key locality: out[0] += adjacent pairs of live rows, out[1] += those within 2^14 table entries
+template <int MAXC>
+__global__ void __launch_bounds__(HBLOCK) k_join_locality(const DevProgram P, const i64 n, const KeySpec K, const HashTable T, const i64 stride, const i64 nsample,
+                                                          u64* __restrict__ out) {
+  const int kr = __builtin_amdgcn_readfirstlane(K.key_reg[0]);
+  u64 pairs = 0, near = 0;
+  for (i64 sidx = (i64)blockIdx.x * HWAVES + hwave(); sidx < nsample; sidx += (i64)gridDim.x * HWAVES) {
+    const i64 pos = ((sidx * stride) << 6) + hlane();
+    bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
+    active = active && !((rnulls >> kr) & 1);
+    const u64 idx = active ? rlo[kr] - (u64)T.dense_min : 0;
+    active = active && idx < T.dense_range;
+    const u64 nidx = __shfl_down(idx, 1);
+    const int nact = __shfl_down((int)active, 1);
+    const bool pair = active && nact && hlane() < 63;
+    const u64 d = nidx > idx ? nidx - idx : idx - nidx;
+    pairs += (u64)__popcll(__ballot(pair));
+    near += (u64)__popcll(__ballot(pair && d < (1ull << 14)));
+  }
+  if (hlane() == 0 && pairs) { atomicAdd((unsigned long long*)out, (unsigned long long)pairs); atomicAdd((unsigned long long*)out + 1, (unsigned long long)near); }
+}
+#endif
+
 #ifndef GPUQ_JIT
 // ------------------------------------------------------------------ launchers
 static int hgrid(i64 n, int blocks_per_cu) {
@@ -1377,6 +1558,53 @@ void launch_copy_segments(hipStream_t s, const uint32_t* seg_build, const uint32
   i64 need = ((i64)nsegs + HWAVES - 1) / HWAVES; const i64 cap = (i64)num_cus() * 8;
   hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)(need < cap ? (need ? need : 1) : cap)), dim3(HBLOCK), 0, s, seg_build, seg_probe, seg_offsets, nsegs, wpw, total,
                      out_build, out_probe, out_cap, flags);
+}
+
+void launch_join_locality(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, i64 stride, i64 nsample, u64* out) {
+  if (n <= 0 || nsample <= 0) return;
+  const int grid = (int)std::min<i64>((nsample + HWAVES - 1) / HWAVES, (i64)num_cus() * 4);
+#define CALL(M) hipLaunchKernelGGL(k_join_locality<M>, dim3(grid), dim3(HBLOCK), 0, s, P, n, K, T, stride < 1 ? 1 : stride, nsample, out)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
+}
+// ---- partitioned probe
+void rj_geometry(i64 n, u64 range, int slice_log2, RjGeomHost* g) {
+  // slices of 2^slice_log2 table entries, at most RJ_MAX_PARTS of them
+  int sh = slice_log2; while (((range + ((1ull << sh) - 1)) >> sh) > RJ_MAX_PARTS) ++sh;
+  g->shift = (uint32_t)sh; g->nparts = (uint32_t)((range + ((1ull << sh) - 1)) >> sh);
+  i64 t = RJ_TILE; const i64 maxb = (i64)num_cus() * 8;
+  while ((n + t - 1) / t > maxb) t += RJ_TILE;
+  g->tile = t; g->nblocks = (int32_t)((n + t - 1) / t); if (g->nblocks < 1) g->nblocks = 1;
+}
+size_t rj_hist_entries(const RjGeomHost& g) { return (size_t)(g.nparts + 1) * g.nblocks + 1; }
+void launch_rj_partition(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, int payload_via, const RjGeomHost& g,
+                         u64* rec, u64* rec_out, int32_t* hist, void* scan_ws, size_t scan_ws_bytes) {
+  RjGeom G{g.nparts, g.shift, g.tile, g.nblocks, 0};
+  if (jit_override().fn && jit_override().kernel_id == 15) {
+    (void)jit_launch(jit_override().fn, dim3(g.nblocks), dim3(HBLOCK), 0, s, P, n, K, T, payload_via, G, rec, hist);
+  } else {
+#define CALL(M) hipLaunchKernelGGL(k_rj_pack<M>, dim3(g.nblocks), dim3(HBLOCK), 0, s, P, n, K, T, payload_via, G, rec, hist)
+  GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
+#undef CALL
+  }
+  launch_exclusive_scan_i32(s, hist, (i64)(g.nparts + 1) * g.nblocks, scan_ws, scan_ws_bytes);
+  hipLaunchKernelGGL(k_rj_scatter, dim3(g.nblocks), dim3(HBLOCK), 0, s, (const u64*)rec, n, G, (const int32_t*)hist, rec_out);
+}
+// grid = what is resident at once (the group's waves must advance together); *wpw_out = scratch words per wave
+int rj_probe_geometry(i64 n, i64* wpw_out) {
+  const i64 nwords = (n + 63) >> 6;
+  i64 nblocks = (i64)num_cus() * 6;                    // 6 blocks of 256 threads per CU fit the kernel's registers / SGPRs
+  const i64 need = (nwords + 4 * HWAVES - 1) / (4 * HWAVES);
+  if (nblocks > need) nblocks = need < 8 ? 8 : need;
+  const i64 nbx_min = nblocks / 8 > 0 ? nblocks / 8 : 1;                       // smallest group
+  const i64 gw = nwords / 8 + 1;                                                // words of the largest group
+  const i64 steps = (gw + nbx_min * HWAVES * 4 - 1) / (nbx_min * HWAVES * 4);   // 4 words per wave and step
+  *wpw_out = steps * 4;
+  return (int)nblocks;
+}
+void launch_rj_probe(hipStream_t s, const u64* rec, const int32_t* n_live, const HashTable& T, int join_type, uint32_t* seg_build, uint32_t* seg_probe,
+                     uint32_t* seg_counts, int nblocks, i64 wpw) {
+  hipLaunchKernelGGL(k_rj_probe, dim3(nblocks), dim3(HBLOCK), 0, s, rec, n_live, T, join_type, seg_build, seg_probe, seg_counts, nblocks * HWAVES, wpw);
 }
 
 #endif  // GPUQ_JIT

@@ -1205,6 +1205,7 @@ int gpuq_plan_execute(gpuq_plan* p, void* stream, int partition, const gpuq_inpu
   *out = nullptr;
   return plan_guarded([&]() {
     if (!p->pin) HIPCHECK(hipHostMalloc((void**)&p->pin, 64, hipHostMallocDefault));
+    (void)use_stream(stream);
     Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin; x.memo = &p->memo;
     PTable t = materialize(x, p->root->execute(partition, x));
     HIPCHECK(hipStreamSynchronize((hipStream_t)stream));

@@ -272,7 +272,7 @@ int gpuq_ipc_encode_batch(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, 
     if (!ctx) throw std::runtime_error("ctx is NULL");
     if (!cols && n_cols > 0) throw std::runtime_error("cols is NULL");
     if (codec != -1 && codec != 0) throw Unsupported("IPC body compression codec " + std::to_string(codec) + " (only LZ4_FRAME = 0 or none = -1)");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     BatchMeta meta; meta.header_type = 3; meta.codec = codec; meta.n_rows = n_rows;
     // ---- the Arrow buffers of every column, in IPC order (validity, [offsets], data)
     std::vector<SrcBuf> bufs;
@@ -411,7 +411,7 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
   int rc = guarded_ipc([&]() {
     if (!ctx) throw std::runtime_error("ctx is NULL");
     if (!bytes || !out || (!fields && n_cols > 0)) throw std::runtime_error("bytes/fields/out is NULL");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = use_stream(stream);
     // ---- host pass over the message headers
     struct Msg { BatchMeta m; int64_t body; int64_t row0; };
     std::vector<Msg> msgs;

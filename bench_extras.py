@@ -421,9 +421,15 @@ if __name__ == "__main__":
         print(json.dumps(cpu_proxy_acero(T, sf), indent=1))
         sys.exit(0)
     tc = g.TaskContext(device=0)
-    if "--probe-micro" in sys.argv:      # the probe kernels alone (for rocprofv3 --pmc passes): --probe-micro 24 27
+    if "--probe-micro" in sys.argv:      # the probe kernels alone (for rocprofv3 --pmc passes): --probe-micro 24 27 [--radix off|force|auto] [--slice N]
         i = sys.argv.index("--probe-micro")
-        bits = [int(a) for a in sys.argv[i + 1:] if a.isdigit()] or [24]
+        bits = [int(a) for a in sys.argv[i + 1:i + 4] if a.isdigit()] or [24]
+        if "--radix" in sys.argv:
+            tc.ctx.set_option("join_radix", sys.argv[sys.argv.index("--radix") + 1])
+        if "--slice" in sys.argv:
+            tc.ctx.set_option("join_radix_slice_log2", int(sys.argv[sys.argv.index("--slice") + 1]))
+        if "--hash" in sys.argv:
+            tc.ctx.set_option("join_dense", 0)
         print(json.dumps([join_probe_micro(tc, g, b, 28, 1.0, reps=2) for b in bits], indent=1))
         sys.exit(0)
     if "--like" in sys.argv:

@@ -78,9 +78,12 @@ typedef struct gpuq_op gpuq_op;
 typedef struct gpuq_join_table gpuq_join_table;
 
 /* ---- context ----------------------------------------------------------------------------- */
-/* Streams: every call takes the HIP stream its work is queued on.  All calls made on one context (and on the operators /
-   join tables created from it) must be queued on ONE stream at a time, or be ordered by the caller: the library recycles
-   its workspaces and join tables through a pool without synchronising, relying on stream order. */
+/* Streams and threads: every call takes the HIP stream its work is queued on.  Calls made on ONE stream are ordered by that
+   stream.  Several host threads may drive one device -- through one context or several -- each on its own stream and with its
+   own operators / plans / join tables (the reference runs `concurrent_tasks` tasks on its task-runner pool,
+   cpu_bound_executor.rs:94-131): the library recycles device memory through a process-wide pool and orders a block released
+   under one stream behind its next user on another with an event (csrc/devbuf.h).  One operator, plan or join table must not be
+   used from two threads at once.  gpuq_last_error() is per calling thread. */
 int gpuq_abi_version(void);
 /* json_opts: NULL or {"device":N}.  Fails (returns NULL) when no HIP device is usable;
    gpuq_last_error(NULL) then holds the reason. */
@@ -90,7 +93,13 @@ const char* gpuq_last_error(gpuq_ctx* ctx);
 int gpuq_ctx_device_info(gpuq_ctx* ctx, char* buf, size_t cap); /* JSON: name, arch, cus, hbm_bytes */
 /* Tuning switches (strings): "join_dense" = "0" | "1" (default 1; env GPUQ_JOIN_DENSE at ctx creation): join tables over ONE
    Int32 / Int64 / Date32 key whose build values span a bounded range are direct-addressed arrays instead of hash tables;
-   "join_dense_ratio" = largest range / key-count ratio that still takes the array (default 128). */
+   "join_dense_ratio" = largest range / key-count ratio that still takes the array (default 128);
+   "join_radix" = "off" | "auto" | "force": partitioned probe (one LDS-staged radix pass over the probe rows on the high bits of
+   key - min, then lookups that stay inside one L2-sized slice of the array at a time) for Inner / RightSemi joins over such
+   an array; the pairs then come out in partition order instead of probe order.  Default "off": on MI355X the pass costs about
+   what the random accesses it removes cost (2^28 probes: 5.5 vs 6.3 ms at 2^24 keys, 7.2 vs 7.3 ms at 2^27).
+   "auto" takes it for >= 2^24 probe rows against a table of >= 64 MiB when a sample of the probe keys shows no locality;
+   "join_radix_slice_log2" = table entries per partition (default 18 = 1 MiB slices). */
 int gpuq_ctx_set_option(gpuq_ctx* ctx, const char* key, const char* value);
 
 /* ---- runtime specialisation (JIT) ---------------------------------------------------------- */

@@ -17,11 +17,17 @@ import test_gpu_operators as M
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["dense", "hash"])
+@pytest.fixture(params=["dense", "hash", "dense+partitioned-probe"])
 def layout(tc, request):
-    tc.ctx.set_option("join_dense", 1 if request.param == "dense" else 0)
+    """Join-table layout and probe strategy: direct-addressed array, hash table, or the array probed through the partitioned
+    (radix) probe -- forced, with 2^10-entry slices so that small test inputs still spread over many partitions."""
+    tc.ctx.set_option("join_dense", 0 if request.param == "hash" else 1)
+    tc.ctx.set_option("join_radix", "force" if "partitioned" in request.param else "off")
+    tc.ctx.set_option("join_radix_slice_log2", 10)
     yield request.param
     tc.ctx.set_option("join_dense", 1)
+    tc.ctx.set_option("join_radix", "off")
+    tc.ctx.set_option("join_radix_slice_log2", 18)
 
 
 @pytest.fixture(params=["off", "force"])
@@ -134,9 +140,16 @@ def test_segments_keep_probe_order_and_cover_ragged_tails(tc, layout, jitmode, j
     else:
         sel = hit < 0; exp_b, exp_p = None, passing[sel]
     assert k == len(exp_p)
-    assert np.array_equal(opb[:k].cpu().numpy().astype(np.int64), exp_p)
+    got_p = opb[:k].cpu().numpy().astype(np.int64)
+    got_b = ob[:k].cpu().numpy().astype(np.int64) if exp_b is not None else None
+    if "partitioned" in layout and jt in ("Inner", "RightSemi"):
+        # partition order: the same pairs, ordered by table slice; inside a slice in no particular order
+        order = np.argsort(got_p, kind="stable")
+        got_p = got_p[order]
+        got_b = got_b[order] if got_b is not None else None
+    assert np.array_equal(got_p, exp_p)
     if exp_b is not None:
-        assert np.array_equal(ob[:k].cpu().numpy().astype(np.int64), exp_b)          # -1 == NULL_ROW (0xFFFFFFFF) for unmatched outer rows
+        assert np.array_equal(got_b, exp_b)          # -1 == NULL_ROW (0xFFFFFFFF) for unmatched outer rows
     assert int(opb[k:].max().item() if k < n else -2) == -2                           # nothing written past the count
 
 
@@ -167,5 +180,9 @@ def test_capacity_overflow_is_reported(tc, layout):
         pop.check(tc.stream_ptr())
     assert e.value.status == 4
     assert int(ob[cap:].max().item()) == -2 and int(opb[cap:].max().item()) == -2
-    assert np.array_equal(opb[:cap].cpu().numpy(), np.arange(cap, dtype=np.int32))
+    got = opb[:cap].cpu().numpy()
+    if "partitioned" in layout:       # partition order: any `cap` distinct probe rows, each paired with its own key's build row
+        assert len(np.unique(got)) == cap and np.array_equal(ob[:cap].cpu().numpy(), got % nb)
+    else:
+        assert np.array_equal(got, np.arange(cap, dtype=np.int32))
     tc.ctx.L.gpuq_join_table_free(h)

@@ -10,7 +10,7 @@ fields = [{"name": "k", "type": "Int64", "nullable": False}, {"name": "d", "type
 pred = binary(col("d", fields), Op.Gt, lit(9204, "Date32"))
 build = {"op": "join_build", "input": {"fields": fields}, "on": [col("k", fields)], "predicate": pred}
 probe = {"op": "join_probe", "input": {"fields": fields}, "on": [col("k", fields)], "predicate": pred, "join_type": "Inner"}
-jobs = [(build, 5, ""), (build, 14, ""), (probe, 6, ""), (probe, 7, ""), (probe, 7, "#define GPUQ_JIT_PROBE1 1\nconstexpr int JIT_KEY_REG0 = %d;\n")]
+jobs = [(build, 5, ""), (build, 14, ""), (probe, 15, ""), (probe, 6, ""), (probe, 7, ""), (probe, 7, "#define GPUQ_JIT_PROBE1 1\nconstexpr int JIT_KEY_REG0 = %d;\n")]
 with tempfile.TemporaryDirectory() as d:
     for desc, kid, spec in jobs:
         src = g.compile_jit_source(desc, kid)
