@@ -132,6 +132,8 @@ def lib():
         "gpuq_result_record": (i32, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(i64)]),
         "gpuq_ipc_peek": (i32, [vp, i64, vp]),
         "gpuq_ipc_schema_message": (i32, [C.POINTER(gpuq_field_info), i32, vp, i64, C.POINTER(i64)]),
+        "gpuq_ipc_schema_message_kv": (i32, [C.POINTER(gpuq_field_info), i32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i32, vp, i64, C.POINTER(i64)]),
+        "gpuq_ipc_schema_metadata": (i32, [vp, i64, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(i32)]),
         "gpuq_ipc_encode_batch": (i32, [vp, vp, C.POINTER(gpuq_column), i32, i64, i32, vp, i64, C.POINTER(i64)]),
         "gpuq_ipc_decode_batch": (i32, [vp, vp, vp, i64, C.POINTER(gpuq_field_info), i32, C.POINTER(vp)]),
         "gpuq_ipc_decode_stream": (i32, [vp, vp, vp, i64, C.POINTER(gpuq_field_info), i32, C.POINTER(vp)]),

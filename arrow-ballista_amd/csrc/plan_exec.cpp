@@ -943,9 +943,12 @@ struct ShuffleWriterExec : PNode {
     try {
       auto put = [&](const void* p, size_t n) { if (n && std::fwrite(p, 1, n, fp) != n) throw std::runtime_error("short write to " + path); sf.bytes += (int64_t)n; };
       int64_t len = 0;
-      ipc_check(gpuq_ipc_schema_message(fields.data(), (int)fields.size(), nullptr, 0, &len));
+      // a hash-partitioned file says which partition function placed its rows (GPUQ_PARTITION_FN_KEY, include/gpuq.h)
+      const char* mk[1] = {GPUQ_PARTITION_FN_KEY}; const char* mv[1] = {GPUQ_PARTITION_FN};
+      const int nkv = hashed ? 1 : 0;
+      ipc_check(gpuq_ipc_schema_message_kv(fields.data(), (int)fields.size(), mk, mv, nkv, nullptr, 0, &len));
       std::vector<uint8_t> sm((size_t)len);
-      ipc_check(gpuq_ipc_schema_message(fields.data(), (int)fields.size(), sm.data(), len, &len));
+      ipc_check(gpuq_ipc_schema_message_kv(fields.data(), (int)fields.size(), mk, mv, nkv, sm.data(), len, &len));
       put(sm.data(), sm.size());
       const int64_t step = std::max<int64_t>(64, (batch_rows + 63) / 64 * 64);      // batches start on bitmap words: row ranges are pointer arithmetic
       // Utf8 byte counts of the whole partition, for the output bound of a batch
@@ -1057,6 +1060,7 @@ struct ShuffleReaderExec : PNode {
     }
     std::vector<PTable> parts;
     std::vector<uint8_t> bytes;
+    std::string part_fn;
     auto wrap = [&](gpuq_ipc_batch* b) {
       PTable t; t.n = gpuq_ipc_batch_num_rows(b);
       t.keep.push_back(BufP(new DevBuf(), [b](DevBuf* d) { delete d; gpuq_ipc_batch_free(b); }));
@@ -1075,6 +1079,16 @@ struct ShuffleReaderExec : PNode {
       const size_t got = bytes.empty() ? 0 : std::fread(bytes.data(), 1, bytes.size(), fp);
       std::fclose(fp);
       if (got != bytes.size()) throw std::runtime_error("short read from " + path);
+      {      // every file of one shuffle partition must have been partitioned by the same function (include/gpuq.h)
+        char val[64] = {0}; int found = 0;
+        if (gpuq_ipc_schema_metadata(bytes.data(), (int64_t)bytes.size(), GPUQ_PARTITION_FN_KEY, val, sizeof(val), &found) == GPUQ_OK) {
+          const std::string fn = found ? std::string(val) : std::string("datafusion-ahash (no " GPUQ_PARTITION_FN_KEY " metadata)");
+          if (part_fn.empty()) part_fn = fn;
+          else if (part_fn != fn)
+            throw std::runtime_error("ShuffleReaderExec: the files of shuffle partition " + std::to_string(part) + " were written with different partition functions (" + part_fn + " vs " + fn +
+                                     " in " + path + "): all map tasks of a hash-partitioned stage must run on the same engine");
+        }
+      }
       gpuq_ipc_batch* b = nullptr;
       ipc_check(gpuq_ipc_decode_stream(x.ctx, x.stream, bytes.data(), (int64_t)bytes.size(), fields.data(), (int)fields.size(), &b));
       parts.push_back(wrap(b));

@@ -156,16 +156,17 @@ struct FbWriter {
   }
 };
 
-std::vector<uint8_t> build_schema_metadata(const gpuq_field_info* fields, int n_cols) {
+std::vector<uint8_t> build_schema_metadata(const gpuq_field_info* fields, int n_cols, const std::vector<std::pair<std::string, std::string>>& kv = {}) {
   FbWriter w;
   std::vector<size_t> at;
   w.grow(4);                                                                        // root uoffset
   const size_t msg = w.table(4, {{3, 8, 0}, {2, 4, 0}, {0, 2, 4 /* V5 */}, {1, 1, 1 /* MessageHeader Schema */}}, at);
   w.point(0, msg);
   const size_t msg_header = at[2];
-  const size_t sch = w.table(4, {{1, 4, 0}, {0, 2, 0 /* Endianness Little */}}, at);
+  const size_t sch = kv.empty() ? w.table(4, {{1, 4, 0}, {0, 2, 0 /* Endianness Little */}}, at)
+                                : w.table(4, {{1, 4, 0}, {2, 4, 0}, {0, 2, 0 /* Endianness Little */}}, at);
   w.point(msg_header, sch);
-  const size_t sch_fields = at[1];
+  const size_t sch_fields = at[1], sch_meta = kv.empty() ? 0 : at[2];
   w.align(4);
   const size_t vec = w.grow(4 + 4 * (size_t)n_cols);
   { const uint32_t n = (uint32_t)n_cols; w.put(vec, &n, 4); }
@@ -202,6 +203,20 @@ std::vector<uint8_t> build_schema_metadata(const gpuq_field_info* fields, int n_
     w.align(4);
     const size_t kids = w.grow(4);                                                 // empty children vector (Arrow C++ insists on its presence)
     w.point(a_children, kids);
+  }
+  if (!kv.empty()) {      // Schema.custom_metadata: [KeyValue{key, value}]
+    w.align(4);
+    const size_t mv = w.grow(4 + 4 * kv.size());
+    { const uint32_t n = (uint32_t)kv.size(); w.put(mv, &n, 4); }
+    w.point(sch_meta, mv);
+    for (size_t i = 0; i < kv.size(); ++i) {
+      std::vector<size_t> ka;
+      const size_t t = w.table(2, {{0, 4, 0}, {1, 4, 0}}, ka);
+      w.point(mv + 4 + 4 * i, t);
+      const size_t a_k = ka[0], a_v = ka[1];
+      w.point(a_k, w.string(kv[i].first));
+      w.point(a_v, w.string(kv[i].second));
+    }
   }
   w.align(8);
   return w.b;
@@ -263,6 +278,52 @@ int gpuq_ipc_schema_message(const gpuq_field_info* fields, int n_cols, uint8_t* 
     if (!out || cap < total) { if (!out && cap == 0) return; throw Capacity("IPC schema message needs " + std::to_string(total) + " bytes"); }
     const uint32_t cont = 0xFFFFFFFFu; const int32_t mlen = (int32_t)fb.size();
     std::memcpy(out, &cont, 4); std::memcpy(out + 4, &mlen, 4); std::memcpy(out + 8, fb.data(), fb.size());
+  });
+}
+
+int gpuq_ipc_schema_message_kv(const gpuq_field_info* fields, int n_cols, const char* const* keys, const char* const* values, int n_kv, uint8_t* out, int64_t cap,
+                               int64_t* len_out) {
+  return guarded_ipc([&]() {
+    if (!fields && n_cols > 0) throw std::runtime_error("fields is NULL");
+    if (n_kv < 0 || (n_kv > 0 && (!keys || !values))) throw std::runtime_error("keys / values are NULL");
+    std::vector<std::pair<std::string, std::string>> kv;
+    for (int i = 0; i < n_kv; ++i) kv.emplace_back(keys[i] ? keys[i] : "", values[i] ? values[i] : "");
+    const std::vector<uint8_t> fb = build_schema_metadata(fields, n_cols, kv);
+    const int64_t total = 8 + (int64_t)fb.size();
+    if (len_out) *len_out = total;
+    if (!out || cap < total) { if (!out && cap == 0) return; throw Capacity("IPC schema message needs " + std::to_string(total) + " bytes"); }
+    const uint32_t cont = 0xFFFFFFFFu; const int32_t mlen = (int32_t)fb.size();
+    std::memcpy(out, &cont, 4); std::memcpy(out + 4, &mlen, 4); std::memcpy(out + 8, fb.data(), fb.size());
+  });
+}
+
+int gpuq_ipc_schema_metadata(const uint8_t* bytes, int64_t avail, const char* key, char* value_out, size_t cap, int* found_out) {
+  return guarded_ipc([&]() {
+    if (!bytes || !key || !found_out) throw std::runtime_error("bytes / key / found_out is NULL");
+    *found_out = 0;
+    if (avail < 8) throw Capacity("IPC message header needs 8 bytes");
+    size_t pos = 0; uint32_t first; std::memcpy(&first, bytes, 4);
+    int32_t mlen;
+    if (first == 0xFFFFFFFFu) { std::memcpy(&mlen, bytes + 4, 4); pos = 8; } else { mlen = (int32_t)first; pos = 4; }      // pre-0.15 streams have no continuation marker
+    if (mlen <= 0 || (int64_t)pos + mlen > avail) throw Capacity("IPC schema message is longer than the bytes given");
+    FbView v{bytes + pos, (size_t)mlen};
+    const size_t msg = v.indirect(0);
+    size_t p = v.field(msg, 1);
+    if (!p || v.u8(p) != 1) throw std::runtime_error("not a Schema message");
+    p = v.field(msg, 2); if (!p) return;
+    const size_t sch = v.indirect(p);
+    p = v.field(sch, 2); if (!p) return;
+    const size_t vec = v.indirect(p); const uint32_t cnt = v.u32(vec);
+    auto str = [&](size_t at) { const size_t s0 = v.indirect(at); const uint32_t n = v.u32(s0); v.need(s0 + 4, n); return std::string((const char*)v.b + s0 + 4, n); };
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const size_t kvt = v.indirect(vec + 4 + 4 * (size_t)i);
+      const size_t kp = v.field(kvt, 0), vp = v.field(kvt, 1);
+      if (!kp || str(kp) != key) continue;
+      const std::string val = vp ? str(vp) : std::string();
+      if (value_out && cap) std::snprintf(value_out, cap, "%s", val.c_str());
+      *found_out = 1;
+      return;
+    }
   });
 }
 

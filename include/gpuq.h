@@ -356,6 +356,17 @@ int gpuq_ipc_peek(const uint8_t* bytes, int64_t avail, gpuq_ipc_info* out);
 /* Host only: the encapsulated Schema message that opens a stream of these fields (name, type, precision, scale, nullable are
    read) -- what `IpcDataGenerator::schema_to_bytes` / `Schema.serialize()` produce.  Size query with out == NULL && cap == 0. */
 int gpuq_ipc_schema_message(const gpuq_field_info* fields, int n_cols, uint8_t* out, int64_t cap, int64_t* len_out);
+/* Host only: the same with Schema.custom_metadata key / value pairs (what arrow-rs writes for `Schema::metadata`). */
+int gpuq_ipc_schema_message_kv(const gpuq_field_info* fields, int n_cols, const char* const* keys, const char* const* values, int n_kv, uint8_t* out, int64_t cap,
+                               int64_t* len_out);
+/* Host only: looks `key` up in the custom_metadata of the Schema message that starts at `bytes`; *found_out = 0 / 1. */
+int gpuq_ipc_schema_metadata(const uint8_t* bytes, int64_t avail, const char* key, char* value_out, size_t cap, int* found_out);
+/* The partition function of a hash-partitioned shuffle file written by this engine, recorded as schema metadata
+   "gpuq.partition_fn" (files written by DataFusion's BatchPartitioner -- fixed-seed ahash -- carry no such key).  Equal keys only
+   meet in one output partition when EVERY map task of a stage used the same function: ShuffleReaderExec refuses a partition
+   whose files disagree (all map tasks of a hash-partitioned stage must run on the same engine). */
+#define GPUQ_PARTITION_FN_KEY "gpuq.partition_fn"
+#define GPUQ_PARTITION_FN "gpuq-mix64-v1"
 /* cols: device columns in GPUQ_REPR_ARROW layout, all of n_rows rows.  codec: 0 = LZ4_FRAME, -1 = uncompressed.  Writes the
    message to out_host (host memory, cap bytes) and its length to *len_out.  out_host == NULL && cap == 0: size query (the
    compression runs, nothing is copied).  GPUQ_ERR_CAPACITY (with *len_out set) when cap is too small.  Synchronous. */

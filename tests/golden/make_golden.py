@@ -2,6 +2,8 @@
 (run in the build container, where /root/reference exists; the GPU box only sees the outputs).
   alltypes_plain.arrow  <- ballista/client/testdata/alltypes_plain.parquet  (8 rows; KATs context.rs:762-967)
   tpch10/*.tbl          <- ballista/scheduler/testdata/**.tbl               (8 TPC-H tables x 10 rows)
+  shuffle_data.arrow    <- ballista/core/tests/data.arrow                   (561-row Utf8 shuffle file, Arrow IPC stream with LZ4_FRAME
+                                                                             buffers; read 1000 x by async_reader/mod.rs:331-357)
 Only data is copied -- no reference source text."""
 import os
 import shutil
@@ -21,4 +23,5 @@ for table in sorted(os.listdir(base)):
     for fn in sorted(os.listdir(os.path.join(base, table))):
         dst = "%s.tbl" % table if fn == table + ".tbl" else "%s.%s" % (table, fn)
         shutil.copyfile(os.path.join(base, table, fn), os.path.join(HERE, "tpch10", dst))
+shutil.copyfile(os.path.join(REF, "ballista/core/tests/data.arrow"), os.path.join(HERE, "shuffle_data.arrow"))
 print(sorted(os.listdir(os.path.join(HERE, "tpch10"))))

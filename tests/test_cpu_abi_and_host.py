@@ -233,3 +233,74 @@ def test_native_plan_parses_the_stage_driver_nodes():
     L.gpuq_plan_free(h)
     plan["ShuffleWriterExec"]["work_dir"] = ""
     assert L.gpuq_plan_create(ctx, json.dumps(plan).encode(), C.byref(h)) == 1 and b"work_dir" in L.gpuq_plan_last_error()
+
+
+def test_ipc_peek_walks_the_reference_shuffle_file():
+    """tests/golden/shuffle_data.arrow is the shuffle file the reference's own reader test loads
+    (ballista/core/tests/data.arrow, async_reader/mod.rs:331-357: 561 Utf8 rows written by the reference's
+    ShuffleWriterExec -- Arrow IPC stream, LZ4_FRAME buffers).  The host-side walk sees Schema, the RecordBatch(es) with
+    561 rows in total and LZ4_FRAME compression, and ends on the end-of-stream marker (or the end of the file: the
+    reference's reader tolerates a missing marker, async_reader/mod.rs:179-189)."""
+    import ctypes as C
+    import os
+    import pyarrow as pa
+    from arrow_ballista_amd import binding as B
+    from arrow_ballista_amd.shuffle import gpuq_ipc_info
+    L = B.lib()
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", "shuffle_data.arrow"), "rb").read()
+    ref = pa.ipc.open_stream(raw).read_all()
+    assert ref.num_rows == 561 and ref.schema.names == ["$d"]
+    buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+    pos, kinds, rows, codecs = 0, [], 0, set()
+    info = gpuq_ipc_info()
+    while pos < len(raw):
+        rc = L.gpuq_ipc_peek(C.c_void_p(C.addressof(buf) + pos), len(raw) - pos, C.byref(info))
+        assert rc == 0, L.gpuq_ipc_last_error()
+        kinds.append(info.header_type)
+        if info.header_type == 0:
+            pos += 8
+            break
+        if info.header_type == 3:
+            rows += info.n_rows
+            codecs.add(info.codec)
+        pos += info.metadata_bytes + info.body_bytes
+    assert kinds[0] == 1 and 3 in kinds and rows == 561 and codecs == {0}
+    assert pos == len(raw)
+
+
+def test_ipc_schema_metadata_round_trip_with_arrow_cpp():
+    """Schema.custom_metadata written by gpuq_ipc_schema_message_kv is what Arrow C++ reads as Schema.metadata, and
+    gpuq_ipc_schema_metadata finds keys in messages written by either side (the partition-function marker of hash-partitioned
+    shuffle files, GPUQ_PARTITION_FN_KEY in include/gpuq.h)."""
+    import ctypes as C
+    import pyarrow as pa
+    from arrow_ballista_amd import binding as B
+    L = B.lib()
+    fields = (B.gpuq_field_info * 2)()
+    fields[0].name, fields[0].type, fields[0].nullable = b"k", 3, 0          # Int64
+    fields[1].name, fields[1].type, fields[1].precision, fields[1].scale, fields[1].nullable = b"d", 6, 15, 2, 1   # Decimal128(15,2)
+    keys = (C.c_char_p * 2)(b"gpuq.partition_fn", b"other")
+    vals = (C.c_char_p * 2)(b"gpuq-mix64-v1", b"")
+    ln = C.c_int64(0)
+    assert L.gpuq_ipc_schema_message_kv(fields, 2, keys, vals, 2, None, 0, C.byref(ln)) == 0
+    buf = (C.c_uint8 * ln.value)()
+    assert L.gpuq_ipc_schema_message_kv(fields, 2, keys, vals, 2, buf, ln.value, C.byref(ln)) == 0, L.gpuq_ipc_last_error()
+    sch = pa.ipc.read_schema(pa.py_buffer(bytes(buf)))
+    assert sch.names == ["k", "d"] and sch.field("d").type == pa.decimal128(15, 2) and not sch.field("k").nullable
+    assert sch.metadata == {b"gpuq.partition_fn": b"gpuq-mix64-v1", b"other": b""}
+
+    def lookup(raw, key):
+        b = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        out = C.create_string_buffer(64)
+        found = C.c_int(0)
+        assert L.gpuq_ipc_schema_metadata(b, len(raw), key, out, 64, C.byref(found)) == 0, L.gpuq_ipc_last_error()
+        return out.value if found.value else None
+    assert lookup(bytes(buf), b"gpuq.partition_fn") == b"gpuq-mix64-v1" and lookup(bytes(buf), b"other") == b"" and lookup(bytes(buf), b"absent") is None
+    theirs = pa.schema([pa.field("x", pa.int32())], metadata={"a": "1", "gpuq.partition_fn": "something-else"}).serialize().to_pybytes()
+    assert lookup(theirs, b"gpuq.partition_fn") == b"something-else" and lookup(theirs, b"a") == b"1"
+    plain = pa.schema([pa.field("x", pa.int32())]).serialize().to_pybytes()
+    assert lookup(plain, b"gpuq.partition_fn") is None
+    # the message without metadata is unchanged by the new entry point
+    l0, l1 = C.c_int64(0), C.c_int64(0)
+    assert L.gpuq_ipc_schema_message(fields, 2, None, 0, C.byref(l0)) == 0 and L.gpuq_ipc_schema_message_kv(fields, 2, None, None, 0, None, 0, C.byref(l1)) == 0
+    assert l0.value == l1.value

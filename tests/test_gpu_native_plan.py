@@ -226,11 +226,23 @@ def test_native_stage_driver_writes_and_reads_shuffle_files(tc, tmp_path):
         got += arrow_rows(rp.execute(q).to_arrow())
     exp = ora_rows(O.aggregate(ot.take(keep), [(col("k64", s), "k64")], aggs, "Single"))
     assert norm(got) == norm(exp)
+    # a hash-partitioned file names its partition function; a partition whose files disagree is refused (a stage whose map tasks
+    # ran partly on a CPU executor -- ahash, no marker -- and partly here would otherwise mis-route equal keys silently)
+    first = next(f for f in files if f[0] == 0)
+    assert pa.ipc.open_stream(first[1]).schema.metadata == {b"gpuq.partition_fn": b"gpuq-mix64-v1"}
+    foreign = str(tmp_path / "cpu_written.arrow")
+    with pa.OSFile(foreign, "wb") as fo, pa.ipc.new_stream(fo, pa.ipc.open_stream(first[1]).schema.remove_metadata(), options=pa.ipc.IpcWriteOptions(compression="lz4")) as w:
+        w.write_table(pa.ipc.open_stream(first[1]).read_all().replace_schema_metadata(None))
+    mixed = g.NativePlan(g.ShuffleReaderExec([[{"path": first[1]}, {"path": foreign}]], s), tc)
+    with pytest.raises(g.GpuqError, match="same engine"):
+        mixed.execute(0)
+    assert g.NativePlan(g.ShuffleReaderExec([[{"path": foreign}, {"path": foreign}]], s), tc).execute(0).num_rows == 2 * first[2]
     # unpartitioned stage: one data.arrow per task; strings longer than 15 bytes travel; missing file = FetchFailed
     w2 = g.NativePlan(g.ShuffleWriterExec("jobN", 3, src, str(tmp_path)), tc)
     (pid, path, rows, batches, nbytes), = arrow_rows(w2.execute(1).to_arrow())
     assert pid == 1 and path.endswith("data.arrow") and rows == 5000
     back = pa.ipc.open_stream(path).read_all()
+    assert not pa.ipc.open_stream(path).schema.metadata          # no partition function involved
     assert norm(ora_rows(O.Table.from_arrow(back))) == norm(ora_rows(O.Table.from_arrow(parts[1])))
     bad = g.NativePlan(g.ShuffleReaderExec([[{"path": str(tmp_path / "nope.arrow")}]], s), tc)
     with pytest.raises(g.GpuqError, match="FetchFailed"):

@@ -225,3 +225,26 @@ def test_lz4_format_boundaries_both_directions(tc):
     # compressible cases must actually shrink: 200,000 zero bytes fit in a few hundred
     dt = g.DeviceTable.from_arrow(pa.table({"x": pa.array(np.zeros(50_000, dtype=np.int32))}), tc.device)
     assert S.encoded_size(tc, dt) < 2000
+
+
+def test_reference_shuffle_file_decodes_on_the_device(tc):
+    """The shuffle file the reference's own reader test loads (ballista/core/tests/data.arrow -> tests/golden/shuffle_data.arrow,
+    async_reader/mod.rs:331-357; written by the reference's ShuffleWriterExec with lz4_flex frames): decoded by
+    gpuq_ipc_decode_stream on the device, byte for byte what Arrow C++ reads from the same file -- 561 Utf8 rows of 190-330
+    bytes each (longer than any PACKED15 key: payload strings travel in Arrow layout)."""
+    import os
+    import pyarrow as pa
+    from arrow_ballista_amd import shuffle as S
+    path = os.path.join(os.path.dirname(__file__), "golden", "shuffle_data.arrow")
+    raw = open(path, "rb").read()
+    ref = pa.ipc.open_stream(raw).read_all()
+    for source in (path, raw):
+        t, schema = S.read_ipc_stream(tc, source)
+        got = t.to_arrow(tc.ctx)
+        assert schema.equals(ref.schema) and got.num_rows == 561
+        assert got.column(0).to_pylist() == ref.column(0).to_pylist()
+    # and back: the device writer's stream of the same rows is read by Arrow C++
+    import io
+    sink = io.BytesIO()
+    S.write_ipc_stream(tc, sink, t)
+    assert pa.ipc.open_stream(sink.getvalue()).read_all().column(0).to_pylist() == ref.column(0).to_pylist()
