@@ -92,6 +92,7 @@ def lib():
         "gpuq_ctx_set_option": (i32, [vp, C.c_char_p, C.c_char_p]),
         "gpuq_ctx_set_jit": (i32, [vp, C.c_char_p, i64]),
         "gpuq_ctx_jit_wait": (i32, [vp]),
+        "gpuq_jit_cache_stats": (i32, [C.POINTER(i32), C.POINTER(i32)]),
         "gpuq_ctx_jit_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]),
         "gpuq_op_jit_source": (i32, [vp, i32, C.c_char_p, C.c_size_t]),
         "gpuq_op_create": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
@@ -122,6 +123,16 @@ def lib():
         "gpuq_plan_num_partitions": (i32, [vp]),
         "gpuq_plan_execute": (i32, [vp, vp, i32, C.POINTER(gpuq_input), i32, C.POINTER(vp)]),
         "gpuq_plan_metrics": (i32, [vp, C.c_char_p, C.c_size_t]),
+        "gpuq_plan_set_comm": (i32, [vp, vp]),
+        "gpuq_comm_unique_id": (i32, [vp]),
+        "gpuq_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "gpuq_comm_create_host": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "gpuq_comm_free": (None, [vp]),
+        "gpuq_comm_rank": (i32, [vp]),
+        "gpuq_comm_world": (i32, [vp]),
+        "gpuq_exchange_partitions": (i32, [vp, vp, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info), i32, C.POINTER(i64), C.POINTER(vp)]),
+        "gpuq_allgather_table": (i32, [vp, vp, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info), i32, i64, C.POINTER(vp)]),
+        "gpuq_exchange_last_error": (C.c_char_p, []),
         "gpuq_plan_last_error": (C.c_char_p, []),
         "gpuq_plan_profile": (i32, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
         "gpuq_plan_profile_all": (i32, [vp, C.c_char_p, C.c_size_t]),

@@ -6,6 +6,7 @@
 #include "gpuq_kernels.h"
 #include "jit_runtime.h"
 #include "devbuf.h"
+#include "gpuq_internal.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <memory>
@@ -30,18 +31,6 @@ u64 next_pow2(u64 v) { u64 r = 1; while (r < v) r <<= 1; return r; }
 
 }  // namespace
 
-struct gpuq_ctx {
-  int device = 0; int cus = 256; size_t hbm = 0; std::string name, arch;
-  int jit_mode = 1;                 // 0 off, 1 auto (inputs >= jit_min_rows), 2 force
-  i64 jit_min_rows = 1ll << 21;
-  std::string last_jit_error;       // auto mode: why the last specialisation fell back to the interpreter kernels
-  int jit_launches = 0;
-  int join_dense = 1;               // direct-addressed join tables for one narrow key of bounded range (gpuq_ctx_set_option "join_dense")
-  i64 join_dense_ratio = 128;       // ... while range <= ratio x keys
-  int join_radix = 0;               // partitioned probe over a direct-addressed table: 0 off (default: measured 1.0-1.16x, pairs
-                                    // leave probe order -- DESIGN.md section 3), 1 auto, 2 force ("join_radix")
-  int join_radix_slice_log2 = 18;   // table entries per partition slice (2^18 x 4 B = 1 MiB: an XCD's L2 holds a few)
-};
 
 struct gpuq_timer { hipEvent_t a = nullptr, b = nullptr; };
 
@@ -1535,7 +1524,6 @@ struct Staging {   // two pinned buffers, copies alternate between them (H2D ove
 };
 thread_local Staging g_staging;
 
-struct ImportedCol { gpuq_column col{}; gpuq_field_info field{}; DevBuf data, offsets, validity; };
 
 DType dtype_from_format(const char* f) {
   DType t; const std::string s = f ? f : "";
@@ -1564,7 +1552,6 @@ std::vector<uint8_t> realign_bits(const uint8_t* src, int64_t off, int64_t nbits
 }
 }  // namespace
 
-struct gpuq_table { gpuq_ctx* ctx = nullptr; int64_t n_rows = 0; std::vector<std::unique_ptr<ImportedCol>> cols; };
 
 extern "C" {
 int gpuq_buffer_alloc(gpuq_ctx* ctx, size_t bytes, void** dev_out) {
@@ -1729,6 +1716,7 @@ int gpuq_ctx_jit_stats(gpuq_ctx* ctx, int* available, int* launches, char* last_
   if (last_error && cap) std::snprintf(last_error, cap, "%s", ctx->last_jit_error.c_str());
   return GPUQ_OK;
 }
+int gpuq_jit_cache_stats(int* disk_hits, int* compiles) { jit_cache_stats(disk_hits, compiles); return GPUQ_OK; }
 int gpuq_op_jit_source(gpuq_op* op, int kernel_id, char* buf, size_t cap) {
   if (!op) return GPUQ_ERR_INVALID;
   return guarded(op->ctx, [&]() {

@@ -8,6 +8,10 @@
 #include "jit_runtime.h"
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cerrno>
+#include <cstdio>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -96,37 +100,106 @@ std::string jit_full_source(const std::string& eval_src, int kernel_id) {
          "\n#include \"gpuq_kernels.h\"\nnamespace gpuq {\n" + eval_src + "}\n#include \"" + file_of(kernel_id) + "\"\n";
 }
 
-// hiprtc compile + module load of one (front-end source, sink) pair; no lock held
+// ---- on-disk code-object cache.  A one-shot task must not pay 0.3-1.9 s of hiprtc for a pipeline some earlier process on this
+// host already compiled: code objects are kept under $GPUQ_JIT_CACHE_DIR (default $XDG_CACHE_HOME/gpuq-jit or ~/.cache/gpuq-jit;
+// "off" disables), one file per (full translation unit, compiler options, hiprtc version), named by a 128-bit hash of that text.
+// Files are written to a temporary name and renamed, so concurrent executors on one node share the directory safely.
+static std::string cache_dir() {
+  static const std::string dir = []() -> std::string {
+    const char* e = std::getenv("GPUQ_JIT_CACHE_DIR");
+    std::string d;
+    if (e && *e) { if (std::string(e) == "off") return std::string(); d = e; }
+    else if (const char* x = std::getenv("XDG_CACHE_HOME")) d = std::string(x) + "/gpuq-jit";
+    else if (const char* h = std::getenv("HOME")) d = std::string(h) + "/.cache/gpuq-jit";
+    else d = "/tmp/gpuq-jit-" + std::to_string((long)getuid());
+    for (size_t i = 1; i <= d.size(); ++i)
+      if (i == d.size() || d[i] == '/') { const std::string p = d.substr(0, i); if (::mkdir(p.c_str(), 0777) != 0 && errno != EEXIST) return std::string(); }
+    return d;
+  }();
+  return dir;
+}
+static std::string cache_name(const std::string& text) {
+  unsigned long long a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
+  for (unsigned char c : text) { a = (a ^ c) * 0x100000001b3ull; b = (b ^ (c + 0x9e)) * 0x100000001b3ull; b ^= b >> 29; }
+  char buf[48]; std::snprintf(buf, sizeof(buf), "%016llx%016llx.co", a, b);
+  return buf;
+}
+static bool cache_read(const std::string& path, std::vector<char>& code) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  std::fseek(f, 0, SEEK_END); const long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+  bool ok = n > 0;
+  if (ok) { code.resize((size_t)n); ok = std::fread(code.data(), 1, (size_t)n, f) == (size_t)n; }
+  std::fclose(f);
+  return ok;
+}
+static void cache_write(const std::string& path, const std::vector<char>& code) {
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
+  std::fclose(f);
+  if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
+static int g_disk_hits = 0, g_compiles = 0;
+void jit_cache_stats(int* disk_hits, int* compiles) { std::lock_guard<std::mutex> lk(g_mu); if (disk_hits) *disk_hits = g_disk_hits; if (compiles) *compiles = g_compiles; }
+
+// hiprtc compile (or disk-cache hit) + module load of one (front-end source, sink) pair on the CURRENT device; no lock held
 static JitFn compile_and_load(const std::string& eval_src, int kernel_id) {
   Rtc& r = rtc();
   if (!r.ok) throw std::runtime_error("jit: hiprtc is not available on this host");
   const std::string src = jit_full_source(eval_src, kernel_id);
-  hiprtcProgram prog = nullptr;
-  if (r.Create(&prog, src.c_str(), "gpuq_jit.hip", gpuq_embedded_count, gpuq_embedded_sources, gpuq_embedded_names) != 0)
-    throw std::runtime_error("jit: hiprtcCreateProgram failed");
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-  const int rc = r.Compile(prog, 3, opts);
-  if (rc != 0) {
-    size_t ls = 0; r.LogSize(prog, &ls);
-    std::string log(ls + 1, 0); if (ls) r.Log(prog, &log[0]);
-    r.Destroy(&prog);
-    throw std::runtime_error("jit: compile failed:\n" + log.substr(0, 4000));
+  std::vector<char> code;
+  std::string cpath;
+  if (!cache_dir().empty()) {
+    int ver = 0; (void)hipRuntimeGetVersion(&ver);
+    std::string ident = src + "|" + std::to_string(ver);
+    for (const char* o : opts) { ident += "|"; ident += o; }
+    for (int i = 0; i < gpuq_embedded_count; ++i) { ident += "|"; ident += gpuq_embedded_sources[i]; }      // the #included sink sources are part of the unit
+    cpath = cache_dir() + "/" + cache_name(ident);
   }
-  size_t cs = 0; r.CodeSize(prog, &cs);
-  std::vector<char> code(cs); r.Code(prog, code.data());
-  r.Destroy(&prog);
+  bool from_disk = !cpath.empty() && cache_read(cpath, code);
+  if (!from_disk) {
+    hiprtcProgram prog = nullptr;
+    if (r.Create(&prog, src.c_str(), "gpuq_jit.hip", gpuq_embedded_count, gpuq_embedded_sources, gpuq_embedded_names) != 0)
+      throw std::runtime_error("jit: hiprtcCreateProgram failed");
+    const int rc = r.Compile(prog, 3, opts);
+    if (rc != 0) {
+      size_t ls = 0; r.LogSize(prog, &ls);
+      std::string log(ls + 1, 0); if (ls) r.Log(prog, &log[0]);
+      r.Destroy(&prog);
+      throw std::runtime_error("jit: compile failed:\n" + log.substr(0, 4000));
+    }
+    size_t cs = 0; r.CodeSize(prog, &cs);
+    code.resize(cs); r.Code(prog, code.data());
+    r.Destroy(&prog);
+  }
   JitFn f{};
   hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
   hipError_t e = hipModuleLoadData(&mod, code.data());
+  if (e != hipSuccess && from_disk) {      // a damaged cache file: compile as if it were not there
+    (void)hipGetLastError(); (void)std::remove(cpath.c_str());
+    const std::string saved = cpath;
+    return compile_and_load(eval_src, kernel_id);
+  }
   if (e != hipSuccess) throw std::runtime_error(std::string("jit: hipModuleLoadData: ") + hipGetErrorString(e));
   e = hipModuleGetFunction(&fn, mod, jit_entry_name(kernel_id));
-  if (e != hipSuccess) throw std::runtime_error(std::string("jit: hipModuleGetFunction: ") + hipGetErrorString(e));
+  if (e != hipSuccess) { (void)hipModuleUnload(mod); throw std::runtime_error(std::string("jit: hipModuleGetFunction: ") + hipGetErrorString(e)); }
+  if (!from_disk && !cpath.empty()) cache_write(cpath, code);
+  { std::lock_guard<std::mutex> lk(g_mu); if (from_disk) ++g_disk_hits; else ++g_compiles; }
   f.module = mod; f.fn = fn;
   return f;
 }
 
+// cache key: a loaded module belongs to the device it was loaded on
+static std::string jit_key(const std::string& eval_src, int kernel_id) {
+  int dev = 0; (void)hipGetDevice(&dev);
+  return std::to_string(dev) + "|" + std::to_string(kernel_id) + "|" + eval_src;
+}
+
 const JitFn* jit_get(const std::string& eval_src, int kernel_id) {
-  const std::string key = std::to_string(kernel_id) + "|" + eval_src;
+  const std::string key = jit_key(eval_src, kernel_id);
   {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_cache.find(key);
@@ -134,7 +207,9 @@ const JitFn* jit_get(const std::string& eval_src, int kernel_id) {
   }
   const JitFn f = compile_and_load(eval_src, kernel_id);      // two threads may compile the same key; the first insert wins
   std::lock_guard<std::mutex> lk(g_mu);
-  return &g_cache.emplace(key, f).first->second;
+  auto ins = g_cache.emplace(key, f);
+  if (!ins.second) (void)hipModuleUnload((hipModule_t)f.module);      // lost the race: drop the duplicate module
+  return &ins.first->second;
 }
 
 // ---- background tier: operators that run again and again on small inputs (a stage's many small partitions, the final stage
@@ -163,7 +238,7 @@ void bg_worker() {
       (void)hipSetDevice(job.device);
       const JitFn f = compile_and_load(job.src, job.kernel_id);
       std::lock_guard<std::mutex> lk(g_mu);
-      g_cache.emplace(job.key, f);
+      if (!g_cache.emplace(job.key, f).second) (void)hipModuleUnload((hipModule_t)f.module);
     } catch (const std::exception&) { /* stays on the interpreter kernels */ }
     {
       std::lock_guard<std::mutex> lk(B.mu);
@@ -181,7 +256,7 @@ void bg_stop_at_exit() {
 }  // namespace
 
 const JitFn* jit_try_get(const std::string& eval_src, int kernel_id) {
-  const std::string key = std::to_string(kernel_id) + "|" + eval_src;
+  const std::string key = jit_key(eval_src, kernel_id);
   {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_cache.find(key);

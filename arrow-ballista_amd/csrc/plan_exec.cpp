@@ -142,6 +142,7 @@ struct Exec {
   const gpuq_input* inputs = nullptr; int n_inputs = 0;
   uint64_t* pin = nullptr;                                // pinned host words for count read-backs
   std::map<std::string, gpuq_op*>* memo = nullptr;       // (call site, input layout) -> operator: skips rebuilding the descriptor
+  gpuq_comm* comm = nullptr;                              // ranks of the node (gpuq_plan_set_comm); nullptr = a single-GPU plan
 };
 
 void check(Exec& x, int rc) {
@@ -1103,6 +1104,96 @@ struct ShuffleReaderExec : PNode {
   }
 };
 
+// ---------------------------------------------------------------- exchange between the GPUs of a node (exchange.cpp)
+// The intra-node stand-ins for a stage boundary of the reference (ShuffleWriterExec -> files -> ShuffleReaderExec):
+//   RepartitionExec {input, hash_expr, partition_count == ranks}: this rank's rows are hash-partitioned by destination rank
+//     (same mix64 partition function on every rank), grouped with one take, and exchanged; the result is what every rank
+//     sent here (RepartitionExecNode, datafusion.proto; the planner splits stages at exactly this node, planner.rs:137-151);
+//   BroadcastExec {input}: every rank receives all ranks' rows -- a CollectLeft build side whose reduce task reads every
+//     partition of the build stage (shuffle_reader.rs: all locations of the stage).
+void xcheck(int rc) {
+  if (rc == GPUQ_OK) return;
+  const std::string msg = gpuq_exchange_last_error();
+  if (rc == GPUQ_ERR_UNSUPPORTED) throw Unsupported(msg);
+  if (rc == GPUQ_ERR_HIP) throw HipError(msg);
+  throw std::runtime_error(msg);
+}
+void table_c_arrays(const PTable& t, std::vector<gpuq_column>& cols, std::vector<gpuq_field_info>& fields) {
+  cols.clear(); fields.clear();
+  for (auto& c : t.cols) {
+    gpuq_field_info f{};
+    std::snprintf(f.name, sizeof(f.name), "%s", c.name.c_str());
+    f.type = c.c.type; f.precision = c.c.precision; f.scale = c.c.scale; f.nullable = c.nullable; f.repr = c.c.repr;
+    cols.push_back(c.c); fields.push_back(f);
+  }
+}
+PTable table_from_owned(gpuq_table* tab, const PTable& like) {
+  PTable out; out.n = gpuq_table_num_rows(tab);
+  out.keep.push_back(BufP(new DevBuf(), [tab](DevBuf* d) { delete d; gpuq_table_free(tab); }));
+  for (size_t i = 0; i < like.cols.size(); ++i) {
+    PCol c; c.name = like.cols[i].name; c.type = like.cols[i].type; c.nullable = like.cols[i].nullable;
+    gpuq_table_column(tab, (int)i, &c.c, nullptr);
+    out.cols.push_back(c); out.sides.push_back(0);
+  }
+  return out;
+}
+struct RepartitionExec : PNode {
+  PNodeP input; Json hash_expr; int64_t partition_count = 0;
+  std::vector<PNode*> children() override { return {input.get()}; }
+  int partitions() override { return input->partitions(); }
+  PTable execute(int part, Exec& x) override {
+    if (!x.comm) throw Unsupported("RepartitionExec inside a stage needs the ranks of the node (gpuq_plan_set_comm); without them the reference's planner splits the stage here");
+    const int W = gpuq_comm_world(x.comm);
+    if (partition_count != W) throw Unsupported("RepartitionExec: partition_count " + std::to_string(partition_count) + " != number of ranks " + std::to_string(W));
+    PTable t = input->execute(part, x);
+    auto t0 = std::chrono::steady_clock::now();
+    PSchema ps = plain_schema(t);
+    std::vector<std::string> names; for (auto& f : ps) names.push_back(f.name);
+    gpuq_op* op = cached_op(x, this, 0, table_sig(t), [&]() {
+      Json he = jarr(); for (auto& e : hash_expr.a) he.a.push_back(rebind(e, names));
+      return jobj({{"op", jstr("partition")}, {"input", jobj({{"fields", table_fields(t)}})}, {"hash_expr", he}, {"partition_count", jnum(partition_count)}});
+    });
+    BufP perm = dev_alloc((size_t)std::max<int64_t>(1, t.n) * 4), offs = dev_alloc((size_t)(partition_count + 2) * 8);
+    InputC ic; make_input(t, ic);
+    check(x, gpuq_partition_run(op, x.stream, &ic.in, (uint32_t*)perm->p, (uint64_t*)offs->p));
+    std::vector<uint64_t> o((size_t)partition_count + 1);
+    HIPCHECK(hipMemcpyAsync(o.data(), offs->p, o.size() * 8, hipMemcpyDeviceToHost, (hipStream_t)x.stream));
+    HIPCHECK(hipStreamSynchronize((hipStream_t)x.stream));
+    // one take groups the rows by destination rank
+    PTable grouped = materialize(x, select_view(x, t, (const uint32_t*)perm->p, t.n, perm));
+    std::vector<gpuq_column> cols; std::vector<gpuq_field_info> fields;
+    table_c_arrays(grouped, cols, fields);
+    // a column read through an index vector may carry NULLs: nullability as the plan sees it (identical on every rank)
+    for (size_t i = 0; i < fields.size(); ++i) fields[i].nullable = ps[i].nullable ? 1 : 0;
+    std::vector<int64_t> doff(o.begin(), o.end());
+    gpuq_table* tab = nullptr;
+    xcheck(gpuq_exchange_partitions(x.comm, x.stream, cols.data(), fields.data(), (int)cols.size(), doff.data(), &tab));
+    PTable out = table_from_owned(tab, grouped);
+    for (size_t i = 0; i < out.cols.size(); ++i) out.cols[i].nullable = ps[i].nullable;
+    return timed(t0, out);
+  }
+};
+struct BroadcastExec : PNode {
+  PNodeP input;
+  std::vector<PNode*> children() override { return {input.get()}; }
+  int partitions() override { return input->partitions(); }
+  PTable execute(int part, Exec& x) override {
+    if (!x.comm) throw Unsupported("BroadcastExec needs the ranks of the node (gpuq_plan_set_comm)");
+    PTable t = input->execute(part, x);
+    auto t0 = std::chrono::steady_clock::now();
+    PSchema ps = plain_schema(t);
+    PTable plain = materialize(x, t);
+    std::vector<gpuq_column> cols; std::vector<gpuq_field_info> fields;
+    table_c_arrays(plain, cols, fields);
+    for (size_t i = 0; i < fields.size(); ++i) fields[i].nullable = ps[i].nullable ? 1 : 0;
+    gpuq_table* tab = nullptr;
+    xcheck(gpuq_allgather_table(x.comm, x.stream, cols.data(), fields.data(), (int)cols.size(), plain.n, &tab));
+    PTable out = table_from_owned(tab, plain);
+    for (size_t i = 0; i < out.cols.size(); ++i) out.cols[i].nullable = ps[i].nullable;
+    return timed(t0, out);
+  }
+};
+
 PNodeP build_node(const Json& j) {
   if (!j.is_obj() || j.o.size() != 1) throw std::runtime_error("plan: a node is an object with one key (the node type): " + j.dump().substr(0, 80));
   const std::string& kind = j.o[0].first; const Json& v = j.o[0].second;
@@ -1150,6 +1241,10 @@ PNodeP build_node(const Json& j) {
     auto n = std::make_unique<GlobalLimitExec>(); n->input = build_child(v, "input"); n->skip = v.get_i64("skip", 0); n->fetch = v.get_i64("fetch", -1); out = std::move(n);
   } else if (kind == "LocalLimitExec") {
     auto n = std::make_unique<LimitExec>(); n->input = build_child(v, "input"); n->fetch = v.at("fetch").i64(); out = std::move(n);
+  } else if (kind == "RepartitionExec") {
+    auto n = std::make_unique<RepartitionExec>(); n->input = build_child(v, "input"); n->hash_expr = v.at("hash_expr"); n->partition_count = v.at("partition_count").i64(); out = std::move(n);
+  } else if (kind == "BroadcastExec") {
+    auto n = std::make_unique<BroadcastExec>(); n->input = build_child(v, "input"); out = std::move(n);
   } else if (kind == "ShuffleWriterExec") {
     auto n = std::make_unique<ShuffleWriterExec>(); n->input = build_child(v, "input");
     n->job_id = v.at("job_id").str(); n->stage_id = v.at("stage_id").i64(); n->work_dir = v.at("work_dir").str(); n->batch_rows = v.get_i64("batch_rows", 1 << 20);
@@ -1177,7 +1272,7 @@ thread_local std::string g_plan_error;
 }  // namespace
 
 struct gpuq_plan {
-  gpuq_ctx* ctx = nullptr; PNodeP root; std::map<std::string, gpuq_op*> ops, memo; uint64_t* pin = nullptr;
+  gpuq_ctx* ctx = nullptr; PNodeP root; std::map<std::string, gpuq_op*> ops, memo; uint64_t* pin = nullptr; gpuq_comm* comm = nullptr;
   ~gpuq_plan() { for (auto& kv : ops) gpuq_op_free(kv.second); if (pin) (void)hipHostFree(pin); }
 };
 struct gpuq_result { PTable t; std::vector<gpuq_field_info> fields; };
@@ -1220,7 +1315,7 @@ int gpuq_plan_execute(gpuq_plan* p, void* stream, int partition, const gpuq_inpu
   return plan_guarded([&]() {
     if (!p->pin) HIPCHECK(hipHostMalloc((void**)&p->pin, 64, hipHostMallocDefault));
     (void)use_stream(stream);
-    Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin; x.memo = &p->memo;
+    Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin; x.memo = &p->memo; x.comm = p->comm;
     PTable t = materialize(x, p->root->execute(partition, x));
     HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
     std::unique_ptr<gpuq_result> r(new gpuq_result());
@@ -1256,6 +1351,8 @@ void gpuq_result_free(gpuq_result* r) { delete r; }
 
 // Device time of the dominant kernel of the plan's operators (gpuq_op_profile on every compiled operator): reports the
 // operator that accumulated the most kernel time since profiling was enabled.
+int gpuq_plan_set_comm(gpuq_plan* p, gpuq_comm* comm) { if (!p) return GPUQ_ERR_INVALID; p->comm = comm; return GPUQ_OK; }
+
 int gpuq_plan_profile(gpuq_plan* p, int enable, float* kernel_ms_out, int* launches_out, char* op_desc_out, size_t cap) {
   if (!p) return GPUQ_ERR_INVALID;
   float best = -1; int bl = 0; std::string bd;

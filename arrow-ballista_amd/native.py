@@ -86,6 +86,10 @@ def plan_to_json(node, tc, inputs):
         return {"GlobalLimitExec": {"input": sub(node.input), "skip": int(node.skip), "fetch": -1 if node.fetch is None else int(node.fetch)}}
     if isinstance(node, P.LocalLimitExec):
         return {"LocalLimitExec": {"input": sub(node.input), "fetch": int(node.fetch)}}
+    if isinstance(node, P.RepartitionExchangeExec):
+        return {"RepartitionExec": {"input": sub(node.input), "hash_expr": list(node.hash_expr), "partition_count": int(node.partition_count)}}
+    if isinstance(node, P.BroadcastExec):
+        return {"BroadcastExec": {"input": sub(node.input)}}
     if isinstance(node, P.ShuffleWriterExec):
         d = {"input": sub(node.plan), "job_id": node.job_id, "stage_id": int(node.stage_id), "work_dir": node.work_dir}
         if node.shuffle_output_partitioning is not None:
@@ -219,6 +223,11 @@ class NativePlan:
         inp.n_rows = result.num_rows
         self._arr[slot] = inp
         self._keep[slot] = (inp, cols, result)
+
+    def set_comm(self, comm):
+        """Attach the ranks of the node (parallel.Comm) for RepartitionExec / BroadcastExec nodes; the comm must outlive the plan."""
+        self._comm = comm
+        _check(self.tc.ctx.L, self.tc.ctx.L.gpuq_plan_set_comm(self.h, comm.h if comm is not None else None))
 
     def execute(self, partition=0):
         L = self.tc.ctx.L

@@ -25,6 +25,155 @@ def world():
     return 0, 1
 
 
+class Comm:
+    """gpuq_comm (include/gpuq.h, "exchange"): the ranks of the node as the native library sees them.  With the "nccl" backend
+    it is an RCCL communicator created inside libgpuq (rank 0 makes the id, torch.distributed's store only carries the 128
+    bytes); otherwise (gloo: CPU tests, several ranks on one GPU) a host-staged transport whose all-to-all is
+    torch.distributed's -- the exchange logic in csrc/exchange.cpp is the same either way."""
+
+    def __init__(self, tc, group=None):
+        import ctypes as C
+        import torch
+        self.tc, self.group = tc, group
+        L = tc.ctx.L
+        dist = _dist()
+        self.rank, self.world = world()
+        h = C.c_void_p()
+        backend = dist.get_backend(group) if self.world > 1 else "none"
+        self.backend = backend
+        if backend == "nccl" or (self.world == 1 and _rccl_wanted()):
+            ident = (C.c_uint8 * 128)()
+            if self.rank == 0:
+                self._xcheck(L.gpuq_comm_unique_id(ident))
+            if self.world > 1:
+                box = [bytes(ident)]
+                dist.broadcast_object_list(box, src=0, group=group)
+                ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            self._xcheck(L.gpuq_comm_create(tc.ctx.h, ident, self.rank, self.world, C.byref(h)))
+            self.transport = "rccl"
+        else:
+            from .binding import gpuq_column  # noqa: F401  (ctypes structs are defined there)
+            CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.c_int)
+
+            def a2av(_user, send, scnt, recv, rcnt, w):
+                try:
+                    sc = [int(scnt[i]) for i in range(w)]
+                    rc = [int(rcnt[i]) for i in range(w)]
+                    st = torch.frombuffer((C.c_uint8 * max(1, sum(sc))).from_address(send), dtype=torch.uint8)[: sum(sc)] if sum(sc) else torch.zeros(0, dtype=torch.uint8)
+                    rt = torch.frombuffer((C.c_uint8 * max(1, sum(rc))).from_address(recv), dtype=torch.uint8)[: sum(rc)] if sum(rc) else torch.zeros(0, dtype=torch.uint8)
+                    if w == 1:
+                        rt.copy_(st)
+                    else:
+                        dist.all_to_all_single(rt, st.contiguous(), output_split_sizes=rc, input_split_sizes=sc, group=group)
+                    return 0
+                except Exception:      # noqa: BLE001 -- must not unwind into C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            class Transport(C.Structure):
+                _fields_ = [("user", C.c_void_p), ("all_to_all_v", CB)]
+            self._cb = CB(a2av)
+            self._tr = Transport(None, self._cb)
+            self._xcheck(L.gpuq_comm_create_host(tc.ctx.h, C.byref(self._tr), self.rank, self.world, C.byref(h)))
+            self.transport = "host"
+        self.h = h
+
+    def _xcheck(self, rc):
+        if rc != 0:
+            from .binding import GpuqError
+            raise GpuqError(rc, (self.tc.ctx.L.gpuq_exchange_last_error() or b"").decode())
+
+    def _table_arrays(self, table):
+        import ctypes as C
+        from . import binding as B
+        from .table import type_id
+        n = len(table.columns)
+        cols, fields, keep = (B.gpuq_column * max(1, n))(), (B.gpuq_field_info * max(1, n))(), []
+        for i, c in enumerate(table.columns):
+            cc = c.to_c()
+            cols[i] = cc
+            keep.append(cc)
+            tid, p, s_ = type_id(c.type)
+            fields[i].name = c.name.encode()[:255]
+            fields[i].type, fields[i].precision, fields[i].scale, fields[i].nullable, fields[i].repr = tid, p, s_, 1 if c.nullable else 0, c.repr
+        return cols, fields, keep
+
+    def _wrap(self, h, like):
+        """gpuq_table -> DeviceTable whose columns alias the library's buffers (freed with the table)."""
+        import ctypes as C
+        import torch
+        from . import binding as B
+        L = self.tc.ctx.L
+        n = int(L.gpuq_table_num_rows(h))
+        owner = _OwnedTable(L, h)
+        cols = []
+        for i, c in enumerate(like.columns):
+            cc = B.gpuq_column()
+            L.gpuq_table_column(h, i, C.byref(cc), None)
+            w = type_width(c.type) if c.offsets is None else 0
+
+            def alias(ptr, nb):
+                class _A:
+                    pass
+                a = _A()
+                a.__cuda_array_interface__ = {"shape": (int(max(nb, 1)),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+                a.owner = owner
+                return torch.as_tensor(a, device=self.tc.device)
+            bm = ((n + 63) // 64) * 8 + 8
+            if cc.offsets:
+                offs = alias(cc.offsets, (n + 1) * 4).view(torch.int32)
+                nbytes = int(offs[n].item()) if n else 0
+                data = alias(cc.data, nbytes + 16)
+            else:
+                offs = None
+                data = alias(cc.data, bm if w == 0 else n * w + 16)
+            validity = alias(cc.validity, bm) if cc.validity else None
+            cols.append(DeviceColumn(c.name, c.type, data, n, offsets=offs, validity=validity, nullable=c.nullable, repr=c.repr))
+        t = DeviceTable(cols, n)
+        t._keep = owner
+        return t
+
+    def exchange_partitions(self, grouped, dest_offsets):
+        """grouped: materialised DeviceTable whose rows [dest_offsets[d], dest_offsets[d+1]) go to rank d."""
+        import ctypes as C
+        cols, fields, keep = self._table_arrays(grouped)
+        off = (C.c_int64 * (self.world + 1))(*[int(x) for x in dest_offsets])
+        h = C.c_void_p()
+        self._xcheck(self.tc.ctx.L.gpuq_exchange_partitions(self.h, self.tc.stream_ptr(), cols, fields, len(grouped.columns), off, C.byref(h)))
+        return self._wrap(h, grouped)
+
+    def allgather(self, table):
+        import ctypes as C
+        cols, fields, keep = self._table_arrays(table)
+        h = C.c_void_p()
+        self._xcheck(self.tc.ctx.L.gpuq_allgather_table(self.h, self.tc.stream_ptr(), cols, fields, len(table.columns), table.num_rows, C.byref(h)))
+        return self._wrap(h, table)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.tc.ctx.L.gpuq_comm_free(self.h)
+            self.h = None
+
+
+def _rccl_wanted():
+    import os
+    return os.environ.get("GPUQ_COMM_TRANSPORT", "rccl") == "rccl"
+
+
+class _OwnedTable:
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.gpuq_table_free(self.h)
+                self.h = None
+        except Exception:      # noqa: BLE001
+            pass
+
+
 def allgather_table(table, cap, group=None):
     """All-gather a small materialised fixed-width table (e.g. partial-aggregate states): every rank receives the
     concatenation, in rank order, of all ranks' rows.  `cap` = per-rank row capacity (>= max rows on any rank, the SAME
@@ -204,11 +353,17 @@ def exchange_partitions(parts, group=None, tc=None):
     return DeviceTable(cols, total)
 
 
-def repartition_exchange(tc, table, hash_expr, group=None):
+def repartition_exchange(tc, table, hash_expr, group=None, comm=None):
     """RepartitionExec(Hash(hash_expr, world)) followed by the exchange: returns the rows of ALL ranks whose key hashes to
-    this rank (planner.rs:137-151 splits a stage here; the reference then writes/reads shuffle files over Flight)."""
+    this rank (planner.rs:137-151 splits a stage here; the reference then writes/reads shuffle files over Flight).
+    comm (a Comm): the exchange runs inside libgpuq (gpuq_exchange_partitions: RCCL, or the host-staged transport); without
+    it the torch.distributed path below moves the tensors (CPU tests)."""
     from . import plan as PL
     rank, ws = world()
+    if comm is not None:
+        perm, offs = PL.partition_perm(tc, table, hash_expr, comm.world)
+        grouped = PL.materialize(tc, PL._select_view(tc, table, perm[: table.num_rows], table.num_rows))
+        return comm.exchange_partitions(grouped, offs)
     if ws == 1:
         return table
     views = PL.partition_table(tc, table, hash_expr, ws)
@@ -216,10 +371,12 @@ def repartition_exchange(tc, table, hash_expr, group=None):
     return exchange_partitions(parts, group=group, tc=tc)
 
 
-def broadcast_table(tc, table, cap=None, group=None):
+def broadcast_table(tc, table, cap=None, group=None, comm=None):
     """Every rank receives all ranks' rows (CollectLeft build sides below the broadcast threshold, config.rs:198-200)."""
     from . import plan as PL
     rank, ws = world()
+    if comm is not None:
+        return comm.allgather(PL.materialize(tc, table))
     if ws == 1:
         return table
     t = PL.materialize(tc, table, force=True)
@@ -234,13 +391,13 @@ def broadcast_table(tc, table, cap=None, group=None):
     return allgather_table(t, cap, group=group)
 
 
-def partitioned_hash_join(tc, left, right, on, join_type="Inner", filter=None, group=None):
+def partitioned_hash_join(tc, left, right, on, join_type="Inner", filter=None, group=None, comm=None):
     """HashJoinExec(PartitionMode::Partitioned) across ranks: both inputs are repartitioned on their join keys with the
     SAME partition function, exchanged, and joined locally.  `on` = [(left_expr, right_expr)].  Returns this rank's share
     of the join result (a view)."""
     from . import plan as PL
-    lt = repartition_exchange(tc, left, [l for l, _ in on], group=group)
-    rt = repartition_exchange(tc, right, [r for _, r in on], group=group)
+    lt = repartition_exchange(tc, left, [l for l, _ in on], group=group, comm=comm)
+    rt = repartition_exchange(tc, right, [r for _, r in on], group=group, comm=comm)
     L, R = PL.MemoryExec([lt]), PL.MemoryExec([rt])
     ls, rs = L.schema(), R.schema()
     from . import expr as E

@@ -967,6 +967,55 @@ class RepartitionExec(ExecutionPlan):
         return outs
 
 
+class ExchangeExec(ExecutionPlan):
+    """Base of the two exchange nodes the NATIVE executor runs across the ranks of a node (csrc/plan_exec.cpp, csrc/exchange.cpp;
+    attach the ranks with NativePlan.set_comm): they are plan-description classes only -- the mirror executes single-rank plans."""
+
+    def __init__(self, input):
+        super().__init__()
+        self.input = input
+
+    def children(self):
+        return [self.input]
+
+    def schema(self):
+        return self.input.schema()
+
+    def output_partition_count(self):
+        return self.input.output_partition_count()
+
+    def execute(self, partition, context):
+        raise B.GpuqError(3, "%s runs in the native plan executor (NativePlan + set_comm)" % type(self).__name__)
+
+
+class RepartitionExchangeExec(ExchangeExec):
+    """RepartitionExec(Hash(hash_expr, ranks)) + the exchange: this rank receives the rows of ALL ranks whose key hashes to it
+    (the stage boundary of planner.rs:137-151, as one RCCL all-to-all instead of shuffle files)."""
+
+    def __init__(self, input, hash_expr, partition_count):
+        super().__init__(input)
+        self.hash_expr, self.partition_count = list(hash_expr), int(partition_count)
+
+
+class BroadcastExec(ExchangeExec):
+    """Every rank receives all ranks' rows (a CollectLeft build side read by every reduce task)."""
+
+
+def partition_perm(tc, table, hash_expr, partition_count):
+    """(perm, offsets): driving positions grouped by partition (input order inside a partition) and the partition_count + 1
+    boundaries as a host list -- gpuq_partition_run."""
+    torch = _torch()
+    schema = table.schema()
+    op = tc.op({"op": "partition", "input": {"fields": schema}, "hash_expr": [E.rebind(e, schema) for e in hash_expr],
+                "partition_count": int(partition_count)})
+    n = table.num_rows
+    perm = torch.empty(max(1, n), dtype=torch.int32, device=tc.device)
+    offs = torch.zeros(partition_count + 2, dtype=torch.int64, device=tc.device)
+    inp, keep = table.input_struct()
+    tc.ctx.check(tc.ctx.L.gpuq_partition_run(op.h, tc.stream_ptr(), C.byref(inp), perm.data_ptr(), offs.data_ptr()))
+    return perm, offs.cpu().tolist()[: partition_count + 1]
+
+
 def partition_table(tc, table, hash_expr, partition_count):
     torch = _torch()
     schema = table.schema()

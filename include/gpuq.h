@@ -114,6 +114,10 @@ int gpuq_ctx_jit_stats(gpuq_ctx* ctx, int* available, int* launches, char* last_
    specialisation; its callers keep running the interpreter kernels until the compiled function is there.  This call waits
    until every compile requested so far has finished (benchmarks call it at the end of their warm-up). */
 int gpuq_ctx_jit_wait(gpuq_ctx* ctx);
+/* Compiled code objects are kept on disk ($GPUQ_JIT_CACHE_DIR, default $XDG_CACHE_HOME/gpuq-jit or ~/.cache/gpuq-jit; "off"
+   disables), keyed by a hash of the whole translation unit, so only the first process on a host pays hiprtc for a pipeline
+   (0.3-1.9 s); later processes load the code object (~ms).  Counters of this process: */
+int gpuq_jit_cache_stats(int* disk_hits, int* compiles);
 
 /* ---- device memory + Arrow C Data Interface ingest/egress ---------------------------------- */
 /* A host that owns Arrow RecordBatches (arrow-rs `arrow::ffi`, pyarrow `_export_to_c`) hands them over
@@ -302,6 +306,10 @@ int gpuq_copy_bits(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_of
          writes <work_dir>/<job_id>/<stage_id>/<q>/<uuid>.arrow per non-empty output partition q (unpartitioned:
          .../<stage_id>/<uuid>/data.arrow), Arrow IPC stream + LZ4_FRAME; result = one row per file:
          partition UInt32, path Utf8, num_rows / num_batches / num_bytes UInt64 (shuffle_writer.rs:470-520)
+     {"RepartitionExec": {"input","hash_expr": [expr],"partition_count": ranks}}  {"BroadcastExec": {"input"}}
+         the exchange between the GPUs of one node (gpuq_plan_set_comm; "exchange" section below): the stand-ins for a stage
+         boundary of the reference -- RepartitionExec(Hash) is where planner.rs:137-151 splits stages; BroadcastExec is a
+         CollectLeft build side read by every reduce task
      {"ShuffleReaderExec": {"schema": [{"name","type","nullable"}], "partition": [[{"path"} | path, ...], ...]}}   (shuffle_reader.rs:149-177;
          local files; a file that cannot be opened is reported as "FetchFailed: ...")
    Expressions are the PhysicalExprNode mirror of gpuq_op_create; columns are resolved by NAME against each operator's input.
@@ -314,6 +322,9 @@ int gpuq_plan_create(gpuq_ctx* ctx, const char* plan_json, gpuq_plan** out);
 void gpuq_plan_free(gpuq_plan* plan);
 int gpuq_plan_num_partitions(gpuq_plan* plan);
 int gpuq_plan_execute(gpuq_plan* plan, void* stream, int partition, const gpuq_input* inputs, int n_inputs, gpuq_result** out);
+/* The ranks of the node for RepartitionExec / BroadcastExec nodes (the comm outlives the plan; NULL detaches). */
+struct gpuq_comm;
+int gpuq_plan_set_comm(gpuq_plan* plan, struct gpuq_comm* comm);
 int gpuq_plan_metrics(gpuq_plan* plan, char* json_out, size_t cap);     /* per node: output_rows, elapsed_compute (ns) -- utils.rs:470-481; ShuffleWriterExec adds write_time, repart_time, input_rows (shuffle_writer.rs:139-160) */
 const char* gpuq_plan_last_error(void);
 /* gpuq_op_profile over every operator the plan has compiled: enable/disable the HIP-event bracket around each operator's
@@ -385,6 +396,43 @@ int gpuq_ipc_batch_num_columns(const gpuq_ipc_batch* b);
 int gpuq_ipc_batch_column(const gpuq_ipc_batch* b, int i, gpuq_column* col_out);
 void gpuq_ipc_batch_free(gpuq_ipc_batch* b);
 const char* gpuq_ipc_last_error(void);
+
+/* ---- exchange between the GPUs of one node ---------------------------------------------------------
+   Stands in for a stage boundary of the reference between executors that each own one GPU of a node: ShuffleWriterExec
+   hash-partitioning into Arrow-IPC files (ballista/core/src/execution_plans/shuffle_writer.rs:328-392) that the next stage's
+   ShuffleReaderExec fetches (shuffle_reader.rs:226-298).  Here it is one exchange step: an all-to-all of per-destination counts,
+   then one variable-size all-to-all per column buffer, posted as grouped RCCL sends / receives so that all xGMI links of a GPU
+   carry traffic at once; nothing is compressed or written to disk.  One process per GPU; every rank makes the same calls in
+   the same order (they are collectives).  Errors: status code + gpuq_exchange_last_error(). */
+typedef struct gpuq_comm gpuq_comm;
+#define GPUQ_COMM_ID_BYTES 128
+/* Rank 0 creates the id; the host hands it to the other ranks over its own channel (the executors' gRPC, a torch.distributed
+   store, a file), then every rank calls gpuq_comm_create (collective: ncclCommInitRank on the context's device). */
+int gpuq_comm_unique_id(uint8_t* id_out /* GPUQ_COMM_ID_BYTES */);
+int gpuq_comm_create(gpuq_ctx* ctx, const uint8_t* id /* GPUQ_COMM_ID_BYTES */, int rank, int world, gpuq_comm** out);
+/* Host-staged transport instead of RCCL: the library stages every buffer through pinned host memory and the caller moves the
+   bytes (tests with several ranks on one GPU; a host that ships bytes over its own network service).  all_to_all_v: this rank
+   sends send_counts[d] bytes to rank d from `send` (host memory, packed in rank order) and receives recv_counts[s] bytes from
+   rank s into `recv` (packed in rank order); returns 0 on success.  Collective. */
+typedef struct gpuq_transport {
+  void* user;
+  int (*all_to_all_v)(void* user, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts, int world);
+} gpuq_transport;
+int gpuq_comm_create_host(gpuq_ctx* ctx, const gpuq_transport* transport, int rank, int world, gpuq_comm** out);
+void gpuq_comm_free(gpuq_comm* comm);
+int gpuq_comm_rank(const gpuq_comm* comm);
+int gpuq_comm_world(const gpuq_comm* comm);
+/* Hash-repartition exchange.  cols / fields: device columns (Arrow layout, Utf8 of any length included, or PACKED15) whose rows
+   are GROUPED BY DESTINATION: rows [dest_offsets[d], dest_offsets[d+1]) go to rank d (host array of world+1 entries; produce
+   the grouping with gpuq_partition_run(partition_count = world) + a take, as the native executor's RepartitionExec does).
+   *out = the rows every rank sent here, concatenated in rank order, in buffers the library owns (gpuq_table_free).
+   fields[i].nullable decides whether a validity bitmap travels (the same on every rank).  Synchronous. */
+int gpuq_exchange_partitions(gpuq_comm* comm, void* stream, const gpuq_column* cols, const gpuq_field_info* fields, int n_cols, const int64_t* dest_offsets,
+                             gpuq_table** out);
+/* Every rank receives all ranks' rows, in rank order: CollectLeft build sides (the reference's reduce task reads every partition
+   of the build stage), partial-aggregate states. */
+int gpuq_allgather_table(gpuq_comm* comm, void* stream, const gpuq_column* cols, const gpuq_field_info* fields, int n_cols, int64_t n_rows, gpuq_table** out);
+const char* gpuq_exchange_last_error(void);
 
 /* ---- synthetic TPC-H-shaped input (bench/test support) ------------------- */
 typedef struct gpuq_lineitem_cols {

@@ -25,11 +25,11 @@ def _dec(x):
     return x
 
 
-def _run(world=2):
-    port = str(29700 + os.getpid() % 1500)
+def _run(world=2, worker="dist_worker.py", port_base=29700):
+    port = str(port_base + os.getpid() % 1500)
     with tempfile.TemporaryDirectory() as d:
         outs = [os.path.join(d, "r%d.json" % r) for r in range(world)]
-        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, outs[r]],
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, worker), str(r), str(world), port, outs[r]],
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
         logs = []
         for p in procs:
@@ -98,3 +98,61 @@ def test_distributed_sort_is_globally_ordered(ranks):
 def test_broadcast_gives_every_rank_all_rows(ranks):
     assert ranks[0]["bcast_rows"] == ranks[1]["bcast_rows"]
     assert len(ranks[0]["bcast_rows"]) == 10 + 11
+
+
+# ---------------------------------------------------------------- the same legs through the C ABI's exchange (csrc/exchange.cpp)
+@pytest.fixture(scope="module")
+def native_ranks():
+    return _run(2, worker="dist_worker_native.py", port_base=31300)
+
+
+def _native_left_shards():
+    out = []
+    for r in range(2):
+        t = rand_table(1000 + r, 3000 + 100 * r, 0.2)
+        out.append(t.append_column(pa.field("long_s", pa.string()),
+                                   pa.array([None if i % 11 == 0 else "rank%d-row%d-%s" % (r, i, "y" * (i % 33)) for i in range(t.num_rows)])))
+    return out
+
+
+def test_native_exchange_is_a_partition_of_the_union(native_ranks):
+    """gpuq_exchange_partitions over the host-staged transport, two ranks: nullable columns, Boolean bitmaps, Utf8 of any
+    length in Arrow layout (offsets rebased per received piece).  The union of what the ranks hold afterwards is the union of
+    what they held before, and no key lives on two ranks."""
+    lts = _native_left_shards()
+    allrows = _orows(O.Table.from_arrow(pa.concat_tables(lts)))
+    got = [r for rk in native_ranks for r in rk["exchange_rows"]]
+    assert norm(got) == norm(allrows)
+    keys = [set((r[0], r[6]) for r in rk["exchange_rows"]) for rk in native_ranks]
+    assert not (keys[0] & keys[1]) and all(len(k) > 0 for k in keys)
+
+
+@pytest.mark.parametrize("jt", ["Inner", "Left"])
+def test_native_partitioned_join_equals_oracle_join_of_union(native_ranks, jt):
+    lts, (_, rts) = _native_left_shards(), _shards()
+    ol, orr = O.Table.from_arrow(pa.concat_tables(lts)), O.Table.from_arrow(pa.concat_tables(rts))
+    pairs = O.hash_join(ol, orr, [({"column": {"name": "k64"}}, {"column": {"name": "r_k64"}})], jt)
+    lrows, rrows = _orows(ol), _orows(orr)
+    exp = [(lrows[i] if i is not None else (None,) * len(ol.names)) + (rrows[j] if j is not None else (None,) * len(orr.names)) for i, j in pairs]
+    got = [r for rk in native_ranks for r in rk["join_" + jt]]
+    assert len(got) == len(exp) and norm(got) == norm(exp)
+
+
+def test_native_broadcast_gives_every_rank_all_rows(native_ranks):
+    assert native_ranks[0]["bcast_rows"] == native_ranks[1]["bcast_rows"] and len(native_ranks[0]["bcast_rows"]) == 10 + 11
+    lts = _native_left_shards()
+    exp = _orows(O.Table.from_arrow(pa.concat_tables([lts[0].slice(0, 10), lts[1].slice(0, 11)])))
+    assert [tuple(r) for r in native_ranks[0]["bcast_rows"]] == exp            # rank order, row order
+
+
+@pytest.mark.parametrize("mode", ["partitioned", "broadcast"])
+def test_native_distributed_q3_equals_the_oracle_on_the_union(native_ranks, mode):
+    """Distributed q3 (BASELINE configs[2] shape across ranks; T.q3_dist_plan) as ONE native plan per rank with the exchanges
+    inside (RepartitionExec / BroadcastExec nodes): every rank ends with the full, globally ordered result, equal to the
+    oracle's q3 over the union of the shards."""
+    import tpch_util as T
+    exp, _st = T.q3_oracle_c(T.gen_q3_tables_host(120_000, 1500))
+    for rk in native_ranks:
+        rows = [tuple(r) for r in rk["q3_" + mode]]
+        assert [(r[1], r[2]) for r in rows] == [(r[1], r[2]) for r in exp]
+        assert sorted(rows) == sorted(exp)

@@ -125,3 +125,39 @@ def test_background_tier_switches_without_changing_results(tc):
     off = tc.ctx.jit_stats()["launches"]
     assert rows(plan.execute(0)) == exp and tc.ctx.jit_stats()["launches"] == off
     tc.ctx.set_jit("auto")
+
+
+def test_code_objects_are_cached_on_disk(tmp_path):
+    """A second PROCESS does not pay hiprtc for a pipeline the first one compiled: code objects are kept under
+    $GPUQ_JIT_CACHE_DIR.  Same q1 rows from both processes; the first compiles and fills the directory, the second only loads."""
+    import json
+    import os
+    import subprocess
+    import sys
+    prog = r"""
+import ctypes as C, json, sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import tpch_util as T, arrow_ballista_amd as g
+tc = g.TaskContext(device=0)
+if not tc.ctx.jit_stats()["available"]:
+    print(json.dumps({"skip": True})); sys.exit(0)
+tc.ctx.set_jit("force")
+li = T.gen_lineitem_device(tc, 50_000, seed=3)
+rows = T.q1_result_to_rows(tc, T.run_q1(tc, li))
+h, c = C.c_int(0), C.c_int(0)
+tc.ctx.L.gpuq_jit_cache_stats(C.byref(h), C.byref(c))
+print(json.dumps({"ok": rows == T.q1_oracle_rows(50_000, seed=3), "disk_hits": h.value, "compiles": c.value}))
+"""
+    env = dict(os.environ, GPUQ_JIT_CACHE_DIR=str(tmp_path / "jit"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", prog], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    if outs[0].get("skip"):
+        pytest.skip("hiprtc not available")
+    assert outs[0]["ok"] and outs[1]["ok"]
+    assert outs[0]["compiles"] > 0 and outs[0]["disk_hits"] == 0
+    assert outs[1]["compiles"] == 0 and outs[1]["disk_hits"] == outs[0]["compiles"]
+    assert len([f for f in os.listdir(tmp_path / "jit") if f.endswith(".co")]) == outs[0]["compiles"]

@@ -294,13 +294,13 @@ def gen_orders_device(tc, n, n_cust, seed=SEED_ORDERS, row0=0):
     return g.DeviceTable(cols, n)
 
 
-def gen_customer_device(tc, n, seed=SEED_CUSTOMER):
+def gen_customer_device(tc, n, seed=SEED_CUSTOMER, row0=0):
     import arrow_ballista_amd as g
     from arrow_ballista_amd import binding as B
-    assert n % 5 == 0
+    assert n % 5 == 0 and row0 % 5 == 0
     cols, p = _dev_cols(tc, [("c_custkey", "Int64", 8), ("c_nationkey", "Int64", 8), ("c_mktsegment", "Utf8", ("utf8", n * 9))], n)
     cs = B.gpuq_customer_cols(**p)
-    tc.ctx.check(tc.ctx.L.gpuq_gen_customer(tc.ctx.h, tc.stream_ptr(), seed, 0, n, C.byref(cs)))
+    tc.ctx.check(tc.ctx.L.gpuq_gen_customer(tc.ctx.h, tc.stream_ptr(), seed, row0, n, C.byref(cs)))
     tc.sync()
     return g.DeviceTable(cols, n)
 
@@ -356,6 +356,56 @@ def q3_plan(customer, orders, lineitem):
                              (col("o_shippriority", as_), "o_shippriority")], agg)
     ps = proj.schema()
     return g.SortExec([{"expr": col("revenue", ps), "asc": False, "nulls_first": True}, {"expr": col("o_orderdate", ps), "asc": True, "nulls_first": False}], proj)
+
+
+def q3_dist_plan(customer, orders, lineitem, world, mode="partitioned"):
+    """q3 across the ranks of a node, every rank holding a shard of the three tables (the stages the reference's planner cuts
+    at RepartitionExec(Hash), planner.rs:137-151, run as one native plan per rank with the exchanges inside):
+      customer |> filter |> c_custkey            -- BroadcastExec (3 M keys per SF100: far below the probe side)
+      orders   |> filter |x| customers           -- local CollectLeft join against the broadcast keys
+      mode "partitioned": both sides of orders |x| lineitem hash-repartitioned on the order key (RepartitionExec + exchange),
+                          HashJoinExec(Partitioned), AggregateExec(Single): a group's rows all meet on one rank
+      mode "broadcast":   the joined orders are broadcast instead, lineitem stays where it is; AggregateExec(Partial) ->
+                          exchange on l_orderkey -> AggregateExec(FinalPartitioned)
+      every rank sorts its groups; the sorted runs are gathered and merged (SortPreservingMergeExec) on every rank."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, Operator as Op
+    cs, os_, ls = customer.schema(), orders.schema(), lineitem.schema()
+    c = g.FilterExec(binary(col("c_mktsegment", cs), Op.Eq, lit("BUILDING")), customer)
+    cb = g.BroadcastExec(g.ProjectionExec([(col("c_custkey", cs), "c_custkey")], c))
+    cbs = cb.schema()
+    o = g.FilterExec(binary(col("o_orderdate", os_), Op.Lt, lit(Q3_DATE, "Date32")), orders)
+    j1 = g.HashJoinExec(cb, g.CoalesceBatchesExec(o), [(col("c_custkey", cbs), col("o_custkey", os_))], None, "Inner", "CollectLeft", False)
+    j1s = j1.schema()
+    j1p = g.ProjectionExec([(col(n, j1s), n) for n in ("o_orderkey", "o_orderdate", "o_shippriority")], j1)
+    ps1 = j1p.schema()
+    l = g.FilterExec(binary(col("l_shipdate", ls), Op.Gt, lit(Q3_DATE, "Date32")), lineitem)
+    lp = g.ProjectionExec([(col(n, ls), n) for n in ("l_orderkey", "l_extendedprice", "l_discount")], l)
+    ps2 = lp.schema()
+    if mode == "partitioned":
+        left = g.RepartitionExchangeExec(j1p, [col("o_orderkey", ps1)], world)
+        right = g.RepartitionExchangeExec(lp, [col("l_orderkey", ps2)], world)
+        j2 = g.HashJoinExec(left, right, [(col("o_orderkey", ps1), col("l_orderkey", ps2))], None, "Inner", "Partitioned", False)
+    else:
+        j2 = g.HashJoinExec(g.BroadcastExec(j1p), lp, [(col("o_orderkey", ps1), col("l_orderkey", ps2))], None, "Inner", "CollectLeft", False)
+    j2s = j2.schema()
+    rev = binary(col("l_extendedprice", j2s), Op.Multiply, binary(lit(1, ("Decimal128", 20, 0)), Op.Minus, col("l_discount", j2s)))
+    groups = [(col("l_orderkey", j2s), "l_orderkey"), (col("o_orderdate", j2s), "o_orderdate"), (col("o_shippriority", j2s), "o_shippriority")]
+    aggs = [{"fn": "SUM", "expr": rev, "name": "revenue"}]
+    if mode == "partitioned":
+        agg = g.AggregateExec("Single", groups, aggs, j2, strategy="hash")
+    else:
+        part = g.AggregateExec("Partial", groups, aggs, j2, strategy="hash")
+        fs = part.schema()
+        ex = g.RepartitionExchangeExec(part, [col("l_orderkey", fs)], world)
+        agg = g.AggregateExec("FinalPartitioned", [(col(n, fs), n) for n in ("l_orderkey", "o_orderdate", "o_shippriority")], [dict(a, expr=None) for a in aggs], ex, strategy="hash")
+    as_ = agg.schema()
+    proj = g.ProjectionExec([(col("l_orderkey", as_), "l_orderkey"), (col("revenue", as_), "revenue"), (col("o_orderdate", as_), "o_orderdate"),
+                             (col("o_shippriority", as_), "o_shippriority")], agg)
+    ps = proj.schema()
+    order = [{"expr": col("revenue", ps), "asc": False, "nulls_first": True}, {"expr": col("o_orderdate", ps), "asc": True, "nulls_first": False}]
+    local = g.SortExec(order, proj)
+    return g.SortPreservingMergeExec(order, g.BroadcastExec(local))
 
 
 def q5_plan(customer, orders, lineitem, supplier, nation, region):
