@@ -16,18 +16,13 @@ operator's kernels on the stream they run on.
 cpu_baseline: the C oracle's q3 ("port", OpenMP over all host cores) on an SF10 sample of the same generator.
 "extra": the join-probe micro-grid (2^28 probes x {2^20, 2^24, 2^27} build keys) and SF100 q1 / q5 wall times.
 
-Workload at N>1 (until the exchange moves under the C ABI): the round-1 q1 weak-scaling leg, below.
----- q1 leg (BASELINE.json configs[1]): TPC-H SF10 q1 -- FilterExec -> ProjectionExec ->
-AggregateExec(Partial) -> AggregateExec(FinalPartitioned) -> ProjectionExec -> SortExec over the 7
-Arrow-physical lineitem columns q1 reads (78 B/row, 59,986,052 rows = 4.68 GB), inputs resident in HBM
-when the timed region starts (synthetic TPC-H-shaped data produced on the device).
-A "step" = one full q1 over the rank's rows.  N>1: weak scaling, every rank owns its own SF10 shard,
-partial states are merged with one tiny all-gather (the path has no row exchange for q1).
-value = rows processed by all ranks / wall time (max over ranks).
-
-roofline: dominant kernel k_agg_tiny (fused filter+projection+partial aggregate); algorithmic bytes
-= 78 B/row x rows per launch; duration = HIP events around the launch on the stream it runs on.
-cpu_baseline: the C oracle's q1 ("port", OpenMP over all host cores) on a bounded sample.
+Workload at N>1 (strong scaling: the job stays SF100, every rank holds 1/N of each table; BASELINE configs[3] shape -- "hash-
+partitioned RCCL all-to-all" -- on q3): ONE native plan per rank with the exchanges inside (csrc/plan_exec.cpp RepartitionExec /
+BroadcastExec over csrc/exchange.cpp): customer keys broadcast, orders joined locally, BOTH sides of orders |x| lineitem
+hash-repartitioned on the order key (counts all-to-all, then one grouped ncclSend / ncclRecv exchange per column buffer),
+HashJoinExec(Partitioned) + aggregate per rank, sorted runs gathered and merged.  value = lineitem rows of the whole job per
+second, time = MAX over ranks between barriers.  "extra": q3 with the joined orders broadcast instead (lineitem stays put) and q1
+(partial states gathered).  GPUQ_BENCH_BACKEND=gloo rehearses the N>1 path with ranks sharing a GPU (host-staged transport).
 """
 import argparse
 import json
@@ -39,150 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-Q1_BYTES_PER_ROW = 78            # 4 x Decimal128 (64) + Date32 (4) + 2 x Utf8 (4 B offset + 1 B data)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
-
-
-def main_q1(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: SF10 lineitem = 59,986,052)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=16_000_000)
-    ap.add_argument("--extras", action="store_true", help="also time the join-probe / sort / partition micro-workloads")
-    args, _unknown = ap.parse_known_args(argv)
-
-    import torch
-    import torch.distributed as dist
-    import tpch_util as T
-    import arrow_ballista_amd as g
-    from arrow_ballista_amd import parallel
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # GPUQ_BENCH_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, the
-    # collectives are staged through host memory); the measured configuration is always nccl = RCCL, one rank per GPU.
-    backend = os.environ.get("GPUQ_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    tc = g.TaskContext(device=local_rank)
-
-    n = args.rows or T.LINEITEM_ROWS[10]
-    lineitem = T.gen_lineitem_device(tc, n, seed=T.SEED_LINEITEM, seed_orders=T.SEED_ORDERS, row0=rank * n)
-
-    # ---- plans (built once).  Both stages run in the native plan executor (csrc/plan_exec.cpp): one library call per stage,
-    # no Python between operators.
-    STATE_CAP = 64      # rows of partial-aggregate state a rank ships; the same on every rank (fixes the record layout)
-    partial_py, full_py, final_src = T.q1_split_plan(lineitem, STATE_CAP)
-    partial = g.NativePlan(partial_py, tc)            # fused filter + projection + partial aggregate over the rank's rows
-
-    def gather(res):
-        states = res.to_device_table(tc.device)
-        return parallel.allgather_table(states, cap=STATE_CAP)
-
-    res0 = partial.execute(0)
-    final_src.partitions[0] = gather(res0) if world > 1 else res0.to_device_table(tc.device)
-    final = g.NativePlan(full_py, tc)                 # final aggregate + projection + sort over the (gathered) states
-
-    def step():
-        res = partial.execute(0)
-        if world > 1:
-            final.set_input(0, gather(res))            # one all-gather of fixed-layout records, read in place through a view
-        else:
-            final.set_input_result(0, res)
-        return final.execute(0), res
-
-    for _ in range(max(args.warmup, 3)):
-        out, _r = step()
-    # programs that keep running on small inputs (the final stage's) are specialised by a background thread from their third
-    # run on: let those compiles finish inside the warm-up, as any JIT's would
-    tc.ctx.jit_wait()
-    out, _r = step()
-    partial.profile(True)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # Python's cyclic GC walks the whole torch/pyarrow heap (~40 ms per full collection): keep it out of the timed region
-    import gc
-    gc.collect()
-    gc.freeze()
-    gc.disable()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, _r = step()
-    fence()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    kernel_ms, launches, _desc = partial.profile(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=tc.device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    rows_total = n * world * args.steps
-    value = rows_total / dt
-    result_rows = out.to_arrow().to_pylist()
-
-    line = {
-        "metric": "tpch_q1_operator_rows_per_sec", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "i128", "data": "synthetic",
-        "config": {"workload": "TPC-H SF10 q1 hash-aggregate (BASELINE configs[1]): filter+projection+partial/final aggregate+sort",
-                   "rows_per_gpu": n, "bytes_per_row": Q1_BYTES_PER_ROW, "input": "Arrow-physical columns resident in HBM (64k-row batches concatenated at ingest)",
-                   "groups": len(result_rows), "parallelism": "partition-per-gpu x%d, all-gather of partial states" % world},
-    }
-    if launches > 0:
-        avg_ms = kernel_ms / launches
-        achieved = Q1_BYTES_PER_ROW * n / (avg_ms * 1e-3) / 1e9
-        # HBM traffic per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes over this same
-        # command, gfx950 correction applied; provenance in profiles/r01_traffic.json).  Only valid for the default workload.
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if n == T.LINEITEM_ROWS[10] and os.path.exists(tp):
-            traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
-        line["roofline"] = {"bound": "hbm", "kernel": "k_agg_tiny (hiprtc-specialised: gpuq_jit_agg_tiny)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
-                            "algorithmic_bytes_per_launch": Q1_BYTES_PER_ROW * n}
-
-    if rank == 0 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(T, min(n, args.cpu_sample_rows))
-    if args.extras and rank == 0:
-        import bench_extras
-        line["extra"] = bench_extras.run(tc, T, g)
-    if rank == 0:
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def cpu_baseline(T, sample_rows):
-    """Oracle (C restatement, OpenMP) q1 on the host cores over a bounded sample of the same workload."""
-    host = T.gen_lineitem_host(sample_rows, seed=T.SEED_LINEITEM, seed_orders=T.SEED_ORDERS)
-    best = None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        T.q1_oracle_raw(sample_rows, host=host)
-        dt = time.perf_counter() - t0
-        best = dt if best is None or dt < best else best
-    return {"value": sample_rows / best, "unit": "rows/s", "cores": T.oracle_lib().oracle_num_threads(), "kind": "port",
-            "sample": "C oracle q1 (filter+project+group-by, int128 sums) over the first %d synthetic lineitem rows, best of 3, data in host memory" % sample_rows}
 
 
 Q3_SLOT_BYTES = 16              # one 16-byte slot touch per probe (key + row id), SURVEY.md section 8d
@@ -195,31 +47,80 @@ def main_q3():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sf", type=float, default=100.0, help="scale factor (default 100 = BASELINE configs[2])")
+    ap.add_argument("--sf", type=float, default=100.0, help="scale factor of the WHOLE job (default 100 = BASELINE configs[2]); N ranks hold 1/N of every table each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-sf", type=float, default=10.0)
-    ap.add_argument("--no-extras", action="store_true", help="skip the probe micro-grid and the SF100 q1 / q5 wall times")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (N=1: probe micro-grid, SF100 q1 / q5; N>1: q3 with the build side broadcast, q1)")
     args = ap.parse_args()
 
     import torch
+    import torch.distributed as dist
     import tpch_util as T
     import arrow_ballista_amd as g
+    from arrow_ballista_amd import parallel
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GPUQ_BENCH_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, the exchange
+    # runs over the host-staged transport); the measured configuration is always nccl = RCCL, one rank per GPU.
+    backend = os.environ.get("GPUQ_BENCH_BACKEND", "nccl")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
-    torch.cuda.set_device(0)
-    tc = g.TaskContext(device=0)
-    sf = args.sf
-    n_li = T.LINEITEM_ROWS.get(int(sf), int(6_000_000 * sf)) if sf == int(sf) else int(6_000_000 * sf)
-    n_orders, n_cust, n_supp = (n_li + 3) // 4, int(150_000 * sf), int(10_000 * sf)
-    li = T.gen_lineitem_device(tc, n_li, n_supp=n_supp, columns=("l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate"))
-    od = T.gen_orders_device(tc, n_orders, n_cust)
-    cu = T.gen_customer_device(tc, n_cust)
-    plan = g.NativePlan(T.q3_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li])), tc)
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    tc = g.TaskContext(device=local_rank)
+    comm = parallel.Comm(tc) if world > 1 else None
 
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_steps(fn, steps):
+        """K steps between fences, MAX over ranks."""
+        import gc
+        gc.collect(); gc.freeze(); gc.disable()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        fence()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=tc.device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    sf = args.sf
+    n_total = T.LINEITEM_ROWS.get(int(sf), int(6_000_000 * sf)) if sf == int(sf) else int(6_000_000 * sf)
+    # strong scaling: the job is SF`sf`; rank r holds rows [r * n_li, (r + 1) * n_li) of lineitem and the matching ranges of orders / customer
+    n_li = n_total if world == 1 else n_total // world // 4 * 4
+    n_orders = (n_li + 3) // 4
+    n_cust_total, n_supp = int(150_000 * sf), int(10_000 * sf)
+    n_cust = n_cust_total if world == 1 else n_cust_total // world // 5 * 5
+    li = T.gen_lineitem_device(tc, n_li, n_supp=n_supp, columns=("l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate"), row0=rank * n_li)
+    od = T.gen_orders_device(tc, n_orders, n_cust_total, row0=rank * n_orders)
+    cu = T.gen_customer_device(tc, n_cust, row0=rank * n_cust)
+    if world == 1:
+        plan = g.NativePlan(T.q3_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li])), tc)
+    else:
+        plan = g.NativePlan(T.q3_dist_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), world, "partitioned"), tc)
+        plan.set_comm(comm)
+
+    fence()
     t0 = time.perf_counter()
     res = plan.execute(0)
     tc.sync()
-    first_ms = (time.perf_counter() - t0) * 1e3          # cold: includes the hiprtc specialisation of every pipeline
+    first_ms = (time.perf_counter() - t0) * 1e3          # cold: hiprtc specialisation of every pipeline (or its load from the on-disk cache)
     for _ in range(max(args.warmup, 2)):
         res = plan.execute(0)
     tc.ctx.jit_wait()
@@ -230,16 +131,7 @@ def main_q3():
     # pairs emitted by the lineitem probe in one run = the larger of the two joins' output rows
     matches = max([int(b["output_rows"]) - int(a["output_rows"]) for a, b in zip(m0, m1) if b["node"] == "HashJoinExec"] or [0])
     plan.profile(True)
-
-    import gc
-    gc.collect(); gc.freeze(); gc.disable()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = plan.execute(0)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    gc.enable()
+    dt, res = timed_steps(lambda: plan.execute(0), args.steps)
     ops = plan.profile_all()
     plan.profile(False)
     groups = res.num_rows
@@ -248,13 +140,18 @@ def main_q3():
     shipdate = li.columns[[c.name for c in li.columns].index("l_shipdate")].data[: 4 * n_li].view(torch.int32)
     probes = int((shipdate > T.Q3_DATE).sum().item())
 
+    rows_job = n_li * world
     line = {
-        "metric": "tpch_sf100_q3_lineitem_rows_per_sec", "value": n_li * args.steps / dt, "unit": "rows/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "metric": "tpch_sf100_q3_lineitem_rows_per_sec", "value": rows_job * args.steps / dt, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "i128", "data": "synthetic",
-        "config": {"workload": "TPC-H SF%g q3 (BASELINE configs[2]): filter x3 + hash join customer|x|orders + hash join |x| lineitem + aggregate + sort, one task on 1 x MI355X" % sf,
-                   "lineitem_rows": n_li, "orders_rows": n_orders, "customer_rows": n_cust, "result_groups": groups,
-                   "input": "Arrow-physical columns resident in HBM", "first_run_ms_cold_jit": first_ms, "parallelism": "single partition"},
+        "config": {"workload": ("TPC-H SF%g q3 (BASELINE configs[2]): filter x3 + hash join customer|x|orders + hash join |x| lineitem + aggregate + sort, " % sf)
+                               + ("one task on 1 x MI355X" if world == 1 else
+                                  "%d ranks x 1/%d of every table: customer keys broadcast, BOTH sides of orders|x|lineitem hash-repartitioned over RCCL (grouped send/recv per column buffer), "
+                                  "partitioned join + aggregate per rank, sorted runs gathered and merged" % (world, world)),
+                   "lineitem_rows": rows_job, "lineitem_rows_per_gpu": n_li, "orders_rows_per_gpu": n_orders, "customer_rows_per_gpu": n_cust, "result_groups": groups,
+                   "input": "Arrow-physical columns resident in HBM", "first_run_ms_cold_jit": first_ms,
+                   "parallelism": "single partition" if world == 1 else "partition-per-gpu x%d, exchange inside the native plan (%s)" % (world, comm.transport)},
     }
     probe_ops = sorted((o for o in ops if o["op"] == "join_probe"), key=lambda o: -o["kernel_ms"])
     if probe_ops and probe_ops[0]["launches"] > 0:
@@ -264,9 +161,9 @@ def main_q3():
         achieved = alg / (avg_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if sf == 100 and os.path.exists(tp):
+        if sf == 100 and world == 1 and os.path.exists(tp):
             traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
-        line["roofline"] = {"bound": "hbm", "kernel": "HashJoinExec probe of lineitem (fused filter l_shipdate > date + key lookup + pair emit)",
+        line["roofline"] = {"bound": "hbm", "kernel": "HashJoinExec probe of lineitem (fused filter l_shipdate > date + key lookup + pair emit; rank 0's launch)",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                             "avg_launch_ms": avg_ms, "launches": po["launches"], "algorithmic_bytes_per_launch": alg,
                             "probe_rows": probes, "matches": matches, "rows_scanned": n_li,
@@ -274,19 +171,46 @@ def main_q3():
                             "achieved_incl_fused_filter_column": (alg + 4 * n_li + Q3_PROBE_KEY_BYTES * (n_li - probes)) / (avg_ms * 1e-3) / 1e9}
     line["operators"] = [{"op": o["op"], "kernel_ms_per_step": o["kernel_ms"] / max(1, args.steps), "launches": o["launches"]} for o in sorted(ops, key=lambda o: -o["kernel_ms"])[:8]]
     del plan, res
-    if not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_q3(T, args.cpu_sample_sf)
     if not args.no_extras:
         import bench_extras
-        del li, od, cu
-        torch.cuda.empty_cache()
-        extra = {"join_probe": [bench_extras.join_probe_micro(tc, g, b, 28, 1.0) for b in (20, 24, 27)]}
-        torch.cuda.empty_cache()
-        extra["sf100_q1"] = bench_extras.q1_pipeline(tc, T, g, 100)
-        tp = bench_extras.tpch_pipelines(tc, T, g, 100)
-        extra["sf100_q3"], extra["sf100_q5"] = tp["q3"], tp["q5"]
+        if world == 1:
+            del li, od, cu
+            torch.cuda.empty_cache()
+            extra = {"join_probe": [bench_extras.join_probe_micro(tc, g, b, 28, 1.0) for b in (20, 24, 27)]}
+            torch.cuda.empty_cache()
+            extra["sf100_q1"] = bench_extras.q1_pipeline(tc, T, g, 100)
+            tp = bench_extras.tpch_pipelines(tc, T, g, 100)
+            extra["sf100_q3"], extra["sf100_q5"] = tp["q3"], tp["q5"]
+        else:
+            # second legs, every rank takes part: q3 with the joined orders BROADCAST instead of both sides exchanged (what a
+            # cost-based planner picks when the build side is 20 x smaller than the probe side), and q1 (partial states gathered)
+            extra = {}
+            k = max(3, args.steps // 4)
+            p2 = g.NativePlan(T.q3_dist_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), world, "broadcast"), tc)
+            p2.set_comm(comm)
+            for _ in range(3):
+                p2.execute(0)
+            d2, r2 = timed_steps(lambda: p2.execute(0), k)
+            extra["q3_build_side_broadcast"] = {"ms_per_step": d2 / k * 1e3, "lineitem_rows_per_s": rows_job * k / d2, "result_groups": r2.num_rows}
+            del p2, r2, li, od, cu
+            torch.cuda.empty_cache()
+            l1 = T.gen_lineitem_device(tc, n_li, row0=rank * n_li)
+            p3 = g.NativePlan(T.q1_dist_plan(l1), tc)
+            p3.set_comm(comm)
+            for _ in range(3):
+                p3.execute(0)
+            tc.ctx.jit_wait()
+            d3, r3 = timed_steps(lambda: p3.execute(0), k)
+            extra["q1_partial_states_gathered"] = {"ms_per_step": d3 / k * 1e3, "lineitem_rows_per_s": rows_job * k / d3, "result_groups": r3.num_rows}
         line["extra"] = extra
-    print(json.dumps(line))
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        comm.close()
+        dist.destroy_process_group()
 
 
 def cpu_baseline_q3(T, sample_sf):
@@ -305,7 +229,4 @@ def cpu_baseline_q3(T, sample_sf):
 
 
 if __name__ == "__main__":
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        main_q1()
-    else:
-        main_q3()
+    main_q3()

@@ -224,6 +224,22 @@ def q1_split_plan(lineitem, state_capacity=64):
     return partial, full, final_src
 
 
+def q1_dist_plan(lineitem):
+    """q1 across the ranks of a node: the partial aggregate over the rank's lineitem shard, the partial states of all ranks
+    gathered (BroadcastExec: 4 groups x 8 state columns per rank -- no row exchange), final aggregate + projection + sort on
+    every rank."""
+    import arrow_ballista_amd as g
+    full = q1_plan(g.MemoryExec([lineitem]), two_phase=True)
+    node = full
+    while not (isinstance(node, g.AggregateExec) and node.mode == "FinalPartitioned"):
+        node = node.children()[0]
+    partial = node.input
+    while not (isinstance(partial, g.AggregateExec) and partial.mode == "Partial"):
+        partial = partial.children()[0]
+    node.input = g.BroadcastExec(partial)
+    return full
+
+
 def run_q1(tc, lineitem, two_phase=True, strategy="auto"):
     import arrow_ballista_amd as g
     plan = q1_plan(g.MemoryExec([lineitem]), two_phase, strategy)
