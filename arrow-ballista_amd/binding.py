@@ -121,6 +121,7 @@ def lib():
         "gpuq_plan_create": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
         "gpuq_plan_free": (None, [vp]),
         "gpuq_plan_num_partitions": (i32, [vp]),
+        "gpuq_plan_schema": (i32, [vp, C.POINTER(gpuq_field_info), i32, C.POINTER(i32)]),
         "gpuq_plan_execute": (i32, [vp, vp, i32, C.POINTER(gpuq_input), i32, C.POINTER(vp)]),
         "gpuq_plan_metrics": (i32, [vp, C.c_char_p, C.c_size_t]),
         "gpuq_plan_set_comm": (i32, [vp, vp]),

@@ -102,7 +102,7 @@ gpuq_field_info make_field(const std::string& name, const DType& t, bool nullabl
   return f;
 }
 
-bool g_upload = true;   // false inside gpuq_compile_check (no device)
+thread_local bool g_upload = true;   // false inside gpuq_compile_check (no device); per thread: other threads create operators meanwhile
 void upload_code(const CompiledProgram& p, DevBuf& dst) {
   if (!g_upload) return;
   dst.ensure(sizeof(DevCode));

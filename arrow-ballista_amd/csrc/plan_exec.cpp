@@ -428,6 +428,9 @@ struct PNode {
   virtual ~PNode() {}
   virtual std::vector<PNode*> children() { return {}; }
   virtual int partitions() { auto c = children(); return c.empty() ? 1 : c[0]->partitions(); }
+  // output schema, known before anything runs (QueryStageExecutor::schema(), execution_engine.rs:59; executor_server.rs:530-534
+  // parses the output partitioning from it before the task executes).  Default: the input's.
+  virtual PSchema schema() { auto c = children(); if (c.empty()) throw std::runtime_error("plan: node without a schema"); return c[0]->schema(); }
   virtual PTable execute(int part, Exec& x) = 0;
   PTable timed(std::chrono::steady_clock::time_point t0, PTable t) {
     m.elapsed_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -438,18 +441,19 @@ typedef std::unique_ptr<PNode> PNodeP;
 PNodeP build_node(const Json& j);
 
 struct MemoryExec : PNode {        // leaf: partitions[p] = index into the inputs handed to gpuq_plan_execute
-  PSchema schema; std::vector<int> parts; bool dense = false;
+  PSchema schema_; std::vector<int> parts; bool dense = false;
+  PSchema schema() override { return schema_; }
   int partitions() override { return (int)parts.size(); }
   PTable execute(int part, Exec& x) override {
     if (part < 0 || part >= (int)parts.size()) throw std::runtime_error("MemoryExec: partition out of range");
     const int slot = parts[(size_t)part];
     if (slot < 0 || slot >= x.n_inputs) throw std::runtime_error("MemoryExec: input " + std::to_string(slot) + " was not supplied");
     const gpuq_input& in = x.inputs[slot];
-    if (in.n_cols != (int)schema.size()) throw std::runtime_error("MemoryExec: input has " + std::to_string(in.n_cols) + " columns, schema has " + std::to_string(schema.size()));
+    if (in.n_cols != (int)schema_.size()) throw std::runtime_error("MemoryExec: input has " + std::to_string(in.n_cols) + " columns, schema_ has " + std::to_string(schema_.size()));
     PTable t; t.n = in.n_rows; t.dense = dense;
     for (int k = 0; k < in.n_via; ++k) t.via.push_back(in.via[k]);
     for (int i = 0; i < in.n_cols; ++i) {
-      PCol c; c.name = schema[(size_t)i].name; c.type = schema[(size_t)i].type; c.nullable = schema[(size_t)i].nullable; c.c = in.cols[i];
+      PCol c; c.name = schema_[(size_t)i].name; c.type = schema_[(size_t)i].type; c.nullable = schema_[(size_t)i].nullable; c.c = in.cols[i];
       int p, s; const int tid = type_id_of(c.type, p, s);
       if (c.c.type != tid) throw std::runtime_error("MemoryExec: column '" + c.name + "' does not have the declared type");
       t.cols.push_back(c);
@@ -460,6 +464,31 @@ struct MemoryExec : PNode {        // leaf: partitions[p] = index into the input
   }
   std::vector<int> sides;       // per column: index vector it is read through (views handed in by the caller)
 };
+
+// ---------------------------------------------------------------- static schemas (no device: gpuq_compile_check types the expressions)
+Json schema_fields(const PSchema& s) {
+  Json f = jarr();
+  for (auto& c : s) f.a.push_back(jobj({{"name", jstr(c.name)}, {"type", c.type}, {"nullable", jbool(c.nullable)}, {"side", jnum(0)}}));
+  return f;
+}
+std::vector<std::string> schema_names(const PSchema& s) { std::vector<std::string> v; for (auto& c : s) v.push_back(c.name); return v; }
+Json type_json_from_string(const std::string& t) {      // DType::to_string(): "Int64", "Decimal128(15, 2)" ...
+  if (t.rfind("Decimal128", 0) == 0) {
+    long long p = 38, sc = 0; std::sscanf(t.c_str(), "Decimal128(%lld, %lld)", &p, &sc);
+    if (t.find(',') != std::string::npos && t.find(", ") == std::string::npos) std::sscanf(t.c_str(), "Decimal128(%lld,%lld)", &p, &sc);
+    return jobj({{"Decimal128", jarr({jnum(p), jnum(sc)})}});
+  }
+  return jstr(t);
+}
+PSchema compiled_outputs(const Json& desc) {
+  std::vector<char> buf(1 << 20);
+  const int rc = gpuq_compile_check(desc.dump().c_str(), buf.data(), buf.size());
+  if (rc != GPUQ_OK) { const char* m = gpuq_last_error(nullptr); throw std::runtime_error(std::string("plan schema: ") + (m ? m : "descriptor does not compile")); }
+  const Json r = JsonParser(buf.data()).parse();
+  PSchema out;
+  for (auto& o : r.at("outputs").a) out.push_back({o.at("name").str(), type_json_from_string(o.at("type").str()), o.get_bool("nullable", true)});
+  return out;
+}
 
 struct PassThrough : PNode {       // CoalesceBatchesExec: whole partitions are already single tables
   PNodeP input;
@@ -475,6 +504,17 @@ struct FilterExec : PNode {
 struct ProjectionExec : PNode {
   PNodeP input; std::vector<Json> exprs; std::vector<std::string> names;
   std::vector<PNode*> children() override { return {input.get()}; }
+  PSchema schema() override {
+    const PSchema in = input->schema(); const auto nm = schema_names(in);
+    std::vector<Json> ex = exprs;
+    // LikeExpr is lowered to a Boolean column at run time: for typing, a like_expr is Boolean with its operand's nullability
+    for (auto& e : ex) e = rewrite_like(e, [&](const Json& v) { return jobj({{"is_not_null_expr", jobj({{"expr", jobj({{"not_expr", jobj({{"expr", jobj({{"is_null_expr", jobj({{"expr", v.at("expr")}})}})}})}})}})}}); });
+    Json exj = jarr();
+    for (size_t i = 0; i < ex.size(); ++i) exj.a.push_back(jobj({{"expr", rebind(ex[i], nm)}, {"name", jstr(names[i])}}));
+    PSchema out = compiled_outputs(jobj({{"op", jstr("project")}, {"input", jobj({{"fields", schema_fields(in)}})}, {"exprs", exj}}));
+    for (size_t i = 0; i < exprs.size() && i < out.size(); ++i) if (has_like(exprs[i])) out[i].nullable = true;
+    return out;
+  }
   PTable execute(int part, Exec& x) override;
 };
 
@@ -529,6 +569,18 @@ PTable ProjectionExec::execute(int part, Exec& x) {
 struct AggregateExec : PNode {
   PNodeP input; std::string mode, strategy = "auto"; Json group_expr, aggr_expr; int64_t expected_groups = 0, output_capacity = 0;
   std::vector<PNode*> children() override { return {input.get()}; }
+  PSchema schema() override {
+    const PSchema in = input->schema(); const auto nm = schema_names(in);
+    Json ge = jarr(), ae = jarr();
+    for (auto& g : group_expr.a) ge.a.push_back(jobj({{"expr", rebind(g.at("expr"), nm)}, {"name", g.at("name")}}));
+    for (auto& a : aggr_expr.a) {
+      std::vector<std::pair<std::string, Json>> o = {{"fn", a.at("fn")}, {"name", a.at("name")}};
+      for (const char* k : {"expr", "expr2"}) if (a.has(k)) o.push_back({k, rebind(a.at(k), nm)});
+      ae.a.push_back(jobj(o));
+    }
+    return compiled_outputs(jobj({{"op", jstr("aggregate")}, {"mode", jstr(mode)}, {"input", jobj({{"fields", schema_fields(in)}})}, {"strategy", jstr("hash")},
+                                  {"group_expr", ge}, {"aggr_expr", ae}}));
+  }
   PTable execute(int part, Exec& x) override {
     const bool final_ = mode == "Final" || mode == "FinalPartitioned";
     Fused f; if (final_) f.src = input.get(); else f = fuse(input.get());
@@ -585,6 +637,16 @@ struct HashJoinExec : PNode {
   PNodeP left, right; Json on; std::string join_type = "Inner", partition_mode = "CollectLeft"; bool null_equals_null = false; bool has_filter = false; Json filter;
   std::vector<PNode*> children() override { return {left.get(), right.get()}; }
   int partitions() override { return right->partitions(); }
+  PSchema schema() override {      // build_join_schema [UPSTREAM-KNOWLEDGE: datafusion joins/utils.rs]: left ++ right, the non-preserved side nullable
+    PSchema l = left->schema(), r = right->schema();
+    const std::string& jt = join_type;
+    if (jt == "LeftSemi" || jt == "LeftAnti") return l;
+    if (jt == "RightSemi" || jt == "RightAnti") return r;
+    if (jt == "Right" || jt == "Full") for (auto& c : l) c.nullable = true;
+    if (jt == "Left" || jt == "Full") for (auto& c : r) c.nullable = true;
+    l.insert(l.end(), r.begin(), r.end());
+    return l;
+  }
   struct Side { PTable t; bool has_pred = false; Json pred; };
   Side side(PNode* plan, int part, Exec& x) {
     Fused f = fuse(plan);
@@ -830,6 +892,11 @@ struct UnionExec : PNode {       // output partitions = the inputs' partitions, 
   std::vector<PNodeP> inputs;
   std::vector<PNode*> children() override { std::vector<PNode*> v; for (auto& i : inputs) v.push_back(i.get()); return v; }
   int partitions() override { int k = 0; for (auto& i : inputs) k += i->partitions(); return k; }
+  PSchema schema() override {      // first input's names and types; a column is nullable when it is in any input
+    PSchema s0 = inputs.at(0)->schema();
+    for (size_t k = 1; k < inputs.size(); ++k) { const PSchema sk = inputs[k]->schema(); for (size_t i = 0; i < s0.size() && i < sk.size(); ++i) s0[i].nullable = s0[i].nullable || sk[i].nullable; }
+    return s0;
+  }
   PTable execute(int part, Exec& x) override {
     for (auto& i : inputs) { const int k = i->partitions(); if (part < k) { PTable t = i->execute(part, x); m.output_rows += t.n; return t; } part -= k; }
     throw std::runtime_error("UnionExec: partition out of range");
@@ -927,6 +994,9 @@ struct ShuffleWriterExec : PNode {
   PNodeP input; std::string job_id, work_dir; int64_t stage_id = 0; bool hashed = false; Json hash_expr; int64_t partition_count = 0; int64_t batch_rows = 1 << 20;
   int64_t write_ns = 0, repart_ns = 0, input_rows = 0;      // ShuffleWriteMetrics, shuffle_writer.rs:139-160
   std::vector<PNode*> children() override { return {input.get()}; }
+  PSchema schema() override {      // the result batch of shuffle_writer.rs:470-520
+    return {{"partition", jstr("UInt32"), false}, {"path", jstr("Utf8"), false}, {"num_rows", jstr("UInt64"), false}, {"num_batches", jstr("UInt64"), false}, {"num_bytes", jstr("UInt64"), false}};
+  }
 
   ShuffleFile write_file(Exec& x, const PTable& view, int64_t partition, const std::string& path) {
     PTable t = arrow_layout(x, view);
@@ -1048,16 +1118,17 @@ struct ShuffleWriterExec : PNode {
 // locations, decoded on the device in one launch per file.  Local files only (a remote location is the Flight client's job);
 // a missing file is the reference's FetchFailed (:654), which makes the scheduler re-run the map stage.
 struct ShuffleReaderExec : PNode {
-  PSchema schema; std::vector<std::vector<std::string>> locations;
+  PSchema schema_; std::vector<std::vector<std::string>> locations;
+  PSchema schema() override { return schema_; }
   int partitions() override { return (int)locations.size(); }
   PTable execute(int part, Exec& x) override {
     auto t0 = std::chrono::steady_clock::now();
     if (part < 0 || part >= (int)locations.size()) throw std::runtime_error("ShuffleReaderExec: partition out of range");
-    std::vector<gpuq_field_info> fields(schema.size());
-    for (size_t i = 0; i < schema.size(); ++i) {
+    std::vector<gpuq_field_info> fields(schema_.size());
+    for (size_t i = 0; i < schema_.size(); ++i) {
       gpuq_field_info& f = fields[i]; f = gpuq_field_info{};
-      std::snprintf(f.name, sizeof(f.name), "%s", schema[i].name.c_str());
-      int p, s; f.type = type_id_of(schema[i].type, p, s); f.precision = p; f.scale = s; f.nullable = schema[i].nullable; f.repr = GPUQ_REPR_ARROW;
+      std::snprintf(f.name, sizeof(f.name), "%s", schema_[i].name.c_str());
+      int p, s; f.type = type_id_of(schema_[i].type, p, s); f.precision = p; f.scale = s; f.nullable = schema_[i].nullable; f.repr = GPUQ_REPR_ARROW;
     }
     std::vector<PTable> parts;
     std::vector<uint8_t> bytes;
@@ -1065,8 +1136,8 @@ struct ShuffleReaderExec : PNode {
     auto wrap = [&](gpuq_ipc_batch* b) {
       PTable t; t.n = gpuq_ipc_batch_num_rows(b);
       t.keep.push_back(BufP(new DevBuf(), [b](DevBuf* d) { delete d; gpuq_ipc_batch_free(b); }));
-      for (size_t i = 0; i < schema.size(); ++i) {
-        PCol c; c.name = schema[i].name; c.type = schema[i].type; c.nullable = schema[i].nullable;
+      for (size_t i = 0; i < schema_.size(); ++i) {
+        PCol c; c.name = schema_[i].name; c.type = schema_[i].type; c.nullable = schema_[i].nullable;
         gpuq_ipc_batch_column(b, (int)i, &c.c);
         t.cols.push_back(c); t.sides.push_back(0);
       }
@@ -1200,7 +1271,7 @@ PNodeP build_node(const Json& j) {
   PNodeP out;
   if (kind == "MemoryExec") {
     auto n = std::make_unique<MemoryExec>();
-    for (auto& f : v.at("schema").a) n->schema.push_back({f.at("name").str(), f.at("type"), f.get_bool("nullable", true)});
+    for (auto& f : v.at("schema").a) n->schema_.push_back({f.at("name").str(), f.at("type"), f.get_bool("nullable", true)});
     for (auto& p : v.at("partitions").a) n->parts.push_back((int)p.i64());
     n->dense = v.get_bool("dense", false);
     if (v.has("sides")) for (auto& s : v.at("sides").a) n->sides.push_back((int)s.i64());
@@ -1257,7 +1328,7 @@ PNodeP build_node(const Json& j) {
     out = std::move(n);
   } else if (kind == "ShuffleReaderExec") {
     auto n = std::make_unique<ShuffleReaderExec>();
-    for (auto& f : v.at("schema").a) n->schema.push_back({f.at("name").str(), f.at("type"), f.get_bool("nullable", true)});
+    for (auto& f : v.at("schema").a) n->schema_.push_back({f.at("name").str(), f.at("type"), f.get_bool("nullable", true)});
     for (auto& p : v.at("partition").a) { n->locations.emplace_back(); for (auto& l : p.a) n->locations.back().push_back(l.is_obj() ? l.at("path").str() : l.str()); }
     out = std::move(n);
   } else throw Unsupported("plan: node type '" + kind + "' is not executed natively");
@@ -1296,7 +1367,8 @@ int gpuq_plan_create(gpuq_ctx* ctx, const char* plan_json, gpuq_plan** out) {
   if (!out) return GPUQ_ERR_INVALID;
   *out = nullptr;
   return plan_guarded([&]() {
-    if (!ctx) throw std::runtime_error("ctx is NULL");
+    // ctx == NULL: a plan for validation only (gpuq_plan_schema / gpuq_plan_num_partitions work without a device; a
+    // scheduler-side process can check and type a stage plan) -- gpuq_plan_execute then fails
     if (!plan_json) throw std::runtime_error("plan_json is NULL");
     std::unique_ptr<gpuq_plan> p(new gpuq_plan());
     p->ctx = ctx;
@@ -1313,6 +1385,7 @@ int gpuq_plan_execute(gpuq_plan* p, void* stream, int partition, const gpuq_inpu
   if (!p || !out) return GPUQ_ERR_INVALID;
   *out = nullptr;
   return plan_guarded([&]() {
+    if (!p->ctx) throw std::runtime_error("this plan was created without a context (validation only): it cannot execute");
     if (!p->pin) HIPCHECK(hipHostMalloc((void**)&p->pin, 64, hipHostMallocDefault));
     (void)use_stream(stream);
     Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin; x.memo = &p->memo; x.comm = p->comm;
@@ -1351,6 +1424,23 @@ void gpuq_result_free(gpuq_result* r) { delete r; }
 
 // Device time of the dominant kernel of the plan's operators (gpuq_op_profile on every compiled operator): reports the
 // operator that accumulated the most kernel time since profiling was enabled.
+int gpuq_plan_schema(gpuq_plan* p, gpuq_field_info* fields_out, int cap, int* n_out) {
+  if (!p || !n_out) return GPUQ_ERR_INVALID;
+  return plan_guarded([&]() {
+    const PSchema s = p->root->schema();
+    *n_out = (int)s.size();
+    if (!fields_out || cap < (int)s.size()) { if (!fields_out && cap == 0) return; throw Capacity("plan schema has " + std::to_string(s.size()) + " fields"); }
+    for (size_t i = 0; i < s.size(); ++i) {
+      gpuq_field_info f{};
+      std::snprintf(f.name, sizeof(f.name), "%s", s[i].name.c_str());
+      int pr = 0, sc = 0; f.type = type_id_of(s[i].type, pr, sc); f.precision = pr; f.scale = sc; f.nullable = s[i].nullable ? 1 : 0;
+      f.repr = GPUQ_REPR_ARROW;
+      DType dt; dt.id = f.type; dt.p = pr; dt.s = sc; f.width = (f.type == T_BOOL) ? 0 : type_width(dt);
+      fields_out[i] = f;
+    }
+  });
+}
+
 int gpuq_plan_set_comm(gpuq_plan* p, gpuq_comm* comm) { if (!p) return GPUQ_ERR_INVALID; p->comm = comm; return GPUQ_OK; }
 
 int gpuq_plan_profile(gpuq_plan* p, int enable, float* kernel_ms_out, int* launches_out, char* op_desc_out, size_t cap) {

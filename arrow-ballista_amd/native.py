@@ -38,6 +38,9 @@ def plan_to_json(node, tc, inputs):
     sub = lambda n: plan_to_json(n, tc, inputs)
     if isinstance(node, P.MemoryExec):
         slots, schema, dense, sides = [], None, False, None
+        if all(p is None for p in node.partitions):      # a schema-only leaf (plan validation / typing without data)
+            return {"MemoryExec": {"schema": [{"name": f["name"], "type": f["type"], "nullable": bool(f.get("nullable", True))} for f in node.schema()],
+                                   "partitions": list(range(len(inputs), len(inputs) + len(node.partitions))), "dense": False}}
         for p in range(node.output_partition_count()):
             tab = node.execute(p, tc)
             slots.append(len(inputs))
@@ -223,6 +226,16 @@ class NativePlan:
         inp.n_rows = result.num_rows
         self._arr[slot] = inp
         self._keep[slot] = (inp, cols, result)
+
+    def schema(self):
+        """[(name, type json, nullable)] of the plan's output, from the plan alone (gpuq_plan_schema: nothing runs)."""
+        from .table import type_json
+        L = self.tc.ctx.L
+        n = C.c_int(0)
+        _check(L, L.gpuq_plan_schema(self.h, None, 0, C.byref(n)))
+        f = (B.gpuq_field_info * max(1, n.value))()
+        _check(L, L.gpuq_plan_schema(self.h, f, n.value, C.byref(n)))
+        return [(f[i].name.decode(), type_json(f[i].type, f[i].precision, f[i].scale), bool(f[i].nullable)) for i in range(n.value)]
 
     def set_comm(self, comm):
         """Attach the ranks of the node (parallel.Comm) for RepartitionExec / BroadcastExec nodes; the comm must outlive the plan."""

@@ -321,6 +321,11 @@ typedef struct gpuq_result gpuq_result;
 int gpuq_plan_create(gpuq_ctx* ctx, const char* plan_json, gpuq_plan** out);
 void gpuq_plan_free(gpuq_plan* plan);
 int gpuq_plan_num_partitions(gpuq_plan* plan);
+/* The plan's output schema BEFORE anything runs -- QueryStageExecutor::schema() (execution_engine.rs:59), which the executor
+   reads to parse the stage's output partitioning ahead of execution (executor_server.rs:530-534).  Host only (no device work):
+   expressions are typed by the same compiler that builds the operators.  Size query with fields_out == NULL && cap == 0;
+   GPUQ_ERR_CAPACITY when cap is too small (*n_out set). */
+int gpuq_plan_schema(gpuq_plan* plan, gpuq_field_info* fields_out, int cap, int* n_out);
 int gpuq_plan_execute(gpuq_plan* plan, void* stream, int partition, const gpuq_input* inputs, int n_inputs, gpuq_result** out);
 /* The ranks of the node for RepartitionExec / BroadcastExec nodes (the comm outlives the plan; NULL detaches). */
 struct gpuq_comm;

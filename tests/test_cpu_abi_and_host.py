@@ -304,3 +304,59 @@ def test_ipc_schema_metadata_round_trip_with_arrow_cpp():
     l0, l1 = C.c_int64(0), C.c_int64(0)
     assert L.gpuq_ipc_schema_message(fields, 2, None, 0, C.byref(l0)) == 0 and L.gpuq_ipc_schema_message_kv(fields, 2, None, None, 0, None, 0, C.byref(l1)) == 0
     assert l0.value == l1.value
+
+
+def test_plan_schema_is_known_before_execution_and_without_a_device():
+    """QueryStageExecutor::schema() (execution_engine.rs:59) is read BEFORE the stage runs (executor_server.rs:530-534).
+    gpuq_plan_schema types a whole plan on the host -- here q1's two-stage shape and q3 (joins, decimal arithmetic with
+    DataFusion's precision rules, AVG widening), built without a GPU context -- and must agree with what the oracle's typing says
+    (the GPU suite checks the same schemas against executed results)."""
+    import ctypes as C
+    import json
+    import pyarrow as pa
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd import binding as B
+    from arrow_ballista_amd.native import plan_to_json
+    from arrow_ballista_amd.table import type_json
+    import tpch_util as T
+    L = B.lib()
+
+    def host_schema(plan):
+        class _TC:      # plan_to_json only asks MemoryExec leaves for their tables
+            pass
+        inputs = []
+        js = json.dumps(plan_to_json(plan, _TC(), inputs))
+        h = C.c_void_p()
+        assert L.gpuq_plan_create(None, js.encode(), C.byref(h)) == 0, L.gpuq_plan_last_error()
+        n = C.c_int(0)
+        assert L.gpuq_plan_schema(h, None, 0, C.byref(n)) == 0, L.gpuq_plan_last_error()
+        f = (B.gpuq_field_info * n.value)()
+        assert L.gpuq_plan_schema(h, f, n.value, C.byref(n)) == 0, L.gpuq_plan_last_error()
+        out = C.c_void_p()
+        assert L.gpuq_plan_execute(h, None, 0, None, 0, C.byref(out)) != 0 and b"without a context" in L.gpuq_plan_last_error()
+        L.gpuq_plan_free(h)
+        return [(f[i].name.decode(), type_json(f[i].type, f[i].precision, f[i].scale), bool(f[i].nullable)) for i in range(n.value)]
+
+    def empty(cols):
+        return g.MemoryExec([None], schema=[{"name": n, "type": t, "nullable": False} for n, t in cols])
+    D = T.D152
+    li = empty([("l_orderkey", "Int64"), ("l_suppkey", "Int64"), ("l_quantity", D), ("l_extendedprice", D), ("l_discount", D), ("l_tax", D),
+                ("l_returnflag", "Utf8"), ("l_linestatus", "Utf8"), ("l_shipdate", "Date32")])
+    q1 = host_schema(T.q1_plan(li))
+    assert [n for n, _, _ in q1] == ["l_returnflag", "l_linestatus", "sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc", "count_order"]
+    dec = lambda p, s: {"Decimal128": [p, s]}
+    assert [t for _, t, _ in q1] == ["Utf8", "Utf8", dec(25, 2), dec(25, 2), dec(38, 4), dec(38, 6), dec(19, 6), dec(19, 6), dec(19, 6), "Int64"]
+    od = empty([("o_orderkey", "Int64"), ("o_custkey", "Int64"), ("o_orderdate", "Date32"), ("o_shippriority", "Int32")])
+    cu = empty([("c_custkey", "Int64"), ("c_nationkey", "Int64"), ("c_mktsegment", "Utf8")])
+    q3 = host_schema(T.q3_plan(cu, od, li))
+    assert [(n, t) for n, t, _ in q3] == [("l_orderkey", "Int64"), ("revenue", dec(38, 4)), ("o_orderdate", "Date32"), ("o_shippriority", "Int32")]
+    # outer joins make the non-preserved side nullable; semi joins keep one side
+    cs, os_ = cu.schema(), od.schema()
+    from arrow_ballista_amd.expr import col
+    on = [(col("c_custkey", cs), col("o_custkey", os_))]
+    full = host_schema(g.HashJoinExec(cu, od, on, None, "Full", "CollectLeft", False))
+    assert all(nullable for _, _, nullable in full) and len(full) == 7
+    assert host_schema(g.HashJoinExec(cu, od, on, None, "RightSemi", "CollectLeft", False)) == [(f["name"], f["type"], False) for f in os_]
+    # the stage root's result batch (shuffle_writer.rs:470-520)
+    w = host_schema(g.ShuffleWriterExec("j", 1, od, "/tmp/x", ([col("o_custkey", os_)], 4)))
+    assert [n for n, _, _ in w] == ["partition", "path", "num_rows", "num_batches", "num_bytes"] and [t for _, t, _ in w] == ["UInt32", "Utf8", "UInt64", "UInt64", "UInt64"]
