@@ -28,12 +28,18 @@ def arrow_rows(t):
 
 
 def native_rows(tc, plan, partition=0):
+    """(rows, NativePlan) of a plan executed by the native executor.  Every plan that goes through here also checks
+    gpuq_plan_schema: the schema announced BEFORE execution (QueryStageExecutor::schema(), execution_engine.rs:59) is the schema
+    of what execution returns -- names, types, and never "non-nullable" for a column that comes back nullable."""
+    from arrow_ballista_amd.table import type_json
     np_ = g.NativePlan(plan, tc)
-    try:
-        r = np_.execute(partition)
-        return arrow_rows(r.to_arrow()), np_
-    finally:
-        pass
+    announced = np_.schema()
+    r = np_.execute(partition)
+    _cols, fields = r.columns_c()
+    got = [(fields[i].name.decode(), type_json(fields[i].type, fields[i].precision, fields[i].scale), bool(fields[i].nullable)) for i in range(r.num_columns)]
+    assert [(n, t) for n, t, _ in announced] == [(n, t) for n, t, _ in got], (announced, got)
+    assert all(a[2] or not b[2] for a, b in zip(announced, got)), (announced, got)
+    return arrow_rows(r.to_arrow()), np_
 
 
 @pytest.mark.parametrize("n", [1, 65, 200_000])
