@@ -5,7 +5,7 @@ import os
 
 T_NULL, T_BOOL, T_INT32, T_INT64, T_DATE32, T_FLOAT64, T_DECIMAL128, T_UTF8, T_UINT32, T_UINT64 = range(10)
 REPR_ARROW, REPR_PACKED15 = 0, 1
-_STATUS = {1: "INVALID", 2: "HIP", 3: "UNSUPPORTED", 4: "CAPACITY", 5: "INTERNAL"}
+_STATUS = {6: "CANCELLED", 1: "INVALID", 2: "HIP", 3: "UNSUPPORTED", 4: "CAPACITY", 5: "INTERNAL"}
 
 
 class GpuqError(RuntimeError):
@@ -123,6 +123,11 @@ def lib():
         "gpuq_plan_num_partitions": (i32, [vp]),
         "gpuq_plan_schema": (i32, [vp, C.POINTER(gpuq_field_info), i32, C.POINTER(i32)]),
         "gpuq_plan_execute": (i32, [vp, vp, i32, C.POINTER(gpuq_input), i32, C.POINTER(vp)]),
+        "gpuq_plan_execute_async": (i32, [vp, vp, i32, C.POINTER(gpuq_input), i32, C.POINTER(vp)]),
+        "gpuq_task_poll": (i32, [vp, C.POINTER(i32)]),
+        "gpuq_task_cancel": (i32, [vp]),
+        "gpuq_task_wait": (i32, [vp, C.POINTER(vp)]),
+        "gpuq_task_free": (None, [vp]),
         "gpuq_plan_metrics": (i32, [vp, C.c_char_p, C.c_size_t]),
         "gpuq_plan_set_comm": (i32, [vp, vp]),
         "gpuq_comm_unique_id": (i32, [vp]),

@@ -19,6 +19,8 @@
 #include "expr_compile.h"
 #include "json.h"
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cerrno>
 #include <chrono>
 #include <random>
@@ -143,9 +145,13 @@ struct Exec {
   uint64_t* pin = nullptr;                                // pinned host words for count read-backs
   std::map<std::string, gpuq_op*>* memo = nullptr;       // (call site, input layout) -> operator: skips rebuilding the descriptor
   gpuq_comm* comm = nullptr;                              // ranks of the node (gpuq_plan_set_comm); nullptr = a single-GPU plan
+  const std::atomic<int>* cancel = nullptr;               // set by gpuq_task_cancel: checked between operator calls
 };
+struct Cancelled : std::runtime_error { using std::runtime_error::runtime_error; };
+inline void check_cancel(const Exec& x) { if (x.cancel && x.cancel->load(std::memory_order_relaxed)) throw Cancelled("task cancelled"); }
 
 void check(Exec& x, int rc) {
+  check_cancel(x);      // every operator call passes through here: the granularity of cancellation is one operator
   if (rc == GPUQ_OK) return;
   const char* m = gpuq_last_error(x.ctx);
   const std::string msg = m ? m : "gpuq error";
@@ -1351,6 +1357,7 @@ struct gpuq_result { PTable t; std::vector<gpuq_field_info> fields; };
 namespace {
 template <class F> int plan_guarded(F&& f) {
   try { f(); return GPUQ_OK; }
+  catch (const Cancelled& e) { g_plan_error = e.what(); return GPUQ_ERR_CANCELLED; }
   catch (const HipError& e) { g_plan_error = e.what(); return GPUQ_ERR_HIP; }
   catch (const Unsupported& e) { g_plan_error = e.what(); return GPUQ_ERR_UNSUPPORTED; }
   catch (const Capacity& e) { g_plan_error = e.what(); return GPUQ_ERR_CAPACITY; }
@@ -1381,15 +1388,20 @@ void gpuq_plan_free(gpuq_plan* p) { delete p; }
 
 int gpuq_plan_num_partitions(gpuq_plan* p) { return p ? p->root->partitions() : 0; }
 
-int gpuq_plan_execute(gpuq_plan* p, void* stream, int partition, const gpuq_input* inputs, int n_inputs, gpuq_result** out) {
-  if (!p || !out) return GPUQ_ERR_INVALID;
+static int plan_execute_impl(gpuq_plan* p, void* stream, int partition, const gpuq_input* inputs, int n_inputs, const std::atomic<int>* cancel, gpuq_result** out) {
   *out = nullptr;
   return plan_guarded([&]() {
     if (!p->ctx) throw std::runtime_error("this plan was created without a context (validation only): it cannot execute");
     if (!p->pin) HIPCHECK(hipHostMalloc((void**)&p->pin, 64, hipHostMallocDefault));
     (void)use_stream(stream);
-    Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin; x.memo = &p->memo; x.comm = p->comm;
-    PTable t = materialize(x, p->root->execute(partition, x));
+    Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin; x.memo = &p->memo; x.comm = p->comm; x.cancel = cancel;
+    PTable t;
+    try { t = materialize(x, p->root->execute(partition, x)); check_cancel(x); }
+    catch (...) {
+      // whatever was queued keeps running: drain it before the buffers it uses go back to the pool (unwinding frees them)
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      throw;
+    }
     HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
     std::unique_ptr<gpuq_result> r(new gpuq_result());
     for (auto& c : t.cols) {
@@ -1404,6 +1416,60 @@ int gpuq_plan_execute(gpuq_plan* p, void* stream, int partition, const gpuq_inpu
     r->t = std::move(t);
     *out = r.release();
   });
+}
+
+int gpuq_plan_execute(gpuq_plan* p, void* stream, int partition, const gpuq_input* inputs, int n_inputs, gpuq_result** out) {
+  if (!p || !out) return GPUQ_ERR_INVALID;
+  return plan_execute_impl(p, stream, partition, inputs, n_inputs, nullptr, out);
+}
+
+// ---- asynchronous execution + cancellation.  The reference runs a task as a future on its task-runner pool and cancels it by
+// dropping the future at an await point (ballista/executor/src/executor.rs:201-240: no callback; whatever holds resources cleans
+// up in Drop).  Here a task is a worker thread running the plan on the caller's stream; cancel raises a flag the executor checks
+// between operator calls, the worker then drains the stream and releases every pooled buffer it held.
+struct gpuq_task {
+  gpuq_plan* plan = nullptr; void* stream = nullptr; int partition = 0;
+  std::vector<gpuq_input> inputs; std::vector<std::vector<gpuq_column>> cols;      // private copies: the caller's arrays may go away
+  std::thread th; std::atomic<int> cancel{0}, done{0};
+  int rc = GPUQ_OK; std::string err; gpuq_result* res = nullptr;
+};
+
+int gpuq_plan_execute_async(gpuq_plan* p, void* stream, int partition, const gpuq_input* inputs, int n_inputs, gpuq_task** out) {
+  if (!p || !out || n_inputs < 0 || (n_inputs > 0 && !inputs)) return GPUQ_ERR_INVALID;
+  *out = nullptr;
+  return plan_guarded([&]() {
+    std::unique_ptr<gpuq_task> t(new gpuq_task());
+    t->plan = p; t->stream = stream; t->partition = partition;
+    t->inputs.assign(inputs, inputs + n_inputs); t->cols.resize((size_t)n_inputs);
+    for (int i = 0; i < n_inputs; ++i) {
+      if (inputs[i].n_cols > 0 && inputs[i].cols) t->cols[(size_t)i].assign(inputs[i].cols, inputs[i].cols + inputs[i].n_cols);
+      t->inputs[(size_t)i].cols = t->cols[(size_t)i].data();
+    }
+    gpuq_task* raw = t.get();
+    int dev = 0; (void)hipGetDevice(&dev);      // the caller's current device (the context's: every context call makes it current)
+    t->th = std::thread([raw, dev]() {
+      (void)hipSetDevice(dev);
+      raw->rc = plan_execute_impl(raw->plan, raw->stream, raw->partition, raw->inputs.data(), (int)raw->inputs.size(), &raw->cancel, &raw->res);
+      if (raw->rc != GPUQ_OK) raw->err = g_plan_error;      // the error text is per thread: carry it to whoever waits
+      raw->done.store(1, std::memory_order_release);
+    });
+    *out = t.release();
+  });
+}
+int gpuq_task_poll(gpuq_task* t, int* done_out) { if (!t || !done_out) return GPUQ_ERR_INVALID; *done_out = t->done.load(std::memory_order_acquire); return GPUQ_OK; }
+int gpuq_task_cancel(gpuq_task* t) { if (!t) return GPUQ_ERR_INVALID; t->cancel.store(1, std::memory_order_relaxed); return GPUQ_OK; }
+int gpuq_task_wait(gpuq_task* t, gpuq_result** out) {
+  if (!t) return GPUQ_ERR_INVALID;
+  if (t->th.joinable()) t->th.join();
+  if (out) { *out = t->res; t->res = nullptr; }
+  if (t->rc != GPUQ_OK) g_plan_error = t->err;
+  return t->rc;
+}
+void gpuq_task_free(gpuq_task* t) {
+  if (!t) return;
+  if (t->th.joinable()) { t->cancel.store(1, std::memory_order_relaxed); t->th.join(); }      // dropping a running task cancels it, as dropping the future does
+  if (t->res) gpuq_result_free(t->res);
+  delete t;
 }
 
 int gpuq_result_record(const gpuq_result* r, void** base_out, size_t* bytes_out, int64_t* cap_out) {

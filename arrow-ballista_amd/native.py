@@ -189,6 +189,37 @@ class NativeResult:
             pass
 
 
+class NativeTask:
+    def __init__(self, ctx, handle, plan):
+        self.ctx, self.h, self._plan = ctx, handle, plan
+
+    def done(self):
+        d = C.c_int(0)
+        _check(self.ctx.L, self.ctx.L.gpuq_task_poll(self.h, C.byref(d)))
+        return bool(d.value)
+
+    def cancel(self):
+        _check(self.ctx.L, self.ctx.L.gpuq_task_cancel(self.h))
+
+    def wait(self):
+        """NativeResult, or raises GpuqError (status 6 = cancelled)."""
+        out = C.c_void_p()
+        rc = self.ctx.L.gpuq_task_wait(self.h, C.byref(out))
+        _check(self.ctx.L, rc)
+        return NativeResult(self.ctx, out)
+
+    def close(self):
+        if self.h:
+            self.ctx.L.gpuq_task_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class NativePlan:
     def __init__(self, plan, tc):
         self.tc = tc
@@ -247,6 +278,13 @@ class NativePlan:
         out = C.c_void_p()
         _check(L, L.gpuq_plan_execute(self.h, self.tc.stream_ptr(), int(partition), self._arr, len(self.inputs), C.byref(out)))
         return NativeResult(self.tc.ctx, out)
+
+    def execute_async(self, partition=0):
+        """Start the plan on a library worker thread; returns a NativeTask (wait / poll / cancel)."""
+        L = self.tc.ctx.L
+        h = C.c_void_p()
+        _check(L, L.gpuq_plan_execute_async(self.h, self.tc.stream_ptr(), int(partition), self._arr, len(self.inputs), C.byref(h)))
+        return NativeTask(self.tc.ctx, h, self)
 
     def profile(self, enable=True):
         """(kernel ms, launches, operator descriptor) of the plan's most expensive operator since profiling was enabled."""

@@ -43,7 +43,8 @@ typedef enum gpuq_status {
   GPUQ_ERR_HIP = 2,          /* HIP runtime error (message has the hipError) */
   GPUQ_ERR_UNSUPPORTED = 3,  /* valid request the device path does not implement (fails loudly, never falls back) */
   GPUQ_ERR_CAPACITY = 4,     /* caller-provided output capacity too small; required size reported */
-  GPUQ_ERR_INTERNAL = 5
+  GPUQ_ERR_INTERNAL = 5,
+  GPUQ_ERR_CANCELLED = 6     /* gpuq_task_cancel reached the task before it finished */
 } gpuq_status;
 
 /* Logical types (subset of ballista/core/proto/datafusion.proto:1004-1040 ArrowType). */
@@ -327,6 +328,20 @@ int gpuq_plan_num_partitions(gpuq_plan* plan);
    GPUQ_ERR_CAPACITY when cap is too small (*n_out set). */
 int gpuq_plan_schema(gpuq_plan* plan, gpuq_field_info* fields_out, int cap, int* n_out);
 int gpuq_plan_execute(gpuq_plan* plan, void* stream, int partition, const gpuq_input* inputs, int n_inputs, gpuq_result** out);
+/* Asynchronous execution and cancellation.  The reference runs a task as a future on its task-runner pool and cancels it by
+   dropping that future (ballista/executor/src/executor.rs:201-240; whatever holds resources cleans up in Drop).  Here
+   gpuq_plan_execute_async starts the plan on a worker thread (same semantics as gpuq_plan_execute; the gpuq_input / gpuq_column
+   arrays are copied, the device buffers they point to must stay valid until the task is done) and returns at once;
+   gpuq_task_wait blocks and hands over the result (or the error: GPUQ_ERR_CANCELLED after a cancel that came in time);
+   gpuq_task_cancel raises a flag the executor checks between operator calls -- the worker then drains `stream` and returns every
+   pooled buffer it held, so the plan, the stream and the context are immediately usable again; gpuq_task_free on a running task
+   cancels and joins it (the Drop of the Rust wrapper).  One task per plan at a time. */
+typedef struct gpuq_task gpuq_task;
+int gpuq_plan_execute_async(gpuq_plan* plan, void* stream, int partition, const gpuq_input* inputs, int n_inputs, gpuq_task** out);
+int gpuq_task_poll(gpuq_task* task, int* done_out);
+int gpuq_task_cancel(gpuq_task* task);
+int gpuq_task_wait(gpuq_task* task, gpuq_result** out);
+void gpuq_task_free(gpuq_task* task);
 /* The ranks of the node for RepartitionExec / BroadcastExec nodes (the comm outlives the plan; NULL detaches). */
 struct gpuq_comm;
 int gpuq_plan_set_comm(gpuq_plan* plan, struct gpuq_comm* comm);

@@ -280,3 +280,38 @@ def test_native_like(tc):
     got, _ = native_rows(tc, g.ProjectionExec(exprs, inner))
     sub = ot.take(O.filter_rows(ot, binary(col("k", s), Op.Gt, lit(10))))
     assert got == ora_rows(O.project(sub, [e for e, _ in exprs], [n for _, n in exprs]))
+
+
+def test_async_execute_and_cancel(tc):
+    """gpuq_plan_execute_async / gpuq_task_cancel: the reference cancels a task by dropping its future (executor.rs:201-240).
+    A q3 over 3 M lineitem rows is started on a worker thread and cancelled at once; the wait reports CANCELLED (or, if the
+    task won the race, its complete result); the same plan, stream and context then run the query again, synchronously and
+    asynchronously, with the oracle's rows; dropping a running task (gpuq_task_free) is a cancel too."""
+    n_li, n_cust = 3_000_000, 30_000
+    cols = ("l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate")
+    li = T.gen_lineitem_device(tc, n_li, n_supp=100, columns=cols)
+    od = T.gen_orders_device(tc, n_li // 4, n_cust)
+    cu = T.gen_customer_device(tc, n_cust)
+    plan = g.NativePlan(T.q3_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li])), tc)
+    exp, _st = T.q3_oracle_c(T.gen_q3_tables_host(n_li, n_cust))
+    want = sorted(exp)
+    assert sorted(tuple(r) for r in arrow_rows(plan.execute(0).to_arrow())) == want      # warm (JIT compiled)
+    cancelled = 0
+    for it in range(6):
+        task = plan.execute_async(0)
+        if it % 2 == 0:
+            task.cancel()
+        try:
+            res = task.wait()
+            assert sorted(tuple(r) for r in arrow_rows(res.to_arrow())) == want
+        except g.GpuqError as e:
+            assert e.status == 6 and it % 2 == 0, e
+            cancelled += 1
+        assert task.done()
+        task.close()
+        # the plan, the stream and the pool are intact: the next run is right
+        assert sorted(tuple(r) for r in arrow_rows(plan.execute(0).to_arrow())) == want
+    assert cancelled >= 1, "no cancel ever arrived before the task finished"
+    t2 = plan.execute_async(0)
+    t2.close()                                              # free while running = cancel + join
+    assert sorted(tuple(r) for r in arrow_rows(plan.execute(0).to_arrow())) == want
