@@ -584,8 +584,15 @@ struct AggregateExec : PNode {
       for (const char* k : {"expr", "expr2"}) if (a.has(k)) o.push_back({k, rebind(a.at(k), nm)});
       ae.a.push_back(jobj(o));
     }
-    return compiled_outputs(jobj({{"op", jstr("aggregate")}, {"mode", jstr(mode)}, {"input", jobj({{"fields", schema_fields(in)}})}, {"strategy", jstr("hash")},
-                                  {"group_expr", ge}, {"aggr_expr", ae}}));
+    PSchema out = compiled_outputs(jobj({{"op", jstr("aggregate")}, {"mode", jstr(mode)}, {"input", jobj({{"fields", schema_fields(in)}})}, {"strategy", jstr("hash")},
+                                         {"group_expr", ge}, {"aggr_expr", ae}}));
+    // DataFusion declares every aggregate but COUNT nullable (an empty group has no SUM / MIN / MAX / AVG) [UPSTREAM-KNOWLEDGE:
+    // Sum::field etc.]; the operator may type a column tighter when its inputs cannot be NULL -- announce the declared form
+    // (COUNT too: the merged count of a two-phase aggregate comes back through a nullable state column here; announcing
+    // "nullable" for a column that never holds a NULL is harmless, the reverse is not)
+    if (mode == "Final" || mode == "FinalPartitioned" || mode == "Single")
+      for (size_t i = group_expr.a.size(); i < out.size(); ++i) out[i].nullable = true;
+    return out;
   }
   PTable execute(int part, Exec& x) override {
     const bool final_ = mode == "Final" || mode == "FinalPartitioned";
