@@ -84,6 +84,14 @@ def lib():
         "gpuq_copy_h2d": (i32, [vp, vp, vp, vp, C.c_size_t]),
         "gpuq_copy_d2h": (i32, [vp, vp, vp, vp, C.c_size_t]),
         "gpuq_table_import_arrow": (i32, [vp, vp, vp, vp, C.POINTER(vp)]),
+        "gpuq_ingest_create": (i32, [vp, vp, i64, i64, i32, C.POINTER(vp)]),
+        "gpuq_ingest_push": (i32, [vp, vp]),
+        "gpuq_ingest_rows_landed": (i32, [vp, C.POINTER(i64)]),
+        "gpuq_ingest_wait_rows": (i32, [vp, i64, C.POINTER(i64)]),
+        "gpuq_ingest_columns": (i32, [vp, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info), i32, C.POINTER(i32)]),
+        "gpuq_ingest_stats": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+        "gpuq_ingest_free": (None, [vp]),
+        "gpuq_ingest_last_error": (C.c_char_p, []),
         "gpuq_table_num_rows": (i64, [vp]),
         "gpuq_table_num_columns": (i32, [vp]),
         "gpuq_table_column": (i32, [vp, i32, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info)]),

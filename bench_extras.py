@@ -391,6 +391,81 @@ def like_micro(tc, T, g, n=1 << 23, reps=5):
     return out
 
 
+def ingest_q1(tc, T, g, sf=10, batch_rows=65536, threads=(4, 8, 16), chunk_batches=64):
+    """BASELINE configs[1] as the boundary hands it over: q1's 7 lineitem columns as 64 Ki-row host Arrow batches (78 B/row).
+    (a) ingest alone (gpuq_ingest_push of every batch, wait for the last): H2D GB/s against the PCIe Gen5 x16 ceiling, for
+    several staging-thread counts; (b) PCIe-inclusive q1: the partial aggregate consumes the landed prefix in chunks of
+    `chunk_batches` batches while the staging threads keep copying, the final aggregate merges the chunks' states; wall time from
+    the first push to the result, next to the HBM-resident time of the same rows."""
+    import pyarrow as pa
+    import torch
+    from arrow_ballista_amd.ingest import Ingest
+    n = T.LINEITEM_ROWS.get(sf, int(6_000_000 * sf))
+    n = n // batch_rows * batch_rows                      # whole batches
+    cols = ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"]
+    host = T.lineitem_host_to_arrow(T.gen_lineitem_host(n), n).select(cols)
+    host = host.cast(pa.schema([pa.field(f.name, f.type, nullable=False) for f in host.schema])).combine_chunks()
+    batches = [host.slice(i, batch_rows).to_batches()[0] for i in range(0, n, batch_rows)]
+    raw = 78 * n
+    out = {"rows": n, "batches": len(batches), "batch_rows": batch_rows, "bytes": raw, "pcie_gen5_x16_spec_GBps": 63.0, "ingest_only": []}
+    for nt in threads:
+        best = None
+        for _ in range(2):
+            ing = Ingest(tc, host.schema, n, 2 * n + 64, n_threads=nt)
+            t0 = time.perf_counter()
+            for b in batches:
+                ing.push(b)
+            ing.wait_rows(n)
+            dt = time.perf_counter() - t0
+            ing.close()
+            best = dt if best is None or dt < best else best
+        out["ingest_only"].append({"threads": nt, "ms": best * 1e3, "GBps": raw / best / 1e9, "frac_of_pcie_spec": raw / best / 1e9 / 63.0})
+    nt = max(out["ingest_only"], key=lambda e: e["GBps"])["threads"]
+    # HBM-resident reference: the same rows already on the device
+    ing = Ingest(tc, host.schema, n, 2 * n + 64, n_threads=nt)
+    for b in batches:
+        ing.push(b)
+    ing.wait_rows(n)
+    resident = ing.table(0, n)
+    plan = g.NativePlan(T.q1_plan(g.MemoryExec([resident]), two_phase=True), tc)
+    for _ in range(3):
+        plan.execute(0)
+    tc.ctx.jit_wait()
+    _sync(tc); t0 = time.perf_counter(); ref = plan.execute(0); _sync(tc)
+    out["q1_hbm_resident_ms"] = (time.perf_counter() - t0) * 1e3
+    ref_rows = ref.to_arrow().to_pylist()
+    del plan, ref, resident
+    ing.close()
+    # pipelined: compiled plans are reused across chunks (same layout), so only data movement + kernels are timed
+    chunk = chunk_batches * batch_rows
+    best, rows_out = None, None
+    for rep in range(3):
+        ing = Ingest(tc, host.schema, n, 2 * n + 64, n_threads=nt)
+        t0 = time.perf_counter()
+        for b in batches:
+            ing.push(b)
+        states, done = [], 0
+        while done < n:
+            k = min(chunk, n - done)
+            ing.wait_rows(done + k)
+            partial_py, full_py, final_src = T.q1_split_plan(ing.table(done, k), 64)
+            res = g.NativePlan(partial_py, tc).execute(0)
+            states.append(g.plan.materialize(tc, res.to_device_table(tc.device), force=True))
+            done += k
+        final_src.partitions[0] = g.plan.concat_tables(tc, states)
+        res = g.NativePlan(full_py, tc).execute(0)
+        _sync(tc)
+        dt = time.perf_counter() - t0
+        rows_out = res.to_arrow().to_pylist()
+        ing.close()
+        if rep > 0:
+            best = dt if best is None or dt < best else best
+    out["q1_pcie_inclusive"] = {"threads": nt, "chunk_batches": chunk_batches, "ms": best * 1e3, "rows_per_s": n / best, "GBps": raw / best / 1e9,
+                                "equals_hbm_resident_result": rows_out == ref_rows}
+    out["q1_hbm_resident_rows_per_s"] = n / (out["q1_hbm_resident_ms"] * 1e-3)
+    return out
+
+
 def run(tc, T, g, full=True):
     extra = {"join_probe": []}
     grid = [(20, 28, 1.0), (24, 28, 1.0), (27, 28, 1.0), (24, 28, 0.5), (24, 28, 0.1)] if full else [(20, 24, 1.0)]
@@ -431,6 +506,10 @@ if __name__ == "__main__":
         if "--hash" in sys.argv:
             tc.ctx.set_option("join_dense", 0)
         print(json.dumps([join_probe_micro(tc, g, b, 28, 1.0, reps=2) for b in bits], indent=1))
+        sys.exit(0)
+    if "--ingest" in sys.argv:
+        sf = 10 if "--sf10" in sys.argv else 1
+        print(json.dumps(ingest_q1(tc, T, g, sf), indent=1))
         sys.exit(0)
     if "--like" in sys.argv:
         print(json.dumps(like_micro(tc, T, g), indent=1))

@@ -151,6 +151,27 @@ void gpuq_table_free(gpuq_table* t);
 int gpuq_export_arrow(gpuq_ctx* ctx, void* stream, const gpuq_column* cols, const gpuq_field_info* fields, int n_cols, int64_t n_rows,
                       struct ArrowArray* out, struct ArrowSchema* out_schema);
 
+/* ---- streaming ingest of a partition ------------------------------------------------------------------------------------
+   The per-batch pull loop of a task (`stream.next()`, shuffle_writer.rs:341 / utils.rs:198) seen from the device: host Arrow
+   RecordBatches (BASELINE configs[1]: 64 Ki rows each) are appended to ONE set of preallocated device columns.
+   gpuq_ingest_push only queues a batch (it is MOVED, Arrow C Data Interface: the library calls its release callback once the
+   copies have landed); n_threads workers (0 = 8) copy the buffers into their own pinned slots in parallel -- one thread feeding
+   pinned memory cannot fill PCIe -- and issue the H2D copies on their own streams.  Batches land out of order; "rows landed" is
+   the contiguous prefix that is complete.  A consumer reads the landed prefix through gpuq_ingest_columns (narrow `length`, or
+   offset the pointers, to the row range it wants) on any stream while later batches are still in flight.
+   max_rows / max_utf8_bytes (per Utf8 column) size the device columns; exceeding them is GPUQ_ERR_CAPACITY.  Nullable and
+   Boolean columns need every batch but the last to hold a multiple of 8 rows.  Errors: gpuq_ingest_last_error(). */
+typedef struct gpuq_ingest gpuq_ingest;
+int gpuq_ingest_create(gpuq_ctx* ctx, const struct ArrowSchema* schema, int64_t max_rows, int64_t max_utf8_bytes, int n_threads, gpuq_ingest** out);
+int gpuq_ingest_push(gpuq_ingest* ingest, struct ArrowArray* batch);
+int gpuq_ingest_rows_landed(gpuq_ingest* ingest, int64_t* rows_out);
+/* blocks until at least `rows` rows have landed, or everything pushed so far has; *rows_out = the landed prefix */
+int gpuq_ingest_wait_rows(gpuq_ingest* ingest, int64_t rows, int64_t* rows_out);
+int gpuq_ingest_columns(gpuq_ingest* ingest, gpuq_column* cols_out, gpuq_field_info* fields_out, int cap, int* n_out);
+int gpuq_ingest_stats(gpuq_ingest* ingest, int64_t* rows_pushed, int64_t* rows_landed, int64_t* bytes_copied);
+void gpuq_ingest_free(gpuq_ingest* ingest);      /* also frees the device columns */
+const char* gpuq_ingest_last_error(void);
+
 /* ---- compiled operators ------------------------------------------------------------------ */
 /* Descriptor JSON (see INTEGRATION.md for the grammar).  Expression nodes mirror PhysicalExprNode
    (datafusion.proto:1142-1180): column, literal, binary_expr, cast, try_cast, not_expr, is_null_expr,
