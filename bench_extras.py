@@ -445,11 +445,17 @@ def ingest_q1(tc, T, g, sf=10, batch_rows=65536, threads=(4, 8, 16), chunk_batch
         for b in batches:
             ing.push(b)
         states, done = [], 0
+        partial = None
         while done < n:
             k = min(chunk, n - done)
             ing.wait_rows(done + k)
-            partial_py, full_py, final_src = T.q1_split_plan(ing.table(done, k), 64)
-            res = g.NativePlan(partial_py, tc).execute(0)
+            view = ing.table(done, k)
+            if partial is None:      # one compiled plan for every chunk: the views share a layout, only pointers and row counts change
+                partial_py, full_py, final_src = T.q1_split_plan(view, 64)
+                partial = g.NativePlan(partial_py, tc)
+            else:
+                partial.set_input(0, view)
+            res = partial.execute(0)
             states.append(g.plan.materialize(tc, res.to_device_table(tc.device), force=True))
             done += k
         final_src.partitions[0] = g.plan.concat_tables(tc, states)
