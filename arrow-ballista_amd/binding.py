@@ -25,6 +25,10 @@ class gpuq_field_info(C.Structure):
                 ("nullable", C.c_int32), ("repr", C.c_int32), ("width", C.c_int32)]
 
 
+class gpuq_csv_options(C.Structure):
+    _fields_ = [("delimiter", C.c_char), ("quote", C.c_char), ("has_header", C.c_int32)]
+
+
 class gpuq_input(C.Structure):
     _fields_ = [("cols", C.POINTER(gpuq_column)), ("n_cols", C.c_int32), ("n_via", C.c_int32), ("n_rows", C.c_int64),
                 ("via", C.c_void_p * 3)]
@@ -92,6 +96,10 @@ def lib():
         "gpuq_ingest_stats": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
         "gpuq_ingest_free": (None, [vp]),
         "gpuq_ingest_last_error": (C.c_char_p, []),
+        "gpuq_csv_decode": (i32, [vp, vp, vp, i64, C.POINTER(gpuq_field_info), i32, C.POINTER(C.c_int32), i32, C.POINTER(gpuq_csv_options), C.POINTER(vp)]),
+        "gpuq_parquet_decode": (i32, [vp, vp, vp, i64, C.POINTER(C.c_char_p), i32, C.POINTER(vp)]),
+        "gpuq_parquet_schema": (i32, [vp, i64, C.POINTER(gpuq_field_info), i32, C.POINTER(i32), C.POINTER(i64)]),
+        "gpuq_scan_last_error": (C.c_char_p, []),
         "gpuq_table_num_rows": (i64, [vp]),
         "gpuq_table_num_columns": (i32, [vp]),
         "gpuq_table_column": (i32, [vp, i32, C.POINTER(gpuq_column), C.POINTER(gpuq_field_info)]),

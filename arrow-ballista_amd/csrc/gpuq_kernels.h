@@ -200,12 +200,38 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, int64_t src_bytes, uin
 struct Utf8Piece { const int32_t* tmp; int64_t n; int32_t* dst; int64_t at, dl, start, used; int32_t first, pad; };   // one batch of a Utf8 column (kernels_lz4.hip)
 void launch_utf8_piece_starts(hipStream_t s, Utf8Piece* pieces, int n_pieces, uint32_t* gap);
 void launch_utf8_piece_offsets(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_rows);
+void launch_utf8_piece_validate(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_rows, uint32_t* status);
 void launch_utf8_piece_compact(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_bytes, const uint8_t* from, uint8_t* to);
 void launch_popcount_bits(hipStream_t s, const uint8_t* bits, int64_t n_bits, unsigned long long* out);
 void launch_gen_lineitem(hipStream_t s, u64 seed, u64 seed_orders, i64 row0, i64 n, i64 n_supp, const LineitemCols& c);
 void launch_gen_orders(hipStream_t s, u64 seed, i64 row0, i64 n, i64 n_cust, const OrdersCols& c);
 void launch_gen_customer(hipStream_t s, u64 seed, i64 row0, i64 n, const CustomerCols& c);
 void launch_gen_supplier(hipStream_t s, u64 seed, i64 row0, i64 n, const SupplierCols& c);
+
+// ----- scan-side decode (kernels_scanfmt.hip): delimited text and Parquet pages
+enum CsvKind : int32_t { CSV_SKIP = 0, CSV_I32 = 1, CSV_I64 = 2, CSV_DATE32 = 3, CSV_DEC128 = 4, CSV_F64 = 5, CSV_BOOL = 6, CSV_UTF8 = 7 };
+constexpr int CSV_MAX_FIELDS = 64;
+struct CsvSpec {
+  int32_t n_fields; int32_t kind[CSV_MAX_FIELDS]; int32_t out[CSV_MAX_FIELDS]; int32_t scale[CSV_MAX_FIELDS]; int32_t nullable[CSV_MAX_FIELDS];
+  uint8_t delim, quote; uint8_t pad[2];
+};
+struct CsvOut { void* data[CSV_MAX_FIELDS]; u64* valid[CSV_MAX_FIELDS]; uint32_t* str_start[CSV_MAX_FIELDS]; int32_t* str_len[CSV_MAX_FIELDS]; };
+constexpr uint32_t CSVF_BAD_NUMBER = 1u, CSVF_FIELD_COUNT = 2u, CSVF_QUOTE = 4u, CSVF_NULL_IN_REQUIRED = 8u, CSVF_FLOAT_PRECISION = 16u;
+void launch_csv_count_lines(hipStream_t s, const uint8_t* text, i64 n, i64 chunk, int nblocks, uint32_t* counts);
+void launch_csv_line_starts(hipStream_t s, const uint8_t* text, i64 n, i64 chunk, int nblocks, const uint32_t* block_offsets, i64* starts);
+void launch_csv_parse(hipStream_t s, const uint8_t* text, i64 n_bytes, const i64* starts, i64 row0, i64 n_rows, const CsvSpec& S, const CsvOut& O, uint32_t* flags);
+void launch_csv_copy_strings(hipStream_t s, const uint8_t* text, const uint32_t* start, const int32_t* offsets, i64 n, uint8_t* out);
+enum PqPhys : int32_t { PQ_BOOL = 0, PQ_I32 = 1, PQ_I64 = 2, PQ_F64 = 5, PQ_BYTE_ARRAY = 6, PQ_FLBA = 7 };
+enum PqEnc : int32_t { PQE_PLAIN = 0, PQE_DICT = 2, PQE_RLE = 3 };
+struct PqPage { i64 src; int32_t bytes; int32_t n_values; i64 row0; int32_t enc; int32_t def_bytes; int32_t def_v2; int32_t dict; };
+struct PqDict { i64 values; i64 str_offsets; int32_t n; int32_t pad; };
+struct PqCol { int32_t phys, width; int32_t flba_len, optional; void* data; u64* valid; int32_t* str_len; i64* str_src; };
+constexpr uint32_t PQF_MALFORMED = 1u, PQF_UNSUPPORTED = 2u;
+void launch_pq_decode(hipStream_t s, const uint8_t* file, i64 file_bytes, const PqPage* pages, int n_pages, const PqCol& C, const PqDict* dicts, const uint8_t* dict_values,
+                      const int32_t* dict_str_offsets, uint32_t* scratch, i64 scratch_stride, uint32_t* flags);
+void launch_pq_copy_strings(hipStream_t s, const uint8_t* file, const uint8_t* dict_values, const i64* src, const int32_t* offsets, i64 n, uint8_t* out);
+void launch_pq_dict_strings(hipStream_t s, const uint8_t* file, i64 src, int32_t bytes, int32_t n, int32_t* offsets, uint8_t* out, uint32_t* flags);
+void launch_pq_dict_fixed(hipStream_t s, const uint8_t* file, i64 src, int32_t n, int32_t phys, int32_t flba_len, int32_t width, uint8_t* out);
 
 // JIT redirection: while a JitOverride is alive on this thread, the next launch of the kernel family it
 // names goes to the hiprtc-compiled function instead of the AOT template instantiation.

@@ -256,22 +256,22 @@ __device__ __forceinline__ int64_t lz4_decode_block(InWin& W, const uint8_t* in8
   const int lane = lane_id();
   while (ip < iend) {
     const int token = win_byte(W, ip); ip += 1;
-    int lit = token >> 4;
-    if (lit == 15) { int x; do { if (ip >= iend) return -1; x = win_byte(W, ip); ip += 1; lit += x; } while (x == 255); }
+    int64_t lit = token >> 4;      // 64-bit, and bounded while it grows: a long run of 0xFF length bytes must not wrap past the checks below
+    if (lit == 15) { int x; do { if (ip >= iend || lit > out_hi - op) return -1; x = win_byte(W, ip); ip += 1; lit += x; } while (x == 255); }
     if (lit > iend - ip || lit > out_hi - op) return -1;
-    if (lit) { wave_copy(out + op, in8 + ip, lit); ip += lit; op += lit; }
+    if (lit) { wave_copy(out + op, in8 + ip, (int)lit); ip += lit; op += lit; }
     if (ip >= iend) break;                            // the last sequence has no match
     if (ip + 2 > iend) return -1;
     const int offset = win_byte(W, ip) | (win_byte(W, ip + 1) << 8); ip += 2;
-    int ml = token & 15;
-    if (ml == 15) { int x; do { if (ip >= iend) return -1; x = win_byte(W, ip); ip += 1; ml += x; } while (x == 255); }
+    int64_t ml = token & 15;
+    if (ml == 15) { int x; do { if (ip >= iend || ml > out_hi - op) return -1; x = win_byte(W, ip); ip += 1; ml += x; } while (x == 255); }
     ml += 4;
     if (offset == 0 || offset > op - out_lo || ml > out_hi - op) return -1;
     // the source lies entirely before op (bytes of a period shorter than the match repeat): every byte is independent
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     const uint8_t* s = out + op - offset;
-    if (offset >= ml) { for (int i = lane; i < ml; i += 64) out[op + i] = s[i]; }
-    else { for (int i = lane; i < ml; i += 64) out[op + i] = s[i % offset]; }
+    if (offset >= ml) { for (int64_t i = lane; i < ml; i += 64) out[op + i] = s[i]; }
+    else { for (int64_t i = lane; i < ml; i += 64) out[op + i] = s[i % offset]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     op += ml;
   }
@@ -351,6 +351,15 @@ __global__ void k_utf8_piece_starts(Utf8Piece* __restrict__ pieces, int n_pieces
     if (g) atomicOr(gap, 2u);
   }
 }
+// A peer's shuffle file is untrusted input: offsets that run backwards, start below zero or end beyond the bytes their data
+// buffer holds would make every later kernel read out of bounds.  Raises bit 2 of the decode status ("malformed").
+__global__ __launch_bounds__(256) void k_utf8_piece_validate(const Utf8Piece* __restrict__ pieces, uint32_t* __restrict__ status) {
+  const Utf8Piece P = pieces[blockIdx.y];
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * 256) bad |= P.tmp[i] > P.tmp[i + 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) bad |= P.tmp[0] < 0 || (int64_t)P.tmp[P.n] > P.dl;
+  if (bad) atomicOr(status, 4u);
+}
 __global__ __launch_bounds__(256) void k_utf8_piece_offsets(const Utf8Piece* __restrict__ pieces) {
   const Utf8Piece P = pieces[blockIdx.y];
   const int32_t delta = (int32_t)(P.start - P.first);
@@ -366,6 +375,11 @@ __global__ __launch_bounds__(256) void k_utf8_piece_compact(const Utf8Piece* __r
 // ---------------------------------------------------------------- launchers
 void launch_utf8_piece_starts(hipStream_t s, Utf8Piece* pieces, int n_pieces, uint32_t* gap) {
   if (n_pieces > 0) hipLaunchKernelGGL(k_utf8_piece_starts, dim3(1), dim3(256), 0, s, pieces, n_pieces, gap);
+}
+void launch_utf8_piece_validate(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_rows, uint32_t* status) {
+  if (n_pieces <= 0) return;
+  const unsigned gx = (unsigned)std::min<int64_t>(64, (max_rows + 256) / 256);
+  hipLaunchKernelGGL(k_utf8_piece_validate, dim3(gx, (unsigned)n_pieces), dim3(256), 0, s, pieces, status);
 }
 void launch_utf8_piece_offsets(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_rows) {
   if (n_pieces <= 0) return;

@@ -1,0 +1,426 @@
+// Scan-side decode, host part: the leaves of the reference's TPC-H plans -- CsvExec / ParquetExec
+// over the files benchmarks/src/bin/tpch.rs:801-862 registers -- produce their columns in HBM.  The host frames (line count
+// read-back, Thrift metadata of a Parquet file: footer + page headers) and never touches values; kernels_scanfmt.hip parses.
+#include "gpuq_internal.h"
+#include "gpuq_kernels.h"
+#include "expr_compile.h"
+#include <cstring>
+#include <functional>
+#include <memory>
+
+using namespace gpuq;
+
+namespace {
+thread_local std::string g_ferr;
+template <class F> int guarded_f(F&& f) {
+  try { f(); return GPUQ_OK; }
+  catch (const HipError& e) { g_ferr = e.what(); return GPUQ_ERR_HIP; }
+  catch (const Unsupported& e) { g_ferr = e.what(); return GPUQ_ERR_UNSUPPORTED; }
+  catch (const Capacity& e) { g_ferr = e.what(); return GPUQ_ERR_CAPACITY; }
+  catch (const std::exception& e) { g_ferr = e.what(); return GPUQ_ERR_INVALID; }
+}
+void h2d(gpuq_ctx* ctx, hipStream_t s, void* dst, const void* src, size_t n) {
+  if (!n) return;
+  if (gpuq_copy_h2d(ctx, (void*)s, dst, src, n) != GPUQ_OK) throw HipError(std::string("scan decode: upload failed: ") + gpuq_last_error(ctx));
+}
+template <class T> T d2h_value(hipStream_t s, const T* dev) { T v; HIPCHECK(hipMemcpyAsync(&v, dev, sizeof(T), hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s)); return v; }
+gpuq_field_info field_of(const std::string& name, int type, int p, int sc, bool nullable) {
+  gpuq_field_info f{}; std::snprintf(f.name, sizeof(f.name), "%s", name.c_str());
+  f.type = type; f.precision = p; f.scale = sc; f.nullable = nullable; f.repr = GPUQ_REPR_ARROW;
+  DType dt; dt.id = type; dt.p = p; dt.s = sc; f.width = type == T_BOOL ? 0 : type_width(dt);
+  return f;
+}
+
+// lengths (int32[n], entry n is scratch) -> offsets in place; bytes copied by `copy`; fills the ImportedCol
+void finish_strings(hipStream_t s, ImportedCol& ic, int32_t* lens_then_offsets, int64_t n, const std::function<void(const int32_t*, uint8_t*, int64_t)>& copy) {
+  DevBuf sws; const size_t swb = exclusive_scan_ws_bytes(n + 1); sws.ensure(swb);
+  launch_exclusive_scan_i32(s, lens_then_offsets, n, sws.p, swb);
+  const int32_t total = d2h_value(s, lens_then_offsets + n);
+  if (total < 0) throw Unsupported("scan decode: a Utf8 column exceeds 2 GiB (int32 offsets)");
+  ic.data.ensure((size_t)total + 16);
+  copy(lens_then_offsets, (uint8_t*)ic.data.p, (int64_t)total);
+  ic.col.data = ic.data.p; ic.col.offsets = lens_then_offsets;
+  HIPCHECK(hipStreamSynchronize(s));      // the scan workspace dies here
+}
+}  // namespace
+
+extern "C" {
+
+const char* gpuq_scan_last_error(void) { return g_ferr.c_str(); }
+
+// ------------------------------------------------------------------ delimited text
+int gpuq_csv_decode(gpuq_ctx* ctx, void* stream, const uint8_t* text, int64_t n_bytes, const gpuq_field_info* file_fields, int n_file_fields, const int32_t* projection,
+                    int n_proj, const gpuq_csv_options* opt, gpuq_table** out) {
+  if (out) *out = nullptr;
+  return guarded_f([&]() {
+    if (!ctx || !out || !file_fields || (n_bytes > 0 && !text)) throw std::runtime_error("ctx / text / file_fields / out is NULL");
+    if (n_file_fields < 1 || n_file_fields > CSV_MAX_FIELDS) throw Unsupported("csv: 1.." + std::to_string(CSV_MAX_FIELDS) + " fields per line");
+    if (n_bytes >= (1ll << 32)) throw Unsupported("csv: decode at most 4 GiB of text per call (split the file at line boundaries)");
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t s = use_stream(stream);
+    const uint8_t delim = opt && opt->delimiter ? (uint8_t)opt->delimiter : (uint8_t)',';
+    const uint8_t quote = opt && opt->quote ? (uint8_t)opt->quote : (uint8_t)'"';
+    const bool header = opt && opt->has_header;
+    std::vector<int32_t> proj;
+    if (projection) proj.assign(projection, projection + n_proj); else for (int i = 0; i < n_file_fields; ++i) proj.push_back(i);
+    CsvSpec S{}; S.n_fields = n_file_fields; S.delim = delim; S.quote = quote;
+    for (int f = 0; f < n_file_fields; ++f) S.kind[f] = CSV_SKIP;
+    for (size_t o = 0; o < proj.size(); ++o) {
+      const int f = proj[o];
+      if (f < 0 || f >= n_file_fields) throw std::runtime_error("csv: projection index out of range");
+      if (S.kind[f] != CSV_SKIP) throw Unsupported("csv: a file column may be projected once");
+      const gpuq_field_info& fi = file_fields[f];
+      int k;
+      switch (fi.type) {
+        case T_INT32: k = CSV_I32; break; case T_INT64: k = CSV_I64; break; case T_DATE32: k = CSV_DATE32; break; case T_DECIMAL128: k = CSV_DEC128; break;
+        case T_FLOAT64: k = CSV_F64; break; case T_BOOL: k = CSV_BOOL; break; case T_UTF8: k = CSV_UTF8; break;
+        default: throw Unsupported("csv: column type " + std::to_string(fi.type));
+      }
+      S.kind[f] = k; S.out[f] = (int32_t)o; S.scale[f] = fi.scale; S.nullable[f] = fi.nullable;
+    }
+    // text on the device (+ one '\n' so that an unterminated last line ends like the others)
+    DevBuf dtext; dtext.ensure((size_t)n_bytes + 64);
+    h2d(ctx, s, dtext.p, text, (size_t)n_bytes);
+    const bool unterminated = n_bytes > 0 && text[n_bytes - 1] != '\n';
+    if (unterminated) { const char nl = '\n'; HIPCHECK(hipMemcpyAsync((char*)dtext.p + n_bytes, &nl, 1, hipMemcpyHostToDevice, s)); }
+    const int64_t nb = n_bytes + (unterminated ? 1 : 0);
+    // line starts
+    const i64 chunk = 1 << 16;
+    const int nblocks = (int)std::max<i64>(1, (nb + chunk - 1) / chunk);
+    DevBuf counts; counts.ensure((size_t)nblocks * 4 + 32);
+    u64* total_dev = (u64*)((char*)counts.p + (((size_t)nblocks * 4 + 15) & ~(size_t)15));
+    launch_csv_count_lines(s, (const uint8_t*)dtext.p, nb, chunk, nblocks, (uint32_t*)counts.p);
+    launch_scan_block_counts(s, (uint32_t*)counts.p, nblocks, total_dev);
+    const i64 n_lines = (i64)d2h_value(s, total_dev);
+    DevBuf starts; starts.ensure((size_t)(n_lines + 2) * 8);
+    HIPCHECK(hipMemsetAsync(starts.p, 0, 8, s));
+    launch_csv_line_starts(s, (const uint8_t*)dtext.p, nb, chunk, nblocks, (const uint32_t*)counts.p, (i64*)starts.p);
+    const i64 row0 = header ? 1 : 0;
+    const i64 n_rows = std::max<i64>(0, n_lines - row0);
+    if (n_rows > 0xFFFFFFFEll) throw Unsupported("csv: more than 2^32-2 rows per call");
+    // outputs
+    std::unique_ptr<gpuq_table> t(new gpuq_table()); t->ctx = ctx; t->n_rows = n_rows;
+    CsvOut O{};
+    std::vector<std::unique_ptr<DevBuf>> tmp;
+    const size_t bm = (size_t)((n_rows + 63) / 64) * 8 + 16;
+    for (size_t o = 0; o < proj.size(); ++o) {
+      const gpuq_field_info& fi = file_fields[proj[o]];
+      std::unique_ptr<ImportedCol> ic(new ImportedCol());
+      ic->field = field_of(fi.name, fi.type, fi.precision, fi.scale, fi.nullable != 0);
+      ic->col.type = fi.type; ic->col.precision = fi.precision; ic->col.scale = fi.scale; ic->col.repr = GPUQ_REPR_ARROW; ic->col.length = n_rows;
+      if (fi.type == T_UTF8) {
+        ic->offsets.ensure((size_t)(n_rows + 2) * 4 + 16);
+        tmp.push_back(std::make_unique<DevBuf>()); tmp.back()->ensure((size_t)std::max<i64>(n_rows, 1) * 4);
+        O.str_len[o] = (int32_t*)ic->offsets.p; O.str_start[o] = (uint32_t*)tmp.back()->p;
+      } else if (fi.type == T_BOOL) { ic->data.ensure(bm); HIPCHECK(hipMemsetAsync(ic->data.p, 0, bm, s)); O.data[o] = ic->data.p; ic->col.data = ic->data.p; }
+      else { DType dt; dt.id = fi.type; dt.p = fi.precision; dt.s = fi.scale; ic->data.ensure((size_t)std::max<i64>(n_rows, 1) * (size_t)type_width(dt) + 16); O.data[o] = ic->data.p; ic->col.data = ic->data.p; }
+      if (fi.nullable) { ic->validity.ensure(bm); HIPCHECK(hipMemsetAsync(ic->validity.p, 0, bm, s)); O.valid[o] = (u64*)ic->validity.p; ic->col.validity = (const uint8_t*)ic->validity.p; }
+      t->cols.push_back(std::move(ic));
+    }
+    DevBuf flags; flags.ensure(16); HIPCHECK(hipMemsetAsync(flags.p, 0, 16, s));
+    launch_csv_parse(s, (const uint8_t*)dtext.p, nb, (const i64*)starts.p, row0, n_rows, S, O, (uint32_t*)flags.p);
+    HIPCHECK(hipGetLastError());
+    const uint32_t fl = d2h_value(s, (const uint32_t*)flags.p);
+    if (fl & CSVF_QUOTE) throw Unsupported("csv: quoted fields are not parsed on the device");
+    if (fl & CSVF_FIELD_COUNT) throw std::runtime_error("csv: a line does not have the schema's number of fields");
+    if (fl & CSVF_BAD_NUMBER) throw std::runtime_error("csv: a field does not parse as its column's type");
+    if (fl & CSVF_NULL_IN_REQUIRED) throw std::runtime_error("csv: an empty field in a non-nullable column");
+    if (fl & CSVF_FLOAT_PRECISION) throw Unsupported("csv: a Float64 field needs more than the exact fast path (> 15 significant digits or |exponent| > 22)");
+    size_t ti = 0;
+    for (size_t o = 0; o < proj.size(); ++o) {
+      if (file_fields[proj[o]].type != T_UTF8) continue;
+      ImportedCol& ic = *t->cols[o];
+      const uint32_t* st = (const uint32_t*)tmp[ti++]->p;
+      const uint8_t* tx = (const uint8_t*)dtext.p;
+      finish_strings(s, ic, (int32_t*)ic.offsets.p, n_rows, [&](const int32_t* offs, uint8_t* dst, int64_t) { launch_csv_copy_strings(s, tx, st, offs, n_rows, dst); });
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+    *out = t.release();
+  });
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ Parquet: Thrift compact protocol, the parts the format uses
+namespace {
+struct TReader {
+  const uint8_t* p; const uint8_t* e;
+  void need(size_t n) const { if ((size_t)(e - p) < n) throw std::runtime_error("parquet: metadata ends inside a Thrift value"); }
+  uint64_t varint() { uint64_t v = 0; int sh = 0; for (;;) { need(1); const uint8_t c = *p++; v |= (uint64_t)(c & 0x7F) << sh; if (!(c & 0x80)) return v; sh += 7; if (sh > 63) throw std::runtime_error("parquet: varint too long"); } }
+  int64_t zigzag() { const uint64_t v = varint(); return (int64_t)(v >> 1) ^ -(int64_t)(v & 1); }
+  std::string binary() { const uint64_t n = varint(); need(n); std::string s((const char*)p, (size_t)n); p += n; return s; }
+  // field header: returns false at STOP; type in the low nibble, id by delta or explicit
+  bool field(int& type, int& id, int& last) {
+    need(1); const uint8_t b = *p++;
+    if (b == 0) return false;
+    type = b & 0x0F; const int delta = b >> 4;
+    id = delta ? last + delta : (int)zigzag();
+    last = id; return true;
+  }
+  void skip(int type) {
+    switch (type) {
+      case 1: case 2: break;                                   // bool true / false (value in the type)
+      case 3: need(1); ++p; break;                             // i8
+      case 4: case 5: case 6: (void)zigzag(); break;           // i16 / i32 / i64
+      case 7: need(8); p += 8; break;                          // double
+      case 8: { const uint64_t n = varint(); need(n); p += n; break; }     // binary
+      case 9: case 10: { need(1); const uint8_t h = *p++; uint64_t n = h >> 4; const int et = h & 0x0F; if (n == 15) n = varint(); for (uint64_t i = 0; i < n; ++i) skip_elem(et); break; }
+      case 11: { const uint64_t n = varint(); if (n) { need(1); const uint8_t kv = *p++; for (uint64_t i = 0; i < n; ++i) { skip_elem(kv >> 4); skip_elem(kv & 0x0F); } } break; }
+      case 12: { int t, id, last = 0; while (field(t, id, last)) skip(t); break; }
+      default: throw std::runtime_error("parquet: unknown Thrift type " + std::to_string(type));
+    }
+  }
+  void skip_elem(int et) { if (et == 1 || et == 2) { need(1); ++p; } else skip(et); }      // booleans inside collections take a byte
+  uint64_t list_header(int& elem_type) { need(1); const uint8_t h = *p++; uint64_t n = h >> 4; elem_type = h & 0x0F; if (n == 15) n = varint(); return n; }
+};
+
+struct PqSchemaElem { int type = -1, type_length = 0, repetition = 0, num_children = 0, converted = -1, scale = 0, precision = 0; std::string name; bool logical_decimal = false, logical_date = false, logical_string = false; };
+struct PqChunk { int type = -1, codec = 0; int64_t num_values = 0, total_compressed = 0, data_page_offset = 0, dict_page_offset = -1; std::vector<std::string> path; };
+struct PqRowGroup { std::vector<PqChunk> cols; int64_t num_rows = 0; };
+struct PqFileMeta { std::vector<PqSchemaElem> schema; std::vector<PqRowGroup> groups; int64_t num_rows = 0; };
+
+PqSchemaElem read_schema_elem(TReader& r) {
+  PqSchemaElem s; int t, id, last = 0;
+  while (r.field(t, id, last)) {
+    switch (id) {
+      case 1: s.type = (int)r.zigzag(); break; case 2: s.type_length = (int)r.zigzag(); break; case 3: s.repetition = (int)r.zigzag(); break;
+      case 4: s.name = r.binary(); break; case 5: s.num_children = (int)r.zigzag(); break; case 6: s.converted = (int)r.zigzag(); break;
+      case 7: s.scale = (int)r.zigzag(); break; case 8: s.precision = (int)r.zigzag(); break;
+      case 10: {      // LogicalType union: field id = which
+        int t2, id2, last2 = 0;
+        while (r.field(t2, id2, last2)) {
+          if (id2 == 1) s.logical_string = true; else if (id2 == 6) s.logical_date = true;
+          if (id2 == 5) {      // DecimalType {1 scale, 2 precision}
+            s.logical_decimal = true; int t3, id3, last3 = 0;
+            while (r.field(t3, id3, last3)) { if (id3 == 1) s.scale = (int)r.zigzag(); else if (id3 == 2) s.precision = (int)r.zigzag(); else r.skip(t3); }
+          } else r.skip(t2);
+        }
+        break;
+      }
+      default: r.skip(t);
+    }
+  }
+  return s;
+}
+PqChunk read_chunk(TReader& r) {
+  PqChunk c; int t, id, last = 0;
+  while (r.field(t, id, last)) {
+    if (id == 3 && t == 12) {
+      int t2, id2, last2 = 0;
+      while (r.field(t2, id2, last2)) {
+        switch (id2) {
+          case 1: c.type = (int)r.zigzag(); break;
+          case 3: { int et; const uint64_t n = r.list_header(et); for (uint64_t i = 0; i < n; ++i) c.path.push_back(r.binary()); break; }
+          case 4: c.codec = (int)r.zigzag(); break; case 5: c.num_values = r.zigzag(); break; case 7: c.total_compressed = r.zigzag(); break;
+          case 9: c.data_page_offset = r.zigzag(); break; case 11: c.dict_page_offset = r.zigzag(); break;
+          default: r.skip(t2);
+        }
+      }
+    } else r.skip(t);
+  }
+  return c;
+}
+PqFileMeta read_footer(const uint8_t* file, int64_t n) {
+  if (n < 12 || std::memcmp(file, "PAR1", 4) != 0 || std::memcmp(file + n - 4, "PAR1", 4) != 0) throw std::runtime_error("parquet: missing PAR1 magic");
+  uint32_t flen; std::memcpy(&flen, file + n - 8, 4);
+  if ((int64_t)flen + 12 > n) throw std::runtime_error("parquet: footer length exceeds the file");
+  TReader r{file + n - 8 - flen, file + n - 8};
+  PqFileMeta m; int t, id, last = 0;
+  while (r.field(t, id, last)) {
+    if (id == 2) { int et; const uint64_t k = r.list_header(et); for (uint64_t i = 0; i < k; ++i) m.schema.push_back(read_schema_elem(r)); }
+    else if (id == 3) m.num_rows = r.zigzag();
+    else if (id == 4) {
+      int et; const uint64_t k = r.list_header(et);
+      for (uint64_t i = 0; i < k; ++i) {
+        PqRowGroup g; int t2, id2, last2 = 0;
+        while (r.field(t2, id2, last2)) {
+          if (id2 == 1) { int et2; const uint64_t kc = r.list_header(et2); for (uint64_t j = 0; j < kc; ++j) g.cols.push_back(read_chunk(r)); }
+          else if (id2 == 3) g.num_rows = r.zigzag();
+          else r.skip(t2);
+        }
+        m.groups.push_back(std::move(g));
+      }
+    } else r.skip(t);
+  }
+  return m;
+}
+struct PqPageHeader { int type = -1, uncompressed = 0, compressed = 0, num_values = 0, encoding = 0, def_v2 = 0, rep_v2 = 0; bool v2_compressed = true; int64_t header_bytes = 0; };
+PqPageHeader read_page_header(const uint8_t* p, const uint8_t* e) {
+  TReader r{p, e}; PqPageHeader h; int t, id, last = 0;
+  while (r.field(t, id, last)) {
+    switch (id) {
+      case 1: h.type = (int)r.zigzag(); break; case 2: h.uncompressed = (int)r.zigzag(); break; case 3: h.compressed = (int)r.zigzag(); break;
+      case 5: case 7: { int t2, id2, last2 = 0; while (r.field(t2, id2, last2)) { if (id2 == 1) h.num_values = (int)r.zigzag(); else if (id2 == 2) h.encoding = (int)r.zigzag(); else r.skip(t2); } break; }
+      case 8: { int t2, id2, last2 = 0;
+        while (r.field(t2, id2, last2)) {
+          if (id2 == 1) h.num_values = (int)r.zigzag(); else if (id2 == 4) h.encoding = (int)r.zigzag(); else if (id2 == 5) h.def_v2 = (int)r.zigzag();
+          else if (id2 == 6) h.rep_v2 = (int)r.zigzag(); else if (id2 == 7) h.v2_compressed = (t2 == 1); else r.skip(t2);
+        }
+        break; }
+      default: r.skip(t);
+    }
+  }
+  h.header_bytes = r.p - p;
+  return h;
+}
+}  // namespace
+
+extern "C" {
+
+int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_t n_bytes, const char* const* columns, int n_columns, gpuq_table** out) {
+  if (out) *out = nullptr;
+  return guarded_f([&]() {
+    if (!ctx || !out || !file) throw std::runtime_error("ctx / file / out is NULL");
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t s = use_stream(stream);
+    const PqFileMeta M = read_footer(file, n_bytes);
+    if (M.schema.empty()) throw std::runtime_error("parquet: empty schema");
+    // flat schemas: the root and its leaf children
+    std::vector<PqSchemaElem> leaves(M.schema.begin() + 1, M.schema.end());
+    for (auto& l : leaves) if (l.num_children > 0 || l.repetition == 2) throw Unsupported("parquet: nested / repeated column '" + l.name + "'");
+    std::vector<int> proj;
+    if (columns) {
+      for (int i = 0; i < n_columns; ++i) {
+        int found = -1; for (size_t k = 0; k < leaves.size(); ++k) if (leaves[k].name == columns[i]) found = (int)k;
+        if (found < 0) throw std::runtime_error(std::string("parquet: column '") + columns[i] + "' is not in the file");
+        proj.push_back(found);
+      }
+    } else for (size_t k = 0; k < leaves.size(); ++k) proj.push_back((int)k);
+    const int64_t n_rows = M.num_rows;
+    if (n_rows > 0xFFFFFFFEll) throw Unsupported("parquet: more than 2^32-2 rows per call");
+    std::unique_ptr<gpuq_table> t(new gpuq_table()); t->ctx = ctx; t->n_rows = n_rows;
+    DevBuf flags; flags.ensure(16); HIPCHECK(hipMemsetAsync(flags.p, 0, 16, s));
+    const size_t bm = (size_t)((n_rows + 63) / 64) * 8 + 16;
+    for (int li : proj) {
+      const PqSchemaElem& L = leaves[(size_t)li];
+      // ---- type mapping (parquet.thrift Type / ConvertedType / LogicalType -> gpuq_type)
+      int gt = -1, gp = 0, gs = 0, width = 0;
+      const bool is_decimal = L.logical_decimal || L.converted == 5;
+      switch (L.type) {
+        case 0: gt = T_BOOL; break;
+        case 1: if (is_decimal) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; width = 16; } else if (L.logical_date || L.converted == 6) { gt = T_DATE32; width = 4; } else { gt = T_INT32; width = 4; } break;
+        case 2: if (is_decimal) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; width = 16; } else { gt = T_INT64; width = 8; } break;
+        case 5: gt = T_FLOAT64; width = 8; break;
+        case 6: if (is_decimal) throw Unsupported("parquet: BYTE_ARRAY decimals ('" + L.name + "')"); gt = T_UTF8; break;
+        case 7: if (!is_decimal || L.type_length > 16) throw Unsupported("parquet: FIXED_LEN_BYTE_ARRAY column '" + L.name + "' (only decimals of <= 16 bytes)"); gt = T_DECIMAL128; gp = L.precision; gs = L.scale; width = 16; break;
+        default: throw Unsupported("parquet: physical type " + std::to_string(L.type) + " of column '" + L.name + "' (FLOAT / INT96 are not read on the device)");
+      }
+      const bool optional = L.repetition == 1;
+      std::unique_ptr<ImportedCol> ic(new ImportedCol());
+      ic->field = field_of(L.name, gt, gp, gs, optional);
+      ic->col.type = gt; ic->col.precision = gp; ic->col.scale = gs; ic->col.repr = GPUQ_REPR_ARROW; ic->col.length = n_rows;
+      PqCol C{}; C.phys = L.type; C.width = width; C.flba_len = L.type_length; C.optional = optional ? 1 : 0;
+      DevBuf str_src;
+      if (gt == T_UTF8) { ic->offsets.ensure((size_t)(n_rows + 2) * 4 + 16); str_src.ensure((size_t)std::max<int64_t>(n_rows, 1) * 8); C.str_len = (int32_t*)ic->offsets.p; C.str_src = (i64*)str_src.p; }
+      else if (gt == T_BOOL) { ic->data.ensure(bm); HIPCHECK(hipMemsetAsync(ic->data.p, 0, bm, s)); C.data = ic->data.p; ic->col.data = ic->data.p; }
+      else { ic->data.ensure((size_t)std::max<int64_t>(n_rows, 1) * (size_t)width + 16); if (optional) HIPCHECK(hipMemsetAsync(ic->data.p, 0, (size_t)std::max<int64_t>(n_rows, 1) * (size_t)width, s)); C.data = ic->data.p; ic->col.data = ic->data.p; }
+      if (optional) { ic->validity.ensure(bm); HIPCHECK(hipMemsetAsync(ic->validity.p, 0, bm, s)); C.valid = (u64*)ic->validity.p; ic->col.validity = (const uint8_t*)ic->validity.p; }
+      // ---- the column's chunks: upload their byte ranges back to back, walk the page headers
+      std::vector<PqPage> pages; std::vector<PqDict> dicts;
+      struct DictSrc { int64_t src; int bytes, n; };
+      std::vector<DictSrc> dict_src;
+      int64_t up_bytes = 0; std::vector<std::pair<int64_t, int64_t>> ranges;      // (file offset, bytes)
+      int64_t row = 0; int max_values = 0;
+      for (const PqRowGroup& G : M.groups) {
+        if ((size_t)li >= G.cols.size()) throw std::runtime_error("parquet: row group without column " + L.name);
+        const PqChunk& K = G.cols[(size_t)li];
+        if (K.num_values == 0) continue;
+        if (K.codec != 0) throw Unsupported("parquet: compressed column chunk (codec " + std::to_string(K.codec) + ") in '" + L.name + "': only UNCOMPRESSED pages are decoded on the device");
+        int64_t pos = K.dict_page_offset >= 0 && K.dict_page_offset < K.data_page_offset ? K.dict_page_offset : K.data_page_offset;
+        const int64_t chunk_end = pos + K.total_compressed;
+        if (pos < 4 || chunk_end > n_bytes - 8) throw std::runtime_error("parquet: column chunk outside the file");
+        const int64_t base = up_bytes - pos;      // device position = file position + base
+        ranges.push_back({pos, K.total_compressed}); up_bytes += (K.total_compressed + 63) & ~(int64_t)63;
+        int64_t seen = 0; int dict_id = -1;
+        while (pos < chunk_end && seen < K.num_values) {
+          const PqPageHeader H = read_page_header(file + pos, file + chunk_end);
+          const int64_t payload = pos + H.header_bytes;
+          if (payload + H.compressed > chunk_end) throw std::runtime_error("parquet: page exceeds its column chunk");
+          if (H.type == 2) {       // dictionary page
+            if (H.encoding != 0 && H.encoding != 2) throw Unsupported("parquet: dictionary page encoding " + std::to_string(H.encoding));
+            dict_id = (int)dict_src.size(); dict_src.push_back({payload + base, H.compressed, H.num_values});
+          } else if (H.type == 0 || H.type == 3) {
+            PqPage P{}; P.src = payload + base; P.bytes = H.compressed; P.n_values = H.num_values; P.row0 = row + seen; P.dict = dict_id;
+            if (H.encoding == 0) P.enc = PQE_PLAIN; else if (H.encoding == 2 || H.encoding == 8) P.enc = PQE_DICT; else if (H.encoding == 3 && L.type == 0) P.enc = PQE_RLE;
+            else throw Unsupported("parquet: data page encoding " + std::to_string(H.encoding) + " in '" + L.name + "' (PLAIN, RLE_DICTIONARY and RLE booleans are decoded)");
+            if (H.type == 3) { if (H.rep_v2 != 0) throw Unsupported("parquet: repetition levels"); P.def_v2 = H.def_v2; if (optional && H.def_v2 == 0) P.def_v2 = 0; }
+            if (H.type == 3 && optional && H.def_v2 == 0 && H.num_values > 0) throw std::runtime_error("parquet: v2 page of an optional column without definition levels");
+            if (P.enc == PQE_DICT && dict_id < 0) throw std::runtime_error("parquet: dictionary-encoded page before any dictionary page");
+            pages.push_back(P); seen += H.num_values; max_values = std::max(max_values, H.num_values);
+          }
+          pos = payload + H.compressed;
+        }
+        if (seen != K.num_values) throw std::runtime_error("parquet: pages of '" + L.name + "' hold " + std::to_string(seen) + " values, the chunk declares " + std::to_string(K.num_values));
+        row += K.num_values;
+      }
+      if (row != n_rows) throw std::runtime_error("parquet: column '" + L.name + "' has " + std::to_string(row) + " values for " + std::to_string(n_rows) + " rows");
+      DevBuf dfile; dfile.ensure((size_t)up_bytes + 64);
+      { int64_t at = 0; for (auto& rg : ranges) { h2d(ctx, s, (char*)dfile.p + at, file + rg.first, (size_t)rg.second); at += (rg.second + 63) & ~(int64_t)63; } }
+      // ---- dictionaries -> output-width values / contiguous strings
+      DevBuf dvalues, dstroffs, ddicts;
+      {
+        size_t vbytes = 0, obytes = 0;
+        for (auto& d : dict_src) { vbytes += (gt == T_UTF8 ? (size_t)d.bytes : (size_t)d.n * (size_t)width) + 64; obytes += ((size_t)d.n + 2) * 4; }
+        dvalues.ensure(vbytes + 64); dstroffs.ensure(obytes + 64);
+        size_t va = 0, oa = 0;
+        for (auto& d : dict_src) {
+          PqDict D{}; D.values = (i64)va; D.str_offsets = (i64)(oa / 4); D.n = d.n;
+          if (gt == T_UTF8) { launch_pq_dict_strings(s, (const uint8_t*)dfile.p, d.src, d.bytes, d.n, (int32_t*)dstroffs.p + oa / 4, (uint8_t*)dvalues.p + va, (uint32_t*)flags.p); va += ((size_t)d.bytes + 63) & ~(size_t)63; oa += ((size_t)d.n + 2) * 4; }
+          else { launch_pq_dict_fixed(s, (const uint8_t*)dfile.p, d.src, d.n, L.type, L.type_length, width, (uint8_t*)dvalues.p + va); va += ((size_t)d.n * (size_t)width + 63) & ~(size_t)63; }
+          dicts.push_back(D);
+        }
+        ddicts.ensure(dicts.size() * sizeof(PqDict) + 64);
+        if (!dicts.empty()) HIPCHECK(hipMemcpyAsync(ddicts.p, dicts.data(), dicts.size() * sizeof(PqDict), hipMemcpyHostToDevice, s));
+      }
+      // ---- pages
+      DevBuf dpages; dpages.ensure(pages.size() * sizeof(PqPage) + 64);
+      if (!pages.empty()) HIPCHECK(hipMemcpyAsync(dpages.p, pages.data(), pages.size() * sizeof(PqPage), hipMemcpyHostToDevice, s));
+      const i64 stride = (3 * (i64)max_values + 9) & ~(i64)1;      // row index + (dictionary indices | 8-byte string positions), 8-byte aligned rows
+      DevBuf scratch; scratch.ensure((size_t)std::max<size_t>(pages.size(), 1) * (size_t)stride * 4 + 64);
+      launch_pq_decode(s, (const uint8_t*)dfile.p, up_bytes, (const PqPage*)dpages.p, (int)pages.size(), C, (const PqDict*)ddicts.p, (const uint8_t*)dvalues.p, (const int32_t*)dstroffs.p,
+                       (uint32_t*)scratch.p, stride, (uint32_t*)flags.p);
+      HIPCHECK(hipGetLastError());
+      if (gt == T_UTF8) {
+        const uint8_t* df = (const uint8_t*)dfile.p; const uint8_t* dv = (const uint8_t*)dvalues.p; const i64* src = (const i64*)str_src.p;
+        finish_strings(s, *ic, (int32_t*)ic->offsets.p, n_rows, [&](const int32_t* offs, uint8_t* dst, int64_t) { launch_pq_copy_strings(s, df, dv, src, offs, n_rows, dst); });
+      }
+      HIPCHECK(hipStreamSynchronize(s));      // host vectors and per-column scratch die with this iteration
+      t->cols.push_back(std::move(ic));
+    }
+    const uint32_t fl = d2h_value(s, (const uint32_t*)flags.p);
+    if (fl & PQF_MALFORMED) throw std::runtime_error("parquet: malformed page (levels / indices / lengths run past the page, or an index beyond its dictionary)");
+    if (fl & PQF_UNSUPPORTED) throw Unsupported("parquet: a page holds a value type the device does not decode");
+    *out = t.release();
+  });
+}
+
+// Host only: the leaf columns of a Parquet file as gpuq fields (type = -1 for a column the device does not decode), and its row count.
+int gpuq_parquet_schema(const uint8_t* file, int64_t n_bytes, gpuq_field_info* fields_out, int cap, int* n_out, int64_t* rows_out) {
+  return guarded_f([&]() {
+    if (!file || !n_out) throw std::runtime_error("file / n_out is NULL");
+    const PqFileMeta M = read_footer(file, n_bytes);
+    const int n = M.schema.empty() ? 0 : (int)M.schema.size() - 1;
+    *n_out = n; if (rows_out) *rows_out = M.num_rows;
+    if (!fields_out || cap < n) { if (!fields_out && cap == 0) return; throw Capacity("parquet schema has " + std::to_string(n) + " columns"); }
+    for (int i = 0; i < n; ++i) {
+      const PqSchemaElem& L = M.schema[(size_t)i + 1];
+      const bool dec = L.logical_decimal || L.converted == 5;
+      int gt = -1, gp = 0, gs = 0;
+      switch (L.type) {
+        case 0: gt = T_BOOL; break;
+        case 1: if (dec) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; } else gt = (L.logical_date || L.converted == 6) ? T_DATE32 : T_INT32; break;
+        case 2: if (dec) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; } else gt = T_INT64; break;
+        case 5: gt = T_FLOAT64; break;
+        case 6: gt = dec ? -1 : T_UTF8; break;
+        case 7: if (dec && L.type_length <= 16) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; } break;
+        default: break;
+      }
+      if (L.num_children > 0 || L.repetition == 2) gt = -1;
+      gpuq_field_info f{}; std::snprintf(f.name, sizeof(f.name), "%s", L.name.c_str());
+      f.type = gt; f.precision = gp; f.scale = gs; f.nullable = L.repetition == 1; f.repr = GPUQ_REPR_ARROW;
+      fields_out[i] = f;
+    }
+  });
+}
+
+}  // extern "C"

@@ -505,6 +505,8 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
     std::vector<Lz4Unit> units, units_seq;      // fast path (independent blocks assumed full) and the always-valid per-frame walk
     bool split_any = false;
     // uncompressed length of buffer j of message g (host only)
+    struct CopyFix { uint8_t* dst; const uint8_t* src; int64_t n; };       // device-to-device copies, in issue order
+    std::vector<CopyFix> copyfix;
     auto ulen_of = [&](const Msg& g, size_t j) -> int64_t {
       const int64_t len = g.m.buffers[j].second;
       if (len == 0 || g.m.codec < 0) return len;
@@ -521,9 +523,11 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
       const int64_t ulen = ulen_of(g, j);
       if (ulen > dst_cap) throw std::runtime_error("IPC buffer " + std::to_string(j) + " holds " + std::to_string(ulen) + " bytes, its column allows " + std::to_string(dst_cap));
       if (ulen == 0) return;
-      if (g.m.codec < 0) { HIPCHECK(hipMemcpyAsync(dst, db + off, (size_t)len, hipMemcpyDeviceToDevice, s)); return; }
+      // raw bytes (an uncompressed batch, or a buffer stored with the -1 length prefix): recorded, not issued -- run() replays the
+      // list on every attempt, so the frame-by-frame fallback (which clears the OR-merged bitmaps first) sees them again
+      if (g.m.codec < 0) { copyfix.push_back({dst, db + off, len}); return; }
       int64_t pre; std::memcpy(&pre, bytes + off, 8);
-      if (pre == -1) { HIPCHECK(hipMemcpyAsync(dst, db + off + 8, (size_t)(len - 8), hipMemcpyDeviceToDevice, s)); return; }
+      if (pre == -1) { copyfix.push_back({dst, db + off + 8, len - 8}); return; }
       // LZ4 frame header
       const uint8_t* f = bytes + off + 8; const int64_t flen = len - 8;
       if (flen < 7 + 4) throw std::runtime_error("truncated LZ4 frame");
@@ -557,10 +561,10 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
       else if (units.size() - first_unit > 1) split_any = true;
     };
     struct BitFix { uint8_t* dst; int64_t bit0; const uint8_t* src; int64_t n; };          // after the decode: dst bits [bit0, +n) |= src (NULL: ones)
-    struct CopyFix { uint8_t* dst; const uint8_t* src; int64_t n; };
     struct Utf8Col { int col; std::vector<Utf8Piece> pieces; int64_t max_rows, total; };
     std::vector<Utf8Col> utf8_cols;
-    std::vector<BitFix> bitfix; std::vector<CopyFix> copyfix;
+    std::vector<Utf8Piece> checks; int64_t max_check_rows = 0;      // offsets decoded in place (one message): validated like the pieces
+    std::vector<BitFix> bitfix;
     std::vector<std::unique_ptr<DevBuf>> temps;
     auto temp = [&](size_t nbytes) -> uint8_t* { temps.push_back(std::make_unique<DevBuf>()); temps.back()->ensure(nbytes + 80); return temps.back()->as<uint8_t>(); };
     // one temp area per kind, carved per batch (a DevBuf per batch would be thousands of pool round trips)
@@ -609,7 +613,7 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
         std::vector<Utf8Piece> pieces;
         for (auto& g : msgs) {
           const int64_t n = g.m.n_rows, cap = (n + 1) * 4 + 64;
-          if (msgs.size() == 1) emit(g, j0 + 1, col->offsets.as<uint8_t>(), cap);
+          if (msgs.size() == 1) { emit(g, j0 + 1, col->offsets.as<uint8_t>(), cap); checks.push_back({col->offsets.as<int32_t>(), n, nullptr, 0, ulen_of(g, j0 + 2), 0, 0, 0, 0}); max_check_rows = std::max(max_check_rows, n); }
           else if (n > 0) {
             uint8_t* t = scratch; scratch += (cap + 15) & ~(int64_t)15;
             emit(g, j0 + 1, t, cap);
@@ -649,12 +653,13 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
     }
     DevBuf dunits, dstatus, dpieces; dstatus.ensure(16);
     // Utf8 piece descriptors of all columns in one upload
-    size_t n_pieces = 0; for (auto& u : utf8_cols) n_pieces += u.pieces.size();
+    size_t n_pieces = checks.size(); for (auto& u : utf8_cols) { n_pieces += u.pieces.size(); max_check_rows = std::max(max_check_rows, u.max_rows); }
     std::vector<size_t> piece0;
     if (n_pieces) {
       dpieces.ensure(sizeof(Utf8Piece) * n_pieces);
       std::vector<Utf8Piece> all; all.reserve(n_pieces);
       for (auto& u : utf8_cols) { piece0.push_back(all.size()); all.insert(all.end(), u.pieces.begin(), u.pieces.end()); }
+      all.insert(all.end(), checks.begin(), checks.end());
       // (pageable source: the copy is staged before the call returns)
       HIPCHECK(hipMemcpyAsync(dpieces.p, all.data(), sizeof(Utf8Piece) * n_pieces, hipMemcpyHostToDevice, s));
       HIPCHECK(hipStreamSynchronize(s));
@@ -671,6 +676,8 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
       }
       for (auto& x : copyfix) HIPCHECK(hipMemcpyAsync(x.dst, x.src, (size_t)x.n, hipMemcpyDeviceToDevice, s));
       for (auto& x : bitfix) launch_concat_bitmap(s, (u64*)x.dst, x.bit0, x.src, 0, x.n);
+      // untrusted offsets: monotone, from >= 0, ending inside their data buffer -- before anything is derived from them
+      launch_utf8_piece_validate(s, (const Utf8Piece*)dpieces.p, (int)n_pieces, max_check_rows, dstatus.as<uint32_t>());
       for (size_t k = 0; k < utf8_cols.size(); ++k) {
         Utf8Piece* dp = (Utf8Piece*)dpieces.p + piece0[k];
         launch_utf8_piece_starts(s, dp, (int)utf8_cols[k].pieces.size(), dstatus.as<uint32_t>() + 1);
@@ -692,6 +699,7 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
       HIPCHECK(hipMemsetAsync(dstatus.p, 0, 16, s));
       st = run(units_seq);
     }
+    if (st & 4u) throw std::runtime_error("malformed Utf8 offsets in an IPC buffer (not monotone, negative, or beyond the data buffer)");
     if (st) throw std::runtime_error("malformed LZ4 data in an IPC buffer");
     if (gap) {                   // some producer padded its string data: move every column's bytes to where the merged offsets point
       for (size_t k = 0; k < utf8_cols.size(); ++k) {

@@ -172,6 +172,29 @@ int gpuq_ingest_stats(gpuq_ingest* ingest, int64_t* rows_pushed, int64_t* rows_l
 void gpuq_ingest_free(gpuq_ingest* ingest);      /* also frees the device columns */
 const char* gpuq_ingest_last_error(void);
 
+/* ---- scan-side decode ------------------------------------------- */
+/* The leaves of the reference's TPC-H plans are CsvExec / ParquetExec over the files benchmarks/src/bin/tpch.rs:801-862
+   registers (`.tbl` text with '|' and no header, or Parquet written by its `convert` command).  These entry points take the
+   FILE bytes in host memory (read or mmap'ed by the caller -- the object-store read stays the reference's), move them to the
+   device once and produce Arrow-layout columns in HBM as a gpuq_table; no value is parsed on the host.
+   gpuq_csv_decode: `file_fields` describes every field of a line in order (name, type, precision/scale, nullable: an empty field
+   of a nullable non-Utf8 column is NULL, as arrow-csv reads it); `projection` (or NULL = all) picks output columns by file index.
+   A trailing delimiter before the newline (TPC-H .tbl) is accepted.  Types: Int32 Int64 Date32 (yyyy-mm-dd) Decimal128 Float64
+   Boolean Utf8.  Refused loudly rather than decoded differently: quoted fields, a Float64 field outside the exactly-rounded fast
+   path (> 15 significant digits or |exponent| > 22), lines whose field count differs from the schema (blank lines included), > 4 GiB per call.
+   gpuq_parquet_decode: flat schemas; physical BOOLEAN INT32 INT64 DOUBLE BYTE_ARRAY FIXED_LEN_BYTE_ARRAY(decimal); DATE and
+   DECIMAL annotations; required / optional columns; PLAIN, PLAIN_DICTIONARY / RLE_DICTIONARY and RLE-boolean pages (v1 and v2); UNCOMPRESSED
+   column chunks (a compressed chunk is GPUQ_ERR_UNSUPPORTED).  `columns` (or NULL = all) projects by name; only the projected
+   chunks' bytes cross PCIe.  The host parses the Thrift footer and page headers, one wave decodes one page.
+   Errors: gpuq_scan_last_error() (thread-local). */
+typedef struct gpuq_csv_options { char delimiter; char quote; int32_t has_header; } gpuq_csv_options;   /* 0 = default ',' / '"' */
+int gpuq_csv_decode(gpuq_ctx* ctx, void* stream, const uint8_t* text, int64_t n_bytes, const gpuq_field_info* file_fields, int n_file_fields,
+                    const int32_t* projection, int n_projection, const gpuq_csv_options* options, gpuq_table** out);
+int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_t n_bytes, const char* const* columns, int n_columns, gpuq_table** out);
+/* host only: leaf columns (type = -1 where the device has no decoder) and row count from the footer */
+int gpuq_parquet_schema(const uint8_t* file, int64_t n_bytes, gpuq_field_info* fields_out, int cap, int* n_out, int64_t* rows_out);
+const char* gpuq_scan_last_error(void);
+
 /* ---- compiled operators ------------------------------------------------------------------ */
 /* Descriptor JSON (see INTEGRATION.md for the grammar).  Expression nodes mirror PhysicalExprNode
    (datafusion.proto:1142-1180): column, literal, binary_expr, cast, try_cast, not_expr, is_null_expr,

@@ -360,3 +360,25 @@ def test_plan_schema_is_known_before_execution_and_without_a_device():
     # the stage root's result batch (shuffle_writer.rs:470-520)
     w = host_schema(g.ShuffleWriterExec("j", 1, od, "/tmp/x", ([col("o_custkey", os_)], 4)))
     assert [n for n, _, _ in w] == ["partition", "path", "num_rows", "num_batches", "num_bytes"] and [t for _, t, _ in w] == ["UInt32", "Utf8", "UInt64", "UInt64", "UInt64"]
+
+
+def test_parquet_footer_is_read_on_the_host():
+    """gpuq_parquet_schema walks the Thrift-compact footer without a device: the reference's alltypes_plain.parquet
+    (ballista/client/testdata) and a pyarrow-written file with logical types."""
+    import io
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from arrow_ballista_amd import scan
+    L = g.lib()
+    fields, rows = scan.parquet_schema(L, os.path.join(os.path.dirname(__file__), "golden", "alltypes_plain.parquet"))
+    assert rows == 8
+    assert fields == [("id", "Int32", True), ("bool_col", "Boolean", True), ("tinyint_col", "Int32", True), ("smallint_col", "Int32", True),
+                      ("int_col", "Int32", True), ("bigint_col", "Int64", True), ("float_col", None, True), ("double_col", "Float64", True),
+                      ("date_string_col", "Utf8", True), ("string_col", "Utf8", True), ("timestamp_col", None, True)]
+    t = pa.table({"d": pa.array([1, 2], pa.date32()), "x": pa.array([1, None], pa.decimal128(15, 2)), "s": ["a", "b"]})
+    t = t.cast(pa.schema([pa.field("d", pa.date32(), False), pa.field("x", pa.decimal128(15, 2), True), pa.field("s", pa.string(), False)]))
+    buf = io.BytesIO()
+    pq.write_table(t, buf)
+    assert scan.parquet_schema(L, buf.getvalue()) == ([("d", "Date32", False), ("x", {"Decimal128": [15, 2]}, True), ("s", "Utf8", False)], 2)
+    with pytest.raises(g.GpuqError):
+        scan.parquet_schema(L, b"PAR1garbagePAR1")

@@ -1,0 +1,270 @@
+"""Scan-side decode on the device (include/gpuq.h "scan-side decode"): the CsvExec / ParquetExec leaves
+of the reference's TPC-H plans (benchmarks/src/bin/tpch.rs:801-862).  Checker: pyarrow's CSV and Parquet readers on the same
+bytes (bit-exact, including Float64: only the exactly-rounded fast path is decoded, anything else is refused)."""
+import decimal
+import io
+import os
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.csv as pacsv
+import pyarrow.parquet as pq
+import pytest
+
+import arrow_ballista_amd as g
+from arrow_ballista_amd import scan
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+D152 = {"Decimal128": [15, 2]}
+# benchmarks/src/bin/tpch.rs get_schema("lineitem") + the trailing `__placeholder` of get_tbl_tpch_table_schema (:959-964)
+LINEITEM = [("l_orderkey", "Int64", False), ("l_partkey", "Int64", False), ("l_suppkey", "Int64", False), ("l_linenumber", "Int32", False),
+            ("l_quantity", D152, False), ("l_extendedprice", D152, False), ("l_discount", D152, False), ("l_tax", D152, False),
+            ("l_returnflag", "Utf8", False), ("l_linestatus", "Utf8", False), ("l_shipdate", "Date32", False), ("l_commitdate", "Date32", False),
+            ("l_receiptdate", "Date32", False), ("l_shipinstruct", "Utf8", False), ("l_shipmode", "Utf8", False), ("l_comment", "Utf8", False),
+            ("__placeholder", "Utf8", False)]
+
+
+def pa_type(t):
+    if isinstance(t, dict):
+        return pa.decimal128(*t["Decimal128"])
+    return {"Int32": pa.int32(), "Int64": pa.int64(), "Date32": pa.date32(), "Float64": pa.float64(), "Boolean": pa.bool_(), "Utf8": pa.string()}[t]
+
+
+def pyarrow_csv(data, schema, delimiter=",", header=False, include=None):
+    names = [s[0] for s in schema]
+    ro = pacsv.ReadOptions(column_names=None if header else names, autogenerate_column_names=False)
+    co = pacsv.ConvertOptions(column_types={s[0]: pa_type(s[1]) for s in schema}, strings_can_be_null=True, null_values=[""], quoted_strings_can_be_null=False,
+                              include_columns=include, true_values=["true", "True", "TRUE"], false_values=["false", "False", "FALSE"])
+    t = pacsv.read_csv(io.BytesIO(data), read_options=ro, parse_options=pacsv.ParseOptions(delimiter=delimiter, quote_char=False), convert_options=co)
+    # the reference's reader (arrow-csv): an empty field is NULL only in a nullable column; in a required Utf8 column it is ""
+    cols = []
+    for f in t.schema:
+        nullable = dict((s[0], s[2]) for s in schema)[f.name]
+        c = t.column(f.name).combine_chunks()
+        if not nullable and pa.types.is_string(f.type):
+            c = c.fill_null("")
+        cols.append(c)
+    return pa.table(cols, names=t.schema.names)
+
+
+def same(got, want):
+    assert got.num_rows == want.num_rows
+    assert got.schema.names == want.schema.names
+    for name in want.schema.names:
+        a, b = got.column(name).combine_chunks(), want.column(name).combine_chunks()
+        assert a.type == b.type, (name, a.type, b.type)
+        assert a.null_count == b.null_count, name
+        if pa.types.is_floating(a.type):      # bit patterns, not ==
+            assert np.array_equal(np.asarray(a.fill_null(0.0)).view(np.uint64), np.asarray(b.fill_null(0.0)).view(np.uint64)), name
+            assert a.is_null().equals(b.is_null()), name
+        else:
+            assert a.equals(b), (name, a.to_pylist()[:5], b.to_pylist()[:5])
+
+
+# ------------------------------------------------------------------ delimited text
+@pytest.mark.parametrize("part", ["lineitem.partition0.tbl", "lineitem.partition1.tbl"])
+def test_tpch_tbl_lineitem_as_the_benchmark_registers_it(tc, part):
+    """The reference's own .tbl fixture (ballista/scheduler/testdata/lineitem), '|' delimited, no header, trailing delimiter."""
+    data = open(os.path.join(GOLD, "tpch10", part), "rb").read()
+    got = scan.read_csv(tc, data, LINEITEM, delimiter="|").to_arrow(tc.ctx)
+    same(got, pyarrow_csv(data, LINEITEM, delimiter="|"))
+    assert got.num_rows == 10 and got.column("__placeholder").to_pylist() == [""] * 10
+
+
+def test_tbl_from_a_path_with_projection_by_name(tc):
+    path = os.path.join(GOLD, "tpch10", "orders.tbl")
+    orders = [("o_orderkey", "Int64", False), ("o_custkey", "Int64", False), ("o_orderstatus", "Utf8", False), ("o_totalprice", D152, False),
+              ("o_orderdate", "Date32", False), ("o_orderpriority", "Utf8", False), ("o_clerk", "Utf8", False), ("o_shippriority", "Int32", False),
+              ("o_comment", "Utf8", False), ("__placeholder", "Utf8", False)]
+    want = pyarrow_csv(open(path, "rb").read(), orders, delimiter="|", include=["o_orderdate", "o_orderkey", "o_totalprice", "o_comment"])
+    got = scan.read_csv(tc, path, orders, projection=["o_orderdate", "o_orderkey", "o_totalprice", "o_comment"], delimiter="|").to_arrow(tc.ctx)
+    same(got, want)
+
+
+AGG100 = [("c1", "Utf8", False), ("c2", "Int32", False), ("c3", "Int32", False), ("c4", "Int32", False), ("c5", "Int64", False), ("c6", "Int64", False),
+          ("c7", "Int32", False), ("c8", "Int32", False), ("c9", "Int64", False), ("c10", "Utf8", False), ("c11", "Float64", False), ("c12", "Float64", False),
+          ("c13", "Utf8", False)]
+
+
+def test_reference_example_csv_with_header(tc):
+    """examples/testdata/aggregate_test_100.csv (header line; c10 exceeds Int64 and is read as text; c12 carries 16-17 significant
+    digits and is outside the exact fast path: projecting it is refused, not rounded differently)."""
+    data = open(os.path.join(GOLD, "aggregate_test_100.csv"), "rb").read()
+    keep = [s[0] for s in AGG100 if s[0] != "c12"]
+    got = scan.read_csv(tc, data, AGG100, projection=keep, has_header=True).to_arrow(tc.ctx)
+    same(got, pyarrow_csv(data, AGG100, header=True, include=keep))
+    assert got.num_rows == 100
+    with pytest.raises(g.GpuqError) as e:
+        scan.read_csv(tc, data, AGG100, has_header=True)
+    assert e.value.status == 3 and "Float64" in str(e.value)
+
+
+def synthetic_csv(n, seed, crlf=False, terminated=True):
+    r = np.random.default_rng(seed)
+    words = np.array(["", "a", "BUILDING", "a-string-longer-than-fifteen-bytes", "x" * 40, "café ☃"])
+    k = r.integers(-2**62, 2**62, n)
+    i = r.integers(-2**31, 2**31 - 1, n)
+    d = r.integers(-5000, 30000, n).astype("datetime64[D]")
+    dec = r.integers(-10**12, 10**12, n)
+    frac = r.integers(0, 3, n)             # 0, 1 or 2 fraction digits written
+    f_m = r.integers(-10**14, 10**14, n)   # <= 15 digits
+    f_e = r.integers(-22, 23, n)
+    b = r.integers(0, 2, n).astype(bool)
+    s = words[r.integers(0, len(words), n)]
+    nk_null = r.random(n) < 0.1
+    ns = words[r.integers(0, len(words), n)]
+    lines = []
+    for j in range(n):
+        v = int(dec[j]); fd = int(frac[j])
+        sign = "-" if v < 0 else ""
+        a = abs(v)
+        if fd == 0:
+            a -= a % 100; ds = "%s%d" % (sign, a // 100)
+        elif fd == 1:
+            a -= a % 10; ds = "%s%d.%d" % (sign, a // 100, (a % 100) // 10)
+        else:
+            ds = "%s%d.%02d" % (sign, a // 100, a % 100)
+        fs = "%de%d" % (f_m[j], f_e[j]) if j % 3 else ("%.6f" % (f_m[j] / 1e6))
+        lines.append(",".join([str(k[j]), str(i[j]), str(d[j]), ds, fs, "true" if b[j] else "false", s[j],
+                               "" if nk_null[j] else str(k[j] // 3), ns[j]]))
+    eol = "\r\n" if crlf else "\n"
+    text = eol.join(lines) + (eol if terminated and n else "")
+    schema = [("k", "Int64", False), ("i", "Int32", False), ("d", "Date32", False), ("dec", D152, False), ("f", "Float64", False), ("b", "Boolean", False),
+              ("s", "Utf8", False), ("nk", "Int64", True), ("ns", "Utf8", True)]
+    return text.encode(), schema
+
+
+@pytest.mark.parametrize("n,crlf,terminated", [(0, False, True), (1, False, False), (63, False, True), (64, True, True), (65, False, False), (50_000, True, False),
+                                                 (200_003, False, True)])
+def test_every_column_kind_against_pyarrow(tc, n, crlf, terminated):
+    """Int64, Int32, Date32 before and after 1970, Decimal128 with 0-2 written fraction digits, Float64 in fixed and
+    exponent notation, Boolean, Utf8 (empty, > 15 bytes, multi-byte), nullable Int64 and nullable Utf8; LF and CRLF; the last
+    line with and without its newline; row counts around the 64-lane validity words."""
+    data, schema = synthetic_csv(n, 11 + n, crlf, terminated)
+    got = scan.read_csv(tc, data, schema).to_arrow(tc.ctx)
+    if n == 0:
+        assert got.num_rows == 0 and got.schema.names == [s[0] for s in schema]
+        return
+    same(got, pyarrow_csv(data, schema))
+
+
+@pytest.mark.parametrize("text,code,what", [
+    (b'1,"a,b"\n', 3, "quoted"), (b"1\n", 1, "number of fields"), (b"1,2,3\n", 1, "number of fields"), (b"1x,a\n", 1, "parse"), (b",a\n", 1, "non-nullable"),
+])
+def test_malformed_text_is_refused(tc, text, code, what):
+    with pytest.raises(g.GpuqError) as e:
+        scan.read_csv(tc, text, [("a", "Int64", False), ("b", "Utf8", False)])
+    assert e.value.status == code and what in str(e.value)
+
+
+# ------------------------------------------------------------------ Parquet
+DEVICE_COLS = ["id", "bool_col", "tinyint_col", "smallint_col", "int_col", "bigint_col", "double_col", "date_string_col", "string_col"]
+
+
+def test_reference_alltypes_plain_parquet(tc):
+    """ballista/client/testdata/alltypes_plain.parquet (Impala-written, v1 pages, PLAIN_DICTIONARY, optional columns): the file the
+    reference's client KATs read (context.rs:762-967).  float_col (FLOAT) and timestamp_col (INT96) have no device decoder and are
+    announced as such by gpuq_parquet_schema; asking for them is refused."""
+    path = os.path.join(GOLD, "alltypes_plain.parquet")
+    fields, rows = scan.parquet_schema(tc.ctx.L, path)
+    assert rows == 8 and [f[0] for f in fields if f[1] is None] == ["float_col", "timestamp_col"]
+    got = scan.read_parquet(tc, path, DEVICE_COLS).to_arrow(tc.ctx)
+    want = pq.read_table(path, columns=DEVICE_COLS)
+    want = want.cast(pa.schema([pa.field(f.name, pa.string() if pa.types.is_binary(f.type) else f.type) for f in want.schema]))
+    same(got, want)
+    assert got.column("id").to_pylist() == [4, 5, 6, 7, 2, 3, 0, 1]
+    with pytest.raises(g.GpuqError) as e:
+        scan.read_parquet(tc, path)
+    assert e.value.status == 3
+
+
+def parquet_table(n, seed):
+    r = np.random.default_rng(seed)
+    words = np.array(["", "a", "BUILDING", "a-string-longer-than-fifteen-bytes", "x" * 40, "café ☃"])
+    dec = [decimal.Decimal(int(v)).scaleb(-2) for v in r.integers(-10**12, 10**12, min(n, 4096))] * (n // 4096 + 1)
+    t = pa.table({
+        "k": pa.array(r.integers(-2**62, 2**62, n), type=pa.int64()),
+        "lowcard": pa.array(r.integers(0, 7, n), type=pa.int64()),
+        "i": pa.array(r.integers(-2**31, 2**31 - 1, n).astype(np.int32)),
+        "d": pa.array(r.integers(-5000, 30000, n).astype(np.int32)).cast(pa.date32()),
+        "f": pa.array(r.normal(0, 1e6, n)),
+        "dec": pa.array(dec[:n], type=pa.decimal128(15, 2)),
+        "dec38": pa.array([x * 10**20 for x in dec[:n]], type=pa.decimal128(38, 2)),
+        "b": pa.array(r.integers(0, 2, n).astype(bool)),
+        "s": pa.array(words[r.integers(0, len(words), n)]),
+        "u": pa.array(["row-%d" % j for j in range(n)]),
+        "nk": pa.array(r.integers(0, 1000, n), type=pa.int64(), mask=r.random(n) < 0.1),
+        "nb": pa.array(r.integers(0, 2, n).astype(bool), mask=r.random(n) < 0.3),
+        "ns": pa.array(words[r.integers(0, len(words), n)], mask=r.random(n) < 0.2),
+        "allnull": pa.array([None] * n, type=pa.int32()),
+    })
+    req = ("k", "lowcard", "i", "d", "f", "dec", "dec38", "b", "s", "u")
+    return t.cast(pa.schema([pa.field(f.name, f.type, nullable=f.name not in req) for f in t.schema]))
+
+
+def write(t, **kw):
+    buf = io.BytesIO()
+    pq.write_table(t, buf, compression="NONE", **kw)
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 1000, 70_001])      # 0 = the schema of a 10-row table, no rows
+@pytest.mark.parametrize("opts", [
+    dict(use_dictionary=True, data_page_version="1.0"),
+    dict(use_dictionary=False, data_page_version="1.0"),
+    dict(use_dictionary=True, data_page_version="2.0", data_page_size=4096),
+    dict(use_dictionary=False, data_page_version="2.0", data_page_size=4096, row_group_size=9000),
+    dict(use_dictionary=["lowcard", "s", "ns"], data_page_version="1.0", data_page_size=2048, row_group_size=20_000, dictionary_pagesize_limit=64),
+], ids=["dict-v1", "plain-v1", "dict-v2-smallpages", "plain-v2-rowgroups", "mixed-dict-fallback"])
+def test_pyarrow_written_files(tc, n, opts):
+    """Required and optional columns of every decoded type; dictionary and PLAIN pages, v1 and v2 headers, many small pages, several
+    row groups, a dictionary that overflows and falls back to PLAIN mid-chunk; decimals as FIXED_LEN_BYTE_ARRAY (15,2) and (38,2)."""
+    t = parquet_table(n, 5 + n) if n else parquet_table(10, 5).slice(0, 0)
+    data = write(t, **opts)
+    got = scan.read_parquet(tc, data).to_arrow(tc.ctx)
+    same(got, pq.read_table(io.BytesIO(data)))
+
+
+def test_decimals_stored_as_integers_and_projection_order(tc):
+    t = parquet_table(5000, 2).select(["dec", "k", "ns"])
+    small = t.set_column(0, "dec", t.column("dec").cast(pa.decimal128(9, 2), safe=False) if False else pa.array([decimal.Decimal(v).scaleb(-2) for v in range(-2500, 2500)], type=pa.decimal128(9, 2)))
+    big = small.append_column("dec18", pa.array([decimal.Decimal(v * 10**9).scaleb(-2) for v in range(-2500, 2500)], type=pa.decimal128(18, 2)))
+    try:
+        data = write(big, store_decimal_as_integer=True)
+    except TypeError:
+        pytest.skip("this pyarrow cannot store decimals as integers")
+    got = scan.read_parquet(tc, data, ["dec18", "ns", "dec"]).to_arrow(tc.ctx)
+    same(got, pq.read_table(io.BytesIO(data), columns=["dec18", "ns", "dec"]))
+
+
+def test_compressed_chunks_and_garbage_are_refused(tc):
+    t = parquet_table(100, 1)
+    buf = io.BytesIO()
+    pq.write_table(t, buf, compression="ZSTD")
+    with pytest.raises(g.GpuqError) as e:
+        scan.read_parquet(tc, buf.getvalue())
+    assert e.value.status == 3 and "compressed" in str(e.value)
+    with pytest.raises(g.GpuqError):
+        scan.read_parquet(tc, b"PAR1" + b"\x00" * 64 + b"PAR1")
+    with pytest.raises(g.GpuqError) as e:
+        scan.read_parquet(tc, write(t), ["no_such_column"])
+    assert "not in the file" in str(e.value)
+
+
+def test_decoded_leaves_feed_q1(tc):
+    """TPC-H q1 over lineitem columns decoded on the device from Parquet bytes and from '|' text == the oracle's q1 over the same
+    generated rows (the plan's MemoryExec leaf holds what CsvExec / ParquetExec would have produced)."""
+    import tpch_util as T
+    n = 30_000
+    li = T.lineitem_host_to_arrow(T.gen_lineitem_host(n), n)
+    li = li.cast(pa.schema([pa.field(f.name, f.type, nullable=False) for f in li.schema]))
+    want = T.q1_oracle_rows(n)
+    from_parquet = scan.read_parquet(tc, write(li, use_dictionary=True, data_page_size=8192))
+    assert T.q1_result_to_rows(tc, T.run_q1(tc, from_parquet)) == want
+    cols = [li.column(i).to_pylist() for i in range(li.num_columns)]
+    text = "".join("|".join(str(c[j]) for c in cols) + "|\n" for j in range(n)).encode()
+    schema = [(f.name, {"int64": "Int64", "string": "Utf8", "date32[day]": "Date32"}.get(str(f.type), D152), False) for f in li.schema] + [("__placeholder", "Utf8", False)]
+    from_text = scan.read_csv(tc, text, schema, projection=list(range(li.num_columns)), delimiter="|")
+    assert T.q1_result_to_rows(tc, T.run_q1(tc, from_text)) == want

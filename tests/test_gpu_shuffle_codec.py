@@ -99,6 +99,56 @@ def test_independent_block_frames_and_block_index_walk(tc):
     same(pa.ipc.open_stream(raw).read_all(), t)
 
 
+def test_frame_by_frame_fallback_keeps_raw_stored_bitmaps(tc):
+    """A frame whose independent blocks are smaller than its declared maximum (legal: BD only bounds them) defeats the host-side
+    block index, and the decoder falls back to walking frames one by one after clearing the OR-merged bitmaps.  Buffers stored raw
+    (the -1 length prefix an incompressible validity bitmap gets) are copied, not decoded: the fallback has to issue those copies
+    again, or the column reads back all-NULL."""
+    import xxhash
+    n = 1 << 18
+    r = np.random.default_rng(5)
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64) % 1000),
+                  "r": pa.array(r.integers(-2**62, 2**62, n), type=pa.int64(), mask=r.random(n) < 0.5),
+                  "b": pa.array(r.integers(0, 2, n).astype(bool))})
+    buf = io.BytesIO()
+    S.write_ipc_stream(tc, buf, g.DeviceTable.from_arrow(t, tc.device), codec=0)
+    raw = bytearray(buf.getvalue())
+    at = raw.find(bytes([0x04, 0x22, 0x4D, 0x18]))
+    assert at > 0 and raw[at + 4: at + 7] == bytes([0x60, 0x40, 0x82])      # 64 KiB independent blocks, 32 of them in k's data
+    raw[at + 5] = 0x50                                                       # claim 256 KiB: every block is now "not full"
+    raw[at + 6] = (xxhash.xxh32(bytes(raw[at + 4: at + 6]), seed=0).intdigest() >> 8) & 0xFF
+    same(pa.ipc.open_stream(bytes(raw)).read_all(), t)                       # still a valid stream for Arrow C++
+    back, _ = S.read_ipc_stream(tc, bytes(raw))
+    got = back.to_arrow(tc.ctx)
+    assert got.column("r").null_count == t.column("r").null_count
+    same(got, t)
+
+
+def test_corrupt_utf8_offsets_are_refused(tc):
+    """Offsets of a peer's shuffle file are untrusted: an uncompressed stream whose Utf8 offsets were made to run backwards / past the
+    data buffer fails with 'malformed', it does not hand out a column whose offsets point outside its bytes."""
+    t = pa.table({"s": pa.array(["row-%05d" % i for i in range(4096)])})
+    sink = io.BytesIO()
+    with pa.ipc.new_stream(sink, t.schema) as w:
+        w.write_table(t)
+    raw = bytearray(sink.getvalue())
+    back, _ = S.read_ipc_stream(tc, bytes(raw))
+    same(back.to_arrow(tc.ctx), t)
+    # the offsets buffer is the run 0, 9, 18, ...: find entry 100 (= 900) followed by 909 and corrupt it
+    pat = np.array([900, 909, 918], dtype=np.int32).tobytes()
+    at = bytes(raw).find(pat)
+    assert at > 0
+    for bad_value in (5_000_000, -7, 700):       # beyond the data, negative, not monotone
+        bad = bytearray(raw)
+        bad[at + 4: at + 8] = np.array([bad_value], dtype=np.int32).tobytes() if bad_value != 5_000_000 else bad[at + 4: at + 8]
+        if bad_value == 5_000_000:               # the LAST offset (4096 * 9) pushed past the data buffer
+            last = bytes(raw).find(np.array([4095 * 9, 4096 * 9], dtype=np.int32).tobytes())
+            bad[last + 4: last + 8] = np.array([bad_value], dtype=np.int32).tobytes()
+        with pytest.raises(g.GpuqError) as e:
+            S.read_ipc_stream(tc, bytes(bad))
+        assert "offsets" in str(e.value)
+
+
 def test_malformed_streams_fail_loudly(tc):
     t = table_for(3, 4000, 0.0)
     sink = io.BytesIO()
