@@ -17,27 +17,49 @@ __device__ __forceinline__ int fwave() { return threadIdx.x >> 6; }
 // ------------------------------------------------------------------ delimited text
 // 1. line ends: every block counts the '\n' bytes of its chunk; after a scan of the counts k_csv_line_starts writes the start
 //    offset of every line (ordered ballot compaction inside a wave, waves of a block in order).
+// 0x80 in every byte of w that equals '\n' (exact per byte: no borrow between bytes)
+__device__ __forceinline__ uint32_t nl_mask(uint32_t w) {
+  const uint32_t x = w ^ 0x0A0A0A0Au;
+  const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  return ~(t | x | 0x7F7F7F7Fu);
+}
+// the 16 bytes at text[i .. i+16) of a 16-byte aligned i, bytes at or beyond `b` (and before `a`) masked out; bit k = byte k is '\n'
+__device__ __forceinline__ uint32_t nl_bits16(const uint8_t* __restrict__ text, i64 i, i64 a, i64 b) {
+  const uint4 v = *(const uint4*)(text + i);
+  const uint32_t m0 = nl_mask(v.x), m1 = nl_mask(v.y), m2 = nl_mask(v.z), m3 = nl_mask(v.w);
+  // gather the 0x80 flags of each word into 4 bits
+  auto pack = [](uint32_t m) -> uint32_t { return ((m >> 7) & 1u) | ((m >> 14) & 2u) | ((m >> 21) & 4u) | ((m >> 28) & 8u); };
+  uint32_t bits = pack(m0) | (pack(m1) << 4) | (pack(m2) << 8) | (pack(m3) << 12);
+  if (i < a) bits &= ~((1u << (int)(a - i)) - 1u);
+  if (i + 16 > b) bits &= (b > i) ? ((1u << (int)(b - i)) - 1u) : 0u;
+  return bits;
+}
+// chunks start on 16-byte boundaries (chunk is a multiple of 16, the text buffer is 256-byte aligned with >= 64 bytes of slack)
 __global__ void __launch_bounds__(FBLOCK) k_csv_count_lines(const uint8_t* __restrict__ text, const i64 n, const i64 chunk, uint32_t* __restrict__ counts) {
   __shared__ uint32_t wc[FWAVES];
   const i64 a = (i64)blockIdx.x * chunk; i64 b = a + chunk; if (b > n) b = n;
   uint32_t c = 0;
-  for (i64 i = a + threadIdx.x; i < b; i += FBLOCK) c += text[i] == '\n';
+  for (i64 i = a + (i64)threadIdx.x * 16; i < b; i += FBLOCK * 16) c += (uint32_t)__popc(nl_bits16(text, i, a, b));
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
   if (flane() == 0) wc[fwave()] = c;
   __syncthreads();
   if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < FWAVES; ++k) t += wc[k]; counts[blockIdx.x] = t; }
 }
-// starts[r + 1] = offset of the byte after the r-th '\n' (starts[0] = 0 is set by the host): one wave walks the block's chunk
+// starts[r + 1] = offset of the byte after the r-th '\n' (starts[0] = 0 is set by the host): one wave walks the block's chunk,
+// 16 bytes per lane and step; the lanes' newline counts are prefix-summed across the wave to place each line start in order
 __global__ void __launch_bounds__(64) k_csv_line_starts(const uint8_t* __restrict__ text, const i64 n, const i64 chunk, const uint32_t* __restrict__ block_offsets,
                                                         i64* __restrict__ starts) {
   const i64 a = (i64)blockIdx.x * chunk; i64 b = a + chunk; if (b > n) b = n;
   u64 out = (u64)block_offsets[blockIdx.x] + 1;
-  for (i64 i0 = a; i0 < b; i0 += 64) {
-    const i64 i = i0 + flane();
-    const bool nl = i < b && text[i] == '\n';
-    const u64 m = __ballot(nl);
-    if (nl) starts[out + (u64)__popcll(m & ((1ull << flane()) - 1))] = i + 1;
-    out += (u64)__popcll(m);
+  for (i64 i0 = a; i0 < b; i0 += 64 * 16) {
+    const i64 i = i0 + (i64)flane() * 16;
+    uint32_t bits = i < b ? nl_bits16(text, i, a, b) : 0u;
+    const uint32_t cnt = (uint32_t)__popc(bits);
+    uint32_t incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (flane() >= o) incl += y; }
+    u64 at = out + (u64)(incl - cnt);
+    while (bits) { const int k = __ffs((int)bits) - 1; bits &= bits - 1; starts[at++] = i + k + 1; }
+    out += (u64)__shfl(incl, 63);
   }
 }
 
@@ -53,12 +75,27 @@ __device__ __forceinline__ int32_t days_from_civil(int y, int m, int d) {
 
 // 2. one lane per line: walk the line's bytes once, parse the projected fields in place.  Strings only record (start, length);
 //    their bytes are copied after the lengths have been scanned into offsets.
-__global__ void __launch_bounds__(FBLOCK) k_csv_parse(const uint8_t* __restrict__ text, const i64 n_bytes, const i64* __restrict__ starts, const i64 row0, const i64 n_rows,
+//    The 256 lines of a block are one contiguous byte range: it is staged into LDS with coalesced 16-byte loads (lane-per-line
+//    byte loads from global memory touch a different cache line per lane and step); ranges beyond the LDS budget are read in place.
+constexpr int CSV_LDS_BYTES = 40 * 1024;
+struct CsvText {
+  const uint8_t* g; const uint8_t* l; i64 base; bool staged;
+  __device__ __forceinline__ uint8_t operator[](i64 i) const { return staged ? l[i - base] : g[i]; }
+};
+__global__ void __launch_bounds__(FBLOCK) k_csv_parse(const uint8_t* __restrict__ gtext, const i64 n_bytes, const i64* __restrict__ starts, const i64 row0, const i64 n_rows,
                                                       const CsvSpec S, const CsvOut O, uint32_t* __restrict__ flags) {
-  for (i64 r = (i64)blockIdx.x * FBLOCK + threadIdx.x; ; r += (i64)gridDim.x * FBLOCK) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[CSV_LDS_BYTES];
+  for (i64 rb = (i64)blockIdx.x * FBLOCK; rb < n_rows; rb += (i64)gridDim.x * FBLOCK) {
+    const i64 r = rb + threadIdx.x;
     const bool live = r < n_rows;
-    // validity words are assembled with ballots: every lane of the wave stays in the loop until the wave's last row is done
-    if (__ballot(live) == 0) break;
+    const i64 rlast = rb + FBLOCK < n_rows ? rb + FBLOCK : n_rows;
+    const i64 lo = starts[row0 + rb] & ~(i64)15, hi = starts[row0 + rlast];      // block-uniform
+    CsvText text{gtext, lds, lo, hi - lo <= (i64)CSV_LDS_BYTES};
+    __syncthreads();                                                              // the previous iteration's readers are done
+    if (text.staged) {
+      for (i64 i = lo + (i64)threadIdx.x * 16; i < hi; i += FBLOCK * 16) *(uint4*)(lds + (i - lo)) = *(const uint4*)(gtext + i);
+      __syncthreads();
+    }
     i64 p = 0, end = 0;
     if (live) {
       p = starts[row0 + r]; end = starts[row0 + r + 1] - 1;            // end = position of the '\n' (or of the end of the text)

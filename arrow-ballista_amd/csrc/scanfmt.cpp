@@ -5,8 +5,11 @@
 #include "gpuq_kernels.h"
 #include "expr_compile.h"
 #include <cstring>
+#include <atomic>
 #include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 using namespace gpuq;
 
@@ -19,9 +22,63 @@ template <class F> int guarded_f(F&& f) {
   catch (const Capacity& e) { g_ferr = e.what(); return GPUQ_ERR_CAPACITY; }
   catch (const std::exception& e) { g_ferr = e.what(); return GPUQ_ERR_INVALID; }
 }
+// File bytes are pageable host memory: one thread staging them through a pinned buffer moves ~6-10 GB/s, a sixth of the link.
+// Bulk uploads therefore go through a few staging lanes (thread + stream + two pinned slots each, kept for the process lifetime):
+// lanes pull 4 MiB chunks off a shared counter, memcpy into a free slot and queue the DMA, so memcpys and DMAs of all lanes overlap.
+struct Uploader {
+  static constexpr size_t SLOT = (size_t)4 << 20;
+  static constexpr int LANES = 8, SLOTS = 2;
+  struct Lane { void* pin[SLOTS] = {}; hipEvent_t ev[SLOTS] = {}; hipStream_t st = nullptr; int dev = -1; };
+  Lane lanes[LANES]; std::mutex mu;
+  void prepare(Lane& L, int device) {
+    if (L.dev == device) return;
+    if (L.dev >= 0) throw Unsupported("scan decode: bulk uploads of one process go to one device");
+    HIPCHECK(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+    for (int k = 0; k < SLOTS; ++k) { HIPCHECK(hipHostMalloc(&L.pin[k], SLOT, hipHostMallocDefault)); HIPCHECK(hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming)); }
+    L.dev = device;
+  }
+  struct Seg { size_t dst_off; const uint8_t* src; size_t n; };      // one byte range of the source -> dst + dst_off
+  void copy(int device, hipStream_t s, void* dst, const void* src, size_t n) { copy_segments(device, s, dst, {Seg{0, (const uint8_t*)src, n}}); }
+  void copy_segments(int device, hipStream_t s, void* dst_base, const std::vector<Seg>& segs) {
+    struct Chunk { size_t dst_off; const uint8_t* src; size_t n; };
+    std::vector<Chunk> chunks; size_t total = 0;
+    for (auto& g : segs) { total += g.n; for (size_t o = 0; o < g.n; o += SLOT) chunks.push_back({g.dst_off + o, g.src + o, std::min(SLOT, g.n - o)}); }
+    if (total < 2 * SLOT) {
+      for (auto& c : chunks) HIPCHECK(hipMemcpyAsync((char*)dst_base + c.dst_off, c.src, c.n, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipStreamSynchronize(s)); return;
+    }
+    HIPCHECK(hipStreamSynchronize(s));      // earlier users of the (pooled) destination on `s` are done before other streams write it
+    std::lock_guard<std::mutex> g(mu);
+    const size_t nchunks = chunks.size();
+    const int nt = (int)std::min<size_t>(LANES, nchunks);
+    std::atomic<size_t> next{0}; std::mutex emu; std::string err;
+    auto work = [&](int t) {
+      try {
+        HIPCHECK(hipSetDevice(device));
+        Lane& L = lanes[t]; prepare(L, device);
+        bool used[SLOTS] = {}; int k = 0;
+        for (;;) {
+          const size_t c = next.fetch_add(1); if (c >= nchunks) break;
+          const Chunk& ch = chunks[c];
+          const int sl = k++ % SLOTS;
+          if (used[sl]) HIPCHECK(hipEventSynchronize(L.ev[sl]));
+          std::memcpy(L.pin[sl], ch.src, ch.n);
+          HIPCHECK(hipMemcpyAsync((char*)dst_base + ch.dst_off, L.pin[sl], ch.n, hipMemcpyHostToDevice, L.st));
+          HIPCHECK(hipEventRecord(L.ev[sl], L.st)); used[sl] = true;
+        }
+        HIPCHECK(hipStreamSynchronize(L.st));
+      } catch (const std::exception& e) { std::lock_guard<std::mutex> g2(emu); err = e.what(); next.store(nchunks); }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    if (!err.empty()) throw HipError("scan decode: upload failed: " + err);
+  }
+};
+Uploader g_uploader;
 void h2d(gpuq_ctx* ctx, hipStream_t s, void* dst, const void* src, size_t n) {
-  if (!n) return;
-  if (gpuq_copy_h2d(ctx, (void*)s, dst, src, n) != GPUQ_OK) throw HipError(std::string("scan decode: upload failed: ") + gpuq_last_error(ctx));
+  if (n) g_uploader.copy(ctx->device, s, dst, src, n);
 }
 template <class T> T d2h_value(hipStream_t s, const T* dev) { T v; HIPCHECK(hipMemcpyAsync(&v, dev, sizeof(T), hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s)); return v; }
 gpuq_field_info field_of(const std::string& name, int type, int p, int sc, bool nullable) {
@@ -288,39 +345,31 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
     } else for (size_t k = 0; k < leaves.size(); ++k) proj.push_back((int)k);
     const int64_t n_rows = M.num_rows;
     if (n_rows > 0xFFFFFFFEll) throw Unsupported("parquet: more than 2^32-2 rows per call");
-    std::unique_ptr<gpuq_table> t(new gpuq_table()); t->ctx = ctx; t->n_rows = n_rows;
-    DevBuf flags; flags.ensure(16); HIPCHECK(hipMemsetAsync(flags.p, 0, 16, s));
-    const size_t bm = (size_t)((n_rows + 63) / 64) * 8 + 16;
+    // ---- pass 1 (host): per projected column the type mapping, the byte ranges of its chunks and one descriptor per page
+    struct DictSrc { int64_t src; int bytes, n; };
+    struct ColPlan {
+      int gt = -1, gp = 0, gs = 0, width = 0, max_values = 0; bool optional = false;
+      std::vector<PqPage> pages; std::vector<DictSrc> dict_src; std::vector<PqDict> dicts;
+      DevBuf str_src, dvalues, dstroffs, ddicts, dpages, scratch;
+    };
+    std::vector<std::unique_ptr<ColPlan>> plans;
+    std::vector<Uploader::Seg> segs; int64_t up_bytes = 0;      // projected chunks back to back (64-byte aligned) in one device buffer
     for (int li : proj) {
       const PqSchemaElem& L = leaves[(size_t)li];
-      // ---- type mapping (parquet.thrift Type / ConvertedType / LogicalType -> gpuq_type)
-      int gt = -1, gp = 0, gs = 0, width = 0;
+      auto P = std::make_unique<ColPlan>();
+      // type mapping (parquet.thrift Type / ConvertedType / LogicalType -> gpuq_type)
       const bool is_decimal = L.logical_decimal || L.converted == 5;
       switch (L.type) {
-        case 0: gt = T_BOOL; break;
-        case 1: if (is_decimal) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; width = 16; } else if (L.logical_date || L.converted == 6) { gt = T_DATE32; width = 4; } else { gt = T_INT32; width = 4; } break;
-        case 2: if (is_decimal) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; width = 16; } else { gt = T_INT64; width = 8; } break;
-        case 5: gt = T_FLOAT64; width = 8; break;
-        case 6: if (is_decimal) throw Unsupported("parquet: BYTE_ARRAY decimals ('" + L.name + "')"); gt = T_UTF8; break;
-        case 7: if (!is_decimal || L.type_length > 16) throw Unsupported("parquet: FIXED_LEN_BYTE_ARRAY column '" + L.name + "' (only decimals of <= 16 bytes)"); gt = T_DECIMAL128; gp = L.precision; gs = L.scale; width = 16; break;
+        case 0: P->gt = T_BOOL; break;
+        case 1: if (is_decimal) { P->gt = T_DECIMAL128; P->gp = L.precision; P->gs = L.scale; P->width = 16; } else if (L.logical_date || L.converted == 6) { P->gt = T_DATE32; P->width = 4; } else { P->gt = T_INT32; P->width = 4; } break;
+        case 2: if (is_decimal) { P->gt = T_DECIMAL128; P->gp = L.precision; P->gs = L.scale; P->width = 16; } else { P->gt = T_INT64; P->width = 8; } break;
+        case 5: P->gt = T_FLOAT64; P->width = 8; break;
+        case 6: if (is_decimal) throw Unsupported("parquet: BYTE_ARRAY decimals ('" + L.name + "')"); P->gt = T_UTF8; break;
+        case 7: if (!is_decimal || L.type_length > 16) throw Unsupported("parquet: FIXED_LEN_BYTE_ARRAY column '" + L.name + "' (only decimals of <= 16 bytes)"); P->gt = T_DECIMAL128; P->gp = L.precision; P->gs = L.scale; P->width = 16; break;
         default: throw Unsupported("parquet: physical type " + std::to_string(L.type) + " of column '" + L.name + "' (FLOAT / INT96 are not read on the device)");
       }
-      const bool optional = L.repetition == 1;
-      std::unique_ptr<ImportedCol> ic(new ImportedCol());
-      ic->field = field_of(L.name, gt, gp, gs, optional);
-      ic->col.type = gt; ic->col.precision = gp; ic->col.scale = gs; ic->col.repr = GPUQ_REPR_ARROW; ic->col.length = n_rows;
-      PqCol C{}; C.phys = L.type; C.width = width; C.flba_len = L.type_length; C.optional = optional ? 1 : 0;
-      DevBuf str_src;
-      if (gt == T_UTF8) { ic->offsets.ensure((size_t)(n_rows + 2) * 4 + 16); str_src.ensure((size_t)std::max<int64_t>(n_rows, 1) * 8); C.str_len = (int32_t*)ic->offsets.p; C.str_src = (i64*)str_src.p; }
-      else if (gt == T_BOOL) { ic->data.ensure(bm); HIPCHECK(hipMemsetAsync(ic->data.p, 0, bm, s)); C.data = ic->data.p; ic->col.data = ic->data.p; }
-      else { ic->data.ensure((size_t)std::max<int64_t>(n_rows, 1) * (size_t)width + 16); if (optional) HIPCHECK(hipMemsetAsync(ic->data.p, 0, (size_t)std::max<int64_t>(n_rows, 1) * (size_t)width, s)); C.data = ic->data.p; ic->col.data = ic->data.p; }
-      if (optional) { ic->validity.ensure(bm); HIPCHECK(hipMemsetAsync(ic->validity.p, 0, bm, s)); C.valid = (u64*)ic->validity.p; ic->col.validity = (const uint8_t*)ic->validity.p; }
-      // ---- the column's chunks: upload their byte ranges back to back, walk the page headers
-      std::vector<PqPage> pages; std::vector<PqDict> dicts;
-      struct DictSrc { int64_t src; int bytes, n; };
-      std::vector<DictSrc> dict_src;
-      int64_t up_bytes = 0; std::vector<std::pair<int64_t, int64_t>> ranges;      // (file offset, bytes)
-      int64_t row = 0; int max_values = 0;
+      P->optional = L.repetition == 1;
+      int64_t row = 0;
       for (const PqRowGroup& G : M.groups) {
         if ((size_t)li >= G.cols.size()) throw std::runtime_error("parquet: row group without column " + L.name);
         const PqChunk& K = G.cols[(size_t)li];
@@ -330,7 +379,7 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
         const int64_t chunk_end = pos + K.total_compressed;
         if (pos < 4 || chunk_end > n_bytes - 8) throw std::runtime_error("parquet: column chunk outside the file");
         const int64_t base = up_bytes - pos;      // device position = file position + base
-        ranges.push_back({pos, K.total_compressed}); up_bytes += (K.total_compressed + 63) & ~(int64_t)63;
+        segs.push_back({(size_t)up_bytes, file + pos, (size_t)K.total_compressed}); up_bytes += (K.total_compressed + 63) & ~(int64_t)63;
         int64_t seen = 0; int dict_id = -1;
         while (pos < chunk_end && seen < K.num_values) {
           const PqPageHeader H = read_page_header(file + pos, file + chunk_end);
@@ -338,15 +387,15 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
           if (payload + H.compressed > chunk_end) throw std::runtime_error("parquet: page exceeds its column chunk");
           if (H.type == 2) {       // dictionary page
             if (H.encoding != 0 && H.encoding != 2) throw Unsupported("parquet: dictionary page encoding " + std::to_string(H.encoding));
-            dict_id = (int)dict_src.size(); dict_src.push_back({payload + base, H.compressed, H.num_values});
+            dict_id = (int)P->dict_src.size(); P->dict_src.push_back({payload + base, H.compressed, H.num_values});
           } else if (H.type == 0 || H.type == 3) {
-            PqPage P{}; P.src = payload + base; P.bytes = H.compressed; P.n_values = H.num_values; P.row0 = row + seen; P.dict = dict_id;
-            if (H.encoding == 0) P.enc = PQE_PLAIN; else if (H.encoding == 2 || H.encoding == 8) P.enc = PQE_DICT; else if (H.encoding == 3 && L.type == 0) P.enc = PQE_RLE;
+            PqPage G2{}; G2.src = payload + base; G2.bytes = H.compressed; G2.n_values = H.num_values; G2.row0 = row + seen; G2.dict = dict_id;
+            if (H.encoding == 0) G2.enc = PQE_PLAIN; else if (H.encoding == 2 || H.encoding == 8) G2.enc = PQE_DICT; else if (H.encoding == 3 && L.type == 0) G2.enc = PQE_RLE;
             else throw Unsupported("parquet: data page encoding " + std::to_string(H.encoding) + " in '" + L.name + "' (PLAIN, RLE_DICTIONARY and RLE booleans are decoded)");
-            if (H.type == 3) { if (H.rep_v2 != 0) throw Unsupported("parquet: repetition levels"); P.def_v2 = H.def_v2; if (optional && H.def_v2 == 0) P.def_v2 = 0; }
-            if (H.type == 3 && optional && H.def_v2 == 0 && H.num_values > 0) throw std::runtime_error("parquet: v2 page of an optional column without definition levels");
-            if (P.enc == PQE_DICT && dict_id < 0) throw std::runtime_error("parquet: dictionary-encoded page before any dictionary page");
-            pages.push_back(P); seen += H.num_values; max_values = std::max(max_values, H.num_values);
+            if (H.type == 3) { if (H.rep_v2 != 0) throw Unsupported("parquet: repetition levels"); G2.def_v2 = H.def_v2; }
+            if (H.type == 3 && P->optional && H.def_v2 == 0 && H.num_values > 0) throw std::runtime_error("parquet: v2 page of an optional column without definition levels");
+            if (G2.enc == PQE_DICT && dict_id < 0) throw std::runtime_error("parquet: dictionary-encoded page before any dictionary page");
+            P->pages.push_back(G2); seen += H.num_values; P->max_values = std::max(P->max_values, H.num_values);
           }
           pos = payload + H.compressed;
         }
@@ -354,40 +403,55 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
         row += K.num_values;
       }
       if (row != n_rows) throw std::runtime_error("parquet: column '" + L.name + "' has " + std::to_string(row) + " values for " + std::to_string(n_rows) + " rows");
-      DevBuf dfile; dfile.ensure((size_t)up_bytes + 64);
-      { int64_t at = 0; for (auto& rg : ranges) { h2d(ctx, s, (char*)dfile.p + at, file + rg.first, (size_t)rg.second); at += (rg.second + 63) & ~(int64_t)63; } }
-      // ---- dictionaries -> output-width values / contiguous strings
-      DevBuf dvalues, dstroffs, ddicts;
-      {
-        size_t vbytes = 0, obytes = 0;
-        for (auto& d : dict_src) { vbytes += (gt == T_UTF8 ? (size_t)d.bytes : (size_t)d.n * (size_t)width) + 64; obytes += ((size_t)d.n + 2) * 4; }
-        dvalues.ensure(vbytes + 64); dstroffs.ensure(obytes + 64);
-        size_t va = 0, oa = 0;
-        for (auto& d : dict_src) {
-          PqDict D{}; D.values = (i64)va; D.str_offsets = (i64)(oa / 4); D.n = d.n;
-          if (gt == T_UTF8) { launch_pq_dict_strings(s, (const uint8_t*)dfile.p, d.src, d.bytes, d.n, (int32_t*)dstroffs.p + oa / 4, (uint8_t*)dvalues.p + va, (uint32_t*)flags.p); va += ((size_t)d.bytes + 63) & ~(size_t)63; oa += ((size_t)d.n + 2) * 4; }
-          else { launch_pq_dict_fixed(s, (const uint8_t*)dfile.p, d.src, d.n, L.type, L.type_length, width, (uint8_t*)dvalues.p + va); va += ((size_t)d.n * (size_t)width + 63) & ~(size_t)63; }
-          dicts.push_back(D);
-        }
-        ddicts.ensure(dicts.size() * sizeof(PqDict) + 64);
-        if (!dicts.empty()) HIPCHECK(hipMemcpyAsync(ddicts.p, dicts.data(), dicts.size() * sizeof(PqDict), hipMemcpyHostToDevice, s));
+      plans.push_back(std::move(P));
+    }
+    // ---- the projected chunks cross PCIe once, all staging lanes busy
+    DevBuf dfile; dfile.ensure((size_t)up_bytes + 64);
+    g_uploader.copy_segments(ctx->device, s, dfile.p, segs);
+    // ---- pass 2 (device): dictionaries, pages, strings; one synchronisation at the end
+    std::unique_ptr<gpuq_table> t(new gpuq_table()); t->ctx = ctx; t->n_rows = n_rows;
+    DevBuf flags; flags.ensure(16); HIPCHECK(hipMemsetAsync(flags.p, 0, 16, s));
+    const size_t bm = (size_t)((n_rows + 63) / 64) * 8 + 16;
+    const size_t rows1 = (size_t)std::max<int64_t>(n_rows, 1);
+    for (size_t pi = 0; pi < plans.size(); ++pi) {
+      ColPlan& P = *plans[pi]; const PqSchemaElem& L = leaves[(size_t)proj[pi]];
+      const int gt = P.gt, width = P.width;
+      std::unique_ptr<ImportedCol> ic(new ImportedCol());
+      ic->field = field_of(L.name, gt, P.gp, P.gs, P.optional);
+      ic->col.type = gt; ic->col.precision = P.gp; ic->col.scale = P.gs; ic->col.repr = GPUQ_REPR_ARROW; ic->col.length = n_rows;
+      PqCol C{}; C.phys = L.type; C.width = width; C.flba_len = L.type_length; C.optional = P.optional ? 1 : 0;
+      if (gt == T_UTF8) { ic->offsets.ensure((size_t)(n_rows + 2) * 4 + 16); P.str_src.ensure(rows1 * 8); C.str_len = (int32_t*)ic->offsets.p; C.str_src = (i64*)P.str_src.p; }
+      else if (gt == T_BOOL) { ic->data.ensure(bm); HIPCHECK(hipMemsetAsync(ic->data.p, 0, bm, s)); C.data = ic->data.p; ic->col.data = ic->data.p; }
+      else { ic->data.ensure(rows1 * (size_t)width + 16); if (P.optional) HIPCHECK(hipMemsetAsync(ic->data.p, 0, rows1 * (size_t)width, s)); C.data = ic->data.p; ic->col.data = ic->data.p; }
+      if (P.optional) { ic->validity.ensure(bm); HIPCHECK(hipMemsetAsync(ic->validity.p, 0, bm, s)); C.valid = (u64*)ic->validity.p; ic->col.validity = (const uint8_t*)ic->validity.p; }
+      // dictionaries -> output-width values / contiguous strings
+      size_t vbytes = 0, obytes = 0;
+      for (auto& d : P.dict_src) { vbytes += (gt == T_UTF8 ? (size_t)d.bytes : (size_t)d.n * (size_t)width) + 64; obytes += ((size_t)d.n + 2) * 4; }
+      P.dvalues.ensure(vbytes + 64); P.dstroffs.ensure(obytes + 64);
+      size_t va = 0, oa = 0;
+      for (auto& d : P.dict_src) {
+        PqDict D{}; D.values = (i64)va; D.str_offsets = (i64)(oa / 4); D.n = d.n;
+        if (gt == T_UTF8) { launch_pq_dict_strings(s, (const uint8_t*)dfile.p, d.src, d.bytes, d.n, (int32_t*)P.dstroffs.p + oa / 4, (uint8_t*)P.dvalues.p + va, (uint32_t*)flags.p); va += ((size_t)d.bytes + 63) & ~(size_t)63; oa += ((size_t)d.n + 2) * 4; }
+        else { launch_pq_dict_fixed(s, (const uint8_t*)dfile.p, d.src, d.n, L.type, L.type_length, width, (uint8_t*)P.dvalues.p + va); va += ((size_t)d.n * (size_t)width + 63) & ~(size_t)63; }
+        P.dicts.push_back(D);
       }
-      // ---- pages
-      DevBuf dpages; dpages.ensure(pages.size() * sizeof(PqPage) + 64);
-      if (!pages.empty()) HIPCHECK(hipMemcpyAsync(dpages.p, pages.data(), pages.size() * sizeof(PqPage), hipMemcpyHostToDevice, s));
-      const i64 stride = (3 * (i64)max_values + 9) & ~(i64)1;      // row index + (dictionary indices | 8-byte string positions), 8-byte aligned rows
-      DevBuf scratch; scratch.ensure((size_t)std::max<size_t>(pages.size(), 1) * (size_t)stride * 4 + 64);
-      launch_pq_decode(s, (const uint8_t*)dfile.p, up_bytes, (const PqPage*)dpages.p, (int)pages.size(), C, (const PqDict*)ddicts.p, (const uint8_t*)dvalues.p, (const int32_t*)dstroffs.p,
-                       (uint32_t*)scratch.p, stride, (uint32_t*)flags.p);
+      P.ddicts.ensure(P.dicts.size() * sizeof(PqDict) + 64);
+      if (!P.dicts.empty()) HIPCHECK(hipMemcpyAsync(P.ddicts.p, P.dicts.data(), P.dicts.size() * sizeof(PqDict), hipMemcpyHostToDevice, s));
+      // pages: row index + (dictionary indices | 8-byte string positions) per page, 8-byte aligned rows
+      P.dpages.ensure(P.pages.size() * sizeof(PqPage) + 64);
+      if (!P.pages.empty()) HIPCHECK(hipMemcpyAsync(P.dpages.p, P.pages.data(), P.pages.size() * sizeof(PqPage), hipMemcpyHostToDevice, s));
+      const i64 stride = (3 * (i64)P.max_values + 9) & ~(i64)1;
+      P.scratch.ensure((size_t)std::max<size_t>(P.pages.size(), 1) * (size_t)stride * 4 + 64);
+      launch_pq_decode(s, (const uint8_t*)dfile.p, up_bytes, (const PqPage*)P.dpages.p, (int)P.pages.size(), C, (const PqDict*)P.ddicts.p, (const uint8_t*)P.dvalues.p, (const int32_t*)P.dstroffs.p,
+                       (uint32_t*)P.scratch.p, stride, (uint32_t*)flags.p);
       HIPCHECK(hipGetLastError());
       if (gt == T_UTF8) {
-        const uint8_t* df = (const uint8_t*)dfile.p; const uint8_t* dv = (const uint8_t*)dvalues.p; const i64* src = (const i64*)str_src.p;
+        const uint8_t* df = (const uint8_t*)dfile.p; const uint8_t* dv = (const uint8_t*)P.dvalues.p; const i64* src = (const i64*)P.str_src.p;
         finish_strings(s, *ic, (int32_t*)ic->offsets.p, n_rows, [&](const int32_t* offs, uint8_t* dst, int64_t) { launch_pq_copy_strings(s, df, dv, src, offs, n_rows, dst); });
       }
-      HIPCHECK(hipStreamSynchronize(s));      // host vectors and per-column scratch die with this iteration
       t->cols.push_back(std::move(ic));
     }
-    const uint32_t fl = d2h_value(s, (const uint32_t*)flags.p);
+    const uint32_t fl = d2h_value(s, (const uint32_t*)flags.p);      // synchronises: the plans' host vectors and scratch may go
     if (fl & PQF_MALFORMED) throw std::runtime_error("parquet: malformed page (levels / indices / lengths run past the page, or an index beyond its dictionary)");
     if (fl & PQF_UNSUPPORTED) throw Unsupported("parquet: a page holds a value type the device does not decode");
     *out = t.release();

@@ -24,15 +24,13 @@ def _host_bytes(src):
         m = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_COPY)      # private mapping: writable view for from_buffer, file untouched
         buf = (C.c_ubyte * n).from_buffer(m)
         return (f, m, buf), C.addressof(buf), n
+    import numpy as np
     mv = memoryview(src).cast("B")
     n = mv.nbytes
     if n == 0:
         return mv, 0, 0
-    if mv.readonly:
-        buf = (C.c_ubyte * n).from_buffer_copy(mv)
-    else:
-        buf = (C.c_ubyte * n).from_buffer(mv)
-    return (mv, buf), C.addressof(buf), n
+    arr = np.frombuffer(mv, dtype=np.uint8)      # no copy, read-only buffers included: the library only reads the bytes
+    return (mv, arr), arr.ctypes.data, n
 
 
 def _wrap_table(tc, h):
