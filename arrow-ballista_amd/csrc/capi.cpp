@@ -186,9 +186,10 @@ struct JitScope {
       const auto fkey = std::make_tuple((const void*)&cp, kernel_id, std::hash<std::string>()(spec));
       const JitFn* f = nullptr;
       auto hit = op->jit_fns.find(fkey);
-      if (hit != op->jit_fns.end()) f = hit->second;
+      if (hit != op->jit_fns.end()) { f = hit->second; if (!f && c->jit_mode == 2) throw std::runtime_error("the run-time source of kernel " + std::to_string(kernel_id) + " failed to compile earlier"); }
       else {
-        f = use ? jit_get(cp.jit_src + spec, kernel_id) : jit_try_get(cp.jit_src + spec, kernel_id);
+        try { f = use ? jit_get(cp.jit_src + spec, kernel_id) : jit_try_get(cp.jit_src + spec, kernel_id); }
+        catch (...) { op->jit_fns[fkey] = nullptr; throw; }      // a source that does not compile is not compiled again on every call
         if (f) op->jit_fns[fkey] = f;
       }
       if (!f) return;
@@ -1265,35 +1266,47 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
     }
     if (total > 128) throw Unsupported("composite sort key needs " + std::to_string(total) + " bits (max 128)");
     { int sh = 0; for (int k = S.n_keys - 1; k >= 0; --k) { K.shift[k] = sh; sh += width[k]; } }
-    // 2. pack + LSD radix passes
+    // 2. pack + LSD radix passes.  <= 32 key bits: one u64 (key << 32 | row) record per row, no separate id array.
+    const bool packed = total >= 1 && total <= 32 && n > sort_small_max();
     u64* klo = (u64*)op->ws[1].ensure((size_t)n * 8);
     u64* klo2 = (u64*)op->ws[2].ensure((size_t)n * 8);
     u64* khi = total > 64 ? (u64*)op->ws[3].ensure((size_t)n * 8) : nullptr;
-    uint32_t* ids = (uint32_t*)op->ws[4].ensure((size_t)n * 4);
-    uint32_t* ids2 = (uint32_t*)op->ws[5].ensure((size_t)n * 4);
-    int nblocks; i64 tile; radix_geometry(n, &nblocks, &tile);
-    int32_t* hist = (int32_t*)op->ws[6].ensure(radix_hist_entries(nblocks) * 4 + 16);
-    const size_t swb = exclusive_scan_ws_bytes((i64)radix_hist_entries(nblocks));
-    void* sws = op->ws[7].ensure(swb);
+    uint32_t* ids = packed ? nullptr : (uint32_t*)op->ws[4].ensure((size_t)n * 4);
+    uint32_t* ids2 = packed ? nullptr : (uint32_t*)op->ws[5].ensure((size_t)n * 4);
     ProfScope ps(op, s);
-    { JitScope js(op, op->prog, 9, n); launch_sort_pack(s, P, n, S, K, klo, khi, ids); }
-    if (n <= sort_small_max()) {      // one block sorts it in LDS: no histogram / scan / scatter launches
+    // digit counts: 256 u64 per pass, two alternating slots (a pass reads its own, fills the next one's)
+    u64* ghist = (u64*)op->ws[6].ensure((size_t)2 * 256 * 8);
+    const bool small = n <= sort_small_max();
+    { JitScope js(op, op->prog, 9, n); launch_sort_pack(s, P, n, S, K, klo, khi, ids, small || total == 0 ? nullptr : ghist); }
+    if (small) {      // one block sorts it in LDS: no histogram / scan / scatter launches
       launch_sort_small(s, klo, khi, ids, n, perm_out);
       HIPCHECK(hipGetLastError());
       return;
     }
-    auto run_passes = [&](int bits) {
-      for (int sh = 0; sh < bits; sh += 8) {
-        launch_radix_pass(s, klo, ids, n, sh, 0xFFu, klo2, ids2, hist, sws, swb);
-        std::swap(klo, klo2); std::swap(ids, ids2);
+    // single-read passes (kernels_sort.hip): the pack kernel counted the first digit, every pass counts the next one while it has the
+    // tile in registers, the last pass writes the row ids straight into perm_out
+    const size_t lwb = onesweep_ws_bytes(n);
+    void* lws = op->ws[7].ensure(lwb);
+    auto run_passes = [&](int bits, int shift0, bool last_word) {
+      const int np = (bits + 7) / 8;
+      if (np == 0) { if (last_word) HIPCHECK(hipMemcpyAsync(perm_out, ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s)); return; }
+      for (int p = 0; p < np; ++p) {
+        const bool final_pass = last_word && p + 1 == np;
+        u64* mine = ghist + (size_t)(p & 1) * 256; u64* next = p + 1 < np ? ghist + (size_t)((p + 1) & 1) * 256 : nullptr;
+        launch_onesweep_pass(s, klo, ids, n, shift0 + 8 * p, mine, lws, lwb, klo2, final_pass ? perm_out : ids2, final_pass, next);
+        std::swap(klo, klo2); if (!final_pass) std::swap(ids, ids2);
       }
     };
-    run_passes(std::min(total, 64));
-    if (total > 64) {
-      launch_gather_u64(s, khi, ids, n, klo);   // hi words in the current order
-      run_passes(total - 64);
+    if (packed) {
+      run_passes(total, 32, true);
+    } else {
+      run_passes(std::min(total, 64), 0, total <= 64);
+      if (total > 64) {
+        launch_gather_u64(s, khi, ids, n, klo);   // hi words in the current order
+        launch_radix_ghist(s, klo, n, 0, 1, ghist);
+        run_passes(total - 64, 0, true);
+      }
     }
-    HIPCHECK(hipMemcpyAsync(perm_out, ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipGetLastError());
   });
 }

@@ -158,7 +158,7 @@ void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec&
                        u64 out_cap, u64* out_count, uint32_t* visited);
 int sort_minmax_blocks(i64 n);
 void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks);
-void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids);
+void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids, u64* hist0);
 void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, uint32_t nparts, u64* pid_out, uint32_t* ids);
 void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out);
 void launch_gather_u64(hipStream_t s, const u64* src, const uint32_t* idx, i64 n, u64* dst);
@@ -168,6 +168,11 @@ void launch_sort_direct(hipStream_t s, const DevProgram& P, i64 n, const SortSpe
 void launch_sort_small(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, i64 n, uint32_t* out);
 void radix_geometry(i64 n, int* nblocks, i64* tile);
 size_t radix_hist_entries(int nblocks);
+size_t onesweep_ws_bytes(i64 n);
+int onesweep_max_passes();
+void launch_radix_ghist(hipStream_t s, const u64* keys, i64 n, int shift0, int npasses, u64* ghist);
+void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, u64* gexcl, void* ws, size_t ws_bytes,
+                          u64* keys_out, uint32_t* vals_out, bool ids_only, u64* next_hist);
 void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, uint32_t mask, u64* keys_out, uint32_t* vals_out,
                        int32_t* hist, void* scan_ws, size_t scan_ws_bytes);
 void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa, const uint32_t* n_groups_dev = nullptr);

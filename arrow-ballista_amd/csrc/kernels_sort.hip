@@ -98,9 +98,12 @@ extern "C" __global__ void __launch_bounds__(SBLOCK) gpuq_jit_entry(const DevPro
 #endif
 
 // ------------------------------------------------------------------ composite key
+// hist0 (or NULL): 256 u64 counters of the lowest 8 key bits -- the first radix pass's digit -- accumulated on the way
 template <int MAXC>
 __device__ __forceinline__ void k_sort_pack_body(const DevProgram P, const i64 n, const SortSpec S, const SortPack K,
-                                                      u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids) {
+                                                      u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids, u64* __restrict__ hist0) {
+  __shared__ uint32_t h0[256];
+  if (hist0) { h0[threadIdx.x] = 0; __syncthreads(); }
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * SWAVES + swave(); w < nwords; w += (i64)gridDim.x * SWAVES) {
     const i64 pos = (w << 6) + slane();
@@ -127,20 +130,23 @@ __device__ __forceinline__ void k_sort_pack_body(const DevProgram P, const i64 n
         comp |= field << K.shift[k];
       }
     }
+    if (hist0) atomicAdd(&h0[(uint32_t)comp & 0xFFu], 1u);
+    if (!ids) { key_lo[pos] = ((u64)comp << 32) | (u64)(uint32_t)pos; continue; }      // <= 32 key bits: one 8-byte (key, row) record
     key_lo[pos] = (u64)comp;
     if (key_hi) key_hi[pos] = (u64)(comp >> 64);
     ids[pos] = (uint32_t)pos;
   }
+  if (hist0) { __syncthreads(); if (h0[threadIdx.x]) atomicAdd((unsigned long long*)&hist0[threadIdx.x], (unsigned long long)h0[threadIdx.x]); }
 }
 #ifndef GPUQ_JIT
 template <int MAXC>
 #ifndef GPUQ_JIT
 __global__ void __launch_bounds__(SBLOCK) k_sort_pack(const DevProgram P, const i64 n, const SortSpec S, const SortPack K,
-                                                      u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids) { k_sort_pack_body<MAXC>(P, n, S, K, key_lo, key_hi, ids); }
+                                                      u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids, u64* __restrict__ hist0) { k_sort_pack_body<MAXC>(P, n, S, K, key_lo, key_hi, ids, hist0); }
 #endif
 #elif GPUQ_JIT_KERNEL == 9
 extern "C" __global__ void __launch_bounds__(SBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const SortSpec S, const SortPack K,
-                                                      u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids) { k_sort_pack_body<0>(P, n, S, K, key_lo, key_hi, ids); }
+                                                      u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids, u64* __restrict__ hist0) { k_sort_pack_body<0>(P, n, S, K, key_lo, key_hi, ids, hist0); }
 #endif
 
 // ------------------------------------------------------------------ small inputs, end to end in one block
@@ -414,6 +420,163 @@ __global__ void __launch_bounds__(SBLOCK) k_radix_scatter(const u64* __restrict_
 #endif
 
 #ifndef GPUQ_JIT
+// ------------------------------------------------------------------ single-read radix passes (decoupled look-back)
+// The hist + scan + scatter pass above reads every key twice.  For SortExec the digit histograms of ALL passes are taken in one
+// read up front (k_radix_ghist: the global count of a digit does not depend on the order of the keys), and a pass is then ONE
+// kernel that reads a tile once: it ranks the tile in LDS as k_radix_scatter does, publishes the tile's per-digit counts, and
+// learns the counts of the tiles before it by looking back over their published words (aggregate of one tile, or inclusive prefix
+// of all tiles up to it) instead of waiting for a separate scan [UPSTREAM-KNOWLEDGE: Merrill & Garland's decoupled look-back /
+// Adinets & Merrill's Onesweep].  Tiles are handed out by a ticket counter, so every tile a block waits for has already started:
+// the look-back cannot deadlock whatever order the hardware schedules workgroups in.  With <= 32 key bits the record is one u64
+// (key << 32 | row): a pass moves 16 B per row, the last one 12 B (row ids only).
+#ifndef GPUQ_JIT
+constexpr u64 LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_MASK = (1ull << 62) - 1;
+constexpr int GHIST_MAX_PASSES = 8;
+__global__ void __launch_bounds__(SBLOCK) k_radix_ghist(const u64* __restrict__ keys, const i64 n, const int shift0, const int npasses, u64* __restrict__ ghist) {
+  __shared__ uint32_t cnt[GHIST_MAX_PASSES][RADIX];
+  for (int i = threadIdx.x; i < GHIST_MAX_PASSES * RADIX; i += SBLOCK) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+  for (i64 i = (i64)blockIdx.x * SBLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * SBLOCK) {
+    const u64 k = keys[i] >> shift0;
+    for (int p = 0; p < npasses; ++p) atomicAdd(&cnt[p][(uint32_t)(k >> (8 * p)) & 0xFFu], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < npasses * RADIX; i += SBLOCK) { const uint32_t c = (&cnt[0][0])[i]; if (c) atomicAdd((unsigned long long*)&ghist[i], (unsigned long long)c); }
+}
+// counts -> exclusive bases, one block per pass
+__global__ void __launch_bounds__(RADIX) k_radix_ghist_scan(u64* __restrict__ ghist) {
+  __shared__ u64 ws[RADIX / 64];
+  u64* h = ghist + (size_t)blockIdx.x * RADIX;
+  const int t = threadIdx.x, l = t & 63;
+  const u64 c = h[t]; u64 x = c;
+  for (int off = 1; off < 64; off <<= 1) { const u64 y = __shfl_up(x, off); if (l >= off) x += y; }
+  if (l == 63) ws[t >> 6] = x;
+  __syncthreads();
+  u64 pre = 0; for (int q = 0; q < (t >> 6); ++q) pre += ws[q];
+  h[t] = pre + x - c;
+}
+template <bool HASVAL>
+__global__ void __launch_bounds__(SBLOCK) k_onesweep(const u64* __restrict__ keys, const uint32_t* __restrict__ vals, const i64 n, const int shift,
+                                                     const u64* __restrict__ gexcl, u64* __restrict__ look, uint32_t* __restrict__ ticket,
+                                                     u64* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const int ids_only,
+                                                     u64* __restrict__ next_hist /* counts of the NEXT pass's digit, or NULL */) {
+  __shared__ uint32_t nh[RADIX];
+  __shared__ u64 sk[RTILE];
+  __shared__ uint32_t sv[HASVAL ? RTILE : 1];
+  __shared__ uint32_t wcnt[SWAVES][RADIX];
+  __shared__ uint32_t dstart[RADIX];
+  __shared__ u64 gbase[RADIX];
+  __shared__ uint32_t wsum[SWAVES];
+  __shared__ uint32_t s_tile;
+  const int t = threadIdx.x, w = swave(), l = slane();
+  const u64 lt = (1ull << l) - 1;
+  if (t == 0) s_tile = atomicAdd(ticket, 1u);
+  nh[t] = 0;
+  for (int i = t; i < SWAVES * RADIX; i += SBLOCK) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+  const i64 T = (i64)s_tile;
+  const i64 s0 = T * RTILE;
+  if (s0 >= n) return;                                 // (grid == number of tiles: not reached)
+  const i64 b = s0 + RTILE < n ? s0 + RTILE : n;
+  // 1. load the wave's quarter, rank every key inside its (wave, digit) sequence
+  const i64 w0 = s0 + (i64)w * (RTILE / SWAVES);
+  u64 k[RROUNDS]; uint32_t v[HASVAL ? RROUNDS : 1]; uint32_t pos[RROUNDS];
+#pragma unroll
+  for (int r = 0; r < RROUNDS; ++r) {
+    const i64 i = w0 + r * 64 + l;
+    const bool act = i < b;
+    k[r] = act ? keys[i] : 0;
+    if (HASVAL) v[r] = act ? vals[i] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < RROUNDS; ++r) {
+    const i64 i = w0 + r * 64 + l;
+    const bool act = i < b;
+    const uint32_t d = (uint32_t)(k[r] >> shift) & 0xFFu;
+    u64 same = __ballot(act);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const u64 m = __ballot((d >> bit) & 1);
+      same &= ((d >> bit) & 1) ? m : ~m;
+    }
+    const uint32_t before = act ? wcnt[w][d] : 0;
+    pos[r] = before + (uint32_t)__popcll(same & lt);
+    __builtin_amdgcn_wave_barrier();
+    if (act && (same >> l) <= 1ull) wcnt[w][d] = before + (uint32_t)__popcll(same);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // 2. tile-local layout (t == digit); the digit's count is published before anything else happens
+  uint32_t tot = 0;
+  {
+    uint32_t c[SWAVES];
+#pragma unroll
+    for (int q = 0; q < SWAVES; ++q) { c[q] = wcnt[q][t]; tot += c[q]; }
+    __hip_atomic_store(&look[(size_t)T * RADIX + t], (T == 0 ? LB_PREFIX : LB_AGG) | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t x = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (l >= off) x += y; }
+    if (l == 63) wsum[w] = x;
+    __syncthreads();
+    uint32_t pre = 0;
+#pragma unroll
+    for (int q = 0; q < SWAVES; ++q) if (q < w) pre += wsum[q];
+    const uint32_t ds = pre + x - tot;
+    dstart[t] = ds;
+    uint32_t run = ds;
+#pragma unroll
+    for (int q = 0; q < SWAVES; ++q) { wcnt[q][t] = run; run += c[q]; }
+  }
+  __syncthreads();
+  // 3. keys to their sorted place in LDS
+#pragma unroll
+  for (int r = 0; r < RROUNDS; ++r) {
+    const i64 i = w0 + r * 64 + l;
+    if (i < b) { const uint32_t d = (uint32_t)(k[r] >> shift) & 0xFFu; const uint32_t j = wcnt[w][d] + pos[r]; sk[j] = k[r]; if (HASVAL) sv[j] = v[r]; }
+  }
+  // 4. look back over the tiles before this one (t == digit): sum aggregates until a tile that knows its inclusive prefix
+  {
+    u64 excl = 0;
+    if (T > 0) {
+      // LBW predecessors per step: their words are independent loads in flight together (a one-at-a-time walk pays a full
+      // device-scope round trip per tile, and at any moment hundreds of tiles have published only their aggregate)
+      constexpr int LBW = 4;
+      bool done = false;
+      for (i64 j = T - 1; !done; j -= LBW) {
+        u64 x[LBW];
+#pragma unroll
+        for (int q = 0; q < LBW; ++q) x[q] = j - q >= 0 ? __hip_atomic_load(&look[(size_t)(j - q) * RADIX + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;
+#pragma unroll
+        for (int q = 0; q < LBW; ++q) {
+          if (done) break;
+          while ((x[q] >> 62) == 0) { __builtin_amdgcn_s_sleep(1); x[q] = __hip_atomic_load(&look[(size_t)(j - q) * RADIX + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          excl += x[q] & LB_MASK;
+          done = (x[q] >> 62) == 2;
+        }
+      }
+      __hip_atomic_store(&look[(size_t)T * RADIX + t], LB_PREFIX | (excl + (u64)tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gbase[t] = gexcl[t] + excl;
+  }
+  __syncthreads();
+  // 5. out, position by position: neighbouring lanes hold neighbouring keys of the same digit
+  const int cnt = (int)(b - s0);
+#pragma unroll 4
+  for (int j = t; j < cnt; j += SBLOCK) {
+    const u64 kk = sk[j];
+    const uint32_t d = (uint32_t)(kk >> shift) & 0xFFu;
+    const u64 dst = gbase[d] + (u64)((uint32_t)j - dstart[d]);
+    if (ids_only) vals_out[dst] = HASVAL ? sv[j] : (uint32_t)kk;
+    else { keys_out[dst] = kk; if (HASVAL) vals_out[dst] = sv[j]; }
+    if (next_hist) atomicAdd(&nh[(uint32_t)(kk >> (shift + 8)) & 0xFFu], 1u);      // the tile is in registers anyway: the next pass's counts ride along
+  }
+  if (next_hist) {
+    __syncthreads();
+    if (nh[t]) atomicAdd((unsigned long long*)&next_hist[t], (unsigned long long)nh[t]);
+  }
+}
+#endif
+
 // ------------------------------------------------------------------ launchers
 static int sgrid(i64 n, int blocks_per_cu) {
   const i64 nwords = (n + 63) >> 6;
@@ -431,12 +594,13 @@ void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpe
 #undef CALL
   }
 }
-void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids) {
+void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids, u64* hist0) {
   if (n <= 0) return;
+  if (hist0) (void)hipMemsetAsync(hist0, 0, RADIX * 8, s);
   if (jit_override().fn && jit_override().kernel_id == 9) {
-    (void)jit_launch(jit_override().fn, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, S, K, key_lo, key_hi, ids);
+    (void)jit_launch(jit_override().fn, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, S, K, key_lo, key_hi, ids, hist0);
   } else {
-#define CALL(M) hipLaunchKernelGGL(k_sort_pack<M>, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, S, K, key_lo, key_hi, ids)
+#define CALL(M) hipLaunchKernelGGL(k_sort_pack<M>, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, S, K, key_lo, key_hi, ids, hist0)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
   }
@@ -521,6 +685,28 @@ void launch_sort_direct(hipStream_t s, const DevProgram& P, i64 n, const SortSpe
 }
 void launch_sort_small(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, i64 n, uint32_t* out) {
   if (n > 0) hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, s, klo, khi, ids, (int)n, out);
+}
+
+size_t onesweep_ws_bytes(i64 n) { const i64 tiles = (n + RTILE - 1) / RTILE; return (size_t)tiles * RADIX * 8 + 256; }      // look-back words + ticket
+int onesweep_max_passes() { return GHIST_MAX_PASSES; }
+// ghist: npasses * 256 u64 digit counts (launch_onesweep_pass turns a pass's counts into bases)
+void launch_radix_ghist(hipStream_t s, const u64* keys, i64 n, int shift0, int npasses, u64* ghist) {
+  if (n <= 0 || npasses <= 0) return;
+  (void)hipMemsetAsync(ghist, 0, (size_t)npasses * RADIX * 8, s);
+  i64 need = (n + SBLOCK * 16 - 1) / (SBLOCK * 16); const i64 cap = (i64)num_cus() * 8;
+  hipLaunchKernelGGL(k_radix_ghist, dim3((unsigned)std::max<i64>(1, std::min(need, cap))), dim3(SBLOCK), 0, s, keys, n, shift0, npasses, ghist);
+}
+// one stable 8-bit pass; vals == NULL: packed (key << 32 | row) records; ids_only: only vals_out is written (the last pass)
+void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, u64* gexcl, void* ws, size_t ws_bytes,
+                          u64* keys_out, uint32_t* vals_out, bool ids_only, u64* next_hist) {
+  if (n <= 0) return;
+  const i64 tiles = (n + RTILE - 1) / RTILE;
+  (void)hipMemsetAsync(ws, 0, ws_bytes, s);
+  u64* look = (u64*)ws; uint32_t* ticket = (uint32_t*)((char*)ws + (size_t)tiles * RADIX * 8);
+  hipLaunchKernelGGL(k_radix_ghist_scan, dim3(1), dim3(RADIX), 0, s, gexcl);      // this pass's counts (from the pack kernel / the pass before) -> bases
+  if (next_hist) (void)hipMemsetAsync(next_hist, 0, RADIX * 8, s);
+  if (vals) hipLaunchKernelGGL(k_onesweep<true>, dim3((unsigned)tiles), dim3(SBLOCK), 0, s, keys, vals, n, shift, (const u64*)gexcl, look, ticket, keys_out, vals_out, ids_only ? 1 : 0, next_hist);
+  else hipLaunchKernelGGL(k_onesweep<false>, dim3((unsigned)tiles), dim3(SBLOCK), 0, s, keys, vals, n, shift, (const u64*)gexcl, look, ticket, keys_out, vals_out, ids_only ? 1 : 0, next_hist);
 }
 
 #endif  // GPUQ_JIT

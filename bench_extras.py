@@ -483,6 +483,31 @@ def run(tc, T, g, full=True):
     return extra
 
 
+def sort_micro(tc, T, g, log2n=27, reps=5):
+    """SortExec alone: 2^log2n generated lineitem rows, (a) by l_extendedprice (Decimal128(15,2): ~24 key bits after range
+    compression -> packed 8-byte records, 3 single-read passes), (b) by (l_orderkey DESC, l_shipdate) (two-field key, one u64 word).
+    Time = one execute() (min/max pass + read-back, pack, histograms, passes), best of `reps`, inputs resident in HBM."""
+    from arrow_ballista_amd.expr import col
+    n = 1 << log2n
+    li = T.gen_lineitem_device(tc, n, columns=("l_orderkey", "l_extendedprice", "l_shipdate"))
+    src = g.MemoryExec([li])
+    s = src.schema()
+    out = {"rows": n}
+    for name, spec in (("by_extendedprice", [("l_extendedprice", True)]), ("by_orderkey_desc_shipdate", [("l_orderkey", False), ("l_shipdate", True)])):
+        plan = g.SortExec([{"expr": col(c, s), "asc": a, "nulls_first": False} for c, a in spec], src)
+        for _ in range(2):
+            plan.execute(0, tc)
+        tc.ctx.jit_wait()
+        best = None
+        for _ in range(reps):
+            _sync(tc); t0 = time.perf_counter(); v = plan.execute(0, tc); _sync(tc)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        out[name] = {"ms": best * 1e3, "rows_per_s": n / best}
+        del v
+    return out
+
+
 def scan_decode(tc, T, g, sf=1):
     """the CsvExec / ParquetExec leaves.  lineitem's 9 generated columns at `sf` as (a) '|' text as dbgen
     writes it, (b) Parquet as the reference's `convert --compression none` writes it (dictionary pages where they pay), both in
@@ -568,6 +593,11 @@ if __name__ == "__main__":
     if "--ingest" in sys.argv:
         sf = 10 if "--sf10" in sys.argv else 1
         print(json.dumps(ingest_q1(tc, T, g, sf), indent=1))
+        sys.exit(0)
+    if "--sort" in sys.argv:
+        i = sys.argv.index("--sort")
+        bits = int(sys.argv[i + 1]) if len(sys.argv) > i + 1 and sys.argv[i + 1].isdigit() else 27
+        print(json.dumps(sort_micro(tc, T, g, bits), indent=1))
         sys.exit(0)
     if "--scan" in sys.argv:
         sf = 10 if "--sf10" in sys.argv else 1

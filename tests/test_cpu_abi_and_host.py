@@ -382,3 +382,16 @@ def test_parquet_footer_is_read_on_the_host():
     assert scan.parquet_schema(L, buf.getvalue()) == ([("d", "Date32", False), ("x", {"Decimal128": [15, 2]}, True), ("s", "Utf8", False)], 2)
     with pytest.raises(g.GpuqError):
         scan.parquet_schema(L, b"PAR1garbagePAR1")
+
+
+def test_every_runtime_kernel_source_compiles_for_gfx950():
+    """The sources the JIT front-end hands to hiprtc (one per kernel id) are cross-compiled with hipcc here: a source that stops
+    compiling would make operators fall back to their AOT kernels on the GPU box -- correct, silently slower, and invisible to
+    the parity tests."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "jit_compile_check.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ok = [l for l in r.stdout.splitlines() if " OK: " in l]
+    assert len(ok) == 16, r.stdout

@@ -1,0 +1,49 @@
+"""SortExec on the single-read radix passes (kernels_sort.hip, decoupled look-back): the permutation must be THE stable order --
+equal keys keep their input order -- at sizes around the 4096-key tiles, for packed (<= 32 key bits), one-word and two-word
+composite keys, with the duplicates that make instability visible.  Checker: numpy's stable argsort / lexsort on the same arrays."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import arrow_ballista_amd as g
+from arrow_ballista_amd.expr import col
+
+pytestmark = pytest.mark.gpu
+
+
+def sorted_row_ids(tc, t, spec_cols):
+    src = g.MemoryExec([t])
+    s = src.schema()
+    spec = [{"expr": col(c, s), "asc": asc, "nulls_first": False} for c, asc in spec_cols]
+    out = g.plan.materialize(tc, g.SortExec(spec, g.ProjectionExec([(col("rid", s), "rid")] + [(col(c, s), c) for c, _ in spec_cols], src)).execute(0, tc))
+    return np.asarray(out.to_arrow(tc.ctx).column("rid"))
+
+
+@pytest.mark.parametrize("n", [2049, 4096, 4097, 8191, 100_003, (1 << 20) + 5])
+def test_stable_order_for_every_key_width(tc, n):
+    r = np.random.default_rng(n)
+    rid = np.arange(n, dtype=np.int64)
+    k20 = r.integers(0, 1 << 20, n).astype(np.int32)                       # 3 packed passes, the last one 4 bits wide
+    few = r.integers(-3, 4, n).astype(np.int64)                            # 3 bits: one pass, ~n/7 duplicates per value
+    k40 = (r.integers(0, 1 << 40, n) - (1 << 39)).astype(np.int64)         # one u64 word, 5 passes
+    wide_a = r.integers(-2**62, 2**62, n).astype(np.int64) >> r.integers(0, 60, n)      # all magnitudes
+    wide_b = r.integers(-2**62, 2**62, n).astype(np.int64)
+    dup_a = wide_a[r.integers(0, max(1, n // 50), n)]                      # two-word key whose first field repeats
+    t = pa.table({"rid": rid, "k20": k20, "few": few, "k40": k40, "dup_a": dup_a, "wide_b": wide_b})
+    t = t.cast(pa.schema([pa.field(f.name, f.type, nullable=False) for f in t.schema]))
+    assert np.array_equal(sorted_row_ids(tc, t, [("k20", True)]), np.argsort(k20, kind="stable"))
+    assert np.array_equal(sorted_row_ids(tc, t, [("few", True)]), np.argsort(few, kind="stable"))
+    assert np.array_equal(sorted_row_ids(tc, t, [("few", False)]), np.argsort(-few, kind="stable"))
+    assert np.array_equal(sorted_row_ids(tc, t, [("k40", True)]), np.argsort(k40, kind="stable"))
+    assert np.array_equal(sorted_row_ids(tc, t, [("few", True), ("k20", False)]), np.lexsort((-k20.astype(np.int64), few)))
+    assert np.array_equal(sorted_row_ids(tc, t, [("dup_a", True), ("wide_b", False)]), np.lexsort((-wide_b, dup_a)))      # |wide_b| < 2^62: no overflow
+
+
+def test_all_keys_equal_and_sorted_inputs(tc):
+    n = 50_000
+    t = pa.table({"rid": np.arange(n, dtype=np.int64), "c": np.full(n, 7, np.int64), "up": np.arange(n, dtype=np.int64), "down": np.arange(n, dtype=np.int64)[::-1].copy()})
+    t = t.cast(pa.schema([pa.field(f.name, f.type, nullable=False) for f in t.schema]))
+    assert np.array_equal(sorted_row_ids(tc, t, [("c", True)]), np.arange(n))
+    assert np.array_equal(sorted_row_ids(tc, t, [("up", True)]), np.arange(n))
+    assert np.array_equal(sorted_row_ids(tc, t, [("down", True)]), np.arange(n)[::-1])
+    assert np.array_equal(sorted_row_ids(tc, t, [("up", False)]), np.arange(n)[::-1])

@@ -1,5 +1,7 @@
-"""Compile (hipcc, gfx950, no GPU needed) the run-time sources the JIT path would hand to hiprtc for the join kernels:
-build (5), key range (14), chained probe (6), unique probe (7, generic and the one-narrow-key specialisation)."""
+"""Compile (hipcc, gfx950, no GPU needed) the run-time sources the JIT path would hand to hiprtc, one per kernel id:
+filter (1), project (2), tiny aggregate (3), hash aggregate (4, 11-13), join build (5), key range (14), radix-join pack (15),
+chained probe (6), unique probe (7, generic and the one-narrow-key specialisation), sort min/max (8), sort pack (9),
+partition ids (10).  A source that does not compile makes the operator fall back to its AOT kernel -- silently slower."""
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +12,14 @@ fields = [{"name": "k", "type": "Int64", "nullable": False}, {"name": "d", "type
 pred = binary(col("d", fields), Op.Gt, lit(9204, "Date32"))
 build = {"op": "join_build", "input": {"fields": fields}, "on": [col("k", fields)], "predicate": pred}
 probe = {"op": "join_probe", "input": {"fields": fields}, "on": [col("k", fields)], "predicate": pred, "join_type": "Inner"}
-jobs = [(build, 5, ""), (build, 14, ""), (probe, 15, ""), (probe, 6, ""), (probe, 7, ""), (probe, 7, "#define GPUQ_JIT_PROBE1 1\nconstexpr int JIT_KEY_REG0 = %d;\n")]
+
+proj = {"op": "project", "input": {"fields": fields}, "exprs": [{"expr": binary(col("k", fields), Op.Plus, lit(1, "Int64")), "name": "k1"}]}
+filt = {"op": "filter", "input": {"fields": fields}, "predicate": pred}
+aggr = {"op": "aggregate", "input": {"fields": fields}, "mode": "Single", "group_expr": [{"expr": col("d", fields), "name": "d"}],
+        "aggr_expr": [{"fn": "SUM", "expr": col("k", fields), "name": "s"}, {"fn": "COUNT", "expr": col("k", fields), "name": "c"}]}
+sort = {"op": "sort", "input": {"fields": fields}, "expr": [{"expr": col("k", fields), "asc": False, "nulls_first": False}, {"expr": col("d", fields), "asc": True, "nulls_first": False}]}
+part = {"op": "partition", "input": {"fields": fields}, "hash_expr": [col("k", fields)], "partition_count": 16}
+jobs = [(filt, 1, ""), (proj, 2, ""), (aggr, 3, ""), (aggr, 4, ""), (aggr, 11, ""), (aggr, 12, ""), (aggr, 13, ""), (sort, 8, ""), (sort, 9, ""), (part, 10, ""), (build, 5, ""), (build, 14, ""), (probe, 15, ""), (probe, 6, ""), (probe, 7, ""), (probe, 7, "#define GPUQ_JIT_PROBE1 1\nconstexpr int JIT_KEY_REG0 = %d;\n")]
 with tempfile.TemporaryDirectory() as d:
     for desc, kid, spec in jobs:
         src = g.compile_jit_source(desc, kid)
