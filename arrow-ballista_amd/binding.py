@@ -126,6 +126,7 @@ def lib():
         "gpuq_join_build_side_rows": (i32, [vp, vp, i32, vp, vp]),
         "gpuq_mark_rows": (i32, [vp, vp, vp, i64, vp]),
         "gpuq_sort_run": (i32, [vp, vp, C.POINTER(gpuq_input), vp]),
+        "gpuq_merge_run": (i32, [vp, vp, C.POINTER(gpuq_input), C.POINTER(i64), i32, vp]),
         "gpuq_partition_run": (i32, [vp, vp, C.POINTER(gpuq_input), vp, vp]),
         "gpuq_op_check": (i32, [vp, vp]),
         "gpuq_unpack_utf8": (i32, [vp, vp, vp, i64, vp, vp, i64, C.POINTER(i64)]),

@@ -1219,24 +1219,9 @@ int gpuq_join_build_side_rows(gpuq_join_table* t, void* stream, int matched, uin
 // ---------------------------------------------------------------- sort
 static int bitlen128(u128 v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
-int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out) {
-  if (!op) return GPUQ_ERR_INVALID;
-  return guarded(op->ctx, [&]() {
-    check_ctx(op->ctx);
-    if (op->kind != K_SORT) throw std::runtime_error("not a sort operator");
-    hipStream_t s = use_stream(stream);
-    DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
-    const i64 n = in->n_rows;
-    if (n == 0) return;
-    if (n >= (1ll << 31)) throw Unsupported("sort of >= 2^31 rows in one call");
-    if (!perm_out) throw std::runtime_error("perm_out is NULL");
+// Per-key min/max in the ordered view (one pass + read-back) -> the bit layout of the composite key (SortExec and the ordered merge)
+static SortPack sort_key_plan(gpuq_op* op, hipStream_t s, const DevProgram& P, i64 n, int* total_out) {
     const SortSpec& S = op->sort;
-    if (n <= sort_direct_max()) {      // one block, no min/max read-back
-      launch_sort_direct(s, P, n, S, perm_out);
-      HIPCHECK(hipGetLastError());
-      return;
-    }
-    // 1. per-key min/max in the ordered view
     const int mb = sort_minmax_blocks(n);
     u64* mm = (u64*)op->ws[0].ensure((size_t)mb * MAX_SORT_KEYS * 5 * 8);
     { JitScope js(op, op->prog, 8, n); launch_sort_minmax(s, P, n, S, mm, mb); }
@@ -1266,6 +1251,29 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
     }
     if (total > 128) throw Unsupported("composite sort key needs " + std::to_string(total) + " bits (max 128)");
     { int sh = 0; for (int k = S.n_keys - 1; k >= 0; --k) { K.shift[k] = sh; sh += width[k]; } }
+    *total_out = total;
+    return K;
+}
+
+int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() {
+    check_ctx(op->ctx);
+    if (op->kind != K_SORT) throw std::runtime_error("not a sort operator");
+    hipStream_t s = use_stream(stream);
+    DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
+    const i64 n = in->n_rows;
+    if (n == 0) return;
+    if (n >= (1ll << 31)) throw Unsupported("sort of >= 2^31 rows in one call");
+    if (!perm_out) throw std::runtime_error("perm_out is NULL");
+    const SortSpec& S = op->sort;
+    if (n <= sort_direct_max()) {      // one block, no min/max read-back
+      launch_sort_direct(s, P, n, S, perm_out);
+      HIPCHECK(hipGetLastError());
+      return;
+    }
+    int total = 0;
+    const SortPack K = sort_key_plan(op, s, P, n, &total);
     // 2. pack + LSD radix passes.  <= 32 key bits: one u64 (key << 32 | row) record per row, no separate id array.
     const bool packed = total >= 1 && total <= 32 && n > sort_small_max();
     u64* klo = (u64*)op->ws[1].ensure((size_t)n * 8);
@@ -1307,6 +1315,54 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
         run_passes(total - 64, 0, true);
       }
     }
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+// ---------------------------------------------------------------- ordered fan-in
+int gpuq_merge_run(gpuq_op* op, void* stream, const gpuq_input* in, const int64_t* run_offsets, int n_runs, uint32_t* perm_out) {
+  if (!op) return GPUQ_ERR_INVALID;
+  return guarded(op->ctx, [&]() {
+    check_ctx(op->ctx);
+    if (op->kind != K_SORT) throw std::runtime_error("not a sort operator");
+    if (!run_offsets || n_runs < 1) throw std::runtime_error("run_offsets is NULL / no runs");
+    hipStream_t s = use_stream(stream);
+    const i64 n = in->n_rows;
+    if (run_offsets[0] != 0 || run_offsets[n_runs] != n) throw std::runtime_error("run_offsets must start at 0 and end at the row count");
+    for (int r = 0; r < n_runs; ++r) if (run_offsets[r] > run_offsets[r + 1]) throw std::runtime_error("run_offsets must not decrease");
+    if (n == 0) return;
+    if (n >= (1ll << 31)) throw Unsupported("merge of >= 2^31 rows in one call");
+    if (!perm_out) throw std::runtime_error("perm_out is NULL");
+    DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
+    int total = 0;
+    const SortPack K = sort_key_plan(op, s, P, n, &total);
+    u64* klo = (u64*)op->ws[1].ensure((size_t)n * 8);
+    u64* klo2 = (u64*)op->ws[2].ensure((size_t)n * 8);
+    u64* khi = total > 64 ? (u64*)op->ws[3].ensure((size_t)n * 8) : nullptr;
+    u64* khi2 = total > 64 ? (u64*)op->ws[8].ensure((size_t)n * 8) : nullptr;
+    uint32_t* ids = (uint32_t*)op->ws[4].ensure((size_t)n * 4);
+    uint32_t* ids2 = (uint32_t*)op->ws[5].ensure((size_t)n * 4);
+    ProfScope ps(op, s);
+    { JitScope js(op, op->prog, 9, n); launch_sort_pack(s, P, n, op->sort, K, klo, khi, ids, nullptr); }
+    // runs -> pairs, round by round (empty runs drop out; an odd run is carried as a pair with an empty right side)
+    std::vector<i64> bounds; bounds.push_back(0);
+    for (int r = 0; r < n_runs; ++r) if (run_offsets[r + 1] > run_offsets[r]) bounds.push_back(run_offsets[r + 1]);
+    i64* dpairs = (i64*)op->ws[9].ensure((size_t)(bounds.size() + 2) * 3 * 8);
+    while (bounds.size() > 2) {
+      std::vector<i64> pairs, next; next.push_back(0); i64 max_len = 0;
+      for (size_t r = 0; r + 1 < bounds.size(); r += 2) {
+        const i64 a0 = bounds[r], a1 = bounds[r + 1], a2 = r + 2 < bounds.size() ? bounds[r + 2] : a1;
+        pairs.push_back(a0); pairs.push_back(a1); pairs.push_back(a2);
+        max_len = std::max(max_len, a2 - a0); next.push_back(a2);
+      }
+      HIPCHECK(hipStreamSynchronize(s));      // the previous round has read its descriptors
+      HIPCHECK(hipMemcpyAsync(dpairs, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipStreamSynchronize(s));      // (pageable source)
+      launch_merge_pairs(s, klo, khi, ids, dpairs, (int)(pairs.size() / 3), max_len, klo2, khi2, ids2);
+      std::swap(klo, klo2); std::swap(khi, khi2); std::swap(ids, ids2);
+      bounds.swap(next);
+    }
+    HIPCHECK(hipMemcpyAsync(perm_out, ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipGetLastError());
   });
 }

@@ -170,6 +170,8 @@ void radix_geometry(i64 n, int* nblocks, i64* tile);
 size_t radix_hist_entries(int nblocks);
 size_t onesweep_ws_bytes(i64 n);
 int onesweep_max_passes();
+void launch_merge_pairs(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, const i64* pairs, int n_pairs, i64 max_len,
+                        u64* klo_out, u64* khi_out, uint32_t* ids_out);
 void launch_radix_ghist(hipStream_t s, const u64* keys, i64 n, int shift0, int npasses, u64* ghist);
 void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, u64* gexcl, void* ws, size_t ws_bytes,
                           u64* keys_out, uint32_t* vals_out, bool ids_only, u64* next_hist);

@@ -577,6 +577,90 @@ __global__ void __launch_bounds__(SBLOCK) k_onesweep(const u64* __restrict__ key
 }
 #endif
 
+// ------------------------------------------------------------------ ordered fan-in: merge of sorted runs
+// CoalesceTasksExec with an order / SortPreservingMergeExec (coalesce_tasks.rs:162-170 `streaming_merge`): the inputs are k
+// runs, each already in the requested order.  The composite keys of the concatenation are packed exactly as for a sort; the runs
+// are then merged pairwise, log2(k) rounds, each round one launch that reads and writes every (key, row) record once.  A block
+// produces MTILE consecutive outputs of one pair: two binary searches along the merge path [UPSTREAM-KNOWLEDGE: Green, McColl &
+// Bader, "GPU Merge Path"] bound the slices of both runs that feed them, the slices are staged in LDS with coalesced loads, every
+// thread finds its own start inside the tile the same way and merges MVT outputs sequentially.  Ties take the element of the
+// LEFT run first: across rounds equal keys keep (run, row) order -- what a loser tree that prefers the lower-numbered stream yields.
+#ifndef GPUQ_JIT
+constexpr int MVT = 8;
+constexpr int MTILE = SBLOCK * MVT;      // 2048 records per block
+struct MKey { u64 hi, lo; };
+__device__ __forceinline__ bool mk_le(const MKey a, const MKey b) { return a.hi < b.hi || (a.hi == b.hi && a.lo <= b.lo); }      // a may precede an equal b
+// number of A elements among the first d outputs of merge(A[0..na), B[0..nb)); key(i) of A / B through the accessors
+template <class FA, class FB>
+__device__ __forceinline__ int merge_path(const int d, const int na, const int nb, FA keyA, FB keyB) {
+  int lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (mk_le(keyA(mid), keyB(d - 1 - mid))) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// pairs[p] = {a0, a1, a2}: runs [a0, a1) and [a1, a2) of the input become one run at the same place of the output (a1 == a2: copy)
+template <bool WIDE>
+__global__ void __launch_bounds__(SBLOCK) k_merge_pairs(const u64* __restrict__ klo, const u64* __restrict__ khi, const uint32_t* __restrict__ ids, const i64* __restrict__ pairs,
+                                                        u64* __restrict__ klo_out, u64* __restrict__ khi_out, uint32_t* __restrict__ ids_out) {
+  __shared__ u64 slo[MTILE]; __shared__ u64 shi[WIDE ? MTILE : 1]; __shared__ uint32_t sid[MTILE];
+  __shared__ i64 s_split[2];
+  const i64 a0 = pairs[3 * blockIdx.y], a1 = pairs[3 * blockIdx.y + 1], a2 = pairs[3 * blockIdx.y + 2];
+  const i64 na = a1 - a0, nb = a2 - a1;
+  const i64 d0 = (i64)blockIdx.x * MTILE;
+  if (d0 >= na + nb) return;
+  const i64 d1 = d0 + MTILE < na + nb ? d0 + MTILE : na + nb;
+  auto gA = [&](i64 i) -> MKey { return MKey{WIDE ? khi[a0 + i] : 0, klo[a0 + i]}; };
+  auto gB = [&](i64 i) -> MKey { return MKey{WIDE ? khi[a1 + i] : 0, klo[a1 + i]}; };
+  // 1. the tile's slices of both runs (global binary searches along the merge path: two threads)
+  if (threadIdx.x < 2) {
+    const i64 d = threadIdx.x == 0 ? d0 : d1;
+    i64 lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+    while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (mk_le(gA(mid), gB(d - 1 - mid))) lo = mid + 1; else hi = mid; }
+    s_split[threadIdx.x] = lo;
+  }
+  __syncthreads();
+  const i64 i0 = s_split[0], i1 = s_split[1];
+  const i64 j0 = d0 - i0, j1 = d1 - i1;
+  const int ca = (int)(i1 - i0), cb = (int)(j1 - j0);      // ca + cb == d1 - d0 <= MTILE
+  // 2. stage: A's slice at [0, ca), B's at [ca, ca + cb)
+  for (int q = threadIdx.x; q < ca + cb; q += SBLOCK) {
+    const i64 src = q < ca ? a0 + i0 + q : a1 + j0 + (q - ca);
+    slo[q] = klo[src]; if (WIDE) shi[q] = khi[src]; sid[q] = ids[src];
+  }
+  __syncthreads();
+  // 3. every thread merges MVT outputs from LDS
+  auto lA = [&](int i) -> MKey { return MKey{WIDE ? shi[i] : 0, slo[i]}; };
+  auto lB = [&](int i) -> MKey { return MKey{WIDE ? shi[ca + i] : 0, slo[ca + i]}; };
+  const int t0 = threadIdx.x * MVT;
+  const int total = ca + cb;
+  u64 olo[MVT], ohi[MVT]; uint32_t oid[MVT];
+  if (t0 < total) {
+    int i = merge_path(t0, ca, cb, lA, lB), j = t0 - i;
+#pragma unroll
+    for (int q = 0; q < MVT; ++q) {
+      if (t0 + q >= total) break;
+      const bool takeA = j >= cb || (i < ca && mk_le(lA(i), lB(j)));
+      const int src = takeA ? i : ca + j;
+      olo[q] = slo[src]; ohi[q] = WIDE ? shi[src] : 0; oid[q] = sid[src];
+      if (takeA) ++i; else ++j;
+    }
+  }
+  __syncthreads();
+  // 4. through LDS again so that the global stores are coalesced
+  if (t0 < total) {
+#pragma unroll
+    for (int q = 0; q < MVT; ++q) if (t0 + q < total) { slo[t0 + q] = olo[q]; if (WIDE) shi[t0 + q] = ohi[q]; sid[t0 + q] = oid[q]; }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < total; q += SBLOCK) {
+    const i64 dst = a0 + d0 + q;
+    klo_out[dst] = slo[q]; if (WIDE) khi_out[dst] = shi[q]; ids_out[dst] = sid[q];
+  }
+}
+#endif
+
 // ------------------------------------------------------------------ launchers
 static int sgrid(i64 n, int blocks_per_cu) {
   const i64 nwords = (n + 63) >> 6;
@@ -707,6 +791,15 @@ void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, 
   if (next_hist) (void)hipMemsetAsync(next_hist, 0, RADIX * 8, s);
   if (vals) hipLaunchKernelGGL(k_onesweep<true>, dim3((unsigned)tiles), dim3(SBLOCK), 0, s, keys, vals, n, shift, (const u64*)gexcl, look, ticket, keys_out, vals_out, ids_only ? 1 : 0, next_hist);
   else hipLaunchKernelGGL(k_onesweep<false>, dim3((unsigned)tiles), dim3(SBLOCK), 0, s, keys, vals, n, shift, (const u64*)gexcl, look, ticket, keys_out, vals_out, ids_only ? 1 : 0, next_hist);
+}
+
+// one round: n_pairs triples in `pairs` (device), the longest pair has max_len records
+void launch_merge_pairs(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, const i64* pairs, int n_pairs, i64 max_len,
+                        u64* klo_out, u64* khi_out, uint32_t* ids_out) {
+  if (n_pairs <= 0 || max_len <= 0) return;
+  const unsigned gx = (unsigned)((max_len + MTILE - 1) / MTILE);
+  if (khi) hipLaunchKernelGGL(k_merge_pairs<true>, dim3(gx, (unsigned)n_pairs), dim3(SBLOCK), 0, s, klo, khi, ids, pairs, klo_out, khi_out, ids_out);
+  else hipLaunchKernelGGL(k_merge_pairs<false>, dim3(gx, (unsigned)n_pairs), dim3(SBLOCK), 0, s, klo, khi, ids, pairs, klo_out, khi_out, ids_out);
 }
 
 #endif  // GPUQ_JIT

@@ -427,6 +427,25 @@ PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetc
 
 PTable concat_tables(Exec& x, std::vector<PTable> parts);
 
+// ordered fan-in (gpuq_merge_run): `t` is the concatenation of runs that are each in `sort_exprs` order
+PTable merge_table(Exec& x, const PTable& t, const std::vector<int64_t>& run_offsets, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
+  if (run_offsets.size() <= 2) return sort_table(x, t, sort_exprs, fetch, site, tag);      // one partition (e.g. gathered by BroadcastExec: several runs inside): sort
+  gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
+    const auto nm = names_of(t);
+    Json ex = jarr();
+    for (auto& s : sort_exprs.a) {
+      const bool asc = s.get_bool("asc", true);
+      ex.a.push_back(jobj({{"expr", rebind(s.at("expr"), nm)}, {"asc", jbool(asc)}, {"nulls_first", jbool(s.get_bool("nulls_first", !asc))}}));
+    }
+    return jobj({{"op", jstr("sort")}, {"input", jobj({{"fields", table_fields(t)}})}, {"expr", ex}});
+  });
+  BufP perm = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 4 + 16);
+  InputC ic; make_input(t, ic);
+  check(x, gpuq_merge_run(op, x.stream, &ic.in, run_offsets.data(), (int)run_offsets.size() - 1, (uint32_t*)perm->p));
+  const int64_t k = (fetch < 0 || fetch > t.n) ? t.n : fetch;
+  return select_view(x, t, (const uint32_t*)perm->p, k, perm);
+}
+
 // ---------------------------------------------------------------- plan nodes
 struct Metrics { int64_t output_rows = 0, elapsed_ns = 0; };
 struct PNode {
@@ -637,10 +656,14 @@ struct SortExec : PNode {
   int partitions() override { return merge_all ? 1 : input->partitions(); }
   PTable execute(int part, Exec& x) override {
     PTable t;
-    if (merge_all && input->partitions() != 1) {
-      std::vector<PTable> in; for (int p = 0; p < input->partitions(); ++p) in.push_back(input->execute(p, x));
+    if (merge_all && input->partitions() != 1) {      // SortPreservingMergeExec: the partitions are sorted runs
+      std::vector<PTable> in; std::vector<int64_t> offs{0};
+      for (int p = 0; p < input->partitions(); ++p) { in.push_back(input->execute(p, x)); offs.push_back(offs.back() + in.back().n); }
+      auto t0 = std::chrono::steady_clock::now();
       t = concat_tables(x, std::move(in));
-    } else t = input->execute(part, x);
+      return timed(t0, merge_table(x, t, offs, expr, fetch, this, 1));
+    }
+    t = input->execute(part, x);
     auto t0 = std::chrono::steady_clock::now();
     return timed(t0, sort_table(x, t, expr, fetch, this, 0));
   }
@@ -926,10 +949,12 @@ struct CoalesceExec : PNode {    // CoalesceTasksExec / CoalescePartitionsExec: 
     // with an order the reference merges ALL input partitions (coalesce_tasks.rs:151), not only the listed ones
     if (all || ordered) for (int p = 0; p < input->partitions(); ++p) in.push_back(input->execute(p, x));
     else for (int p : parts) in.push_back(input->execute(p, x));
+    std::vector<int64_t> offs{0};
+    for (auto& t : in) offs.push_back(offs.back() + t.n);
     auto t0 = std::chrono::steady_clock::now();
     PTable out = concat_tables(x, std::move(in));
-    // k-way merge = concatenation in partition order + the stable sort (ties keep (partition, row) order)
-    if (ordered) out = sort_table(x, out, order_by, -1, this, 0);
+    // k-way merge (coalesce_tasks.rs:162-170): pairwise merge-path rounds, ties keep (partition, row) order
+    if (ordered) out = merge_table(x, out, offs, order_by, -1, this, 0);
     return timed(t0, out);
   }
 };

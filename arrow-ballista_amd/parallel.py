@@ -350,7 +350,9 @@ def exchange_partitions(parts, group=None, tc=None):
         nullable = any(c.nullable for c in pcs)
         validity = exchange_bitmap([c.validity for c in pcs]) if nullable else None
         cols.append(DeviceColumn(c0.name, c0.type, data, total, validity=validity, nullable=nullable, repr=c0.repr))
-    return DeviceTable(cols, total)
+    out = DeviceTable(cols, total)
+    out.recv_counts = rc          # rows received from every rank, in rank order (the runs of an ordered fan-in)
+    return out
 
 
 def repartition_exchange(tc, table, hash_expr, group=None, comm=None):
@@ -454,4 +456,6 @@ def distributed_sort(tc, table, sort_expr, samples_per_rank=1024, group=None):
     # 3. ranges -> owners, merge the received runs
     parts = [PL.materialize(tc, PL.slice_table(tc, rows_only, bounds[r], bounds[r + 1] - bounds[r]), force=True) for r in range(ws)]
     mine = exchange_partitions(parts, group=group, tc=tc)
-    return PL.sort_table(tc, mine, [dict(s, expr=E.rebind(s["expr"], schema)) for s in sort_expr])
+    # every received piece is a sorted run (a slice of its sender's sorted rows): ordered fan-in, not a second sort
+    rc = [int(k) for k in getattr(mine, "recv_counts", [mine.num_rows])]
+    return PL.merge_tables(tc, rc, [dict(s, expr=E.rebind(s["expr"], schema)) for s in sort_expr], pre_concatenated=mine)

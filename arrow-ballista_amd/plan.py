@@ -318,6 +318,35 @@ def sort_table(tc, table, sort_expr, fetch=None, memo=None):
     return _select_view(tc, table, perm[:k], k)
 
 
+def merge_tables(tc, parts, sort_expr, fetch=None, memo=None, pre_concatenated=None):
+    """Ordered fan-in of tables that are each sorted by `sort_expr` (gpuq_merge_run): the merged order as a view over their
+    concatenation; ties keep (part, row) order.  pre_concatenated: the table the parts are consecutive slices of, when the
+    caller already holds it (the runs received by an exchange); `parts` may then be plain row counts."""
+    torch = _torch()
+    parts = [p for p in parts]
+    table = pre_concatenated if pre_concatenated is not None else concat_tables(tc, parts)
+    if len(parts) <= 1:      # one partition (it may hold several runs, e.g. gathered by BroadcastExec): sort
+        return sort_table(tc, table, sort_expr, fetch, memo=memo)
+    memo = tc._memo if memo is None else memo
+    mk = ("sort", id(tc), repr(sort_expr) if memo is tc._memo else None, table_sig(table))
+    op = memo.get(mk)
+    if op is None:
+        schema = table.schema()
+        desc = {"op": "sort", "input": {"fields": schema},
+                "expr": [{"expr": E.rebind(s["expr"], schema), "asc": bool(s.get("asc", True)),
+                          "nulls_first": bool(s.get("nulls_first", not s.get("asc", True)))} for s in sort_expr]}
+        op = memo[mk] = tc.op(desc)
+    n = table.num_rows
+    offs = [0]
+    for p in parts:
+        offs.append(offs[-1] + (p if isinstance(p, int) else p.num_rows))
+    perm = torch.empty(max(1, n), dtype=torch.int32, device=tc.device)
+    inp, keep = table.input_struct()
+    tc.ctx.check(tc.ctx.L.gpuq_merge_run(op.h, tc.stream_ptr(), C.byref(inp), (C.c_int64 * len(offs))(*offs), len(parts), perm.data_ptr()))
+    k = n if fetch is None or fetch < 0 else min(n, int(fetch))
+    return _select_view(tc, table, perm[:k], k)
+
+
 def slice_table(tc, table, skip, fetch):
     """Rows [skip, skip+fetch) of a table as a view (fetch None: to the end)."""
     torch = _torch()
@@ -802,9 +831,9 @@ class SortExec(ExecutionPlan):
 
 class SortPreservingMergeExec(ExecutionPlan):
     """SortPreservingMergeExec(expr, input, fetch) -- datafusion.proto:1473-1478: merges the input's sorted partitions
-    into one sorted partition.  On the device the k-way merge is a concatenation in partition order followed by the
-    stable LSD radix sort: equal keys keep (partition, row) order, which is what a merge that prefers the
-    lower-numbered stream on ties produces [UPSTREAM-KNOWLEDGE: streaming_merge loser tree]."""
+    into one sorted partition.  On the device: pairwise merge-path rounds over the packed composite keys (gpuq_merge_run);
+    equal keys keep (partition, row) order, which is what a merge that prefers the lower-numbered stream on ties
+    produces [UPSTREAM-KNOWLEDGE: streaming_merge loser tree]."""
 
     def __init__(self, expr, input, fetch=None):
         super().__init__()
@@ -822,8 +851,7 @@ class SortPreservingMergeExec(ExecutionPlan):
     def execute(self, partition, context):
         parts = [self.input.execute(p, context) for p in range(self.input.output_partition_count())]
         t0 = time.perf_counter()
-        merged = concat_tables(context, parts)
-        return self._timed(t0, sort_table(context, merged, self.expr, self.fetch, memo=self._memo))
+        return self._timed(t0, merge_tables(context, parts, self.expr, self.fetch, memo=self._memo))
 
 
 class CoalesceTasksExec(ExecutionPlan):
@@ -852,9 +880,8 @@ class CoalesceTasksExec(ExecutionPlan):
         which = range(self.input.output_partition_count()) if self.order_by else self.partitions
         parts = [self.input.execute(p, context) for p in which]
         t0 = time.perf_counter()
-        out = concat_tables(context, parts)
-        if self.order_by:
-            out = sort_table(context, out, self.order_by, None, memo=self._memo)
+        # ordered: the k-way merge of coalesce_tasks.rs:162-170 (pairwise merge-path rounds on the device)
+        out = merge_tables(context, parts, self.order_by, None, memo=self._memo) if self.order_by else concat_tables(context, parts)
         return self._timed(t0, out)
 
     def __str__(self):

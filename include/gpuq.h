@@ -280,6 +280,13 @@ int gpuq_mark_rows(gpuq_ctx* ctx, void* stream, const uint32_t* rows, int64_t n,
    Asynchronous. */
 int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out);
 
+/* Ordered fan-in -- CoalesceTasksExec with `order_by` / SortPreservingMergeExec (coalesce_tasks.rs:162-170 `streaming_merge`):
+   `in` is the concatenation of n_runs runs, run r = rows [run_offsets[r], run_offsets[r+1]) (host array of n_runs + 1 entries,
+   empty runs allowed), each already in the order of `op` (a "sort" operator).  Writes the permutation of the merged order; equal
+   keys keep (run, row) order, i.e. the result equals the stable sort of the concatenation.  log2(n_runs) merge-path rounds on the
+   device, one read + one write of the (key, row) records per round.  Runs that are NOT sorted give an unspecified permutation. */
+int gpuq_merge_run(gpuq_op* op, void* stream, const gpuq_input* in, const int64_t* run_offsets, int n_runs, uint32_t* perm_out);
+
 /* Hash repartition (BatchPartitioner::partition call site, shuffle_writer.rs:336-391):
    perm_out lists driving positions grouped by partition (input order inside a partition),
    part_offsets_out[p]..[p+1] (device u64, partition_count+1 entries) delimit partition p.

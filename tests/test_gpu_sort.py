@@ -47,3 +47,37 @@ def test_all_keys_equal_and_sorted_inputs(tc):
     assert np.array_equal(sorted_row_ids(tc, t, [("up", True)]), np.arange(n))
     assert np.array_equal(sorted_row_ids(tc, t, [("down", True)]), np.arange(n)[::-1])
     assert np.array_equal(sorted_row_ids(tc, t, [("up", False)]), np.arange(n)[::-1])
+
+
+# ------------------------------------------------------------------ ordered fan-in (gpuq_merge_run)
+def run_table(r, n, wide):
+    """n rows sorted by the test's key(s): few distinct values (ties across runs) or full-range two-field keys."""
+    a = np.sort(r.integers(0, 50, n).astype(np.int64)) if not wide else r.integers(-2**62, 2**62, n).astype(np.int64)
+    b = r.integers(-2**62, 2**62, n).astype(np.int64)
+    if wide:
+        order = np.lexsort((b, a)); a, b = a[order], b[order]
+    return a, b
+
+
+@pytest.mark.parametrize("wide", [False, True], ids=["one-word-ties", "two-word"])
+@pytest.mark.parametrize("sizes", [[5, 0, 7], [1], [2048, 2049], [1000, 0, 0, 3000, 17, 4096, 1], [30_000] * 16, [100_003, 5, 70_001]])
+def test_merge_of_sorted_runs_is_the_stable_sort_of_their_concatenation(tc, sizes, wide):
+    """CoalesceTasksExec(order_by) over MemoryExec partitions that are each sorted: merge-path rounds on the device.  Ties must
+    come out in (partition, row) order, empty partitions and a lone partition are fine, tiles of 2048 records are crossed."""
+    r = np.random.default_rng(sum(sizes) + len(sizes))
+    parts, allk, allb, rid0 = [], [], [], 0
+    for n in sizes:
+        a, b = run_table(r, n, wide)
+        t = pa.table({"rid": np.arange(rid0, rid0 + n, dtype=np.int64), "a": a, "b": b})
+        parts.append(t.cast(pa.schema([pa.field(f.name, f.type, nullable=False) for f in t.schema])))
+        allk.append(a); allb.append(b); rid0 += n
+    src = g.MemoryExec(parts)
+    s = src.schema()
+    order = [{"expr": col("a", s), "asc": True, "nulls_first": False}] + ([{"expr": col("b", s), "asc": True, "nulls_first": False}] if wide else [])
+    A, Bv = np.concatenate(allk), np.concatenate(allb)
+    want = np.lexsort((Bv, A)) if wide else np.argsort(A, kind="stable")
+    for plan in (g.CoalesceTasksExec(src, list(range(len(sizes))), order_by=order), g.SortPreservingMergeExec(order, src)):
+        got = np.asarray(g.plan.materialize(tc, plan.execute(0, tc)).to_arrow(tc.ctx).column("rid"))
+        assert np.array_equal(got, want)
+        native = g.NativePlan(plan, tc).execute(0).to_arrow()
+        assert np.array_equal(np.asarray(native.column("rid")), want)
