@@ -1,0 +1,44 @@
+"""profiles/r02_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py`: HBM-side bytes per launch of
+the dominant kernel (the q3 lineitem probe), corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes.
+usage: make_traffic.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <bench json line file> <out json>"""
+import collections, csv, glob, json, sys
+
+
+def per_dispatch(d, counter, kern):
+    by = collections.defaultdict(lambda: {"v": 0.0, "grid": 0})
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kern in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                e = by[r["Dispatch_Id"]]
+                e["v"] += float(r["Counter_Value"]); e["grid"] = int(r["Grid_Size"])
+    return list(by.values())
+
+
+def biggest(ds):
+    """q3 launches this kernel twice per run (customer|x|orders, then |x|lineitem): the lineitem probe is the larger half"""
+    ds = sorted(ds, key=lambda e: -e["v"])
+    return ds[: max(1, len(ds) // 2)]
+
+
+kern = "join_probe_unique"
+fetch = biggest(per_dispatch(sys.argv[1], "FETCH_SIZE", kern))
+write = biggest(per_dispatch(sys.argv[2], "WRITE_SIZE", kern))
+line = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1])
+f_kb = sum(e["v"] for e in fetch) / len(fetch)
+w_kb = sum(e["v"] for e in write) / len(write)
+alg = line["roofline"]["algorithmic_bytes_per_launch"]
+out = {
+    "kernel": "gpuq_jit_join_probe_unique (HashJoinExec probe of lineitem: fused l_shipdate filter + direct-addressed lookup + probe-ordered pair emit)",
+    "workload": line["config"]["workload"],
+    "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras",
+    "launches_averaged": {"FETCH_SIZE": len(fetch), "WRITE_SIZE": len(write)},
+    "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
+    "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact. "
+                  "The guide calibrates this for wide streaming reads; the probe mixes streamed key / date columns with line-granular table lookups, so the read figure is an upper-bound estimate",
+    "traffic_bytes_per_launch": 2 * f_kb * 1024 + w_kb * 1024,
+    "read_bytes_per_launch": 2 * f_kb * 1024, "write_bytes_per_launch": w_kb * 1024,
+    "algorithmic_bytes_per_launch": alg,
+    "traffic_over_algorithmic": (2 * f_kb * 1024 + w_kb * 1024) / alg,
+}
+json.dump(out, open(sys.argv[4], "w"), indent=1)
+print(json.dumps(out, indent=1))
