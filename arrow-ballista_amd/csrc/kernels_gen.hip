@@ -2,7 +2,7 @@
 // Distributions follow SURVEY.md §8(d); the schema is the reference's
 // (benchmarks/src/bin/tpch.rs:864-957): Int64 keys, Decimal128(15,2) money, Date32 dates, Utf8 flags.
 // Counter-based: value = f(seed, column id, row), so any row range can be produced independently on
-// any GPU and restated bit-for-bit on the CPU (oracle/gen.c).
+// any GPU and restated bit-for-bit on the CPU (oracle/oracle.c: oracle_gen_lineitem / _orders / _customer / _supplier).
 //
 // Deviation from dbgen, stated once: every order has exactly 4 lineitems (dbgen: 1..7, mean 4), so
 // lineitem row i belongs to order index i>>2 and offsets have a closed form.
