@@ -1031,6 +1031,7 @@ struct ShuffleFile { int64_t partition; std::string path; int64_t rows, batches,
 struct ShuffleWriterExec : PNode {
   PNodeP input; std::string job_id, work_dir; int64_t stage_id = 0; bool hashed = false; Json hash_expr; int64_t partition_count = 0; int64_t batch_rows = 1 << 20;
   int64_t write_ns = 0, repart_ns = 0, input_rows = 0;      // ShuffleWriteMetrics, shuffle_writer.rs:139-160
+  std::vector<int64_t> stage_partitions;                    // shuffle_writer.rs:118-119
   std::vector<PNode*> children() override { return {input.get()}; }
   PSchema schema() override {      // the result batch of shuffle_writer.rs:470-520
     return {{"partition", jstr("UInt32"), false}, {"path", jstr("Utf8"), false}, {"num_rows", jstr("UInt64"), false}, {"num_batches", jstr("UInt64"), false}, {"num_bytes", jstr("UInt64"), false}};
@@ -1357,6 +1358,9 @@ PNodeP build_node(const Json& j) {
   } else if (kind == "ShuffleWriterExec") {
     auto n = std::make_unique<ShuffleWriterExec>(); n->input = build_child(v, "input");
     n->job_id = v.at("job_id").str(); n->stage_id = v.at("stage_id").i64(); n->work_dir = v.at("work_dir").str(); n->batch_rows = v.get_i64("batch_rows", 1 << 20);
+    // the stage partitions this task executes (shuffle_writer.rs:118-119): the child's CoalesceTasksExec does the work, the writer
+    // only reports them back in every ShuffleWritePartition (:319, :411) -- echoed in gpuq_plan_metrics for the shim to fill in
+    if (v.has("partitions")) for (auto& e : v.at("partitions").a) { if (e.i64() < 0) throw std::runtime_error("ShuffleWriterExec: negative stage partition"); n->stage_partitions.push_back(e.i64()); }
     if (n->work_dir.empty()) throw std::runtime_error("ShuffleWriterExec: work_dir is empty (the decoded plan carries \"\"; the engine sets the executor's, serde/mod.rs:191)");
     if (v.has("output_partitioning")) {
       const Json& op = v.at("output_partitioning");
@@ -1580,7 +1584,11 @@ int gpuq_plan_metrics(gpuq_plan* p, char* buf, size_t cap) {
   {
     s += std::string(i ? "," : "") + "{\"node\":\"" + nodes[i]->kind + "\",\"output_rows\":" + std::to_string(nodes[i]->m.output_rows) + ",\"elapsed_compute\":" + std::to_string(nodes[i]->m.elapsed_ns);
     if (auto* w = dynamic_cast<ShuffleWriterExec*>(nodes[i]))
-      s += ",\"write_time\":" + std::to_string(w->write_ns) + ",\"repart_time\":" + std::to_string(w->repart_ns) + ",\"input_rows\":" + std::to_string(w->input_rows);
+    {
+      s += ",\"write_time\":" + std::to_string(w->write_ns) + ",\"repart_time\":" + std::to_string(w->repart_ns) + ",\"input_rows\":" + std::to_string(w->input_rows) + ",\"partitions\":[";
+      for (size_t k = 0; k < w->stage_partitions.size(); ++k) s += (k ? "," : "") + std::to_string(w->stage_partitions[k]);
+      s += "]";
+    }
     s += "}";
   }
   s += "]";

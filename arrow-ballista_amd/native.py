@@ -98,6 +98,8 @@ def plan_to_json(node, tc, inputs):
         if node.shuffle_output_partitioning is not None:
             exprs, n = node.shuffle_output_partitioning
             d["output_partitioning"] = {"hash_expr": list(exprs), "partition_count": int(n)}
+        if node.partitions is not None:
+            d["partitions"] = [int(x) for x in node.partitions]
         return {"ShuffleWriterExec": d}
     if isinstance(node, P.ShuffleReaderExec):
         return {"ShuffleReaderExec": {"schema": [{"name": f["name"], "type": f["type"], "nullable": bool(f.get("nullable", True))} for f in node.schema()],

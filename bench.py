@@ -50,7 +50,7 @@ def main_q3():
     ap.add_argument("--sf", type=float, default=100.0, help="scale factor of the WHOLE job (default 100 = BASELINE configs[2]); N ranks hold 1/N of every table each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-sf", type=float, default=10.0)
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (N=1: probe micro-grid, SF100 q1 / q5; N>1: q3 with the build side broadcast, q1)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (N=1: probe micro-grid, SF100 q1 / q5; N>1: q3 with the build side broadcast, distributed q5, q1)")
     args = ap.parse_args()
 
     import torch
@@ -194,7 +194,18 @@ def main_q3():
                 p2.execute(0)
             d2, r2 = timed_steps(lambda: p2.execute(0), k)
             extra["q3_build_side_broadcast"] = {"ms_per_step": d2 / k * 1e3, "lineitem_rows_per_s": rows_job * k / d2, "result_groups": r2.num_rows}
-            del p2, r2, li, od, cu
+            # BASELINE configs[3]: q5, the 6-way join with orders |x| lineitem hash-partitioned across the ranks (T.q5_dist_plan)
+            sper = n_supp // world
+            su = T.gen_supplier_device(tc, sper if rank < world - 1 else n_supp - sper * (world - 1), row0=rank * sper)
+            nation, region = T.nation_region_arrow()
+            p5 = g.NativePlan(T.q5_dist_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), g.MemoryExec([su]), g.MemoryExec([nation]), g.MemoryExec([region]), world), tc)
+            p5.set_comm(comm)
+            for _ in range(3):
+                p5.execute(0)
+            tc.ctx.jit_wait()
+            d5, r5 = timed_steps(lambda: p5.execute(0), k)
+            extra["q5_partitioned_join"] = {"ms_per_step": d5 / k * 1e3, "lineitem_rows_per_s": rows_job * k / d5, "result_groups": r5.num_rows}
+            del p2, r2, p5, r5, su, li, od, cu
             torch.cuda.empty_cache()
             l1 = T.gen_lineitem_device(tc, n_li, row0=rank * n_li)
             p3 = g.NativePlan(T.q1_dist_plan(l1), tc)

@@ -354,7 +354,10 @@ int gpuq_copy_bits(gpuq_ctx* ctx, void* stream, uint8_t* dst, int64_t dst_bit_of
      {"GlobalLimitExec": {"input","skip","fetch"}}  {"UnionExec": {"inputs": [node]}}  {"CoalescePartitionsExec": {"input"}}   (:1453, :1319, :1492)
      {"CoalesceTasksExec": {"input","partitions": [p],"order_by"?: [sort expr]}}     (ballista coalesce_tasks.rs:46-70)
      {"ShuffleWriterExec": {"input","job_id","stage_id","work_dir","output_partitioning"?: {"hash_expr": [expr], "partition_count": n},
-                            "batch_rows"?: rows per RecordBatch, default 2^20}}      (ballista shuffle_writer.rs:234-456: the stage root)
+                            "batch_rows"?: rows per RecordBatch, default 2^20,
+                            "partitions"?: [stage partitions of this task, shuffle_writer.rs:118-119: echoed by gpuq_plan_metrics
+                                            for ShuffleWritePartition.partitions, the CoalesceTasksExec child does the work]}}
+                                                                                   (ballista shuffle_writer.rs:234-456: the stage root)
          writes <work_dir>/<job_id>/<stage_id>/<q>/<uuid>.arrow per non-empty output partition q (unpartitioned:
          .../<stage_id>/<uuid>/data.arrow), Arrow IPC stream + LZ4_FRAME; result = one row per file:
          partition UInt32, path Utf8, num_rows / num_batches / num_bytes UInt64 (shuffle_writer.rs:470-520)

@@ -51,6 +51,14 @@ def main():
             plan = g.NativePlan(T.q3_dist_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), world, mode), tc)
             plan.set_comm(comm)
             res["q3_" + mode] = [list(r) for r in arrow_rows(plan.execute(0).to_arrow())]
+        # distributed q5 (BASELINE configs[3]): sharded customer / orders / lineitem / supplier, replicated nation / region
+        n_supp = 100
+        sper = n_supp // world
+        su = T.gen_supplier_device(tc, sper if rank < world - 1 else n_supp - sper * (world - 1), row0=rank * sper)
+        nation, region = T.nation_region_arrow()
+        plan = g.NativePlan(T.q5_dist_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), g.MemoryExec([su]), g.MemoryExec([nation]), g.MemoryExec([region]), world), tc)
+        plan.set_comm(comm)
+        res["q5"] = [list(r) for r in arrow_rows(plan.execute(0).to_arrow())]
         comm.close()
     finally:
         dist.destroy_process_group()

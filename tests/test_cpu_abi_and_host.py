@@ -350,6 +350,12 @@ def test_plan_schema_is_known_before_execution_and_without_a_device():
     cu = empty([("c_custkey", "Int64"), ("c_nationkey", "Int64"), ("c_mktsegment", "Utf8")])
     q3 = host_schema(T.q3_plan(cu, od, li))
     assert [(n, t) for n, t, _ in q3] == [("l_orderkey", "Int64"), ("revenue", dec(38, 4)), ("o_orderdate", "Date32"), ("o_shippriority", "Int32")]
+    # the distributed plans (exchange nodes inside) type the same way
+    su = empty([("s_suppkey", "Int64"), ("s_nationkey", "Int64")])
+    na = empty([("n_nationkey", "Int64"), ("n_name", "Utf8"), ("n_regionkey", "Int64")])
+    re_ = empty([("r_regionkey", "Int64"), ("r_name", "Utf8")])
+    assert [(n, t) for n, t, _ in host_schema(T.q5_dist_plan(cu, od, li, su, na, re_, 2))] == [("n_name", "Utf8"), ("revenue", dec(38, 4))]
+    assert [(n, t) for n, t, _ in host_schema(T.q3_dist_plan(cu, od, li, 2, "partitioned"))] == [(n, t) for n, t, _ in q3]
     # outer joins make the non-preserved side nullable; semi joins keep one side
     cs, os_ = cu.schema(), od.schema()
     from arrow_ballista_amd.expr import col

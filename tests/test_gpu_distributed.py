@@ -156,3 +156,17 @@ def test_native_distributed_q3_equals_the_oracle_on_the_union(native_ranks, mode
         rows = [tuple(r) for r in rk["q3_" + mode]]
         assert [(r[1], r[2]) for r in rows] == [(r[1], r[2]) for r in exp]
         assert sorted(rows) == sorted(exp)
+
+
+def test_native_distributed_q5_equals_the_oracle_on_the_union(native_ranks):
+    """Distributed q5 (BASELINE configs[3]: 6-way join, the big join hash-partitioned across ranks; T.q5_dist_plan): broadcast of the
+    filtered customers and of supplier, both sides of orders |x| lineitem exchanged, partial aggregate states gathered; every
+    rank ends with the oracle's q5 over the union of the shards."""
+    import tpch_util as T
+    hl = T.lineitem_host_to_arrow(T.gen_lineitem_host(120_000, n_supp=100), 120_000)
+    ho, hc, hs = T.gen_other_tables_host(30_000, 1500, 100)
+    exp = [tuple(r) for r in T.q5_oracle(hc, ho, hl, hs)]
+    assert len(exp) > 0
+    for rk in native_ranks:
+        got = [(r[0], int(r[1]["d"].replace(".", "")) if isinstance(r[1], dict) else r[1]) for r in rk["q5"]]
+        assert got == exp

@@ -202,7 +202,7 @@ def test_native_stage_driver_writes_and_reads_shuffle_files(tc, tmp_path):
     s = src.schema()
     pred = binary(col("k32", s), Op.Gt, lit(-30, "Int32"))
     nred = 3
-    writer = g.ShuffleWriterExec("jobN", 2, g.FilterExec(pred, src), str(tmp_path), ([col("k64", s)], nred))
+    writer = g.ShuffleWriterExec("jobN", 2, g.FilterExec(pred, src), str(tmp_path), ([col("k64", s)], nred), partitions=[0, 1])
     wp = g.NativePlan(writer, tc)
     files = []
     for p in range(2):
@@ -222,6 +222,7 @@ def test_native_stage_driver_writes_and_reads_shuffle_files(tc, tmp_path):
     mets = {m["node"]: m for m in wp.metrics()}
     assert mets["ShuffleWriterExec"]["output_rows"] == len(keep) and mets["ShuffleWriterExec"]["write_time"] > 0 and mets["ShuffleWriterExec"]["repart_time"] > 0
     assert mets["ShuffleWriterExec"]["input_rows"] == len(keep)
+    assert mets["ShuffleWriterExec"]["partitions"] == [0, 1]      # the stage partitions of the task (shuffle_writer.rs:118-119), echoed for ShuffleWritePartition
     # reduce side
     reader = g.ShuffleReaderExec([[{"path": f[1]} for f in files if f[0] == q] for q in range(nred)], s)
     rs = reader.schema()

@@ -321,12 +321,12 @@ def gen_customer_device(tc, n, seed=SEED_CUSTOMER, row0=0):
     return g.DeviceTable(cols, n)
 
 
-def gen_supplier_device(tc, n, seed=SEED_SUPPLIER):
+def gen_supplier_device(tc, n, seed=SEED_SUPPLIER, row0=0):
     import arrow_ballista_amd as g
     from arrow_ballista_amd import binding as B
     cols, p = _dev_cols(tc, [("s_suppkey", "Int64", 8), ("s_nationkey", "Int64", 8)], n)
     cs = B.gpuq_supplier_cols(**p)
-    tc.ctx.check(tc.ctx.L.gpuq_gen_supplier(tc.ctx.h, tc.stream_ptr(), seed, 0, n, C.byref(cs)))
+    tc.ctx.check(tc.ctx.L.gpuq_gen_supplier(tc.ctx.h, tc.stream_ptr(), seed, row0, n, C.byref(cs)))
     tc.sync()
     return g.DeviceTable(cols, n)
 
@@ -445,6 +445,49 @@ def q5_plan(customer, orders, lineitem, supplier, nation, region):
     agg = g.AggregateExec("Single", [(col("n_name", j5s), "n_name")], [{"fn": "SUM", "expr": rev, "name": "revenue"}], j5)
     as_ = agg.schema()
     return g.SortExec([{"expr": col("revenue", as_), "asc": False, "nulls_first": True}], agg)
+
+
+def q5_dist_plan(customer, orders, lineitem, supplier, nation, region, world):
+    """q5 (BASELINE configs[3]: "6-way join, hash-partitioned across the GPUs") as one native plan per rank.  customer, orders,
+    lineitem and supplier are sharded; nation and region are replicated (dimension tables far below the reference's broadcast
+    threshold, config.rs:198-200).
+      region |> filter |x| nation |x| customer shard     -- local CollectLeft joins; the ASIA customers' (key, nation, name)
+                                                            are then BROADCAST (a fifth of customer)
+      orders shard |> filter |x| customers               -- local CollectLeft join against the broadcast rows
+      both sides of orders |x| lineitem hash-repartitioned on the order key, HashJoinExec(Partitioned)
+      supplier shards BROADCAST, |x| on (suppkey, nationkey)
+      AggregateExec(Partial) by n_name -> partial states gathered on every rank -> AggregateExec(Final) -> SortExec."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, Operator as Op
+    rs, ns, cs, os_, ls, ss = region.schema(), nation.schema(), customer.schema(), orders.schema(), lineitem.schema(), supplier.schema()
+    r = g.FilterExec(binary(col("r_name", rs), Op.Eq, lit("ASIA")), region)
+    j1 = g.HashJoinExec(r, nation, [(col("r_regionkey", rs), col("n_regionkey", ns))], None, "Inner", "CollectLeft", False)
+    j1s = j1.schema()
+    j2 = g.HashJoinExec(j1, customer, [(col("n_nationkey", j1s), col("c_nationkey", cs))], None, "Inner", "CollectLeft", False)
+    j2s = j2.schema()
+    cb = g.BroadcastExec(g.ProjectionExec([(col(n, j2s), n) for n in ("c_custkey", "c_nationkey", "n_name")], j2))
+    cbs = cb.schema()
+    o = g.FilterExec(and_(binary(col("o_orderdate", os_), Op.GtEq, lit(Q5_DATE_LO, "Date32")), binary(col("o_orderdate", os_), Op.Lt, lit(Q5_DATE_HI, "Date32"))), orders)
+    j3 = g.HashJoinExec(cb, g.CoalesceBatchesExec(o), [(col("c_custkey", cbs), col("o_custkey", os_))], None, "Inner", "CollectLeft", False)
+    j3s = j3.schema()
+    j3p = g.ProjectionExec([(col(n, j3s), n) for n in ("o_orderkey", "c_nationkey", "n_name")], j3)
+    p3 = j3p.schema()
+    lp = g.ProjectionExec([(col(n, ls), n) for n in ("l_orderkey", "l_suppkey", "l_extendedprice", "l_discount")], lineitem)
+    pl = lp.schema()
+    left = g.RepartitionExchangeExec(j3p, [col("o_orderkey", p3)], world)
+    right = g.RepartitionExchangeExec(lp, [col("l_orderkey", pl)], world)
+    j4 = g.HashJoinExec(left, right, [(col("o_orderkey", p3), col("l_orderkey", pl))], None, "Inner", "Partitioned", False)
+    j4s = j4.schema()
+    sb = g.BroadcastExec(supplier)
+    j5 = g.HashJoinExec(sb, j4, [(col("s_suppkey", ss), col("l_suppkey", j4s)), (col("s_nationkey", ss), col("c_nationkey", j4s))], None, "Inner", "CollectLeft", False)
+    j5s = j5.schema()
+    rev = binary(col("l_extendedprice", j5s), Op.Multiply, binary(lit(1, ("Decimal128", 20, 0)), Op.Minus, col("l_discount", j5s)))
+    aggs = [{"fn": "SUM", "expr": rev, "name": "revenue"}]
+    part = g.AggregateExec("Partial", [(col("n_name", j5s), "n_name")], aggs, j5)
+    fs = part.schema()
+    fin = g.AggregateExec("Final", [(col("n_name", fs), "n_name")], [dict(a, expr=None) for a in aggs], g.BroadcastExec(part))
+    as_ = fin.schema()
+    return g.SortExec([{"expr": col("revenue", as_), "asc": False, "nulls_first": True}], fin)
 
 
 def q3_oracle(customer, orders, lineitem):
