@@ -372,6 +372,64 @@ __global__ __launch_bounds__(256) void k_utf8_piece_compact(const Utf8Piece* __r
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.used; i += (int64_t)gridDim.x * 256) d[i] = s[i];
 }
 
+// ---------------------------------------------------------------- Snappy (Parquet pages; kernels_scanfmt.hip decodes what this unpacks)
+// Raw Snappy block format [UPSTREAM-KNOWLEDGE: google/snappy format_description.txt]: varint uncompressed length, then elements --
+// tag & 3 == 0 literal (length (tag >> 2) + 1, or 1-4 length bytes when that is 61-64), 1 copy with 11-bit offset and length 4-11,
+// 2 copy with 16-bit offset, 3 copy with 32-bit offset (length (tag >> 2) + 1).  One wave per page: every lane reads the same tag
+// bytes (uniform loads), literals and copies are moved by all lanes; a copy whose offset is shorter than its length repeats the
+// period (source byte i % offset lies before the copy).  mode 0 = stored (plain copy).  `raw_prefix` bytes in front of the
+// compressed stream are copied verbatim (a v2 data page's levels).
+__global__ __launch_bounds__(64) void k_unpack_pages(const uint8_t* __restrict__ src_base, uint8_t* __restrict__ dst_base, const UnpackJob* __restrict__ jobs, int n_jobs,
+                                                     uint32_t* __restrict__ status) {
+  const int u = (int)blockIdx.x;
+  if (u >= n_jobs) return;
+  const UnpackJob J = jobs[u];
+  const int lane = lane_id();
+  const uint8_t* in = src_base + J.src; uint8_t* out = dst_base + J.dst;
+  if (J.raw_prefix > J.src_len || J.raw_prefix > J.dst_len) { if (lane == 0) atomicOr(status, 1u); return; }
+  for (int64_t i = lane; i < J.raw_prefix; i += 64) out[i] = in[i];
+  in += J.raw_prefix; out += J.raw_prefix;
+  const int64_t in_len = J.src_len - J.raw_prefix, out_len = J.dst_len - J.raw_prefix;
+  if (J.mode == 0) {
+    if (in_len != out_len) { if (lane == 0) atomicOr(status, 1u); return; }
+    for (int64_t i = lane; i < in_len; i += 64) out[i] = in[i];
+    return;
+  }
+  int64_t ip = 0, op = 0;
+  // preamble: uncompressed length
+  uint64_t ulen = 0; int sh = 0; bool bad = false;
+  for (;;) { if (ip >= in_len || sh > 35) { bad = true; break; } const uint8_t c = in[ip++]; ulen |= (uint64_t)(c & 0x7F) << sh; if (!(c & 0x80)) break; sh += 7; }
+  if (bad || (int64_t)ulen != out_len) { if (lane == 0) atomicOr(status, 1u); return; }
+  while (ip < in_len) {
+    const uint32_t tag = in[ip++];
+    int64_t len; int64_t off = 0;
+    if ((tag & 3) == 0) {
+      len = (int64_t)(tag >> 2) + 1;
+      if (len > 60) {
+        const int nb = (int)len - 60;
+        if (ip + nb > in_len) { bad = true; break; }
+        uint32_t v = 0; for (int k = 0; k < nb; ++k) v |= (uint32_t)in[ip + k] << (8 * k);
+        ip += nb; len = (int64_t)v + 1;
+      }
+      if (len > in_len - ip || len > out_len - op) { bad = true; break; }
+      for (int64_t i = lane; i < len; i += 64) out[op + i] = in[ip + i];
+      ip += len; op += len;
+      continue;
+    }
+    if ((tag & 3) == 1) { if (ip + 1 > in_len) { bad = true; break; } len = 4 + ((tag >> 2) & 7); off = (int64_t)((tag >> 5) << 8) | in[ip]; ip += 1; }
+    else if ((tag & 3) == 2) { if (ip + 2 > in_len) { bad = true; break; } len = (int64_t)(tag >> 2) + 1; off = (int64_t)in[ip] | ((int64_t)in[ip + 1] << 8); ip += 2; }
+    else { if (ip + 4 > in_len) { bad = true; break; } len = (int64_t)(tag >> 2) + 1; off = (int64_t)in[ip] | ((int64_t)in[ip + 1] << 8) | ((int64_t)in[ip + 2] << 16) | ((int64_t)in[ip + 3] << 24); ip += 4; }
+    if (off == 0 || off > op || len > out_len - op) { bad = true; break; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // earlier stores of this wave are visible to its loads
+    const uint8_t* m = out + op - off;
+    if (off >= len) { for (int64_t i = lane; i < len; i += 64) out[op + i] = m[i]; }
+    else { for (int64_t i = lane; i < len; i += 64) out[op + i] = m[i % off]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    op += len;
+  }
+  if (bad || op != out_len) { if (lane == 0) atomicOr(status, 1u); }
+}
+
 // ---------------------------------------------------------------- launchers
 void launch_utf8_piece_starts(hipStream_t s, Utf8Piece* pieces, int n_pieces, uint32_t* gap) {
   if (n_pieces > 0) hipLaunchKernelGGL(k_utf8_piece_starts, dim3(1), dim3(256), 0, s, pieces, n_pieces, gap);
@@ -415,6 +473,10 @@ void launch_popcount_bits(hipStream_t s, const uint8_t* bits, int64_t n_bits, un
   if (words <= 0) return;
   const int blocks = (int)std::min<int64_t>(1024, (words + 255) / 256);
   hipLaunchKernelGGL(k_popcount_bits, dim3((unsigned)blocks), dim3(256), 0, s, (const u64*)bits, n_bits, out);
+}
+
+void launch_unpack_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, int n_jobs, uint32_t* status) {
+  if (n_jobs > 0) hipLaunchKernelGGL(k_unpack_pages, dim3((unsigned)n_jobs), dim3(64), 0, s, src, dst, jobs, n_jobs, status);
 }
 
 }  // namespace gpuq

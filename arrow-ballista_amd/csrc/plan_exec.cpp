@@ -742,8 +742,14 @@ struct HashJoinExec : PNode {
     const bool residual = has_filter && join_type != "Inner";
     const std::string jt = residual ? std::string("Inner") : join_type;
     int lpart = partition_mode == "Partitioned" ? part : 0;
-    if (partition_mode != "Partitioned" && left->partitions() != 1) throw Unsupported("CollectLeft with a multi-partition build side: wrap the left input in a single partition");
-    Side L = side(left.get(), lpart, x), R = side(right.get(), part, x);
+    Side L;
+    if (partition_mode != "Partitioned" && left->partitions() != 1) {
+      // CollectLeft: the build side is ALL partitions of the left input, collected into one table (what DataFusion's collect_left_input
+      // does before it builds); each partition runs with its own filters / projections applied
+      std::vector<PTable> in; for (int p = 0; p < left->partitions(); ++p) in.push_back(left->execute(p, x));
+      L.t = concat_tables(x, std::move(in));
+    } else L = side(left.get(), lpart, x);
+    Side R = side(right.get(), part, x);
     auto t0 = std::chrono::steady_clock::now();
     if (residual) {      // rows that fail a side's own predicate are not part of the join at all: apply those first
       if (L.has_pred) { L.t = filter_table(x, L.t, L.pred, this, 3); L.has_pred = false; }

@@ -354,6 +354,16 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
     };
     std::vector<std::unique_ptr<ColPlan>> plans;
     std::vector<Uploader::Seg> segs; int64_t up_bytes = 0;      // projected chunks back to back (64-byte aligned) in one device buffer
+    // Snappy chunks: every page (of every projected column) goes through one unpack launch into a second buffer the decoders read
+    bool any_compressed = false;
+    for (int li : proj) for (const PqRowGroup& G : M.groups) if ((size_t)li < G.cols.size() && G.cols[(size_t)li].num_values > 0 && G.cols[(size_t)li].codec != 0) any_compressed = true;
+    std::vector<UnpackJob> jobs; int64_t page_bytes = 0;
+    auto place = [&](int64_t src, int comp, int uncomp, int raw_prefix, int mode) -> int64_t {      // -> the page's position for the decoders
+      if (!any_compressed) return src;
+      const int64_t dst = page_bytes; page_bytes += ((int64_t)uncomp + 63) & ~(int64_t)63;
+      jobs.push_back({src, dst, comp, uncomp, raw_prefix, mode, 0});
+      return dst;
+    };
     for (int li : proj) {
       const PqSchemaElem& L = leaves[(size_t)li];
       auto P = std::make_unique<ColPlan>();
@@ -374,7 +384,8 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
         if ((size_t)li >= G.cols.size()) throw std::runtime_error("parquet: row group without column " + L.name);
         const PqChunk& K = G.cols[(size_t)li];
         if (K.num_values == 0) continue;
-        if (K.codec != 0) throw Unsupported("parquet: compressed column chunk (codec " + std::to_string(K.codec) + ") in '" + L.name + "': only UNCOMPRESSED pages are decoded on the device");
+        if (K.codec != 0 && K.codec != 1) throw Unsupported("parquet: compressed column chunk (codec " + std::to_string(K.codec) + ") in '" + L.name + "': UNCOMPRESSED and SNAPPY pages are decoded on the device");
+        const int cmode = K.codec == 1 ? 1 : 0;
         int64_t pos = K.dict_page_offset >= 0 && K.dict_page_offset < K.data_page_offset ? K.dict_page_offset : K.data_page_offset;
         const int64_t chunk_end = pos + K.total_compressed;
         if (pos < 4 || chunk_end > n_bytes - 8) throw std::runtime_error("parquet: column chunk outside the file");
@@ -387,9 +398,13 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
           if (payload + H.compressed > chunk_end) throw std::runtime_error("parquet: page exceeds its column chunk");
           if (H.type == 2) {       // dictionary page
             if (H.encoding != 0 && H.encoding != 2) throw Unsupported("parquet: dictionary page encoding " + std::to_string(H.encoding));
-            dict_id = (int)P->dict_src.size(); P->dict_src.push_back({payload + base, H.compressed, H.num_values});
+            dict_id = (int)P->dict_src.size(); P->dict_src.push_back({place(payload + base, H.compressed, H.uncompressed, 0, cmode), any_compressed ? H.uncompressed : H.compressed, H.num_values});
           } else if (H.type == 0 || H.type == 3) {
-            PqPage G2{}; G2.src = payload + base; G2.bytes = H.compressed; G2.n_values = H.num_values; G2.row0 = row + seen; G2.dict = dict_id;
+            // a v2 page stores its levels uncompressed in front of the (optionally) compressed values
+            const int prefix = H.type == 3 ? H.def_v2 + H.rep_v2 : 0;
+            const int pmode = (H.type == 3 && !H.v2_compressed) ? 0 : cmode;
+            PqPage G2{}; G2.src = place(payload + base, H.compressed, H.uncompressed, prefix, pmode); G2.bytes = any_compressed ? H.uncompressed : H.compressed;
+            G2.n_values = H.num_values; G2.row0 = row + seen; G2.dict = dict_id;
             if (H.encoding == 0) G2.enc = PQE_PLAIN; else if (H.encoding == 2 || H.encoding == 8) G2.enc = PQE_DICT; else if (H.encoding == 3 && L.type == 0) G2.enc = PQE_RLE;
             else throw Unsupported("parquet: data page encoding " + std::to_string(H.encoding) + " in '" + L.name + "' (PLAIN, RLE_DICTIONARY and RLE booleans are decoded)");
             if (H.type == 3) { if (H.rep_v2 != 0) throw Unsupported("parquet: repetition levels"); G2.def_v2 = H.def_v2; }
@@ -408,9 +423,17 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
     // ---- the projected chunks cross PCIe once, all staging lanes busy
     DevBuf dfile; dfile.ensure((size_t)up_bytes + 64);
     g_uploader.copy_segments(ctx->device, s, dfile.p, segs);
+    DevBuf flags; flags.ensure(16); HIPCHECK(hipMemsetAsync(flags.p, 0, 16, s));
+    DevBuf dpagebuf, djobs;
+    const uint8_t* pages_base = (const uint8_t*)dfile.p; int64_t pages_bytes = up_bytes;
+    if (any_compressed) {
+      dpagebuf.ensure((size_t)page_bytes + 64); djobs.ensure(jobs.size() * sizeof(UnpackJob) + 64);
+      HIPCHECK(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(UnpackJob), hipMemcpyHostToDevice, s));
+      launch_unpack_pages(s, (const uint8_t*)dfile.p, (uint8_t*)dpagebuf.p, (const UnpackJob*)djobs.p, (int)jobs.size(), (uint32_t*)flags.p + 1);
+      pages_base = (const uint8_t*)dpagebuf.p; pages_bytes = page_bytes;
+    }
     // ---- pass 2 (device): dictionaries, pages, strings; one synchronisation at the end
     std::unique_ptr<gpuq_table> t(new gpuq_table()); t->ctx = ctx; t->n_rows = n_rows;
-    DevBuf flags; flags.ensure(16); HIPCHECK(hipMemsetAsync(flags.p, 0, 16, s));
     const size_t bm = (size_t)((n_rows + 63) / 64) * 8 + 16;
     const size_t rows1 = (size_t)std::max<int64_t>(n_rows, 1);
     for (size_t pi = 0; pi < plans.size(); ++pi) {
@@ -431,8 +454,8 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
       size_t va = 0, oa = 0;
       for (auto& d : P.dict_src) {
         PqDict D{}; D.values = (i64)va; D.str_offsets = (i64)(oa / 4); D.n = d.n;
-        if (gt == T_UTF8) { launch_pq_dict_strings(s, (const uint8_t*)dfile.p, d.src, d.bytes, d.n, (int32_t*)P.dstroffs.p + oa / 4, (uint8_t*)P.dvalues.p + va, (uint32_t*)flags.p); va += ((size_t)d.bytes + 63) & ~(size_t)63; oa += ((size_t)d.n + 2) * 4; }
-        else { launch_pq_dict_fixed(s, (const uint8_t*)dfile.p, d.src, d.n, L.type, L.type_length, width, (uint8_t*)P.dvalues.p + va); va += ((size_t)d.n * (size_t)width + 63) & ~(size_t)63; }
+        if (gt == T_UTF8) { launch_pq_dict_strings(s, pages_base, d.src, d.bytes, d.n, (int32_t*)P.dstroffs.p + oa / 4, (uint8_t*)P.dvalues.p + va, (uint32_t*)flags.p); va += ((size_t)d.bytes + 63) & ~(size_t)63; oa += ((size_t)d.n + 2) * 4; }
+        else { launch_pq_dict_fixed(s, pages_base, d.src, d.n, L.type, L.type_length, width, (uint8_t*)P.dvalues.p + va); va += ((size_t)d.n * (size_t)width + 63) & ~(size_t)63; }
         P.dicts.push_back(D);
       }
       P.ddicts.ensure(P.dicts.size() * sizeof(PqDict) + 64);
@@ -442,16 +465,18 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
       if (!P.pages.empty()) HIPCHECK(hipMemcpyAsync(P.dpages.p, P.pages.data(), P.pages.size() * sizeof(PqPage), hipMemcpyHostToDevice, s));
       const i64 stride = (3 * (i64)P.max_values + 9) & ~(i64)1;
       P.scratch.ensure((size_t)std::max<size_t>(P.pages.size(), 1) * (size_t)stride * 4 + 64);
-      launch_pq_decode(s, (const uint8_t*)dfile.p, up_bytes, (const PqPage*)P.dpages.p, (int)P.pages.size(), C, (const PqDict*)P.ddicts.p, (const uint8_t*)P.dvalues.p, (const int32_t*)P.dstroffs.p,
+      launch_pq_decode(s, pages_base, pages_bytes, (const PqPage*)P.dpages.p, (int)P.pages.size(), C, (const PqDict*)P.ddicts.p, (const uint8_t*)P.dvalues.p, (const int32_t*)P.dstroffs.p,
                        (uint32_t*)P.scratch.p, stride, (uint32_t*)flags.p);
       HIPCHECK(hipGetLastError());
       if (gt == T_UTF8) {
-        const uint8_t* df = (const uint8_t*)dfile.p; const uint8_t* dv = (const uint8_t*)P.dvalues.p; const i64* src = (const i64*)P.str_src.p;
+        const uint8_t* df = pages_base; const uint8_t* dv = (const uint8_t*)P.dvalues.p; const i64* src = (const i64*)P.str_src.p;
         finish_strings(s, *ic, (int32_t*)ic->offsets.p, n_rows, [&](const int32_t* offs, uint8_t* dst, int64_t) { launch_pq_copy_strings(s, df, dv, src, offs, n_rows, dst); });
       }
       t->cols.push_back(std::move(ic));
     }
-    const uint32_t fl = d2h_value(s, (const uint32_t*)flags.p);      // synchronises: the plans' host vectors and scratch may go
+    uint32_t fl2[2]; HIPCHECK(hipMemcpyAsync(fl2, flags.p, 8, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s));      // synchronises: the plans' host vectors and scratch may go
+    if (fl2[1]) throw std::runtime_error("parquet: malformed Snappy data in a page");
+    const uint32_t fl = fl2[0];
     if (fl & PQF_MALFORMED) throw std::runtime_error("parquet: malformed page (levels / indices / lengths run past the page, or an index beyond its dictionary)");
     if (fl & PQF_UNSUPPORTED) throw Unsupported("parquet: a page holds a value type the device does not decode");
     *out = t.release();

@@ -547,6 +547,13 @@ def scan_decode(tc, T, g, sf=1):
     out["parquet_device"] = {"ms": dt * 1e3, "file_GBps": len(pfile) / dt / 1e9, "rows_per_s": n / dt}
     dt = best_of(lambda: scan.read_parquet(tc, pfile, ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"]))
     out["parquet_device_q1_columns"] = {"ms": dt * 1e3, "rows_per_s": n / dt}
+    buf = io.BytesIO()
+    pq.write_table(li, buf, compression="SNAPPY", use_dictionary=True, data_page_size=1 << 20, row_group_size=1 << 20)
+    sfile = buf.getvalue()
+    dt = best_of(lambda: scan.read_parquet(tc, sfile))
+    out["parquet_snappy_device"] = {"ms": dt * 1e3, "file_bytes": len(sfile), "file_GBps": len(sfile) / dt / 1e9, "rows_per_s": n / dt}
+    dt = best_of(lambda: pq.read_table(io.BytesIO(sfile)))
+    out["parquet_snappy_pyarrow_host"] = {"ms": dt * 1e3, "rows_per_s": n / dt, "threads": os.cpu_count()}
     co = pacsv.ConvertOptions(column_types=li.schema)
     dt = best_of(lambda: pacsv.read_csv(io.BytesIO(text), read_options=pacsv.ReadOptions(column_names=li.schema.names),
                                         parse_options=pacsv.ParseOptions(delimiter="|", quote_char=False), convert_options=co))

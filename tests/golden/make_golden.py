@@ -5,6 +5,7 @@
   shuffle_data.arrow    <- ballista/core/tests/data.arrow                   (561-row Utf8 shuffle file, Arrow IPC stream with LZ4_FRAME
                                                                              buffers; read 1000 x by async_reader/mod.rs:331-357)
   alltypes_plain.parquet <- ballista/client/testdata/alltypes_plain.parquet (the file itself: input of the device Parquet decoder)
+  single_nan.parquet     <- ballista/client/testdata/single_nan.parquet     (one optional DOUBLE, SNAPPY pages: the Snappy unpack path)
   aggregate_test_100.csv <- examples/testdata/aggregate_test_100.csv        (100 rows x 13 columns; input of the device CSV parser)
 Only data is copied -- no reference source text."""
 import os
@@ -27,5 +28,6 @@ for table in sorted(os.listdir(base)):
         shutil.copyfile(os.path.join(base, table, fn), os.path.join(HERE, "tpch10", dst))
 shutil.copyfile(os.path.join(REF, "ballista/core/tests/data.arrow"), os.path.join(HERE, "shuffle_data.arrow"))
 shutil.copyfile(os.path.join(REF, "ballista/client/testdata/alltypes_plain.parquet"), os.path.join(HERE, "alltypes_plain.parquet"))
+shutil.copyfile(os.path.join(REF, "ballista/client/testdata/single_nan.parquet"), os.path.join(HERE, "single_nan.parquet"))
 shutil.copyfile(os.path.join(REF, "examples/testdata/aggregate_test_100.csv"), os.path.join(HERE, "aggregate_test_100.csv"))
 print(sorted(os.listdir(os.path.join(HERE, "tpch10"))))

@@ -112,6 +112,37 @@ def test_native_hash_join_types(tc, jt):
         assert norm(got) == norm(dev_rows(tc, plan.execute(0, tc)))
 
 
+@pytest.mark.parametrize("jt", ["Inner", "Left", "Full", "LeftAnti"])
+def test_native_collect_left_gathers_every_build_partition(tc, jt):
+    """CollectLeft with a build side of several partitions (each with its own fused filter): the native executor collects them
+    all into one build table, as DataFusion's collect_left_input does; every probe partition's task sees the whole build side.
+    Checked against the oracle's join of the concatenated build partitions, by row ids."""
+    lparts, lid0 = [], 0
+    for i in range(3):
+        t = rand_table(31 + i, 1500 + 300 * i, 0.2)
+        lparts.append(t.append_column("lid", pa.array(np.arange(lid0, lid0 + t.num_rows, dtype=np.int64)))); lid0 += t.num_rows
+    rparts = []
+    for i in range(2):
+        t = rand_table(41 + i, 4000, 0.2).append_column("rid", pa.array(np.arange(4000, dtype=np.int64)))
+        rparts.append(t.rename_columns([c if c == "rid" else "r_" + c for c in t.schema.names]))
+    L, R = g.MemoryExec(lparts), g.MemoryExec(rparts)
+    ls, rs = L.schema(), R.schema()
+    lpred = is_not_null(col("d", ls))
+    on = [(col("k64", ls), col("r_k64", rs))]
+    plan = g.HashJoinExec(g.FilterExec(lpred, L), R, on, None, jt, "CollectLeft", False)
+    js = plan.schema()
+    proj = g.ProjectionExec([(col("lid", js), "lid")] + ([] if jt == "LeftAnti" else [(col("rid", js), "rid")]), plan)
+    lo = O.Table.from_arrow(pa.concat_tables(lparts))
+    native = g.NativePlan(proj, tc)
+    for q in range(2):
+        got = sorted(tuple(-1 if v is None else v for v in r) for r in arrow_rows(native.execute(q).to_arrow()))
+        ro = O.Table.from_arrow(rparts[q])
+        pairs = O.hash_join(lo, ro, on, jt, left_pred=lpred)
+        lid, rid = lo.col("lid"), ro.col("rid")
+        exp = sorted((-1 if i is None else lid[i],) if jt == "LeftAnti" else (-1 if i is None else lid[i], -1 if j is None else rid[j]) for i, j in pairs)
+        assert got == exp and len(exp) > 0
+
+
 def test_native_sort_fetch_and_limit(tc):
     t = rand_table(77, 50_000, 0.1)
     ot = O.Table.from_arrow(t)

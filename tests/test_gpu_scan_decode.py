@@ -206,7 +206,8 @@ def parquet_table(n, seed):
 
 def write(t, **kw):
     buf = io.BytesIO()
-    pq.write_table(t, buf, compression="NONE", **kw)
+    kw.setdefault("compression", "NONE")
+    pq.write_table(t, buf, **kw)
     return buf.getvalue()
 
 
@@ -217,7 +218,9 @@ def write(t, **kw):
     dict(use_dictionary=True, data_page_version="2.0", data_page_size=4096),
     dict(use_dictionary=False, data_page_version="2.0", data_page_size=4096, row_group_size=9000),
     dict(use_dictionary=["lowcard", "s", "ns"], data_page_version="1.0", data_page_size=2048, row_group_size=20_000, dictionary_pagesize_limit=64),
-], ids=["dict-v1", "plain-v1", "dict-v2-smallpages", "plain-v2-rowgroups", "mixed-dict-fallback"])
+    dict(use_dictionary=True, data_page_version="1.0", compression="SNAPPY", data_page_size=16384),
+    dict(use_dictionary=["lowcard", "s"], data_page_version="2.0", compression="SNAPPY", data_page_size=4096, row_group_size=25_000),
+], ids=["dict-v1", "plain-v1", "dict-v2-smallpages", "plain-v2-rowgroups", "mixed-dict-fallback", "snappy-v1", "snappy-v2"])
 def test_pyarrow_written_files(tc, n, opts):
     """Required and optional columns of every decoded type; dictionary and PLAIN pages, v1 and v2 headers, many small pages, several
     row groups, a dictionary that overflows and falls back to PLAIN mid-chunk; decimals as FIXED_LEN_BYTE_ARRAY (15,2) and (38,2)."""
@@ -225,6 +228,25 @@ def test_pyarrow_written_files(tc, n, opts):
     data = write(t, **opts)
     got = scan.read_parquet(tc, data).to_arrow(tc.ctx)
     same(got, pq.read_table(io.BytesIO(data)))
+
+
+def test_reference_single_nan_parquet_snappy(tc):
+    """ballista/client/testdata/single_nan.parquet: one optional DOUBLE column, SNAPPY-compressed dictionary + data page."""
+    path = os.path.join(GOLD, "single_nan.parquet")
+    same(scan.read_parquet(tc, path).to_arrow(tc.ctx), pq.read_table(path))
+
+
+def test_snappy_streams_with_long_literals_and_overlapping_copies(tc):
+    """Snappy's element kinds: highly repetitive columns (copies whose offset is shorter than their length), incompressible ones
+    (literals with 2- and 3-byte length fields), and pages far beyond 64 KiB (2- and 4-byte offset copies)."""
+    n = 300_000
+    r = np.random.default_rng(4)
+    t = pa.table({"same": pa.array(np.full(n, 123456789, np.int64)), "ramp": pa.array(np.arange(n, dtype=np.int64) % 7),
+                  "noise": pa.array(r.integers(-2**62, 2**62, n)), "txt": pa.array(["abcabcabc-%d" % (j % 13) for j in range(n)]),
+                  "opt": pa.array(r.integers(0, 3, n), type=pa.int32(), mask=r.random(n) < 0.5)})
+    for opts in (dict(use_dictionary=False, data_page_size=1 << 20), dict(use_dictionary=False, data_page_size=1 << 14, data_page_version="2.0")):
+        data = write(t, compression="SNAPPY", **opts)
+        same(scan.read_parquet(tc, data).to_arrow(tc.ctx), pq.read_table(io.BytesIO(data)))
 
 
 def test_decimals_stored_as_integers_and_projection_order(tc):
@@ -246,6 +268,12 @@ def test_compressed_chunks_and_garbage_are_refused(tc):
     with pytest.raises(g.GpuqError) as e:
         scan.read_parquet(tc, buf.getvalue())
     assert e.value.status == 3 and "compressed" in str(e.value)
+    # a corrupted Snappy stream is flagged by the unpack kernel, not decoded into garbage
+    snap = bytearray(write(t.select(["k"]), compression="SNAPPY", use_dictionary=False))
+    for k in range(40, 120):
+        snap[k] = 0xFF
+    with pytest.raises(g.GpuqError):
+        scan.read_parquet(tc, bytes(snap))
     with pytest.raises(g.GpuqError):
         scan.read_parquet(tc, b"PAR1" + b"\x00" * 64 + b"PAR1")
     with pytest.raises(g.GpuqError) as e:
