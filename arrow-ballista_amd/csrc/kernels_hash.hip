@@ -1044,7 +1044,38 @@ __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, con
   uint32_t cnt = 0;
   for (i64 wb = w0; wb < w1; wb += U) {
     bool act[U]; u64 key[U]; u64 hs[U]; bool isn[U]; uint32_t prow[U];
-    // stage 1: evaluate U rows (column loads of all U rows are independent -> in flight together)
+    // stage 1: evaluate U rows.  The generated evaluator is used in its three stages (expr_compile.cpp: pre / load / compute) so that
+    // EVERY column load of all U rows is issued before any loaded value is looked at: calling the one-shot evaluator per row puts
+    // each row's loads behind the previous row's predicate (vmcnt is in order), i.e. 2 U dependent memory round trips per step
+    // instead of 2.  Rows beyond the end are clamped to the last row and masked afterwards (no exec-masked load regions).
+#ifndef GPUQ_PROBE_STAGED
+#define GPUQ_PROBE_STAGED 1
+#endif
+#if GPUQ_PROBE_STAGED
+    {
+      JitPre jq[U]; JitRaw jw[U]; i64 posc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const i64 pos = ((wb + u) << 6) + hlane();
+        act[u] = (wb + u) < w1 && pos < n;
+        posc[u] = act[u] ? pos : (n > 0 ? n - 1 : 0);
+        prow[u] = (uint32_t)pos;
+        gpuq_jit_pre(P, posc[u], jq[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) gpuq_jit_load(P, posc[u], jq[u], jw[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        GPUQ_REGS_DECL;
+        const bool pass = gpuq_jit_compute(P, posc[u], jw[u], GPUQ_REGS);
+        act[u] = act[u] && pass;
+        isn[u] = pass && ((rnulls >> JIT_KEY_REG0) & 1);
+        key[u] = (pass && !isn[u]) ? rlo[JIT_KEY_REG0] : 0;
+        hs[u] = 0;
+        if (act[u] && payload_via > 0) prow[u] = P.via[payload_via - 1][posc[u]];
+      }
+    }
+#else
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const i64 pos = ((wb + u) << 6) + hlane();
@@ -1058,6 +1089,7 @@ __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, con
         if (payload_via > 0) prow[u] = P.via[payload_via - 1][pos];
       }
     }
+#endif
     uint32_t hit[U];
     if (dense) {
       // direct addressing: one load per row, all U in flight; neighbouring lanes with equal or adjacent keys share cache lines
