@@ -801,22 +801,62 @@ extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevPro
 // ------------------------------------------------------------------ join build
 // Key range of the rows the build would insert (single narrow key): decides between the direct-addressed table and
 // open addressing.  out = {min, max, count}, pre-set by the host to {INT64_MAX, INT64_MIN, 0}.
-template <int MAXC>
-__device__ __forceinline__ void k_join_keyrange_body(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out) {
-  __shared__ i64 smn[HWAVES], smx[HWAVES]; __shared__ u64 scn[HWAVES];
-  i64 mn = 0x7FFFFFFFFFFFFFFFll, mx = (i64)0x8000000000000000ull; u64 cn = 0;
+// Rows-in-flight driver for the one-row-per-lane kernels (key range, build): a wave takes ROWS_U of its 64-row words per step.  With
+// the generated evaluator its three stages are used so that every column load of all ROWS_U words is issued before any loaded
+// value is looked at (one memory round trip per step instead of one per word: vmcnt is in order, and the one-shot evaluator waits
+// for its record before the next word's loads can be issued); with the interpreter the words are simply taken one after the other.
+// body(w, pos, active, regs...) runs wave-uniformly once per word (active = row exists and passes the fused predicate).
+#ifndef GPUQ_ROWS_U
+#define GPUQ_ROWS_U 2
+#endif
+template <int MAXC, class Body>
+__device__ __forceinline__ void for_rows_in_flight(const DevProgram& P, const i64 n, const i64 w_first, const i64 w_stride, Body body) {
   const i64 nwords = (n + 63) >> 6;
-  const int kr = __builtin_amdgcn_readfirstlane(K.key_reg[0]);
-  for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
+#ifdef GPUQ_JIT
+  constexpr int U = GPUQ_ROWS_U;
+  for (i64 w0 = w_first; w0 < nwords; w0 += w_stride * U) {
+    JitPre jq[U]; JitRaw jw[U]; i64 posc[U]; bool ex[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const i64 w = w0 + (i64)u * w_stride;
+      const i64 pos = (w << 6) + hlane();
+      ex[u] = w < nwords && pos < n;
+      posc[u] = ex[u] ? pos : n - 1;      // clamped, masked afterwards: no exec-masked load regions (n > 0 here: nwords > 0)
+      gpuq_jit_pre(P, posc[u], jq[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) gpuq_jit_load(P, posc[u], jq[u], jw[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const i64 w = w0 + (i64)u * w_stride;
+      if (w >= nwords) break;             // wave-uniform
+      GPUQ_REGS_DECL;
+      const bool pass = gpuq_jit_compute(P, posc[u], jw[u], GPUQ_REGS);
+      body(w, (w << 6) + hlane(), ex[u] && pass, GPUQ_REGS);
+    }
+  }
+#else
+  for (i64 w = w_first; w < nwords; w += w_stride) {
     const i64 pos = (w << 6) + hlane();
     bool active = pos < n;
     GPUQ_REGS_DECL;
     if (active) active = GPUQ_EVAL(MAXC, P, pos);
+    body(w, pos, active, GPUQ_REGS);
+  }
+#endif
+}
+
+template <int MAXC>
+__device__ __forceinline__ void k_join_keyrange_body(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out) {
+  __shared__ i64 smn[HWAVES], smx[HWAVES]; __shared__ u64 scn[HWAVES];
+  i64 mn = 0x7FFFFFFFFFFFFFFFll, mx = (i64)0x8000000000000000ull; u64 cn = 0;
+  const int kr = __builtin_amdgcn_readfirstlane(K.key_reg[0]);
+  for_rows_in_flight<MAXC>(P, n, (i64)blockIdx.x * HWAVES + hwave(), (i64)gridDim.x * HWAVES, [&](const i64, const i64, const bool active, GPUQ_REGS_PARAM) {
     if (active && !((rnulls >> kr) & 1)) {
       const i64 v = (i64)rlo[kr];
       mn = v < mn ? v : mn; mx = v > mx ? v : mx; ++cn;
     }
-  }
+  });
   (void)null_eq;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -841,29 +881,24 @@ template <int MAXC>
 __device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
                                                        uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
                                                        const int null_eq) {
-  const i64 nwords = (n + 63) >> 6;
-  for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
-    const i64 pos = (w << 6) + hlane();
-    bool active = pos < n;
-    GPUQ_REGS_DECL;
-    if (active) active = GPUQ_EVAL(MAXC, P, pos);
+  for_rows_in_flight<MAXC>(P, n, (i64)blockIdx.x * HWAVES + hwave(), (i64)gridDim.x * HWAVES, [&](const i64 w, const i64 pos, const bool active, GPUQ_REGS_PARAM) {
     // `present` = every build-side row that passes the side's predicate, NULL keys included (outer joins emit them).  When rows
     // are positions, the 64 rows of this step ARE word w of the bitmap: one plain 8-byte store (64 lanes OR-ing into two words
     // serialise in the L2's atomic unit -- it was most of the build's time: 1.4 ms for 14.6 M rows)
     if (present && payload_via == 0) { const u64 am = __ballot(active); if (hlane() == 0) ((u64*)present)[w] = am; }
-    if (!active) continue;
+    if (!active) return;
     u64 kw[MAX_KW]; u64 h;
 #pragma unroll
     for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
     const bool any_null = make_key(K, GPUQ_REGS, kw, h);
     uint32_t row = (uint32_t)pos;
     if (payload_via > 0) { row = P.via[payload_via - 1][pos]; if (present) atomicOr(&present[row >> 5], 1u << (row & 31)); }
-    if (any_null && !null_eq) continue;   // a NULL key never matches (SQL equi-join)
+    if (any_null && !null_eq) return;   // a NULL key never matches (SQL equi-join)
     bool inserted; uint32_t old = NIL;
     if (T.dense) {
       // direct addressing: the table word is the chain head; an exchange both claims the key and links a duplicate
       const u64 idx = kw[0] - (u64)T.dense_min;
-      if (idx >= T.dense_range) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }      // cannot happen: the range was measured on these rows
+      if (idx >= T.dense_range) { atomicOr(P.flags, FLAG_TABLE_FULL); return; }      // cannot happen: the range was measured on these rows
       if (T.dense_bits) {
         // presence bitmap + uninitialised row array: valid for unique keys only; a duplicate raises the flag and the host rebuilds
         // with the initialised array (chains need a defined head)
@@ -877,7 +912,7 @@ __device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 
       }
     } else {
       const u64 s = ht_find_or_insert(T, kw, h, row, inserted);
-      if (s == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); continue; }
+      if (s == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); return; }
       if (!inserted && next) {
         uint32_t* head = (uint32_t*)(T.slots + s * (u64)T.slot_words) + 1;   // high half of word 0
         old = __hip_atomic_exchange(head, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -890,7 +925,7 @@ __device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 
       if (!(__hip_atomic_load(P.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_DUP_BUILD_KEY)) atomicOr(P.flags, FLAG_DUP_BUILD_KEY);
       if (next) next[row] = old;
     }
-  }
+  });
 }
 #ifndef GPUQ_JIT
 template <int MAXC>
