@@ -1467,6 +1467,67 @@ int gpuq_mark_rows(gpuq_ctx* ctx, void* stream, const uint32_t* rows, int64_t n,
   });
 }
 
+// ---------------------------------------------------------------- Utf8 dictionary codes (keys longer than 15 bytes)
+struct gpuq_utf8_dict { gpuq_ctx* ctx; DevBuf table; u64 mask = 0; gpuq_column dict_col{}; bool filled = false; };
+
+int gpuq_utf8_max_len(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int32_t* max_len_out) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!col || !max_len_out) throw std::runtime_error("col / max_len_out is NULL");
+    if (col->type != T_UTF8 || col->repr != GPUQ_REPR_ARROW) throw Unsupported("gpuq_utf8_max_len needs a Utf8 column in Arrow layout");
+    *max_len_out = 0;
+    if (n <= 0) return;
+    hipStream_t s = use_stream(stream);
+    DevBuf out; out.ensure(16); HIPCHECK(hipMemsetAsync(out.p, 0, 16, s));
+    launch_utf8_max_len(s, col->offsets, col->validity, idx, n, (int32_t*)out.p);
+    HIPCHECK(hipMemcpyAsync(max_len_out, out.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+  });
+}
+int gpuq_utf8_dict_create(gpuq_ctx* ctx, void* stream, int64_t capacity_rows, gpuq_utf8_dict** out) {
+  if (out) *out = nullptr;
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!out || capacity_rows < 0) throw std::runtime_error("out is NULL / negative capacity");
+    std::unique_ptr<gpuq_utf8_dict> d(new gpuq_utf8_dict()); d->ctx = ctx;
+    u64 slots = 1024; while (slots < (u64)capacity_rows * 2) slots <<= 1;
+    d->mask = slots - 1;
+    d->table.ensure((size_t)slots * 8);
+    HIPCHECK(hipMemsetAsync(d->table.p, 0, (size_t)slots * 8, use_stream(stream)));
+    *out = d.release();
+  });
+}
+void gpuq_utf8_dict_free(gpuq_utf8_dict* d) { delete d; }
+int gpuq_utf8_code_rows(gpuq_ctx* ctx, void* stream, const gpuq_column* codes, int64_t n, uint32_t* rows_out) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!codes || (n > 0 && !rows_out)) throw std::runtime_error("codes / rows_out is NULL");
+    if (codes->type != T_INT64) throw std::runtime_error("gpuq_utf8_code_rows: the code column is Int64");
+    launch_utf8_code_rows(use_stream(stream), (const i64*)codes->data, codes->validity, n, rows_out);
+    HIPCHECK(hipGetLastError());
+  });
+}
+int gpuq_utf8_intern(gpuq_utf8_dict* d, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int insert, int64_t* codes_out, uint8_t* validity_out) {
+  if (!d) return GPUQ_ERR_INVALID;
+  return guarded(d->ctx, [&]() {
+    check_ctx(d->ctx);
+    if (!col || (n > 0 && (!codes_out || !validity_out))) throw std::runtime_error("col / codes_out / validity_out is NULL");
+    if (col->type != T_UTF8 || col->repr != GPUQ_REPR_ARROW || (col->length > 0 && !col->offsets)) throw Unsupported("gpuq_utf8_intern needs a Utf8 column in Arrow layout (offsets + bytes)");
+    if (insert) {
+      if (d->filled && (d->dict_col.data != col->data || d->dict_col.offsets != col->offsets)) throw std::runtime_error("a dictionary is filled from ONE column (its codes are that column's row ids)");
+      if ((u64)std::min<int64_t>(n, col->length) * 2 > d->mask + 1) throw Capacity("dictionary created for fewer rows than are inserted");
+      d->dict_col = *col; d->filled = true;
+    } else if (!d->filled) throw std::runtime_error("lookup in a dictionary nothing was inserted into");
+    if (n <= 0) return;
+    hipStream_t s = use_stream(stream);
+    DevBuf flags; flags.ensure(16); HIPCHECK(hipMemsetAsync(flags.p, 0, 16, s));
+    launch_utf8_intern(s, (const uint8_t*)d->dict_col.data, d->dict_col.offsets, (const uint8_t*)col->data, col->offsets, col->validity, idx, n,
+                       (u64*)d->table.p, d->mask, insert ? 1 : 0, (i64*)codes_out, (u64*)validity_out, (uint32_t*)flags.p);
+    uint32_t fl = 0; HIPCHECK(hipMemcpyAsync(&fl, flags.p, 4, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s));
+    if (fl) throw Capacity("string dictionary is full");
+  });
+}
+
 // ---------------------------------------------------------------- LIKE
 int gpuq_like_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, const char* pattern, int negated, int case_insensitive,
                    uint8_t* bits_out, uint8_t* validity_out) {

@@ -1102,6 +1102,90 @@ void launch_like_utf8(hipStream_t s, const uint8_t* data, const int32_t* offsets
                       u64* bits_out, u64* valid_out) {
   if (n > 0) hipLaunchKernelGGL(k_like_utf8, dim3(lin_grid(n)), dim3(BLOCK), 0, s, data, offsets, validity, idx, n, pat, negated, bits_out, valid_out);
 }
+// ------------------------------------------------------------------ Utf8 values as exact dictionary codes (f-4: keys longer than 15 bytes)
+// Strings of any length become group / join keys through a device dictionary: an open-addressing table of 8-byte entries
+// (hash tag << 32 | representative row of the dictionary column).  One 64-bit CAS both claims an entry and publishes its row, the
+// bytes it stands for live in the (immutable) dictionary column, so there is nothing to lock or fence.  An entry whose tag matches is
+// verified byte for byte; a different string with the same tag just moves on along the probe sequence: codes are EXACT.
+// code = the representative's row in the dictionary column (equal strings -> equal codes; the string comes back with a take).
+__device__ __forceinline__ u64 utf8_hash(const uint8_t* __restrict__ p, int32_t len) {
+  u64 h = 0xCBF29CE484222325ull ^ (u64)(uint32_t)len;
+  int32_t i = 0;
+  for (; i + 8 <= len; i += 8) { u64 w; __builtin_memcpy(&w, p + i, 8); h = (h ^ w) * 0x100000001B3ull; h ^= h >> 29; }
+  u64 tail = 0; for (int k = 0; i + k < len; ++k) tail |= (u64)p[i + k] << (8 * k);
+  h = (h ^ tail) * 0x100000001B3ull;
+  h ^= h >> 32; h *= 0x9FB21C651E98DF25ull; h ^= h >> 29;
+  return h;
+}
+__global__ void __launch_bounds__(BLOCK) k_utf8_max_len(const int32_t* __restrict__ offsets, const uint8_t* __restrict__ validity, const uint32_t* __restrict__ idx, const i64 n,
+                                                        int32_t* __restrict__ out) {
+  int32_t m = 0;
+  for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    const uint32_t r = idx ? idx[i] : (uint32_t)i;
+    if (r == 0xFFFFFFFFu) continue;
+    if (validity && !((validity[r >> 3] >> (r & 7)) & 1)) continue;
+    const int32_t len = offsets[r + 1] - offsets[r];
+    m = len > m ? len : m;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const int32_t y = __shfl_xor(m, o); m = y > m ? y : m; }
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+// codes[i] = dictionary code of row i (through idx), valid bit i = the row has a code (not NULL; for lookups: the string is in the dictionary)
+__global__ void __launch_bounds__(BLOCK) k_utf8_intern(const uint8_t* __restrict__ ddata, const int32_t* __restrict__ doffs,
+                                                       const uint8_t* __restrict__ data, const int32_t* __restrict__ offsets, const uint8_t* __restrict__ validity,
+                                                       const uint32_t* __restrict__ idx, const i64 n, u64* __restrict__ table, const u64 mask, const int insert,
+                                                       i64* __restrict__ codes, u64* __restrict__ valid_out, uint32_t* __restrict__ flags) {
+  for (i64 i0 = (i64)blockIdx.x * BLOCK + (threadIdx.x & ~63); i0 < n; i0 += (i64)gridDim.x * BLOCK) {
+    const i64 i = i0 + (threadIdx.x & 63);
+    bool has = false; i64 code = 0;
+    if (i < n) {
+      const uint32_t r = idx ? idx[i] : (uint32_t)i;
+      const bool isnull = r == 0xFFFFFFFFu || (validity && !((validity[r >> 3] >> (r & 7)) & 1));
+      if (!isnull) {
+        const int32_t o = offsets[r], len = offsets[r + 1] - o;
+        const uint8_t* p = data + o;
+        const u64 h = utf8_hash(p, len);
+        const u64 tag = (h >> 32) | 1ull;
+        u64 slot = h & mask;
+        for (u64 probes = 0; probes <= mask; ++probes, slot = (slot + 1) & mask) {
+          u64 e = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (e == 0) {
+            if (!insert) break;                                     // not in the dictionary
+            const u64 mine = (tag << 32) | (u64)r;
+            u64 expected = 0;
+            if (__hip_atomic_compare_exchange_strong(&table[slot], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { has = true; code = (i64)r; break; }
+            e = expected;                                           // somebody else took the entry: it may be this very string
+          }
+          if ((e >> 32) != tag) continue;
+          const uint32_t rep = (uint32_t)e;
+          const int32_t ro = doffs[rep], rlen = doffs[rep + 1] - ro;
+          bool same = rlen == len;
+          if (same) { const uint8_t* q = ddata + ro; for (int32_t k = 0; k < len; ++k) if (p[k] != q[k]) { same = false; break; } }
+          if (same) { has = true; code = (i64)rep; break; }
+        }
+        if (insert && !has) atomicOr(flags, 1u);                    // table full (cannot happen: it is sized for every row)
+      }
+      codes[i] = code;
+    }
+    const u64 m = __ballot(has);
+    if ((threadIdx.x & 63) == 0 && valid_out) valid_out[i0 >> 6] = m;
+  }
+}
+// codes (Int64 + validity) -> row ids for a take: NULL -> 0xFFFFFFFF
+__global__ void __launch_bounds__(BLOCK) k_utf8_code_rows(const i64* __restrict__ codes, const uint8_t* __restrict__ validity, const i64 n, uint32_t* __restrict__ rows) {
+  for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK)
+    rows[i] = (validity && !((validity[i >> 3] >> (i & 7)) & 1)) ? 0xFFFFFFFFu : (uint32_t)codes[i];
+}
+void launch_utf8_code_rows(hipStream_t s, const i64* codes, const uint8_t* validity, i64 n, uint32_t* rows) {
+  if (n > 0) hipLaunchKernelGGL(k_utf8_code_rows, dim3(lin_grid(n)), dim3(BLOCK), 0, s, codes, validity, n, rows);
+}
+void launch_utf8_max_len(hipStream_t s, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int32_t* out) {
+  if (n > 0) hipLaunchKernelGGL(k_utf8_max_len, dim3(lin_grid(n)), dim3(BLOCK), 0, s, offsets, validity, idx, n, out);
+}
+void launch_utf8_intern(hipStream_t s, const uint8_t* ddata, const int32_t* doffs, const uint8_t* data, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n,
+                        u64* table, u64 mask, int insert, i64* codes, u64* valid_out, uint32_t* flags) {
+  if (n > 0) hipLaunchKernelGGL(k_utf8_intern, dim3(lin_grid(n)), dim3(BLOCK), 0, s, ddata, doffs, data, offsets, validity, idx, n, table, mask, insert, codes, valid_out, flags);
+}
 // bitmap[rows[i]] = 1 for every i (0xFFFFFFFF skipped): which rows of a join side survive in the filtered pair list
 __global__ void __launch_bounds__(BLOCK) k_mark_rows(const uint32_t* __restrict__ rows, const i64 n, unsigned int* __restrict__ bitmap) {
   for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {

@@ -268,6 +268,38 @@ PTable lower_like(Exec& x, const PTable& t, std::vector<Json>& exprs) {
   return out;
 }
 
+// ---------------------------------------------------------------- Utf8 keys longer than 15 bytes
+// The expression programs carry a string as one 16-byte integer (<= 15 bytes).  When an aggregate or a join reports that a longer
+// value reached a key, the executor runs the operator again over exact dictionary codes (gpuq_utf8_intern): a group / join key
+// that is a plain Utf8 column in Arrow layout is replaced by an Int64 code column appended to (a copy of) the table; strings come
+// back with a take through the codes.  Nothing is paid on the common path: the rewrite only happens after the loud failure.
+bool is_long_string_failure(const std::exception& e) { return std::string(e.what()).find("longer than 15 bytes reached") != std::string::npos; }
+// index of the column `e` names when `e` is a bare column reference to an Arrow-layout Utf8 column of `t`, else -1
+int long_key_column(const PTable& t, const Json& e) {
+  if (!(e.is_obj() && e.o.size() == 1 && e.o[0].first == "column" && e.o[0].second.is_obj() && e.o[0].second.find("name"))) return -1;
+  const std::string& n = e.o[0].second.at("name").str();
+  for (size_t i = 0; i < t.cols.size(); ++i)
+    if (t.cols[i].name == n) return (t.cols[i].c.type == T_UTF8 && t.cols[i].c.repr == GPUQ_REPR_ARROW) ? (int)i : -1;
+  return -1;
+}
+struct Utf8DictGuard { gpuq_utf8_dict* d = nullptr; ~Utf8DictGuard() { if (d) gpuq_utf8_dict_free(d); } };
+// appends the code column of t.cols[ci] (insert: fills `dict` from it; else looks it up in `dict`) under `name`
+void append_code_column(Exec& x, PTable& t, int ci, gpuq_utf8_dict* dict, bool insert, const std::string& name) {
+  const PCol& c = t.cols[(size_t)ci]; const int sd = t.sides[(size_t)ci];
+  const size_t nb = (size_t)((t.n + 63) / 64) * 8 + 8;
+  BufP codes = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 8 + 16), valid = dev_alloc(nb);
+  HIPCHECK(hipMemsetAsync(valid->p, 0, nb, (hipStream_t)x.stream));
+  const int rc = gpuq_utf8_intern(dict, x.stream, &c.c, sd > 0 ? t.via[(size_t)sd - 1] : nullptr, t.n, insert ? 1 : 0, (int64_t*)codes->p, (uint8_t*)valid->p);
+  check(x, rc);
+  PCol k; k.name = name; k.type = jstr("Int64"); k.nullable = true;
+  k.c.type = T_INT64; k.c.repr = GPUQ_REPR_ARROW; k.c.data = codes->p; k.c.validity = (const uint8_t*)valid->p; k.c.length = t.n;
+  t.cols.push_back(k); t.sides.push_back(0); t.keep.push_back(codes); t.keep.push_back(valid); t.record_cap = 0;
+}
+void strip_code_columns(PTable& t) {
+  for (size_t i = t.cols.size(); i-- > 0;)
+    if (t.cols[i].name.rfind("__code_", 0) == 0) { t.cols.erase(t.cols.begin() + (long)i); t.sides.erase(t.sides.begin() + (long)i); t.record_cap = 0; }
+}
+
 PTable project(Exec& x, const PTable& t_in, const std::vector<Json>& exprs_in, const std::vector<std::string>& names, const void* site, int tag) {
   std::vector<Json> exprs = exprs_in;
   const PTable t = lower_like(x, t_in, exprs);
@@ -588,6 +620,23 @@ PTable ProjectionExec::execute(int part, Exec& x) {
   if (f.has_pred) t = filter_table(x, t, f.pred, this, 0);
   std::vector<Json> ex;
   for (auto& e : exprs) ex.push_back(inline_projection(e, f.has_map ? &f.map : nullptr));
+  // a projection that only selects / renames columns is a view of its input: no kernel, and strings of any length pass through
+  // (the project kernel writes Utf8 results as 16-byte PACKED15 values)
+  std::vector<int> pick;
+  for (auto& e : ex) {
+    int ci = -1;
+    if (e.is_obj() && e.o.size() == 1 && e.o[0].first == "column" && e.o[0].second.is_obj() && e.o[0].second.find("name")) {
+      const std::string& n = e.o[0].second.at("name").str();
+      for (size_t i = 0; i < t.cols.size(); ++i) if (t.cols[i].name == n) { ci = (int)i; break; }
+    }
+    if (ci < 0) { pick.clear(); break; }
+    pick.push_back(ci);
+  }
+  if (!pick.empty() && pick.size() == ex.size()) {
+    PTable out; out.n = t.n; out.via = t.via; out.dense = t.dense; out.keep = t.keep;
+    for (size_t i = 0; i < pick.size(); ++i) { PCol c = t.cols[(size_t)pick[i]]; c.name = names[i]; out.cols.push_back(c); out.sides.push_back(t.sides[(size_t)pick[i]]); }
+    return timed(t0, out);
+  }
   return timed(t0, project(x, t, ex, names, this, 1));
 }
 
@@ -618,11 +667,31 @@ struct AggregateExec : PNode {
     Fused f; if (final_) f.src = input.get(); else f = fuse(input.get());
     PTable t = f.src->execute(part, x);
     auto t0 = std::chrono::steady_clock::now();
-    gpuq_op* op = cached_op(x, this, 0, table_sig(t), [&]() {
+    try { return timed(t0, run(x, t, f, false)); }
+    catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+    return timed(t0, run(x, t, f, true));      // a group key holds strings of more than 15 bytes: again, over dictionary codes
+  }
+  PTable run(Exec& x, PTable t, const Fused& f, const bool long_keys) {
+    const ColMap* cm0 = f.has_map ? &f.map : nullptr;
+    // group expressions over the source table; with long_keys every plain Arrow-layout Utf8 key column is replaced by its codes
+    std::vector<Json> gexprs; std::vector<int> coded;      // coded[k] = column of `t` key k's strings come from, or -1
+    Utf8DictGuard dicts[8]; int nd = 0;
+    const PTable t_src = t;
+    for (auto& g : group_expr.a) {
+      Json e = inline_projection(g.at("expr"), cm0); int ci = -1;
+      if (long_keys && (ci = long_key_column(t_src, e)) >= 0 && nd < 8) {
+        const std::string nm = "__code_" + std::to_string(gexprs.size());
+        check(x, gpuq_utf8_dict_create(x.ctx, x.stream, std::min<int64_t>(t_src.n, t_src.cols[(size_t)ci].c.length), &dicts[nd].d));
+        append_code_column(x, t, ci, dicts[nd].d, true, nm); ++nd;
+        e = jobj({{"column", jobj({{"name", jstr(nm)}})}});
+      } else ci = -1;
+      gexprs.push_back(e); coded.push_back(ci);
+    }
+    gpuq_op* op = cached_op(x, this, long_keys ? 6 : 0, table_sig(t), [&]() {
     const auto nm = names_of(t);
     const ColMap* cm = f.has_map ? &f.map : nullptr;
     Json ge = jarr(), ae = jarr();
-    for (auto& g : group_expr.a) ge.a.push_back(jobj({{"expr", rebind(inline_projection(g.at("expr"), cm), nm)}, {"name", g.at("name")}}));
+    for (size_t k = 0; k < group_expr.a.size(); ++k) ge.a.push_back(jobj({{"expr", rebind(gexprs[k], nm)}, {"name", group_expr.a[k].at("name")}}));
     for (auto& a : aggr_expr.a) {
       std::vector<std::pair<std::string, Json>> o = {{"fn", a.at("fn")}, {"name", a.at("name")}};
       for (const char* k : {"expr", "expr2"}) if (a.has(k)) o.push_back({k, rebind(inline_projection(a.at(k), cm), nm)});
@@ -645,7 +714,17 @@ struct AggregateExec : PNode {
       if (rc == GPUQ_ERR_CAPACITY && ng > cap) { cap = ng; continue; }
       check(x, rc);
       out.n = ng; for (auto& c : out.cols) c.c.length = ng;
-      return timed(t0, out);       // synchronous call: the input buffers are no longer referenced
+      // coded keys: the code IS the row of a representative string in the source column -- take the strings back
+      for (size_t k = 0; k < coded.size(); ++k) {
+        if (coded[k] < 0) continue;
+        BufP rows = dev_alloc((size_t)std::max<int64_t>(ng, 1) * 4 + 16);
+        check(x, gpuq_utf8_code_rows(x.ctx, x.stream, &out.cols[k].c, ng, (uint32_t*)rows->p));
+        const PCol& src = t_src.cols[(size_t)coded[k]];
+        PCol sc = take_utf8(x, src, (const uint32_t*)rows->p, ng, true, out.keep);
+        sc.name = out.cols[k].name; out.cols[k] = sc; out.record_cap = 0;
+        HIPCHECK(hipStreamSynchronize((hipStream_t)x.stream));      // `rows` dies here
+      }
+      return out;       // synchronous call: the input buffers are no longer referenced
     }
   }
 };
@@ -739,6 +818,15 @@ struct HashJoinExec : PNode {
     return join_view(x, lt, rt, a, b, k3, ob3, opb3);
   }
   PTable execute(int part, Exec& x) override {
+    try { return execute_impl(part, x, false); }
+    catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+    // a join key holds strings of more than 15 bytes: again, with those key columns replaced by exact dictionary codes (the
+    // build side fills the dictionary, the probe side is looked up in it; a probe string that is not in it gets no code = no match)
+    PTable out = execute_impl(part, x, true);
+    strip_code_columns(out);
+    return out;
+  }
+  PTable execute_impl(int part, Exec& x, const bool long_keys) {
     const bool residual = has_filter && join_type != "Inner";
     const std::string jt = residual ? std::string("Inner") : join_type;
     int lpart = partition_mode == "Partitioned" ? part : 0;
@@ -755,18 +843,33 @@ struct HashJoinExec : PNode {
       if (L.has_pred) { L.t = filter_table(x, L.t, L.pred, this, 3); L.has_pred = false; }
       if (R.has_pred) { R.t = filter_table(x, R.t, R.pred, this, 4); R.has_pred = false; }
     }
-    gpuq_op* bop = cached_op(x, this, 0, table_sig(L.t), [&]() {
+    Json on_eff = on;
+    Utf8DictGuard dicts[8]; int nd = 0;
+    if (long_keys) {
+      if (null_equals_null) throw Unsupported("null_equals_null with Utf8 join keys longer than 15 bytes");
+      for (size_t k = 0; k < on_eff.a.size() && nd < 8; ++k) {
+        const int li = long_key_column(L.t, on.a[k].at("left")), ri = long_key_column(R.t, on.a[k].at("right"));
+        if (li < 0 || ri < 0) continue;
+        const std::string nm = "__code_" + std::to_string(k);
+        check(x, gpuq_utf8_dict_create(x.ctx, x.stream, std::min<int64_t>(L.t.n, L.t.cols[(size_t)li].c.length), &dicts[nd].d));
+        append_code_column(x, L.t, li, dicts[nd].d, true, nm + "l");
+        append_code_column(x, R.t, ri, dicts[nd].d, false, nm + "r");
+        ++nd;
+        on_eff.a[k] = jobj({{"left", jobj({{"column", jobj({{"name", jstr(nm + "l")}})}})}, {"right", jobj({{"column", jobj({{"name", jstr(nm + "r")}})}})}});
+      }
+    }
+    gpuq_op* bop = cached_op(x, this, long_keys ? 7 : 0, table_sig(L.t), [&]() {
       const auto ln = names_of(L.t);
       Json lk = jarr();
-      for (auto& o : on.a) lk.a.push_back(rebind(o.at("left"), ln));
+      for (auto& o : on_eff.a) lk.a.push_back(rebind(o.at("left"), ln));
       std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(L.t)}})}, {"on", lk}, {"null_equals_null", jbool(null_equals_null)}};
       if (L.has_pred) bd.push_back({"predicate", rebind(L.pred, ln)});
       return jobj(bd);
     });
-    gpuq_op* pop = cached_op(x, this, 1, table_sig(R.t), [&]() {
+    gpuq_op* pop = cached_op(x, this, long_keys ? 8 : 1, table_sig(R.t), [&]() {
       const auto rn = names_of(R.t);
       Json rk = jarr();
-      for (auto& o : on.a) rk.a.push_back(rebind(o.at("right"), rn));
+      for (auto& o : on_eff.a) rk.a.push_back(rebind(o.at("right"), rn));
       std::vector<std::pair<std::string, Json>> pd = {{"op", jstr("join_probe")}, {"input", jobj({{"fields", table_fields(R.t)}})}, {"on", rk}, {"join_type", jstr(jt)},
                                                      {"null_equals_null", jbool(null_equals_null)}};
       if (R.has_pred) pd.push_back({"predicate", rebind(R.pred, rn)});

@@ -310,6 +310,23 @@ int gpuq_op_jit_source(gpuq_op* op, int kernel_id, char* buf, size_t cap);
 int gpuq_take_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int32_t* offsets_out, uint8_t* validity_out,
                    uint8_t* data_out, int64_t data_cap, int64_t* data_len_out);
 
+/* Utf8 values of ANY length as group-by / join keys (q10's c_name, q16's p_type): the expression
+   programs carry strings as 16-byte integers (<= 15 bytes); longer key columns are replaced by exact dictionary codes first.
+   gpuq_utf8_max_len: the longest value of an Arrow-layout Utf8 column (rows through `idx` when given) -- tells an executor
+   whether the rewrite is needed.  gpuq_utf8_dict_create(capacity_rows = rows that will be inserted) / gpuq_utf8_intern:
+   insert != 0 fills the dictionary from ONE column and returns every row's code = the row id (in that column) of the string's
+   representative; insert == 0 looks rows of ANOTHER column up (a join's probe side).  codes_out: int64[n];
+   validity_out: (n + 63) / 64 * 8 bytes, bit i = row i has a code (0: the value is NULL, or -- lookup -- not in the dictionary, which
+   an equi-join treats the same way).  Equal strings get equal codes, different strings different ones, whatever they hash to: a
+   tag match is verified byte for byte.  The string of a code comes back with gpuq_take_utf8(dictionary column, rows = codes). */
+typedef struct gpuq_utf8_dict gpuq_utf8_dict;
+int gpuq_utf8_max_len(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int32_t* max_len_out);
+int gpuq_utf8_dict_create(gpuq_ctx* ctx, void* stream, int64_t capacity_rows, gpuq_utf8_dict** out);
+int gpuq_utf8_intern(gpuq_utf8_dict* dict, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int insert, int64_t* codes_out, uint8_t* validity_out);
+void gpuq_utf8_dict_free(gpuq_utf8_dict* dict);
+/* an Int64 code column (with or without validity) -> the row ids a take wants (NULL -> 0xFFFFFFFF) */
+int gpuq_utf8_code_rows(gpuq_ctx* ctx, void* stream, const gpuq_column* codes, int64_t n, uint32_t* rows_out);
+
 /* LikeExpr (PhysicalLikeExprNode, datafusion.proto:1240-1245: negated, case_insensitive, expr, pattern) of a Utf8 column in Arrow
    layout against a literal pattern: '%' any run of characters, '_' one character, "\\%" / "\\_" the literal characters (arrow-string's
    `like` / `nlike` with a scalar pattern).  idx (optional) addresses the column through an index vector; 0xFFFFFFFF or a NULL
