@@ -101,3 +101,22 @@ def test_fk_join_finds_every_order_sf10(tc):
     # anti join of the same inputs is empty, semi join keeps everything
     for jt, exp in (("RightAnti", 0), ("RightSemi", N)):
         assert g.HashJoinExec(L, R, [(col("o_orderkey", ls), col("l_orderkey", rs))], None, jt, "CollectLeft", False).execute(0, tc).num_rows == exp
+
+
+def test_q3_sf10_equals_the_c_oracle_row_for_row(tc):
+    """BASELINE configs[2]'s query at SF10 (59,986,052 lineitem / 14,996,513 orders / 1,500,000 customer rows): at this size the C
+    oracle (OpenMP, oracle/oracle.c::oracle_q3) still finishes in well under a second on the box's host cores, so the whole
+    result -- every group's key, revenue, date and priority, and the ORDER BY -- is compared, not just properties."""
+    n_li, n_cust = N, 1_500_000
+    cols = ("l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate")
+    li = T.gen_lineitem_device(tc, n_li, columns=cols)
+    od = T.gen_orders_device(tc, (n_li + 3) // 4, n_cust)
+    cu = T.gen_customer_device(tc, n_cust)
+    res = g.NativePlan(T.q3_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li])), tc).execute(0).to_arrow()
+    exp, st = T.q3_oracle_c(T.gen_q3_tables_host(n_li, n_cust))
+    assert res.num_rows == len(exp) == st["groups"] and len(exp) > 100_000
+    got_key = np.asarray(res.column("l_orderkey")); got_date = np.asarray(res.column("o_orderdate").cast("int32")); got_pri = np.asarray(res.column("o_shippriority"))
+    got_rev = [int(v.scaleb(4)) for v in res.column("revenue").to_pylist()]
+    # ORDER BY revenue DESC, o_orderdate: the sort columns agree position by position; ties may permute, so rows are compared as sets
+    assert got_rev == [r[1] for r in exp] and got_date.tolist() == [r[2] for r in exp]
+    assert sorted(zip(got_key.tolist(), got_rev, got_date.tolist(), got_pri.tolist())) == sorted(exp)
