@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 2 step x: SQ counters of the single-read sort pass (where do its cycles go?)
+set -o pipefail
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+O=gpurun_out/r02x; mkdir -p $O
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc1 -- python3 bench_extras.py --sort 27 > $O/pmc1.log 2>&1 || { tail -20 $O/pmc1.log; exit 1; }
+python3 tools/pmc_summary.py $O/pmc1 "k_onesweep<false>"
+timeout -k 10 400 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $O/pmc2 -- python3 bench_extras.py --sort 27 > $O/pmc2.log 2>&1 || { tail -20 $O/pmc2.log; exit 1; }
+python3 tools/pmc_summary.py $O/pmc2 "k_onesweep<false>"
