@@ -226,6 +226,7 @@ enum CsvKind : int32_t { CSV_SKIP = 0, CSV_I32 = 1, CSV_I64 = 2, CSV_DATE32 = 3,
 constexpr int CSV_MAX_FIELDS = 64;
 struct CsvSpec {
   int32_t n_fields; int32_t kind[CSV_MAX_FIELDS]; int32_t out[CSV_MAX_FIELDS]; int32_t scale[CSV_MAX_FIELDS]; int32_t nullable[CSV_MAX_FIELDS];
+  int32_t prec[CSV_MAX_FIELDS];
   uint8_t delim, quote; uint8_t pad[2];
 };
 struct CsvOut { void* data[CSV_MAX_FIELDS]; u64* valid[CSV_MAX_FIELDS]; uint32_t* str_start[CSV_MAX_FIELDS]; int32_t* str_len[CSV_MAX_FIELDS]; };

@@ -120,8 +120,17 @@ __global__ void __launch_bounds__(FBLOCK) k_csv_parse(const uint8_t* __restrict_
               i64 v = 0; bool neg = false; i64 k = p;
               if (k < q && (text[k] == '-' || text[k] == '+')) { neg = text[k] == '-'; ++k; }
               if (k == q && !empty) myflags |= CSVF_BAD_NUMBER;
-              for (; k < q; ++k) { const int dg = (int)text[k] - '0'; if (dg < 0 || dg > 9) { myflags |= CSVF_BAD_NUMBER; break; } v = v * 10 + dg; }
-              if (neg) v = -v;
+              // accumulated as a magnitude with an overflow check: a field that does not fit its column's type is an error
+              // (arrow-csv and pyarrow refuse it too), not a wrapped value
+              u64 mag = 0; bool ovf = false;
+              for (; k < q; ++k) {
+                const int dg = (int)text[k] - '0'; if (dg < 0 || dg > 9) { myflags |= CSVF_BAD_NUMBER; break; }
+                if (mag > (0xFFFFFFFFFFFFFFFFull - (u64)dg) / 10) ovf = true;
+                mag = mag * 10 + (u64)dg;
+              }
+              const u64 lim = kind == CSV_I32 ? (neg ? 0x80000000ull : 0x7FFFFFFFull) : (neg ? 0x8000000000000000ull : 0x7FFFFFFFFFFFFFFFull);
+              if (ovf || mag > lim) myflags |= CSVF_BAD_NUMBER;
+              v = neg ? (i64)(0 - mag) : (i64)mag;
               if (kind == CSV_I32) ((int32_t*)O.data[oc])[r] = (int32_t)v; else ((i64*)O.data[oc])[r] = v;
               break;
             }
@@ -149,6 +158,8 @@ __global__ void __launch_bounds__(FBLOCK) k_csv_parse(const uint8_t* __restrict_
               if (frac < 0) frac = 0;
               if (frac > S.scale[f]) myflags |= CSVF_BAD_NUMBER;
               for (int z = frac; z < S.scale[f]; ++z) v *= 10;
+              // more digits than the column's precision (or than 38: the accumulator would have wrapped) is an error
+              { i128 lim10 = 1; for (int z = 0; z < S.prec[f]; ++z) lim10 *= 10; if (q - p > 40 || v >= lim10) myflags |= CSVF_BAD_NUMBER; }
               if (neg) v = -v;
               ((u64*)O.data[oc])[2 * r] = (u64)v; ((u64*)O.data[oc])[2 * r + 1] = (u64)((u128)v >> 64);
               break;

@@ -133,7 +133,8 @@ int gpuq_csv_decode(gpuq_ctx* ctx, void* stream, const uint8_t* text, int64_t n_
         case T_FLOAT64: k = CSV_F64; break; case T_BOOL: k = CSV_BOOL; break; case T_UTF8: k = CSV_UTF8; break;
         default: throw Unsupported("csv: column type " + std::to_string(fi.type));
       }
-      S.kind[f] = k; S.out[f] = (int32_t)o; S.scale[f] = fi.scale; S.nullable[f] = fi.nullable;
+      S.kind[f] = k; S.out[f] = (int32_t)o; S.scale[f] = fi.scale; S.nullable[f] = fi.nullable; S.prec[f] = fi.type == T_DECIMAL128 ? std::min(std::max(fi.precision, 1), 38) : 0;
+      if (fi.type == T_DECIMAL128 && (fi.scale < 0 || fi.scale > 38)) throw std::runtime_error("csv: Decimal128 scale out of range");
     }
     // text on the device (+ one '\n' so that an unterminated last line ends like the others)
     DevBuf dtext; dtext.ensure((size_t)n_bytes + 64);

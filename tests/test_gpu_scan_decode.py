@@ -152,11 +152,23 @@ def test_every_column_kind_against_pyarrow(tc, n, crlf, terminated):
 
 @pytest.mark.parametrize("text,code,what", [
     (b'1,"a,b"\n', 3, "quoted"), (b"1\n", 1, "number of fields"), (b"1,2,3\n", 1, "number of fields"), (b"1x,a\n", 1, "parse"), (b",a\n", 1, "non-nullable"),
+    (b"9223372036854775808,a\n", 1, "parse"), (b"-9223372036854775809,a\n", 1, "parse"), (b"123456789012345678901234567890,a\n", 1, "parse"),
 ])
 def test_malformed_text_is_refused(tc, text, code, what):
     with pytest.raises(g.GpuqError) as e:
         scan.read_csv(tc, text, [("a", "Int64", False), ("b", "Utf8", False)])
     assert e.value.status == code and what in str(e.value)
+
+
+def test_numeric_limits_of_the_text_parser(tc):
+    """The extremes of every integer type parse exactly; one past them, and decimals beyond the column's precision, are refused."""
+    schema = [("a", "Int64", False), ("b", "Int32", False), ("c", {"Decimal128": [5, 2]}, False)]
+    ok = b"9223372036854775807,2147483647,999.99\n-9223372036854775808,-2147483648,-999.99\n"
+    got = scan.read_csv(tc, ok, schema).to_arrow(tc.ctx)
+    same(got, pyarrow_csv(ok, schema))
+    for bad in (b"1,2147483648,1.00\n", b"1,-2147483649,1.00\n", b"1,2,1000.00\n", b"1,2,1.001\n"):
+        with pytest.raises(g.GpuqError, match="parse"):
+            scan.read_csv(tc, bad, schema)
 
 
 # ------------------------------------------------------------------ Parquet
