@@ -250,17 +250,19 @@ __device__ __forceinline__ bool pq_hybrid(const uint8_t* p, const uint8_t* end, 
     if (b.p >= b.end) return false;
     const uint32_t h = pq_varint(b);
     if (h & 1) {      // bit-packed: (h >> 1) groups of 8 values
-      const int cnt = (int)(h >> 1) * 8;
-      const int take = cnt < n - done ? cnt : n - done;
+      const i64 cnt = (i64)(h >> 1) * 8;      // 64-bit: a corrupt header must not wrap into a negative count
+      if (cnt == 0) return false;
+      const int take = cnt < (i64)(n - done) ? (int)cnt : n - done;
       for (int i = flane(); i < take; i += 64) sink(done + i, pq_unpack(b.p, b.end, bw, (uint32_t)i));
-      b.p += ((i64)cnt * bw + 7) / 8; done += take;
+      const i64 adv = (cnt * bw + 7) / 8;
+      b.p = adv < b.end - b.p ? b.p + adv : b.end; done += take;
     } else {          // run of one value, (bw + 7) / 8 bytes little-endian
-      const int cnt = (int)(h >> 1);
+      const i64 cnt = (i64)(h >> 1);
       if (cnt == 0) return false;
       uint32_t v = 0; const int nb = (bw + 7) / 8;
       for (int k = 0; k < nb; ++k) if (b.p + k < b.end) v |= (uint32_t)b.p[k] << (8 * k);
       b.p += nb;
-      const int take = cnt < n - done ? cnt : n - done;
+      const int take = cnt < (i64)(n - done) ? (int)cnt : n - done;
       for (int i = flane(); i < take; i += 64) sink(done + i, v);
       done += take;
     }
@@ -357,15 +359,18 @@ __global__ void __launch_bounds__(64) k_pq_decode(const uint8_t* __restrict__ fi
   if (C.phys == PQ_BYTE_ARRAY) {
     // length-prefixed values: a serial walk (lane 0) over the page's present values records where each one starts
     i64* starts = (i64*)(vidx + n + (n & 1));      // 8-byte aligned tail of the scratch row: n_present positions
+    int walk_bad = 0;
     if (flane() == 0) {
       const uint8_t* q = p;
       for (int i = 0; i < n_present; ++i) {
-        if (end - q < 4) { atomicOr(flags, PQF_MALFORMED); break; }
+        if (end - q < 4) { walk_bad = 1; break; }
         const uint32_t len = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
         starts[i] = (q + 4) - file; q += 4 + (i64)len;
-        if (q > end) { atomicOr(flags, PQF_MALFORMED); break; }
+        if (q > end) { walk_bad = 1; break; }
       }
+      if (walk_bad) atomicOr(flags, PQF_MALFORMED);
     }
+    if (__shfl(walk_bad, 0)) return;      // the positions beyond the break are not written: nobody may follow them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     for (int i = flane(); i < n; i += 64) {
       const uint32_t vi = C.optional ? vidx[i] : (uint32_t)i;
@@ -377,6 +382,11 @@ __global__ void __launch_bounds__(64) k_pq_decode(const uint8_t* __restrict__ fi
       C.str_src[r] = s0;
     }
     return;
+  }
+  {      // the page must hold every value its header and levels announce: nothing below reads past `end`
+    const i64 have = end - p;
+    const i64 need = C.phys == PQ_BOOL ? ((i64)n_present + 7) / 8 : (i64)n_present * (C.phys == PQ_I32 ? 4 : (C.phys == PQ_FLBA ? C.flba_len : 8));
+    if (need > have) { if (flane() == 0) atomicOr(flags, PQF_MALFORMED); return; }
   }
   for (int i = flane(); i < n; i += 64) {
     const uint32_t vi = C.optional ? vidx[i] : (uint32_t)i;

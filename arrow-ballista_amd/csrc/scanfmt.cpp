@@ -385,6 +385,7 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
         if ((size_t)li >= G.cols.size()) throw std::runtime_error("parquet: row group without column " + L.name);
         const PqChunk& K = G.cols[(size_t)li];
         if (K.num_values == 0) continue;
+        if (K.num_values < 0 || K.total_compressed <= 0 || K.data_page_offset < 0) throw std::runtime_error("parquet: negative size / offset in a column chunk's metadata");
         if (K.codec != 0 && K.codec != 1) throw Unsupported("parquet: compressed column chunk (codec " + std::to_string(K.codec) + ") in '" + L.name + "': UNCOMPRESSED and SNAPPY pages are decoded on the device");
         const int cmode = K.codec == 1 ? 1 : 0;
         int64_t pos = K.dict_page_offset >= 0 && K.dict_page_offset < K.data_page_offset ? K.dict_page_offset : K.data_page_offset;
@@ -396,7 +397,9 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
         while (pos < chunk_end && seen < K.num_values) {
           const PqPageHeader H = read_page_header(file + pos, file + chunk_end);
           const int64_t payload = pos + H.header_bytes;
+          if (H.compressed < 0 || H.uncompressed < 0 || H.num_values < 0 || H.def_v2 < 0 || H.rep_v2 < 0 || H.header_bytes <= 0) throw std::runtime_error("parquet: negative size in a page header");
           if (payload + H.compressed > chunk_end) throw std::runtime_error("parquet: page exceeds its column chunk");
+          if (H.type == 3 && (int64_t)H.def_v2 + H.rep_v2 > H.compressed) throw std::runtime_error("parquet: v2 page levels exceed the page");
           if (H.type == 2) {       // dictionary page
             if (H.encoding != 0 && H.encoding != 2) throw Unsupported("parquet: dictionary page encoding " + std::to_string(H.encoding));
             dict_id = (int)P->dict_src.size(); P->dict_src.push_back({place(payload + base, H.compressed, H.uncompressed, 0, cmode), any_compressed ? H.uncompressed : H.compressed, H.num_values});
@@ -456,7 +459,10 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
       for (auto& d : P.dict_src) {
         PqDict D{}; D.values = (i64)va; D.str_offsets = (i64)(oa / 4); D.n = d.n;
         if (gt == T_UTF8) { launch_pq_dict_strings(s, pages_base, d.src, d.bytes, d.n, (int32_t*)P.dstroffs.p + oa / 4, (uint8_t*)P.dvalues.p + va, (uint32_t*)flags.p); va += ((size_t)d.bytes + 63) & ~(size_t)63; oa += ((size_t)d.n + 2) * 4; }
-        else { launch_pq_dict_fixed(s, pages_base, d.src, d.n, L.type, L.type_length, width, (uint8_t*)P.dvalues.p + va); va += ((size_t)d.n * (size_t)width + 63) & ~(size_t)63; }
+        else {
+          const int64_t elem = L.type == 1 ? 4 : (L.type == 7 ? L.type_length : 8);
+          if ((int64_t)d.n * elem > d.bytes) throw std::runtime_error("parquet: dictionary page of '" + L.name + "' is shorter than its value count");
+          launch_pq_dict_fixed(s, pages_base, d.src, d.n, L.type, L.type_length, width, (uint8_t*)P.dvalues.p + va); va += ((size_t)d.n * (size_t)width + 63) & ~(size_t)63; }
         P.dicts.push_back(D);
       }
       P.ddicts.ensure(P.dicts.size() * sizeof(PqDict) + 64);
@@ -470,6 +476,10 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
                        (uint32_t*)P.scratch.p, stride, (uint32_t*)flags.p);
       HIPCHECK(hipGetLastError());
       if (gt == T_UTF8) {
+        // lengths and positions of a malformed page are garbage: look at the flags BEFORE anything copies through them
+        uint32_t early[2]; HIPCHECK(hipMemcpyAsync(early, flags.p, 8, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s));
+        if (early[1]) throw std::runtime_error("parquet: malformed Snappy data in a page");
+        if (early[0] & PQF_MALFORMED) throw std::runtime_error("parquet: malformed page (levels / indices / lengths run past the page, or an index beyond its dictionary)");
         const uint8_t* df = pages_base; const uint8_t* dv = (const uint8_t*)P.dvalues.p; const i64* src = (const i64*)P.str_src.p;
         finish_strings(s, *ic, (int32_t*)ic->offsets.p, n_rows, [&](const int32_t* offs, uint8_t* dst, int64_t) { launch_pq_copy_strings(s, df, dv, src, offs, n_rows, dst); });
       }

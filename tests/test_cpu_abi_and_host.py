@@ -401,3 +401,36 @@ def test_every_runtime_kernel_source_compiles_for_gfx950():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     ok = [l for l in r.stdout.splitlines() if " OK: " in l]
     assert len(ok) == 16, r.stdout
+
+
+def test_parquet_footer_parser_survives_corruption():
+    """The Thrift-compact reader takes untrusted bytes: 400 random single- and multi-byte corruptions and every truncation of a valid
+    footer either parse or fail with an error -- no crash, no hang (run on the host: gpuq_parquet_schema needs no device)."""
+    import io
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from arrow_ballista_amd import scan
+    L = g.lib()
+    t = pa.table({"a": pa.array(range(1000), pa.int64()), "s": pa.array(["x%d" % i for i in range(1000)]), "d": pa.array([1] * 1000, pa.int32()).cast(pa.date32())})
+    buf = io.BytesIO()
+    pq.write_table(t, buf, row_group_size=300)
+    good = buf.getvalue()
+    flen = int.from_bytes(good[-8:-4], "little")
+    r = np.random.default_rng(1)
+    outcomes = {"ok": 0, "err": 0}
+    for it in range(400):
+        bad = bytearray(good)
+        for _ in range(1 + it % 4):
+            bad[len(good) - 8 - int(r.integers(1, flen + 1))] = int(r.integers(0, 256))
+        try:
+            scan.parquet_schema(L, bytes(bad)); outcomes["ok"] += 1
+        except g.GpuqError:
+            outcomes["err"] += 1
+    for cut in range(1, flen, max(1, flen // 60)):
+        bad = good[: len(good) - 8 - cut] + good[-8:]            # footer shorter than its length field says / shifted
+        try:
+            scan.parquet_schema(L, bad)
+        except g.GpuqError:
+            outcomes["err"] += 1
+    assert outcomes["err"] > 50

@@ -308,3 +308,41 @@ def test_decoded_leaves_feed_q1(tc):
     schema = [(f.name, {"int64": "Int64", "string": "Utf8", "date32[day]": "Date32"}.get(str(f.type), D152), False) for f in li.schema] + [("__placeholder", "Utf8", False)]
     from_text = scan.read_csv(tc, text, schema, projection=list(range(li.num_columns)), delimiter="|")
     assert T.q1_result_to_rows(tc, T.run_q1(tc, from_text)) == want
+
+
+@pytest.mark.parametrize("compression", ["NONE", "SNAPPY"])
+def test_corrupted_pages_never_read_out_of_bounds(tc, compression):
+    """Page bytes are untrusted: random corruptions of the data region of a valid file (levels, run headers, dictionary indices, length
+    prefixes, Snappy tags) must end in an error or in (different) in-bounds values -- every length the kernels follow is checked
+    against the page it came from.  A clean decode of the untouched file afterwards shows the device is still healthy."""
+    t = parquet_table(20_000, 77)
+    good = write(t, compression=compression, use_dictionary=["lowcard", "s", "ns"], data_page_size=8192, row_group_size=7000)
+    flen = int.from_bytes(good[-8:-4], "little")
+    data_end = len(good) - 8 - flen
+    r = np.random.default_rng(9)
+    outcomes = {"ok": 0, "err": 0}
+    for it in range(48):
+        bad = bytearray(good)
+        for _ in range(1 + it % 6):
+            at = int(r.integers(4, data_end))
+            bad[at] = int(r.integers(0, 256)) if it % 2 else 0xFF
+        try:
+            scan.read_parquet(tc, bytes(bad)); outcomes["ok"] += 1
+        except g.GpuqError:
+            outcomes["err"] += 1
+    assert outcomes["err"] > 0
+    same(scan.read_parquet(tc, good).to_arrow(tc.ctx), pq.read_table(io.BytesIO(good)))
+
+
+def test_random_text_is_parsed_or_refused(tc):
+    r = np.random.default_rng(3)
+    schema = [("a", "Int64", True), ("b", {"Decimal128": [15, 2]}, True), ("c", "Date32", True), ("d", "Float64", True), ("e", "Utf8", True)]
+    alphabet = np.frombuffer(b"0123456789-+.,eE\n\r x", dtype=np.uint8)
+    for it in range(30):
+        text = alphabet[r.integers(0, len(alphabet), 5000)].tobytes()
+        try:
+            scan.read_csv(tc, text, schema)
+        except g.GpuqError:
+            pass
+    data, sch = synthetic_csv(1000, 5)
+    same(scan.read_csv(tc, data, sch).to_arrow(tc.ctx), pyarrow_csv(data, sch))
