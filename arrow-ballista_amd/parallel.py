@@ -244,8 +244,9 @@ def unpack_records(columns, recv, counts, cap):
         classes = sorted(set(widths))
         vias = []
         for w in classes:
-            idx = [r * (B // w) + i for r, k in enumerate(counts) for i in range(k)] or [0]
-            vias.append(torch.tensor(idx, dtype=torch.int32).to(dev, non_blocking=True))
+            pieces = [torch.arange(k, dtype=torch.int32) + r * (B // w) for r, k in enumerate(counts) if k > 0]      # no per-row Python work
+            idx = torch.cat(pieces) if pieces else torch.zeros(1, dtype=torch.int32)
+            vias.append(idx.to(dev, non_blocking=True))
         cols = [DeviceColumn(c.name, c.type, recv[doff:], total, nullable=False, repr=c.repr) for c, (doff, _, _, _) in zip(columns, lay)]
         out = DeviceTable(cols, total, via=vias, sides=[classes.index(w) + 1 for w in widths], dense=True)
         out._keep = recv
