@@ -1284,37 +1284,35 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
     uint32_t* ids = packed ? nullptr : (uint32_t*)op->ws[4].ensure((size_t)n * 4);
     uint32_t* ids2 = packed ? nullptr : (uint32_t*)op->ws[5].ensure((size_t)n * 4);
     ProfScope ps(op, s);
-    // digit counts: 256 u64 per pass, two alternating slots (a pass reads its own, fills the next one's)
-    u64* ghist = (u64*)op->ws[6].ensure((size_t)2 * 256 * 8);
+    // digit counts of every pass (256 u64 each), taken by the pack kernel on the way
+    const int np_all = (total + 7) / 8;
+    u64* ghist = (u64*)op->ws[6].ensure((size_t)sort_max_passes() * 256 * 8);
     const bool small = n <= sort_small_max();
-    { JitScope js(op, op->prog, 9, n); launch_sort_pack(s, P, n, S, K, klo, khi, ids, small || total == 0 ? nullptr : ghist); }
+    { JitScope js(op, op->prog, 9, n); launch_sort_pack(s, P, n, S, K, klo, khi, ids, small || total == 0 ? nullptr : ghist, np_all); }
     if (small) {      // one block sorts it in LDS: no histogram / scan / scatter launches
       launch_sort_small(s, klo, khi, ids, n, perm_out);
       HIPCHECK(hipGetLastError());
       return;
     }
-    // single-read passes (kernels_sort.hip): the pack kernel counted the first digit, every pass counts the next one while it has the
-    // tile in registers, the last pass writes the row ids straight into perm_out
+    // single-read passes (kernels_sort.hip): one look-back kernel per 8 key bits, the last one writes the row ids straight into perm_out
     const size_t lwb = onesweep_ws_bytes(n);
     void* lws = op->ws[7].ensure(lwb);
-    auto run_passes = [&](int bits, int shift0, bool last_word) {
+    auto run_passes = [&](int bits, int shift0, int pass0, bool last_word) {
       const int np = (bits + 7) / 8;
       if (np == 0) { if (last_word) HIPCHECK(hipMemcpyAsync(perm_out, ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s)); return; }
       for (int p = 0; p < np; ++p) {
         const bool final_pass = last_word && p + 1 == np;
-        u64* mine = ghist + (size_t)(p & 1) * 256; u64* next = p + 1 < np ? ghist + (size_t)((p + 1) & 1) * 256 : nullptr;
-        launch_onesweep_pass(s, klo, ids, n, shift0 + 8 * p, mine, lws, lwb, klo2, final_pass ? perm_out : ids2, final_pass, next);
+        launch_onesweep_pass(s, klo, ids, n, shift0 + 8 * p, ghist + (size_t)(pass0 + p) * 256, lws, lwb, klo2, final_pass ? perm_out : ids2, final_pass);
         std::swap(klo, klo2); if (!final_pass) std::swap(ids, ids2);
       }
     };
     if (packed) {
-      run_passes(total, 32, true);
+      run_passes(total, 32, 0, true);
     } else {
-      run_passes(std::min(total, 64), 0, total <= 64);
+      run_passes(std::min(total, 64), 0, 0, total <= 64);
       if (total > 64) {
-        launch_gather_u64(s, khi, ids, n, klo);   // hi words in the current order
-        launch_radix_ghist(s, klo, n, 0, 1, ghist);
-        run_passes(total - 64, 0, true);
+        launch_gather_u64(s, khi, ids, n, klo);   // hi words in the current order (their digit counts are passes 8.. of the pack kernel's)
+        run_passes(total - 64, 0, 8, true);
       }
     }
     HIPCHECK(hipGetLastError());
@@ -1345,7 +1343,7 @@ int gpuq_merge_run(gpuq_op* op, void* stream, const gpuq_input* in, const int64_
     uint32_t* ids = (uint32_t*)op->ws[4].ensure((size_t)n * 4);
     uint32_t* ids2 = (uint32_t*)op->ws[5].ensure((size_t)n * 4);
     ProfScope ps(op, s);
-    { JitScope js(op, op->prog, 9, n); launch_sort_pack(s, P, n, op->sort, K, klo, khi, ids, nullptr); }
+    { JitScope js(op, op->prog, 9, n); launch_sort_pack(s, P, n, op->sort, K, klo, khi, ids, nullptr, 0); }
     // runs -> pairs, round by round (empty runs drop out; an odd run is carried as a pair with an empty right side)
     std::vector<i64> bounds; bounds.push_back(0);
     for (int r = 0; r < n_runs; ++r) if (run_offsets[r + 1] > run_offsets[r]) bounds.push_back(run_offsets[r + 1]);

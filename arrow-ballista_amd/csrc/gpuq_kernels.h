@@ -80,6 +80,7 @@ struct SortSpec {
   int32_t nulls_first[MAX_SORT_KEYS];
   int32_t kind[MAX_SORT_KEYS];     // 0 integer/decimal/date, 1 float64 (total order), 2 packed Utf8
 };
+constexpr int SORT_MAX_PASSES = 16;  // 8-bit digits of a composite key of up to 128 bits
 struct SortPack {                   // computed on the host from the per-key min/max
   u64 base_lo[MAX_SORT_KEYS], base_hi[MAX_SORT_KEYS];   // min (ASC) or max (DESC) in the ordered view
   int32_t shift[MAX_SORT_KEYS];     // bit position of the key's field in the composite
@@ -158,7 +159,8 @@ void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec&
                        u64 out_cap, u64* out_count, uint32_t* visited);
 int sort_minmax_blocks(i64 n);
 void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks);
-void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids, u64* hist0);
+int sort_max_passes();
+void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids, u64* hist, int hist_passes);
 void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, uint32_t nparts, u64* pid_out, uint32_t* ids);
 void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out);
 void launch_gather_u64(hipStream_t s, const u64* src, const uint32_t* idx, i64 n, u64* dst);
@@ -174,7 +176,7 @@ void launch_merge_pairs(hipStream_t s, const u64* klo, const u64* khi, const uin
                         u64* klo_out, u64* khi_out, uint32_t* ids_out);
 void launch_radix_ghist(hipStream_t s, const u64* keys, i64 n, int shift0, int npasses, u64* ghist);
 void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, u64* gexcl, void* ws, size_t ws_bytes,
-                          u64* keys_out, uint32_t* vals_out, bool ids_only, u64* next_hist);
+                          u64* keys_out, uint32_t* vals_out, bool ids_only);
 void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, uint32_t mask, u64* keys_out, uint32_t* vals_out,
                        int32_t* hist, void* scan_ws, size_t scan_ws_bytes);
 void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa, const uint32_t* n_groups_dev = nullptr);
