@@ -8,6 +8,25 @@ sys.path.insert(0, ROOT)
 import arrow_ballista_amd as g
 from arrow_ballista_amd.expr import col, lit, binary, Operator as Op
 
+# hiprtc has no libc / libstdc++ headers: a system #include that is live under GPUQ_JIT compiles here (hipcc) and fails on the GPU box,
+# where the operator then silently runs its AOT kernel.  Walk the files a run-time translation unit includes and refuse any such line.
+def live_includes_under_jit(path):
+    bad, stack = [], []          # stack of booleans: is this conditional branch live when GPUQ_JIT is defined?
+    for ln, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.startswith("#ifndef GPUQ_JIT"): stack.append(False)
+        elif t.startswith("#ifdef GPUQ_JIT") or t.startswith("#if defined(GPUQ_JIT)"): stack.append(True)
+        elif t.startswith("#if"): stack.append(all(stack) if stack else True)
+        elif t.startswith("#else") and stack: stack[-1] = not stack[-1] if t == "#else" else stack[-1]
+        elif t.startswith("#elif") and stack: stack[-1] = True if "GPUQ_JIT_KERNEL" in t else stack[-1]
+        elif t.startswith("#endif") and stack: stack.pop()
+        elif t.startswith("#include <") and all(stack) and not any(h in t for h in ("hip/hip_runtime.h", "stdint.h")): bad.append("%s:%d: %s" % (os.path.basename(path), ln, t))
+    return bad
+CSRC = os.path.join(ROOT, "arrow-ballista_amd", "csrc")
+bad = sum((live_includes_under_jit(os.path.join(CSRC, f)) for f in ("kernels_scan.hip", "kernels_hash.hip", "kernels_sort.hip", "gpuq_dev.h", "gpuq_kernels.h")), [])
+if bad:
+    print("system headers live under GPUQ_JIT (hiprtc cannot find them):\n  " + "\n  ".join(bad)); sys.exit(1)
+
 fields = [{"name": "k", "type": "Int64", "nullable": False}, {"name": "d", "type": "Date32", "nullable": False}]
 pred = binary(col("d", fields), Op.Gt, lit(9204, "Date32"))
 build = {"op": "join_build", "input": {"fields": fields}, "on": [col("k", fields)], "predicate": pred}
