@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(RADIX) k_radix_ghist_scan(u64* __restrict__ gh
 }
 // OROUNDS keys per thread: the tile is SBLOCK * OROUNDS records.  Longer tiles mean longer runs per digit in the write-out and fewer
 // barriers / look-back words per key (measured on 2^27 packed records: 2048-record tiles 1.2 ms per pass, 4096: 0.75, 8192: 0.63); the
-// (key, value) form keeps 4096 because its 12 bytes per record would leave one block per CU at 8192.
+// (key, value) form uses 6144 because its 12 bytes per record would leave one block per CU at 8192.
 template <bool HASVAL, int OROUNDS>
 __global__ void __launch_bounds__(SBLOCK) k_onesweep(const u64* __restrict__ keys, const uint32_t* __restrict__ vals, const i64 n, const int shift,
                                                      const u64* __restrict__ gexcl, u64* __restrict__ look, uint32_t* __restrict__ ticket,
@@ -786,7 +786,7 @@ void launch_sort_small(hipStream_t s, const u64* klo, const u64* khi, const uint
   if (n > 0) hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, s, klo, khi, ids, (int)n, out);
 }
 
-constexpr int OS_ROUNDS_PACKED = 32, OS_ROUNDS_KV = 16;      // 8192-record tiles for 8-byte records (6144: 3.4 ms instead of 3.15 on 2^27 rows), 4096 for (key, value)
+constexpr int OS_ROUNDS_PACKED = 32, OS_ROUNDS_KV = 24;      // 8192-record tiles for 8-byte records (6144: 3.4 ms instead of 3.15 on 2^27 rows), 6144 for (key, value) (4096: 6.55 ms instead of 5.9 over 5 passes; 8192 leaves one block per CU)
 size_t onesweep_ws_bytes(i64 n) { const i64 tiles = (n + SBLOCK * OS_ROUNDS_KV - 1) / (SBLOCK * OS_ROUNDS_KV); return (size_t)tiles * RADIX * 8 + 256; }      // look-back words + ticket (the smallest tile: an upper bound)
 int onesweep_max_passes() { return GHIST_MAX_PASSES; }
 // ghist: npasses * 256 u64 digit counts (launch_onesweep_pass turns a pass's counts into bases)
