@@ -98,6 +98,8 @@ def lib():
         "gpuq_ingest_last_error": (C.c_char_p, []),
         "gpuq_csv_decode": (i32, [vp, vp, vp, i64, C.POINTER(gpuq_field_info), i32, C.POINTER(C.c_int32), i32, C.POINTER(gpuq_csv_options), C.POINTER(vp)]),
         "gpuq_parquet_decode": (i32, [vp, vp, vp, i64, C.POINTER(C.c_char_p), i32, C.POINTER(vp)]),
+        "gpuq_parquet_decode_groups": (i32, [vp, vp, vp, i64, C.POINTER(C.c_char_p), i32, C.POINTER(C.c_int32), i32, C.POINTER(vp)]),
+        "gpuq_parquet_row_groups": (i32, [vp, i64, C.POINTER(i64), i32, C.POINTER(i32)]),
         "gpuq_parquet_schema": (i32, [vp, i64, C.POINTER(gpuq_field_info), i32, C.POINTER(i32), C.POINTER(i64)]),
         "gpuq_scan_last_error": (C.c_char_p, []),
         "gpuq_table_num_rows": (i64, [vp]),

@@ -326,12 +326,25 @@ PqPageHeader read_page_header(const uint8_t* p, const uint8_t* e) {
 extern "C" {
 
 int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_t n_bytes, const char* const* columns, int n_columns, gpuq_table** out) {
+  return gpuq_parquet_decode_groups(ctx, stream, file, n_bytes, columns, n_columns, nullptr, 0, out);
+}
+
+int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_t n_bytes, const char* const* columns, int n_columns,
+                               const int32_t* row_groups, int n_row_groups, gpuq_table** out) {
   if (out) *out = nullptr;
   return guarded_f([&]() {
     if (!ctx || !out || !file) throw std::runtime_error("ctx / file / out is NULL");
     HIPCHECK(hipSetDevice(ctx->device));
     hipStream_t s = use_stream(stream);
-    const PqFileMeta M = read_footer(file, n_bytes);
+    PqFileMeta M = read_footer(file, n_bytes);
+    if (row_groups) {      // the caller's pruning (statistics, partition filters): only these row groups, in the order given
+      std::vector<PqRowGroup> pick; int64_t rows = 0;
+      for (int i = 0; i < n_row_groups; ++i) {
+        if (row_groups[i] < 0 || (size_t)row_groups[i] >= M.groups.size()) throw std::runtime_error("parquet: row group " + std::to_string(row_groups[i]) + " is not in the file");
+        pick.push_back(M.groups[(size_t)row_groups[i]]); rows += pick.back().num_rows;
+      }
+      M.groups.swap(pick); M.num_rows = rows;
+    }
     if (M.schema.empty()) throw std::runtime_error("parquet: empty schema");
     // flat schemas: the root and its leaf children
     std::vector<PqSchemaElem> leaves(M.schema.begin() + 1, M.schema.end());
@@ -491,6 +504,17 @@ int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_
     if (fl & PQF_MALFORMED) throw std::runtime_error("parquet: malformed page (levels / indices / lengths run past the page, or an index beyond its dictionary)");
     if (fl & PQF_UNSUPPORTED) throw Unsupported("parquet: a page holds a value type the device does not decode");
     *out = t.release();
+  });
+}
+
+int gpuq_parquet_row_groups(const uint8_t* file, int64_t n_bytes, int64_t* rows_out, int cap, int* n_out) {
+  return guarded_f([&]() {
+    if (!file || !n_out) throw std::runtime_error("file / n_out is NULL");
+    const PqFileMeta M = read_footer(file, n_bytes);
+    *n_out = (int)M.groups.size();
+    if (!rows_out) return;
+    if (cap < *n_out) throw Capacity("the file has " + std::to_string(*n_out) + " row groups");
+    for (size_t i = 0; i < M.groups.size(); ++i) rows_out[i] = M.groups[i].num_rows;
   });
 }
 

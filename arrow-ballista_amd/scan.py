@@ -90,6 +90,28 @@ def read_csv(tc, src, schema, projection=None, delimiter=",", has_header=False, 
     return _wrap_table(tc, h)
 
 
+def read_csv_chunked(tc, src, schema, projection=None, delimiter=",", has_header=False, chunk_bytes=1 << 30):
+    """Files beyond one call's 4 GiB (SF100's lineitem.tbl is 75 GB): decoded in pieces cut at line boundaries on the host (a scan
+    backwards for the last newline of every chunk -- no value is looked at).  Returns the pieces as a list of DeviceTables: the
+    partitions of the scan leaf (MemoryExec(parts))."""
+    keep, addr, n = _host_bytes(src)
+    if n == 0:
+        return [read_csv(tc, b"", schema, projection, delimiter, has_header)]
+    mv = memoryview((C.c_ubyte * n).from_address(addr)).cast("B")
+    parts, at, first = [], 0, True
+    while at < n:
+        end = min(n, at + int(chunk_bytes))
+        if end < n:
+            cut = bytes(mv[at:end]).rfind(b"\n")
+            if cut < 0:
+                raise B.GpuqError(1, "csv: a line longer than chunk_bytes")
+            end = at + cut + 1
+        parts.append(read_csv(tc, mv[at:end], schema, projection, delimiter, has_header and first))
+        at, first = end, False
+    del keep
+    return parts
+
+
 def parquet_schema(L, src):
     """[(name, type or None when the device has no decoder, nullable)], num_rows -- from the footer, host only."""
     keep, addr, n = _host_bytes(src)
@@ -101,13 +123,27 @@ def parquet_schema(L, src):
     return [(f.name.decode(), None if f.type < 0 else type_json(f.type, f.precision, f.scale), bool(f.nullable)) for f in fields[:k.value]], int(rows.value)
 
 
-def read_parquet(tc, src, columns=None):
+def parquet_row_groups(L, src):
+    """rows of every row group of the file (host only)."""
+    keep, addr, n = _host_bytes(src)
+    k = C.c_int(0)
+    _check(L, L.gpuq_parquet_row_groups(C.c_void_p(addr), n, None, 0, C.byref(k)))
+    rows = (C.c_int64 * max(1, k.value))()
+    _check(L, L.gpuq_parquet_row_groups(C.c_void_p(addr), n, rows, k.value, C.byref(k)))
+    del keep
+    return [int(rows[i]) for i in range(k.value)]
+
+
+def read_parquet(tc, src, columns=None, row_groups=None):
+    """row_groups: indices of the row groups to decode (the caller's pruning), in that order; None = all."""
     L = tc.ctx.L
     keep, addr, n = _host_bytes(src)
     names = None
     if columns is not None:
         names = (C.c_char_p * max(1, len(columns)))(*[c.encode() for c in columns])
     h = C.c_void_p()
-    _check(L, L.gpuq_parquet_decode(tc.ctx.h, tc.stream_ptr(), C.c_void_p(addr), n, names, 0 if columns is None else len(columns), C.byref(h)))
+    rg = None if row_groups is None else (C.c_int32 * max(1, len(row_groups)))(*[int(x) for x in row_groups])
+    _check(L, L.gpuq_parquet_decode_groups(tc.ctx.h, tc.stream_ptr(), C.c_void_p(addr), n, names, 0 if columns is None else len(columns), rg,
+                                           0 if row_groups is None else len(row_groups), C.byref(h)))
     del keep
     return _wrap_table(tc, h)

@@ -191,6 +191,12 @@ typedef struct gpuq_csv_options { char delimiter; char quote; int32_t has_header
 int gpuq_csv_decode(gpuq_ctx* ctx, void* stream, const uint8_t* text, int64_t n_bytes, const gpuq_field_info* file_fields, int n_file_fields,
                     const int32_t* projection, int n_projection, const gpuq_csv_options* options, gpuq_table** out);
 int gpuq_parquet_decode(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_t n_bytes, const char* const* columns, int n_columns, gpuq_table** out);
+/* the same over selected row groups (indices into the file's row groups, in the order given): predicate push-down stays where the
+   reference has it -- ParquetExec prunes row groups from footer statistics on the host -- and only the surviving groups' chunks
+   cross PCIe.  gpuq_parquet_row_groups: rows of every row group (host only), so that a caller can map its pruning to indices. */
+int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file, int64_t n_bytes, const char* const* columns, int n_columns,
+                               const int32_t* row_groups, int n_row_groups, gpuq_table** out);
+int gpuq_parquet_row_groups(const uint8_t* file, int64_t n_bytes, int64_t* rows_out, int cap, int* n_out);
 /* host only: leaf columns (type = -1 where the device has no decoder) and row count from the footer */
 int gpuq_parquet_schema(const uint8_t* file, int64_t n_bytes, gpuq_field_info* fields_out, int cap, int* n_out, int64_t* rows_out);
 const char* gpuq_scan_last_error(void);

@@ -346,3 +346,30 @@ def test_random_text_is_parsed_or_refused(tc):
             pass
     data, sch = synthetic_csv(1000, 5)
     same(scan.read_csv(tc, data, sch).to_arrow(tc.ctx), pyarrow_csv(data, sch))
+
+
+def test_row_group_selection_and_chunked_text(tc):
+    """Predicate push-down stays on the host (the reference prunes row groups from footer statistics): the engine decodes the row
+    groups it is given, in the order given.  Text beyond one call's size is decoded in chunks cut at line boundaries; the chunks are
+    the partitions of the scan leaf."""
+    t = parquet_table(10_000, 21)
+    data = write(t, row_group_size=3000, use_dictionary=True)
+    assert scan.parquet_row_groups(tc.ctx.L, data) == [3000, 3000, 3000, 1000]
+    got = scan.read_parquet(tc, data, ["k", "ns", "b"], row_groups=[3, 1]).to_arrow(tc.ctx)
+    want = pa.concat_tables([pq.ParquetFile(io.BytesIO(data)).read_row_group(g_, columns=["k", "ns", "b"]) for g_ in (3, 1)])
+    same(got, want)
+    assert scan.read_parquet(tc, data, ["k"], row_groups=[]).num_rows == 0
+    with pytest.raises(g.GpuqError, match="not in the file"):
+        scan.read_parquet(tc, data, row_groups=[4])
+    text, schema = synthetic_csv(20_000, 4)
+    parts = scan.read_csv_chunked(tc, text, schema, chunk_bytes=200_000)
+    assert len(parts) > 5 and sum(p.num_rows for p in parts) == 20_000
+    same(pa.concat_tables([p.to_arrow(tc.ctx) for p in parts]), pyarrow_csv(text, schema))
+    # the chunks feed a plan as the partitions of its leaf
+    src = g.MemoryExec(parts)
+    s_ = src.schema()
+    from arrow_ballista_amd.expr import col as C_, lit as L_
+    plan = g.AggregateExec("Single", [], [{"fn": "COUNT", "expr": L_(1), "name": "c"}, {"fn": "SUM", "expr": C_("i", s_), "name": "si"}], g.CoalescePartitionsExec(src))
+    row = g.NativePlan(plan, tc).execute(0).to_arrow().to_pylist()[0]
+    ref = pyarrow_csv(text, schema)
+    assert row["c"] == 20_000 and row["si"] == sum(ref.column("i").to_pylist())
