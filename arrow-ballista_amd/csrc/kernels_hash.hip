@@ -155,6 +155,52 @@ __global__ void __launch_bounds__(HBLOCK) k_ht_init(const HashTable T, const Agg
 #endif
 
 // ------------------------------------------------------------------ hash aggregate
+// Rows-in-flight driver for the one-row-per-lane kernels (hash aggregate, key range, build, generic unique probe): a wave takes ROWS_U of its 64-row words per step.  With
+// the generated evaluator its three stages are used so that every column load of all ROWS_U words is issued before any loaded
+// value is looked at (one memory round trip per step instead of one per word: vmcnt is in order, and the one-shot evaluator waits
+// for its record before the next word's loads can be issued); with the interpreter the words are simply taken one after the other.
+// body(w, pos, active, regs...) runs wave-uniformly once per word (active = row exists and passes the fused predicate).
+#ifndef GPUQ_ROWS_U
+#define GPUQ_ROWS_U 2
+#endif
+template <int MAXC, class Body>
+__device__ __forceinline__ void for_rows_in_flight(const DevProgram& P, const i64 n, const i64 w_first, const i64 w_stride, Body body, const i64 w_end = -1) {
+  const i64 nw_all = (n + 63) >> 6;
+  const i64 nwords = (w_end >= 0 && w_end < nw_all) ? w_end : nw_all;      // words [w_first, nwords) in steps of w_stride
+#ifdef GPUQ_JIT
+  constexpr int U = GPUQ_ROWS_U;
+  for (i64 w0 = w_first; w0 < nwords; w0 += w_stride * U) {
+    JitPre jq[U]; JitRaw jw[U]; i64 posc[U]; bool ex[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const i64 w = w0 + (i64)u * w_stride;
+      const i64 pos = (w << 6) + hlane();
+      ex[u] = w < nwords && pos < n;
+      posc[u] = ex[u] ? pos : n - 1;      // clamped, masked afterwards: no exec-masked load regions (n > 0 here: nwords > 0)
+      gpuq_jit_pre(P, posc[u], jq[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) gpuq_jit_load(P, posc[u], jq[u], jw[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const i64 w = w0 + (i64)u * w_stride;
+      if (w >= nwords) break;             // wave-uniform
+      GPUQ_REGS_DECL;
+      const bool pass = gpuq_jit_compute(P, posc[u], jw[u], GPUQ_REGS);
+      body(w, (w << 6) + hlane(), ex[u] && pass, GPUQ_REGS);
+    }
+  }
+#else
+  for (i64 w = w_first; w < nwords; w += w_stride) {
+    const i64 pos = (w << 6) + hlane();
+    bool active = pos < n;
+    GPUQ_REGS_DECL;
+    if (active) active = GPUQ_EVAL(MAXC, P, pos);
+    body(w, pos, active, GPUQ_REGS);
+  }
+#endif
+}
+
 template <int MAXC>
 __device__ __forceinline__ void k_agg_hash_body(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T) {
   const i64 nwords = (n + 63) >> 6;
@@ -165,12 +211,8 @@ __device__ __forceinline__ void k_agg_hash_body(const DevProgram P, const i64 n,
   bool combine = true;
   for (int a = 0; a < A.n_accs; ++a) combine = combine && A.acc_kind[a] != ACC_FMIN && A.acc_kind[a] != ACC_FMAX;
   const int lane = hlane();
-  for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
-    const i64 pos = (w << 6) + lane;
-    bool active = pos < n;
-    GPUQ_REGS_DECL;
-    if (active) active = GPUQ_EVAL(MAXC, P, pos);
-    if (__ballot(active) == 0) continue;
+  for_rows_in_flight<MAXC>(P, n, (i64)blockIdx.x * HWAVES + hwave(), (i64)gridDim.x * HWAVES, [&](const i64, const i64, const bool active, GPUQ_REGS_PARAM) {
+    if (__ballot(active) == 0) return;
     u64 kw[MAX_KW]; u64 h = 0;
 #pragma unroll
     for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
@@ -266,7 +308,7 @@ __device__ __forceinline__ void k_agg_hash_body(const DevProgram P, const i64 n,
         default: break;
       }
     }
-  }
+  });
 }
 #ifndef GPUQ_JIT
 template <int MAXC>
@@ -801,51 +843,6 @@ extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevPro
 // ------------------------------------------------------------------ join build
 // Key range of the rows the build would insert (single narrow key): decides between the direct-addressed table and
 // open addressing.  out = {min, max, count}, pre-set by the host to {INT64_MAX, INT64_MIN, 0}.
-// Rows-in-flight driver for the one-row-per-lane kernels (key range, build): a wave takes ROWS_U of its 64-row words per step.  With
-// the generated evaluator its three stages are used so that every column load of all ROWS_U words is issued before any loaded
-// value is looked at (one memory round trip per step instead of one per word: vmcnt is in order, and the one-shot evaluator waits
-// for its record before the next word's loads can be issued); with the interpreter the words are simply taken one after the other.
-// body(w, pos, active, regs...) runs wave-uniformly once per word (active = row exists and passes the fused predicate).
-#ifndef GPUQ_ROWS_U
-#define GPUQ_ROWS_U 2
-#endif
-template <int MAXC, class Body>
-__device__ __forceinline__ void for_rows_in_flight(const DevProgram& P, const i64 n, const i64 w_first, const i64 w_stride, Body body) {
-  const i64 nwords = (n + 63) >> 6;
-#ifdef GPUQ_JIT
-  constexpr int U = GPUQ_ROWS_U;
-  for (i64 w0 = w_first; w0 < nwords; w0 += w_stride * U) {
-    JitPre jq[U]; JitRaw jw[U]; i64 posc[U]; bool ex[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const i64 w = w0 + (i64)u * w_stride;
-      const i64 pos = (w << 6) + hlane();
-      ex[u] = w < nwords && pos < n;
-      posc[u] = ex[u] ? pos : n - 1;      // clamped, masked afterwards: no exec-masked load regions (n > 0 here: nwords > 0)
-      gpuq_jit_pre(P, posc[u], jq[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) gpuq_jit_load(P, posc[u], jq[u], jw[u]);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const i64 w = w0 + (i64)u * w_stride;
-      if (w >= nwords) break;             // wave-uniform
-      GPUQ_REGS_DECL;
-      const bool pass = gpuq_jit_compute(P, posc[u], jw[u], GPUQ_REGS);
-      body(w, (w << 6) + hlane(), ex[u] && pass, GPUQ_REGS);
-    }
-  }
-#else
-  for (i64 w = w_first; w < nwords; w += w_stride) {
-    const i64 pos = (w << 6) + hlane();
-    bool active = pos < n;
-    GPUQ_REGS_DECL;
-    if (active) active = GPUQ_EVAL(MAXC, P, pos);
-    body(w, pos, active, GPUQ_REGS);
-  }
-#endif
-}
-
 template <int MAXC>
 __device__ __forceinline__ void k_join_keyrange_body(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out) {
   __shared__ i64 smn[HWAVES], smx[HWAVES]; __shared__ u64 scn[HWAVES];
@@ -1220,11 +1217,8 @@ __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, con
   const bool probe_outer = (join_type == JT_RIGHT || join_type == JT_FULL);
   const bool want_pairs = (join_type == JT_INNER || join_type == JT_LEFT || join_type == JT_RIGHT || join_type == JT_FULL);
   uint32_t cnt = 0;
-  for (i64 w = w0; w < w1; ++w) {
-    const i64 pos = (w << 6) + hlane();
-    bool active = pos < n;
-    GPUQ_REGS_DECL;
-    if (active) active = GPUQ_EVAL(MAXC, P, pos);
+  // the segment's words in order (pair positions depend on it), two of them with all column loads in flight per step
+  for_rows_in_flight<MAXC>(P, n, w0, 1, [&](const i64, const i64 pos, bool active, GPUQ_REGS_PARAM) {
     uint32_t hit = NIL, prow = (uint32_t)pos;
     if (active) {
       if (payload_via > 0) prow = P.via[payload_via - 1][pos];
@@ -1240,7 +1234,7 @@ __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, con
     else if (join_type == JT_RIGHT_ANTI) emit = active && hit == NIL;
     else emit = want_pairs && active && (hit != NIL || probe_outer);
     cnt += emit_pairs(emit, hit, prow, seg_base, cnt, seg_build, seg_probe);
-  }
+  }, w1);
   if (hlane() == 0) seg_counts[seg] = cnt;
 }
 #endif  // GPUQ_JIT_PROBE1
