@@ -110,6 +110,7 @@ def lib():
         "gpuq_ctx_set_option": (i32, [vp, C.c_char_p, C.c_char_p]),
         "gpuq_ctx_set_jit": (i32, [vp, C.c_char_p, i64]),
         "gpuq_ctx_jit_wait": (i32, [vp]),
+        "gpuq_jit_quiesce": (None, []),
         "gpuq_jit_cache_stats": (i32, [C.POINTER(i32), C.POINTER(i32)]),
         "gpuq_ctx_jit_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]),
         "gpuq_op_jit_source": (i32, [vp, i32, C.c_char_p, C.c_size_t]),
@@ -199,6 +200,8 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     L._gpuq_symbols = sorted(sig)
+    import atexit
+    atexit.register(L.gpuq_jit_quiesce)      # background compiles must not outlive the interpreter (include/gpuq.h)
     _LIB = L
     return L
 

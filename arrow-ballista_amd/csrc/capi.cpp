@@ -1839,6 +1839,7 @@ int gpuq_ctx_set_option(gpuq_ctx* ctx, const char* key, const char* value) {
   });
 }
 int gpuq_ctx_jit_wait(gpuq_ctx* ctx) { return guarded(ctx, [&]() { check_ctx(ctx); jit_drain(); }); }
+void gpuq_jit_quiesce(void) { try { jit_drain(); } catch (...) {} }
 int gpuq_ctx_jit_stats(gpuq_ctx* ctx, int* available, int* launches, char* last_error, size_t cap) {
   if (!ctx) return GPUQ_ERR_INVALID;
   if (available) *available = jit_available() ? 1 : 0;

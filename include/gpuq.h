@@ -115,6 +115,10 @@ int gpuq_ctx_jit_stats(gpuq_ctx* ctx, int* available, int* launches, char* last_
    specialisation; its callers keep running the interpreter kernels until the compiled function is there.  This call waits
    until every compile requested so far has finished (benchmarks call it at the end of their warm-up). */
 int gpuq_ctx_jit_wait(gpuq_ctx* ctx);
+/* Call before the process exits (the Python binding registers it with atexit): waits for background compiles still in flight.  The
+   run-time compiler's libraries are loaded on first use, i.e. after this library registered its own exit handler, so they are torn
+   down first -- a worker thread still inside one of them at that moment takes the process down with it. */
+void gpuq_jit_quiesce(void);
 /* Compiled code objects are kept on disk ($GPUQ_JIT_CACHE_DIR, default $XDG_CACHE_HOME/gpuq-jit or ~/.cache/gpuq-jit; "off"
    disables), keyed by a hash of the whole translation unit, so only the first process on a host pays hiprtc for a pipeline
    (0.3-1.9 s); later processes load the code object (~ms).  Counters of this process: */
