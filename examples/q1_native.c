@@ -109,6 +109,7 @@ int main(int argc, char** argv) {
   gpuq_result_free(res); gpuq_plan_free(plan);
   void* all[9] = {qty, ext, disc, tax, ship, rf, rfo, ls, lso};
   for (int i = 0; i < 9; ++i) gpuq_buffer_free(ctx, all[i]);
+  gpuq_jit_quiesce();      /* no background compile may outlive main (include/gpuq.h) */
   gpuq_ctx_free(ctx);
   free(plan_json);
   return 0;
