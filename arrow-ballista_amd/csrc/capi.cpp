@@ -1381,24 +1381,26 @@ int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t
     if (n == 0) { HIPCHECK(hipMemsetAsync(part_offsets_out, 0, (size_t)(np + 1) * 8, s)); return; }
     if (n >= (1ll << 31)) throw Unsupported("partition of >= 2^31 rows in one call");
     if (!perm_out) throw std::runtime_error("perm_out is NULL");
+    // one 8-byte (partition << 32 | row) record per row; the partition sizes double as the digit counts of the single-read pass
+    // (<= 256 partitions: one pass that reads 8 and writes 4 bytes per row; more: one pass per 8 bits of the partition id)
     u64* pid = (u64*)op->ws[1].ensure((size_t)n * 8);
     u64* pid2 = (u64*)op->ws[2].ensure((size_t)n * 8);
-    uint32_t* ids = (uint32_t*)op->ws[4].ensure((size_t)n * 4);
-    uint32_t* ids2 = (uint32_t*)op->ws[5].ensure((size_t)n * 4);
-    int nblocks; i64 tile; radix_geometry(n, &nblocks, &tile);
-    int32_t* hist = (int32_t*)op->ws[6].ensure(radix_hist_entries(nblocks) * 4 + 16);
-    const size_t swb = exclusive_scan_ws_bytes((i64)radix_hist_entries(nblocks));
-    void* sws = op->ws[7].ensure(swb);
+    uint32_t* counts = (uint32_t*)op->ws[8].ensure((size_t)(np + 1) * 4 + 16);
+    u64* ghist = (u64*)op->ws[6].ensure((size_t)sort_max_passes() * 256 * 8);
+    const size_t lwb = onesweep_ws_bytes(n);
+    void* lws = op->ws[7].ensure(lwb);
     ProfScope ps(op, s);
-    { JitScope js(op, op->prog, 10, n); launch_part_pid(s, P, n, op->keys, np, pid, ids); }
-    launch_part_offsets(s, pid, n, np, (uint32_t*)op->ws[8].ensure((size_t)(np + 1) * 4 + 16), (u64*)part_offsets_out);
+    { JitScope js(op, op->prog, 10, n); launch_part_pid(s, P, n, op->keys, np, pid, nullptr); }
+    launch_part_offsets(s, pid, n, np, counts, (u64*)part_offsets_out, 32);
     int bits = 0; while ((1u << bits) < np) ++bits;
-    for (int sh = 0; sh < bits || sh == 0; sh += 8) {
-      launch_radix_pass(s, pid, ids, n, sh, 0xFFu, pid2, ids2, hist, sws, swb);
-      std::swap(pid, pid2); std::swap(ids, ids2);
-      if (bits == 0) break;
+    const int npass = std::max(1, (bits + 7) / 8);
+    if (npass == 1) launch_counts_to_ghist(s, counts, np, ghist);
+    else launch_radix_ghist(s, pid, n, 32, npass, ghist);
+    for (int p = 0; p < npass; ++p) {
+      const bool final_pass = p + 1 == npass;
+      launch_onesweep_pass(s, pid, nullptr, n, 32 + 8 * p, ghist + (size_t)p * 256, lws, lwb, pid2, final_pass ? perm_out : nullptr, final_pass);
+      std::swap(pid, pid2);
     }
-    HIPCHECK(hipMemcpyAsync(perm_out, ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipGetLastError());
   });
 }

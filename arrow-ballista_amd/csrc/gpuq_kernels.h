@@ -162,7 +162,8 @@ void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpe
 int sort_max_passes();
 void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids, u64* hist, int hist_passes);
 void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, uint32_t nparts, u64* pid_out, uint32_t* ids);
-void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out);
+void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out, int shift);
+void launch_counts_to_ghist(hipStream_t s, const uint32_t* counts, uint32_t np, u64* ghist);
 void launch_gather_u64(hipStream_t s, const u64* src, const uint32_t* idx, i64 n, u64* dst);
 int sort_small_max();
 int sort_direct_max();

@@ -260,6 +260,7 @@ __device__ __forceinline__ void k_part_pid_body(const DevProgram P, const i64 n,
         h = hash_combine(h, isn ? 0 : rlo[r], (K.key_wide[k] && !isn) ? rhi[r] : 0, isn);
       }
     }
+    if (!ids) { pid_out[pos] = ((u64)(h % nparts) << 32) | (u64)(uint32_t)pos; continue; }      // one 8-byte (partition, row) record
     pid_out[pos] = h % nparts;
     ids[pos] = (uint32_t)pos;
   }
@@ -279,12 +280,12 @@ extern "C" __global__ void __launch_bounds__(SBLOCK) gpuq_jit_entry(const DevPro
 // one-block exclusive scan.  (Per-wave global atomics serialise on the handful of counter words: 26 ms
 // for 2^27 rows into 8 partitions.)
 #ifndef GPUQ_JIT
-__global__ void __launch_bounds__(SBLOCK) k_pid_count(const u64* __restrict__ pid, const i64 n, const uint32_t np, uint32_t* __restrict__ counts) {
+__global__ void __launch_bounds__(SBLOCK) k_pid_count(const u64* __restrict__ pid, const i64 n, const uint32_t np, uint32_t* __restrict__ counts, const int shift) {
   extern __shared__ uint32_t hist[];
   const bool lds = np <= 8192;
   if (lds) { for (uint32_t d = threadIdx.x; d < np; d += SBLOCK) hist[d] = 0; __syncthreads(); }
   for (i64 i = (i64)blockIdx.x * SBLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * SBLOCK) {
-    const uint32_t d = (uint32_t)pid[i];
+    const uint32_t d = (uint32_t)(pid[i] >> shift);
     if (lds) atomicAdd(&hist[d], 1u); else atomicAdd(&counts[d], 1u);
   }
   if (lds) { __syncthreads(); for (uint32_t d = threadIdx.x; d < np; d += SBLOCK) { const uint32_t c = hist[d]; if (c) atomicAdd(&counts[d], c); } }
@@ -714,10 +715,17 @@ void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K
 #undef CALL
   }
 }
-void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out) {
+// counts (u32[np]) -> the 256 u64 digit counts of a single 8-bit pass (np <= 256: the digit IS the partition)
+__global__ void __launch_bounds__(RADIX) k_counts_to_ghist(const uint32_t* __restrict__ counts, const uint32_t np, u64* __restrict__ ghist) {
+  ghist[threadIdx.x] = threadIdx.x < np ? (u64)counts[threadIdx.x] : 0;
+}
+void launch_counts_to_ghist(hipStream_t s, const uint32_t* counts, uint32_t np, u64* ghist) {
+  hipLaunchKernelGGL(k_counts_to_ghist, dim3(1), dim3(RADIX), 0, s, counts, np, ghist);
+}
+void launch_part_offsets(hipStream_t s, const u64* pid, i64 n, uint32_t nparts, uint32_t* counts_ws, u64* offsets_out, int shift) {
   (void)hipMemsetAsync(counts_ws, 0, (size_t)(nparts + 1) * 4, s);
   i64 need = (n + SBLOCK - 1) / SBLOCK; const i64 cap = (i64)num_cus() * 8; if (need < 1) need = 1;
-  hipLaunchKernelGGL(k_pid_count, dim3((int)(need < cap ? need : cap)), dim3(SBLOCK), nparts <= 8192 ? (size_t)nparts * 4 : 0, s, pid, n, nparts, counts_ws);
+  hipLaunchKernelGGL(k_pid_count, dim3((int)(need < cap ? need : cap)), dim3(SBLOCK), nparts <= 8192 ? (size_t)nparts * 4 : 0, s, pid, n, nparts, counts_ws, shift);
   hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)counts_ws, nparts, offsets_out);
 }
 void launch_gather_u64(hipStream_t s, const u64* src, const uint32_t* idx, i64 n, u64* dst) {
