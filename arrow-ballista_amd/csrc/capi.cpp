@@ -902,21 +902,24 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         u64 nbk = next_pow2(std::max<u64>(1, (est + per_bucket - 1) / per_bucket)); if (nbk > (1ull << 24)) nbk = 1ull << 24;
         if (n >= (1ll << 20) && nbk < 2048) nbk = 2048;                          // one block per bucket: enough of them to fill the chip
         int bits = 0; while ((1ull << bits) < nbk) ++bits;
-        DevBuf b_bid, b_bid2, b_ids, b_ids2, b_hist, b_scan, b_bounds;
+        // 8-byte (bucket << 32 | row) records, bucketed by single-read radix passes (kernels_sort.hip); the last pass also writes the
+        // row ids the bucket kernel walks
+        DevBuf b_bid, b_bid2, b_ids, b_hist, b_look, b_bounds;
         u64* bid = (u64*)b_bid.ensure((size_t)n * 8); u64* bid2 = (u64*)b_bid2.ensure((size_t)n * 8);
-        uint32_t* ids = (uint32_t*)b_ids.ensure((size_t)n * 4 + 16); uint32_t* ids2 = (uint32_t*)b_ids2.ensure((size_t)n * 4 + 16);
-        int nblocks; i64 tile; radix_geometry(n, &nblocks, &tile);
-        int32_t* hist = (int32_t*)b_hist.ensure(radix_hist_entries(nblocks) * 4 + 16);
-        const size_t swb = exclusive_scan_ws_bytes((i64)radix_hist_entries(nblocks));
-        void* sws = b_scan.ensure(swb);
+        uint32_t* ids = (uint32_t*)b_ids.ensure((size_t)n * 4 + 16);
+        u64* ghist = (u64*)b_hist.ensure((size_t)sort_max_passes() * 256 * 8);
+        const size_t lwb = onesweep_ws_bytes(n);
+        void* lws = b_look.ensure(lwb);
         uint32_t* bounds = (uint32_t*)b_bounds.ensure((size_t)(nbk + 2) * 4);
         reset_flags(op, s);
-        { JitScope js(op, op->prog, 11, n); launch_agg_bucket_id(s, P, n, op->keys, nbk - 1, bid, ids); }
-        for (int sh = 0; sh < bits; sh += 8) {
-          launch_radix_pass(s, bid, ids, n, sh, 0xFFu, bid2, ids2, hist, sws, swb);
-          std::swap(bid, bid2); std::swap(ids, ids2);
+        { JitScope js(op, op->prog, 11, n); launch_agg_bucket_id(s, P, n, op->keys, nbk - 1, bid, nullptr); }
+        const int npass = std::max(1, (bits + 7) / 8);
+        launch_radix_ghist(s, bid, n, 32, npass, ghist);
+        for (int p = 0; p < npass; ++p) {
+          launch_onesweep_pass(s, bid, nullptr, n, 32 + 8 * p, ghist + (size_t)p * 256, lws, lwb, bid2, ids, p + 1 == npass ? 2 : 0);
+          std::swap(bid, bid2);
         }
-        launch_bucket_bounds(s, bid, n, nbk, bounds);
+        launch_bucket_bounds(s, bid, n, nbk, bounds, 32);
         alloc_raw((i64)std::min<u64>((u64)std::max<i64>(n, 1), std::max<u64>(est + est / 4, 1ull << 20)));
         { JitScope js(op, op->prog, 12, n); ProfScope ps(op, s); launch_agg_bucket(s, P, op->keys, op->agg, ids, bounds, (uint32_t)nbk, capslots, slot_words, raw); }
         HIPCHECK(hipGetLastError());
@@ -1302,7 +1305,7 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
       if (np == 0) { if (last_word) HIPCHECK(hipMemcpyAsync(perm_out, ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s)); return; }
       for (int p = 0; p < np; ++p) {
         const bool final_pass = last_word && p + 1 == np;
-        launch_onesweep_pass(s, klo, ids, n, shift0 + 8 * p, ghist + (size_t)(pass0 + p) * 256, lws, lwb, klo2, final_pass ? perm_out : ids2, final_pass);
+        launch_onesweep_pass(s, klo, ids, n, shift0 + 8 * p, ghist + (size_t)(pass0 + p) * 256, lws, lwb, klo2, final_pass ? perm_out : ids2, final_pass ? 1 : 0);
         std::swap(klo, klo2); if (!final_pass) std::swap(ids, ids2);
       }
     };
@@ -1398,7 +1401,7 @@ int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t
     else launch_radix_ghist(s, pid, n, 32, npass, ghist);
     for (int p = 0; p < npass; ++p) {
       const bool final_pass = p + 1 == npass;
-      launch_onesweep_pass(s, pid, nullptr, n, 32 + 8 * p, ghist + (size_t)p * 256, lws, lwb, pid2, final_pass ? perm_out : nullptr, final_pass);
+      launch_onesweep_pass(s, pid, nullptr, n, 32 + 8 * p, ghist + (size_t)p * 256, lws, lwb, pid2, final_pass ? perm_out : nullptr, final_pass ? 1 : 0);
       std::swap(pid, pid2);
     }
     HIPCHECK(hipGetLastError());

@@ -126,7 +126,7 @@ uint32_t agg_lds_slots(const HashTable& T);
 int agg_lds_grid(i64 n);
 void launch_agg_lds(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const AggSpec& A, const HashTable& T, u64* fstage, int n_fsum);
 void launch_agg_bucket_id(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, u64 bucket_mask, u64* bid, uint32_t* ids);
-void launch_bucket_bounds(hipStream_t s, const u64* sorted_bid, i64 n, u64 nbuckets, uint32_t* bounds);
+void launch_bucket_bounds(hipStream_t s, const u64* sorted_bid, i64 n, u64 nbuckets, uint32_t* bounds, int shift);
 void launch_agg_bucket(hipStream_t s, const DevProgram& P, const KeySpec& K, const AggSpec& A, const uint32_t* ids, const uint32_t* bounds, uint32_t nbuckets,
                        uint32_t cap, int slot_words, const AggOut& out);
 void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags);
@@ -169,17 +169,13 @@ int sort_small_max();
 int sort_direct_max();
 void launch_sort_direct(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, uint32_t* perm);
 void launch_sort_small(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, i64 n, uint32_t* out);
-void radix_geometry(i64 n, int* nblocks, i64* tile);
-size_t radix_hist_entries(int nblocks);
 size_t onesweep_ws_bytes(i64 n);
 int onesweep_max_passes();
 void launch_merge_pairs(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, const i64* pairs, int n_pairs, i64 max_len,
                         u64* klo_out, u64* khi_out, uint32_t* ids_out);
 void launch_radix_ghist(hipStream_t s, const u64* keys, i64 n, int shift0, int npasses, u64* ghist);
 void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, u64* gexcl, void* ws, size_t ws_bytes,
-                          u64* keys_out, uint32_t* vals_out, bool ids_only);
-void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, uint32_t mask, u64* keys_out, uint32_t* vals_out,
-                       int32_t* hist, void* scan_ws, size_t scan_ws_bytes);
+                          u64* keys_out, uint32_t* vals_out, int ids_only /* 0 records, 1 row ids only, 2 packed records + row ids */);
 void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, uint32_t n_groups, const AggSoA& soa, const uint32_t* n_groups_dev = nullptr);
 void launch_concat_bitmap(hipStream_t s, u64* dst, i64 dst_bit_offset, const uint8_t* src, i64 src_bit_offset, i64 n_bits);
 void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out, uint32_t* too_long);

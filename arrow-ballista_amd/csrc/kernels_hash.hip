@@ -398,18 +398,18 @@ __device__ __forceinline__ void k_agg_bucket_id_body(const DevProgram P, const i
 #pragma unroll
     for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
     if (pass) make_key(K, GPUQ_REGS, kw, h);
-    bid[pos] = h & bucket_mask;
-    ids[pos] = pass ? (uint32_t)pos : NIL;
+    if (!ids) bid[pos] = ((h & bucket_mask) << 32) | (u64)(pass ? (uint32_t)pos : NIL);      // one 8-byte (bucket, row) record
+    else { bid[pos] = h & bucket_mask; ids[pos] = pass ? (uint32_t)pos : NIL; }
   }
 }
 #ifndef GPUQ_JIT
 template <int MAXC>
 __global__ void __launch_bounds__(HBLOCK) k_agg_bucket_id(const DevProgram P, const i64 n, const KeySpec K, const u64 bucket_mask,
                                                           u64* __restrict__ bid, uint32_t* __restrict__ ids) { k_agg_bucket_id_body<MAXC>(P, n, K, bucket_mask, bid, ids); }
-__global__ void __launch_bounds__(HBLOCK) k_bucket_bounds(const u64* __restrict__ sorted_bid, const i64 n, const u64 nbuckets, uint32_t* __restrict__ bounds) {
+__global__ void __launch_bounds__(HBLOCK) k_bucket_bounds(const u64* __restrict__ sorted_bid, const i64 n, const u64 nbuckets, uint32_t* __restrict__ bounds, const int shift) {
   for (u64 b = (u64)blockIdx.x * HBLOCK + threadIdx.x; b <= nbuckets; b += (u64)gridDim.x * HBLOCK) {
     i64 lo = 0, hi = n;                     // first position whose bucket id is >= b
-    while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (sorted_bid[mid] < b) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const i64 mid = (lo + hi) >> 1; if ((sorted_bid[mid] >> shift) < b) lo = mid + 1; else hi = mid; }
     bounds[b] = (uint32_t)lo;
   }
 }
@@ -1527,9 +1527,9 @@ void launch_agg_bucket_id(hipStream_t s, const DevProgram& P, i64 n, const KeySp
 #undef CALL
   }
 }
-void launch_bucket_bounds(hipStream_t s, const u64* sorted_bid, i64 n, u64 nbuckets, uint32_t* bounds) {
+void launch_bucket_bounds(hipStream_t s, const u64* sorted_bid, i64 n, u64 nbuckets, uint32_t* bounds, int shift) {
   const u64 need = (nbuckets + 1 + HBLOCK - 1) / HBLOCK;
-  hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)(need < 4096 ? need : 4096)), dim3(HBLOCK), 0, s, sorted_bid, n, nbuckets, bounds);
+  hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)(need < 4096 ? need : 4096)), dim3(HBLOCK), 0, s, sorted_bid, n, nbuckets, bounds, shift);
 }
 void launch_agg_bucket(hipStream_t s, const DevProgram& P, const KeySpec& K, const AggSpec& A, const uint32_t* ids, const uint32_t* bounds, uint32_t nbuckets,
                        uint32_t cap, int slot_words, const AggOut& out) {

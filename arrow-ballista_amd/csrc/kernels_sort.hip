@@ -312,131 +312,14 @@ __global__ void __launch_bounds__(SBLOCK) k_gather_u64(const u64* __restrict__ s
 }
 #endif
 
-// ------------------------------------------------------------------ stable radix pass
-// Tile = the contiguous range of a block: each wave owns a contiguous quarter, processed 64 keys
-// at a time, so (block, wave, step, lane) order == input order and the pass is stable.
-// hist layout: [digit][block] (digit-major) so one exclusive scan gives global scatter bases.
-#ifndef GPUQ_JIT
-__global__ void __launch_bounds__(SBLOCK) k_radix_hist(const u64* __restrict__ keys, const i64 n, const int shift, const uint32_t mask,
-                                                       const i64 tile, int32_t* __restrict__ hist, const int nblocks) {
-  __shared__ uint32_t cnt[RADIX];
-  for (int d = threadIdx.x; d < RADIX; d += SBLOCK) cnt[d] = 0;
-  __syncthreads();
-  const i64 a = (i64)blockIdx.x * tile;
-  i64 b = a + tile; if (b > n) b = n;
-  for (i64 i = a + threadIdx.x; i < b; i += SBLOCK) atomicAdd(&cnt[(uint32_t)(keys[i] >> shift) & mask], 1u);
-  __syncthreads();
-  for (int d = threadIdx.x; d < RADIX; d += SBLOCK) hist[(size_t)d * nblocks + blockIdx.x] = (int32_t)cnt[d];
-}
-#endif
-
-#ifndef GPUQ_JIT
-// Scatter with the tile sorted by digit in LDS first, so that a block writes every digit's run as consecutive addresses
-// (a lane-per-key scatter sends each of a wave's 64 stores to a different cache line: 1.1 TB/s on 2^27 rows).
-// The block walks its range in sub-tiles of RTILE keys.  Per sub-tile: every wave owns a contiguous quarter and takes it
-// in RROUNDS steps of 64 keys held in registers; a match-any over the digit bits gives each key its stable rank inside
-// the step, per-(wave, digit) counters in LDS carry the ranks across steps; one 256-wide scan turns the counters into
-// tile-local positions; keys and values go to their sorted place in LDS and are written out position by position.
-// Order inside a digit = (block, sub-tile, wave, step, lane) = input order: the pass is stable.
-constexpr int RROUNDS = 16;
-constexpr int RTILE = SBLOCK * RROUNDS;            // 4096 keys: 32 KB keys + 16 KB values in LDS
-__global__ void __launch_bounds__(SBLOCK) k_radix_scatter(const u64* __restrict__ keys, const uint32_t* __restrict__ vals, const i64 n,
-                                                          const int shift, const uint32_t mask, const i64 tile,
-                                                          const int32_t* __restrict__ offsets, const int nblocks,
-                                                          u64* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-  __shared__ u64 sk[RTILE];
-  __shared__ uint32_t sv[RTILE];
-  __shared__ uint32_t wcnt[SWAVES][RADIX];   // per-wave digit counts of the sub-tile, then the waves' start positions
-  __shared__ uint32_t dstart[RADIX];         // tile-local start of every digit
-  __shared__ uint32_t gbase[RADIX];          // global position of the next key of every digit
-  __shared__ uint32_t wsum[SWAVES];
-  const int t = threadIdx.x, w = swave(), l = slane();
-  const u64 lt = (1ull << l) - 1;
-  for (int d = t; d < RADIX; d += SBLOCK) gbase[d] = (uint32_t)offsets[(size_t)d * nblocks + blockIdx.x];
-  const i64 a = (i64)blockIdx.x * tile;
-  i64 b = a + tile; if (b > n) b = n;
-  for (i64 s0 = a; s0 < b; s0 += RTILE) {
-    for (int i = t; i < SWAVES * RADIX; i += SBLOCK) (&wcnt[0][0])[i] = 0;
-    __syncthreads();
-    // 1. load the wave's quarter, rank every key inside its (wave, digit) sequence
-    const i64 w0 = s0 + (i64)w * (RTILE / SWAVES);
-    u64 k[RROUNDS]; uint32_t v[RROUNDS]; uint32_t pos[RROUNDS];
-#pragma unroll
-    for (int r = 0; r < RROUNDS; ++r) {
-      const i64 i = w0 + r * 64 + l;
-      const bool act = i < b;
-      k[r] = act ? keys[i] : 0; v[r] = act ? vals[i] : 0;
-    }
-#pragma unroll
-    for (int r = 0; r < RROUNDS; ++r) {
-      const i64 i = w0 + r * 64 + l;
-      const bool act = i < b;
-      const uint32_t d = (uint32_t)(k[r] >> shift) & mask;
-      u64 same = __ballot(act);
-#pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
-        const u64 m = __ballot((d >> bit) & 1);
-        same &= ((d >> bit) & 1) ? m : ~m;
-      }
-      const uint32_t before = act ? wcnt[w][d] : 0;
-      pos[r] = before + (uint32_t)__popcll(same & lt);
-      __builtin_amdgcn_wave_barrier();
-      if (act && (same >> l) <= 1ull) wcnt[w][d] = before + (uint32_t)__popcll(same);   // highest lane of each digit group
-      __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    // 2. tile-local layout: digit-major, wave-minor (t == digit)
-    {
-      uint32_t c[SWAVES]; uint32_t tot = 0;
-#pragma unroll
-      for (int q = 0; q < SWAVES; ++q) { c[q] = wcnt[q][t]; tot += c[q]; }
-      uint32_t x = tot;                           // inclusive scan over the block's 256 digits
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (l >= off) x += y; }
-      if (l == 63) wsum[w] = x;
-      __syncthreads();
-      uint32_t pre = 0;
-#pragma unroll
-      for (int q = 0; q < SWAVES; ++q) if (q < w) pre += wsum[q];
-      const uint32_t ds = pre + x - tot;
-      dstart[t] = ds;
-      uint32_t run = ds;
-#pragma unroll
-      for (int q = 0; q < SWAVES; ++q) { wcnt[q][t] = run; run += c[q]; }
-    }
-    __syncthreads();
-    // 3. keys to their sorted place in LDS
-#pragma unroll
-    for (int r = 0; r < RROUNDS; ++r) {
-      const i64 i = w0 + r * 64 + l;
-      if (i < b) { const uint32_t d = (uint32_t)(k[r] >> shift) & mask; const uint32_t j = wcnt[w][d] + pos[r]; sk[j] = k[r]; sv[j] = v[r]; }
-    }
-    __syncthreads();
-    // 4. out, position by position: neighbouring lanes hold neighbouring keys of the same digit
-    const int cnt = (int)((b - s0) < RTILE ? (b - s0) : RTILE);
-#pragma unroll 4
-    for (int j = t; j < cnt; j += SBLOCK) {
-      const u64 kk = sk[j];
-      const uint32_t d = (uint32_t)(kk >> shift) & mask;
-      const uint32_t dst = gbase[d] + ((uint32_t)j - dstart[d]);
-      keys_out[dst] = kk; vals_out[dst] = sv[j];
-    }
-    __syncthreads();
-    // 5. advance the global bases by the sub-tile's digit totals
-    {
-      const uint32_t nxt = (t + 1 < RADIX) ? dstart[t + 1] : (uint32_t)cnt;
-      gbase[t] += nxt - dstart[t];
-    }
-    __syncthreads();
-  }
-}
-#endif
-
 #ifndef GPUQ_JIT
 // ------------------------------------------------------------------ single-read radix passes (decoupled look-back)
-// The hist + scan + scatter pass above reads every key twice.  For SortExec the digit histograms of ALL passes are taken in one
-// read up front (k_radix_ghist: the global count of a digit does not depend on the order of the keys), and a pass is then ONE
-// kernel that reads a tile once: it ranks the tile in LDS as k_radix_scatter does, publishes the tile's per-digit counts, and
+// A classic radix pass (histogram, scan, scatter) reads every key twice; round 1 shipped that form.  Here the digit counts of ALL
+// passes are taken while the records are written (the pack kernel; k_radix_ghist for records that come from elsewhere: the count of
+// a digit does not depend on the order of the keys), and a pass is ONE kernel that reads a tile once: every wave ranks its keys
+// inside (wave, digit) sequences with match-any ballots, per-(wave, digit) counters in LDS carry the ranks across steps, one scan
+// over the 256 digits gives tile-local positions, records go to their sorted place in LDS and are written out position by position
+// (neighbouring lanes hold neighbouring records of one digit: coalesced runs).  The tile publishes its per-digit counts and
 // learns the counts of the tiles before it by looking back over their published words (aggregate of one tile, or inclusive prefix
 // of all tiles up to it) instead of waiting for a separate scan [UPSTREAM-KNOWLEDGE: Merrill & Garland's decoupled look-back /
 // Adinets & Merrill's Onesweep].  Tiles are handed out by a ticket counter, so every tile a block waits for has already started:
@@ -586,8 +469,9 @@ __global__ void __launch_bounds__(SBLOCK) k_onesweep(const u64* __restrict__ key
     const u64 kk = sk[j];
     const uint32_t d = (uint32_t)(kk >> shift) & 0xFFu;
     const u64 dst = gbase[d] + (u64)((uint32_t)j - dstart[d]);
-    if (ids_only) vals_out[dst] = HASVAL ? sv[j] : (uint32_t)kk;
-    else { keys_out[dst] = kk; if (HASVAL) vals_out[dst] = sv[j]; }
+    // ids_only: 0 = records (and values), 1 = row ids only (a sort's last pass), 2 = packed records AND their row ids
+    if (ids_only != 1) { keys_out[dst] = kk; if (HASVAL) vals_out[dst] = sv[j]; }
+    if (ids_only != 0 && (ids_only == 1 || !HASVAL)) vals_out[dst] = HASVAL ? sv[j] : (uint32_t)kk;
   }
 }
 #endif
@@ -733,23 +617,6 @@ void launch_gather_u64(hipStream_t s, const u64* src, const uint32_t* idx, i64 n
   i64 need = (n + SBLOCK - 1) / SBLOCK; const i64 cap = (i64)num_cus() * 16;
   hipLaunchKernelGGL(k_gather_u64, dim3((int)(need < cap ? need : cap)), dim3(SBLOCK), 0, s, src, idx, n, dst);
 }
-void radix_geometry(i64 n, int* nblocks, i64* tile) {
-  // tiles of >= 4096 keys, at most 8 blocks per CU
-  i64 t = 4096; const i64 maxb = (i64)num_cus() * 8;
-  while ((n + t - 1) / t > maxb) t *= 2;
-  *tile = t; *nblocks = (int)((n + t - 1) / t); if (*nblocks < 1) *nblocks = 1;
-}
-size_t radix_hist_entries(int nblocks) { return (size_t)RADIX * nblocks + 1; }
-void launch_radix_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, uint32_t mask, u64* keys_out, uint32_t* vals_out,
-                       int32_t* hist, void* scan_ws, size_t scan_ws_bytes) {
-  if (n <= 0) return;
-  int nblocks; i64 tile; radix_geometry(n, &nblocks, &tile);
-  hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(SBLOCK), 0, s, keys, n, shift, mask, tile, hist, nblocks);
-  launch_exclusive_scan_i32(s, hist, (i64)RADIX * nblocks, scan_ws, scan_ws_bytes);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(SBLOCK), 0, s, keys, vals, n, shift, mask, tile, (const int32_t*)hist, nblocks,
-                     keys_out, vals_out);
-}
-
 // ------------------------------------------------------------------ small inputs: one block, bitonic network in LDS
 // Replaces the radix passes (5 launches per 8 key bits) when the whole input fits one block: the sort of a final
 // aggregate's handful of groups (q1: 4 rows) is pure launch latency otherwise.  Order = (composite key, row id): the row
@@ -806,7 +673,7 @@ void launch_radix_ghist(hipStream_t s, const u64* keys, i64 n, int shift0, int n
 }
 // one stable 8-bit pass; vals == NULL: packed (key << 32 | row) records; ids_only: only vals_out is written (the last pass)
 void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, u64* gexcl, void* ws, size_t ws_bytes,
-                          u64* keys_out, uint32_t* vals_out, bool ids_only) {
+                          u64* keys_out, uint32_t* vals_out, int ids_only) {
   if (n <= 0) return;
   const int rounds = vals ? OS_ROUNDS_KV : OS_ROUNDS_PACKED;
   const i64 tile = (i64)SBLOCK * rounds;
@@ -814,8 +681,8 @@ void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, 
   (void)hipMemsetAsync(ws, 0, ws_bytes, s);
   u64* look = (u64*)ws; uint32_t* ticket = (uint32_t*)((char*)ws + (size_t)tiles * RADIX * 8);
   hipLaunchKernelGGL(k_radix_ghist_scan, dim3(1), dim3(RADIX), 0, s, gexcl);      // this pass's counts (taken by the pack kernel) -> bases
-  if (vals) hipLaunchKernelGGL((k_onesweep<true, OS_ROUNDS_KV>), dim3((unsigned)tiles), dim3(SBLOCK), 0, s, keys, vals, n, shift, (const u64*)gexcl, look, ticket, keys_out, vals_out, ids_only ? 1 : 0);
-  else hipLaunchKernelGGL((k_onesweep<false, OS_ROUNDS_PACKED>), dim3((unsigned)tiles), dim3(SBLOCK), 0, s, keys, vals, n, shift, (const u64*)gexcl, look, ticket, keys_out, vals_out, ids_only ? 1 : 0);
+  if (vals) hipLaunchKernelGGL((k_onesweep<true, OS_ROUNDS_KV>), dim3((unsigned)tiles), dim3(SBLOCK), 0, s, keys, vals, n, shift, (const u64*)gexcl, look, ticket, keys_out, vals_out, ids_only);
+  else hipLaunchKernelGGL((k_onesweep<false, OS_ROUNDS_PACKED>), dim3((unsigned)tiles), dim3(SBLOCK), 0, s, keys, vals, n, shift, (const u64*)gexcl, look, ticket, keys_out, vals_out, ids_only);
 }
 
 // one round: n_pairs triples in `pairs` (device), the longest pair has max_len records
