@@ -16,7 +16,7 @@ struct gpuq_ctx {
   std::string last_jit_error;       // auto mode: why the last specialisation fell back to the interpreter kernels
   int jit_launches = 0;
   int join_dense = 1;               // direct-addressed join tables for one narrow key of bounded range (gpuq_ctx_set_option "join_dense")
-  i64 join_dense_ratio = 128;       // ... while range <= ratio x keys
+  i64 join_dense_ratio = 4096;      // ... while range <= ratio x keys (sparse domains sit behind a presence bitmap: nothing but the bitmap is initialised)
   int join_radix = 0;               // partitioned probe over a direct-addressed table: 0 off (default: measured 1.0-1.16x, pairs
                                     // leave probe order -- DESIGN.md section 3), 1 auto, 2 force ("join_radix")
   int join_radix_slice_log2 = 18;   // table entries per partition slice (2^18 x 4 B = 1 MiB: an XCD's L2 holds a few)

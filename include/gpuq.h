@@ -94,7 +94,7 @@ const char* gpuq_last_error(gpuq_ctx* ctx);
 int gpuq_ctx_device_info(gpuq_ctx* ctx, char* buf, size_t cap); /* JSON: name, arch, cus, hbm_bytes */
 /* Tuning switches (strings): "join_dense" = "0" | "1" (default 1; env GPUQ_JOIN_DENSE at ctx creation): join tables over ONE
    Int32 / Int64 / Date32 key whose build values span a bounded range are direct-addressed arrays instead of hash tables;
-   "join_dense_ratio" = largest range / key-count ratio that still takes the array (default 128);
+   "join_dense_ratio" = largest range / key-count ratio that still takes the array (default 4096);
    "join_radix" = "off" | "auto" | "force": partitioned probe (one LDS-staged radix pass over the probe rows on the high bits of
    key - min, then lookups that stay inside one L2-sized slice of the array at a time) for Inner / RightSemi joins over such
    an array; the pairs then come out in partition order instead of probe order.  Default "off": on MI355X the pass costs about
