@@ -862,7 +862,10 @@ struct HashJoinExec : PNode {
       const auto ln = names_of(L.t);
       Json lk = jarr();
       for (auto& o : on_eff.a) lk.a.push_back(rebind(o.at("left"), ln));
-      std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(L.t)}})}, {"on", lk}, {"null_equals_null", jbool(null_equals_null)}};
+      // only Left / Full / LeftSemi / LeftAnti ask the table for its build side's rows afterwards
+      const bool side_rows = jt == "Left" || jt == "Full" || jt == "LeftSemi" || jt == "LeftAnti";
+      std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(L.t)}})}, {"on", lk}, {"null_equals_null", jbool(null_equals_null)},
+                                                     {"build_side_rows", jbool(side_rows)}};
       if (L.has_pred) bd.push_back({"predicate", rebind(L.pred, ln)});
       return jobj(bd);
     });

@@ -214,7 +214,8 @@ const char* gpuq_scan_last_error(void);
      "project"     ProjectionExec    {input, exprs:[{expr,name}]}
      "aggregate"   AggregateExec     {input, mode:Partial|Final|FinalPartitioned|Single, group_expr:[{expr,name}],
                                       aggr_expr:[{fn:SUM|AVG|COUNT|MIN|MAX, expr, name}], predicate?, strategy?:auto|tiny|hash|lds|radix, expected_groups?}
-     "join_build"  HashJoinExec build (left) side  {input, on:[expr], predicate?, null_equals_null?}
+     "join_build"  HashJoinExec build (left) side  {input, on:[expr], predicate?, null_equals_null?,
+                                                     build_side_rows?: false = gpuq_join_build_side_rows will not be called (Inner / Right / RightSemi / RightAnti)}
      "join_probe"  HashJoinExec probe (right) side {input, on:[expr], predicate?, join_type, null_equals_null?}
      "sort"        SortExec          {input, expr:[{expr, asc, nulls_first}], fetch?}
      "partition"   BatchPartitioner  {input, hash_expr:[expr], partition_count}
