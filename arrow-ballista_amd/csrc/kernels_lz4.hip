@@ -379,8 +379,18 @@ __global__ __launch_bounds__(256) void k_utf8_piece_compact(const Utf8Piece* __r
 // bytes (uniform loads), literals and copies are moved by all lanes; a copy whose offset is shorter than its length repeats the
 // period (source byte i % offset lies before the copy).  mode 0 = stored (plain copy).  `raw_prefix` bytes in front of the
 // compressed stream are copied verbatim (a v2 data page's levels).
+// The element stream is read through a 4 KiB window in LDS (refilled with coalesced 16-byte loads) and the last 32 KiB of output
+// are mirrored in an LDS ring: a tag byte or a short back-reference fetched from global memory costs a full L2 round trip
+// (~0.7 us, and a copy's source was written only moments ago).  Copies that reach further back than the ring read global memory.
+// What remains is the serial element chain itself: sorted / low-entropy numeric columns compress into one or two elements per VALUE
+// (a 1 MB page of ascending int64 keys is ~260 K elements), a few LDS round trips each: ~10 MB/s per wave, i.e. the decoder's
+// throughput is the number of pages in flight (SF1 lineitem, 110 pages of 1 MB: 117 ms -- the host's 93 ms on 256 threads;
+// a wide copy for literals made it slower, the literals are short).
+constexpr int SNAPPY_INWIN = 4096, SNAPPY_RING = 32768;
 __global__ __launch_bounds__(64) void k_unpack_pages(const uint8_t* __restrict__ src_base, uint8_t* __restrict__ dst_base, const UnpackJob* __restrict__ jobs, int n_jobs,
                                                      uint32_t* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) uint8_t inw[SNAPPY_INWIN + 16];
+  __shared__ uint8_t ring[SNAPPY_RING];
   const int u = (int)blockIdx.x;
   if (u >= n_jobs) return;
   const UnpackJob J = jobs[u];
@@ -395,35 +405,55 @@ __global__ __launch_bounds__(64) void k_unpack_pages(const uint8_t* __restrict__
     for (int64_t i = lane; i < in_len; i += 64) out[i] = in[i];
     return;
   }
+  // input window: bytes [wbase, wbase + SNAPPY_INWIN) of `in`
+  int64_t wbase = -(int64_t)SNAPPY_INWIN - 16;
+  auto want = [&](int64_t pos, int nbytes) {      // wave-uniform
+    if (pos >= wbase && pos + nbytes <= wbase + SNAPPY_INWIN) return;
+    wbase = pos;
+    for (int j = lane * 16; j < SNAPPY_INWIN; j += 64 * 16) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (wbase + j + 16 <= in_len) __builtin_memcpy(&v, in + wbase + j, 16);
+      else for (int q = 0; q < 16; ++q) if (wbase + j + q < in_len) ((uint8_t*)&v)[q] = in[wbase + j + q];
+      *(uint4*)(inw + j) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+  };
+  auto ib = [&](int64_t pos) -> uint32_t { return inw[pos - wbase]; };
   int64_t ip = 0, op = 0;
+  bool bad = false;
   // preamble: uncompressed length
-  uint64_t ulen = 0; int sh = 0; bool bad = false;
-  for (;;) { if (ip >= in_len || sh > 35) { bad = true; break; } const uint8_t c = in[ip++]; ulen |= (uint64_t)(c & 0x7F) << sh; if (!(c & 0x80)) break; sh += 7; }
+  want(0, 8);
+  uint64_t ulen = 0; int sh = 0;
+  for (;;) { if (ip >= in_len || sh > 35) { bad = true; break; } const uint32_t c = ib(ip++); ulen |= (uint64_t)(c & 0x7F) << sh; if (!(c & 0x80)) break; sh += 7; }
   if (bad || (int64_t)ulen != out_len) { if (lane == 0) atomicOr(status, 1u); return; }
   while (ip < in_len) {
-    const uint32_t tag = in[ip++];
+    want(ip, 5);                                       // a tag and up to four length / offset bytes
+    const uint32_t tag = ib(ip++);
     int64_t len; int64_t off = 0;
     if ((tag & 3) == 0) {
       len = (int64_t)(tag >> 2) + 1;
       if (len > 60) {
         const int nb = (int)len - 60;
         if (ip + nb > in_len) { bad = true; break; }
-        uint32_t v = 0; for (int k = 0; k < nb; ++k) v |= (uint32_t)in[ip + k] << (8 * k);
+        uint32_t v = 0; for (int k = 0; k < nb; ++k) v |= ib(ip + k) << (8 * k);
         ip += nb; len = (int64_t)v + 1;
       }
       if (len > in_len - ip || len > out_len - op) { bad = true; break; }
-      for (int64_t i = lane; i < len; i += 64) out[op + i] = in[ip + i];
+      for (int64_t i = lane; i < len; i += 64) { const uint8_t b = in[ip + i]; out[op + i] = b; ring[(op + i) & (SNAPPY_RING - 1)] = b; }
       ip += len; op += len;
       continue;
     }
-    if ((tag & 3) == 1) { if (ip + 1 > in_len) { bad = true; break; } len = 4 + ((tag >> 2) & 7); off = (int64_t)((tag >> 5) << 8) | in[ip]; ip += 1; }
-    else if ((tag & 3) == 2) { if (ip + 2 > in_len) { bad = true; break; } len = (int64_t)(tag >> 2) + 1; off = (int64_t)in[ip] | ((int64_t)in[ip + 1] << 8); ip += 2; }
-    else { if (ip + 4 > in_len) { bad = true; break; } len = (int64_t)(tag >> 2) + 1; off = (int64_t)in[ip] | ((int64_t)in[ip + 1] << 8) | ((int64_t)in[ip + 2] << 16) | ((int64_t)in[ip + 3] << 24); ip += 4; }
+    if ((tag & 3) == 1) { if (ip + 1 > in_len) { bad = true; break; } len = 4 + ((tag >> 2) & 7); off = (int64_t)((tag >> 5) << 8) | ib(ip); ip += 1; }
+    else if ((tag & 3) == 2) { if (ip + 2 > in_len) { bad = true; break; } len = (int64_t)(tag >> 2) + 1; off = (int64_t)ib(ip) | ((int64_t)ib(ip + 1) << 8); ip += 2; }
+    else { if (ip + 4 > in_len) { bad = true; break; } len = (int64_t)(tag >> 2) + 1; off = (int64_t)ib(ip) | ((int64_t)ib(ip + 1) << 8) | ((int64_t)ib(ip + 2) << 16) | ((int64_t)ib(ip + 3) << 24); ip += 4; }
     if (off == 0 || off > op || len > out_len - op) { bad = true; break; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // earlier stores of this wave are visible to its loads
-    const uint8_t* m = out + op - off;
-    if (off >= len) { for (int64_t i = lane; i < len; i += 64) out[op + i] = m[i]; }
-    else { for (int64_t i = lane; i < len; i += 64) out[op + i] = m[i % off]; }
+    const bool near = off + 64 <= SNAPPY_RING;         // every source byte is still in the ring (a copy is at most 64 bytes long)
+    for (int64_t i = lane; i < len; i += 64) {
+      const int64_t sp = op - off + (off >= len ? i : i % off);
+      const uint8_t b = near ? ring[sp & (SNAPPY_RING - 1)] : out[sp];
+      out[op + i] = b; ring[(op + i) & (SNAPPY_RING - 1)] = b;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     op += len;
   }
