@@ -512,6 +512,36 @@ def sort_micro(tc, T, g, log2n=27, reps=5):
     return out
 
 
+def merge_micro(tc, T, g, log2n=27, runs=8, reps=3):
+    """Ordered fan-in alone (gpuq_merge_run behind CoalesceTasksExec with an order): `runs` partitions of 2^log2n / runs rows, each
+    already sorted by l_extendedprice, merged into one order; next to it the stable sort of their concatenation (what round 1 did)."""
+    from arrow_ballista_amd.expr import col
+    n = (1 << log2n) // runs
+    order = lambda s: [{"expr": col("l_extendedprice", s), "asc": True, "nulls_first": False}]
+    parts = []
+    for r in range(runs):
+        li = T.gen_lineitem_device(tc, n, columns=("l_orderkey", "l_extendedprice"), row0=r * n)
+        src = g.MemoryExec([li])
+        parts.append(g.plan.materialize(tc, g.SortExec(order(src.schema()), src).execute(0, tc), force=True))
+    src = g.MemoryExec(parts)
+    s = src.schema()
+    out = {"rows": n * runs, "runs": runs}
+    for name, plan in (("merge", g.CoalesceTasksExec(src, list(range(runs)), order_by=order(s))),
+                       ("concat_then_sort", g.SortExec(order(s), g.CoalescePartitionsExec(src)))):
+        native = g.NativePlan(plan, tc)
+        for _ in range(2):
+            native.execute(0)
+        tc.ctx.jit_wait()
+        best = None
+        for _ in range(reps):
+            _sync(tc); t0 = time.perf_counter(); res = native.execute(0); _sync(tc)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+            del res
+        out[name] = {"ms": best * 1e3, "rows_per_s": n * runs / best}
+    return out
+
+
 def scan_decode(tc, T, g, sf=1):
     """the CsvExec / ParquetExec leaves.  lineitem's 9 generated columns at `sf` as (a) '|' text as dbgen
     writes it, (b) Parquet as the reference's `convert --compression none` writes it (dictionary pages where they pay), both in
@@ -609,6 +639,11 @@ if __name__ == "__main__":
         i = sys.argv.index("--sort")
         bits = int(sys.argv[i + 1]) if len(sys.argv) > i + 1 and sys.argv[i + 1].isdigit() else 27
         print(json.dumps(sort_micro(tc, T, g, bits), indent=1))
+        sys.exit(0)
+    if "--merge" in sys.argv:
+        i = sys.argv.index("--merge")
+        bits = int(sys.argv[i + 1]) if len(sys.argv) > i + 1 and sys.argv[i + 1].isdigit() else 27
+        print(json.dumps(merge_micro(tc, T, g, bits), indent=1))
         sys.exit(0)
     if "--scan" in sys.argv:
         sf = 10 if "--sf10" in sys.argv else 1

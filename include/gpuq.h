@@ -295,7 +295,9 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
    `in` is the concatenation of n_runs runs, run r = rows [run_offsets[r], run_offsets[r+1]) (host array of n_runs + 1 entries,
    empty runs allowed), each already in the order of `op` (a "sort" operator).  Writes the permutation of the merged order; equal
    keys keep (run, row) order, i.e. the result equals the stable sort of the concatenation.  log2(n_runs) merge-path rounds on the
-   device, one read + one write of the (key, row) records per round.  Runs that are NOT sorted give an unspecified permutation. */
+   device, one read + one write of the (key, row) records per round -- or, when the packed key is so narrow that its radix passes
+   cost less than the rounds (many runs, <= 32 key bits), those passes: the permutation is the same.  Runs that are NOT sorted
+   give an unspecified permutation through the rounds. */
 int gpuq_merge_run(gpuq_op* op, void* stream, const gpuq_input* in, const int64_t* run_offsets, int n_runs, uint32_t* perm_out);
 
 /* Hash repartition (BatchPartitioner::partition call site, shuffle_writer.rs:336-391):

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 2 step ah: ordered fan-in chooses rounds or passes by cost: parity + micro
+set -o pipefail
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+O=gpurun_out/r02ah; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_sort.py tests/test_gpu_native_plan.py tests/test_gpu_operators.py tests/test_gpu_distributed.py -q -m gpu -k "merge or sort or coalesce or fan_in or distributed" > $O/tests.log 2>&1 || { grep -E "^E  |^FAILED|Error" $O/tests.log | head -40; tail -5 $O/tests.log; exit 1; }
+tail -2 $O/tests.log
+timeout -k 10 600 python bench_extras.py --merge 27 > $O/merge.json 2> $O/merge.err || { tail -20 $O/merge.err; exit 1; }
+cat $O/merge.json | tr -d "\n "
