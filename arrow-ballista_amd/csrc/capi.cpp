@@ -1357,14 +1357,15 @@ int gpuq_merge_run(gpuq_op* op, void* stream, const gpuq_input* in, const int64_
     int total = 0;
     const SortPack K = sort_key_plan(op, s, P, n, &total);
     // Rounds or passes?  Both give the same permutation (the stable sort of the concatenation IS the merge that prefers the lower
-    // run on ties).  Measured at 2^27 records: a merge-path round 2.0 ms (2.6 with a two-word key), a radix pass 0.65 ms on packed
+    // run on ties).  Measured at 2^27 records: a merge-path round 1.45 ms (est. 1.9 with a two-word key), a radix pass 0.65 ms on packed
     // 8-byte records (<= 32 key bits), 1.0 ms otherwise.  Few runs and wide keys merge; many runs of narrow keys take the passes.
     {
       int live = 0; for (int r = 0; r < n_runs; ++r) live += run_offsets[r + 1] > run_offsets[r];
       int rounds = 0; while ((1 << rounds) < live) ++rounds;
-      const double est_merge = rounds * (total > 64 ? 2.6 : 2.0);
+      const double est_merge = rounds * (total > 64 ? 1.9 : 1.45);
       const double est_passes = ((total + 7) / 8) * (total <= 32 ? 0.65 : 1.0) + (total > 64 ? 1.0 : 0.0);
-      if (live > 1 && est_passes < est_merge) { sort_with_plan(op, s, P, n, K, total, perm_out); return; }
+      static const bool force_rounds = []() { const char* e = std::getenv("GPUQ_MERGE_ROUNDS"); return e && std::string(e) == "force"; }();      // measurement switch
+      if (live > 1 && est_passes < est_merge && !force_rounds) { sort_with_plan(op, s, P, n, K, total, perm_out); return; }
     }
     u64* klo = (u64*)op->ws[1].ensure((size_t)n * 8);
     u64* klo2 = (u64*)op->ws[2].ensure((size_t)n * 8);
@@ -1388,7 +1389,8 @@ int gpuq_merge_run(gpuq_op* op, void* stream, const gpuq_input* in, const int64_
       HIPCHECK(hipStreamSynchronize(s));      // the previous round has read its descriptors
       HIPCHECK(hipMemcpyAsync(dpairs, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, s));
       HIPCHECK(hipStreamSynchronize(s));      // (pageable source)
-      launch_merge_pairs(s, klo, khi, ids, dpairs, (int)(pairs.size() / 3), max_len, klo2, khi2, ids2);
+      i64* splits = (i64*)op->ws[0].ensure(merge_splits_entries(max_len, (int)(pairs.size() / 3)) * 8 + 64);
+      launch_merge_pairs(s, klo, khi, ids, dpairs, (int)(pairs.size() / 3), max_len, splits, klo2, khi2, ids2);
       std::swap(klo, klo2); std::swap(khi, khi2); std::swap(ids, ids2);
       bounds.swap(next);
     }

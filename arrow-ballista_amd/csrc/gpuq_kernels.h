@@ -171,7 +171,8 @@ void launch_sort_direct(hipStream_t s, const DevProgram& P, i64 n, const SortSpe
 void launch_sort_small(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, i64 n, uint32_t* out);
 size_t onesweep_ws_bytes(i64 n);
 int onesweep_max_passes();
-void launch_merge_pairs(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, const i64* pairs, int n_pairs, i64 max_len,
+size_t merge_splits_entries(i64 max_len, int n_pairs);
+void launch_merge_pairs(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, const i64* pairs, int n_pairs, i64 max_len, i64* splits,
                         u64* klo_out, u64* khi_out, uint32_t* ids_out);
 void launch_radix_ghist(hipStream_t s, const u64* keys, i64 n, int shift0, int npasses, u64* ghist);
 void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, u64* gexcl, void* ws, size_t ws_bytes,

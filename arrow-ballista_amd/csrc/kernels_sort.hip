@@ -499,12 +499,31 @@ __device__ __forceinline__ int merge_path(const int d, const int na, const int n
   }
   return lo;
 }
+// Tile boundaries along the merge path, ALL tiles of a round at once: one thread per (pair, tile) runs the ~26-step binary search
+// over global memory.  Inside the merge kernel the same search was a serial 20 us in front of every tile (two threads, dependent
+// loads): 1.3 of a round's 2.0 ms at 2^27 records.
+template <bool WIDE>
+__global__ void __launch_bounds__(SBLOCK) k_merge_partition(const u64* __restrict__ klo, const u64* __restrict__ khi, const i64* __restrict__ pairs, const int tiles_per_pair,
+                                                            i64* __restrict__ splits) {
+  const int t = blockIdx.x * SBLOCK + threadIdx.x;
+  if (t > tiles_per_pair) return;                      // tiles_per_pair + 1 boundaries per pair
+  const i64 a0 = pairs[3 * blockIdx.y], a1 = pairs[3 * blockIdx.y + 1], a2 = pairs[3 * blockIdx.y + 2];
+  const i64 na = a1 - a0, nb = a2 - a1;
+  i64 d = (i64)t * MTILE; if (d > na + nb) d = na + nb;
+  i64 lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+  while (lo < hi) {
+    const i64 mid = (lo + hi) >> 1;
+    const MKey ka{WIDE ? khi[a0 + mid] : 0, klo[a0 + mid]}, kb{WIDE ? khi[a1 + d - 1 - mid] : 0, klo[a1 + d - 1 - mid]};
+    if (mk_le(ka, kb)) lo = mid + 1; else hi = mid;
+  }
+  splits[(size_t)blockIdx.y * (size_t)(tiles_per_pair + 1) + t] = lo;
+}
 // pairs[p] = {a0, a1, a2}: runs [a0, a1) and [a1, a2) of the input become one run at the same place of the output (a1 == a2: copy)
 template <bool WIDE>
 __global__ void __launch_bounds__(SBLOCK) k_merge_pairs(const u64* __restrict__ klo, const u64* __restrict__ khi, const uint32_t* __restrict__ ids, const i64* __restrict__ pairs,
+                                                        const i64* __restrict__ splits, const int tiles_per_pair,
                                                         u64* __restrict__ klo_out, u64* __restrict__ khi_out, uint32_t* __restrict__ ids_out) {
   __shared__ u64 slo[MTILE]; __shared__ u64 shi[WIDE ? MTILE : 1]; __shared__ uint32_t sid[MTILE];
-  __shared__ i64 s_split[2];
   const i64 a0 = pairs[3 * blockIdx.y], a1 = pairs[3 * blockIdx.y + 1], a2 = pairs[3 * blockIdx.y + 2];
   const i64 na = a1 - a0, nb = a2 - a1;
   const i64 d0 = (i64)blockIdx.x * MTILE;
@@ -512,15 +531,9 @@ __global__ void __launch_bounds__(SBLOCK) k_merge_pairs(const u64* __restrict__ 
   const i64 d1 = d0 + MTILE < na + nb ? d0 + MTILE : na + nb;
   auto gA = [&](i64 i) -> MKey { return MKey{WIDE ? khi[a0 + i] : 0, klo[a0 + i]}; };
   auto gB = [&](i64 i) -> MKey { return MKey{WIDE ? khi[a1 + i] : 0, klo[a1 + i]}; };
-  // 1. the tile's slices of both runs (global binary searches along the merge path: two threads)
-  if (threadIdx.x < 2) {
-    const i64 d = threadIdx.x == 0 ? d0 : d1;
-    i64 lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
-    while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (mk_le(gA(mid), gB(d - 1 - mid))) lo = mid + 1; else hi = mid; }
-    s_split[threadIdx.x] = lo;
-  }
-  __syncthreads();
-  const i64 i0 = s_split[0], i1 = s_split[1];
+  // 1. the tile's slices of both runs: the boundaries k_merge_partition found
+  const i64* sp = splits + (size_t)blockIdx.y * (size_t)(tiles_per_pair + 1) + blockIdx.x;
+  const i64 i0 = sp[0], i1 = sp[1];
   const i64 j0 = d0 - i0, j1 = d1 - i1;
   const int ca = (int)(i1 - i0), cb = (int)(j1 - j0);      // ca + cb == d1 - d0 <= MTILE
   // 2. stage: A's slice at [0, ca), B's at [ca, ca + cb)
@@ -686,12 +699,19 @@ void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, 
 }
 
 // one round: n_pairs triples in `pairs` (device), the longest pair has max_len records
-void launch_merge_pairs(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, const i64* pairs, int n_pairs, i64 max_len,
+size_t merge_splits_entries(i64 max_len, int n_pairs) { return (size_t)n_pairs * (size_t)((max_len + MTILE - 1) / MTILE + 1); }
+void launch_merge_pairs(hipStream_t s, const u64* klo, const u64* khi, const uint32_t* ids, const i64* pairs, int n_pairs, i64 max_len, i64* splits,
                         u64* klo_out, u64* khi_out, uint32_t* ids_out) {
   if (n_pairs <= 0 || max_len <= 0) return;
-  const unsigned gx = (unsigned)((max_len + MTILE - 1) / MTILE);
-  if (khi) hipLaunchKernelGGL(k_merge_pairs<true>, dim3(gx, (unsigned)n_pairs), dim3(SBLOCK), 0, s, klo, khi, ids, pairs, klo_out, khi_out, ids_out);
-  else hipLaunchKernelGGL(k_merge_pairs<false>, dim3(gx, (unsigned)n_pairs), dim3(SBLOCK), 0, s, klo, khi, ids, pairs, klo_out, khi_out, ids_out);
+  const int tpp = (int)((max_len + MTILE - 1) / MTILE);
+  const dim3 pg((unsigned)((tpp + 1 + SBLOCK - 1) / SBLOCK), (unsigned)n_pairs), mg((unsigned)tpp, (unsigned)n_pairs);
+  if (khi) {
+    hipLaunchKernelGGL(k_merge_partition<true>, pg, dim3(SBLOCK), 0, s, klo, khi, pairs, tpp, splits);
+    hipLaunchKernelGGL(k_merge_pairs<true>, mg, dim3(SBLOCK), 0, s, klo, khi, ids, pairs, (const i64*)splits, tpp, klo_out, khi_out, ids_out);
+  } else {
+    hipLaunchKernelGGL(k_merge_partition<false>, pg, dim3(SBLOCK), 0, s, klo, khi, pairs, tpp, splits);
+    hipLaunchKernelGGL(k_merge_pairs<false>, mg, dim3(SBLOCK), 0, s, klo, khi, ids, pairs, (const i64*)splits, tpp, klo_out, khi_out, ids_out);
+  }
 }
 
 #endif  // GPUQ_JIT
