@@ -86,6 +86,9 @@ struct SortPack {                   // computed on the host from the per-key min
   int32_t shift[MAX_SORT_KEYS];     // bit position of the key's field in the composite
   int32_t null_bit[MAX_SORT_KEYS];  // bit (inside the field) of the null flag, -1 = none
   int32_t rshift[MAX_SORT_KEYS];    // packed Utf8: drop the length byte and the bytes beyond the longest string
+  int32_t vbits[MAX_SORT_KEYS];     // width of the value field (without the null flag)
+  int32_t check;                    // 1: the layout was GUESSED from a sample -- the pack kernel verifies every row against it and raises
+                                    // hist[SORT_MAX_PASSES * 256] when a value falls outside its field or a NULL meets a key without a null bit
 };
 
 // aggregate post-processing (kernels_scan.hip): AoS result -> one (lo,hi) column per key / accumulator
@@ -158,7 +161,7 @@ void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec&
                        int join_type, int payload_via, int null_equals_null, uint32_t* out_build, uint32_t* out_probe,
                        u64 out_cap, u64* out_count, uint32_t* visited);
 int sort_minmax_blocks(i64 n);
-void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks);
+void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks, i64 wstep = 1);   // wstep > 1: every wstep-th 64-row word only (a sample)
 int sort_max_passes();
 void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids, u64* hist, int hist_passes);
 void launch_part_pid(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, uint32_t nparts, u64* pid_out, uint32_t* ids);

@@ -60,13 +60,15 @@ __device__ __forceinline__ void mm_reduce_store(MinMax& m, int k, u64 (*red)[MAX
   if (slane() == 0) { red[swave()][k][0] = m.mn_lo; red[swave()][k][1] = m.mn_hi; red[swave()][k][2] = m.mx_lo; red[swave()][k][3] = m.mx_hi; red[swave()][k][4] = m.fl; }
 }
 template <int MAXC>
-__device__ __forceinline__ void k_sort_minmax_body(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out) {
+__device__ __forceinline__ void k_sort_minmax_body(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out, const i64 wstep) {
   __shared__ u64 red[SWAVES][MAX_SORT_KEYS][5];
   MinMax m0, m1, m2, m3;   // scalars on purpose: an indexed array here competes with the register file for promotion
   mm_init(m0); mm_init(m1); mm_init(m2); mm_init(m3);
-  const i64 nwords = (n + 63) >> 6;
+  const i64 nw_all = (n + 63) >> 6;
+  const i64 nwords = wstep > 1 ? (nw_all + wstep - 1) / wstep + 1 : nw_all;      // wstep > 1: a strided sample of 64-row words + the last word
   for (i64 w = (i64)blockIdx.x * SWAVES + swave(); w < nwords; w += (i64)gridDim.x * SWAVES) {
-    const i64 pos = (w << 6) + slane();
+    const i64 wi = w * wstep < nw_all ? w * wstep : nw_all - 1;
+    const i64 pos = (wi << 6) + slane();
     if (pos >= n) continue;
     GPUQ_REGS_DECL;
     (void)GPUQ_EVAL(MAXC, P, pos);
@@ -91,10 +93,10 @@ __device__ __forceinline__ void k_sort_minmax_body(const DevProgram P, const i64
 #ifndef GPUQ_JIT
 template <int MAXC>
 #ifndef GPUQ_JIT
-__global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out) { k_sort_minmax_body<MAXC>(P, n, S, out); }
+__global__ void __launch_bounds__(SBLOCK) k_sort_minmax(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out, const i64 wstep) { k_sort_minmax_body<MAXC>(P, n, S, out, wstep); }
 #endif
 #elif GPUQ_JIT_KERNEL == 8
-extern "C" __global__ void __launch_bounds__(SBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out) { k_sort_minmax_body<0>(P, n, S, out); }
+extern "C" __global__ void __launch_bounds__(SBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out, const i64 wstep) { k_sort_minmax_body<0>(P, n, S, out, wstep); }
 #endif
 
 // ------------------------------------------------------------------ composite key
@@ -106,6 +108,9 @@ __device__ __forceinline__ void k_sort_pack_body(const DevProgram P, const i64 n
                                                       u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids, u64* __restrict__ hist, const int hist_passes) {
   __shared__ uint32_t h0[SORT_MAX_PASSES][256];
   if (hist) { for (int p = 0; p < hist_passes; ++p) h0[p][threadIdx.x] = 0; __syncthreads(); }
+  bool bad = false;      // K.check: a row the guessed layout does not hold
+  // (taking two or four 64-row words per wave and step with all their column loads issued first, as the join and aggregate kernels
+  // do, was measured here and changes nothing: 2.74 / 2.80 / 2.77 ms per sort of 2^27 rows with 1 / 2 / 4 words)
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * SWAVES + swave(); w < nwords; w += (i64)gridDim.x * SWAVES) {
     const i64 pos = (w << 6) + slane();
@@ -123,7 +128,8 @@ __device__ __forceinline__ void k_sort_pack_body(const DevProgram P, const i64 n
           const i128 v = sort_view(rlo[r], rhi[r], S.kind[k]) >> K.rshift[k];   // arithmetic shift keeps the order
           const i128 base = mk128(K.base_lo[k], K.base_hi[k]);
           field = S.desc[k] ? (u128)(base - v) : (u128)(v - base);
-        }
+          if (K.check && K.vbits[k] < 128 && (field >> K.vbits[k]) != 0) bad = true;      // below the base wraps to a huge field: caught too
+        } else if (K.check && K.null_bit[k] < 0) bad = true;
         if (K.null_bit[k] >= 0) {
           // nulls_first: NULL -> 0, value -> 1 in the bit above the value field
           const u128 flag = (isn != (bool)S.nulls_first[k]) ? 1 : 0;
@@ -149,6 +155,7 @@ __device__ __forceinline__ void k_sort_pack_body(const DevProgram P, const i64 n
     ids[pos] = (uint32_t)pos;
   }
   if (hist) { __syncthreads(); for (int p = 0; p < hist_passes; ++p) if (h0[p][threadIdx.x]) atomicAdd((unsigned long long*)&hist[p * 256 + threadIdx.x], (unsigned long long)h0[p][threadIdx.x]); }
+  if (K.check && hist && bad) atomicOr((unsigned long long*)&hist[SORT_MAX_PASSES * 256], 1ull);
 }
 #ifndef GPUQ_JIT
 template <int MAXC>
@@ -581,11 +588,12 @@ static int sgrid(i64 n, int blocks_per_cu) {
   return (int)(need < cap ? need : cap);
 }
 int sort_minmax_blocks(i64 n) { return sgrid(n, 4); }
-void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks) {
+void launch_sort_minmax(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, u64* out, int nblocks, i64 wstep) {
+  if (wstep < 1) wstep = 1;
   if (jit_override().fn && jit_override().kernel_id == 8) {
-    (void)jit_launch(jit_override().fn, dim3(nblocks), dim3(SBLOCK), 0, s, P, n, S, out);
+    (void)jit_launch(jit_override().fn, dim3(nblocks), dim3(SBLOCK), 0, s, P, n, S, out, wstep);
   } else {
-#define CALL(M) hipLaunchKernelGGL(k_sort_minmax<M>, dim3(nblocks), dim3(SBLOCK), 0, s, P, n, S, out)
+#define CALL(M) hipLaunchKernelGGL(k_sort_minmax<M>, dim3(nblocks), dim3(SBLOCK), 0, s, P, n, S, out, wstep)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
   }
@@ -594,6 +602,7 @@ int sort_max_passes() { return SORT_MAX_PASSES; }
 void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids, u64* hist, int hist_passes) {
   if (n <= 0) return;
   if (hist) (void)hipMemsetAsync(hist, 0, (size_t)hist_passes * RADIX * 8, s);
+  if (hist && K.check) (void)hipMemsetAsync(hist + (size_t)SORT_MAX_PASSES * RADIX, 0, 8, s);      // the "layout does not hold" word
   if (jit_override().fn && jit_override().kernel_id == 9) {
     (void)jit_launch(jit_override().fn, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, S, K, key_lo, key_hi, ids, hist, hist_passes);
   } else {

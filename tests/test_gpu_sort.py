@@ -49,6 +49,39 @@ def test_all_keys_equal_and_sorted_inputs(tc):
     assert np.array_equal(sorted_row_ids(tc, t, [("up", False)]), np.arange(n)[::-1])
 
 
+# ------------------------------------------------------------------ large inputs: key layout guessed from a sample, verified by the pack kernel
+def test_guessed_key_layout_holds_or_falls_back(tc):
+    """From 2^22 rows on gpuq_sort_run sizes the composite key from the min/max of every 16th 64-row word (here) and the pack kernel
+    checks each row against it.  The permutation must be the stable order whether the guess holds (uniform keys), or does not:
+    an outlier / a NULL in a word the sample skips, keys far outside a clustered sample."""
+    n = (1 << 22) + 77
+    r = np.random.default_rng(22)
+    rid = np.arange(n, dtype=np.int64)
+    price = r.integers(90_000, 10_494_951, n).astype(np.int64)              # 24 bits: packed records, 3 passes
+    date = r.integers(8000, 10_600, n).astype(np.int32)
+    low = price.copy(); low[100] = -5_000_000_000                           # row 100 is in word 1: not sampled
+    high = price.copy(); high[n - 3] = 1 << 50
+    hidden = r.integers(0, 1000, n).astype(np.int64); hidden[64:] += np.where(np.arange(64, n) % 1024 >= 64, 1 << 30, 0)   # sampled words hold 0..999 only
+    t = pa.table({"rid": rid, "price": price, "date": date, "low": low, "high": high, "hidden": hidden})
+    t = t.cast(pa.schema([pa.field(f.name, f.type, nullable=False) for f in t.schema]))
+    assert np.array_equal(sorted_row_ids(tc, t, [("price", True)]), np.argsort(price, kind="stable"))
+    assert np.array_equal(sorted_row_ids(tc, t, [("price", False), ("date", True)]), np.lexsort((date, -price)))
+    assert np.array_equal(sorted_row_ids(tc, t, [("low", True)]), np.argsort(low, kind="stable"))
+    assert np.array_equal(sorted_row_ids(tc, t, [("high", False)]), np.argsort(-high, kind="stable"))
+    assert np.array_equal(sorted_row_ids(tc, t, [("date", True), ("hidden", True)]), np.lexsort((hidden, date)))
+    # a NULL the sample does not see: the guessed layout has no null bit
+    mask = np.zeros(n, bool); mask[200] = True; mask[n - 1] = True
+    tn = pa.table({"rid": rid, "v": pa.array(price, mask=mask)})
+    src = g.MemoryExec([tn]); s = src.schema()
+    for nulls_first in (True, False):
+        plan = g.SortExec([{"expr": col("v", s), "asc": True, "nulls_first": nulls_first}], src)
+        got = np.asarray(g.plan.materialize(tc, plan.execute(0, tc)).to_arrow(tc.ctx).column("rid"))
+        vals = np.argsort(np.where(mask, np.iinfo(np.int64).min if nulls_first else np.iinfo(np.int64).max, price), kind="stable")
+        assert np.array_equal(got, vals)
+        got2 = np.asarray(g.plan.materialize(tc, plan.execute(0, tc)).to_arrow(tc.ctx).column("rid"))      # the operator has stopped guessing by now
+        assert np.array_equal(got2, vals)
+
+
 # ------------------------------------------------------------------ ordered fan-in (gpuq_merge_run)
 def run_table(r, n, wide):
     """n rows sorted by the test's key(s): few distinct values (ties across runs) or full-range two-field keys."""
