@@ -288,7 +288,9 @@ int gpuq_join_build_side_rows(gpuq_join_table* t, void* stream, int matched, uin
 int gpuq_mark_rows(gpuq_ctx* ctx, void* stream, const uint32_t* rows, int64_t n, uint8_t* bitmap);
 
 /* SortExec: writes the permutation (driving positions in sorted order; stable) to perm_out (n_rows).
-   Asynchronous. */
+   The call reads the key range back (one stream synchronisation in the middle).  From 2^22 rows on the range comes from a row
+   sample and the pack kernel verifies it; the call then waits for one word at the end and re-runs with the exact range when the
+   guess did not hold (env GPUQ_SORT_SPECULATE=0: always the exact range, the permutation is the same either way). */
 int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out);
 
 /* Ordered fan-in -- CoalesceTasksExec with `order_by` / SortPreservingMergeExec (coalesce_tasks.rs:162-170 `streaming_merge`):
