@@ -136,7 +136,7 @@ void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, 
 void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
                        int payload_via, int null_equals_null);
 // key range of the rows a join build would insert: out = {min (i64), max (i64), count (u64)}, pre-set by the caller to {INT64_MAX, INT64_MIN, 0}
-void launch_join_keyrange(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, int null_equals_null, u64* out);
+void launch_join_keyrange(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, int null_equals_null, u64* out, i64 wstep = 1);   // wstep > 1: every wstep-th 64-row word
 // unique build keys: every wave owns `wpw` consecutive 64-row words (segment g = words [g*wpw, (g+1)*wpw)) and writes its pairs, in probe
 // order, to seg_build / seg_probe starting at row g*wpw*64; seg_counts[g] = pairs of the segment.  launch_copy_segments then moves
 // the segments to their final places (seg_counts already scanned to exclusive offsets).

@@ -844,11 +844,12 @@ extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevPro
 // Key range of the rows the build would insert (single narrow key): decides between the direct-addressed table and
 // open addressing.  out = {min, max, count}, pre-set by the host to {INT64_MAX, INT64_MIN, 0}.
 template <int MAXC>
-__device__ __forceinline__ void k_join_keyrange_body(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out) {
+__device__ __forceinline__ void k_join_keyrange_body(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out, const i64 wstep) {
   __shared__ i64 smn[HWAVES], smx[HWAVES]; __shared__ u64 scn[HWAVES];
   i64 mn = 0x7FFFFFFFFFFFFFFFll, mx = (i64)0x8000000000000000ull; u64 cn = 0;
   const int kr = __builtin_amdgcn_readfirstlane(K.key_reg[0]);
-  for_rows_in_flight<MAXC>(P, n, (i64)blockIdx.x * HWAVES + hwave(), (i64)gridDim.x * HWAVES, [&](const i64, const i64, const bool active, GPUQ_REGS_PARAM) {
+  // wstep > 1: every wstep-th 64-row word only (a sample: the host widens what comes out and the build checks every row against it)
+  for_rows_in_flight<MAXC>(P, n, ((i64)blockIdx.x * HWAVES + hwave()) * wstep, (i64)gridDim.x * HWAVES * wstep, [&](const i64, const i64, const bool active, GPUQ_REGS_PARAM) {
     if (active && !((rnulls >> kr) & 1)) {
       const i64 v = (i64)rlo[kr];
       mn = v < mn ? v : mn; mx = v > mx ? v : mx; ++cn;
@@ -869,9 +870,9 @@ __device__ __forceinline__ void k_join_keyrange_body(const DevProgram P, const i
 }
 #ifndef GPUQ_JIT
 template <int MAXC>
-__global__ void __launch_bounds__(HBLOCK) k_join_keyrange(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out) { k_join_keyrange_body<MAXC>(P, n, K, null_eq, out); }
+__global__ void __launch_bounds__(HBLOCK) k_join_keyrange(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out, const i64 wstep) { k_join_keyrange_body<MAXC>(P, n, K, null_eq, out, wstep); }
 #elif GPUQ_JIT_KERNEL == 14
-extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out) { k_join_keyrange_body<0>(P, n, K, null_eq, out); }
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out, const i64 wstep) { k_join_keyrange_body<0>(P, n, K, null_eq, out, wstep); }
 #endif
 
 template <int MAXC>
@@ -1592,12 +1593,14 @@ void launch_join_probe(hipStream_t s, const DevProgram& P, i64 n, const KeySpec&
   }
 }
 
-void launch_join_keyrange(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, int null_equals_null, u64* out) {
+void launch_join_keyrange(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, int null_equals_null, u64* out, i64 wstep) {
   if (n <= 0) return;
+  if (wstep < 1) wstep = 1;
+  const int grid = hgrid((n + wstep - 1) / wstep, 8);
   if (jit_override().fn && jit_override().kernel_id == 14) {
-    (void)jit_launch(jit_override().fn, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, null_equals_null, out);
+    (void)jit_launch(jit_override().fn, dim3(grid), dim3(HBLOCK), 0, s, P, n, K, null_equals_null, out, wstep);
   } else {
-#define CALL(M) hipLaunchKernelGGL(k_join_keyrange<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, null_equals_null, out)
+#define CALL(M) hipLaunchKernelGGL(k_join_keyrange<M>, dim3(grid), dim3(HBLOCK), 0, s, P, n, K, null_equals_null, out, wstep)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
   }
