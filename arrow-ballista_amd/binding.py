@@ -136,6 +136,7 @@ def lib():
         "gpuq_offsets_rebase": (i32, [vp, vp, vp, i64, i32, vp]),
         "gpuq_take_utf8": (i32, [vp, vp, C.POINTER(gpuq_column), vp, i64, vp, vp, vp, i64, C.POINTER(i64)]),
         "gpuq_utf8_max_len": (i32, [vp, vp, C.POINTER(gpuq_column), vp, i64, C.POINTER(C.c_int32)]),
+        "gpuq_utf8_sort_piece": (i32, [vp, vp, C.POINTER(gpuq_column), vp, i64, i32, vp, vp]),
         "gpuq_utf8_dict_create": (i32, [vp, vp, i64, C.POINTER(vp)]),
         "gpuq_utf8_intern": (i32, [vp, vp, C.POINTER(gpuq_column), vp, i64, i32, vp, vp]),
         "gpuq_utf8_dict_free": (None, [vp]),

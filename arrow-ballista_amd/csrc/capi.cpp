@@ -1267,7 +1267,12 @@ static SortPack sort_key_plan(gpuq_op* op, hipStream_t s, const DevProgram& P, i
     { JitScope js(op, op->prog, 8, n); launch_sort_minmax(s, P, n, S, mm, mb, wstep); }
     std::vector<u64> hmm((size_t)mb * MAX_SORT_KEYS * 5);
     HIPCHECK(hipMemcpyAsync(hmm.data(), mm, hmm.size() * 8, hipMemcpyDeviceToHost, s));
+    // the pass has evaluated the key expressions of every row it saw: what they could not do (a Utf8 value beyond the 15 bytes a
+    // packed key holds) is reported with the same read-back instead of sorting by a truncated key
+    uint32_t eflags = 0;
+    HIPCHECK(hipMemcpyAsync(&eflags, op->flags_dev.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+    if (eflags) { reset_flags(op, s); raise_flags(eflags); }
     const i128 I128_MAX = ((i128)0x7FFFFFFFFFFFFFFFll << 64) | (i128)0xFFFFFFFFFFFFFFFFull, I128_MIN = -I128_MAX - 1;
     i128 mn[MAX_SORT_KEYS], mx[MAX_SORT_KEYS]; u64 fl[MAX_SORT_KEYS] = {0, 0, 0, 0}; int rshift[MAX_SORT_KEYS] = {0, 0, 0, 0};
     for (int k = 0; k < S.n_keys; ++k) {
@@ -1340,9 +1345,12 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
     if (n >= (1ll << 31)) throw Unsupported("sort of >= 2^31 rows in one call");
     if (!perm_out) throw std::runtime_error("perm_out is NULL");
     const SortSpec& S = op->sort;
+    bool string_key = false;
+    for (int k = 0; k < S.n_keys; ++k) string_key = string_key || S.kind[k] == 2;
     if (n <= sort_direct_max()) {      // one block, no min/max read-back
       launch_sort_direct(s, P, n, S, perm_out);
       HIPCHECK(hipGetLastError());
+      if (string_key) { const uint32_t f = read_flags(op, s); if (f) { reset_flags(op, s); raise_flags(f); } }      // a value beyond 15 bytes: refuse, do not sort by a prefix
       return;
     }
     int total = 0;
@@ -1358,9 +1366,11 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
       const SortPack G = sort_key_plan(op, s, P, n, &total, wstep);
       if (total > 0) {      // (no key bits: the pack kernel takes no counts and has nowhere to report to)
         sort_with_plan(op, s, P, n, G, total, perm_out);
-        u64 failed = 0;
+        u64 failed = 0; uint32_t eflags = 0;
         HIPCHECK(hipMemcpyAsync(&failed, (const u64*)op->ws[6].p + (size_t)sort_max_passes() * 256, 8, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(&eflags, op->flags_dev.p, 4, hipMemcpyDeviceToHost, s));      // the pack kernel evaluated every row
         HIPCHECK(hipStreamSynchronize(s));
+        if (eflags) { reset_flags(op, s); raise_flags(eflags); }
         if (!failed) return;
         op->sort_guess_failed = true;
       }
@@ -1594,6 +1604,17 @@ int gpuq_utf8_max_len(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const
     launch_utf8_max_len(s, col->offsets, col->validity, idx, n, (int32_t*)out.p);
     HIPCHECK(hipMemcpyAsync(max_len_out, out.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+  });
+}
+int gpuq_utf8_sort_piece(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int piece, void* keys_out, uint8_t* validity_out) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!col || !keys_out) throw std::runtime_error("col / keys_out is NULL");
+    if (col->type != T_UTF8 || col->repr != GPUQ_REPR_ARROW) throw Unsupported("gpuq_utf8_sort_piece needs a Utf8 column in Arrow layout");
+    if (piece < 0 || piece > (1 << 27)) throw std::runtime_error("piece out of range");
+    if (n <= 0) return;
+    launch_utf8_sort_piece(use_stream(stream), (const uint8_t*)col->data, col->offsets, col->validity, idx, n, piece, keys_out, (u64*)validity_out);
+    HIPCHECK(hipGetLastError());
   });
 }
 int gpuq_utf8_dict_create(gpuq_ctx* ctx, void* stream, int64_t capacity_rows, gpuq_utf8_dict** out) {

@@ -1185,6 +1185,38 @@ __global__ void __launch_bounds__(BLOCK) k_utf8_code_rows(const i64* __restrict_
 void launch_utf8_code_rows(hipStream_t s, const i64* codes, const uint8_t* validity, i64 n, uint32_t* rows) {
   if (n > 0) hipLaunchKernelGGL(k_utf8_code_rows, dim3(lin_grid(n)), dim3(BLOCK), 0, s, codes, validity, n, rows);
 }
+// Order-preserving fixed-width pieces of a Utf8 column (sort keys of any length): piece j of a string = bytes [14 j, 14 j + 14) as a
+// big-endian integer, zero padded, times 256 plus the number of bytes the piece holds (0..14).  Comparing the pieces of two
+// strings in order is comparing the strings bytewise (the count separates "ab" from "ab\0").  out: 16-byte integers (< 2^120);
+// valid_out bit i = row i is not NULL (same for every piece).
+__global__ void __launch_bounds__(BLOCK) k_utf8_sort_piece(const uint8_t* __restrict__ data, const int32_t* __restrict__ offsets, const uint8_t* __restrict__ validity,
+                                                           const uint32_t* __restrict__ idx, const i64 n, const int piece, ulonglong2* __restrict__ out, u64* __restrict__ valid_out) {
+  for (i64 i0 = (i64)blockIdx.x * BLOCK + (threadIdx.x & ~63); i0 < n; i0 += (i64)gridDim.x * BLOCK) {
+    const i64 i = i0 + (threadIdx.x & 63);
+    bool has = false; u64 lo = 0, hi = 0;
+    if (i < n) {
+      const uint32_t r = idx ? idx[i] : (uint32_t)i;
+      has = !(r == 0xFFFFFFFFu || (validity && !((validity[r >> 3] >> (r & 7)) & 1)));
+      if (has) {
+        const int32_t o = offsets[r], len = offsets[r + 1] - o;
+        int32_t m = len - 14 * piece; m = m < 0 ? 0 : (m > 14 ? 14 : m);
+        const uint8_t* p = data + o + 14 * piece;
+        // value bits: byte 0 at bits 119..112, ..., byte 13 at bits 15..8, count at bits 7..0
+        for (int b = 0; b < m; ++b) {
+          const u64 v = p[b]; const int sh = 112 - 8 * b;
+          if (sh >= 64) hi |= v << (sh - 64); else lo |= v << sh;
+        }
+        lo |= (u64)m;
+      }
+    }
+    const u64 vm = __ballot(has);
+    if (valid_out && (threadIdx.x & 63) == 0) valid_out[i0 >> 6] = vm;
+    if (i < n) out[i] = make_ulonglong2(lo, hi);
+  }
+}
+void launch_utf8_sort_piece(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int piece, void* out, u64* valid_out) {
+  if (n > 0) hipLaunchKernelGGL(k_utf8_sort_piece, dim3(lin_grid(n)), dim3(BLOCK), 0, s, data, offsets, validity, idx, n, piece, (ulonglong2*)out, valid_out);
+}
 void launch_utf8_max_len(hipStream_t s, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int32_t* out) {
   if (n > 0) hipLaunchKernelGGL(k_utf8_max_len, dim3(lin_grid(n)), dim3(BLOCK), 0, s, offsets, validity, idx, n, out);
 }

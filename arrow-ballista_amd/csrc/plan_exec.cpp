@@ -440,7 +440,8 @@ PTable filter_table(Exec& x, const PTable& source, const Json& predicate_in, con
   return select_view(x, source, (const uint32_t*)sel->p, k, sel);
 }
 
-PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
+// the stable permutation that puts `t` in `sort_exprs` order (one gpuq_sort_run: <= 4 keys whose composite fits 128 bits)
+static BufP sort_perm(Exec& x, const PTable& t, const Json& sort_exprs, const void* site, int tag) {
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     const auto nm = names_of(t);
     Json ex = jarr();
@@ -453,8 +454,64 @@ PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetc
   BufP perm = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 4 + 16);
   InputC ic; make_input(t, ic);
   check(x, gpuq_sort_run(op, x.stream, &ic.in, (uint32_t*)perm->p));
+  return perm;
+}
+
+// Utf8 sort keys longer than 15 bytes (q2 / q21's s_name, q16's p_type, q18's c_name).  The packed key has refused; the order is then
+// built from stable passes, least significant first (LSD over the ORDER BY list): a long string key becomes ceil(max_len / 14)
+// pieces, each an order-preserving 16-byte integer column (gpuq_utf8_sort_piece) sorted in a pass of its own; the keys between
+// long strings go through in groups of up to four, as one composite key per pass.  Every pass sorts the rows in the order the
+// later keys left them, so ties keep that order.  Nothing is paid on the common path: this runs only after the loud failure.
+struct PermOut { const uint32_t* p = nullptr; std::vector<BufP> keep; };
+static PermOut sort_perm_long(Exec& x, const PTable& t, const Json& sort_exprs, const void* site, int tag) {
+  PTable w = t;
+  std::vector<Json> groups; Json cur = jarr();
+  auto flush = [&]() { if (!cur.a.empty()) { groups.push_back(cur); cur = jarr(); } };
+  int np = 0;
+  for (auto& s : sort_exprs.a) {
+    const int ci = long_key_column(t, s.at("expr"));
+    int32_t maxlen = 0;
+    if (ci >= 0) { const int sd = t.sides[(size_t)ci]; check(x, gpuq_utf8_max_len(x.ctx, x.stream, &t.cols[(size_t)ci].c, sd > 0 ? t.via[(size_t)sd - 1] : nullptr, t.n, &maxlen)); }
+    if (ci < 0 || maxlen <= 15) { cur.a.push_back(s); if (cur.a.size() == 4) flush(); continue; }
+    flush();
+    const bool asc = s.get_bool("asc", true);
+    for (int j = 0; j < (maxlen + 13) / 14; ++j) {
+      const std::string name = "__sortpiece_" + std::to_string(np++);
+      const PCol& c = w.cols[(size_t)ci]; const int sd = w.sides[(size_t)ci];
+      const size_t nb = (size_t)((w.n + 63) / 64) * 8 + 8;
+      BufP keys = dev_alloc((size_t)std::max<int64_t>(w.n, 1) * 16 + 16), valid = dev_alloc(nb);
+      HIPCHECK(hipMemsetAsync(valid->p, 0, nb, (hipStream_t)x.stream));
+      check(x, gpuq_utf8_sort_piece(x.ctx, x.stream, &c.c, sd > 0 ? w.via[(size_t)sd - 1] : nullptr, w.n, j, keys->p, (uint8_t*)valid->p));
+      PCol k; k.name = name; k.type = jobj({{"Decimal128", jarr({jnum(38), jnum(0)})}}); k.nullable = true;
+      k.c.type = T_DECIMAL128; k.c.precision = 38; k.c.scale = 0; k.c.repr = GPUQ_REPR_ARROW; k.c.data = keys->p; k.c.validity = (const uint8_t*)valid->p; k.c.length = w.n;
+      w.cols.push_back(k); w.sides.push_back(0); w.keep.push_back(keys); w.keep.push_back(valid); w.record_cap = 0;
+      groups.push_back(jarr({jobj({{"expr", jcol(name, (int)w.cols.size() - 1)}, {"asc", jbool(asc)}, {"nulls_first", jbool(s.get_bool("nulls_first", !asc))}})}));
+    }
+  }
+  flush();
+  PermOut out;
+  for (size_t gi = groups.size(); gi-- > 0;) {
+    if (!out.p) { BufP p = sort_perm(x, w, groups[gi], site, tag * 64 + 8 + (int)gi); out.p = (const uint32_t*)p->p; out.keep.push_back(p); continue; }
+    PTable view = select_view(x, w, out.p, w.n, nullptr);
+    BufP p2 = sort_perm(x, view, groups[gi], site, tag * 64 + 8 + (int)gi);
+    out.keep.push_back(p2);
+    for (auto& b : view.keep) out.keep.push_back(b);
+    out.p = take_u32(x, out.p, w.n, (const uint32_t*)p2->p, w.n, out.keep);      // rows in the new order = old order read through the pass's permutation
+  }
+  for (auto& b : w.keep) out.keep.push_back(b);
+  return out;
+}
+
+PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
   const int64_t k = (fetch < 0 || fetch > t.n) ? t.n : fetch;
-  return select_view(x, t, (const uint32_t*)perm->p, k, perm);
+  try {
+    BufP perm = sort_perm(x, t, sort_exprs, site, tag);
+    return select_view(x, t, (const uint32_t*)perm->p, k, perm);
+  } catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+  PermOut po = sort_perm_long(x, t, sort_exprs, site, tag);
+  PTable out = select_view(x, t, po.p, k, nullptr);
+  for (auto& b : po.keep) out.keep.push_back(b);
+  return out;
 }
 
 PTable concat_tables(Exec& x, std::vector<PTable> parts);

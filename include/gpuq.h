@@ -334,6 +334,13 @@ int gpuq_take_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const ui
    validity_out: (n + 63) / 64 * 8 bytes, bit i = row i has a code (0: the value is NULL, or -- lookup -- not in the dictionary, which
    an equi-join treats the same way).  Equal strings get equal codes, different strings different ones, whatever they hash to: a
    tag match is verified byte for byte.  The string of a code comes back with gpuq_take_utf8(dictionary column, rows = codes). */
+/* Utf8 values of any length as SORT keys: gpuq_utf8_sort_piece writes piece `piece` of every string (rows through `idx` when
+   given) as a 16-byte integer that compares like the bytes [14 piece, 14 piece + 14) do -- the bytes big-endian and zero padded,
+   times 256, plus the number of bytes the piece holds, so that "ab" < "ab\0".  Sorting stably by the last piece, then the one
+   before, ... (ceil(max_len / 14) passes; the executors' SortExec does this after the packed 15-byte key has refused) yields
+   the bytewise order of the strings, which is Arrow's.  keys_out: n x 16 bytes (values < 2^120: a Decimal128(38, 0) column);
+   validity_out: (n + 63) / 64 * 8 bytes, bit i = row i is not NULL.  Asynchronous. */
+int gpuq_utf8_sort_piece(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int piece, void* keys_out, uint8_t* validity_out);
 typedef struct gpuq_utf8_dict gpuq_utf8_dict;
 int gpuq_utf8_max_len(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int32_t* max_len_out);
 int gpuq_utf8_dict_create(gpuq_ctx* ctx, void* stream, int64_t capacity_rows, gpuq_utf8_dict** out);
