@@ -97,3 +97,74 @@ def test_the_mirror_still_refuses_and_says_why(tc):
     plan = g.AggregateExec("Single", [(col("name", s), "name")], [{"fn": "COUNT", "expr": lit(1), "name": "c"}], src)
     with pytest.raises(g.GpuqError, match="15 bytes"):
         g.plan.materialize(tc, plan.execute(0, tc))
+
+
+# ------------------------------------------------------------------ ORDER BY a long string (q2 / q21's s_name, q16's p_type, q18's c_name)
+def sort_key(row, spec):
+    """Python key for [(column index, asc, nulls_first)]: bytewise string order (Arrow's), NULLs by their flag."""
+    out = []
+    for ci, asc, nulls_first in spec:
+        v = row[ci]
+        if v is None:
+            out.append((0 if nulls_first else 2, ()))
+            continue
+        b = v.encode() if isinstance(v, str) else v
+        if not asc:
+            b = tuple(255 - x for x in b) + (256,) if isinstance(b, bytes) else -b      # reversed bytewise order: a prefix sorts AFTER its extensions
+        elif isinstance(b, bytes):
+            b = tuple(b)
+        out.append((1, b))
+    return tuple(out)
+
+
+@pytest.mark.parametrize("n,distinct,nulls", [(1, 1, 0.0), (3000, 40, 0.2), (150_000, 20_000, 0.05)])
+def test_order_by_long_strings(tc, n, distinct, nulls):
+    t = names_table(n, 11 + n, distinct, nulls).append_column("rid", pa.array(np.arange(n, dtype=np.int64)))
+    src = g.MemoryExec([t])
+    s = src.schema()
+    rows = rows_of(t)
+    cases = [
+        ([("name", True, False)], [(0, True, False)]),
+        ([("name", False, True)], [(0, False, True)]),
+        ([("short", True, False), ("name", False, False), ("v", True, False)], [(1, True, False), (0, False, False), (2, True, False)]),
+        ([("v", False, False), ("name", True, True)], [(2, False, False), (0, True, True)]),
+    ]
+    for spec, pyspec in cases:
+        order = [{"expr": col(c, s), "asc": asc, "nulls_first": nf} for c, asc, nf in spec]
+        got = rows_of(g.NativePlan(g.SortExec(order, src), tc).execute(0).to_arrow())
+        want = sorted(rows, key=lambda r: sort_key(r, pyspec))      # Python's sort is stable, as SortExec is: ties keep input order
+        assert got == want, spec
+
+
+def test_order_by_strings_that_differ_only_beyond_a_piece_boundary_or_by_trailing_nul(tc):
+    """Pieces are 14 bytes: values equal up to byte 14 / 28, a value that is a prefix of another, and "x" vs "x\\0" (zero padding
+    alone would call them equal) must come out in bytewise order, under a fused filter and through a view (index vectors)."""
+    base = "0123456789abcd"                       # 14 bytes = exactly one piece
+    vals = [base + base + "b", base + base + "a", base + base, base + "z", base, base + "\x00", base + base + "a\x00", "", "\x00", "é" * 9, "é" * 8 + "e",
+            base + base + base + "1", base + base + base + "0", None]
+    r = np.random.default_rng(5)
+    pick = r.integers(0, len(vals), 5000)
+    t = pa.table({"s": pa.array([vals[i] for i in pick]), "v": pa.array(r.integers(0, 100, 5000), pa.int64()), "rid": pa.array(np.arange(5000, dtype=np.int64))})
+    src = g.MemoryExec([t])
+    s = src.schema()
+    inp = g.FilterExec(binary(col("v", s), Op.Lt, lit(80, "Int64")), src)
+    rows = [x for x in rows_of(t) if x[1] < 80]
+    for asc in (True, False):
+        got = rows_of(g.NativePlan(g.SortExec([{"expr": col("s", s), "asc": asc, "nulls_first": False}], inp), tc).execute(0).to_arrow())
+        assert got == sorted(rows, key=lambda x: sort_key(x, [(0, asc, False)]))
+    # top-k: fetch
+    got = rows_of(g.NativePlan(g.SortExec([{"expr": col("s", s), "asc": True, "nulls_first": True}], inp, fetch=7), tc).execute(0).to_arrow())
+    assert got == sorted(rows, key=lambda x: sort_key(x, [(0, True, True)]))[:7]
+
+
+def test_the_mirror_refuses_a_long_sort_key(tc):
+    """SortExec used to order such rows by their first 15 bytes without a word; the mirror has no piece passes and must say so."""
+    t = names_table(500, 3, 50)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    with pytest.raises(g.GpuqError, match="15 bytes"):
+        g.plan.materialize(tc, g.SortExec([{"expr": col("name", s), "asc": True, "nulls_first": False}], src).execute(0, tc))
+    big = names_table(70_000, 4, 5000)      # beyond the one-block sort: the min/max pass reports it
+    bsrc = g.MemoryExec([big])
+    with pytest.raises(g.GpuqError, match="15 bytes"):
+        g.plan.materialize(tc, g.SortExec([{"expr": col("name", bsrc.schema()), "asc": True, "nulls_first": False}], bsrc).execute(0, tc))
