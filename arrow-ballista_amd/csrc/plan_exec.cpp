@@ -126,6 +126,40 @@ bool has_like(const Json& e) {
   if (e.is_arr()) { for (auto& v : e.a) if (has_like(v)) return true; }
   return false;
 }
+// `column = 'literal'` / `column != 'literal'` with a Utf8 literal beyond the 15 bytes a register holds (q19's l_shipinstruct =
+// 'DELIVER IN PERSON'): equality with a literal is LIKE without wildcards, and LIKE runs over the Arrow-layout bytes at any length
+// (gpuq_like_utf8) -- so the comparison becomes a like_expr whose pattern is the literal with its % and _ escaped.  NULL semantics
+// are the same (NULL operand -> NULL).  Applied to the whole plan when it is created; shorter literals are left alone.
+Json lower_long_string_eq(const Json& e) {
+  if (e.is_obj()) {
+    if (e.o.size() == 1 && e.o[0].first == "binary_expr" && e.o[0].second.is_obj()) {
+      const Json& b = e.o[0].second;
+      const std::string op = b.get_str("op", "");
+      if ((op == "=" || op == "!=" || op == "Eq" || op == "NotEq") && b.find("l") && b.find("r")) {
+        auto is_col = [](const Json& v) { return v.is_obj() && v.o.size() == 1 && v.o[0].first == "column"; };
+        auto long_lit = [](const Json& v) {
+          if (!(v.is_obj() && v.o.size() == 1 && v.o[0].first == "literal" && v.o[0].second.is_obj())) return false;
+          const Json& l = v.o[0].second;
+          return l.get_str("type", "") == "Utf8" && l.find("value") && !l.at("value").is_null() && l.at("value").str().size() > 15;
+        };
+        const Json* c = nullptr; const Json* l = nullptr;
+        if (is_col(b.at("l")) && long_lit(b.at("r"))) { c = &b.at("l"); l = &b.at("r"); }
+        else if (is_col(b.at("r")) && long_lit(b.at("l"))) { c = &b.at("r"); l = &b.at("l"); }
+        if (c) {
+          std::string pat;
+          for (char ch : l->o[0].second.at("value").str()) { if (ch == '%' || ch == '_') pat += '\\'; pat += ch; }
+          return jobj({{"like_expr", jobj({{"negated", jbool(op == "!=" || op == "NotEq")}, {"case_insensitive", jbool(false)}, {"expr", *c},
+                                           {"pattern", jobj({{"literal", jobj({{"type", jstr("Utf8")}, {"value", jstr(pat)}})}})}})}});
+        }
+      }
+    }
+    Json r = jobj();
+    for (auto& kv : e.o) r.o.emplace_back(kv.first, lower_long_string_eq(kv.second));
+    return r;
+  }
+  if (e.is_arr()) { Json r = jarr(); for (auto& v : e.a) r.a.push_back(lower_long_string_eq(v)); return r; }
+  return e;
+}
 Json rewrite_like(const Json& e, const std::function<Json(const Json&)>& fn) {
   if (e.is_obj()) {
     if (e.o.size() == 1 && e.o[0].first == "like_expr") return fn(e.o[0].second);
@@ -1584,7 +1618,7 @@ int gpuq_plan_create(gpuq_ctx* ctx, const char* plan_json, gpuq_plan** out) {
     if (!plan_json) throw std::runtime_error("plan_json is NULL");
     std::unique_ptr<gpuq_plan> p(new gpuq_plan());
     p->ctx = ctx;
-    p->root = build_node(JsonParser(plan_json).parse());
+    p->root = build_node(lower_long_string_eq(JsonParser(plan_json).parse()));
     *out = p.release();
   });
 }

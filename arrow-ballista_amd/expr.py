@@ -172,6 +172,29 @@ def rewrite_like(e, fn):
     return copy.deepcopy(e)
 
 
+def lower_long_string_eq(e):
+    """`column = 'literal'` / `!=` with a Utf8 literal beyond the 15 bytes a register holds becomes LIKE without wildcards (the
+    literal's % and _ escaped): LIKE runs over the Arrow-layout bytes at any length.  Same rewrite as plan_exec.cpp's."""
+    if isinstance(e, dict):
+        b = e.get("binary_expr") if len(e) == 1 else None
+        if isinstance(b, dict) and b.get("op") in ("=", "!=", "Eq", "NotEq"):
+            def is_col(v):
+                return isinstance(v, dict) and len(v) == 1 and "column" in v
+
+            def long_lit(v):
+                return (isinstance(v, dict) and len(v) == 1 and isinstance(v.get("literal"), dict) and v["literal"].get("type") == "Utf8"
+                        and isinstance(v["literal"].get("value"), str) and len(v["literal"]["value"].encode()) > 15)
+            pair = (b["l"], b["r"]) if is_col(b.get("l")) and long_lit(b.get("r")) else (b["r"], b["l"]) if is_col(b.get("r")) and long_lit(b.get("l")) else None
+            if pair:
+                pat = pair[1]["literal"]["value"].replace("%", "\\%").replace("_", "\\_")
+                return {"like_expr": {"negated": b["op"] in ("!=", "NotEq"), "case_insensitive": False, "expr": copy.deepcopy(pair[0]),
+                                      "pattern": {"literal": {"type": "Utf8", "value": pat}}}}
+        return {k: lower_long_string_eq(v) for k, v in e.items()}
+    if isinstance(e, (list, tuple)):
+        return type(e)(lower_long_string_eq(v) for v in e)
+    return e
+
+
 def like_placeholder(e):
     """For type inference only: LIKE is Boolean and NULL exactly where its operand is -- as `operand = operand`."""
     return rewrite_like(e, lambda v: {"binary_expr": {"l": v["expr"], "r": copy.deepcopy(v["expr"]), "op": "Eq"}})

@@ -482,7 +482,7 @@ class FilterExec(ExecutionPlan):
 
     def __init__(self, predicate, input):
         super().__init__()
-        self.predicate, self.input = predicate, input
+        self.predicate, self.input = E.lower_long_string_eq(predicate), input
 
     def children(self):
         return [self.input]
@@ -528,7 +528,7 @@ class ProjectionExec(ExecutionPlan):
 
     def __init__(self, expr, input):
         super().__init__()
-        self.expr, self.input = list(expr), input
+        self.expr, self.input = [(E.lower_long_string_eq(e), n) for e, n in expr], input
 
     def children(self):
         return [self.input]

@@ -168,3 +168,25 @@ def test_the_mirror_refuses_a_long_sort_key(tc):
     bsrc = g.MemoryExec([big])
     with pytest.raises(g.GpuqError, match="15 bytes"):
         g.plan.materialize(tc, g.SortExec([{"expr": col("name", bsrc.schema()), "asc": True, "nulls_first": False}], bsrc).execute(0, tc))
+
+
+# ------------------------------------------------------------------ = / != against a literal beyond 15 bytes (q19: l_shipinstruct = 'DELIVER IN PERSON')
+@pytest.mark.parametrize("native", [False, True], ids=["mirror", "native"])
+def test_equality_with_a_long_literal(tc, native):
+    vals = ["DELIVER IN PERSON", "TAKE BACK RETURN", "COLLECT COD", "NONE", "DELIVER IN PERSON!", "DELIVER IN PERSO", "100%_sure it is long", "100%xsure it is long", "100%_sure it is lon", None]
+    r = np.random.default_rng(19)
+    pick = r.integers(0, len(vals), 20_000)
+    t = pa.table({"s": pa.array([vals[i] for i in pick]), "rid": pa.array(np.arange(20_000, dtype=np.int64))})
+    src = g.MemoryExec([t])
+    s = src.schema()
+    rows = rows_of(t)
+
+    def run(plan):
+        return rows_of(g.NativePlan(plan, tc).execute(0).to_arrow()) if native else rows_of(g.plan.materialize(tc, plan.execute(0, tc)).to_arrow(tc.ctx))
+    for literal in ("DELIVER IN PERSON", "100%_sure it is long", "a literal no row holds at all"):
+        assert run(g.FilterExec(binary(col("s", s), Op.Eq, lit(literal)), src)) == [x for x in rows if x[0] == literal]
+        assert run(g.FilterExec(binary(lit(literal), Op.NotEq, col("s", s)), src)) == [x for x in rows if x[0] is not None and x[0] != literal]      # NULL != x is NULL: dropped
+        both = binary(binary(col("s", s), Op.Eq, lit(literal)), Op.Or, binary(col("rid", s), Op.Lt, lit(5, "Int64")))
+        assert run(g.FilterExec(both, src)) == [x for x in rows if x[0] == literal or x[1] < 5]
+    got = run(g.ProjectionExec([(binary(col("s", s), Op.Eq, lit("DELIVER IN PERSON")), "is_dip"), (col("rid", s), "rid")], src))
+    assert got == [((None if x[0] is None else x[0] == "DELIVER IN PERSON"), x[1]) for x in rows]
