@@ -134,6 +134,7 @@ DevProgram bind_program(const CompiledProgram& cp, const Schema& schema, const D
     d.cls = f.raw128 ? CC_I128 : col_class_for(f.type);
     if (d.cls == CC_STR && !f.raw128 && !col.offsets && col.length > 0) throw std::runtime_error("Utf8 column '" + f.name + "' has no offsets");
     if (f.raw128 && f.type.id == T_UTF8) d.cls = CC_I128;
+    if (d.cls == CC_STR && c < cp.col_loose.size() && cp.col_loose[c]) d.cls = CC_STRQ;
     d.via = f.side;
   }
   return P;

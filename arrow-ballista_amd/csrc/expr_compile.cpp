@@ -434,6 +434,27 @@ CompiledProgram ExprCompiler::finish() {
     reg[n] = (int)C.col_field.size();
     C.col_field.push_back(n->col);
   }
+  // Utf8 columns whose every use is `= literal` / `!= literal` (IN lists compile to those) or IS [NOT] NULL: the packed form carries
+  // the true length in its low byte, so a value beyond 15 bytes differs from every literal a register can hold and needs no refusal
+  C.col_loose.assign(C.col_field.size(), false);
+  for (size_t c = 0; c < C.col_field.size(); ++c) {
+    const Field& f = schema_.fields[C.col_field[c]];
+    if (f.type.id != T_UTF8 || f.raw128) continue;
+    bool loose = true;
+    auto is_this = [&](Node* m) { return m->kind == Node::COL && m->col == C.col_field[c]; };
+    if (pred_ && is_this(rep(pred_.get()))) loose = false;
+    for (auto& o : outs_) if (is_this(rep(o.get()))) loose = false;
+    for (Node* n : order) {
+      if (n->kind != Node::OPN) continue;
+      for (size_t k = 0; k < n->ch.size(); ++k) {
+        if (!is_this(rep(n->ch[k].get()))) continue;
+        if (n->op == OP_ISNULL || n->op == OP_ISNOTNULL) continue;
+        const bool eq_lit = (n->op == OP_EQ || n->op == OP_NE) && n->ch.size() == 2 && rep(n->ch[1 - k].get())->kind == Node::LIT;
+        if (!eq_lit) loose = false;
+      }
+    }
+    C.col_loose[c] = loose;
+  }
   std::vector<bool> busy(NREG, false);
   for (size_t i = 0; i < C.col_field.size(); ++i) busy[i] = true;
   auto alloc = [&]() { for (int r = 0; r < NREG; ++r) if (!busy[r]) { busy[r] = true; return r; } throw std::runtime_error("expression needs more than " + std::to_string(NREG) + " live registers"); return -1; };
@@ -601,7 +622,7 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
     if (is_str(n)) {
       if (f.raw128) { L("const u64 c" + cs + "_lo = a" + cs + ".x, c" + cs + "_hi = a" + cs + ".y;"); }
       else {
-        L("if (len" + cs + " > 15 && P.flags) atomicOr(P.flags, FLAG_STR_TRUNC);");
+        if (!(c < C.col_loose.size() && C.col_loose[c])) L("if (len" + cs + " > 15 && P.flags) atomicOr(P.flags, FLAG_STR_TRUNC);");
         L("u64 c" + cs + "_hi = fb" + cs + " << 56, c" + cs + "_lo = 0;");
         L("{ const int nb = len" + cs + " < 15 ? len" + cs + " : 15; for (int k = 1; k < nb; ++k) { const u64 b = sp" + cs + "[k]; if (k < 8) c" + cs + "_hi |= b << (56 - 8 * k); else c" + cs + "_lo |= b << (56 - 8 * (k - 8)); } }");
         L("c" + cs + "_lo |= (u64)(len" + cs + " < 255 ? len" + cs + " : 255);");

@@ -73,6 +73,7 @@ struct CompiledProgram {
   DevCode code{};
   int n_insns = 0;
   std::vector<int> col_field;   // program column slot -> schema field index
+  std::vector<bool> col_loose;  // Utf8 slot only compared for (in)equality with literals / tested for NULL: values beyond 15 bytes are fine (CC_STRQ)
   int pred_reg = -1;
   std::vector<int> out_reg;
   std::vector<DType> out_type;

@@ -42,6 +42,8 @@ enum ColClass : int32_t {
   CC_STR = 3,   // Utf8: first <=15 bytes big-endian in bits 127..8, length in bits 7..0
   CC_BIT = 4,   // Boolean (Arrow bit-packed) -> 0/1
   CC_U32 = 5,   // 4-byte unsigned (row ids)
+  CC_STRQ = 6,  // Utf8 as CC_STR, for a column the program only compares for (in)equality with literals or tests for NULL: the length
+                // byte alone tells a value beyond 15 bytes from every literal a register can hold, so such a value is not an error
 };
 
 struct DevCol {
@@ -190,7 +192,7 @@ __device__ __forceinline__ void load_phase_a(const DevProgram& P, const RowIdx& 
           case CC_I64: { const uint2 v = ((const uint2*)col.data)[row]; r.r0 = v.x; r.r1 = v.y; break; }
           case CC_I128: { const uint4 v = ((const uint4*)col.data)[row]; r.r0 = v.x; r.r1 = v.y; r.r2 = v.z; r.r3 = v.w; break; }
           case CC_BIT: r.r0 = ((const uint8_t*)col.data)[row >> 3]; break;
-          case CC_STR: r.r0 = (uint32_t)col.offsets[row]; r.r1 = (uint32_t)col.offsets[row + 1]; break;
+          case CC_STR: case CC_STRQ: r.r0 = (uint32_t)col.offsets[row]; r.r1 = (uint32_t)col.offsets[row + 1]; break;
           default: break;
         }
       }
@@ -204,7 +206,7 @@ __device__ __forceinline__ void load_phase_b1(const DevProgram& P, const RowIdx&
     RawSlot& r = raw_slot<C>(raw);
     if (C < P.n_cols) {
       const DevCol col = P.cols[C];
-      if (col.cls == CC_STR) {
+      if (col.cls == CC_STR || col.cls == CC_STRQ) {
         const uint32_t row = slot_row(col, rows);
         const bool ok = (col.via == 0) || (row != NULL_ROW);
         if (ok && r.r1 != r.r0) r.b = ((const uint8_t*)col.data)[(int32_t)r.r0];
@@ -232,10 +234,10 @@ __device__ __forceinline__ void load_phase_b2(const DevProgram& P, const RowIdx&
           case CC_I64: lo = (u64)r.r0 | ((u64)r.r1 << 32); hi = (u64)((i64)lo >> 63); break;
           case CC_I128: lo = (u64)r.r0 | ((u64)r.r1 << 32); hi = (u64)r.r2 | ((u64)r.r3 << 32); break;
           case CC_BIT: lo = (r.r0 >> (row & 7)) & 1u; break;
-          case CC_STR: {
+          case CC_STR: case CC_STRQ: {
             const int32_t o0 = (int32_t)r.r0, o1 = (int32_t)r.r1;
             const int32_t len = o1 - o0;
-            if (len > 15) { if (P.flags) atomicOr(P.flags, FLAG_STR_TRUNC); }
+            if (len > 15 && col.cls == CC_STR) { if (P.flags) atomicOr(P.flags, FLAG_STR_TRUNC); }
             const int32_t n = len < 15 ? len : 15;
             const uint8_t* p = (const uint8_t*)col.data + o0;
             u64 h = (n > 0) ? ((u64)(r.b & 0xFFu) << 56) : 0, l = 0;

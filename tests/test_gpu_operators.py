@@ -697,8 +697,15 @@ def test_runtime_limits_fail_loudly(tc):
     src = g.MemoryExec([t])
     s = src.schema()
     with pytest.raises(g.GpuqError) as e:
-        dev_rows(tc, g.FilterExec(binary(col("s", s), Op.Eq, lit("short")), src).execute(0, tc))
+        dev_rows(tc, g.FilterExec(binary(col("s", s), Op.Lt, lit("short")), src).execute(0, tc))
     assert e.value.status == 3 and "15 bytes" in str(e.value)
+    with pytest.raises(g.GpuqError) as e:      # two columns: equal prefixes and lengths would compare equal
+        dev_rows(tc, g.FilterExec(binary(col("s", s), Op.Eq, col("s", s)), src).execute(0, tc))
+    assert e.value.status == 3
+    # (in)equality with a literal and IS NULL are exact at any length (the packed form carries the true length): no refusal
+    assert dev_rows(tc, g.FilterExec(binary(col("s", s), Op.Eq, lit("short")), src).execute(0, tc)) == [("short", 1)]
+    assert dev_rows(tc, g.FilterExec(binary(col("s", s), Op.NotEq, lit("exactly15bytes!")), src).execute(0, tc)) == [("short", 1), ("a string value longer than fifteen bytes", 3)]
+    assert dev_rows(tc, g.FilterExec(binary(binary(col("s", s), Op.Eq, lit("a string value")), Op.Or, {"is_null_expr": {"expr": col("s", s)}}), src).execute(0, tc)) == [(None, 4)]
     with pytest.raises(g.GpuqError) as e:
         dev_rows(tc, g.AggregateExec("Single", [(col("s", s), "s")], [{"fn": "SUM", "expr": col("v", s), "name": "x"}], src).execute(0, tc))
     assert e.value.status == 3
