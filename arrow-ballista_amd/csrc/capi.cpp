@@ -1094,6 +1094,7 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
       }
     }
     bool sparse_bits = false;
+    t->T.dense = nullptr; t->T.dense_bits = nullptr; t->T.dense_min = 0; t->T.dense_range = 0;      // (a second attempt starts from a clean descriptor)
     if (dense) {
       t->T.n_slots = 0; t->T.slots = nullptr;
       t->T.dense = (uint32_t*)t->dense.ensure((size_t)krange * 4 + 16); t->T.dense_min = kmin; t->T.dense_range = krange;
@@ -1138,8 +1139,9 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     return true;
     };
     bool built = false;
-    if (spec_on && narrow_key && n >= (1ll << 21) && !op->join_guess_failed) { built = attempt(true); if (!built) op->join_guess_failed = true; }
-    if (!built) attempt(false);
+    static const bool trace = getenv("GPUQ_TRACE_JOIN_BUILD") != nullptr;
+    if (spec_on && narrow_key && n >= (1ll << 21) && !op->join_guess_failed) { built = attempt(true); if (!built) op->join_guess_failed = true; if (trace) fprintf(stderr, "[gpuq] join build: %lld rows, guessed range %s\n", (long long)n, built ? "held" : "did not hold"); }
+    if (!built) { attempt(false); if (trace) fprintf(stderr, "[gpuq] join build: %lld rows, measured range, %s\n", (long long)n, t->T.dense ? (t->T.dense_bits ? "array + bitmap" : "array") : "hash table"); }
     *out = t;
   });
   if (rc != GPUQ_OK) { delete t; if (out) *out = nullptr; }
