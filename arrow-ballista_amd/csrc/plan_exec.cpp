@@ -347,6 +347,13 @@ PTable project(Exec& x, const PTable& t_in, const std::vector<Json>& exprs_in, c
   PTable out = alloc_outputs(op, t.n, carr);
   InputC ic; make_input(t, ic);
   check(x, gpuq_project_run(op, x.stream, &ic.in, carr.data(), (int)carr.size()));
+  // A computed expression over a table that holds strings: what the evaluator could not do (an ordering comparison of a value beyond
+  // 15 bytes, ...) is in the operator's status word and nothing downstream would read it -- a bare column that is merely packed is
+  // caught later, when its bytes are needed (gpuq_unpack_utf8).  Projections of numeric tables stay asynchronous.
+  bool has_utf8 = false, computed = false;
+  for (auto& c : t.cols) has_utf8 = has_utf8 || c.c.type == T_UTF8;
+  for (auto& e : exprs) computed = computed || !(e.is_obj() && e.o.size() == 1 && (e.o[0].first == "column" || e.o[0].first == "literal"));
+  if (has_utf8 && computed) check(x, gpuq_op_check(op, x.stream));
   return out;
 }
 

@@ -166,6 +166,9 @@ def _project(tc, table, exprs, names, memo_key=None, memo=None):
     cols, arr, _ = _alloc_outputs(op, n, tc.device)
     inp, keep = table.input_struct()
     tc.ctx.check(tc.ctx.L.gpuq_project_run(op.h, tc.stream_ptr(), C.byref(inp), arr, len(cols)))
+    # a computed expression over a table that holds strings: read the status word (as plan_exec.cpp's project does)
+    if not callable(exprs) and any(c.type == "Utf8" for c in table.columns) and any(not (isinstance(e, dict) and len(e) == 1 and ("column" in e or "literal" in e)) for e in exprs):
+        tc.ctx.check(tc.ctx.L.gpuq_op_check(op.h, tc.stream_ptr()))
     return DeviceTable(cols, n)
 
 

@@ -699,6 +699,12 @@ def test_runtime_limits_fail_loudly(tc):
     with pytest.raises(g.GpuqError) as e:
         dev_rows(tc, g.FilterExec(binary(col("s", s), Op.Lt, lit("short")), src).execute(0, tc))
     assert e.value.status == 3 and "15 bytes" in str(e.value)
+    with pytest.raises(g.GpuqError) as e:      # the same comparison as a computed projection (asynchronous call: the executors read the status word)
+        dev_rows(tc, g.ProjectionExec([(binary(col("s", s), Op.Lt, lit("short")), "b"), (col("v", s), "v")], src).execute(0, tc))
+    assert e.value.status == 3 and "15 bytes" in str(e.value)
+    with pytest.raises(g.GpuqError) as e:
+        g.NativePlan(g.ProjectionExec([(binary(col("s", s), Op.Lt, lit("short")), "b"), (col("v", s), "v")], src), tc).execute(0)
+    assert e.value.status == 3 and "15 bytes" in str(e.value)
     with pytest.raises(g.GpuqError) as e:      # two columns: equal prefixes and lengths would compare equal
         dev_rows(tc, g.FilterExec(binary(col("s", s), Op.Eq, col("s", s)), src).execute(0, tc))
     assert e.value.status == 3
