@@ -31,7 +31,7 @@ class gpuq_csv_options(C.Structure):
 
 class gpuq_input(C.Structure):
     _fields_ = [("cols", C.POINTER(gpuq_column)), ("n_cols", C.c_int32), ("n_via", C.c_int32), ("n_rows", C.c_int64),
-                ("via", C.c_void_p * 3)]
+                ("via", C.c_void_p * 3), ("n_rows_dev", C.c_void_p)]
 
 
 class gpuq_lineitem_cols(C.Structure):
@@ -123,6 +123,10 @@ def lib():
         "gpuq_filter_run": (i32, [vp, vp, C.POINTER(gpuq_input), i32, vp, vp]),
         "gpuq_project_run": (i32, [vp, vp, C.POINTER(gpuq_input), C.POINTER(gpuq_column), i32]),
         "gpuq_aggregate_run": (i32, [vp, vp, C.POINTER(gpuq_input), C.POINTER(gpuq_column), i32, i64, C.POINTER(i64)]),
+        "gpuq_aggregate_run_deferred": (i32, [vp, vp, C.POINTER(gpuq_input), C.POINTER(gpuq_column), i32, i64, C.POINTER(i64), C.POINTER(vp)]),
+        "gpuq_op_set_deferred": (i32, [vp, i32]),
+        "gpuq_op_can_defer": (i32, [vp]),
+        "gpuq_ops_settle": (i32, [vp, vp, C.POINTER(vp), i32, C.POINTER(vp), i32, C.POINTER(u64)]),
         "gpuq_join_build_run": (i32, [vp, vp, C.POINTER(gpuq_input), i32, i64, C.POINTER(vp)]),
         "gpuq_join_table_free": (None, [vp]),
         "gpuq_join_probe_run": (i32, [vp, vp, vp, C.POINTER(gpuq_input), i32, vp, vp, u64, vp]),
@@ -156,6 +160,7 @@ def lib():
         "gpuq_task_free": (None, [vp]),
         "gpuq_plan_metrics": (i32, [vp, C.c_char_p, C.c_size_t]),
         "gpuq_plan_set_comm": (i32, [vp, vp]),
+        "gpuq_plan_exec_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "gpuq_comm_unique_id": (i32, [vp]),
         "gpuq_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
         "gpuq_comm_create_host": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),

@@ -60,6 +60,12 @@ struct gpuq_op {
   SortSpec sort{}; i64 fetch = -1; bool sort_guess_failed = false, join_guess_failed = false;
   // partition
   uint32_t nparts = 0;
+  // deferred execution (include/gpuq.h): what the last completed synchronous run learned, and what a deferred run may leave behind
+  bool deferred = false, defer_client = false;
+  uint32_t expect_flags = 0;        // status bits a deferred run is allowed to raise (a build side known to hold duplicate keys)
+  struct { bool valid = false, dense = false, sparse_bits = false, has_dups = false; i64 kmin = 0; u64 krange = 0; u64 n_slots = 0; } jb;
+  struct { bool valid = false; int path = 0, gmax = 0; u64 est = 0; bool use_lds = false; i64 groups = 0; } ag;      // path: 1 LDS dictionary, 2 global hash table
+  struct { bool valid = false; SortPack K{}; int total = 0; } so;
   // scratch
   DevBuf ws[10];
   // pinned host words for the small device->host reads (flags, counts): a pageable destination makes every such copy a
@@ -89,6 +95,7 @@ template <class F> int guarded(gpuq_ctx* ctx, F&& f) {
   catch (const HipError& e) { set_err(ctx, e.what()); return GPUQ_ERR_HIP; }
   catch (const Unsupported& e) { set_err(ctx, e.what()); return GPUQ_ERR_UNSUPPORTED; }
   catch (const Capacity& e) { set_err(ctx, e.what()); return GPUQ_ERR_CAPACITY; }
+  catch (const Retry& e) { set_err(ctx, e.what()); return GPUQ_ERR_RETRY; }
   catch (const std::bad_alloc&) { set_err(ctx, "out of host memory"); return GPUQ_ERR_INTERNAL; }
   catch (const std::exception& e) { set_err(ctx, e.what()); return GPUQ_ERR_INVALID; }
 }
@@ -119,7 +126,7 @@ DevProgram bind_program(const CompiledProgram& cp, const Schema& schema, const D
   DevProgram P{};
   P.n_cols = (int)cp.col_field.size(); P.n_insns = cp.n_insns; P.pred_reg = cp.pred_reg; P.n_via = in->n_via;
   for (int k = 0; k < in->n_via; ++k) { if (!in->via[k] && in->n_rows > 0) throw std::runtime_error("index vector is NULL"); P.via[k] = in->via[k]; }
-  P.code = code_dev; P.flags = flags_dev;
+  P.code = code_dev; P.flags = flags_dev; P.n_dev = (const u64*)in->n_rows_dev;
   for (size_t c = 0; c < cp.col_field.size(); ++c) {
     const int fi = cp.col_field[c];
     const Field& f = schema.fields[fi];
@@ -140,6 +147,10 @@ DevProgram bind_program(const CompiledProgram& cp, const Schema& schema, const D
   return P;
 }
 
+// entry points that decide things on the host from the exact row count cannot take a device-side one
+void need_exact_rows(const gpuq_input* in, const char* what) {
+  if (in && in->n_rows_dev) throw std::runtime_error(std::string(what) + ": the input carries a device-side row count (n_rows_dev); this entry point needs the exact count");
+}
 void reset_flags(gpuq_op* op, hipStream_t s) { HIPCHECK(hipMemsetAsync(op->flags_dev.p, 0, 4, s)); }
 // words [0, n) of the op's status block (flags, pad, n_groups, pad) -> host
 void read_status(gpuq_op* op, hipStream_t s, uint32_t* out, int n) {
@@ -156,6 +167,7 @@ void raise_flags(uint32_t f) {
   if (f & FLAG_OUT_OVERFLOW) throw Capacity("join output capacity exceeded; see the pair count for the required size");
   if (f & FLAG_TABLE_FULL) throw std::runtime_error("hash table full");
   if (f & FLAG_GROUP_OVERFLOW) throw Capacity("group capacity exceeded");
+  if (f & FLAG_SORT_LAYOUT) throw std::runtime_error("a row does not fit the remembered sort key layout");
 }
 
 struct ProfScope {
@@ -721,6 +733,50 @@ int gpuq_op_check(gpuq_op* op, void* stream) {
   if (!op) return GPUQ_ERR_INVALID;
   return guarded(op->ctx, [&]() { check_ctx(op->ctx); const uint32_t f = read_flags(op, use_stream(stream)); if (f) { reset_flags(op, use_stream(stream)); raise_flags(f); } });
 }
+int gpuq_op_set_deferred(gpuq_op* op, int on) { if (!op) return GPUQ_ERR_INVALID; op->deferred = on != 0; op->defer_client = true; return GPUQ_OK; }
+int gpuq_op_can_defer(gpuq_op* op) {
+  if (!op) return 0;
+  switch (op->kind) {
+    case K_FILTER: case K_PROJECT: case K_JOIN_PROBE: return 1;      // nothing is read back inside these calls
+    case K_JOIN_BUILD: return op->jb.valid ? 1 : 0;
+    case K_AGG: return op->ag.valid ? 1 : 0;
+    case K_SORT: return op->so.valid ? 1 : 0;
+    default: return 0;
+  }
+}
+int gpuq_ops_settle(gpuq_ctx* ctx, void* stream, gpuq_op* const* ops, int n_ops, const uint64_t* const* words, int n_words, uint64_t* words_out) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (n_ops < 0 || n_words < 0 || (n_ops && !ops) || (n_words && (!words || !words_out))) throw std::runtime_error("settle: bad arguments");
+    hipStream_t s = use_stream(stream);
+    const int total = n_ops + n_words;
+    // one pinned block and one device block per calling thread (plans of several task threads settle concurrently)
+    struct Blocks { u64* host = nullptr; DevBuf dev; size_t cap = 0; };
+    thread_local Blocks B;
+    if ((size_t)total > B.cap) {
+      if (B.host) (void)hipHostFree(B.host);
+      B.cap = (size_t)std::max(total, 256); B.host = nullptr;
+      HIPCHECK(hipHostMalloc((void**)&B.host, B.cap * 8, hipHostMallocDefault));
+    }
+    u64* dev = (u64*)B.dev.ensure(B.cap * 8);
+    for (int base = 0; base < total; base += 64) {
+      GatherWords g{}; g.n = std::min(64, total - base);
+      for (int i = 0; i < g.n; ++i) { const int k = base + i; g.src[i] = k < n_ops ? (const u64*)ops[k]->flags_dev.p : (const u64*)words[k - n_ops]; if (!g.src[i]) throw std::runtime_error("settle: NULL word"); }
+      launch_gather_words(s, g, dev + base);
+    }
+    HIPCHECK(hipGetLastError());
+    if (total > 0) HIPCHECK(hipMemcpyAsync(B.host, dev, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < n_words; ++i) words_out[i] = B.host[n_ops + i];
+    bool retry = false;
+    for (int i = 0; i < n_ops; ++i) {
+      const uint32_t f = (uint32_t)B.host[i];
+      if (f) reset_flags(ops[i], s);
+      if (f & ~ops[i]->expect_flags) { retry = true; ops[i]->jb.valid = false; ops[i]->ag.valid = false; ops[i]->so.valid = false; }
+    }
+    if (retry) throw Retry("an assumption of a deferred run did not hold");
+  });
+}
 int gpuq_op_profile(gpuq_op* op, int enable, float* kernel_ms_out, int* launches_out) {
   if (!op) return GPUQ_ERR_INVALID;
   return guarded(op->ctx, [&]() {
@@ -772,8 +828,10 @@ int gpuq_project_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_colum
 }
 
 // ---------------------------------------------------------------- aggregate
-int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs, int64_t cap, int64_t* n_groups_out) {
+// ndev_out != NULL: the deferred form is allowed (gpuq_aggregate_run_deferred)
+static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs, int64_t cap, int64_t* n_groups_out, const uint64_t** ndev_out) {
   if (!op) return GPUQ_ERR_INVALID;
+  if (ndev_out) *ndev_out = nullptr;
   return guarded(op->ctx, [&]() {
     check_ctx(op->ctx);
     if (op->kind != K_AGG) throw std::runtime_error("not an aggregate operator");
@@ -816,13 +874,63 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
       gpuq_input pin{}; pin.cols = pcols.data(); pin.n_cols = nk + na; pin.n_rows = rows; pin.n_via = 0;
       for (auto& pc : op->posts) {
         DevProgram PP = bind_program(pc.prog, op->post_schema, pc.code.as<DevCode>(), op->flags_dev.as<uint32_t>(), &pin);
-        PP.n_dev = rows_dev;
+        PP.n_dev = (const u64*)rows_dev;      // (the 8 bytes at raw.n_groups are zeroed together: the u32 count reads as a u64)
         const int no = (int)pc.prog.out_reg.size();
         std::vector<gpuq_field_info> fi(op->out_fields.begin() + pc.first_out, op->out_fields.begin() + pc.first_out + no);
         OutSpec O = make_outspec(pc.prog, outs + pc.first_out, no, fi);
         { JitScope js(op, pc.prog, 2, rows); launch_project(s, PP, rows, O); }
       }
     };
+    // ---- deferred form: the strategy, table size and output capacity of the last completed synchronous run, nothing read back; a
+    // table or an output that turns out too small raises the status word gpuq_ops_settle reads
+    if (ndev_out && op->deferred && op->ag.valid) {
+      if (op->ag.path == 1) {
+        const int gmax = op->ag.gmax;
+        int nb = 0; const size_t wsb = agg_tiny_workspace_bytes(gmax, nk, na, &nb);
+        void* wsp = op->ws[4].ensure(wsb);
+        alloc_raw(64);
+        if ((i64)raw.cap <= cap) {
+          const std::string spec = agg_tiny_spec(op, gmax);
+          { JitScope js(op, op->prog, 3, n, spec); ProfScope ps(op, s); launch_agg_tiny(s, P, n, op->agg, gmax, wsp); }
+          launch_agg_tiny_merge(s, P, n, op->agg, gmax, wsp, raw);
+          run_post((uint32_t)raw.cap, raw.n_groups);
+          HIPCHECK(hipGetLastError());
+          for (int i = 0; i < n_outs; ++i) outs[i].length = raw.cap;
+          if (n_groups_out) *n_groups_out = raw.cap;
+          *ndev_out = (const uint64_t*)raw.n_groups;
+          return;
+        }
+      } else if (op->ag.path == 2) {
+        HashTable T{};
+        T.key_words = op->keys.key_words; T.slot_words = 1 + T.key_words + 2 * na;
+        const u64 est = op->ag.est;
+        i64 rcap = op->ag.groups + op->ag.groups / 4 + 1024; if (rcap > cap) rcap = cap;
+        if (rcap >= 1 && rcap <= 0x7FFFFFFFll) {
+          T.n_slots = next_pow2(est * 2);
+          T.slots = (u64*)op->ws[5].ensure((size_t)T.n_slots * T.slot_words * 8);
+          launch_ht_init(s, T, &op->agg);
+          if (op->ag.use_lds) {
+            int n_fsum = 0; for (int a = 0; a < na; ++a) n_fsum += op->agg.acc_kind[a] == ACC_FSUM;
+            u64* fstage = nullptr;
+            const size_t fbytes = (size_t)T.n_slots * (size_t)n_fsum * (size_t)agg_lds_grid(n) * 8;
+            if (n_fsum > 0 && fbytes <= ((size_t)256 << 20)) { fstage = (u64*)op->ws[8].ensure(fbytes); HIPCHECK(hipMemsetAsync(fstage, 0, fbytes, s)); }
+            JitScope js(op, op->prog, 13, n); ProfScope ps(op, s); launch_agg_lds(s, P, n, op->keys, op->agg, T, fstage, n_fsum);
+          }
+          else { JitScope js(op, op->prog, 4, n); ProfScope ps(op, s); launch_agg_hash(s, P, n, op->keys, op->agg, T); }
+          alloc_raw(rcap);
+          launch_agg_hash_extract(s, op->keys, op->agg, T, raw, op->flags_dev.as<uint32_t>());
+          run_post((uint32_t)raw.cap, raw.n_groups);
+          HIPCHECK(hipGetLastError());
+          for (int i = 0; i < n_outs; ++i) outs[i].length = raw.cap;
+          if (n_groups_out) *n_groups_out = raw.cap;
+          *ndev_out = (const uint64_t*)raw.n_groups;
+          return;
+        }
+      }
+    }
+    if (in->n_rows_dev) throw std::runtime_error("aggregate: a device-side row count needs a deferred operator with a completed synchronous run (gpuq_op_can_defer)");
+    op->ag.valid = false;
+    int path_done = 0, gmax_done = 0; u64 est_done = 0; bool lds_done = false;
     bool done = false;
     std::string strat = op->strategy;
     if (nk == 0) strat = "tiny";
@@ -886,7 +994,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
           read_status(op, s, fw, 4);
           const uint32_t f = fw[0];
           if (f & ~FLAG_GROUP_OVERFLOW) { reset_flags(op, s); raise_flags(f & ~FLAG_GROUP_OVERFLOW); }
-          if (!(f & FLAG_GROUP_OVERFLOW)) { ng = fw[2]; done = true; posted = ahead; break; }
+          if (!(f & FLAG_GROUP_OVERFLOW)) { ng = fw[2]; done = true; posted = ahead; path_done = 1; gmax_done = gmax; break; }
         }
         if (!done && strat == "tiny") throw Capacity("more groups than the LDS aggregate holds; use strategy hash/auto");
       }
@@ -966,6 +1074,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
         if (f) { reset_flags(op, s); raise_flags(f); }
         break;
       }
+      path_done = 2; est_done = est; lds_done = use_lds;
       if (n <= (1ll << 20)) {
         // small input: groups <= rows, so size the raw result by n and extract once (one sync instead of three)
         alloc_raw(std::max<i64>(n, 1));
@@ -1010,6 +1119,7 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
       }
     }
     op->last_groups = (i64)ng;
+    if (path_done) { op->ag.valid = true; op->ag.path = path_done; op->ag.gmax = gmax_done; op->ag.est = est_done; op->ag.use_lds = lds_done; op->ag.groups = (i64)ng; op->expect_flags = 0; }
     if (n_groups_out) *n_groups_out = ng;
     if ((i64)ng > cap) throw Capacity("aggregate produced " + std::to_string(ng) + " groups, output capacity is " + std::to_string(cap));
     for (int i = 0; i < n_outs; ++i) outs[i].length = ng;
@@ -1019,6 +1129,14 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
       HIPCHECK(hipStreamSynchronize(s));
     }
   });
+}
+
+int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs, int64_t cap, int64_t* n_groups_out) {
+  return aggregate_run_impl(op, stream, in, outs, n_outs, cap, n_groups_out, nullptr);
+}
+int gpuq_aggregate_run_deferred(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs, int64_t cap, int64_t* n_bound_out, const uint64_t** n_groups_dev_out) {
+  if (!n_groups_dev_out) return GPUQ_ERR_INVALID;
+  return aggregate_run_impl(op, stream, in, outs, n_outs, cap, n_bound_out, n_groups_dev_out);
 }
 
 // ---------------------------------------------------------------- join
@@ -1066,9 +1184,14 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     static const bool spec_on = []() { const char* e = getenv("GPUQ_JOIN_SPECULATE"); return !(e && e[0] == '0'); }();
     const int dense_mode = op->ctx->join_dense; const i64 dense_ratio = op->ctx->join_dense_ratio;
     const bool narrow_key = dense_mode && n > 0 && op->keys.n_keys == 1 && !op->keys.key_wide[0] && !op->keys.null_word;
-    auto attempt = [&](const bool guess) -> bool {
+    // mode 0: the key range is measured, 1: guessed from a sample, 2: deferred -- the layout of the last completed synchronous run is
+    // taken as it is (no pass over the keys, nothing read back; the build kernel's own bounds / duplicate tests raise the status word
+    // that gpuq_ops_settle reads)
+    auto attempt = [&](const int mode) -> bool {
+    const bool guess = mode == 1, memo = mode == 2;
     bool dense = false; i64 kmin = 0; u64 krange = 0, kcount = 0;
-    if (narrow_key) {
+    if (memo) { dense = op->jb.dense; kmin = op->jb.kmin; krange = op->jb.krange; }
+    else if (narrow_key) {
       u64* kr = (u64*)op->ws[0].ensure(32);
       const u64 init[3] = {0x7FFFFFFFFFFFFFFFull, 0x8000000000000000ull, 0};
       const i64 wstep = guess ? std::max<i64>(1, ((n + 63) >> 6) >> 12) : 1;
@@ -1099,7 +1222,7 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
       t->T.n_slots = 0; t->T.slots = nullptr;
       t->T.dense = (uint32_t*)t->dense.ensure((size_t)krange * 4 + 16); t->T.dense_min = kmin; t->T.dense_range = krange;
       // sparse domain (fewer than one value in four is a key): presence bitmap + uninitialised row array (gpuq_kernels.h)
-      sparse_bits = kcount * 4 < krange;
+      sparse_bits = memo ? op->jb.sparse_bits : kcount * 4 < krange;
       if (sparse_bits) {
         const size_t bb = ((size_t)krange + 63) / 64 * 8 + 8;
         t->T.dense_bits = (uint32_t*)t->dense_bits.ensure(bb);
@@ -1108,6 +1231,18 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     } else {
       t->T.n_slots = next_pow2(std::max<u64>((u64)n * 3, 1024));   // load factor in (0.17, 0.33]: a miss ends after ~1.5 slot visits (2.5 at 0.5)
       t->T.slots = (u64*)t->slots.ensure((size_t)t->T.n_slots * t->T.slot_words * 8);
+    }
+    if (memo) {
+      uint32_t* next = (uint32_t*)t->next.ensure((size_t)std::max<i64>(build_rows_bound, 1) * 4);
+      const size_t bm = ((size_t)build_rows_bound + 63) / 64 * 8 + 8;
+      uint32_t* present = nullptr;
+      if (op->build_side_rows) { present = (uint32_t*)t->present.ensure(bm); HIPCHECK(hipMemsetAsync(present, 0, bm, s)); }
+      t->has_present = op->build_side_rows;
+      if (!dense) launch_ht_init(s, t->T, nullptr);
+      { JitScope js(op, op->prog, 5, n); ProfScope ps(op, s); launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq); }
+      HIPCHECK(hipGetLastError());
+      t->has_dups = op->jb.has_dups;
+      return true;
     }
     uint32_t* next = (uint32_t*)t->next.ensure((size_t)std::max<i64>(build_rows_bound, 1) * 4);
     const size_t bm = ((size_t)build_rows_bound + 63) / 64 * 8 + 8;
@@ -1136,11 +1271,16 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     if (f & ~FLAG_DUP_BUILD_KEY) { reset_flags(op, s); raise_flags(f & ~FLAG_DUP_BUILD_KEY); }
     if (f) reset_flags(op, s);
     t->has_dups = (f & FLAG_DUP_BUILD_KEY) != 0;
+    // what a deferred run goes by next time (a guessed range is remembered widened, as it was used)
+    op->jb.valid = true; op->jb.dense = dense; op->jb.sparse_bits = t->T.dense_bits != nullptr; op->jb.has_dups = t->has_dups; op->jb.kmin = kmin; op->jb.krange = krange;
+    op->expect_flags = t->has_dups ? FLAG_DUP_BUILD_KEY : 0u;
     return true;
     };
     bool built = false;
     static const bool trace = getenv("GPUQ_TRACE_JOIN_BUILD") != nullptr;
-    if (spec_on && narrow_key && n >= (1ll << 21) && !op->join_guess_failed) { built = attempt(true); if (!built) op->join_guess_failed = true; if (trace) fprintf(stderr, "[gpuq] join build: %lld rows, guessed range %s\n", (long long)n, built ? "held" : "did not hold"); }
+    if (op->deferred && op->jb.valid) { built = attempt(2); if (trace) fprintf(stderr, "[gpuq] join build: %lld rows (bound), deferred with the remembered layout\n", (long long)n); }
+    else if (in->n_rows_dev) throw std::runtime_error("join build: a device-side row count needs a deferred operator with a completed synchronous run (gpuq_op_can_defer)");
+    if (!built && spec_on && narrow_key && n >= (1ll << 21) && !op->join_guess_failed) { built = attempt(true); if (!built) op->join_guess_failed = true; if (trace) fprintf(stderr, "[gpuq] join build: %lld rows, guessed range %s\n", (long long)n, built ? "held" : "did not hold"); }
     if (!built) { attempt(false); if (trace) fprintf(stderr, "[gpuq] join build: %lld rows, measured range, %s\n", (long long)n, t->T.dense ? (t->T.dense_bits ? "array + bitmap" : "array") : "hash table"); }
     *out = t;
   });
@@ -1353,10 +1493,24 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
     if (n <= sort_direct_max()) {      // one block, no min/max read-back
       launch_sort_direct(s, P, n, S, perm_out);
       HIPCHECK(hipGetLastError());
+      if (op->deferred) return;      // (the status word is read by gpuq_ops_settle)
+      if (in->n_rows_dev) throw std::runtime_error("sort: a device-side row count needs a deferred operator (gpuq_op_set_deferred)");
       if (string_key) { const uint32_t f = read_flags(op, s); if (f) { reset_flags(op, s); raise_flags(f); } }      // a value beyond 15 bytes: refuse, do not sort by a prefix
+      // a client that defers (gpuq_op_set_deferred was called on this operator) will come back with a BOUND instead of a count, and
+      // the bound of a handful of groups is easily beyond what one block sorts: learn the key layout now, while reading back is allowed
+      if (op->defer_client) { int total = 0; const SortPack K = sort_key_plan(op, s, P, n, &total); op->so.valid = true; op->so.K = K; op->so.total = total; op->expect_flags = 0; }
       return;
     }
     int total = 0;
+    // deferred: the key layout of the last completed synchronous run, verified row by row by the pack kernel (FLAG_SORT_LAYOUT); rows
+    // beyond the device-side count become padding records that sort behind everything
+    if (op->deferred && op->so.valid) {
+      SortPack K = op->so.K; K.check = 2;
+      sort_with_plan(op, s, P, n, K, op->so.total, perm_out);
+      return;
+    }
+    if (in->n_rows_dev) throw std::runtime_error("sort: a device-side row count needs a deferred operator with a completed synchronous run (gpuq_op_can_defer)");
+    op->so.valid = false;
     // Large inputs: the exact min/max pass reads every key once more (0.48 of 3.15 ms at 2^27 Decimal128 keys).  Guess the layout from
     // 2^18 sampled rows instead, let the pack kernel verify it on the way, and read one word back at the end; a guess that does not
     // hold (outliers beyond the margin, a NULL the sample did not see) costs the pack + passes again, so an operator whose guess
@@ -1374,18 +1528,20 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
         HIPCHECK(hipMemcpyAsync(&eflags, op->flags_dev.p, 4, hipMemcpyDeviceToHost, s));      // the pack kernel evaluated every row
         HIPCHECK(hipStreamSynchronize(s));
         if (eflags) { reset_flags(op, s); raise_flags(eflags); }
-        if (!failed) return;
+        if (!failed) { op->so.valid = true; op->so.K = G; op->so.total = total; op->expect_flags = 0; return; }
         op->sort_guess_failed = true;
       }
     }
     const SortPack K = sort_key_plan(op, s, P, n, &total);
     sort_with_plan(op, s, P, n, K, total, perm_out);
+    op->so.valid = true; op->so.K = K; op->so.total = total; op->expect_flags = 0;
   });
 }
 
 // pack + LSD radix passes over a composite key whose layout is known (SortExec; the ordered fan-in when passes are cheaper than rounds)
-static void sort_with_plan(gpuq_op* op, hipStream_t s, const DevProgram& P, const i64 n, const SortPack& K, const int total, uint32_t* perm_out) {
+static void sort_with_plan(gpuq_op* op, hipStream_t s, const DevProgram& P, const i64 n, const SortPack& K_in, const int total, uint32_t* perm_out) {
   {
+    SortPack K = K_in; K.total_bits = total;
     const SortSpec& S = op->sort;
     // 2. pack + LSD radix passes.  <= 32 key bits: one u64 (key << 32 | row) record per row, no separate id array.
     const bool packed = total >= 1 && total <= 32 && n > sort_small_max();
@@ -1438,6 +1594,7 @@ int gpuq_merge_run(gpuq_op* op, void* stream, const gpuq_input* in, const int64_
     if (op->kind != K_SORT) throw std::runtime_error("not a sort operator");
     if (!run_offsets || n_runs < 1) throw std::runtime_error("run_offsets is NULL / no runs");
     hipStream_t s = use_stream(stream);
+    need_exact_rows(in, "merge");
     const i64 n = in->n_rows;
     if (run_offsets[0] != 0 || run_offsets[n_runs] != n) throw std::runtime_error("run_offsets must start at 0 and end at the row count");
     for (int r = 0; r < n_runs; ++r) if (run_offsets[r] > run_offsets[r + 1]) throw std::runtime_error("run_offsets must not decrease");
@@ -1496,6 +1653,7 @@ int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t
   return guarded(op->ctx, [&]() {
     check_ctx(op->ctx);
     if (op->kind != K_PARTITION) throw std::runtime_error("not a partition operator");
+    need_exact_rows(in, "partition");
     hipStream_t s = use_stream(stream);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     const i64 n = in->n_rows;

@@ -12,6 +12,7 @@ namespace gpuq {
 struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
 struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
 struct Capacity : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Retry : std::runtime_error { using std::runtime_error::runtime_error; };      // deferred execution: an assumption did not hold (GPUQ_ERR_RETRY)
 
 #define HIPCHECK(expr)                                                                                   \
   do {                                                                                                   \
@@ -83,8 +84,9 @@ struct DevBuf {
   DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { if (p) DevPool::get().give(p, cap, st); }
   void* ensure(size_t bytes) {
-    st = tls_stream();
     if (bytes > cap) {
+      // the old block goes back tagged with the stream that last used it (its kernels may still be in flight there), not with the
+      // stream of the caller that happens to grow the buffer
       if (p) { DevPool::get().give(p, cap, st); p = nullptr; cap = 0; }
       size_t want = bytes < 256 ? 256 : bytes;
       p = DevPool::get().take(want, &cap);
@@ -94,6 +96,7 @@ struct DevBuf {
         cap = want;
       }
     }
+    st = tls_stream();
     return p;
   }
   template <class T> T* as() const { return (T*)p; }

@@ -92,9 +92,13 @@ struct DevProgram {
   const uint32_t* via[MAX_VIA];
   const DevCode* code;   // device memory
   uint32_t* flags;       // device status word (FLAG_* bits)
-  const uint32_t* n_dev; // k_project only: when set, the row count is min(*n_dev, n) -- lets the host queue the projection
-                         // of an aggregate's groups before it knows how many there are
+  const u64* n_dev;      // deferred execution: when set, the row count is min(*n_dev, n) and the launch's n is only a bound -- a producer's
+                         // count (join pairs, filter survivors, groups) is handed over on the device, the host never reads it between operators
 };
+__device__ __forceinline__ i64 rows_of(const DevProgram& P, const i64 n_bound) {
+  if (P.n_dev) { const i64 nd = (i64)*P.n_dev; return nd < n_bound ? nd : n_bound; }
+  return n_bound;
+}
 
 // launcher-side dispatch over the column-slot template parameter
 #define GPUQ_DISPATCH_MAXC(ncols, CALL)          \
@@ -111,6 +115,7 @@ constexpr uint32_t FLAG_TABLE_FULL = 4u;
 constexpr uint32_t FLAG_DUP_BUILD_KEY = 8u;
 constexpr uint32_t FLAG_OUT_OVERFLOW = 16u;
 constexpr uint32_t FLAG_WIDE_MINMAX = 32u;  // MIN/MAX over a value outside the int64 range
+constexpr uint32_t FLAG_SORT_LAYOUT = 64u;  // a row does not fit the composite sort key layout remembered from the previous run (deferred execution)
 
 // Per-lane register file.  lo/hi MUST be separate plain u64 arrays local to the kernel: hipcc then
 // keeps them in VGPRs and lowers wave-uniform dynamic indexing to s_set_gpr_idx_on.  Wrapped in a

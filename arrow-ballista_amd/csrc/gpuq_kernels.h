@@ -89,6 +89,8 @@ struct SortPack {                   // computed on the host from the per-key min
   int32_t vbits[MAX_SORT_KEYS];     // width of the value field (without the null flag)
   int32_t check;                    // 1: the layout was GUESSED from a sample -- the pack kernel verifies every row against it and raises
                                     // hist[SORT_MAX_PASSES * 256] when a value falls outside its field or a NULL meets a key without a null bit
+                                    // 2: the same, reported as FLAG_SORT_LAYOUT in the operator's status word (deferred execution: nobody reads hist)
+  int32_t total_bits;               // width of the composite key: padding records (rows beyond a device-side row count) hold all ones in it
 };
 
 // aggregate post-processing (kernels_scan.hip): AoS result -> one (lo,hi) column per key / accumulator
@@ -109,8 +111,12 @@ struct OrdersCols { i64* o_orderkey; i64* o_custkey; int32_t* o_orderdate; int32
 struct CustomerCols { i64* c_custkey; i64* c_nationkey; uint8_t* c_mktsegment; int32_t* c_mktsegment_off; };
 struct SupplierCols { i64* s_suppkey; i64* s_nationkey; };
 
+// deferred execution: up to 64 device words gathered into one contiguous block (gpuq_ops_settle)
+struct GatherWords { int32_t n; int32_t pad; const u64* src[64]; };
+
 #ifndef GPUQ_JIT
 // ---- host launch interface (AOT build only)
+void launch_gather_words(hipStream_t s, const GatherWords& g, u64* out);
 void set_num_cus(int n);
 int num_cus();
 void launch_filter_bitmap(hipStream_t s, const DevProgram& P, i64 n, u64* bitmap, uint32_t* block_counts, int nblocks, i64 words_per_block);

@@ -202,7 +202,8 @@ __device__ __forceinline__ void for_rows_in_flight(const DevProgram& P, const i6
 }
 
 template <int MAXC>
-__device__ __forceinline__ void k_agg_hash_body(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T) {
+__device__ __forceinline__ void k_agg_hash_body(const DevProgram P, const i64 n_arg, const KeySpec K, const AggSpec A, const HashTable T) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   const i64 nwords = (n + 63) >> 6;
   const int cell0 = 1 + T.key_words;
   // Rows with equal keys in neighbouring lanes (clustered input: lineitem rows of one order, a join's probe-ordered
@@ -386,8 +387,9 @@ __global__ void __launch_bounds__(HBLOCK) k_agg_hash_extract(const KeySpec K, co
 //   k_bucket_bounds     lower bound of every bucket in the sorted bucket-id array
 //   k_agg_bucket        per bucket: LDS find-or-insert + accumulate over the bucket's rows (re-evaluated by row id), extract
 template <int MAXC>
-__device__ __forceinline__ void k_agg_bucket_id_body(const DevProgram P, const i64 n, const KeySpec K, const u64 bucket_mask,
+__device__ __forceinline__ void k_agg_bucket_id_body(const DevProgram P, const i64 n_arg, const KeySpec K, const u64 bucket_mask,
                                                          u64* __restrict__ bid, uint32_t* __restrict__ ids) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * HWAVES + hwave(); w < nwords; w += (i64)gridDim.x * HWAVES) {
     const i64 pos = (w << 6) + hlane();
@@ -556,8 +558,9 @@ __device__ __forceinline__ void global_fold(u64* c, const int kind, const u64 vl
 }
 
 template <int MAXC>
-__device__ __forceinline__ void k_agg_lds_body(const DevProgram P, const i64 n, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap,
+__device__ __forceinline__ void k_agg_lds_body(const DevProgram P, const i64 n_arg, const KeySpec K, const AggSpec A, const HashTable T, const uint32_t lcap,
                                                u64* __restrict__ fstage, const int n_fsum) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   extern __shared__ __attribute__((aligned(16))) u64 lslots[];
   __shared__ uint32_t lfull;
   const int key_words = K.key_words;
@@ -844,7 +847,8 @@ extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevPro
 // Key range of the rows the build would insert (single narrow key): decides between the direct-addressed table and
 // open addressing.  out = {min, max, count}, pre-set by the host to {INT64_MAX, INT64_MIN, 0}.
 template <int MAXC>
-__device__ __forceinline__ void k_join_keyrange_body(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out, const i64 wstep) {
+__device__ __forceinline__ void k_join_keyrange_body(const DevProgram P, const i64 n_arg, const KeySpec K, const int null_eq, u64* __restrict__ out, const i64 wstep) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   __shared__ i64 smn[HWAVES], smx[HWAVES]; __shared__ u64 scn[HWAVES];
   i64 mn = 0x7FFFFFFFFFFFFFFFll, mx = (i64)0x8000000000000000ull; u64 cn = 0;
   const int kr = __builtin_amdgcn_readfirstlane(K.key_reg[0]);
@@ -876,9 +880,10 @@ extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevPro
 #endif
 
 template <int MAXC>
-__device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+__device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 n_arg, const KeySpec K, const HashTable T,
                                                        uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
                                                        const int null_eq) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   for_rows_in_flight<MAXC>(P, n, (i64)blockIdx.x * HWAVES + hwave(), (i64)gridDim.x * HWAVES, [&](const i64 w, const i64 pos, const bool active, GPUQ_REGS_PARAM) {
     // `present` = every build-side row that passes the side's predicate, NULL keys included (outer joins emit them).  When rows
     // are positions, the 64 rows of this step ARE word w of the bitmap: one plain 8-byte store (64 lanes OR-ing into two words
@@ -953,10 +958,11 @@ __device__ __forceinline__ uint32_t join_lookup(const HashTable& T, const u64 (&
 // chain step.  Pair order is not input order (DataFusion's is batch-local and unspecified across
 // partitions); the SET of pairs is deterministic.
 template <int MAXC>
-__device__ __forceinline__ void k_join_probe_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+__device__ __forceinline__ void k_join_probe_body(const DevProgram P, const i64 n_arg, const KeySpec K, const HashTable T,
                                                        const uint32_t* __restrict__ next, const int join_type, const int payload_via,
                                                        const int null_eq, uint32_t* __restrict__ out_build, uint32_t* __restrict__ out_probe,
                                                        const u64 out_cap, u64* __restrict__ out_count, uint32_t* __restrict__ visited) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   const i64 nwords = (n + 63) >> 6;
   const bool emit_pairs = (join_type == JT_INNER || join_type == JT_LEFT || join_type == JT_RIGHT || join_type == JT_FULL);
   const bool probe_outer = (join_type == JT_RIGHT || join_type == JT_FULL);
@@ -1054,11 +1060,12 @@ __device__ __forceinline__ uint32_t emit_pairs(const bool emit, const uint32_t h
 // then U resolutions -- the random table access is the long pole of a probe, and one outstanding access per lane cannot
 // cover its latency (measured: 26-38 G probes/s with U = 1 whatever the table size).
 template <int MAXC>
-__device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+__device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, const i64 n_arg, const KeySpec K, const HashTable T,
                                                               const int join_type, const int null_eq, const int payload_via,
                                                               uint32_t* __restrict__ seg_build, uint32_t* __restrict__ seg_probe,
                                                               uint32_t* __restrict__ seg_counts, const int nsegs, const i64 wpw,
                                                               uint32_t* __restrict__ visited) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
 #ifndef GPUQ_PROBE_ROWS
 #define GPUQ_PROBE_ROWS 4
 #endif
@@ -1204,11 +1211,12 @@ __device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, con
 }
 #else
 template <int MAXC>
-__device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+__device__ __forceinline__ void k_join_probe_unique_body(const DevProgram P, const i64 n_arg, const KeySpec K, const HashTable T,
                                                               const int join_type, const int null_eq, const int payload_via,
                                                               uint32_t* __restrict__ seg_build, uint32_t* __restrict__ seg_probe,
                                                               uint32_t* __restrict__ seg_counts, const int nsegs, const i64 wpw,
                                                               uint32_t* __restrict__ visited) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   const i64 seg = (i64)blockIdx.x * HWAVES + hwave();
   if (seg >= nsegs) return;
   const i64 nwords = (n + 63) >> 6;
@@ -1296,8 +1304,9 @@ constexpr u64 RJ_DROPPED = ~0ull;             // a row that cannot match (predic
 struct RjGeom { uint32_t nparts; uint32_t shift; i64 tile; int32_t nblocks; int32_t pad; };      // digit = index >> shift; digit nparts = dropped rows
 
 template <int MAXC>
-__device__ __forceinline__ void k_rj_pack_body(const DevProgram P, const i64 n, const KeySpec K, const HashTable T, const int payload_via, const RjGeom G,
+__device__ __forceinline__ void k_rj_pack_body(const DevProgram P, const i64 n_arg, const KeySpec K, const HashTable T, const int payload_via, const RjGeom G,
                                                    u64* __restrict__ rec, int32_t* __restrict__ hist) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   __shared__ uint32_t lcnt[RJ_MAX_PARTS + 1];
   for (uint32_t d = threadIdx.x; d <= G.nparts; d += HBLOCK) lcnt[d] = 0;
   __syncthreads();

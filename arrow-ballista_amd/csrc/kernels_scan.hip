@@ -25,10 +25,11 @@ __device__ __forceinline__ u64 uniform_u64(u64 v) {   // value known to be equal
 // Pass 1: evaluate the predicate once per row, keep it as a bitmap (N/8 bytes) plus one
 // count per block.  Block b owns the contiguous word range [b*wpb, (b+1)*wpb).
 template <int MAXC>
-__device__ __forceinline__ void k_filter_bitmap_body(const DevProgram P, const i64 n, u64* __restrict__ bitmap,
+__device__ __forceinline__ void k_filter_bitmap_body(const DevProgram P, const i64 n_arg, u64* __restrict__ bitmap,
                                                          uint32_t* __restrict__ block_counts, const i64 wpb) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   __shared__ uint32_t wave_cnt[WAVES];
-  const i64 nwords = (n + 63) >> 6;
+  const i64 nwords = (n_arg + 63) >> 6;      // every word up to the BOUND is written (zeros beyond the actual rows): the compaction reads them all
   const i64 w0 = (i64)blockIdx.x * wpb;
   i64 w1 = w0 + wpb; if (w1 > nwords) w1 = nwords;
   uint32_t cnt = 0;
@@ -133,8 +134,7 @@ __global__ void __launch_bounds__(BLOCK) k_compact(const u64* __restrict__ bitma
 // ------------------------------------------------------------------ project
 template <int MAXC>
 __device__ __forceinline__ void k_project_body(const DevProgram P, const i64 n_arg, const OutSpec O) {
-  i64 n = n_arg;
-  if (P.n_dev) { const i64 nd = (i64)*P.n_dev; if (nd < n) n = nd; }
+  const i64 n = rows_of(P, n_arg);
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * WAVES + wave_id(); w < nwords; w += (i64)gridDim.x * WAVES) {
     const i64 pos = (w << 6) + lane_id();
@@ -242,8 +242,9 @@ __device__ __forceinline__ void lds_st(u64* p, u64 v) { __hip_atomic_store(p, v,
 #define LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 
 template <int MAXC>
-__device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n, const AggSpec A, const int gmax_arg,
+__device__ __forceinline__ void k_agg_tiny_body(const DevProgram P, const i64 n_arg, const AggSpec A, const int gmax_arg,
                                                     char* __restrict__ workspace, const size_t partial_stride) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // Under the JIT the aggregate's shape is a compile-time constant (capi.cpp emits JIT_* into the source):
   // loops unroll, the switch over accumulator kinds folds, every register index is static.
@@ -750,6 +751,17 @@ __global__ void __launch_bounds__(MERGE_BLOCK) k_agg_tiny_merge(const AggSpec A,
   for (int i = tid; i < nf * kstride * 2; i += MERGE_BLOCK) out.keys[i] = fkeys[i];
   for (int i = tid; i < nf; i += MERGE_BLOCK) out.key_nulls[i] = fnulls[i];
   if (tid == 0) *out.n_groups = (uint32_t)nf;
+}
+#endif
+
+// ------------------------------------------------------------------ deferred execution: status and count words of a whole plan in one copy
+#ifndef GPUQ_JIT
+__global__ void __launch_bounds__(64) k_gather_words(const GatherWords g, u64* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i < g.n) out[i] = *g.src[i];
+}
+void launch_gather_words(hipStream_t s, const GatherWords& g, u64* out) {
+  if (g.n > 0) hipLaunchKernelGGL(k_gather_words, dim3(1), dim3(64), 0, s, g, out);
 }
 #endif
 

@@ -60,7 +60,8 @@ __device__ __forceinline__ void mm_reduce_store(MinMax& m, int k, u64 (*red)[MAX
   if (slane() == 0) { red[swave()][k][0] = m.mn_lo; red[swave()][k][1] = m.mn_hi; red[swave()][k][2] = m.mx_lo; red[swave()][k][3] = m.mx_hi; red[swave()][k][4] = m.fl; }
 }
 template <int MAXC>
-__device__ __forceinline__ void k_sort_minmax_body(const DevProgram P, const i64 n, const SortSpec S, u64* __restrict__ out, const i64 wstep) {
+__device__ __forceinline__ void k_sort_minmax_body(const DevProgram P, const i64 n_arg, const SortSpec S, u64* __restrict__ out, const i64 wstep) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   __shared__ u64 red[SWAVES][MAX_SORT_KEYS][5];
   MinMax m0, m1, m2, m3;   // scalars on purpose: an indexed array here competes with the register file for promotion
   mm_init(m0); mm_init(m1); mm_init(m2); mm_init(m3);
@@ -106,6 +107,11 @@ extern "C" __global__ void __launch_bounds__(SBLOCK) gpuq_jit_entry(const DevPro
 template <int MAXC>
 __device__ __forceinline__ void k_sort_pack_body(const DevProgram P, const i64 n, const SortSpec S, const SortPack K,
                                                       u64* __restrict__ key_lo, u64* __restrict__ key_hi, uint32_t* __restrict__ ids, u64* __restrict__ hist, const int hist_passes) {
+  // deferred execution (P.n_dev): only rows [0, n_real) exist; the positions up to the bound n become PADDING records whose composite key is
+  // all ones -- the passes are stable, so they end up behind every real row (a real row with that very key came first) and the first
+  // n_real entries of the permutation are the sort of the real rows
+  const i64 n_real = rows_of(P, n);
+  const u128 pad_key = K.total_bits >= 128 ? ~(u128)0 : ((((u128)1) << K.total_bits) - 1);
   __shared__ uint32_t h0[SORT_MAX_PASSES][256];
   if (hist) { for (int p = 0; p < hist_passes; ++p) h0[p][threadIdx.x] = 0; __syncthreads(); }
   bool bad = false;      // K.check: a row the guessed layout does not hold
@@ -115,12 +121,13 @@ __device__ __forceinline__ void k_sort_pack_body(const DevProgram P, const i64 n
   for (i64 w = (i64)blockIdx.x * SWAVES + swave(); w < nwords; w += (i64)gridDim.x * SWAVES) {
     const i64 pos = (w << 6) + slane();
     if (pos >= n) continue;
+    const bool real = pos < n_real;
     GPUQ_REGS_DECL;
-    (void)GPUQ_EVAL(MAXC, P, pos);
-    u128 comp = 0;
+    if (real) (void)GPUQ_EVAL(MAXC, P, pos);
+    u128 comp = real ? (u128)0 : pad_key;
 #pragma unroll
     for (int k = 0; k < MAX_SORT_KEYS; ++k) {
-      if (k < S.n_keys) {
+      if (k < S.n_keys && real) {
         const int r = __builtin_amdgcn_readfirstlane(S.reg[k]);
         const bool isn = (rnulls >> r) & 1;
         u128 field = 0;
@@ -155,7 +162,8 @@ __device__ __forceinline__ void k_sort_pack_body(const DevProgram P, const i64 n
     ids[pos] = (uint32_t)pos;
   }
   if (hist) { __syncthreads(); for (int p = 0; p < hist_passes; ++p) if (h0[p][threadIdx.x]) atomicAdd((unsigned long long*)&hist[p * 256 + threadIdx.x], (unsigned long long)h0[p][threadIdx.x]); }
-  if (K.check && hist && bad) atomicOr((unsigned long long*)&hist[SORT_MAX_PASSES * 256], 1ull);
+  if (K.check == 1 && hist && bad) atomicOr((unsigned long long*)&hist[SORT_MAX_PASSES * 256], 1ull);
+  if (K.check == 2 && bad) atomicOr(P.flags, FLAG_SORT_LAYOUT);
 }
 #ifndef GPUQ_JIT
 template <int MAXC>
@@ -180,12 +188,13 @@ __device__ __forceinline__ void k_sort_direct_body(const DevProgram P, const int
   __shared__ uint32_t rk[SORT_DIRECT_MAX], sid[SORT_DIRECT_MAX];      // rk: 2 bits per key (0 NULL first, 1 value, 2 NULL last, 3 padding)
   int m = 2; while (m < n) m <<= 1;
   const int i = threadIdx.x;
+  const int n_real = (int)rows_of(P, (i64)n);      // deferred execution: positions [n_real, n) are padding like [n, m)
   if (i < m) {
     uint32_t ranks = 0xFFu; uint32_t id = 0xFFFFFFFFu;
     u64 lo[MAX_SORT_KEYS], hi[MAX_SORT_KEYS];
 #pragma unroll
     for (int k = 0; k < MAX_SORT_KEYS; ++k) { lo[k] = 0; hi[k] = 0; }
-    const bool act = i < n;
+    const bool act = i < n_real;
     GPUQ_REGS_DECL;
     if (act) (void)GPUQ_EVAL(MAXC, P, (i64)i);
     if (act) {
@@ -250,8 +259,9 @@ __global__ void __launch_bounds__(SORT_DIRECT_MAX) k_sort_direct(const DevProgra
 
 // ------------------------------------------------------------------ partition ids
 template <int MAXC>
-__device__ __forceinline__ void k_part_pid_body(const DevProgram P, const i64 n, const KeySpec K, const uint32_t nparts,
+__device__ __forceinline__ void k_part_pid_body(const DevProgram P, const i64 n_arg, const KeySpec K, const uint32_t nparts,
                                                      u64* __restrict__ pid_out, uint32_t* __restrict__ ids) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
   const i64 nwords = (n + 63) >> 6;
   for (i64 w = (i64)blockIdx.x * SWAVES + swave(); w < nwords; w += (i64)gridDim.x * SWAVES) {
     const i64 pos = (w << 6) + slane();
@@ -602,7 +612,7 @@ int sort_max_passes() { return SORT_MAX_PASSES; }
 void launch_sort_pack(hipStream_t s, const DevProgram& P, i64 n, const SortSpec& S, const SortPack& K, u64* key_lo, u64* key_hi, uint32_t* ids, u64* hist, int hist_passes) {
   if (n <= 0) return;
   if (hist) (void)hipMemsetAsync(hist, 0, (size_t)hist_passes * RADIX * 8, s);
-  if (hist && K.check) (void)hipMemsetAsync(hist + (size_t)SORT_MAX_PASSES * RADIX, 0, 8, s);      // the "layout does not hold" word
+  if (hist && K.check == 1) (void)hipMemsetAsync(hist + (size_t)SORT_MAX_PASSES * RADIX, 0, 8, s);      // the "layout does not hold" word
   if (jit_override().fn && jit_override().kernel_id == 9) {
     (void)jit_launch(jit_override().fn, dim3(sgrid(n, 8)), dim3(SBLOCK), 0, s, P, n, S, K, key_lo, key_hi, ids, hist, hist_passes);
   } else {

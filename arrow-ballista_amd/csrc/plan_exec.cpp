@@ -69,8 +69,14 @@ struct PTable {
   std::vector<const uint32_t*> via; std::vector<int> sides; bool dense = false;
   std::vector<BufP> keep;          // owners of every buffer the table points into
   int64_t record_cap = 0;          // > 0: all columns live in keep[0], laid out for this row capacity (alloc_outputs)
+  // Deferred execution (include/gpuq.h): n_dev != nullptr means `n` is only an upper BOUND of the row count and the actual count is
+  // the device u64 *n_dev (a join's pair count, a filter's survivors, an aggregate's groups), owned by n_keep.  Operators that
+  // can run deferred pass both on (gpuq_input.n_rows_dev); everything else calls resolve() first, which settles the plan's
+  // pending operators and makes n exact.
+  const uint64_t* n_dev = nullptr; BufP n_keep;
   bool is_view() const { return !via.empty(); }
   void own(const PTable& o) { keep.insert(keep.end(), o.keep.begin(), o.keep.end()); }
+  void count_from(const PTable& o) { n_dev = o.n_dev; n_keep = o.n_keep; }
 };
 
 // field list of a table as an operator sees it (side / raw128 / dense annotations)
@@ -180,8 +186,17 @@ struct Exec {
   std::map<std::string, gpuq_op*>* memo = nullptr;       // (call site, input layout) -> operator: skips rebuilding the descriptor
   gpuq_comm* comm = nullptr;                              // ranks of the node (gpuq_plan_set_comm); nullptr = a single-GPU plan
   const std::atomic<int>* cancel = nullptr;               // set by gpuq_task_cancel: checked between operator calls
+  // Deferred execution: from a plan's second run on, operators that remember a completed synchronous run queue their kernels
+  // without reading anything back; row counts travel as device words (PTable::n_dev) and everything is settled in ONE host round
+  // trip (settle(): at the plan's end, or earlier where a node needs an exact count -- an exchange, a concatenation, a file).
+  bool deferred = false;
+  std::vector<gpuq_op*> pending;                          // operators with deferred runs since the last settle
+  struct CountFix { const uint64_t* word; int64_t bound; int64_t* rows; BufP keep; };
+  std::vector<CountFix> fixes;                            // output_rows metrics booked with a bound: corrected at the settle
+  int settles = 0, host_syncs = 0;                        // per execution: settles, and count / status read-backs of the synchronous paths
 };
 struct Cancelled : std::runtime_error { using std::runtime_error::runtime_error; };
+struct DeferredRetry : std::runtime_error { using std::runtime_error::runtime_error; };      // an assumption of a deferred run did not hold: the plan runs again, synchronously
 inline void check_cancel(const Exec& x) { if (x.cancel && x.cancel->load(std::memory_order_relaxed)) throw Cancelled("task cancelled"); }
 
 void check(Exec& x, int rc) {
@@ -216,15 +231,60 @@ template <class MakeDesc> gpuq_op* cached_op(Exec& x, const void* site, int tag,
 uint64_t read_u64(Exec& x, const void* dev) {
   HIPCHECK(hipMemcpyAsync(x.pin, dev, 8, hipMemcpyDeviceToHost, (hipStream_t)x.stream));
   HIPCHECK(hipStreamSynchronize((hipStream_t)x.stream));
+  ++x.host_syncs;
   return x.pin[0];
 }
+// ---------------------------------------------------------------- deferred execution
+// May `op` run deferred in this execution?  Marks it and books it for the next settle.
+void settle(Exec& x, struct PTable* t);
+// the operator runs synchronously: what deferred runs of it may have left in its status word (a synchronous run resets it) is looked at first
+void use_sync(Exec& x, gpuq_op* op) {
+  if (std::find(x.pending.begin(), x.pending.end(), op) != x.pending.end()) settle(x, nullptr);
+  gpuq_op_set_deferred(op, 0);
+}
+bool use_deferred(Exec& x, gpuq_op* op) {
+  if (!x.deferred || !gpuq_op_can_defer(op)) { use_sync(x, op); return false; }
+  // (one operator may run deferred several times before a settle -- the take / materialise projections do: status bits are sticky,
+  // workspaces are reused in stream order, and counts are copied out of the operator right after each run)
+  gpuq_op_set_deferred(op, 1);
+  if (std::find(x.pending.begin(), x.pending.end(), op) == x.pending.end()) x.pending.push_back(op);
+  return true;
+}
 BufP dev_alloc(size_t bytes) { BufP b = std::make_shared<DevBuf>(); b->ensure(bytes ? bytes : 16); return b; }
+
+// ONE host round trip for everything deferred so far: the status words of the pending operators, the count behind `t` (made exact)
+// and the counts behind the metrics booked with a bound.
+void settle(Exec& x, PTable* t) {
+  if (x.pending.empty() && x.fixes.empty() && !(t && t->n_dev)) return;
+  std::vector<const uint64_t*> words; std::vector<uint64_t> vals;
+  for (auto& f : x.fixes) words.push_back(f.word);
+  if (t && t->n_dev) words.push_back(t->n_dev);
+  vals.assign(words.size() + 1, 0);
+  const int rc = gpuq_ops_settle(x.ctx, x.stream, x.pending.data(), (int)x.pending.size(), words.data(), (int)words.size(), vals.data());
+  ++x.settles;
+  for (gpuq_op* op : x.pending) gpuq_op_set_deferred(op, 0);
+  x.pending.clear();
+  if (rc == GPUQ_ERR_RETRY) { x.fixes.clear(); throw DeferredRetry("deferred run did not hold"); }
+  check(x, rc);
+  for (size_t i = 0; i < x.fixes.size(); ++i) { const int64_t actual = std::min<int64_t>((int64_t)vals[i], x.fixes[i].bound); *x.fixes[i].rows += actual - x.fixes[i].bound; }
+  if (t && t->n_dev) {
+    const int64_t actual = std::min<int64_t>((int64_t)vals[x.fixes.size()], t->n);
+    // plain (non-view) tables carry their length in every column too
+    if (!t->is_view()) for (auto& c : t->cols) if (c.c.length == t->n) c.c.length = actual;
+    t->n = actual; t->n_dev = nullptr; t->n_keep = nullptr;
+  }
+  x.fixes.clear();
+}
+// make t.n exact (a node that concatenates, slices, writes files, exchanges or hands the table to the caller)
+inline void resolve(Exec& x, PTable& t) { if (t.n_dev) settle(x, &t); }
+// does `op` run deferred over `t`?  When it does not, t's count is made exact first (synchronous entry points need it)
+inline bool prep(Exec& x, gpuq_op* op, PTable& t) { const bool d = use_deferred(x, op); if (!d) resolve(x, t); return d; }
 
 struct InputC { gpuq_input in{}; std::vector<gpuq_column> cols; };
 void make_input(const PTable& t, InputC& ic) {
   ic.cols.clear();
   for (auto& c : t.cols) ic.cols.push_back(c.c);
-  ic.in.cols = ic.cols.data(); ic.in.n_cols = (int)ic.cols.size(); ic.in.n_via = (int)t.via.size(); ic.in.n_rows = t.n;
+  ic.in.cols = ic.cols.data(); ic.in.n_cols = (int)ic.cols.size(); ic.in.n_via = (int)t.via.size(); ic.in.n_rows = t.n; ic.in.n_rows_dev = t.n_dev;
   for (int k = 0; k < 3; ++k) ic.in.via[k] = k < (int)t.via.size() ? t.via[k] : nullptr;
 }
 
@@ -336,17 +396,22 @@ void strip_code_columns(PTable& t) {
 
 PTable project(Exec& x, const PTable& t_in, const std::vector<Json>& exprs_in, const std::vector<std::string>& names, const void* site, int tag) {
   std::vector<Json> exprs = exprs_in;
-  const PTable t = lower_like(x, t_in, exprs);
+  bool any_like = false; for (auto& e : exprs) any_like = any_like || has_like(e);
+  PTable t_res = t_in; if (any_like) resolve(x, t_res);      // the LIKE kernel takes an exact row count
+  PTable t = lower_like(x, t_res, exprs);
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     Json ex = jarr();
     const auto nm = names_of(t);
     for (size_t i = 0; i < exprs.size(); ++i) ex.a.push_back(jobj({{"expr", rebind(exprs[i], nm)}, {"name", jstr(names[i])}}));
     return jobj({{"op", jstr("project")}, {"input", jobj({{"fields", table_fields(t)}})}, {"exprs", ex}});
   });
+  const bool deferred = prep(x, op, t);
   std::vector<gpuq_column> carr;
   PTable out = alloc_outputs(op, t.n, carr);
+  out.count_from(t);
   InputC ic; make_input(t, ic);
   check(x, gpuq_project_run(op, x.stream, &ic.in, carr.data(), (int)carr.size()));
+  if (deferred) return out;      // (the status word is read at the settle)
   // A computed expression over a table that holds strings: what the evaluator could not do (an ordering comparison of a value beyond
   // 15 bytes, ...) is in the operator's status word and nothing downstream would read it -- a bare column that is merely packed is
   // caught later, when its bytes are needed (gpuq_unpack_utf8).  Projections of numeric tables stay asynchronous.
@@ -358,8 +423,9 @@ PTable project(Exec& x, const PTable& t_in, const std::vector<Json>& exprs_in, c
 }
 
 // new[j] = vec[idx[j]] with NULL_ROW propagated
-const uint32_t* take_u32(Exec& x, const uint32_t* vec, int64_t vec_len, const uint32_t* idx, int64_t n, std::vector<BufP>& keep) {
+const uint32_t* take_u32(Exec& x, const uint32_t* vec, int64_t vec_len, const uint32_t* idx, int64_t n, std::vector<BufP>& keep, const PTable* count = nullptr) {
   PTable src; src.n = n; src.via.push_back(idx); src.sides.push_back(1);
+  if (count) src.count_from(*count);
   PCol c; c.name = "v"; c.type = jstr("UInt32"); c.nullable = false; c.c.type = T_UINT32; c.c.data = vec; c.c.length = vec_len;
   src.cols.push_back(c);
   static const int take_site = 0;
@@ -374,8 +440,10 @@ const uint32_t* take_u32(Exec& x, const uint32_t* vec, int64_t vec_len, const ui
 PTable materialize(Exec& x, const PTable& t, bool force = false);
 
 // address `t`'s rows through idx[0..n): a view
-PTable select_view(Exec& x, const PTable& t, const uint32_t* idx, int64_t n, const BufP& idx_owner) {
+// count: the table whose (device-side) row count the n positions of idx have -- the view's count; nullptr = n is exact
+PTable select_view(Exec& x, const PTable& t, const uint32_t* idx, int64_t n, const BufP& idx_owner, const PTable* count = nullptr) {
   PTable out; out.n = n; out.own(t); if (idx_owner) out.keep.push_back(idx_owner);
+  if (count) out.count_from(*count);
   if (!t.is_view()) {
     out.cols = t.cols; out.via = {idx}; out.sides.assign(t.cols.size(), 1);
     return out;
@@ -388,7 +456,7 @@ PTable select_view(Exec& x, const PTable& t, const uint32_t* idx, int64_t n, con
   }
   out.cols = t.cols;
   if (has0) out.via.push_back(idx);
-  for (const uint32_t* v : t.via) out.via.push_back(take_u32(x, v, t.n, idx, n, out.keep));
+  for (const uint32_t* v : t.via) out.via.push_back(take_u32(x, v, t.n, idx, n, out.keep, count));
   const int shift = has0 ? 1 : 0;
   for (int s : t.sides) out.sides.push_back(s == 0 ? 1 : s + shift);
   return out;
@@ -411,10 +479,16 @@ PCol take_utf8(Exec& x, const PCol& c, const uint32_t* idx, int64_t n, bool null
 
 // force: also re-encode a plain table; strings then become fixed-width PACKED15 (concat / row ranges need fixed widths),
 // which holds 15 bytes.  Otherwise Utf8 columns in Arrow layout are taken as they are, whatever their length.
-PTable materialize(Exec& x, const PTable& t, bool force) {
-  if (!t.is_view() && !force) return t;
+PTable materialize(Exec& x, const PTable& t_in, bool force) {
+  if (!t_in.is_view() && !force) return t_in;
   const bool pack_strings = force;
-  PTable out; out.n = t.n;
+  PTable t = t_in;
+  if (t.n_dev) {      // taking Arrow-layout strings is two passes with a size read-back in between; a forced re-encode feeds concatenations
+    bool strings = force;
+    for (auto& c : t.cols) strings = strings || (c.c.offsets && !pack_strings);
+    if (strings) resolve(x, t);
+  }
+  PTable out; out.n = t.n; out.count_from(t);
   out.cols.resize(t.cols.size()); out.sides.assign(t.cols.size(), 0);
   std::vector<size_t> fixed;
   for (size_t i = 0; i < t.cols.size(); ++i) {
@@ -425,7 +499,7 @@ PTable materialize(Exec& x, const PTable& t, bool force) {
     } else fixed.push_back(i);
   }
   for (size_t a = 0; a < fixed.size(); a += 12) {
-    PTable sub; sub.n = t.n; sub.via = t.via; sub.dense = t.dense;
+    PTable sub; sub.n = t.n; sub.via = t.via; sub.dense = t.dense; sub.count_from(t);
     std::vector<Json> ex; std::vector<std::string> nm;
     const size_t hi = std::min(a + 12, fixed.size());
     for (size_t k = a; k < hi; ++k) { sub.cols.push_back(t.cols[fixed[k]]); sub.sides.push_back(t.sides[fixed[k]]); }
@@ -437,6 +511,8 @@ PTable materialize(Exec& x, const PTable& t, bool force) {
       for (size_t i = 0; i < ex.size(); ++i) exj.a.push_back(jobj({{"expr", ex[i]}, {"name", jstr(nm[i])}}));
       return jobj({{"op", jstr("project")}, {"input", jobj({{"fields", table_fields(sub)}})}, {"exprs", exj}});
     });
+    prep(x, op, sub);
+    if (!sub.n_dev && t.n_dev) { t.n = sub.n; t.count_from(sub); out.n = sub.n; out.count_from(sub); }      // (resolved on the way)
     std::vector<gpuq_column> carr;
     PTable part = alloc_outputs(op, sub.n, carr);
     InputC ic; make_input(sub, ic);
@@ -450,8 +526,9 @@ PTable materialize(Exec& x, const PTable& t, bool force) {
 }
 
 // the passing driving positions of `source` (in order) and their number
-int64_t filter_sel(Exec& x, const PTable& source, const Json& predicate_in, const void* site, int tag, BufP& sel_out) {
+int64_t filter_sel(Exec& x, const PTable& source_in, const Json& predicate_in, const void* site, int tag, BufP& sel_out) {
   std::vector<Json> pe{predicate_in};
+  PTable source = source_in; resolve(x, source);      // (the callers of this form need the exact count back)
   const PTable t = lower_like(x, source, pe);
   const Json& predicate = pe[0];
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
@@ -466,23 +543,31 @@ int64_t filter_sel(Exec& x, const PTable& source, const Json& predicate_in, cons
   return k;
 }
 
-PTable filter_table(Exec& x, const PTable& source, const Json& predicate_in, const void* site, int tag) {
+PTable filter_table(Exec& x, const PTable& source_in, const Json& predicate_in, const void* site, int tag) {
   std::vector<Json> pe{predicate_in};
-  const PTable t = lower_like(x, source, pe);          // helper columns are visible to the predicate only: the view is over `source`
+  PTable source = source_in;
+  if (has_like(predicate_in)) resolve(x, source);      // the LIKE kernel takes an exact row count
+  PTable t = lower_like(x, source, pe);          // helper columns are visible to the predicate only: the view is over `source`
   const Json& predicate = pe[0];
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     return jobj({{"op", jstr("filter")}, {"input", jobj({{"fields", table_fields(t)}})}, {"predicate", rebind(predicate, names_of(t))}});
   });
+  const bool deferred = prep(x, op, t);
+  if (!t.n_dev && source.n_dev) { source.n = t.n; source.count_from(t); }
   BufP sel = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 4 + 16), cnt = dev_alloc(16);
   InputC ic; make_input(t, ic);
   check(x, gpuq_filter_run(op, x.stream, &ic.in, 0, (uint32_t*)sel->p, (uint64_t*)cnt->p));
+  if (deferred && t.n > 0) {      // the survivors' count stays on the device: the view is as long as its input at most
+    PTable c; c.n_dev = (const uint64_t*)cnt->p; c.n_keep = cnt;
+    return select_view(x, source, (const uint32_t*)sel->p, t.n, sel, &c);
+  }
   const int64_t k = (int64_t)read_u64(x, cnt->p);
   check(x, gpuq_op_check(op, x.stream));
   return select_view(x, source, (const uint32_t*)sel->p, k, sel);
 }
 
 // the stable permutation that puts `t` in `sort_exprs` order (one gpuq_sort_run: <= 4 keys whose composite fits 128 bits)
-static BufP sort_perm(Exec& x, const PTable& t, const Json& sort_exprs, const void* site, int tag) {
+static BufP sort_perm(Exec& x, PTable& t, const Json& sort_exprs, const void* site, int tag) {      // (t's count is made exact when the operator cannot run deferred)
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     const auto nm = names_of(t);
     Json ex = jarr();
@@ -492,6 +577,7 @@ static BufP sort_perm(Exec& x, const PTable& t, const Json& sort_exprs, const vo
     }
     return jobj({{"op", jstr("sort")}, {"input", jobj({{"fields", table_fields(t)}})}, {"expr", ex}});
   });
+  prep(x, op, t);
   BufP perm = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 4 + 16);
   InputC ic; make_input(t, ic);
   check(x, gpuq_sort_run(op, x.stream, &ic.in, (uint32_t*)perm->p));
@@ -532,7 +618,7 @@ static PermOut sort_perm_long(Exec& x, const PTable& t, const Json& sort_exprs, 
   flush();
   PermOut out;
   for (size_t gi = groups.size(); gi-- > 0;) {
-    if (!out.p) { BufP p = sort_perm(x, w, groups[gi], site, tag * 64 + 8 + (int)gi); out.p = (const uint32_t*)p->p; out.keep.push_back(p); continue; }
+    if (!out.p) { BufP p = sort_perm(x, w, groups[gi], site, tag * 64 + 8 + (int)gi); out.p = (const uint32_t*)p->p; out.keep.push_back(p); continue; }      // (w is exact: see sort_table)
     PTable view = select_view(x, w, out.p, w.n, nullptr);
     BufP p2 = sort_perm(x, view, groups[gi], site, tag * 64 + 8 + (int)gi);
     out.keep.push_back(p2);
@@ -543,12 +629,16 @@ static PermOut sort_perm_long(Exec& x, const PTable& t, const Json& sort_exprs, 
   return out;
 }
 
-PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
-  const int64_t k = (fetch < 0 || fetch > t.n) ? t.n : fetch;
+PTable sort_table(Exec& x, const PTable& t_in, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
+  PTable t = t_in;
   try {
     BufP perm = sort_perm(x, t, sort_exprs, site, tag);
-    return select_view(x, t, (const uint32_t*)perm->p, k, perm);
+    // deferred: the first *n_dev entries of the permutation are the sorted rows (padding sorts behind them); a fetch bounds both
+    const int64_t k = (fetch < 0 || fetch > t.n) ? t.n : fetch;
+    return select_view(x, t, (const uint32_t*)perm->p, k, perm, t.n_dev ? &t : nullptr);
   } catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+  resolve(x, t);
+  const int64_t k = (fetch < 0 || fetch > t.n) ? t.n : fetch;
   PermOut po = sort_perm_long(x, t, sort_exprs, site, tag);
   PTable out = select_view(x, t, po.p, k, nullptr);
   for (auto& b : po.keep) out.keep.push_back(b);
@@ -558,8 +648,9 @@ PTable sort_table(Exec& x, const PTable& t, const Json& sort_exprs, int64_t fetc
 PTable concat_tables(Exec& x, std::vector<PTable> parts);
 
 // ordered fan-in (gpuq_merge_run): `t` is the concatenation of runs that are each in `sort_exprs` order
-PTable merge_table(Exec& x, const PTable& t, const std::vector<int64_t>& run_offsets, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
-  if (run_offsets.size() <= 2) return sort_table(x, t, sort_exprs, fetch, site, tag);      // one partition (e.g. gathered by BroadcastExec: several runs inside): sort
+PTable merge_table(Exec& x, const PTable& t_in, const std::vector<int64_t>& run_offsets, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
+  if (run_offsets.size() <= 2) return sort_table(x, t_in, sort_exprs, fetch, site, tag);
+  PTable t = t_in; resolve(x, t);      // one partition (e.g. gathered by BroadcastExec: several runs inside): sort
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     const auto nm = names_of(t);
     Json ex = jarr();
@@ -587,9 +678,11 @@ struct PNode {
   // parses the output partitioning from it before the task executes).  Default: the input's.
   virtual PSchema schema() { auto c = children(); if (c.empty()) throw std::runtime_error("plan: node without a schema"); return c[0]->schema(); }
   virtual PTable execute(int part, Exec& x) = 0;
-  PTable timed(std::chrono::steady_clock::time_point t0, PTable t) {
+  PTable timed(Exec& x, std::chrono::steady_clock::time_point t0, PTable t) {
     m.elapsed_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-    m.output_rows += t.n; return t;
+    m.output_rows += t.n;
+    if (t.n_dev) x.fixes.push_back({t.n_dev, t.n, &m.output_rows, t.n_keep});      // booked with the bound, corrected at the settle
+    return t;
   }
 };
 typedef std::unique_ptr<PNode> PNodeP;
@@ -704,12 +797,12 @@ PTable FilterExec::execute(int part, Exec& x) {
   } else f = fuse(this);
   PTable t = f.src->execute(part, x);
   auto t0 = std::chrono::steady_clock::now();
-  if (!f.has_map) return timed(t0, filter_table(x, t, f.pred, this, 0));
+  if (!f.has_map) return timed(x, t0, filter_table(x, t, f.pred, this, 0));
   // a computed projection sits below: run it on the filtered rows
   PTable v = filter_table(x, t, f.pred, this, 0);
   std::vector<Json> ex; std::vector<std::string> nm;
   for (auto& kv : f.map) { nm.push_back(kv.first); ex.push_back(kv.second); }
-  return timed(t0, project(x, v, ex, nm, this, 1));
+  return timed(x, t0, project(x, v, ex, nm, this, 1));
 }
 PTable ProjectionExec::execute(int part, Exec& x) {
   Fused f = fuse(input.get());
@@ -731,11 +824,11 @@ PTable ProjectionExec::execute(int part, Exec& x) {
     pick.push_back(ci);
   }
   if (!pick.empty() && pick.size() == ex.size()) {
-    PTable out; out.n = t.n; out.via = t.via; out.dense = t.dense; out.keep = t.keep;
+    PTable out; out.n = t.n; out.via = t.via; out.dense = t.dense; out.keep = t.keep; out.count_from(t);
     for (size_t i = 0; i < pick.size(); ++i) { PCol c = t.cols[(size_t)pick[i]]; c.name = names[i]; out.cols.push_back(c); out.sides.push_back(t.sides[(size_t)pick[i]]); }
-    return timed(t0, out);
+    return timed(x, t0, out);
   }
-  return timed(t0, project(x, t, ex, names, this, 1));
+  return timed(x, t0, project(x, t, ex, names, this, 1));
 }
 
 struct AggregateExec : PNode {
@@ -765,9 +858,10 @@ struct AggregateExec : PNode {
     Fused f; if (final_) f.src = input.get(); else f = fuse(input.get());
     PTable t = f.src->execute(part, x);
     auto t0 = std::chrono::steady_clock::now();
-    try { return timed(t0, run(x, t, f, false)); }
+    try { return timed(x, t0, run(x, t, f, false)); }
     catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
-    return timed(t0, run(x, t, f, true));      // a group key holds strings of more than 15 bytes: again, over dictionary codes
+    resolve(x, t);
+    return timed(x, t0, run(x, t, f, true));      // a group key holds strings of more than 15 bytes: again, over dictionary codes
   }
   PTable run(Exec& x, PTable t, const Fused& f, const bool long_keys) {
     const ColMap* cm0 = f.has_map ? &f.map : nullptr;
@@ -801,14 +895,32 @@ struct AggregateExec : PNode {
     if (expected_groups) d.push_back({"expected_groups", jnum(expected_groups)});
     return jobj(d);
     });
+    const bool deferred = !long_keys && prep(x, op, t);
+    if (!deferred) resolve(x, t);
     int64_t cap = output_capacity > 0 ? output_capacity : (group_expr.a.empty() ? 4096 : std::max<int64_t>(4096, std::min<int64_t>(t.n, 1ll << 22)));
     if (output_capacity <= 0 && expected_groups > 0) cap = std::max<int64_t>(cap, std::min<int64_t>(t.n, expected_groups + expected_groups / 4));   // a too-small capacity costs a second run
     InputC ic; make_input(t, ic);
+    if (deferred) {
+      // nothing is read back: the result is as long as the remembered group count allows, its actual length is a device word
+      // (copied out of the operator's status block, which its next run reuses)
+      std::vector<gpuq_column> carr;
+      PTable out = alloc_outputs(op, cap, carr);
+      int64_t bound = 0; const uint64_t* ndev = nullptr;
+      check(x, gpuq_aggregate_run_deferred(op, x.stream, &ic.in, carr.data(), (int)carr.size(), cap, &bound, &ndev));
+      out.n = bound; for (auto& c : out.cols) c.c.length = bound;
+      if (ndev) {
+        BufP cnt = dev_alloc(16);
+        HIPCHECK(hipMemcpyAsync(cnt->p, ndev, 8, hipMemcpyDeviceToDevice, (hipStream_t)x.stream));
+        out.n_dev = (const uint64_t*)cnt->p; out.n_keep = cnt;
+      }
+      return out;
+    }
     for (;;) {
       std::vector<gpuq_column> carr;
       PTable out = alloc_outputs(op, cap, carr);
       int64_t ng = 0;
       const int rc = gpuq_aggregate_run(op, x.stream, &ic.in, carr.data(), (int)carr.size(), cap, &ng);
+      ++x.host_syncs;
       if (rc == GPUQ_ERR_CAPACITY && ng > cap) { cap = ng; continue; }
       check(x, rc);
       out.n = ng; for (auto& c : out.cols) c.c.length = ng;
@@ -835,14 +947,14 @@ struct SortExec : PNode {
     PTable t;
     if (merge_all && input->partitions() != 1) {      // SortPreservingMergeExec: the partitions are sorted runs
       std::vector<PTable> in; std::vector<int64_t> offs{0};
-      for (int p = 0; p < input->partitions(); ++p) { in.push_back(input->execute(p, x)); offs.push_back(offs.back() + in.back().n); }
+      for (int p = 0; p < input->partitions(); ++p) { in.push_back(input->execute(p, x)); resolve(x, in.back()); offs.push_back(offs.back() + in.back().n); }
       auto t0 = std::chrono::steady_clock::now();
       t = concat_tables(x, std::move(in));
-      return timed(t0, merge_table(x, t, offs, expr, fetch, this, 1));
+      return timed(x, t0, merge_table(x, t, offs, expr, fetch, this, 1));
     }
     t = input->execute(part, x);
     auto t0 = std::chrono::steady_clock::now();
-    return timed(t0, sort_table(x, t, expr, fetch, this, 0));
+    return timed(x, t0, sort_table(x, t, expr, fetch, this, 0));
   }
 };
 
@@ -868,12 +980,14 @@ struct HashJoinExec : PNode {
     s.t = f.src->execute(part, x); s.has_pred = f.has_pred; s.pred = f.pred;
     return s;
   }
-  PTable join_view(Exec& x, const PTable& lt, const PTable& rt, const uint32_t* ob, const uint32_t* opb, int64_t k, const BufP& ob_own, const BufP& opb_own) {
-    PTable lv = select_view(x, lt, ob, k, ob_own), rv = select_view(x, rt, opb, k, opb_own);
+  int64_t last_pairs = -1;      // pairs the last synchronous run of this call site emitted: sizes the pair vectors of a deferred run
+  PTable join_view(Exec& x, const PTable& lt, const PTable& rt, const uint32_t* ob, const uint32_t* opb, int64_t k, const BufP& ob_own, const BufP& opb_own, const PTable* count = nullptr) {
+    PTable lv = select_view(x, lt, ob, k, ob_own, count), rv = select_view(x, rt, opb, k, opb_own, count);
     if (lv.via.size() + rv.via.size() > 3) {
       if (lv.via.size() >= rv.via.size()) lv = materialize(x, lv); else rv = materialize(x, rv);
     }
     PTable out; out.n = k; out.own(lv); out.own(rv);
+    if (count) out.count_from(*count);
     out.cols = lv.cols; out.via = lv.via; out.sides = lv.sides;
     const int shift = (int)lv.via.size();
     for (size_t i = 0; i < rv.cols.size(); ++i) { out.cols.push_back(rv.cols[i]); out.sides.push_back(rv.sides[i] == 0 ? 0 : rv.sides[i] + shift); }
@@ -916,17 +1030,8 @@ struct HashJoinExec : PNode {
     return join_view(x, lt, rt, a, b, k3, ob3, opb3);
   }
   PTable execute(int part, Exec& x) override {
-    try { return execute_impl(part, x, false); }
-    catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
-    // a join key holds strings of more than 15 bytes: again, with those key columns replaced by exact dictionary codes (the
-    // build side fills the dictionary, the probe side is looked up in it; a probe string that is not in it gets no code = no match)
-    PTable out = execute_impl(part, x, true);
-    strip_code_columns(out);
-    return out;
-  }
-  PTable execute_impl(int part, Exec& x, const bool long_keys) {
-    const bool residual = has_filter && join_type != "Inner";
-    const std::string jt = residual ? std::string("Inner") : join_type;
+    // The two inputs are executed ONCE; what may run twice is the join over the tables they produced (a retry that went back to the
+    // children re-entered the exchanges below them on this rank alone, re-read shuffle files and counted the children's metrics twice).
     int lpart = partition_mode == "Partitioned" ? part : 0;
     Side L;
     if (partition_mode != "Partitioned" && left->partitions() != 1) {
@@ -937,9 +1042,23 @@ struct HashJoinExec : PNode {
     } else L = side(left.get(), lpart, x);
     Side R = side(right.get(), part, x);
     auto t0 = std::chrono::steady_clock::now();
+    try { return timed(x, t0, join_sides(x, L, R, false)); }
+    catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+    // a join key holds strings of more than 15 bytes: again, with those key columns replaced by exact dictionary codes (the
+    // build side fills the dictionary, the probe side is looked up in it; a probe string that is not in it gets no code = no match)
+    resolve(x, L.t); resolve(x, R.t);
+    PTable out = join_sides(x, L, R, true);
+    strip_code_columns(out);
+    return timed(x, t0, out);
+  }
+  PTable join_sides(Exec& x, Side L, Side R, const bool long_keys) {
+    const bool residual = has_filter && join_type != "Inner";
+    const std::string jt = residual ? std::string("Inner") : join_type;
     if (residual) {      // rows that fail a side's own predicate are not part of the join at all: apply those first
+      resolve(x, L.t); resolve(x, R.t);
       if (L.has_pred) { L.t = filter_table(x, L.t, L.pred, this, 3); L.has_pred = false; }
       if (R.has_pred) { R.t = filter_table(x, R.t, R.pred, this, 4); R.has_pred = false; }
+      resolve(x, L.t); resolve(x, R.t);
     }
     Json on_eff = on;
     Utf8DictGuard dicts[8]; int nd = 0;
@@ -976,42 +1095,61 @@ struct HashJoinExec : PNode {
       if (R.has_pred) pd.push_back({"predicate", rebind(R.pred, rn)});
       return jobj(pd);
     });
+    // Deferred (a plan's second run on): the build keeps the table layout it remembers, the probe's pair count stays on the device and
+    // sizes nothing on the host -- the pair vectors are as long as the count this call site produced last time allows (+ 1/8), an
+    // overflow raises the probe's status word.  Only the join types whose output is the pair list itself run this way.
+    const bool plain = !long_keys && !residual && !has_filter && (jt == "Inner" || jt == "Right" || jt == "RightSemi" || jt == "RightAnti");
+    bool deferred = false;
+    if (plain && x.deferred && last_pairs >= 0 && gpuq_op_can_defer(bop)) deferred = use_deferred(x, bop) && use_deferred(x, pop);
+    if (!deferred) { use_sync(x, bop); use_sync(x, pop); resolve(x, L.t); resolve(x, R.t); }
     InputC lic, ric; make_input(L.t, lic); make_input(R.t, ric);
     gpuq_join_table* jtab = nullptr;
     check(x, gpuq_join_build_run(bop, x.stream, &lic.in, 0, L.t.n, &jtab));
+    if (!deferred) x.host_syncs += 2;
     struct Guard { gpuq_join_table* t; ~Guard() { if (t) gpuq_join_table_free(t); } } guard{jtab};
     const bool lout = jt == "Left" || jt == "Full";
     const int64_t extra_cap = lout ? L.t.n : 0;
     int64_t cap = std::max<int64_t>(R.t.n, 1) + extra_cap;
     BufP cnt = dev_alloc(16), ob, opb; int64_t k = 0;
+    if (deferred) {
+      cap = std::min<int64_t>(cap, last_pairs + last_pairs / 8 + 4096);
+      ob = dev_alloc((size_t)cap * 4 + 16); opb = dev_alloc((size_t)cap * 4 + 16);
+      const bool pairs = jt == "Inner" || jt == "Right";
+      check(x, gpuq_join_probe_run(pop, x.stream, jtab, &ric.in, 0, pairs ? (uint32_t*)ob->p : nullptr, (uint32_t*)opb->p, (uint64_t)cap, (uint64_t*)cnt->p));
+      PTable c; c.n_dev = (const uint64_t*)cnt->p; c.n_keep = cnt;
+      if (!pairs) return select_view(x, R.t, (const uint32_t*)opb->p, cap, opb, &c);
+      return join_view(x, L.t, R.t, (const uint32_t*)ob->p, (const uint32_t*)opb->p, cap, ob, opb, &c);
+    }
     for (;;) {
       ob = dev_alloc((size_t)cap * 4 + 16); opb = dev_alloc((size_t)cap * 4 + 16);
       check(x, gpuq_join_probe_run(pop, x.stream, jtab, &ric.in, 0, (uint32_t*)ob->p, (uint32_t*)opb->p, (uint64_t)(cap - extra_cap), (uint64_t*)cnt->p));
       k = (int64_t)read_u64(x, cnt->p);
       const int rc = gpuq_op_check(pop, x.stream);
+      ++x.host_syncs;
       if (rc == GPUQ_ERR_CAPACITY) { cap = k + extra_cap + 1; continue; }
       check(x, rc);
       break;
     }
+    if (plain) last_pairs = k;
     if (jt == "LeftSemi" || jt == "LeftAnti" || lout) {
       BufP extra = dev_alloc(16);
       if (!lout) {
         BufP rows = dev_alloc((size_t)std::max<int64_t>(L.t.n, 1) * 4 + 16);
         check(x, gpuq_join_build_side_rows(jtab, x.stream, jt == "LeftSemi" ? 1 : 0, (uint32_t*)rows->p, (uint64_t*)extra->p));
         const int64_t mrows = (int64_t)read_u64(x, extra->p);
-        return timed(t0, select_view(x, L.t, (const uint32_t*)rows->p, mrows, rows));
+        return select_view(x, L.t, (const uint32_t*)rows->p, mrows, rows);
       }
       check(x, gpuq_join_build_side_rows(jtab, x.stream, 0, (uint32_t*)ob->p + k, (uint64_t*)extra->p));
       const int64_t mrows = (int64_t)read_u64(x, extra->p);
       if (mrows > 0) HIPCHECK(hipMemsetAsync((uint32_t*)opb->p + k, 0xFF, (size_t)mrows * 4, (hipStream_t)x.stream));     // NULL_ROW on the probe side
       k += mrows;
     }
-    if (jt == "RightSemi" || jt == "RightAnti") return timed(t0, select_view(x, R.t, (const uint32_t*)opb->p, k, opb));
+    if (jt == "RightSemi" || jt == "RightAnti") return select_view(x, R.t, (const uint32_t*)opb->p, k, opb);
     PTable out = join_view(x, L.t, R.t, (const uint32_t*)ob->p, (const uint32_t*)opb->p, k, ob, opb);
-    if (residual) return timed(t0, residual_join(x, L.t, R.t, out, ob, opb, k));
+    if (residual) return residual_join(x, L.t, R.t, out, ob, opb, k);
     if (has_filter) out = filter_table(x, out, filter, this, 2);
     // the probe kernels read the build table asynchronously; results were read back (synchronised) above
-    return timed(t0, out);
+    return out;
   }
 };
 
@@ -1020,6 +1158,7 @@ struct LimitExec : PNode {       // LocalLimitExec: first `fetch` rows of each p
   std::vector<PNode*> children() override { return {input.get()}; }
   PTable execute(int part, Exec& x) override {
     PTable t = input->execute(part, x);
+    resolve(x, t);
     if (fetch < t.n) { t.n = fetch; for (auto& c : t.cols) if (!t.is_view() && c.c.length > fetch) c.c.length = fetch; }
     m.output_rows += t.n;
     return t;
@@ -1030,6 +1169,7 @@ struct LimitExec : PNode {       // LocalLimitExec: first `fetch` rows of each p
 // Concatenation in partition order.  Pieces are first brought to the fixed-width layout (materialize(force): no views,
 // Utf8 as PACKED15); data buffers are joined with device copies, validity / Boolean bitmaps at bit granularity.
 PTable concat_tables(Exec& x, std::vector<PTable> parts) {
+  for (auto& p : parts) resolve(x, p);
   std::vector<PTable> live;
   for (auto& p : parts) if (p.n > 0) live.push_back(p);
   if (live.empty() && !parts.empty()) live.push_back(parts[0]);
@@ -1108,6 +1248,7 @@ PTable concat_tables(Exec& x, std::vector<PTable> parts) {
 
 // rows [skip, skip + count) of a table
 PTable slice_table(Exec& x, PTable t, int64_t skip, int64_t count) {
+  resolve(x, t);
   skip = std::min(std::max<int64_t>(skip, 0), t.n);
   count = (count < 0 || skip + count > t.n) ? t.n - skip : count;
   if (skip == 0) { t.n = count; if (!t.is_view()) for (auto& c : t.cols) c.c.length = count; return t; }
@@ -1144,7 +1285,7 @@ struct UnionExec : PNode {       // output partitions = the inputs' partitions, 
     return s0;
   }
   PTable execute(int part, Exec& x) override {
-    for (auto& i : inputs) { const int k = i->partitions(); if (part < k) { PTable t = i->execute(part, x); m.output_rows += t.n; return t; } part -= k; }
+    for (auto& i : inputs) { const int k = i->partitions(); if (part < k) { PTable t = i->execute(part, x); return timed(x, std::chrono::steady_clock::now(), t); } part -= k; }
     throw std::runtime_error("UnionExec: partition out of range");
   }
 };
@@ -1160,12 +1301,12 @@ struct CoalesceExec : PNode {    // CoalesceTasksExec / CoalescePartitionsExec: 
     if (all || ordered) for (int p = 0; p < input->partitions(); ++p) in.push_back(input->execute(p, x));
     else for (int p : parts) in.push_back(input->execute(p, x));
     std::vector<int64_t> offs{0};
-    for (auto& t : in) offs.push_back(offs.back() + t.n);
+    for (auto& t : in) { resolve(x, t); offs.push_back(offs.back() + t.n); }
     auto t0 = std::chrono::steady_clock::now();
     PTable out = concat_tables(x, std::move(in));
     // k-way merge (coalesce_tasks.rs:162-170): pairwise merge-path rounds, ties keep (partition, row) order
     if (ordered) out = merge_table(x, out, offs, order_by, -1, this, 0);
-    return timed(t0, out);
+    return timed(x, t0, out);
   }
 };
 
@@ -1177,7 +1318,7 @@ struct GlobalLimitExec : PNode {
     if (input->partitions() != 1) throw std::runtime_error("GlobalLimitExec requires a single input partition");
     PTable t = input->execute(0, x);
     auto t0 = std::chrono::steady_clock::now();
-    return timed(t0, slice_table(x, t, skip, fetch));
+    return timed(x, t0, slice_table(x, t, skip, fetch));
   }
 };
 
@@ -1222,7 +1363,8 @@ struct PinnedBuf {
 thread_local PinnedBuf g_sink_buf;
 
 // plain table with every Utf8 column in Arrow layout (PACKED15 columns are unpacked)
-PTable arrow_layout(Exec& x, const PTable& in) {
+PTable arrow_layout(Exec& x, const PTable& in_) {
+  PTable in = in_; resolve(x, in);
   PTable t = materialize(x, in);
   for (auto& c : t.cols) {
     if (c.c.repr != GPUQ_REPR_PACKED15) continue;
@@ -1305,6 +1447,7 @@ struct ShuffleWriterExec : PNode {
   PTable execute(int part, Exec& x) override {
     auto t0 = std::chrono::steady_clock::now();
     PTable t = input->execute(part, x);
+    resolve(x, t);      // files are written from exact counts (and only after everything deferred below has held)
     input_rows += t.n;
     const std::string base = work_dir + "/" + job_id + "/" + std::to_string(stage_id);
     std::vector<ShuffleFile> files;
@@ -1420,7 +1563,7 @@ struct ShuffleReaderExec : PNode {
       ipc_check(gpuq_ipc_decode_stream(x.ctx, x.stream, eos, 8, fields.data(), (int)fields.size(), &b));
       parts.push_back(wrap(b));
     }
-    return timed(t0, parts.size() == 1 ? parts[0] : concat_tables(x, std::move(parts)));
+    return timed(x, t0, parts.size() == 1 ? parts[0] : concat_tables(x, std::move(parts)));
   }
 };
 
@@ -1466,6 +1609,7 @@ struct RepartitionExec : PNode {
     const int W = gpuq_comm_world(x.comm);
     if (partition_count != W) throw Unsupported("RepartitionExec: partition_count " + std::to_string(partition_count) + " != number of ranks " + std::to_string(W));
     PTable t = input->execute(part, x);
+    resolve(x, t);
     auto t0 = std::chrono::steady_clock::now();
     PSchema ps = plain_schema(t);
     std::vector<std::string> names; for (auto& f : ps) names.push_back(f.name);
@@ -1490,7 +1634,7 @@ struct RepartitionExec : PNode {
     xcheck(gpuq_exchange_partitions(x.comm, x.stream, cols.data(), fields.data(), (int)cols.size(), doff.data(), &tab));
     PTable out = table_from_owned(tab, grouped);
     for (size_t i = 0; i < out.cols.size(); ++i) out.cols[i].nullable = ps[i].nullable;
-    return timed(t0, out);
+    return timed(x, t0, out);
   }
 };
 struct BroadcastExec : PNode {
@@ -1500,6 +1644,7 @@ struct BroadcastExec : PNode {
   PTable execute(int part, Exec& x) override {
     if (!x.comm) throw Unsupported("BroadcastExec needs the ranks of the node (gpuq_plan_set_comm)");
     PTable t = input->execute(part, x);
+    resolve(x, t);
     auto t0 = std::chrono::steady_clock::now();
     PSchema ps = plain_schema(t);
     PTable plain = materialize(x, t);
@@ -1510,7 +1655,7 @@ struct BroadcastExec : PNode {
     xcheck(gpuq_allgather_table(x.comm, x.stream, cols.data(), fields.data(), (int)cols.size(), plain.n, &tab));
     PTable out = table_from_owned(tab, plain);
     for (size_t i = 0; i < out.cols.size(); ++i) out.cols[i].nullable = ps[i].nullable;
-    return timed(t0, out);
+    return timed(x, t0, out);
   }
 };
 
@@ -1596,6 +1741,10 @@ thread_local std::string g_plan_error;
 
 struct gpuq_plan {
   gpuq_ctx* ctx = nullptr; PNodeP root; std::map<std::string, gpuq_op*> ops, memo; uint64_t* pin = nullptr; gpuq_comm* comm = nullptr;
+  // deferred execution: allowed once an execution has completed synchronously (the operators then remember what they need); switched
+  // off for good after three deferred executions had to be redone (inputs that change from call to call)
+  int completed = 0, retries = 0; bool defer_ok = true;
+  int last_settles = 0, last_host_syncs = 0, last_deferred = 0;      // of the last execution (gpuq_plan_exec_stats)
   ~gpuq_plan() { for (auto& kv : ops) gpuq_op_free(kv.second); if (pin) (void)hipHostFree(pin); }
 };
 struct gpuq_result { PTable t; std::vector<gpuq_field_info> fields; };
@@ -1641,14 +1790,34 @@ static int plan_execute_impl(gpuq_plan* p, void* stream, int partition, const gp
     if (!p->pin) HIPCHECK(hipHostMalloc((void**)&p->pin, 64, hipHostMallocDefault));
     (void)use_stream(stream);
     Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin; x.memo = &p->memo; x.comm = p->comm; x.cancel = cancel;
+    static const bool defer_env = []() { const char* e = getenv("GPUQ_DEFER"); return !(e && e[0] == '0'); }();
+    // a plan with exchanges inside runs synchronously: a rank that had to redo a deferred execution would re-enter the collectives alone
+    x.deferred = defer_env && p->defer_ok && p->completed > 0 && !p->comm;
     PTable t;
-    try { t = materialize(x, p->root->execute(partition, x)); check_cancel(x); }
-    catch (...) {
-      // whatever was queued keeps running: drain it before the buffers it uses go back to the pool (unwinding frees them)
+    auto run = [&]() { t = materialize(x, p->root->execute(partition, x)); check_cancel(x); settle(x, &t); };
+    auto drain = [&]() {
+      // whatever was queued keeps running: drain it before the buffers it uses go back to the pool (unwinding frees them); status
+      // words deferred runs may have raised are cleared with it
       (void)hipStreamSynchronize((hipStream_t)stream);
-      throw;
+      if (!x.pending.empty()) { std::vector<uint64_t> none(1); (void)gpuq_ops_settle(x.ctx, stream, x.pending.data(), (int)x.pending.size(), nullptr, 0, none.data()); }
+      for (gpuq_op* op : x.pending) gpuq_op_set_deferred(op, 0);
+      x.pending.clear(); x.fixes.clear();
+    };
+    const bool was_deferred = x.deferred;
+    try { run(); }
+    catch (const Cancelled&) { drain(); throw; }
+    catch (...) {
+      drain();
+      if (!x.deferred) throw;
+      // a deferred execution that did not hold (or failed in any other way): the same plan again, synchronously -- that run either
+      // succeeds and refreshes what the operators remember, or raises the error with its proper message
+      if (++p->retries >= 3) p->defer_ok = false;
+      x.deferred = false; t = PTable();
+      try { run(); } catch (...) { drain(); throw; }
     }
     HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+    ++p->completed;
+    p->last_settles = x.settles; p->last_host_syncs = x.host_syncs; p->last_deferred = was_deferred && x.deferred ? 1 : 0;
     std::unique_ptr<gpuq_result> r(new gpuq_result());
     for (auto& c : t.cols) {
       gpuq_field_info f{};
@@ -1753,6 +1922,14 @@ int gpuq_plan_schema(gpuq_plan* p, gpuq_field_info* fields_out, int cap, int* n_
   });
 }
 
+int gpuq_plan_exec_stats(gpuq_plan* p, int* deferred_out, int* settles_out, int* host_syncs_out, int* retries_out) {
+  if (!p) return GPUQ_ERR_INVALID;
+  if (deferred_out) *deferred_out = p->last_deferred;
+  if (settles_out) *settles_out = p->last_settles;
+  if (host_syncs_out) *host_syncs_out = p->last_host_syncs;
+  if (retries_out) *retries_out = p->retries;
+  return GPUQ_OK;
+}
 int gpuq_plan_set_comm(gpuq_plan* p, gpuq_comm* comm) { if (!p) return GPUQ_ERR_INVALID; p->comm = comm; return GPUQ_OK; }
 
 int gpuq_plan_profile(gpuq_plan* p, int enable, float* kernel_ms_out, int* launches_out, char* op_desc_out, size_t cap) {

@@ -215,7 +215,10 @@ struct TReader {
     id = delta ? last + delta : (int)zigzag();
     last = id; return true;
   }
+  int depth = 0;      // nesting of the value being skipped: a crafted footer of struct headers must not walk the host stack down
+  struct Nest { int& d; Nest(int& d_) : d(d_) { if (++d > 64) throw std::runtime_error("parquet: Thrift metadata nested deeper than 64 levels"); } ~Nest() { --d; } };
   void skip(int type) {
+    Nest nest(depth);
     switch (type) {
       case 1: case 2: break;                                   // bool true / false (value in the type)
       case 3: need(1); ++p; break;                             // i8
@@ -389,7 +392,7 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
         case 2: if (is_decimal) { P->gt = T_DECIMAL128; P->gp = L.precision; P->gs = L.scale; P->width = 16; } else { P->gt = T_INT64; P->width = 8; } break;
         case 5: P->gt = T_FLOAT64; P->width = 8; break;
         case 6: if (is_decimal) throw Unsupported("parquet: BYTE_ARRAY decimals ('" + L.name + "')"); P->gt = T_UTF8; break;
-        case 7: if (!is_decimal || L.type_length > 16) throw Unsupported("parquet: FIXED_LEN_BYTE_ARRAY column '" + L.name + "' (only decimals of <= 16 bytes)"); P->gt = T_DECIMAL128; P->gp = L.precision; P->gs = L.scale; P->width = 16; break;
+        case 7: if (!is_decimal || L.type_length < 1 || L.type_length > 16) throw Unsupported("parquet: FIXED_LEN_BYTE_ARRAY column '" + L.name + "' (only decimals of 1..16 bytes; type_length " + std::to_string(L.type_length) + ")"); P->gt = T_DECIMAL128; P->gp = L.precision; P->gs = L.scale; P->width = 16; break;
         default: throw Unsupported("parquet: physical type " + std::to_string(L.type) + " of column '" + L.name + "' (FLOAT / INT96 are not read on the device)");
       }
       P->optional = L.repetition == 1;
@@ -536,7 +539,7 @@ int gpuq_parquet_schema(const uint8_t* file, int64_t n_bytes, gpuq_field_info* f
         case 2: if (dec) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; } else gt = T_INT64; break;
         case 5: gt = T_FLOAT64; break;
         case 6: gt = dec ? -1 : T_UTF8; break;
-        case 7: if (dec && L.type_length <= 16) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; } break;
+        case 7: if (dec && L.type_length >= 1 && L.type_length <= 16) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; } break;
         default: break;
       }
       if (L.num_children > 0 || L.repetition == 2) gt = -1;

@@ -301,6 +301,12 @@ class NativePlan:
         _check(self.tc.ctx.L, self.tc.ctx.L.gpuq_plan_profile_all(self.h, buf, len(buf)))
         return json.loads(buf.value.decode())
 
+    def exec_stats(self):
+        """How the last execution went: {deferred, settles, host_syncs, retries} (include/gpuq.h gpuq_plan_exec_stats)."""
+        v = [C.c_int(0) for _ in range(4)]
+        _check(self.tc.ctx.L, self.tc.ctx.L.gpuq_plan_exec_stats(self.h, *[C.byref(a) for a in v]))
+        return {"deferred": bool(v[0].value), "settles": v[1].value, "host_syncs": v[2].value, "retries": v[3].value}
+
     def metrics(self):
         buf = C.create_string_buffer(1 << 16)
         _check(self.tc.ctx.L, self.tc.ctx.L.gpuq_plan_metrics(self.h, buf, len(buf)))

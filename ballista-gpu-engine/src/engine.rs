@@ -167,7 +167,7 @@ impl QueryStageExecutor for GpuQueryStageExec {
             cols.push(v);
         }
         for (t, v) in imported.0.iter().zip(cols.iter()) {
-            inputs.push(gpuq_input { cols: v.as_ptr(), n_cols: v.len() as i32, n_via: 0, n_rows: unsafe { gpuq_table_num_rows(*t) }, via: [std::ptr::null(); 3] });
+            inputs.push(gpuq_input { cols: v.as_ptr(), n_cols: v.len() as i32, n_via: 0, n_rows: unsafe { gpuq_table_num_rows(*t) }, via: [std::ptr::null(); 3], n_rows_dev: std::ptr::null() });
         }
         // 2. start the plan on the library's worker thread; await it without blocking the task-runner's worker
         //    (cpu_bound_executor.rs:94-131: blocking in poll stalls a worker)

@@ -50,6 +50,7 @@ pub struct gpuq_input {
     pub n_via: i32,
     pub n_rows: i64,
     pub via: [*const u32; 3],
+    pub n_rows_dev: *const u64, // NULL: n_rows is exact (include/gpuq.h "Deferred execution")
 }
 
 extern "C" {

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GPUQ_ABI_VERSION 1
+#define GPUQ_ABI_VERSION 2
 
 typedef enum gpuq_status {
   GPUQ_OK = 0,
@@ -44,7 +44,8 @@ typedef enum gpuq_status {
   GPUQ_ERR_UNSUPPORTED = 3,  /* valid request the device path does not implement (fails loudly, never falls back) */
   GPUQ_ERR_CAPACITY = 4,     /* caller-provided output capacity too small; required size reported */
   GPUQ_ERR_INTERNAL = 5,
-  GPUQ_ERR_CANCELLED = 6     /* gpuq_task_cancel reached the task before it finished */
+  GPUQ_ERR_CANCELLED = 6,    /* gpuq_task_cancel reached the task before it finished */
+  GPUQ_ERR_RETRY = 7         /* gpuq_ops_settle: something a deferred run assumed did not hold; run again without deferral */
 } gpuq_status;
 
 /* Logical types (subset of ballista/core/proto/datafusion.proto:1004-1040 ArrowType). */
@@ -240,6 +241,12 @@ typedef struct gpuq_input {
   int32_t n_via;
   int64_t n_rows;
   const uint32_t* via[3];
+  /* Deferred execution (below): NULL, or a device u64 holding the ACTUAL number of driving positions; n_rows is then only an
+     upper bound (it sizes grids and workspaces) and the kernels stop at min(n_rows, *n_rows_dev).  This is how one operator's
+     count -- join pairs, filter survivors, groups -- reaches the next without a host round trip.  Honoured by gpuq_filter_run,
+     gpuq_project_run, gpuq_aggregate_run_deferred, gpuq_join_build_run, gpuq_join_probe_run and gpuq_sort_run; every other
+     entry point refuses an input that carries it (GPUQ_ERR_INVALID). */
+  const uint64_t* n_rows_dev;
 } gpuq_input;
 
 /* FilterExec.  Writes the passing driving positions (or via[payload_via-1][pos] when payload_via>0),
@@ -308,6 +315,30 @@ int gpuq_merge_run(gpuq_op* op, void* stream, const gpuq_input* in, const int64_
    partition = mix64-hash(keys) % partition_count -- gpuq's own function (ahash
    assignment is not a portable contract).  Asynchronous. */
 int gpuq_partition_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out, uint64_t* part_offsets_out);
+
+/* Deferred execution: one host round trip per plan instead of one or two per operator.
+   An operator's synchronous entry points read small things back (a build side's key range, "did the table fill up", the number of
+   groups, a sort key's range) because the next decision depends on them.  An operator that has completed a synchronous run
+   REMEMBERS what it learned; with gpuq_op_set_deferred(op, 1) its next runs assume the same answers, queue all their kernels
+   without waiting, let the kernels verify the assumptions (a key outside the remembered range, a table or an output that turned
+   out too small, a row that does not fit the remembered sort-key layout raise bits in the operator's status word) and hand row
+   counts on as device words (gpuq_input.n_rows_dev).  The caller then settles everything at once: gpuq_ops_settle waits for the
+   stream ONCE, reads the status words of all the operators and any number of count words in one copy, and returns GPUQ_OK, or
+   GPUQ_ERR_RETRY when an assumption did not hold -- the results of the deferred runs are then void and the caller runs the
+   operators again synchronously (which refreshes what they remember).  gpuq_op_can_defer tells whether an operator has a
+   completed synchronous run to go by; without one a deferred call simply runs synchronously.  The native plan executor drives
+   its plans this way from their second execution on (csrc/plan_exec.cpp). */
+int gpuq_op_set_deferred(gpuq_op* op, int on);
+int gpuq_op_can_defer(gpuq_op* op);
+/* gpuq_aggregate_run without the wait: *n_bound_out (host) = capacity bound of the result, *n_groups_dev_out = device u64 holding
+   the actual group count (valid until the operator's next run); the result columns hold that many rows.  When the operator
+   cannot defer (no completed synchronous run, or a strategy without a deferred form) this IS gpuq_aggregate_run: *n_bound_out is
+   then exact and *n_groups_dev_out NULL. */
+int gpuq_aggregate_run_deferred(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs, int64_t cap,
+                                int64_t* n_bound_out, const uint64_t** n_groups_dev_out);
+/* One wait for everything deferred on `stream`: the status words of ops[0..n_ops) and the device u64 words[0..n_words) (copied to
+   words_out, host).  GPUQ_ERR_RETRY when an operator's assumptions did not hold (it forgets them); other errors as gpuq_op_check. */
+int gpuq_ops_settle(gpuq_ctx* ctx, void* stream, gpuq_op* const* ops, int n_ops, const uint64_t* const* words, int n_words, uint64_t* words_out);
 
 /* Waits for `stream`, then reports device-side conditions raised by the op's kernels since the last
    check (string longer than 15 bytes in a packed comparison, output capacity overflow, ...). */
@@ -438,6 +469,11 @@ void gpuq_task_free(gpuq_task* task);
 /* The ranks of the node for RepartitionExec / BroadcastExec nodes (the comm outlives the plan; NULL detaches). */
 struct gpuq_comm;
 int gpuq_plan_set_comm(gpuq_plan* plan, struct gpuq_comm* comm);
+/* How the plan's last execution went: *deferred_out = 1 when it ran deferred (see "Deferred execution" above: from a plan's second
+   execution on, env GPUQ_DEFER=0 switches it off) and held; *settles_out = host round trips that settled deferred operators (1 for
+   a single-GPU plan without files); *host_syncs_out = count / status read-backs of the operators that ran synchronously;
+   *retries_out = deferred executions of this plan that had to be redone synchronously so far.  Any pointer may be NULL. */
+int gpuq_plan_exec_stats(gpuq_plan* plan, int* deferred_out, int* settles_out, int* host_syncs_out, int* retries_out);
 int gpuq_plan_metrics(gpuq_plan* plan, char* json_out, size_t cap);     /* per node: output_rows, elapsed_compute (ns) -- utils.rs:470-481; ShuffleWriterExec adds write_time, repart_time, input_rows (shuffle_writer.rs:139-160) */
 const char* gpuq_plan_last_error(void);
 /* gpuq_op_profile over every operator the plan has compiled: enable/disable the HIP-event bracket around each operator's

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, missing
     assert len(declared) >= 30
-    assert g.lib().gpuq_abi_version() == 1
+    assert g.lib().gpuq_abi_version() == 2
     assert set(g.lib()._gpuq_symbols) <= declared | {"gpuq_abi_version"}
 
 
@@ -434,3 +434,62 @@ def test_parquet_footer_parser_survives_corruption():
         except g.GpuqError:
             outcomes["err"] += 1
     assert outcomes["err"] > 50
+
+
+def _thrift_footer(schema_elems, extra_struct_depth=0):
+    """A minimal Parquet file image whose footer is hand-written Thrift compact: FileMetaData {1: version, 2: schema list,
+    3: num_rows, 4: row_groups (empty)} -- enough for gpuq_parquet_schema.  schema_elems: list of dicts (type, type_length,
+    repetition, name, num_children, converted, scale, precision)."""
+    def varint(v):
+        out = bytearray()
+        while True:
+            b = v & 0x7F; v >>= 7
+            if v:
+                out.append(b | 0x80)
+            else:
+                out.append(b); return bytes(out)
+
+    def zz(v):
+        return varint((v << 1) ^ (v >> 63))
+
+    def field(delta, typ):
+        return bytes([(delta << 4) | typ])
+
+    def elem(e):
+        out = bytearray(); last = 0
+        for fid, key, typ in ((1, "type", 5), (2, "type_length", 5), (3, "repetition", 5), (4, "name", 8), (5, "num_children", 5), (6, "converted", 5), (7, "scale", 5), (8, "precision", 5)):
+            if key not in e:
+                continue
+            out += field(fid - last, typ); last = fid
+            if typ == 8:
+                nb = e[key].encode(); out += varint(len(nb)) + nb
+            else:
+                out += zz(e[key])
+        return bytes(out) + b"\x00"
+    meta = bytearray()
+    meta += field(1, 5) + zz(1)                                            # version
+    meta += field(1, 9) + bytes([(len(schema_elems) << 4) | 12]) + b"".join(elem(e) for e in schema_elems)
+    meta += field(1, 6) + zz(0)                                            # num_rows
+    meta += field(1, 9) + bytes([(0 << 4) | 12])                           # row_groups: empty list of structs
+    if extra_struct_depth:                                                 # field 5 (key_value_metadata slot) abused as a struct nested N deep
+        meta += field(1, 12) + bytes([0x1C]) * extra_struct_depth + b"\x00" * (extra_struct_depth + 1)
+    meta += b"\x00"
+    return b"PAR1" + bytes(meta) + len(meta).to_bytes(4, "little") + b"PAR1"
+
+
+def test_parquet_footer_with_hostile_type_length_and_nesting():
+    """FIXED_LEN_BYTE_ARRAY's type_length is a zigzag varint from an untrusted footer: 0 and negative values must not
+    reach the page decoders (they index file + vi * type_length), and a footer of nested struct headers must not recurse the host
+    stack away.  Host only: gpuq_parquet_schema announces such a column as undecodable; the deep footer is an error, not a crash."""
+    from arrow_ballista_amd import scan
+    L = g.lib()
+    root = {"name": "schema", "num_children": 1}
+    for tl, ok in ((16, True), (5, True), (0, False), (-4, False), (17, False), (-2**31, False)):
+        img = _thrift_footer([root, {"type": 7, "type_length": tl, "repetition": 0, "name": "x", "converted": 5, "scale": 2, "precision": 9}])
+        fields, rows = scan.parquet_schema(L, img)
+        assert rows == 0 and len(fields) == 1 and fields[0][0] == "x"
+        assert (fields[0][1] is not None) == ok, (tl, fields)
+    # 60 nested structs are walked; 100 000 are refused (they used to overflow the stack)
+    scan.parquet_schema(L, _thrift_footer([root, {"type": 2, "repetition": 0, "name": "y"}], extra_struct_depth=60))
+    with pytest.raises(g.GpuqError, match="nested deeper"):
+        scan.parquet_schema(L, _thrift_footer([root, {"type": 2, "repetition": 0, "name": "y"}], extra_struct_depth=100_000))
