@@ -129,6 +129,8 @@ def lib():
         "gpuq_ops_settle": (i32, [vp, vp, C.POINTER(vp), i32, C.POINTER(vp), i32, C.POINTER(u64)]),
         "gpuq_join_build_run": (i32, [vp, vp, C.POINTER(gpuq_input), i32, i64, C.POINTER(vp)]),
         "gpuq_join_table_free": (None, [vp]),
+        "gpuq_join_build_run_semi": (i32, [vp, vp, C.POINTER(gpuq_input), i32, i64, vp, vp, vp, C.POINTER(vp)]),
+        "gpuq_join_table_has_duplicates": (i32, [vp]),
         "gpuq_join_probe_run": (i32, [vp, vp, vp, C.POINTER(gpuq_input), i32, vp, vp, u64, vp]),
         "gpuq_join_build_side_rows": (i32, [vp, vp, i32, vp, vp]),
         "gpuq_mark_rows": (i32, [vp, vp, vp, i64, vp]),

@@ -56,6 +56,7 @@ struct gpuq_op {
   i64 last_groups = -1;             // groups of this operator's previous run
   // join
   int join_type = JT_INNER; int null_eq = 0; bool build_side_rows = true;
+  bool has_semi = false; KeySpec semi_keys{};      // chain fusion: the keys this build's rows are looked up with in another join's table
   // sort
   SortSpec sort{}; i64 fetch = -1; bool sort_guess_failed = false, join_guess_failed = false;
   // partition
@@ -592,11 +593,23 @@ static void compile_op(gpuq_op* op, const Json& d) {
       std::vector<NodeP> ks;
       for (const Json& e : d.at("on").a) { NodeP n = ec.from_json(e); ks.push_back(n); ec.add_output(n); }
       if (ks.empty()) throw std::runtime_error("join needs at least one key");
+      // "semi_on" (join_build only): keys these rows are first looked up with in ANOTHER join's table (gpuq_join_build_run_semi)
+      std::vector<NodeP> semi;
+      if (d.has("semi_on")) {
+        if (op->kind != K_JOIN_BUILD) throw std::runtime_error("semi_on belongs to a join_build operator");
+        for (const Json& e : d.at("semi_on").a) { NodeP n = ec.from_json(e); semi.push_back(n); ec.add_output(n); }
+      }
       op->prog = ec.finish(); upload_code(op->prog, op->code_dev);
       op->null_eq = d.get_bool("null_equals_null", false) ? 1 : 0;
       op->build_side_rows = d.get_bool("build_side_rows", true);
       std::vector<int> regs; for (size_t k = 0; k < ks.size(); ++k) { regs.push_back(op->prog.out_reg[k]); op->key_types.push_back(ks[k]->type); }
       op->keys = make_keyspec(regs, op->key_types, op->null_eq != 0);
+      op->has_semi = !semi.empty();
+      if (op->has_semi) {
+        std::vector<int> sregs; std::vector<DType> stypes;
+        for (size_t k = 0; k < semi.size(); ++k) { sregs.push_back(op->prog.out_reg[ks.size() + k]); stypes.push_back(semi[k]->type); }
+        op->semi_keys = make_keyspec(sregs, stypes, op->null_eq != 0);
+      }
       if (op->kind == K_JOIN_PROBE) {
         static const std::map<std::string, int> jt = {{"Inner", JT_INNER}, {"Left", JT_LEFT}, {"Right", JT_RIGHT}, {"Full", JT_FULL},
             {"LeftSemi", JT_LEFT_SEMI}, {"LeftAnti", JT_LEFT_ANTI}, {"RightSemi", JT_RIGHT_SEMI}, {"RightAnti", JT_RIGHT_ANTI}};
@@ -772,6 +785,8 @@ int gpuq_ops_settle(gpuq_ctx* ctx, void* stream, gpuq_op* const* ops, int n_ops,
     for (int i = 0; i < n_ops; ++i) {
       const uint32_t f = (uint32_t)B.host[i];
       if (f) reset_flags(ops[i], s);
+      static const bool trace = getenv("GPUQ_TRACE_DEFER") != nullptr;
+      if (trace && (f & ~ops[i]->expect_flags)) fprintf(stderr, "[gpuq] settle: operator %d of %d (kind %d) raised status 0x%x (expected 0x%x)\n", i, n_ops, (int)ops[i]->kind, f, ops[i]->expect_flags);
       if (f & ~ops[i]->expect_flags) { retry = true; ops[i]->jb.valid = false; ops[i]->ag.valid = false; ops[i]->so.valid = false; }
     }
     if (retry) throw Retry("an assumption of a deferred run did not hold");
@@ -903,7 +918,8 @@ static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, g
       } else if (op->ag.path == 2) {
         HashTable T{};
         T.key_words = op->keys.key_words; T.slot_words = 1 + T.key_words + 2 * na;
-        const u64 est = op->ag.est;
+        // the table follows the group count of the last run (+ 1/4), not the size that run happened to use (its first run sizes from a sample)
+        const u64 est = std::min<u64>(std::max<u64>(op->ag.est, 64), (u64)(op->ag.groups + op->ag.groups / 4 + 64));
         i64 rcap = op->ag.groups + op->ag.groups / 4 + 1024; if (rcap > cap) rcap = cap;
         if (rcap >= 1 && rcap <= 0x7FFFFFFFll) {
           T.n_slots = next_pow2(est * 2);
@@ -1045,7 +1061,9 @@ static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, g
       // global hash table; grow on FLAG_TABLE_FULL
       // the group count this operator produced last time (another partition of the same stage, the same query again) stands in
       // for a missing expected_groups: it sizes the table and decides on block-local pre-aggregation
-      const i64 known = known_groups >= 0 ? (op->expected_groups > 0 ? known_groups : std::max<i64>(known_groups * 2, 64)) : -1;
+      // (a quarter of head-room over the last run's count: the table is twice that, rounded up to a power of two -- SF100 q3's 1.2 M groups sat
+      // in 8 Mi slots of 56 bytes when the count was doubled first: 0.09 ms to initialise and 0.26 ms to extract from, now half of both)
+      const i64 known = known_groups >= 0 ? (op->expected_groups > 0 ? known_groups : std::max<i64>(known_groups + known_groups / 4, 64)) : -1;
       u64 est = known > 0 ? (u64)std::min<i64>(known, std::max<i64>(n, 1)) : (u64)std::min<i64>(std::max<i64>(n, 1), 1ll << 24);
       if (est < 64) est = 64;
       HashTable T{};
@@ -1156,7 +1174,8 @@ bool probe_keys_local(gpuq_op* op, hipStream_t s, const DevProgram& P, i64 n, co
   return got[0] == 0 || got[1] * 2 >= got[0];
 }
 }  // namespace
-int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, int64_t build_rows_bound, gpuq_join_table** out) {
+static int join_build_impl(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, int64_t build_rows_bound, gpuq_join_table* semi_table,
+                           uint32_t* semi_hits_out, uint64_t* rows_out, gpuq_join_table** out) {
   if (!op) return GPUQ_ERR_INVALID;
   gpuq_join_table* t = nullptr;
   int rc = guarded(op->ctx, [&]() {
@@ -1164,6 +1183,16 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     if (op->kind != K_JOIN_BUILD) throw std::runtime_error("not a join_build operator");
     if (!out) throw std::runtime_error("out is NULL");
     hipStream_t s = use_stream(stream);
+    SemiProbe semi{}; const SemiProbe* semi_p = nullptr;
+    if (semi_table) {
+      if (!op->has_semi) throw std::runtime_error("join build: the descriptor has no \"semi_on\" keys");
+      if (semi_table->has_dups) throw std::runtime_error("join build: the semi table holds duplicate keys (a row could survive more than once)");
+      if (op->semi_keys.n_keys != semi_table->keys.n_keys || op->semi_keys.key_words != semi_table->keys.key_words) throw std::runtime_error("semi keys do not match the semi table's keys (count / width)");
+      for (int k = 0; k < op->semi_keys.n_keys; ++k) if (op->semi_keys.key_wide[k] != semi_table->keys.key_wide[k]) throw std::runtime_error("semi key " + std::to_string(k) + " width class differs from the table's key; cast one side");
+      if (payload_via != 0) throw std::runtime_error("join build over a semi table: payload_via must be 0 (the build row is the position)");
+      semi.T = semi_table->T; semi.K = op->semi_keys; semi.null_eq = semi_table->null_eq; semi.on = 1; semi.hit_out = semi_hits_out; semi.rows_out = (u64*)rows_out;
+      semi_p = &semi;
+    } else if (op->has_semi) throw std::runtime_error("join build: this operator was compiled with \"semi_on\" keys: call gpuq_join_build_run_semi");
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     if (payload_via < 0 || payload_via > in->n_via) throw std::runtime_error("payload_via out of range");
     const i64 n = in->n_rows;
@@ -1187,6 +1216,16 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     // mode 0: the key range is measured, 1: guessed from a sample, 2: deferred -- the layout of the last completed synchronous run is
     // taken as it is (no pass over the keys, nothing read back; the build kernel's own bounds / duplicate tests raise the status word
     // that gpuq_ops_settle reads)
+    // run-time specialisation of the chain-fusion build: the PK/FK shape (one narrow key on each side, a direct-addressed table to
+    // build, no `present` bitmap) gets the probe-style front (kernels_hash.hip k_join_build_semi1_body), anything else the generic one
+    auto semi_spec = [&](const HashTable& T2, const uint32_t* present_) -> std::string {
+      if (!semi_p) return std::string();
+      const KeySpec& A = op->semi_keys; const KeySpec& B = op->keys;
+      const bool narrow = A.n_keys == 1 && A.key_words == 1 && !A.null_word && B.n_keys == 1 && B.key_words == 1 && !B.null_word;
+      if (narrow && T2.dense && !present_ && payload_via == 0)
+        return "#define GPUQ_JIT_SEMI 2\nconstexpr int JIT_KEY_REG0 = " + std::to_string(A.key_reg[0]) + ";\nconstexpr int JIT_KEY2_REG = " + std::to_string(B.key_reg[0]) + ";\n";
+      return "#define GPUQ_JIT_SEMI 1\n";
+    };
     auto attempt = [&](const int mode) -> bool {
     const bool guess = mode == 1, memo = mode == 2;
     bool dense = false; i64 kmin = 0; u64 krange = 0, kcount = 0;
@@ -1233,13 +1272,15 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
       t->T.slots = (u64*)t->slots.ensure((size_t)t->T.n_slots * t->T.slot_words * 8);
     }
     if (memo) {
-      uint32_t* next = (uint32_t*)t->next.ensure((size_t)std::max<i64>(build_rows_bound, 1) * 4);
+      // unique keys remembered: no chain array (a duplicate raises the status word and the run is redone with one)
+      uint32_t* next = op->jb.has_dups ? (uint32_t*)t->next.ensure((size_t)std::max<i64>(build_rows_bound, 1) * 4) : nullptr;
       const size_t bm = ((size_t)build_rows_bound + 63) / 64 * 8 + 8;
       uint32_t* present = nullptr;
       if (op->build_side_rows) { present = (uint32_t*)t->present.ensure(bm); HIPCHECK(hipMemsetAsync(present, 0, bm, s)); }
       t->has_present = op->build_side_rows;
       if (!dense) launch_ht_init(s, t->T, nullptr);
-      { JitScope js(op, op->prog, 5, n); ProfScope ps(op, s); launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq); }
+      if (rows_out) HIPCHECK(hipMemsetAsync(rows_out, 0, 8, s));      // (a build that is redone counts its survivors again)
+      { JitScope js(op, op->prog, 5, n, semi_spec(t->T, present)); ProfScope ps(op, s); if (!launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq, semi_p)) throw Unsupported("join build over a semi table: more than 8 input columns without the specialised kernel"); }
       HIPCHECK(hipGetLastError());
       t->has_dups = op->jb.has_dups;
       return true;
@@ -1254,7 +1295,8 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
     t->has_present = op->build_side_rows;
     if (!dense) launch_ht_init(s, t->T, nullptr);
     reset_flags(op, s);
-    { JitScope js(op, op->prog, 5, n); ProfScope ps(op, s); launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq); }
+    if (rows_out) HIPCHECK(hipMemsetAsync(rows_out, 0, 8, s));      // (a build that is redone counts its survivors again)
+      { JitScope js(op, op->prog, 5, n, semi_spec(t->T, present)); ProfScope ps(op, s); if (!launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq, semi_p)) throw Unsupported("join build over a semi table: more than 8 input columns without the specialised kernel"); }
     HIPCHECK(hipGetLastError());
     uint32_t f = read_flags(op, s);
     if (guess && (f & FLAG_TABLE_FULL)) { reset_flags(op, s); return false; }      // a key outside the guessed range
@@ -1264,7 +1306,8 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
       HIPCHECK(hipMemsetAsync(t->T.dense, 0xFF, (size_t)krange * 4, s));
       if (present) HIPCHECK(hipMemsetAsync(present, 0, bm, s));
       reset_flags(op, s);
-      { JitScope js(op, op->prog, 5, n); ProfScope ps(op, s); launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq); }
+      if (rows_out) HIPCHECK(hipMemsetAsync(rows_out, 0, 8, s));      // (a build that is redone counts its survivors again)
+      { JitScope js(op, op->prog, 5, n, semi_spec(t->T, present)); ProfScope ps(op, s); if (!launch_join_build(s, P, n, op->keys, t->T, next, present, payload_via, op->null_eq, semi_p)) throw Unsupported("join build over a semi table: more than 8 input columns without the specialised kernel"); }
       HIPCHECK(hipGetLastError());
       f = read_flags(op, s);
     }
@@ -1287,6 +1330,15 @@ int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int pay
   if (rc != GPUQ_OK) { delete t; if (out) *out = nullptr; }
   return rc;
 }
+int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, int64_t build_rows_bound, gpuq_join_table** out) {
+  return join_build_impl(op, stream, in, payload_via, build_rows_bound, nullptr, nullptr, nullptr, out);
+}
+int gpuq_join_build_run_semi(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, int64_t build_rows_bound, gpuq_join_table* semi_table,
+                             uint32_t* semi_hits_out, uint64_t* rows_out, gpuq_join_table** out) {
+  if (!semi_table) return GPUQ_ERR_INVALID;
+  return join_build_impl(op, stream, in, payload_via, build_rows_bound, semi_table, semi_hits_out, rows_out, out);
+}
+int gpuq_join_table_has_duplicates(const gpuq_join_table* t) { return t && t->has_dups ? 1 : 0; }
 void gpuq_join_table_free(gpuq_join_table* t) { delete t; }
 
 int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpuq_input* in, int payload_via, uint32_t* out_build,

@@ -565,8 +565,9 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
     const int cls = f.raw128 ? (int)CC_I128 : col_class_for(f.type);
     const std::string A = "a" + cs;
     switch (cls) {
-      case CC_I32: case CC_U32: fieldR("uint32_t", A); LL("w." + A + " = ((const uint32_t*)col" + cs + ".data)[r" + cs + "];"); L("const uint32_t " + A + " = w." + A + ";"); break;
-      case CC_I64: fieldR("u64", A); LL("w." + A + " = ((const u64*)col" + cs + ".data)[r" + cs + "];"); L("const u64 " + A + " = w." + A + ";"); break;
+      // (columns read by position stream through once: GPUQ_LD_STREAM can make those loads non-temporal, gpuq_dev.h)
+      case CC_I32: case CC_U32: fieldR("uint32_t", A); LL("w." + A + " = " + std::string(f.side == 0 ? "GPUQ_LD_STREAM" : "*") + "(((const uint32_t*)col" + cs + ".data) + r" + cs + ");"); L("const uint32_t " + A + " = w." + A + ";"); break;
+      case CC_I64: fieldR("u64", A); LL("w." + A + " = " + std::string(f.side == 0 ? "GPUQ_LD_STREAM" : "*") + "(((const u64*)col" + cs + ".data) + r" + cs + ");"); L("const u64 " + A + " = w." + A + ";"); break;
       case CC_I128:
         if (narrow128[c]) {   // declared precision fits 64 bits: only the low half of the 16-byte value is ever used
           fieldR("u64", A); LL("w." + A + " = ((const u64*)col" + cs + ".data)[2 * (size_t)r" + cs + "];"); L("const ulonglong2 " + A + " = make_ulonglong2(w." + A + ", 0ull);");

@@ -95,6 +95,13 @@ struct DevProgram {
   const u64* n_dev;      // deferred execution: when set, the row count is min(*n_dev, n) and the launch's n is only a bound -- a producer's
                          // count (join pairs, filter survivors, groups) is handed over on the device, the host never reads it between operators
 };
+// Loads of columns that are read by position, once, front to back.  GPUQ_NT_STREAM=1 (a tuning switch, GPUQ_JIT_DEFINES) makes them
+// non-temporal so that a multi-GB scan does not wash a join table's bitmap out of the L2 / Infinity Cache.
+#ifdef GPUQ_NT_STREAM
+#define GPUQ_LD_STREAM(p) __builtin_nontemporal_load(p)
+#else
+#define GPUQ_LD_STREAM(p) (*(p))
+#endif
 __device__ __forceinline__ i64 rows_of(const DevProgram& P, const i64 n_bound) {
   if (P.n_dev) { const i64 nd = (i64)*P.n_dev; return nd < n_bound ? nd : n_bound; }
   return n_bound;

@@ -67,6 +67,8 @@ struct HashTable {
   // Only for unique build keys (duplicates need the chain heads initialised).  nullptr = the array alone (NIL = no key).
   uint32_t* dense_bits;
 };
+// chain fusion: the build kernel first looks its rows up in ANOTHER join's table (kernels_hash.hip k_join_build_body)
+struct SemiProbe { HashTable T; KeySpec K; int32_t null_eq; int32_t on; uint32_t* hit_out; u64* rows_out; };
 enum JoinType : int32_t { JT_INNER = 0, JT_LEFT = 1, JT_RIGHT = 2, JT_FULL = 3, JT_LEFT_SEMI = 4, JT_LEFT_ANTI = 5, JT_RIGHT_SEMI = 6, JT_RIGHT_ANTI = 7 };
 
 // build: payload = payload_via ? via[payload_via-1][pos] : pos.  next == nullptr => unique keys only (FLAG_DUP_BUILD_KEY on a duplicate)
@@ -139,8 +141,9 @@ void launch_bucket_bounds(hipStream_t s, const u64* sorted_bid, i64 n, u64 nbuck
 void launch_agg_bucket(hipStream_t s, const DevProgram& P, const KeySpec& K, const AggSpec& A, const uint32_t* ids, const uint32_t* bounds, uint32_t nbuckets,
                        uint32_t cap, int slot_words, const AggOut& out);
 void launch_agg_hash_extract(hipStream_t s, const KeySpec& K, const AggSpec& A, const HashTable& T, const AggOut& out, uint32_t* flags);
-void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
-                       int payload_via, int null_equals_null);
+// false: no interpreter kernel for this shape (chain fusion over more than 8 input columns)
+bool launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
+                       int payload_via, int null_equals_null, const SemiProbe* semi = nullptr);
 // key range of the rows a join build would insert: out = {min (i64), max (i64), count (u64)}, pre-set by the caller to {INT64_MAX, INT64_MIN, 0}
 void launch_join_keyrange(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, int null_equals_null, u64* out, i64 wstep = 1);   // wstep > 1: every wstep-th 64-row word
 // unique build keys: every wave owns `wpw` consecutive 64-row words (segment g = words [g*wpw, (g+1)*wpw)) and writes its pairs, in probe

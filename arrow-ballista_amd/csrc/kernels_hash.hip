@@ -879,68 +879,6 @@ __global__ void __launch_bounds__(HBLOCK) k_join_keyrange(const DevProgram P, co
 extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const int null_eq, u64* __restrict__ out, const i64 wstep) { k_join_keyrange_body<0>(P, n, K, null_eq, out, wstep); }
 #endif
 
-template <int MAXC>
-__device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 n_arg, const KeySpec K, const HashTable T,
-                                                       uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
-                                                       const int null_eq) {
-  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
-  for_rows_in_flight<MAXC>(P, n, (i64)blockIdx.x * HWAVES + hwave(), (i64)gridDim.x * HWAVES, [&](const i64 w, const i64 pos, const bool active, GPUQ_REGS_PARAM) {
-    // `present` = every build-side row that passes the side's predicate, NULL keys included (outer joins emit them).  When rows
-    // are positions, the 64 rows of this step ARE word w of the bitmap: one plain 8-byte store (64 lanes OR-ing into two words
-    // serialise in the L2's atomic unit -- it was most of the build's time: 1.4 ms for 14.6 M rows)
-    if (present && payload_via == 0) { const u64 am = __ballot(active); if (hlane() == 0) ((u64*)present)[w] = am; }
-    if (!active) return;
-    u64 kw[MAX_KW]; u64 h;
-#pragma unroll
-    for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
-    const bool any_null = make_key(K, GPUQ_REGS, kw, h);
-    uint32_t row = (uint32_t)pos;
-    if (payload_via > 0) { row = P.via[payload_via - 1][pos]; if (present) atomicOr(&present[row >> 5], 1u << (row & 31)); }
-    if (any_null && !null_eq) return;   // a NULL key never matches (SQL equi-join)
-    bool inserted; uint32_t old = NIL;
-    if (T.dense) {
-      // direct addressing: the table word is the chain head; an exchange both claims the key and links a duplicate
-      const u64 idx = kw[0] - (u64)T.dense_min;
-      if (idx >= T.dense_range) { atomicOr(P.flags, FLAG_TABLE_FULL); return; }      // cannot happen: the range was measured on these rows
-      if (T.dense_bits) {
-        // presence bitmap + uninitialised row array: valid for unique keys only; a duplicate raises the flag and the host rebuilds
-        // with the initialised array (chains need a defined head)
-        const uint32_t bit = 1u << (idx & 31);
-        const uint32_t was = atomicOr(T.dense_bits + (idx >> 5), bit);
-        T.dense[idx] = row;
-        inserted = !(was & bit);
-      } else {
-        old = __hip_atomic_exchange(T.dense + idx, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        inserted = old == NIL;
-      }
-    } else {
-      const u64 s = ht_find_or_insert(T, kw, h, row, inserted);
-      if (s == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); return; }
-      if (!inserted && next) {
-        uint32_t* head = (uint32_t*)(T.slots + s * (u64)T.slot_words) + 1;   // high half of word 0
-        old = __hip_atomic_exchange(head, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if (inserted) {
-      if (next) next[row] = NIL;
-    } else {
-      // duplicate key: remember it (the host then uses the chained probe) -- test first, one word must not be hammered
-      if (!(__hip_atomic_load(P.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_DUP_BUILD_KEY)) atomicOr(P.flags, FLAG_DUP_BUILD_KEY);
-      if (next) next[row] = old;
-    }
-  });
-}
-#ifndef GPUQ_JIT
-template <int MAXC>
-__global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
-                                                       uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
-                                                       const int null_eq) { k_join_build_body<MAXC>(P, n, K, T, next, present, payload_via, null_eq); }
-#elif GPUQ_JIT_KERNEL == 5
-extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
-                                                       uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
-                                                       const int null_eq) { k_join_build_body<0>(P, n, K, T, next, present, payload_via, null_eq); }
-#endif
-
 // key lookup shared by the probes: chain head row of the key, or NIL
 __device__ __forceinline__ uint32_t join_lookup(const HashTable& T, const u64 (&kw)[MAX_KW], const u64 h) {
   if (T.dense) {
@@ -952,6 +890,267 @@ __device__ __forceinline__ uint32_t join_lookup(const HashTable& T, const u64 (&
   uint32_t payload;
   return ht_find(T, kw, h, payload) ? payload : NIL;
 }
+
+// Chain fusion (A |x| B) |x| C with A's keys unique: the build side of the second join is "the rows of B that find their key in A's
+// table".  Instead of probing A with B, writing the pairs, and building from the pairs through an index vector, the BUILD kernel of
+// the second join looks every row of B up in A's table (S.T, key registers S.K) and inserts the survivors: one pass over B, B's row
+// position is the build row.  hit_out[pos] (optional) = A's row for the surviving position (A's columns are then read through it);
+// rows_out (optional) += number of surviving rows (one atomic per wave at the end).
+// one row into the direct-addressed table (idx = key - dense_min, checked by the caller)
+__device__ __forceinline__ void build_insert_dense(const DevProgram& P, const HashTable& T, uint32_t* __restrict__ next, const u64 idx, const uint32_t row) {
+  bool inserted; uint32_t old = NIL;
+  if (T.dense_bits) {
+    // presence bitmap + uninitialised row array: valid for unique keys only; a duplicate raises the flag and the host rebuilds
+    // with the initialised array (chains need a defined head)
+    const uint32_t bit = 1u << (idx & 31);
+    const uint32_t was = atomicOr(T.dense_bits + (idx >> 5), bit);
+    T.dense[idx] = row;
+    inserted = !(was & bit);
+  } else {
+    // the table word is the chain head; an exchange both claims the key and links a duplicate
+    old = __hip_atomic_exchange(T.dense + idx, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    inserted = old == NIL;
+  }
+  if (inserted) {
+    if (next) next[row] = NIL;
+  } else {
+    // duplicate key: remember it (the host then uses the chained probe) -- test first, one word must not be hammered
+    if (!(__hip_atomic_load(P.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_DUP_BUILD_KEY)) atomicOr(P.flags, FLAG_DUP_BUILD_KEY);
+    if (next) next[row] = old;
+  }
+}
+constexpr int BUILD_QCAP = 128;      // survivor queue per wave: < 64 waiting + <= 64 from one more word
+// SEMI: compiled with the chain-fusion front (the plain build keeps its register budget: the 16-column interpreter instantiation
+// spilled its register file with both key sets live)
+template <int MAXC, bool SEMI>
+__device__ __forceinline__ void k_join_build_body(const DevProgram P, const i64 n_arg, const KeySpec K, const HashTable T,
+                                                       uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
+                                                       const int null_eq, const SemiProbe S) {
+  const i64 n = rows_of(P, n_arg);      // deferred execution: the row count is a device word, n_arg its host-side bound
+  // Chain fusion over a direct-addressed table: only a fraction of the rows survives the lookup in the other join's table (SF100 q3:
+  // one order in ten), and an insert is a chain of dependent memory operations (atomic on the bitmap, store of the row, the other
+  // table's row for the hit vector).  Run per 64-row word, that chain is paid 2.3 M times with six lanes busy (measured: 2.27 ms for
+  // the orders side, worse than the two-step form).  So the survivors of a wave are QUEUED in LDS -- (position, table index, the other
+  // table's index) -- and inserted 64 at a time with every lane busy: the chain is paid once per 64 survivors.
+  __shared__ uint32_t q_pos[SEMI ? HWAVES : 1][SEMI ? BUILD_QCAP : 1], q_idx[SEMI ? HWAVES : 1][SEMI ? BUILD_QCAP : 1], q_aux[SEMI ? HWAVES : 1][SEMI ? BUILD_QCAP : 1];
+  const bool queued = SEMI && S.on && T.dense != nullptr;
+  const bool s_bits = S.T.dense != nullptr && S.T.dense_bits != nullptr;      // the other table answers "is it there" from its bitmap alone
+  uint32_t qn = 0, survivors = 0;
+  const int wv = SEMI ? hwave() : 0;
+  auto flush = [&](const uint32_t from, const uint32_t cnt) {      // entries [from, from + cnt) of the queue, cnt <= 64
+    const bool on = (uint32_t)hlane() < cnt;
+    const uint32_t j = from + (on ? (uint32_t)hlane() : 0u);
+    const uint32_t pos = q_pos[wv][j], idx = q_idx[wv][j], aux = q_aux[wv][j];
+    if (on) {
+      if (S.hit_out) S.hit_out[pos] = s_bits ? S.T.dense[aux] : aux;
+      build_insert_dense(P, T, next, (u64)idx, pos);
+    }
+  };
+  for_rows_in_flight<MAXC>(P, n, (i64)blockIdx.x * HWAVES + hwave(), (i64)gridDim.x * HWAVES, [&](const i64 w, const i64 pos, bool active, GPUQ_REGS_PARAM) {
+    uint32_t aux = NIL;
+    if (SEMI && S.on) {
+      bool found = false;
+      if (active) {
+        u64 kw1[MAX_KW]; u64 h1;
+#pragma unroll
+        for (int q = 0; q < MAX_KW; ++q) kw1[q] = 0;
+        const bool null1 = make_key(S.K, GPUQ_REGS, kw1, h1);
+        if (!(null1 && !S.null_eq)) {
+          if (s_bits && queued) {
+            const u64 i1 = kw1[0] - (u64)S.T.dense_min;
+            if (i1 < S.T.dense_range && ((S.T.dense_bits[i1 >> 5] >> (i1 & 31)) & 1u)) { found = true; aux = (uint32_t)i1; }      // the row itself is read at the flush
+          } else { aux = join_lookup(S.T, kw1, h1); found = aux != NIL; }
+        }
+      }
+      active = active && found;
+      if (!queued && active && S.hit_out) S.hit_out[pos] = aux;
+      if (S.rows_out) survivors += active ? 1u : 0u;
+    }
+    // `present` = every build-side row that passes the side's predicate, NULL keys included (outer joins emit them).  When rows
+    // are positions, the 64 rows of this step ARE word w of the bitmap: one plain 8-byte store (64 lanes OR-ing into two words
+    // serialise in the L2's atomic unit -- it was most of the build's time: 1.4 ms for 14.6 M rows)
+    if (present && payload_via == 0) { const u64 am = __ballot(active); if (hlane() == 0) ((u64*)present)[w] = am; }
+    if (queued) {
+      u64 idx = 0; bool ins = false;
+      if (active) {
+        u64 kw[MAX_KW]; u64 h;
+#pragma unroll
+        for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
+        const bool any_null = make_key(K, GPUQ_REGS, kw, h);
+        idx = kw[0] - (u64)T.dense_min;
+        ins = !(any_null && !null_eq);
+        if (ins && idx >= T.dense_range) { atomicOr(P.flags, FLAG_TABLE_FULL); ins = false; }
+        if (!ins && S.hit_out) S.hit_out[pos] = s_bits ? S.T.dense[aux] : aux;      // a surviving row without a usable key is still a row of the build side
+      }
+      const u64 m = __ballot(ins);
+      if (ins) {
+        const uint32_t j = qn + (uint32_t)__popcll(m & ((1ull << hlane()) - 1));
+        q_pos[wv][j] = (uint32_t)pos; q_idx[wv][j] = (uint32_t)idx; q_aux[wv][j] = aux;
+      }
+      qn += (uint32_t)__popcll(m);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (qn >= 64) { qn -= 64; flush(qn, 64); __builtin_amdgcn_wave_barrier(); }
+      return;
+    }
+    if (!active) return;
+    u64 kw[MAX_KW]; u64 h;
+#pragma unroll
+    for (int q = 0; q < MAX_KW; ++q) kw[q] = 0;
+    const bool any_null = make_key(K, GPUQ_REGS, kw, h);
+    uint32_t row = (uint32_t)pos;
+    if (payload_via > 0) { row = P.via[payload_via - 1][pos]; if (present) atomicOr(&present[row >> 5], 1u << (row & 31)); }
+    if (any_null && !null_eq) return;   // a NULL key never matches (SQL equi-join)
+    if (T.dense) {
+      const u64 idx = kw[0] - (u64)T.dense_min;
+      if (idx >= T.dense_range) { atomicOr(P.flags, FLAG_TABLE_FULL); return; }      // cannot happen: the range was measured on these rows
+      build_insert_dense(P, T, next, idx, row);
+      return;
+    }
+    bool inserted; uint32_t old = NIL;
+    const u64 s = ht_find_or_insert(T, kw, h, row, inserted);
+    if (s == ~0ull) { atomicOr(P.flags, FLAG_TABLE_FULL); return; }
+    if (!inserted && next) {
+      uint32_t* head = (uint32_t*)(T.slots + s * (u64)T.slot_words) + 1;   // high half of word 0
+      old = __hip_atomic_exchange(head, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (inserted) {
+      if (next) next[row] = NIL;
+    } else {
+      if (!(__hip_atomic_load(P.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_DUP_BUILD_KEY)) atomicOr(P.flags, FLAG_DUP_BUILD_KEY);
+      if (next) next[row] = old;
+    }
+  });
+  if (queued && qn > 0) flush(0, qn);
+  if (SEMI && S.on && S.rows_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) survivors += __shfl_xor(survivors, o);
+    if (hlane() == 0 && survivors) atomicAdd((unsigned long long*)S.rows_out, (unsigned long long)survivors);
+  }
+}
+#if defined(GPUQ_JIT) && defined(GPUQ_JIT_SEMI) && GPUQ_JIT_SEMI == 2
+// Chain fusion, specialised (run-time compiled) for the PK/FK shape: ONE narrow key on each side (registers JIT_KEY_REG0 = the key
+// the rows are looked up with in the other join's table, JIT_KEY2_REG = this build's key), a direct-addressed table to build, no
+// `present` bitmap.  The front is the unique probe's (k_join_probe_unique_body): U words of rows per step, every column load of all
+// U issued before any value is looked at, then the U lookups in the other table back to back; survivors go to the wave's LDS queue
+// and are inserted 64 at a time (see k_join_build_body).  The per-word form above waits for one lookup per word: 1.9 ms for the
+// orders side of SF100 q3 against 0.84 ms for the unique probe over the same rows.
+template <int MAXC>
+__device__ __forceinline__ void k_join_build_semi1_body(const DevProgram P, const i64 n_arg, const HashTable T, uint32_t* __restrict__ next, const SemiProbe S) {
+#ifndef GPUQ_SEMI_ROWS
+#define GPUQ_SEMI_ROWS 4
+#endif
+  constexpr int U = GPUQ_SEMI_ROWS;
+  constexpr int QC = 64 * (U + 1);
+  __shared__ uint32_t q_pos[HWAVES][QC], q_idx[HWAVES][QC], q_aux[HWAVES][QC];
+  const i64 n = rows_of(P, n_arg);
+  const i64 nwords = (n + 63) >> 6;
+  const int wv = hwave();
+  const bool s_dense = S.T.dense != nullptr;
+  const uint32_t* __restrict__ sbits = S.T.dense_bits;
+  const bool late_row = s_dense && sbits != nullptr;      // the other table's row is only read for the survivors, at the flush
+  uint32_t qn = 0, survivors = 0;
+  auto flush = [&](const uint32_t from, const uint32_t cnt) {
+    const bool on = (uint32_t)hlane() < cnt;
+    const uint32_t j = from + (on ? (uint32_t)hlane() : 0u);
+    const uint32_t pos = q_pos[wv][j], idx = q_idx[wv][j], aux = q_aux[wv][j];
+    if (on) {
+      if (S.hit_out) S.hit_out[pos] = late_row ? S.T.dense[aux] : aux;
+      build_insert_dense(P, T, next, (u64)idx, pos);
+    }
+  };
+  const i64 wave0 = ((i64)blockIdx.x * HWAVES + hwave()) * U, wstride = (i64)gridDim.x * HWAVES * U;
+  for (i64 wb = wave0; wb < nwords; wb += wstride) {
+    bool act[U]; u64 key1[U], key2[U]; bool n1[U], n2[U]; i64 posc[U];
+    {
+      JitPre jq[U]; JitRaw jw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const i64 pos = ((wb + u) << 6) + hlane();
+        act[u] = (wb + u) < nwords && pos < n;
+        posc[u] = act[u] ? pos : n - 1;      // clamped, masked afterwards (n > 0 here)
+        gpuq_jit_pre(P, posc[u], jq[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) gpuq_jit_load(P, posc[u], jq[u], jw[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        GPUQ_REGS_DECL;
+        const bool pass = gpuq_jit_compute(P, posc[u], jw[u], GPUQ_REGS);
+        act[u] = act[u] && pass;
+        n1[u] = (rnulls >> JIT_KEY_REG0) & 1; n2[u] = (rnulls >> JIT_KEY2_REG) & 1;
+        key1[u] = rlo[JIT_KEY_REG0]; key2[u] = rlo[JIT_KEY2_REG];
+      }
+    }
+    // the other table: all U lookups in flight
+    uint32_t aux[U]; bool found[U];
+    if (s_dense) {
+      uint32_t bw[U]; u64 i1[U]; bool in[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        i1[u] = key1[u] - (u64)S.T.dense_min;
+        in[u] = act[u] && !n1[u] && i1[u] < S.T.dense_range;
+        bw[u] = 0;
+        if (in[u]) bw[u] = sbits ? sbits[i1[u] >> 5] : S.T.dense[i1[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (sbits) { found[u] = in[u] && ((bw[u] >> (i1[u] & 31)) & 1u); aux[u] = (uint32_t)i1[u]; }
+        else { found[u] = in[u] && bw[u] != NIL; aux[u] = bw[u]; }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        aux[u] = NIL;
+        if (act[u] && !n1[u]) { u64 kw1[MAX_KW]; for (int q = 0; q < MAX_KW; ++q) kw1[q] = 0; kw1[0] = key1[u]; aux[u] = join_lookup(S.T, kw1, hash_combine(0x243F6A8885A308D3ull, key1[u], 0, false)); }
+        found[u] = aux[u] != NIL;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool surv = act[u] && found[u];
+      survivors += surv ? 1u : 0u;
+      const u64 idx = key2[u] - (u64)T.dense_min;
+      bool ins = surv && !n2[u];
+      if (ins && idx >= T.dense_range) { atomicOr(P.flags, FLAG_TABLE_FULL); ins = false; }
+      if (surv && !ins && S.hit_out) S.hit_out[posc[u]] = late_row ? S.T.dense[aux[u]] : aux[u];
+      const u64 m = __ballot(ins);
+      if (ins) {
+        const uint32_t j = qn + (uint32_t)__popcll(m & ((1ull << hlane()) - 1));
+        q_pos[wv][j] = (uint32_t)posc[u]; q_idx[wv][j] = (uint32_t)idx; q_aux[wv][j] = aux[u];
+      }
+      qn += (uint32_t)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    while (qn >= 64) { qn -= 64; flush(qn, 64); }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (qn > 0) flush(0, qn);
+  if (S.rows_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) survivors += __shfl_xor(survivors, o);
+    if (hlane() == 0 && survivors) atomicAdd((unsigned long long*)S.rows_out, (unsigned long long)survivors);
+  }
+}
+#endif
+#ifndef GPUQ_JIT
+template <int MAXC, bool SEMI>
+__global__ void __launch_bounds__(HBLOCK) k_join_build(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                       uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
+                                                       const int null_eq, const SemiProbe S) { k_join_build_body<MAXC, SEMI>(P, n, K, T, next, present, payload_via, null_eq, S); }
+#elif GPUQ_JIT_KERNEL == 5
+#ifndef GPUQ_JIT_SEMI
+#define GPUQ_JIT_SEMI 0
+#endif
+extern "C" __global__ void __launch_bounds__(HBLOCK) gpuq_jit_entry(const DevProgram P, const i64 n, const KeySpec K, const HashTable T,
+                                                       uint32_t* __restrict__ next, uint32_t* __restrict__ present, const int payload_via,
+                                                       const int null_eq, const SemiProbe S) {
+#if GPUQ_JIT_SEMI == 2
+  k_join_build_semi1_body<0>(P, n, T, next, S);
+#else
+  k_join_build_body<0, GPUQ_JIT_SEMI != 0>(P, n, K, T, next, present, payload_via, null_eq, S);
+#endif
+}
+#endif
 
 // ------------------------------------------------------------------ join probe
 // Emits (build_row, probe_row) pairs with wave-ballot compaction: one global atomic per wave per
@@ -1553,16 +1752,25 @@ void launch_agg_bucket(hipStream_t s, const DevProgram& P, const KeySpec& K, con
 #undef CALL
   }
 }
-void launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
-                       int payload_via, int null_equals_null) {
-  if (n <= 0) return;
+bool launch_join_build(hipStream_t s, const DevProgram& P, i64 n, const KeySpec& K, const HashTable& T, uint32_t* next, uint32_t* present,
+                       int payload_via, int null_equals_null, const SemiProbe* semi) {
+  if (n <= 0) return true;
+  SemiProbe S{}; if (semi) S = *semi;
   if (jit_override().fn && jit_override().kernel_id == 5) {
-    (void)jit_launch(jit_override().fn, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, present, payload_via, null_equals_null);
+    (void)jit_launch(jit_override().fn, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, present, payload_via, null_equals_null, S);
   } else {
-#define CALL(M) hipLaunchKernelGGL(k_join_build<M>, dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, present, payload_via, null_equals_null)
+    if (semi) {      // chain fusion: the interpreter form exists for up to 8 input columns (the specialised form for any)
+      if (P.n_cols > 8) return false;
+#define CALLS(M) hipLaunchKernelGGL((k_join_build<M, true>), dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, present, payload_via, null_equals_null, S)
+      if (P.n_cols <= 2) { CALLS(2); } else if (P.n_cols <= 4) { CALLS(4); } else { CALLS(8); }
+#undef CALLS
+      return true;
+    }
+#define CALL(M) hipLaunchKernelGGL((k_join_build<M, false>), dim3(hgrid(n, 8)), dim3(HBLOCK), 0, s, P, n, K, T, next, present, payload_via, null_equals_null, S)
   GPUQ_DISPATCH_MAXC(P.n_cols, CALL);
 #undef CALL
   }
+  return true;
 }
 
 // build-side row selection for Left/Full/LeftSemi/LeftAnti: present & (visited | ~visited)

@@ -30,6 +30,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -678,6 +679,10 @@ struct PNode {
   // parses the output partitioning from it before the task executes).  Default: the input's.
   virtual PSchema schema() { auto c = children(); if (c.empty()) throw std::runtime_error("plan: node without a schema"); return c[0]->schema(); }
   virtual PTable execute(int part, Exec& x) = 0;
+  // Which of this node's output columns does anything above it read?  (nullptr = all of them: the root, or a parent that does not
+  // say.)  Walked once when the plan is created; a chain-fused join drops the inner build side's columns when nobody wants them.
+  typedef std::set<std::string> Names;
+  virtual void require(const Names* need) { (void)need; for (PNode* c : children()) c->require(nullptr); }
   PTable timed(Exec& x, std::chrono::steady_clock::time_point t0, PTable t) {
     m.elapsed_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     m.output_rows += t.n;
@@ -738,20 +743,26 @@ PSchema compiled_outputs(const Json& desc) {
   return out;
 }
 
+void collect_columns(const Json& e, std::set<std::string>& out) {
+  (void)rewrite_columns(e, [&](const Json& c) { out.insert(c.at("name").str()); return jobj({{"column", c}}); });
+}
 struct PassThrough : PNode {       // CoalesceBatchesExec: whole partitions are already single tables
   PNodeP input;
   std::vector<PNode*> children() override { return {input.get()}; }
+  void require(const Names* need) override { input->require(need); }
   PTable execute(int part, Exec& x) override { return input->execute(part, x); }
 };
 
 struct FilterExec : PNode {
   PNodeP input; Json predicate;
   std::vector<PNode*> children() override { return {input.get()}; }
+  void require(const Names* need) override { if (!need) { input->require(nullptr); return; } Names n = *need; collect_columns(predicate, n); input->require(&n); }
   PTable execute(int part, Exec& x) override;
 };
 struct ProjectionExec : PNode {
   PNodeP input; std::vector<Json> exprs; std::vector<std::string> names;
   std::vector<PNode*> children() override { return {input.get()}; }
+  void require(const Names*) override { Names n; for (auto& e : exprs) collect_columns(e, n); input->require(&n); }
   PSchema schema() override {
     const PSchema in = input->schema(); const auto nm = schema_names(in);
     std::vector<Json> ex = exprs;
@@ -834,6 +845,13 @@ PTable ProjectionExec::execute(int part, Exec& x) {
 struct AggregateExec : PNode {
   PNodeP input; std::string mode, strategy = "auto"; Json group_expr, aggr_expr; int64_t expected_groups = 0, output_capacity = 0;
   std::vector<PNode*> children() override { return {input.get()}; }
+  void require(const Names*) override {
+    if (mode == "Final" || mode == "FinalPartitioned") { input->require(nullptr); return; }      // reads its input's state columns by position
+    Names n;
+    for (auto& g : group_expr.a) collect_columns(g.at("expr"), n);
+    for (auto& a : aggr_expr.a) for (const char* k : {"expr", "expr2"}) if (a.has(k)) collect_columns(a.at(k), n);
+    input->require(&n);
+  }
   PSchema schema() override {
     const PSchema in = input->schema(); const auto nm = schema_names(in);
     Json ge = jarr(), ae = jarr();
@@ -942,6 +960,7 @@ struct AggregateExec : PNode {
 struct SortExec : PNode {
   PNodeP input; Json expr; int64_t fetch = -1; bool merge_all = false;     // merge_all: SortPreservingMergeExec over a single partition
   std::vector<PNode*> children() override { return {input.get()}; }
+  void require(const Names* need) override { if (!need) { input->require(nullptr); return; } Names n = *need; for (auto& s : expr.a) collect_columns(s.at("expr"), n); input->require(&n); }
   int partitions() override { return merge_all ? 1 : input->partitions(); }
   PTable execute(int part, Exec& x) override {
     PTable t;
@@ -961,6 +980,15 @@ struct SortExec : PNode {
 struct HashJoinExec : PNode {
   PNodeP left, right; Json on; std::string join_type = "Inner", partition_mode = "CollectLeft"; bool null_equals_null = false; bool has_filter = false; Json filter;
   std::vector<PNode*> children() override { return {left.get(), right.get()}; }
+  bool out_need_all = true; Names out_need;      // what is read of this join's output (require())
+  void require(const Names* need) override {
+    out_need_all = need == nullptr; if (need) out_need = *need;
+    if (!need) { left->require(nullptr); right->require(nullptr); return; }
+    Names n = *need;
+    for (auto& o : on.a) { collect_columns(o.at("left"), n); collect_columns(o.at("right"), n); }
+    if (has_filter) collect_columns(filter, n);
+    left->require(&n); right->require(&n);
+  }
   int partitions() override { return right->partitions(); }
   PSchema schema() override {      // build_join_schema [UPSTREAM-KNOWLEDGE: datafusion joins/utils.rs]: left ++ right, the non-preserved side nullable
     PSchema l = left->schema(), r = right->schema();
@@ -1032,15 +1060,24 @@ struct HashJoinExec : PNode {
   PTable execute(int part, Exec& x) override {
     // The two inputs are executed ONCE; what may run twice is the join over the tables they produced (a retry that went back to the
     // children re-entered the exchanges below them on this rank alone, re-read shuffle files and counted the children's metrics twice).
-    int lpart = partition_mode == "Partitioned" ? part : 0;
-    Side L;
-    if (partition_mode != "Partitioned" && left->partitions() != 1) {
-      // CollectLeft: the build side is ALL partitions of the left input, collected into one table (what DataFusion's collect_left_input
-      // does before it builds); each partition runs with its own filters / projections applied
-      std::vector<PTable> in; for (int p = 0; p < left->partitions(); ++p) in.push_back(left->execute(p, x));
-      L.t = concat_tables(x, std::move(in));
-    } else L = side(left.get(), lpart, x);
-    Side R = side(right.get(), part, x);
+    Side L, R;
+    HashJoinExec* inner = chain_inner();
+    if (inner) {
+      // (A |x| B) |x| C: this join's build side is built straight from B (see chain_build); the inner join's own output is never formed
+      const int lpart = partition_mode == "Partitioned" ? part : 0;
+      Side Li, Ri; inner->sides(lpart, x, Li, Ri);
+      R = side(right.get(), part, x);
+      auto t0 = std::chrono::steady_clock::now();
+      Chain ch;
+      if (chain_build(x, inner, Li, Ri, ch)) {
+        struct Guard { gpuq_join_table* t; ~Guard() { if (t) gpuq_join_table_free(t); } } guard{ch.table};
+        Side Lv; Lv.t = ch.view;
+        return timed(x, t0, join_sides(x, Lv, R, false, &ch));
+      }
+      // the inner build side holds duplicate keys (or a layout the fused form does not take): the two-step form, over the same inputs
+      auto t1 = std::chrono::steady_clock::now();
+      L.t = inner->timed(x, t1, inner->join_sides(x, Li, Ri, false));
+    } else sides(part, x, L, R);
     auto t0 = std::chrono::steady_clock::now();
     try { return timed(x, t0, join_sides(x, L, R, false)); }
     catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
@@ -1051,7 +1088,105 @@ struct HashJoinExec : PNode {
     strip_code_columns(out);
     return timed(x, t0, out);
   }
-  PTable join_sides(Exec& x, Side L, Side R, const bool long_keys) {
+  void sides(int part, Exec& x, Side& L, Side& R) {
+    const int lpart = partition_mode == "Partitioned" ? part : 0;
+    if (partition_mode != "Partitioned" && left->partitions() != 1) {
+      // CollectLeft: the build side is ALL partitions of the left input, collected into one table (what DataFusion's collect_left_input
+      // does before it builds); each partition runs with its own filters / projections applied
+      std::vector<PTable> in; for (int p = 0; p < left->partitions(); ++p) in.push_back(left->execute(p, x));
+      L.t = concat_tables(x, std::move(in));
+    } else L = side(left.get(), lpart, x);
+    R = side(right.get(), part, x);
+  }
+  // ---- chain fusion (include/gpuq.h gpuq_join_build_run_semi).  This join is the outer one of (A |x| B) |x| C: its left input is an
+  // Inner join without a JoinFilter, and its own build keys are columns of B.  When A's keys turn out unique, B's rows that find
+  // their key in A's table ARE this join's build side, so the build kernel looks them up on the way: one pass over B instead of
+  // probe + pair emit + compaction + a build through an index vector (SF100 q3: the orders side 0.83 + 0.08 + 0.71 ms -> one kernel).
+  struct Chain { gpuq_join_table* table = nullptr; PTable view; bool deferred = false; };
+  static bool is_plain_column(const Json& e, std::string& name) {
+    if (!(e.is_obj() && e.o.size() == 1 && e.o[0].first == "column" && e.o[0].second.is_obj() && e.o[0].second.find("name"))) return false;
+    name = e.o[0].second.at("name").str(); return true;
+  }
+  int chain_checked = 0;      // 0 not looked at yet, 1 candidate, -1 no
+  HashJoinExec* chain_inner() {
+    static const bool on_env = []() { const char* e = getenv("GPUQ_JOIN_CHAIN"); return !(e && e[0] == '0'); }();
+    if (!on_env || chain_checked < 0) return nullptr;
+    PNode* n = left.get();
+    while (auto* p = dynamic_cast<PassThrough*>(n)) n = p->input.get();
+    auto* in = dynamic_cast<HashJoinExec*>(n);
+    if (chain_checked > 0) return in;
+    chain_checked = -1;
+    if (!in || has_filter || null_equals_null || in->has_filter || in->null_equals_null || in->join_type != "Inner") return nullptr;
+    if (!(join_type == "Inner" || join_type == "Right" || join_type == "RightSemi" || join_type == "RightAnti")) return nullptr;
+    if (partition_mode != "Partitioned" && left->partitions() != 1) return nullptr;
+    // this join's build keys must be plain columns of the inner join's probe side (B), under names its build side (A) does not use
+    std::vector<std::string> ln, rn;
+    for (auto& f : in->left->schema()) ln.push_back(f.name);
+    for (auto& f : in->right->schema()) rn.push_back(f.name);
+    for (auto& o : on.a) {
+      std::string nm;
+      if (!is_plain_column(o.at("left"), nm)) return nullptr;
+      if (std::count(rn.begin(), rn.end(), nm) != 1 || std::count(ln.begin(), ln.end(), nm) != 0) return nullptr;
+    }
+    chain_checked = 1;
+    return in;
+  }
+  bool chain_build(Exec& x, HashJoinExec* in, Side& Li, Side& Ri, Chain& ch) {
+    if (Li.t.is_view() || Ri.t.via.size() > 2) return false;      // A's rows are addressed by position; B may bring up to two index vectors
+    for (auto& c : Ri.t.cols) if (c.c.type == T_UTF8 && false) return false;
+    // 1. A's table, exactly as the inner join would build it
+    gpuq_op* bop1 = cached_op(x, in, 0, table_sig(Li.t), [&]() {
+      const auto ln = names_of(Li.t);
+      Json lk = jarr(); for (auto& o : in->on.a) lk.a.push_back(rebind(o.at("left"), ln));
+      std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(Li.t)}})}, {"on", lk}, {"null_equals_null", jbool(false)},
+                                                     {"build_side_rows", jbool(false)}};
+      if (Li.has_pred) bd.push_back({"predicate", rebind(Li.pred, ln)});
+      return jobj(bd);
+    });
+    // 2. this join's table from B's rows that are in A's table
+    gpuq_op* bop2 = cached_op(x, this, 12, table_sig(Ri.t), [&]() {
+      const auto rn = names_of(Ri.t);
+      Json lk = jarr(), sk = jarr();
+      for (auto& o : on.a) lk.a.push_back(rebind(o.at("left"), rn));
+      for (auto& o : in->on.a) sk.a.push_back(rebind(o.at("right"), rn));
+      std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(Ri.t)}})}, {"on", lk}, {"semi_on", sk},
+                                                     {"null_equals_null", jbool(false)}, {"build_side_rows", jbool(false)}};
+      if (Ri.has_pred) bd.push_back({"predicate", rebind(Ri.pred, rn)});
+      return jobj(bd);
+    });
+    bool deferred = x.deferred && last_pairs >= 0 && gpuq_op_can_defer(bop1) && gpuq_op_can_defer(bop2);
+    if (deferred) deferred = use_deferred(x, bop1) && use_deferred(x, bop2);
+    if (!deferred) { use_sync(x, bop1); use_sync(x, bop2); resolve(x, Li.t); resolve(x, Ri.t); }
+    InputC lic, ric; make_input(Li.t, lic); make_input(Ri.t, ric);
+    gpuq_join_table* t1 = nullptr;
+    check(x, gpuq_join_build_run(bop1, x.stream, &lic.in, 0, Li.t.n, &t1));
+    struct Guard { gpuq_join_table* t; ~Guard() { if (t) gpuq_join_table_free(t); } } g1{t1};
+    if (!deferred) x.host_syncs += 2;
+    if (gpuq_join_table_has_duplicates(t1)) return false;
+    // A's row of every surviving position of B (A's columns are read through it) -- not formed at all when nothing above the inner
+    // join reads a column of A (its keys have done their work in A's table): two scattered accesses per surviving row less
+    bool want_hits = in->out_need_all;
+    for (auto& c : Li.t.cols) want_hits = want_hits || in->out_need.count(c.name) > 0;
+    BufP hits = want_hits ? dev_alloc((size_t)std::max<int64_t>(Ri.t.n, 1) * 4 + 16) : nullptr, rows = dev_alloc(16);
+    gpuq_join_table* t2 = nullptr;
+    check(x, gpuq_join_build_run_semi(bop2, x.stream, &ric.in, 0, Ri.t.n, t1, want_hits ? (uint32_t*)hits->p : nullptr, (uint64_t*)rows->p, &t2));
+    ch.table = t2; ch.deferred = deferred;
+    // the inner join's output_rows: the survivors (booked with the bound and corrected at the settle when nothing is read back)
+    if (deferred) { in->m.output_rows += Ri.t.n; x.fixes.push_back({(const uint64_t*)rows->p, Ri.t.n, &in->m.output_rows, rows}); }
+    else { in->m.output_rows += (int64_t)read_u64(x, rows->p); x.host_syncs += 2; }
+    // the build side as a table: B's rows by position, A's columns through `hits`
+    PTable v; v.n = Ri.t.n; v.count_from(Ri.t); v.own(Ri.t);
+    if (want_hits) {
+      v.own(Li.t); v.keep.push_back(hits);
+      v.via.push_back((const uint32_t*)hits->p);
+      for (auto p : Ri.t.via) v.via.push_back(p);
+      for (size_t i = 0; i < Li.t.cols.size(); ++i) { v.cols.push_back(Li.t.cols[i]); v.sides.push_back(1); }
+      for (size_t i = 0; i < Ri.t.cols.size(); ++i) { v.cols.push_back(Ri.t.cols[i]); v.sides.push_back(Ri.t.sides[i] == 0 ? 0 : Ri.t.sides[i] + 1); }
+    } else { v.via = Ri.t.via; v.cols = Ri.t.cols; v.sides = Ri.t.sides; v.dense = Ri.t.dense; }      // B alone: A's columns are not part of what flows up
+    ch.view = v;
+    return true;
+  }
+  PTable join_sides(Exec& x, Side L, Side R, const bool long_keys, Chain* chain = nullptr) {
     const bool residual = has_filter && join_type != "Inner";
     const std::string jt = residual ? std::string("Inner") : join_type;
     if (residual) {      // rows that fail a side's own predicate are not part of the join at all: apply those first
@@ -1075,7 +1210,7 @@ struct HashJoinExec : PNode {
         on_eff.a[k] = jobj({{"left", jobj({{"column", jobj({{"name", jstr(nm + "l")}})}})}, {"right", jobj({{"column", jobj({{"name", jstr(nm + "r")}})}})}});
       }
     }
-    gpuq_op* bop = cached_op(x, this, long_keys ? 7 : 0, table_sig(L.t), [&]() {
+    gpuq_op* bop = chain ? nullptr : cached_op(x, this, long_keys ? 7 : 0, table_sig(L.t), [&]() {
       const auto ln = names_of(L.t);
       Json lk = jarr();
       for (auto& o : on_eff.a) lk.a.push_back(rebind(o.at("left"), ln));
@@ -1100,19 +1235,24 @@ struct HashJoinExec : PNode {
     // overflow raises the probe's status word.  Only the join types whose output is the pair list itself run this way.
     const bool plain = !long_keys && !residual && !has_filter && (jt == "Inner" || jt == "Right" || jt == "RightSemi" || jt == "RightAnti");
     bool deferred = false;
-    if (plain && x.deferred && last_pairs >= 0 && gpuq_op_can_defer(bop)) deferred = use_deferred(x, bop) && use_deferred(x, pop);
-    if (!deferred) { use_sync(x, bop); use_sync(x, pop); resolve(x, L.t); resolve(x, R.t); }
+    if (chain) deferred = chain->deferred && plain && use_deferred(x, pop);      // (the table is there already: chain_build)
+    else if (plain && x.deferred && last_pairs >= 0 && gpuq_op_can_defer(bop)) deferred = use_deferred(x, bop) && use_deferred(x, pop);
+    if (!deferred) { if (bop) use_sync(x, bop); use_sync(x, pop); resolve(x, L.t); resolve(x, R.t); }
     InputC lic, ric; make_input(L.t, lic); make_input(R.t, ric);
-    gpuq_join_table* jtab = nullptr;
-    check(x, gpuq_join_build_run(bop, x.stream, &lic.in, 0, L.t.n, &jtab));
-    if (!deferred) x.host_syncs += 2;
-    struct Guard { gpuq_join_table* t; ~Guard() { if (t) gpuq_join_table_free(t); } } guard{jtab};
+    gpuq_join_table* jtab = chain ? chain->table : nullptr;
+    if (!chain) {
+      check(x, gpuq_join_build_run(bop, x.stream, &lic.in, 0, L.t.n, &jtab));
+      if (!deferred) x.host_syncs += 2;
+    }
+    struct Guard { gpuq_join_table* t; ~Guard() { if (t) gpuq_join_table_free(t); } } guard{chain ? nullptr : jtab};
     const bool lout = jt == "Left" || jt == "Full";
     const int64_t extra_cap = lout ? L.t.n : 0;
     int64_t cap = std::max<int64_t>(R.t.n, 1) + extra_cap;
     BufP cnt = dev_alloc(16), ob, opb; int64_t k = 0;
     if (deferred) {
-      cap = std::min<int64_t>(cap, last_pairs + last_pairs / 8 + 4096);
+      // (unique build keys: no more pairs than probe rows; duplicate keys can multiply them)
+      cap = gpuq_join_table_has_duplicates(jtab) ? last_pairs + last_pairs / 8 + 4096 : std::min<int64_t>(cap, last_pairs + last_pairs / 8 + 4096);
+      { static const bool trace = getenv("GPUQ_TRACE_DEFER") != nullptr; if (trace) fprintf(stderr, "[gpuq] deferred %s join: build bound %lld, probe bound %lld, pair capacity %lld (last run %lld pairs), dups %d\n", jt.c_str(), (long long)L.t.n, (long long)R.t.n, (long long)cap, (long long)last_pairs, gpuq_join_table_has_duplicates(jtab)); }
       ob = dev_alloc((size_t)cap * 4 + 16); opb = dev_alloc((size_t)cap * 4 + 16);
       const bool pairs = jt == "Inner" || jt == "Right";
       check(x, gpuq_join_probe_run(pop, x.stream, jtab, &ric.in, 0, pairs ? (uint32_t*)ob->p : nullptr, (uint32_t*)opb->p, (uint64_t)cap, (uint64_t*)cnt->p));
@@ -1775,6 +1915,7 @@ int gpuq_plan_create(gpuq_ctx* ctx, const char* plan_json, gpuq_plan** out) {
     std::unique_ptr<gpuq_plan> p(new gpuq_plan());
     p->ctx = ctx;
     p->root = build_node(lower_long_string_eq(JsonParser(plan_json).parse()));
+    p->root->require(nullptr);
     *out = p.release();
   });
 }
@@ -1806,7 +1947,9 @@ static int plan_execute_impl(gpuq_plan* p, void* stream, int partition, const gp
     const bool was_deferred = x.deferred;
     try { run(); }
     catch (const Cancelled&) { drain(); throw; }
-    catch (...) {
+    catch (const std::exception& e) {
+      static const bool trace = getenv("GPUQ_TRACE_DEFER") != nullptr;
+      if (trace && x.deferred) fprintf(stderr, "[gpuq] deferred execution redone synchronously: %s\n", e.what());
       drain();
       if (!x.deferred) throw;
       // a deferred execution that did not hold (or failed in any other way): the same plan again, synchronously -- that run either

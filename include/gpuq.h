@@ -275,6 +275,17 @@ int gpuq_aggregate_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_col
 int gpuq_join_build_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, int64_t build_rows_bound,
                         gpuq_join_table** out);
 void gpuq_join_table_free(gpuq_join_table* t);
+/* Chain fusion for (A |x| B) |x| C when A's keys are unique: the second join's build side is "the rows of B whose key is in A's
+   table".  Instead of probing A with B, materialising the pairs and building from them through an index vector, build the second
+   table straight from B: the operator's descriptor carries "semi_on" (B's key expressions for A, next to "on", B's key expressions
+   for C), every row of `in` (= B) that passes the fused predicate is looked up in semi_table (= A's table, gpuq_join_build_run)
+   and inserted when found -- one pass over B, the build row is B's position (payload_via must be 0).  semi_hits_out (device u32 per
+   row of B, or NULL) receives A's row for every surviving position (A's columns are then read through it as an index vector);
+   rows_out (device u64, or NULL) the number of surviving rows.  GPUQ_ERR_INVALID when semi_table holds duplicate keys
+   (gpuq_join_table_has_duplicates): fall back to the two-step form.  Otherwise as gpuq_join_build_run. */
+int gpuq_join_build_run_semi(gpuq_op* op, void* stream, const gpuq_input* in, int payload_via, int64_t build_rows_bound,
+                             gpuq_join_table* semi_table, uint32_t* semi_hits_out, uint64_t* rows_out, gpuq_join_table** out);
+int gpuq_join_table_has_duplicates(const gpuq_join_table* t);
 /* Probe side.  Emits matching (build_row, probe_row) pairs (probe_row = position or via[..]) into
    out_build/out_probe (capacity out_cap pairs; out_build may be NULL for RightSemi/RightAnti) and the
    total pair count into *count_out (device u64).  Join types follow datafusion.proto:280-289; the

@@ -400,7 +400,7 @@ def test_every_runtime_kernel_source_compiles_for_gfx950():
     r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     ok = [l for l in r.stdout.splitlines() if " OK: " in l]
-    assert len(ok) == 16, r.stdout
+    assert len(ok) == 18, r.stdout
 
 
 def test_parquet_footer_parser_survives_corruption():

@@ -38,11 +38,17 @@ aggr = {"op": "aggregate", "input": {"fields": fields}, "mode": "Single", "group
         "aggr_expr": [{"fn": "SUM", "expr": col("k", fields), "name": "s"}, {"fn": "COUNT", "expr": col("k", fields), "name": "c"}]}
 sort = {"op": "sort", "input": {"fields": fields}, "expr": [{"expr": col("k", fields), "asc": False, "nulls_first": False}, {"expr": col("d", fields), "asc": True, "nulls_first": False}]}
 part = {"op": "partition", "input": {"fields": fields}, "hash_expr": [col("k", fields)], "partition_count": 16}
-jobs = [(filt, 1, ""), (proj, 2, ""), (aggr, 3, ""), (aggr, 4, ""), (aggr, 11, ""), (aggr, 12, ""), (aggr, 13, ""), (sort, 8, ""), (sort, 9, ""), (part, 10, ""), (build, 5, ""), (build, 14, ""), (probe, 15, ""), (probe, 6, ""), (probe, 7, ""), (probe, 7, "#define GPUQ_JIT_PROBE1 1\nconstexpr int JIT_KEY_REG0 = %d;\n")]
+fields3 = fields + [{"name": "k2", "type": "Int64", "nullable": False}]
+build_semi = {"op": "join_build", "input": {"fields": fields3}, "on": [col("k", fields3)], "semi_on": [col("k2", fields3)], "predicate": binary(col("d", fields3), Op.Gt, lit(9204, "Date32"))}
+jobs = [(build_semi, 5, "#define GPUQ_JIT_SEMI 1\n"), (build_semi, 5, "#define GPUQ_JIT_SEMI 2\nconstexpr int JIT_KEY_REG0 = 1;\nconstexpr int JIT_KEY2_REG = 0;\n"), (filt, 1, ""), (proj, 2, ""), (aggr, 3, ""), (aggr, 4, ""), (aggr, 11, ""), (aggr, 12, ""), (aggr, 13, ""), (sort, 8, ""), (sort, 9, ""), (part, 10, ""), (build, 5, ""), (build, 14, ""), (probe, 15, ""), (probe, 6, ""), (probe, 7, ""), (probe, 7, "#define GPUQ_JIT_PROBE1 1\nconstexpr int JIT_KEY_REG0 = %d;\n")]
 with tempfile.TemporaryDirectory() as d:
     for desc, kid, spec in jobs:
         src = g.compile_jit_source(desc, kid)
-        if spec:
+        if spec and "GPUQ_JIT_SEMI" in spec:
+            marker = '}\n#include "kernels_hash.hip"'
+            assert marker in src
+            src = src.replace(marker, spec + marker)
+        elif spec:
             import json, re
             chk = g.binding.compile_check(desc)
             m = re.search(r"key_regs?\D+(\d+)", json.dumps(chk))
@@ -61,4 +67,4 @@ with tempfile.TemporaryDirectory() as d:
         if r.returncode != 0:
             print(r.stderr[-3000:]); sys.exit(1)
         res = [l.split("remark: ")[-1].strip() for l in r.stderr.splitlines() if any(t in l for t in ("Function Name", "VGPRs:", "ScratchSize", "SGPRs:", "Occupancy"))]
-        print("kernel %d%s OK: %s" % (kid, " (PROBE1)" if spec else "", "; ".join(res[-5:])))
+        print("kernel %d%s OK: %s" % (kid, " (SEMI)" if "SEMI" in spec else " (PROBE1)" if spec else "", "; ".join(res[-5:])))
