@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <memory>
 #include <mutex>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,6 +55,7 @@ struct gpuq_op {
   std::deque<PostChunk> posts; Schema post_schema;
   i64 expected_groups = 0;
   i64 last_groups = -1;             // groups of this operator's previous run
+  int last_path = 0;                // ... and the way it took: 1 LDS dictionary, 2 global hash table, 3 radix-partitioned
   // join
   int join_type = JT_INNER; int null_eq = 0; bool build_side_rows = true;
   bool has_semi = false; KeySpec semi_keys{};      // chain fusion: the keys this build's rows are looked up with in another join's table
@@ -62,6 +64,7 @@ struct gpuq_op {
   // partition
   uint32_t nparts = 0;
   // deferred execution (include/gpuq.h): what the last completed synchronous run learned, and what a deferred run may leave behind
+  std::string label;                // descriptor "label": appended to the run-time compiled kernels' names (a plan node id: profiles tell call sites apart)
   bool deferred = false, defer_client = false;
   uint32_t expect_flags = 0;        // status bits a deferred run is allowed to raise (a build side known to hold duplicate keys)
   struct { bool valid = false, dense = false, sparse_bits = false, has_dups = false; i64 kmin = 0; u64 krange = 0; u64 n_slots = 0; } jb;
@@ -202,7 +205,8 @@ struct JitScope {
       auto hit = op->jit_fns.find(fkey);
       if (hit != op->jit_fns.end()) { f = hit->second; if (!f && c->jit_mode == 2) throw std::runtime_error("the run-time source of kernel " + std::to_string(kernel_id) + " failed to compile earlier"); }
       else {
-        try { f = use ? jit_get(cp.jit_src + spec, kernel_id) : jit_try_get(cp.jit_src + spec, kernel_id); }
+        const std::string lab = op->label.empty() ? std::string() : "//@label " + op->label + "\n";
+        try { f = use ? jit_get(cp.jit_src + spec + lab, kernel_id) : jit_try_get(cp.jit_src + spec + lab, kernel_id); }
         catch (...) { op->jit_fns[fkey] = nullptr; throw; }      // a source that does not compile is not compiled again on every call
         if (f) op->jit_fns[fkey] = f;
       }
@@ -572,6 +576,7 @@ int gpuq_ctx_device_info(gpuq_ctx* ctx, char* buf, size_t cap) {
 // ---------------------------------------------------------------- op create
 static void compile_op(gpuq_op* op, const Json& d) {
     const std::string kind = d.at("op").str();
+    for (char c : d.get_str("label", "")) if (std::isalnum((unsigned char)c) || c == '_') op->label += c;
     op->in_schema = schema_from_json(d.at("input"));
     if (kind == "filter") {
       op->kind = K_FILTER;
@@ -1015,7 +1020,11 @@ static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, g
         if (!done && strat == "tiny") throw Capacity("more groups than the LDS aggregate holds; use strategy hash/auto");
       }
     }
-    if (!done && (strat == "radix" || (strat == "auto" && ((n >= (1ll << 22) && op->expected_groups >= (1ll << 20)) ||
+    // (a count that is merely REMEMBERED says nothing about how the keys lie: the run that produced it went through the global table --
+    // e.g. because its keys are clustered, which the table's wave-level run combining turns into one touch per run -- so the same
+    // path is taken again; the partitioned form is for a caller's hint or a sample that saw every group several times)
+    const bool remembered_hash = op->expected_groups <= 0 && op->last_path == 2;
+    if (!done && (strat == "radix" || (strat == "auto" && !remembered_hash && ((n >= (1ll << 22) && op->expected_groups >= (1ll << 20)) ||
                                                             (n >= (1ll << 20) && known_groups >= 4096))))) {
       // High cardinality: partition the rows by key hash into buckets whose groups fit an LDS table, aggregate every bucket
       // inside one block (kernels_hash.hip).  Falls through to the global table when a bucket overflows (skew, or more
@@ -1052,7 +1061,7 @@ static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, g
         uint32_t fw[4] = {0, 0, 0, 0};
         read_status(op, s, fw, 4);
         if (fw[0] & ~(FLAG_TABLE_FULL | FLAG_GROUP_OVERFLOW)) { reset_flags(op, s); raise_flags(fw[0] & ~(FLAG_TABLE_FULL | FLAG_GROUP_OVERFLOW)); }
-        if (!(fw[0] & (FLAG_TABLE_FULL | FLAG_GROUP_OVERFLOW))) { ng = fw[2]; done = true; }
+        if (!(fw[0] & (FLAG_TABLE_FULL | FLAG_GROUP_OVERFLOW))) { ng = fw[2]; done = true; path_done = 3; }
         else if (strat == "radix" && op->expected_groups > 0 && est < (u64)n) throw Capacity("radix aggregate: a bucket overflowed; raise expected_groups or use strategy hash/auto");
         else reset_flags(op, s);
       } else if (strat == "radix") throw Unsupported("radix aggregate: the group state does not fit an LDS table");
@@ -1137,7 +1146,8 @@ static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, g
       }
     }
     op->last_groups = (i64)ng;
-    if (path_done) { op->ag.valid = true; op->ag.path = path_done; op->ag.gmax = gmax_done; op->ag.est = est_done; op->ag.use_lds = lds_done; op->ag.groups = (i64)ng; op->expect_flags = 0; }
+    op->last_path = path_done;
+    if (path_done == 1 || path_done == 2) { op->ag.valid = true; op->ag.path = path_done; op->ag.gmax = gmax_done; op->ag.est = est_done; op->ag.use_lds = lds_done; op->ag.groups = (i64)ng; op->expect_flags = 0; }
     if (n_groups_out) *n_groups_out = ng;
     if ((i64)ng > cap) throw Capacity("aggregate produced " + std::to_string(ng) + " groups, output capacity is " + std::to_string(cap));
     for (int i = 0; i < n_outs; ++i) outs[i].length = ng;

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <cctype>
 #include <cerrno>
 #include <cstdio>
 #include <chrono>
@@ -95,8 +96,20 @@ static const char* jit_entry_name(int kernel_id) {
   return (kernel_id >= 1 && kernel_id <= 15) ? n[kernel_id] : n[0];
 }
 
+// "//@label xyz" anywhere in the front-end source (an operator's descriptor "label": a plan node id) is appended to the entry point's name:
+// two call sites of one sink kernel -- the two probes of q3 -- then show up as two kernels in a profile
+static std::string entry_name(const std::string& eval_src, int kernel_id) {
+  std::string n = jit_entry_name(kernel_id);
+  const size_t p = eval_src.find("//@label ");
+  if (p != std::string::npos) {
+    std::string l;
+    for (size_t i = p + 9; i < eval_src.size() && (std::isalnum((unsigned char)eval_src[i]) || eval_src[i] == '_') && l.size() < 32; ++i) l += eval_src[i];
+    if (!l.empty()) n += "_" + l;
+  }
+  return n;
+}
 std::string jit_full_source(const std::string& eval_src, int kernel_id) {
-  return env_defines() + "#define gpuq_jit_entry " + jit_entry_name(kernel_id) + "\n#define GPUQ_JIT 1\n#define GPUQ_JIT_KERNEL " + std::to_string(kernel_id) +
+  return env_defines() + "#define gpuq_jit_entry " + entry_name(eval_src, kernel_id) + "\n#define GPUQ_JIT 1\n#define GPUQ_JIT_KERNEL " + std::to_string(kernel_id) +
          "\n#include \"gpuq_kernels.h\"\nnamespace gpuq {\n" + eval_src + "}\n#include \"" + file_of(kernel_id) + "\"\n";
 }
 
@@ -184,7 +197,7 @@ static JitFn compile_and_load(const std::string& eval_src, int kernel_id) {
     return compile_and_load(eval_src, kernel_id);
   }
   if (e != hipSuccess) throw std::runtime_error(std::string("jit: hipModuleLoadData: ") + hipGetErrorString(e));
-  e = hipModuleGetFunction(&fn, mod, jit_entry_name(kernel_id));
+  e = hipModuleGetFunction(&fn, mod, entry_name(eval_src, kernel_id).c_str());
   if (e != hipSuccess) { (void)hipModuleUnload(mod); throw std::runtime_error(std::string("jit: hipModuleGetFunction: ") + hipGetErrorString(e)); }
   if (!from_disk && !cpath.empty()) cache_write(cpath, code);
   { std::lock_guard<std::mutex> lk(g_mu); if (from_disk) ++g_disk_hits; else ++g_compiles; }

@@ -198,6 +198,9 @@ struct Exec {
 };
 struct Cancelled : std::runtime_error { using std::runtime_error::runtime_error; };
 struct DeferredRetry : std::runtime_error { using std::runtime_error::runtime_error; };      // an assumption of a deferred run did not hold: the plan runs again, synchronously
+// ... and every rank of the node already knows (it came out of a collective, or was announced to the peers): not to be announced again
+struct AgreedRetry : DeferredRetry { using DeferredRetry::DeferredRetry; };
+struct AgreedFailure : std::runtime_error { int rc; AgreedFailure(const std::string& m, int rc_ = GPUQ_ERR_PEER) : std::runtime_error(m), rc(rc_) {} };
 inline void check_cancel(const Exec& x) { if (x.cancel && x.cancel->load(std::memory_order_relaxed)) throw Cancelled("task cancelled"); }
 
 void check(Exec& x, int rc) {
@@ -671,7 +674,8 @@ PTable merge_table(Exec& x, const PTable& t_in, const std::vector<int64_t>& run_
 // ---------------------------------------------------------------- plan nodes
 struct Metrics { int64_t output_rows = 0, elapsed_ns = 0; };
 struct PNode {
-  std::string kind; Metrics m;
+  std::string kind; Metrics m; int id = 0;      // id: position in the plan, pre-order (labels the node's run-time compiled kernels)
+  std::string label(const char* what) const { return std::string(what) + "_n" + std::to_string(id); }
   virtual ~PNode() {}
   virtual std::vector<PNode*> children() { return {}; }
   virtual int partitions() { auto c = children(); return c.empty() ? 1 : c[0]->partitions(); }
@@ -1139,7 +1143,7 @@ struct HashJoinExec : PNode {
       const auto ln = names_of(Li.t);
       Json lk = jarr(); for (auto& o : in->on.a) lk.a.push_back(rebind(o.at("left"), ln));
       std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(Li.t)}})}, {"on", lk}, {"null_equals_null", jbool(false)},
-                                                     {"build_side_rows", jbool(false)}};
+                                                     {"build_side_rows", jbool(false)}, {"label", jstr(in->label("build"))}};
       if (Li.has_pred) bd.push_back({"predicate", rebind(Li.pred, ln)});
       return jobj(bd);
     });
@@ -1150,7 +1154,7 @@ struct HashJoinExec : PNode {
       for (auto& o : on.a) lk.a.push_back(rebind(o.at("left"), rn));
       for (auto& o : in->on.a) sk.a.push_back(rebind(o.at("right"), rn));
       std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(Ri.t)}})}, {"on", lk}, {"semi_on", sk},
-                                                     {"null_equals_null", jbool(false)}, {"build_side_rows", jbool(false)}};
+                                                     {"null_equals_null", jbool(false)}, {"build_side_rows", jbool(false)}, {"label", jstr(label("chain_build"))}};
       if (Ri.has_pred) bd.push_back({"predicate", rebind(Ri.pred, rn)});
       return jobj(bd);
     });
@@ -1217,7 +1221,7 @@ struct HashJoinExec : PNode {
       // only Left / Full / LeftSemi / LeftAnti ask the table for its build side's rows afterwards
       const bool side_rows = jt == "Left" || jt == "Full" || jt == "LeftSemi" || jt == "LeftAnti";
       std::vector<std::pair<std::string, Json>> bd = {{"op", jstr("join_build")}, {"input", jobj({{"fields", table_fields(L.t)}})}, {"on", lk}, {"null_equals_null", jbool(null_equals_null)},
-                                                     {"build_side_rows", jbool(side_rows)}};
+                                                     {"build_side_rows", jbool(side_rows)}, {"label", jstr(label("build"))}};
       if (L.has_pred) bd.push_back({"predicate", rebind(L.pred, ln)});
       return jobj(bd);
     });
@@ -1226,7 +1230,7 @@ struct HashJoinExec : PNode {
       Json rk = jarr();
       for (auto& o : on_eff.a) rk.a.push_back(rebind(o.at("right"), rn));
       std::vector<std::pair<std::string, Json>> pd = {{"op", jstr("join_probe")}, {"input", jobj({{"fields", table_fields(R.t)}})}, {"on", rk}, {"join_type", jstr(jt)},
-                                                     {"null_equals_null", jbool(null_equals_null)}};
+                                                     {"null_equals_null", jbool(null_equals_null)}, {"label", jstr(label("probe"))}};
       if (R.has_pred) pd.push_back({"predicate", rebind(R.pred, rn)});
       return jobj(pd);
     });
@@ -1714,12 +1718,29 @@ struct ShuffleReaderExec : PNode {
 //     sent here (RepartitionExecNode, datafusion.proto; the planner splits stages at exactly this node, planner.rs:137-151);
 //   BroadcastExec {input}: every rank receives all ranks' rows -- a CollectLeft build side whose reduce task reads every
 //     partition of the build stage (shuffle_reader.rs: all locations of the stage).
+// What comes out of a collective call is the same on every rank (or the communicator is gone): nothing is left to announce.
 void xcheck(int rc) {
   if (rc == GPUQ_OK) return;
   const std::string msg = gpuq_exchange_last_error();
-  if (rc == GPUQ_ERR_UNSUPPORTED) throw Unsupported(msg);
-  if (rc == GPUQ_ERR_HIP) throw HipError(msg);
-  throw std::runtime_error(msg);
+  if (rc == GPUQ_ERR_RETRY) throw AgreedRetry(msg);
+  throw AgreedFailure(msg, rc);
+}
+// The part of an exchange node that runs BEFORE its collective (the child plan, the grouping by destination): when it fails, the
+// peers are -- or will be -- waiting in that collective's meta round.  They are told (status 1: failed; 2 while executing
+// deferred: "everybody runs again, synchronously") through the same fixed-size round, and only then does the failure travel up.
+template <class F> auto announce_failures(Exec& x, F&& local_part) -> decltype(local_part()) {
+  try { return local_part(); }
+  catch (const AgreedRetry&) { throw; }
+  catch (const AgreedFailure&) { throw; }
+  catch (const Cancelled&) { throw; }
+  catch (const std::exception& e) {
+    (void)gpuq_comm_set_status(x.comm, x.deferred ? 2 : 1);
+    (void)gpuq_comm_announce(x.comm, x.stream);
+    if (x.deferred) throw AgreedRetry(e.what());
+    int rc = GPUQ_ERR_INVALID;
+    if (dynamic_cast<const Unsupported*>(&e)) rc = GPUQ_ERR_UNSUPPORTED; else if (dynamic_cast<const Capacity*>(&e)) rc = GPUQ_ERR_CAPACITY; else if (dynamic_cast<const HipError*>(&e)) rc = GPUQ_ERR_HIP;
+    throw AgreedFailure(e.what(), rc);
+  }
 }
 void table_c_arrays(const PTable& t, std::vector<gpuq_column>& cols, std::vector<gpuq_field_info>& fields) {
   cols.clear(); fields.clear();
@@ -1748,10 +1769,14 @@ struct RepartitionExec : PNode {
     if (!x.comm) throw Unsupported("RepartitionExec inside a stage needs the ranks of the node (gpuq_plan_set_comm); without them the reference's planner splits the stage here");
     const int W = gpuq_comm_world(x.comm);
     if (partition_count != W) throw Unsupported("RepartitionExec: partition_count " + std::to_string(partition_count) + " != number of ranks " + std::to_string(W));
+    std::chrono::steady_clock::time_point t0;
+    PSchema ps; PTable grouped; std::vector<int64_t> doff;
+    std::vector<gpuq_column> cols; std::vector<gpuq_field_info> fields;
+    announce_failures(x, [&]() {
     PTable t = input->execute(part, x);
-    resolve(x, t);
-    auto t0 = std::chrono::steady_clock::now();
-    PSchema ps = plain_schema(t);
+    resolve(x, t);      // (a settle: everything deferred below this exchange is looked at before a row leaves the rank)
+    t0 = std::chrono::steady_clock::now();
+    ps = plain_schema(t);
     std::vector<std::string> names; for (auto& f : ps) names.push_back(f.name);
     gpuq_op* op = cached_op(x, this, 0, table_sig(t), [&]() {
       Json he = jarr(); for (auto& e : hash_expr.a) he.a.push_back(rebind(e, names));
@@ -1763,13 +1788,16 @@ struct RepartitionExec : PNode {
     std::vector<uint64_t> o((size_t)partition_count + 1);
     HIPCHECK(hipMemcpyAsync(o.data(), offs->p, o.size() * 8, hipMemcpyDeviceToHost, (hipStream_t)x.stream));
     HIPCHECK(hipStreamSynchronize((hipStream_t)x.stream));
+    ++x.host_syncs;
     // one take groups the rows by destination rank
-    PTable grouped = materialize(x, select_view(x, t, (const uint32_t*)perm->p, t.n, perm));
-    std::vector<gpuq_column> cols; std::vector<gpuq_field_info> fields;
+    grouped = materialize(x, select_view(x, t, (const uint32_t*)perm->p, t.n, perm));
+    resolve(x, grouped);
     table_c_arrays(grouped, cols, fields);
     // a column read through an index vector may carry NULLs: nullability as the plan sees it (identical on every rank)
     for (size_t i = 0; i < fields.size(); ++i) fields[i].nullable = ps[i].nullable ? 1 : 0;
-    std::vector<int64_t> doff(o.begin(), o.end());
+    doff.assign(o.begin(), o.end());
+    return 0;
+    });
     gpuq_table* tab = nullptr;
     xcheck(gpuq_exchange_partitions(x.comm, x.stream, cols.data(), fields.data(), (int)cols.size(), doff.data(), &tab));
     PTable out = table_from_owned(tab, grouped);
@@ -1783,14 +1811,20 @@ struct BroadcastExec : PNode {
   int partitions() override { return input->partitions(); }
   PTable execute(int part, Exec& x) override {
     if (!x.comm) throw Unsupported("BroadcastExec needs the ranks of the node (gpuq_plan_set_comm)");
+    std::chrono::steady_clock::time_point t0;
+    PSchema ps; PTable plain;
+    std::vector<gpuq_column> cols; std::vector<gpuq_field_info> fields;
+    announce_failures(x, [&]() {
     PTable t = input->execute(part, x);
     resolve(x, t);
-    auto t0 = std::chrono::steady_clock::now();
-    PSchema ps = plain_schema(t);
-    PTable plain = materialize(x, t);
-    std::vector<gpuq_column> cols; std::vector<gpuq_field_info> fields;
+    t0 = std::chrono::steady_clock::now();
+    ps = plain_schema(t);
+    plain = materialize(x, t);
+    resolve(x, plain);
     table_c_arrays(plain, cols, fields);
     for (size_t i = 0; i < fields.size(); ++i) fields[i].nullable = ps[i].nullable ? 1 : 0;
+    return 0;
+    });
     gpuq_table* tab = nullptr;
     xcheck(gpuq_allgather_table(x.comm, x.stream, cols.data(), fields.data(), (int)cols.size(), plain.n, &tab));
     PTable out = table_from_owned(tab, plain);
@@ -1893,6 +1927,7 @@ namespace {
 template <class F> int plan_guarded(F&& f) {
   try { f(); return GPUQ_OK; }
   catch (const Cancelled& e) { g_plan_error = e.what(); return GPUQ_ERR_CANCELLED; }
+  catch (const AgreedFailure& e) { g_plan_error = e.what(); return e.rc; }
   catch (const HipError& e) { g_plan_error = e.what(); return GPUQ_ERR_HIP; }
   catch (const Unsupported& e) { g_plan_error = e.what(); return GPUQ_ERR_UNSUPPORTED; }
   catch (const Capacity& e) { g_plan_error = e.what(); return GPUQ_ERR_CAPACITY; }
@@ -1916,6 +1951,9 @@ int gpuq_plan_create(gpuq_ctx* ctx, const char* plan_json, gpuq_plan** out) {
     p->ctx = ctx;
     p->root = build_node(lower_long_string_eq(JsonParser(plan_json).parse()));
     p->root->require(nullptr);
+    int next_id = 0;
+    std::function<void(PNode*)> number = [&](PNode* n) { n->id = next_id++; for (PNode* c : n->children()) number(c); };
+    number(p->root.get());
     *out = p.release();
   });
 }
@@ -1933,9 +1971,14 @@ static int plan_execute_impl(gpuq_plan* p, void* stream, int partition, const gp
     Exec x; x.ctx = p->ctx; x.stream = stream; x.ops = &p->ops; x.inputs = inputs; x.n_inputs = n_inputs; x.pin = p->pin; x.memo = &p->memo; x.comm = p->comm; x.cancel = cancel;
     static const bool defer_env = []() { const char* e = getenv("GPUQ_DEFER"); return !(e && e[0] == '0'); }();
     // a plan with exchanges inside runs synchronously: a rank that had to redo a deferred execution would re-enter the collectives alone
-    x.deferred = defer_env && p->defer_ok && p->completed > 0 && !p->comm;
+    // With the ranks of a node attached, "redo it synchronously" is a decision all ranks take together: it travels in the status word of
+    // the exchanges' meta rounds (gpuq_comm_set_status: 2) and a deferred execution ends with one such round that says "nobody has to".
+    x.deferred = defer_env && p->defer_ok && p->completed > 0;
     PTable t;
-    auto run = [&]() { t = materialize(x, p->root->execute(partition, x)); check_cancel(x); settle(x, &t); };
+    auto run = [&]() {
+      t = materialize(x, p->root->execute(partition, x)); check_cancel(x); settle(x, &t);
+      if (x.comm && x.deferred) xcheck(gpuq_comm_announce(x.comm, x.stream));
+    };
     auto drain = [&]() {
       // whatever was queued keeps running: drain it before the buffers it uses go back to the pool (unwinding frees them); status
       // words deferred runs may have raised are cleared with it
@@ -1952,6 +1995,11 @@ static int plan_execute_impl(gpuq_plan* p, void* stream, int partition, const gp
       if (trace && x.deferred) fprintf(stderr, "[gpuq] deferred execution redone synchronously: %s\n", e.what());
       drain();
       if (!x.deferred) throw;
+      // the peers are waiting in (or heading for) a collective: tell them this rank starts over, unless they already know
+      if (x.comm && !dynamic_cast<const AgreedRetry*>(&e)) {
+        if (dynamic_cast<const AgreedFailure*>(&e)) throw;      // (a failed collective: every rank has the error, nobody starts over)
+        (void)gpuq_comm_set_status(x.comm, 2); (void)gpuq_comm_announce(x.comm, x.stream);
+      }
       // a deferred execution that did not hold (or failed in any other way): the same plan again, synchronously -- that run either
       // succeeds and refreshes what the operators remember, or raises the error with its proper message
       if (++p->retries >= 3) p->defer_ok = false;

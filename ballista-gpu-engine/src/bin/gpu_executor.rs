@@ -7,9 +7,17 @@ use std::sync::Arc;
 use ballista_executor::executor_process::{start_executor_process, ExecutorProcessConfig};
 use ballista_gpu_engine::GpuExecutionEngine;
 
-// The option struct and its parsing are the stock binary's (generated by configure_me from executor_config_spec.toml);
-// a GPU build includes the same generated module.
-include!(concat!(env!("OUT_DIR"), "/executor_configure_me_config.rs"));
+// The option struct and its parsing are the stock binary's: this crate's build.rs runs configure_me_codegen over the SAME
+// executor_config_spec.toml ([package.metadata.configure_me.bin] executor = ... in Cargo.toml), which writes
+// OUT_DIR/executor_configure_me_config.rs for THIS crate (ballista/executor/src/bin/main.rs:30-35 includes its own copy the same way).
+#[macro_use]
+extern crate configure_me;
+
+#[allow(clippy::all, warnings)]
+mod config {
+    include!(concat!(env!("OUT_DIR"), "/executor_configure_me_config.rs"));
+}
+use config::prelude::*;
 
 #[tokio::main]
 async fn main() -> anyhow::Result<()> {
@@ -39,5 +47,9 @@ async fn main() -> anyhow::Result<()> {
         execution_engine: Some(Arc::new(engine)),          // <- the one change
         replication_url: opt.replication_url,
     };
-    start_executor_process(config).await
+    let r = start_executor_process(config).await;
+    // background specialisations may still be inside hiprtc: let them finish before the process' static destructors run
+    // (include/gpuq.h gpuq_jit_quiesce; DESIGN.md section 7 "Exit order")
+    ballista_gpu_engine::quiesce();
+    r
 }

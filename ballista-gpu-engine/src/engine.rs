@@ -28,8 +28,13 @@ struct Ctx(*mut gpuq_ctx);
 unsafe impl Send for Ctx {}
 unsafe impl Sync for Ctx {}
 impl Drop for Ctx {
-    fn drop(&mut self) { unsafe { gpuq_ctx_free(self.0) } }
+    // background specialisations may still be inside hiprtc: they finish before the context (and, at process exit, the library's
+    // statics) go away (include/gpuq.h gpuq_jit_quiesce)
+    fn drop(&mut self) { unsafe { gpuq_jit_quiesce(); gpuq_ctx_free(self.0) } }
 }
+
+/// Waits for the library's background compiles; a custom `main` calls it before it returns (bin/gpu_executor.rs).
+pub fn quiesce() { unsafe { gpuq_jit_quiesce() } }
 
 pub struct GpuExecutionEngine {
     ctx: Arc<Ctx>,
@@ -81,6 +86,7 @@ impl ExecutionEngine for GpuExecutionEngine {
             sender,
             metrics: ExecutionPlanMetricsSet::new(),
             display: format!("GpuQueryStageExec: job={job_id} stage={stage_id}"),
+            job_id,
         }))
     }
 }
@@ -100,6 +106,7 @@ pub struct GpuQueryStageExec {
     sender: Option<mpsc::Sender<replicator::Command>>,
     metrics: ExecutionPlanMetricsSet,
     display: String,
+    job_id: String,                   // replicator::Command::Replicate carries it (shuffle_writer.rs:429-447)
 }
 
 impl Debug for GpuQueryStageExec {
@@ -158,20 +165,22 @@ impl QueryStageExecutor for GpuQueryStageExec {
         for (leaf, part) in &self.walked.host_leaves {
             imported.0.push(self.import_leaf(leaf, *part, context.clone()).await?);
         }
-        let mut cols: Vec<Vec<gpuq_column>> = vec![];
-        let mut inputs: Vec<gpuq_input> = vec![];
-        for t in &imported.0 {
-            let nc = unsafe { gpuq_table_num_columns(*t) };
-            let mut v = vec![unsafe { std::mem::zeroed::<gpuq_column>() }; nc as usize];
-            for i in 0..nc { unsafe { gpuq_table_column(*t, i, &mut v[i as usize], std::ptr::null_mut()) }; }
-            cols.push(v);
-        }
-        for (t, v) in imported.0.iter().zip(cols.iter()) {
-            inputs.push(gpuq_input { cols: v.as_ptr(), n_cols: v.len() as i32, n_via: 0, n_rows: unsafe { gpuq_table_num_rows(*t) }, via: [std::ptr::null(); 3], n_rows_dev: std::ptr::null() });
-        }
         // 2. start the plan on the library's worker thread; await it without blocking the task-runner's worker
-        //    (cpu_bound_executor.rs:94-131: blocking in poll stalls a worker)
+        //    (cpu_bound_executor.rs:94-131: blocking in poll stalls a worker).  The column / input arrays hold raw pointers (!Send):
+        //    they live in this block only -- gpuq_plan_execute_async copies them -- so that nothing !Send is held across an await
+        //    (QueryStageExecutor is #[async_trait]: its future must be Send).
         let task = {
+            let mut cols: Vec<Vec<gpuq_column>> = vec![];
+            let mut inputs: Vec<gpuq_input> = vec![];
+            for t in &imported.0 {
+                let nc = unsafe { gpuq_table_num_columns(*t) };
+                let mut v = vec![unsafe { std::mem::zeroed::<gpuq_column>() }; nc as usize];
+                for i in 0..nc { unsafe { gpuq_table_column(*t, i, &mut v[i as usize], std::ptr::null_mut()) }; }
+                cols.push(v);
+            }
+            for (t, v) in imported.0.iter().zip(cols.iter()) {
+                inputs.push(gpuq_input { cols: v.as_ptr(), n_cols: v.len() as i32, n_via: 0, n_rows: unsafe { gpuq_table_num_rows(*t) }, via: [std::ptr::null(); 3], n_rows_dev: std::ptr::null() });
+            }
             let plan = self.plan.lock().unwrap();
             let mut t: *mut gpuq_task = std::ptr::null_mut();
             let rc = unsafe { gpuq_plan_execute_async(plan.0, std::ptr::null_mut::<c_void>(), 0, inputs.as_ptr(), inputs.len() as i32, &mut t) };
@@ -184,16 +193,20 @@ impl QueryStageExecutor for GpuQueryStageExec {
             if done != 0 { break; }
             tokio::time::sleep(std::time::Duration::from_micros(200)).await;      // an await point: dropping the future here cancels (TaskGuard::drop)
         }
-        let mut res: *mut gpuq_result = std::ptr::null_mut();
-        let rc = unsafe { gpuq_task_wait(task.0, &mut res) };
-        if rc != GPUQ_OK {
-            let why = plan_error();
-            // "FetchFailed: ..." must reach the scheduler as such: it re-runs the map stage (shuffle_reader.rs:654)
-            return Err(if why.starts_with("FetchFailed") { DataFusionError::Execution(why) } else { DataFusionError::Execution(format!("gpuq: {why}")) });
-        }
-        // 3. the result batch (partition, path, num_rows, num_batches, num_bytes) -> Vec<ShuffleWritePartition>
-        let batch = export_result(self.ctx.0, res)?;
-        unsafe { gpuq_result_free(res) };
+        // 3. the result batch (partition, path, num_rows, num_batches, num_bytes) -> Vec<ShuffleWritePartition>; the raw result
+        //    pointer is converted and freed here, before the next await (sender.send below)
+        let batch = {
+            let mut res: *mut gpuq_result = std::ptr::null_mut();
+            let rc = unsafe { gpuq_task_wait(task.0, &mut res) };
+            if rc != GPUQ_OK {
+                let why = plan_error();
+                // "FetchFailed: ..." must reach the scheduler as such: it re-runs the map stage (shuffle_reader.rs:654)
+                return Err(if why.starts_with("FetchFailed") { DataFusionError::Execution(why) } else { DataFusionError::Execution(format!("gpuq: {why}")) });
+            }
+            let b = export_result(self.ctx.0, res);
+            unsafe { gpuq_result_free(res) };
+            b?
+        };
         let part = batch.column(0).as_any().downcast_ref::<UInt32Array>().unwrap();
         let path = batch.column(1).as_any().downcast_ref::<StringArray>().unwrap();
         let rows = batch.column(2).as_any().downcast_ref::<UInt64Array>().unwrap();
@@ -211,7 +224,7 @@ impl QueryStageExecutor for GpuQueryStageExec {
             });
             if rows.value(i) > 0 {
                 if let Some(sender) = self.sender.as_ref() {      // replication hand-off, shuffle_writer.rs:429-447
-                    let cmd = replicator::Command::Replicate { job_id: String::new(), path: path.value(i).to_string(), created: std::time::Instant::now() };
+                    let cmd = replicator::Command::Replicate { job_id: self.job_id.clone(), path: path.value(i).to_string(), created: std::time::Instant::now() };
                     let _ = sender.send(cmd).await;
                 }
             }

@@ -11,4 +11,4 @@ pub mod engine;
 pub mod ffi;
 pub mod plan_walk;
 
-pub use engine::{GpuExecutionEngine, GpuQueryStageExec};
+pub use engine::{quiesce, GpuExecutionEngine, GpuQueryStageExec};

@@ -12,9 +12,11 @@ benchmarks/src/bin/tpch.rs:286-351) over synthetic TPC-H-shaped tables resident 
 value = lineitem rows through the query per second.
 roofline: the hash-join probe of lineitem (the operator with the most kernel time); algorithmic bytes = SURVEY.md section 8d's
 24 B per probe row + 12 B per emitted pair x the counts measured on this input; duration = HIP events around the probe
-operator's kernels on the stream they run on.
-cpu_baseline: the C oracle's q3 ("port", OpenMP over all host cores) on an SF10 sample of the same generator.
-"extra": the join-probe micro-grid (2^28 probes x {2^20, 2^24, 2^27} build keys) and SF100 q1 / q5 wall times.
+operator's kernels on the stream they run on.  "host": how the steps ran (deferred: one host round trip per step).
+"check": the SF100 result against an independent torch computation over the same columns (sum of revenue, number of groups).
+cpu_baseline: the C oracle's q3 ("port", OpenMP over all host cores) on an SF10 sample of the same generator, min and mean of 3, with
+q1 and q5 and a pyarrow Acero proxy beside it.
+"extra": the join-probe micro-grid (2^28 probes x {2^20, 2^24, 2^27} build keys x hit rates x uniform / Zipf) and SF100 q1 / q5 wall times.
 
 Workload at N>1 (strong scaling: the job stays SF100, every rank holds 1/N of each table): ONE native plan per rank with the
 exchanges inside (csrc/plan_exec.cpp RepartitionExec / BroadcastExec over csrc/exchange.cpp).  The headline plan is the one a
@@ -35,7 +37,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
 
@@ -58,7 +59,7 @@ def main_q3():
 
     import torch
     import torch.distributed as dist
-    import tpch_util as T
+    from benchmarks import tpch as T
     import arrow_ballista_amd as g
     from arrow_ballista_amd import parallel
 
@@ -116,7 +117,7 @@ def main_q3():
     if world == 1:
         plan = g.NativePlan(T.q3_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li])), tc)
     else:
-        plan = g.NativePlan(T.q3_dist_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), world, "broadcast"), tc)
+        plan = g.NativePlan(T.q3_dist_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), world, "partitioned"), tc)
         plan.set_comm(comm)
 
     fence()
@@ -137,6 +138,7 @@ def main_q3():
     dt, res = timed_steps(lambda: plan.execute(0), args.steps)
     ops = plan.profile_all()
     plan.profile(False)
+    host = plan.exec_stats()
     groups = res.num_rows
 
     # measured counts of the lineitem probe on this input (outside the timed region): rows that pass the fused filter = probes
@@ -153,50 +155,72 @@ def main_q3():
                                   "%d ranks x 1/%d of every table: customer keys and the joined orders broadcast over RCCL (grouped send/recv per column buffer), lineitem stays in place, "
                                   "join + partial aggregate per rank, partial states repartitioned on the group key, final aggregate, sorted runs gathered and merged" % (world, world)),
                    "lineitem_rows": rows_job, "lineitem_rows_per_gpu": n_li, "orders_rows_per_gpu": n_orders, "customer_rows_per_gpu": n_cust, "result_groups": groups,
-                   "input": "Arrow-physical columns resident in HBM", "first_run_ms_cold_jit": first_ms,
+                   "input": "Arrow-physical columns resident in HBM", "first_run_ms_cold_jit": first_ms, "aggregate_strategy": "auto",
                    "parallelism": "single partition" if world == 1 else "partition-per-gpu x%d, exchange inside the native plan (%s)" % (world, comm.transport)},
     }
+    # host side of a step: deferred = no operator read anything back (counts travel as device words, operators keep what their first run
+    # learned); settles = host round trips per step (one: the plan's end), host_syncs = read-backs of operators that ran synchronously
+    line["host"] = {"deferred": host["deferred"], "round_trips_per_step": host["settles"] + host["host_syncs"], "settles": host["settles"],
+                    "operator_read_backs": host["host_syncs"], "deferred_runs_redone": host["retries"]}
     probe_ops = sorted((o for o in ops if o["op"] == "join_probe"), key=lambda o: -o["kernel_ms"])
     if probe_ops and probe_ops[0]["launches"] > 0:
         po = probe_ops[0]
         avg_ms = po["kernel_ms"] / po["launches"]
         alg = (Q3_PROBE_KEY_BYTES + Q3_SLOT_BYTES) * probes + Q3_PAIR_BYTES * matches
         achieved = alg / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if sf == 100 and world == 1 and os.path.exists(tp):
-            traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
+        # traffic: HBM bytes per launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) of an EARLIER run of this
+        # command, read from profiles/ -- counters cannot be collected inside this process; traffic_source says which file
+        traffic, traffic_source = None, None
+        for name in ("r03_traffic.json", "r02_traffic.json"):
+            tp = os.path.join(ROOT, "profiles", name)
+            if sf == 100 and world == 1 and os.path.exists(tp):
+                traffic, traffic_source = json.load(open(tp)).get("traffic_bytes_per_launch"), "profiles/" + name + " (PMC passes of an earlier run of this command, not this run)"
+                break
+        import re
+        lab = re.search(r'"label":"(\w+)"', po.get("desc", ""))
         line["roofline"] = {"bound": "hbm", "kernel": "HashJoinExec probe of lineitem (fused filter l_shipdate > date + key lookup + pair emit; rank 0's launch)",
-                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                            "kernel_name": "gpuq_jit_join_probe_unique" + ("_" + lab.group(1) if lab else ""),
+                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                             "avg_launch_ms": avg_ms, "launches": po["launches"], "algorithmic_bytes_per_launch": alg,
                             "probe_rows": probes, "matches": matches, "rows_scanned": n_li,
-                            "probe_rows_per_s": probes / (avg_ms * 1e-3), "rows_scanned_per_s": n_li / (avg_ms * 1e-3),
-                            "achieved_incl_fused_filter_column": (alg + 4 * n_li + Q3_PROBE_KEY_BYTES * (n_li - probes)) / (avg_ms * 1e-3) / 1e9}
-    line["operators"] = [{"op": o["op"], "kernel_ms_per_step": o["kernel_ms"] / max(1, args.steps), "launches": o["launches"]} for o in sorted(ops, key=lambda o: -o["kernel_ms"])[:8]]
+                            "probe_rows_per_s": probes / (avg_ms * 1e-3), "rows_scanned_per_s": n_li / (avg_ms * 1e-3)}
+    # the dominant kernel of every operator the plan compiled (HIP events around it); the smaller launches around them (scans of segment
+    # counts, table initialisation, the aggregate's extract / emit) are inside ms_per_step, not in this list
+    import re as _re
+    def _lab(o):
+        m = _re.search(r'"label":"(\w+)"', o.get("desc", ""))
+        return m.group(1) if m else None
+    line["operators"] = [{"op": o["op"], "label": _lab(o), "kernel_ms_per_step": o["kernel_ms"] / max(1, args.steps), "launches": o["launches"]}
+                         for o in sorted(ops, key=lambda o: -o["kernel_ms"]) if o["launches"] > 0]
+    line["operators_ms_per_step"] = sum(o["kernel_ms_per_step"] for o in line["operators"])
+    if world == 1:
+        line["check"] = check_q3_result(torch, T, tc, res, li, od, cu)
     del plan, res
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_q3(T, args.cpu_sample_sf)
+        line["cpu_baseline"] = cpu_baseline(args.cpu_sample_sf)
     if not args.no_extras:
         import bench_extras
         if world == 1:
             del li, od, cu
             torch.cuda.empty_cache()
-            extra = {"join_probe": [bench_extras.join_probe_micro(tc, g, b, 28, 1.0) for b in (20, 24, 27)]}
+            # SURVEY.md section 8d grid: |B| in {2^20, 2^24, 2^27} x hit rate {1.0, 0.5, 0.1} uniform, and Zipf(1.05) probe keys
+            extra = {"join_probe": [bench_extras.join_probe_micro(tc, g, b, 28, h) for b in (20, 24, 27) for h in (1.0, 0.5, 0.1)]
+                                   + [bench_extras.join_probe_micro(tc, g, b, 28, 1.0, zipf=1.05) for b in (20, 24, 27)]}
             torch.cuda.empty_cache()
             extra["sf100_q1"] = bench_extras.q1_pipeline(tc, T, g, 100)
             tp = bench_extras.tpch_pipelines(tc, T, g, 100)
             extra["sf100_q3"], extra["sf100_q5"] = tp["q3"], tp["q5"]
         else:
-            # second legs, every rank takes part: q3 with BOTH sides of orders |x| lineitem repartitioned (the BASELINE configs[3]
-            # shape: 60 x the bytes of the broadcast plan above), distributed q5, and q1 (partial states gathered)
+            # second legs, every rank takes part: q3 with the build side of orders |x| lineitem BROADCAST instead (what a cost-based
+            # planner picks when the build side is 20 x smaller: 1/60 of the bytes cross the links), distributed q5, and q1
             extra = {}
             k = max(3, args.steps // 4)
-            p2 = g.NativePlan(T.q3_dist_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), world, "partitioned"), tc)
+            p2 = g.NativePlan(T.q3_dist_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), world, "broadcast"), tc)
             p2.set_comm(comm)
             for _ in range(3):
                 p2.execute(0)
             d2, r2 = timed_steps(lambda: p2.execute(0), k)
-            extra["q3_both_sides_repartitioned"] = {"ms_per_step": d2 / k * 1e3, "lineitem_rows_per_s": rows_job * k / d2, "result_groups": r2.num_rows}
+            extra["q3_build_side_broadcast"] = {"ms_per_step": d2 / k * 1e3, "lineitem_rows_per_s": rows_job * k / d2, "result_groups": r2.num_rows}
             # BASELINE configs[3]: q5, the 6-way join with orders |x| lineitem hash-partitioned across the ranks (T.q5_dist_plan)
             sper = n_supp // world
             su = T.gen_supplier_device(tc, sper if rank < world - 1 else n_supp - sper * (world - 1), row0=rank * sper)
@@ -227,19 +251,85 @@ def main_q3():
         dist.destroy_process_group()
 
 
-def cpu_baseline_q3(T, sample_sf):
-    """Oracle (C restatement, OpenMP) q3 on the host cores over an SF`sample_sf` sample of the same generator."""
-    n_li = T.LINEITEM_ROWS.get(int(sample_sf), int(6_000_000 * sample_sf))
-    h = T.gen_q3_tables_host(n_li, int(150_000 * sample_sf))
-    best, st = None, None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        _rows, st = T.q3_oracle_c(h, cap=0)
-        dt = time.perf_counter() - t0
-        best = dt if best is None or dt < best else best
-    return {"value": n_li / best, "unit": "rows/s", "cores": T.oracle_lib().oracle_num_threads(), "kind": "port", "wall_ms": best * 1e3,
-            "sample": "C oracle q3 (3 filters, 2 chained-hash-table joins, per-thread hash aggregate, sort) over synthetic SF%g tables (%d lineitem rows, %d groups), best of 3, data in host memory"
-                      % (sample_sf, n_li, st["groups"])}
+def check_q3_result(torch, T, tc, res, li, od, cu):
+    """The SF100 result against an independent computation with plain torch ops over the same HBM-resident columns (no gpuq kernel
+    involved): the customers of the segment -> a Boolean table by key, the orders before the date whose customer is in it -> a
+    Boolean table by order key, the lineitems shipped after the date whose order is in it; sum over them of l_extendedprice *
+    (100 - l_discount) must equal the sum of the result's revenue column, the number of distinct orders among them its row count."""
+    def colv(t, name, dtype, width):
+        c = t.columns[[c.name for c in t.columns].index(name)]
+        return c.data[: width * t.num_rows].view(dtype)
+    ck = colv(cu, "c_custkey", torch.int64, 8)
+    seg = cu.columns[[c.name for c in cu.columns].index("c_mktsegment")]
+    offs = seg.offsets[: cu.num_rows + 1].to(torch.int64)              # (int32 tensor)
+    first = seg.data[offs[:-1].clamp(max=seg.data.numel() - 1)]
+    building = (first == ord("B")) & ((offs[1:] - offs[:-1]) == 8)      # the generator's five segments: only BUILDING starts with B
+    in_seg = torch.zeros(int(ck.max().item()) + 2, dtype=torch.bool, device=ck.device)
+    in_seg[ck[building]] = True
+    ok, oc, odate = colv(od, "o_orderkey", torch.int64, 8), colv(od, "o_custkey", torch.int64, 8), colv(od, "o_orderdate", torch.int32, 4)
+    o_live = (odate < T.Q3_DATE) & in_seg[oc.clamp(max=in_seg.numel() - 1)]
+    in_ord = torch.zeros(int(ok.max().item()) + 2, dtype=torch.bool, device=ok.device)
+    in_ord[ok[o_live]] = True
+    del o_live, in_seg
+    lk, ship = colv(li, "l_orderkey", torch.int64, 8), colv(li, "l_shipdate", torch.int32, 4)
+    live = (ship > T.Q3_DATE) & in_ord[lk.clamp(max=in_ord.numel() - 1)]
+    ext = colv(li, "l_extendedprice", torch.int64, 16)[0::2]          # low halves of the Decimal128 cells (15 digits: the high halves are sign extension)
+    disc = colv(li, "l_discount", torch.int64, 16)[0::2]
+    exp_rev = int((ext[live] * (100 - disc[live])).sum().item())
+    hit = torch.zeros_like(in_ord)
+    hit[lk[live]] = True
+    exp_groups = int(hit.sum().item())
+    del live, hit, in_ord
+    t = res.to_device_table(tc.device)
+    rc = t.columns[[c.name for c in t.columns].index("revenue")]
+    got_rev = int(rc.data[: 16 * t.num_rows].view(torch.int64)[0::2].sum().item())
+    return {"what": "SF result vs plain torch ops over the same columns: sum(revenue) and number of groups", "sum_revenue_matches": got_rev == exp_rev,
+            "groups_match": t.num_rows == exp_groups, "sum_revenue_unscaled": got_rev, "groups": t.num_rows}
+
+
+def cpu_baseline(sample_sf):
+    """The oracle (C restatement, OpenMP over all host cores: "port") on an SF`sample_sf` sample of the same generator, data in host memory:
+    q3 is the headline (`value`), q1 and q5 beside it; 3 runs each, min and mean (the reference's harness prints per-iteration and
+    average times, benchmarks/src/bin/tpch.rs:333-344).  pyarrow Acero (hash join / group-by / sort on all host threads, money as int64
+    cents) runs the same q3 / q5 as a second, independent CPU engine -- a proxy, not the reference's DataFusion path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tpch_util as TO           # the oracle side lives with the tests
+    n_li = TO.LINEITEM_ROWS.get(int(sample_sf), int(6_000_000 * sample_sf))
+    n_cust, n_supp = int(150_000 * sample_sf), int(10_000 * sample_sf)
+    h = TO.gen_q5_tables_host(n_li, n_cust, n_supp)
+
+    def timed3(fn):
+        ts, out = [], None
+        for _ in range(3):
+            t0 = time.perf_counter(); out = fn(); ts.append(time.perf_counter() - t0)
+        return ts, out
+    t3, (_r3, st3) = timed3(lambda: TO.q3_oracle_c(h, cap=0))
+    t5, (_r5, st5) = timed3(lambda: TO.q5_oracle_c(h))
+    hq1 = TO.gen_lineitem_host(n_li)
+    t1, r1 = timed3(lambda: TO.q1_oracle_raw(n_li, host=hq1))
+    del hq1
+
+    def entry(ts, extra):
+        return dict({"wall_ms_min": min(ts) * 1e3, "wall_ms_mean": sum(ts) / len(ts) * 1e3, "lineitem_rows_per_s": n_li / min(ts)}, **extra)
+    cpu = ""
+    try:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        mem = [l for l in open("/proc/meminfo") if l.startswith("MemTotal")][0].split()[1]
+        cpu += ", %d GiB RAM" % (int(mem) >> 20)
+    except Exception:
+        pass
+    out = {"value": n_li / min(t3), "unit": "rows/s", "cores": TO.oracle_lib().oracle_num_threads(), "kind": "port", "wall_ms": min(t3) * 1e3, "wall_ms_mean": sum(t3) / 3 * 1e3,
+           "host": cpu,
+           "sample": "C oracle q3 (3 filters, 2 chained-hash-table joins, per-thread hash aggregate, sort) over synthetic SF%g tables (%d lineitem rows, %d groups), "
+                     "min of 3 (mean beside it), data in host memory; the GPU line above is SF100: the sample is bounded so that the default run stays within minutes" % (sample_sf, n_li, st3["groups"]),
+           "q1": entry(t1, {"groups": len(r1)}), "q3": entry(t3, {"groups": st3["groups"]}), "q5": entry(t5, {"groups": len(_r5), "pairs": st5["pairs"]})}
+    del h
+    try:
+        import bench_extras
+        out["proxy_acero"] = bench_extras.cpu_proxy_acero(TO, int(sample_sf))
+    except Exception as e:      # the proxy is an extra: never lose the line over it
+        out["proxy_acero"] = {"error": str(e)[:200]}
+    return out
 
 
 if __name__ == "__main__":

@@ -45,7 +45,8 @@ typedef enum gpuq_status {
   GPUQ_ERR_CAPACITY = 4,     /* caller-provided output capacity too small; required size reported */
   GPUQ_ERR_INTERNAL = 5,
   GPUQ_ERR_CANCELLED = 6,    /* gpuq_task_cancel reached the task before it finished */
-  GPUQ_ERR_RETRY = 7         /* gpuq_ops_settle: something a deferred run assumed did not hold; run again without deferral */
+  GPUQ_ERR_RETRY = 7,        /* gpuq_ops_settle: something a deferred run assumed did not hold; run again without deferral */
+  GPUQ_ERR_PEER = 8          /* exchange: a rank of the node announced a failure (or cannot hold what it would receive); no payload moved */
 } gpuq_status;
 
 /* Logical types (subset of ballista/core/proto/datafusion.proto:1004-1040 ArrowType). */
@@ -580,6 +581,15 @@ typedef struct gpuq_transport {
 } gpuq_transport;
 int gpuq_comm_create_host(gpuq_ctx* ctx, const gpuq_transport* transport, int rank, int world, gpuq_comm** out);
 void gpuq_comm_free(gpuq_comm* comm);
+/* Failing together.  Every exchange starts with a fixed-size meta round that carries, next to the row counts, a status word per
+   rank: 0 fine, 1 "I have failed", 2 "my deferred execution did not hold" (GPUQ_ERR_RETRY on every rank: all of them run again,
+   synchronously).  gpuq_comm_set_status arms the word for this rank's NEXT collective call; gpuq_comm_announce is that meta round
+   alone (no table): a rank whose plan failed below an exchange calls set_status(1) + announce so that the peers waiting in the
+   exchange return GPUQ_ERR_PEER instead of hanging, and with status 0 everywhere it is the barrier that closes a deferred execution
+   ("nobody has to redo anything").  A second, one-word round agrees on limits the counts imply (2^32 rows / 2 GiB of strings on a
+   rank) before any payload moves; a failure inside the payload round aborts the communicator (ncclCommAbort).  Collective. */
+int gpuq_comm_set_status(gpuq_comm* comm, int status);
+int gpuq_comm_announce(gpuq_comm* comm, void* stream);
 int gpuq_comm_rank(const gpuq_comm* comm);
 int gpuq_comm_world(const gpuq_comm* comm);
 /* Hash-repartition exchange.  cols / fields: device columns (Arrow layout, Utf8 of any length included, or PACKED15) whose rows

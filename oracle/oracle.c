@@ -370,3 +370,102 @@ i64 oracle_q3(i64 n_cust, const i64* c_custkey, const uint8_t* c_mktsegment, con
   free(out); free(all.g); free(ck); free(cnt); free(jk); free(jd); free(jp);
   return ng;
 }
+
+/* ---------------------------------------------------------------- q5: six-way join + group-by + sort
+ * reference benchmarks/queries/q5.sql: region(r_name = 'ASIA') |x| nation |x| customer |x| orders(1994) |x| lineitem |x| supplier
+ * on (l_suppkey = s_suppkey AND c_nationkey = s_nationkey), SUM(l_extendedprice * (1 - l_discount)) by n_name, ORDER BY revenue
+ * DESC (tpch.rs:286-351 runs it as five HashJoinExec(CollectLeft) -> AggregateExec -> SortExec).  Executed here the way
+ * oracle_q3 is: chained hash tables with key re-verification, the probe sides split over threads, per-thread partial sums.
+ * nation_region[k] = region key of nation key k (n_nations entries); groups are nation KEYS (the caller maps them to n_name).
+ * Returns the number of groups; out_nation / out_revenue ([..][2], Decimal128(38,4) as lo,hi) ordered by revenue DESC, nation key. */
+typedef struct { int32_t nation; i128 rev; } q5_group;
+static int q5_cmp(const void* a, const void* b) {
+  const q5_group* x = (const q5_group*)a; const q5_group* y = (const q5_group*)b;
+  if (x->rev != y->rev) return x->rev > y->rev ? -1 : 1;
+  return x->nation < y->nation ? -1 : (x->nation > y->nation ? 1 : 0);
+}
+i64 oracle_q5(i64 n_nations, const i64* nation_region, i64 region_key,
+              i64 n_cust, const i64* c_custkey, const i64* c_nationkey,
+              i64 n_orders, const i64* o_orderkey, const i64* o_custkey, const int32_t* o_orderdate, int32_t date_lo, int32_t date_hi,
+              i64 n_line, const i64* l_orderkey, const i64* l_suppkey, const u64* l_extendedprice, const u64* l_discount,
+              i64 n_supp, const i64* s_suppkey, const i64* s_nationkey,
+              int32_t* out_nation, u64* out_revenue, i64* stats /* optional [3]: customers kept, orders kept, lineitem pairs that reach the aggregate */) {
+  const int nthreads = oracle_num_threads();
+  if (n_nations > 64) return -1;
+  /* region |x| nation |x| customer: customers of the region's nations */
+  i64* ck = (i64*)malloc((size_t)(n_cust > 0 ? n_cust : 1) * 8); int32_t* cn = (int32_t*)malloc((size_t)(n_cust > 0 ? n_cust : 1) * 4); i64 nck = 0;
+  for (i64 i = 0; i < n_cust; ++i) {
+    const i64 nk = c_nationkey[i];
+    if (nk >= 0 && nk < n_nations && nation_region[nk] == region_key) { ck[nck] = c_custkey[i]; cn[nck] = (int32_t)nk; ++nck; }
+  }
+  void* t1 = oracle_join_build(ck, nck);
+  const oracle_join_table* T1 = (const oracle_join_table*)t1;
+  /* |x| orders of the date range: (o_orderkey, customer's nation), in orders order */
+  i64* cnt = (i64*)calloc((size_t)nthreads + 1, 8);
+  i64* jk = NULL; int32_t* jn = NULL; i64 nj = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma omp parallel
+    {
+      int tid = 0;
+#ifdef _OPENMP
+      tid = omp_get_thread_num();
+#endif
+      const i64 a = n_orders * tid / nthreads, b = n_orders * (tid + 1) / nthreads;
+      i64 w = pass ? cnt[tid] : 0;
+      for (i64 j = a; j < b; ++j) {
+        if (!(o_orderdate[j] >= date_lo && o_orderdate[j] < date_hi)) continue;
+        const i64 k = o_custkey[j];
+        for (uint32_t r = T1->head[mix64((u64)k) & T1->mask]; r != 0xFFFFFFFFu; r = T1->next[r])
+          if (T1->keys[r] == k) { if (pass) { jk[w] = o_orderkey[j]; jn[w] = cn[r]; } ++w; }
+      }
+      if (!pass) cnt[tid + 1] = w;
+    }
+    if (!pass) {
+      cnt[0] = 0; for (int t = 0; t < nthreads; ++t) cnt[t + 1] += cnt[t];
+      nj = cnt[nthreads];
+      jk = (i64*)malloc((size_t)(nj > 0 ? nj : 1) * 8); jn = (int32_t*)malloc((size_t)(nj > 0 ? nj : 1) * 4);
+    }
+  }
+  oracle_join_free(t1);
+  /* |x| lineitem on the order key, |x| supplier on (suppkey, nation); partial sums per thread */
+  void* t2 = oracle_join_build(jk, nj);
+  void* t3 = oracle_join_build(s_suppkey, n_supp);
+  const oracle_join_table* T2 = (const oracle_join_table*)t2; const oracle_join_table* T3 = (const oracle_join_table*)t3;
+  i128* part = (i128*)calloc((size_t)nthreads * 64, sizeof(i128));
+  i64 pairs = 0;
+#pragma omp parallel reduction(+ : pairs)
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    i128* mine = part + (size_t)tid * 64;
+    const i64 a = n_line * tid / nthreads, b = n_line * (tid + 1) / nthreads;
+    for (i64 i = a; i < b; ++i) {
+      const i64 k = l_orderkey[i];
+      for (uint32_t r = T2->head[mix64((u64)k) & T2->mask]; r != 0xFFFFFFFFu; r = T2->next[r]) {
+        if (T2->keys[r] != k) continue;
+        const i64 sk = l_suppkey[i];
+        for (uint32_t q = T3->head[mix64((u64)sk) & T3->mask]; q != 0xFFFFFFFFu; q = T3->next[q]) {
+          if (T3->keys[q] != sk || s_nationkey[q] != (i64)jn[r]) continue;
+          const i128 ext = (i128)(((u128)l_extendedprice[2 * i + 1] << 64) | l_extendedprice[2 * i]);
+          const i128 disc = (i128)(((u128)l_discount[2 * i + 1] << 64) | l_discount[2 * i]);
+          mine[jn[r]] += ext * (100 - disc);
+          ++pairs;
+        }
+      }
+    }
+  }
+  oracle_join_free(t2); oracle_join_free(t3);
+  /* a nation is a group when at least one row reached it: keep a presence flag next to the sums */
+  q5_group out[64]; i64 ng = 0;
+  for (int k = 0; k < (int)n_nations; ++k) {
+    i128 s = 0; for (int t = 0; t < nthreads; ++t) s += part[(size_t)t * 64 + k];
+    if (s != 0) { out[ng].nation = k; out[ng].rev = s; ++ng; }      /* (revenue of a non-empty group is positive: prices > 0, discounts < 1) */
+  }
+  qsort(out, (size_t)ng, sizeof(q5_group), q5_cmp);
+  for (i64 g = 0; g < ng; ++g) { out_nation[g] = out[g].nation; out_revenue[2 * g] = (u64)out[g].rev; out_revenue[2 * g + 1] = (u64)((u128)out[g].rev >> 64); }
+  if (stats) { stats[0] = nck; stats[1] = nj; stats[2] = pairs; }
+  free(part); free(ck); free(cn); free(cnt); free(jk); free(jn);
+  return ng;
+}

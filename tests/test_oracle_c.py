@@ -60,3 +60,15 @@ def test_q3_c_equals_python_oracle():
     assert st["groups"] == len(exp) > 0 and st["j2_matches"] >= len(exp)
     assert [(r[1], r[2]) for r in rows] == [(r[1], r[2]) for r in exp]          # ORDER BY revenue desc, o_orderdate
     assert sorted(rows) == sorted(exp)
+
+
+def test_c_q5_equals_the_python_restatement():
+    """oracle_q5 (C, OpenMP: the CPU baseline of bench.py) against q5_oracle (plain Python dictionaries) on the same generated tables."""
+    import tpch_util as T
+    n_li, n_cust, n_supp = 60_000, 1500, 100
+    h = T.gen_q5_tables_host(n_li, n_cust, n_supp)
+    rows, st = T.q5_oracle_c(h)
+    hl = T.lineitem_host_to_arrow(T.gen_lineitem_host(n_li, n_supp=n_supp), n_li)
+    ho, hc, hs = T.gen_other_tables_host((n_li + 3) // 4, n_cust, n_supp)
+    exp = T.q5_oracle(hc, ho, hl, hs)
+    assert [tuple(r) for r in rows] == [tuple(r) for r in exp] and len(rows) == 5 and st["pairs"] > 0
