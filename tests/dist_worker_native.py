@@ -51,6 +51,32 @@ def main():
             plan = g.NativePlan(T.q3_dist_plan(g.MemoryExec([cu]), g.MemoryExec([od]), g.MemoryExec([li]), world, mode), tc)
             plan.set_comm(comm)
             res["q3_" + mode] = [list(r) for r in arrow_rows(plan.execute(0).to_arrow())]
+            # twice more: deferred on every rank, closed by the agreement round (no rank redoes anything alone)
+            for k in range(2):
+                again = [list(r) for r in arrow_rows(plan.execute(0).to_arrow())]
+                st = plan.exec_stats()
+                res["q3_%s_again%d_same" % (mode, k)] = [[int(again == res["q3_" + mode]), int(st["deferred"]), st["retries"]]]
+            if mode == "partitioned":
+                # rank 1 alone gets a bigger orders shard under the plan: what it remembered no longer fits, so BOTH ranks redo the
+                # execution synchronously (the status word of the exchanges' meta round) -- and neither hangs
+                od2 = T.gen_orders_device(tc, n_li // 4 + (4000 if rank == 1 else 0), n_cust, row0=rank * (n_li // 4))
+                plan.set_input(1, od2)
+                r1 = [list(r) for r in arrow_rows(plan.execute(0).to_arrow())]
+                st = plan.exec_stats()
+                res["q3_changed_input"] = r1
+                res["q3_changed_stats"] = [[int(st["deferred"]), st["retries"]]]
+                plan.set_input(1, od)
+        # one rank fails below an exchange (rank 0 orders strings of more than 15 bytes, which the device refuses at run time): the
+        # other rank must come back with an error naming it, not wait for data that never comes
+        from arrow_ballista_amd.expr import binary, lit, Operator as Op
+        pred = binary(col("long_s", ls), Op.Lt, lit("zzz")) if rank == 0 else binary(col("k32", ls), Op.Gt, lit(0, "Int32"))
+        try:
+            p = g.NativePlan(g.BroadcastExec(g.FilterExec(pred, L)), tc)
+            p.set_comm(comm)
+            p.execute(0)
+            res["peer_failure"] = [["no error", ""]]
+        except Exception as e:          # noqa: BLE001
+            res["peer_failure"] = [[type(e).__name__, str(e)[:300]]]
         # distributed q5 (BASELINE configs[3]): sharded customer / orders / lineitem / supplier, replicated nation / region
         n_supp = 100
         sper = n_supp // world

@@ -170,3 +170,21 @@ def test_native_distributed_q5_equals_the_oracle_on_the_union(native_ranks):
     for rk in native_ranks:
         got = [(r[0], int(r[1]["d"].replace(".", "")) if isinstance(r[1], dict) else r[1]) for r in rk["q5"]]
         assert got == exp
+
+
+def test_native_distributed_plans_run_deferred_and_fail_together(native_ranks):
+    """The same distributed plan executed again runs deferred on both ranks (identical rows, no retries); when ONE rank's input
+    changes under the plan both redo the execution synchronously (the status word of the exchange's meta round) and agree on the new
+    answer; when one rank fails below an exchange the other returns an error that names it.  None of this may hang: the worker
+    processes are under a timeout."""
+    for r in native_ranks:
+        for mode in ("partitioned", "broadcast"):
+            for k in range(2):
+                same, deferred, retries = r["q3_%s_again%d_same" % (mode, k)][0]
+                assert same == 1 and deferred == 1 and retries == 0, (mode, k, r["q3_%s_again%d_same" % (mode, k)])
+        deferred, retries = r["q3_changed_stats"][0]
+        assert deferred == 0 and retries == 1, r["q3_changed_stats"]
+    assert native_ranks[0]["q3_changed_input"] == native_ranks[1]["q3_changed_input"] and len(native_ranks[0]["q3_changed_input"]) > 0
+    e0, e1 = native_ranks[0]["peer_failure"][0], native_ranks[1]["peer_failure"][0]
+    assert e0[0] == "GpuqError" and "15 bytes" in e0[1], e0
+    assert e1[0] == "GpuqError" and "rank 0 failed" in e1[1], e1
