@@ -204,6 +204,7 @@ def lib():
         "gpuq_timer_elapsed_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "gpuq_timer_free": (None, [vp]),
         "gpuq_op_profile": (i32, [vp, i32, C.POINTER(C.c_float), C.POINTER(i32)]),
+        "gpuq_op_profile_total": (i32, [vp, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError when the library lacks a declared symbol

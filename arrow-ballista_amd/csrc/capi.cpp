@@ -78,7 +78,9 @@ struct gpuq_op {
   uint32_t* pinned() { if (!pin) { if (hipHostMalloc((void**)&pin, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pin = nullptr; } } return pin; }
   // profiling of the dominant kernel
   bool profile = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float kernel_ms = 0; int launches = 0; bool ev_pending = false;
-  ~gpuq_op() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); if (pin) (void)hipHostFree(pin); }
+  // ... and of everything one call queues (the dominant kernel plus table initialisation, scans, compaction, result projection)
+  hipEvent_t ev2 = nullptr, ev3 = nullptr; float total_ms = 0, last_total_ms = 0; bool ev_total_pending = false;
+  ~gpuq_op() { for (hipEvent_t e : {ev0, ev1, ev2, ev3}) if (e) (void)hipEventDestroy(e); if (pin) (void)hipHostFree(pin); }
 };
 
 struct gpuq_join_table {
@@ -184,6 +186,24 @@ struct ProfScope {
     }
   }
   ~ProfScope() { if (op->profile) { (void)hipEventRecord(op->ev1, s); op->ev_pending = true; op->launches++; } }
+};
+
+// events around EVERYTHING a run call queues on its stream (gpuq_op_profile_total)
+struct ProfTotal {
+  gpuq_op* op; hipStream_t s; bool on = false;
+  ProfTotal(gpuq_op* o, hipStream_t st) : op(o), s(st) {
+    if (op->profile) {
+      if (!op->ev2) { HIPCHECK(hipEventCreate(&op->ev2)); HIPCHECK(hipEventCreate(&op->ev3)); }
+      if (op->ev_total_pending) {
+        // never wait here (a deferred step must not meet a host round trip because it is being measured): a previous interval that
+        // has not finished yet -- the same operator twice in a row, e.g. the take projections -- leaves this call unmeasured
+        if (hipEventQuery(op->ev3) != hipSuccess) { (void)hipGetLastError(); return; }
+        float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, op->ev2, op->ev3)); op->total_ms += ms; op->ev_total_pending = false;
+      }
+      HIPCHECK(hipEventRecord(op->ev2, s)); on = true;
+    }
+  }
+  ~ProfTotal() { if (on) { (void)hipEventRecord(op->ev3, s); op->ev_total_pending = true; } }
 };
 
 // Route the next launch of sink kernel `kernel_id` to the hiprtc-specialised function when the context's
@@ -801,10 +821,17 @@ int gpuq_op_profile(gpuq_op* op, int enable, float* kernel_ms_out, int* launches
   if (!op) return GPUQ_ERR_INVALID;
   return guarded(op->ctx, [&]() {
     if (op->ev_pending) { float ms = 0; HIPCHECK(hipEventSynchronize(op->ev1)); HIPCHECK(hipEventElapsedTime(&ms, op->ev0, op->ev1)); op->kernel_ms += ms; op->ev_pending = false; }
+    if (op->ev_total_pending) { float ms = 0; HIPCHECK(hipEventSynchronize(op->ev3)); HIPCHECK(hipEventElapsedTime(&ms, op->ev2, op->ev3)); op->total_ms += ms; op->ev_total_pending = false; }
     if (kernel_ms_out) *kernel_ms_out = op->kernel_ms;
     if (launches_out) *launches_out = op->launches;
-    op->kernel_ms = 0; op->launches = 0; if (enable >= 0) op->profile = enable != 0;
+    op->last_total_ms = op->total_ms;
+    op->kernel_ms = 0; op->total_ms = 0; op->launches = 0; if (enable >= 0) op->profile = enable != 0;
   });
+}
+int gpuq_op_profile_total(gpuq_op* op, float* total_ms_out) {      // of the interval the last gpuq_op_profile call closed
+  if (!op || !total_ms_out) return GPUQ_ERR_INVALID;
+  *total_ms_out = op->last_total_ms;
+  return GPUQ_OK;
 }
 
 // ---------------------------------------------------------------- filter
@@ -814,6 +841,7 @@ int gpuq_filter_run(gpuq_op* op, void* stream, const gpuq_input* in, int payload
     check_ctx(op->ctx);
     if (op->kind != K_FILTER) throw std::runtime_error("not a filter operator");
     hipStream_t s = use_stream(stream);
+    ProfTotal ptot(op, s);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     if (payload_via < 0 || payload_via > in->n_via) throw std::runtime_error("payload_via out of range");
     const i64 n = in->n_rows;
@@ -839,6 +867,7 @@ int gpuq_project_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_colum
     check_ctx(op->ctx);
     if (op->kind != K_PROJECT) throw std::runtime_error("not a project operator");
     hipStream_t s = use_stream(stream);
+    ProfTotal ptot(op, s);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     OutSpec O = make_outspec(op->prog, outs, n_outs, op->out_fields);
     for (int i = 0; i < n_outs; ++i) outs[i].length = in->n_rows;
@@ -856,6 +885,7 @@ static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, g
     check_ctx(op->ctx);
     if (op->kind != K_AGG) throw std::runtime_error("not an aggregate operator");
     hipStream_t s = use_stream(stream);
+    ProfTotal ptot(op, s);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     const i64 n = in->n_rows;
     const int nk = op->agg.n_keys, na = op->agg.n_accs, kstride = nk > 0 ? nk : 1;
@@ -1193,6 +1223,7 @@ static int join_build_impl(gpuq_op* op, void* stream, const gpuq_input* in, int 
     if (op->kind != K_JOIN_BUILD) throw std::runtime_error("not a join_build operator");
     if (!out) throw std::runtime_error("out is NULL");
     hipStream_t s = use_stream(stream);
+    ProfTotal ptot(op, s);
     SemiProbe semi{}; const SemiProbe* semi_p = nullptr;
     if (semi_table) {
       if (!op->has_semi) throw std::runtime_error("join build: the descriptor has no \"semi_on\" keys");
@@ -1361,6 +1392,7 @@ int gpuq_join_probe_run(gpuq_op* op, void* stream, gpuq_join_table* t, const gpu
     if (op->keys.n_keys != t->keys.n_keys || op->keys.key_words != t->keys.key_words) throw std::runtime_error("probe keys do not match the build keys (count / width)");
     for (int k = 0; k < op->keys.n_keys; ++k) if (op->keys.key_wide[k] != t->keys.key_wide[k]) throw std::runtime_error("probe key " + std::to_string(k) + " width class differs from the build key; cast one side");
     hipStream_t s = use_stream(stream);
+    ProfTotal ptot(op, s);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     if (payload_via < 0 || payload_via > in->n_via) throw std::runtime_error("payload_via out of range");
     const int jt = op->join_type;
@@ -1544,6 +1576,7 @@ int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* per
     check_ctx(op->ctx);
     if (op->kind != K_SORT) throw std::runtime_error("not a sort operator");
     hipStream_t s = use_stream(stream);
+    ProfTotal ptot(op, s);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
     const i64 n = in->n_rows;
     if (n == 0) return;

@@ -2146,7 +2146,9 @@ int gpuq_plan_profile_all(gpuq_plan* p, char* json_out, size_t cap) {
     std::string kind;
     try { kind = JsonParser(kv.first.c_str()).parse().get_str("op", ""); } catch (const std::exception&) {}
     Json num; num.kind = Json::NUM; { char b[64]; std::snprintf(b, sizeof(b), "%.6f", (double)ms); num.s = b; }
-    arr.a.push_back(jobj({{"op", jstr(kind)}, {"kernel_ms", num}, {"launches", jnum(n)}, {"desc", jstr(kv.first)}}));
+    float tot = 0; (void)gpuq_op_profile_total(kv.second, &tot);
+    Json tnum; tnum.kind = Json::NUM; { char b[64]; std::snprintf(b, sizeof(b), "%.6f", (double)tot); tnum.s = b; }
+    arr.a.push_back(jobj({{"op", jstr(kind)}, {"kernel_ms", num}, {"op_ms", tnum}, {"launches", jnum(n)}, {"desc", jstr(kv.first)}}));
   }
   const std::string s = arr.dump();
   if (s.size() + 1 > cap) return GPUQ_ERR_CAPACITY;

@@ -632,6 +632,9 @@ void gpuq_timer_free(gpuq_timer* t);
 /* Per-op device time of the last call(s): the op brackets its dominant kernel with HIP events when
    enabled; returns the accumulated ms and launch count since the last reset.  enable < 0 keeps the current setting. */
 int gpuq_op_profile(gpuq_op* op, int enable, float* kernel_ms_out, int* launches_out);
+/* ... and of EVERYTHING the op's run calls queued in the interval the last gpuq_op_profile call closed (the dominant kernel plus table
+   initialisation, scans, compactions, the result projection): the operator's share of a step. */
+int gpuq_op_profile_total(gpuq_op* op, float* total_ms_out);
 
 #ifdef __cplusplus
 }
