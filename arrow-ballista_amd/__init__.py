@@ -17,7 +17,7 @@ from .plan import (  # noqa: F401
     MemoryExec, FilterExec, ProjectionExec, AggregateExec, HashJoinExec, SortExec, CoalesceBatchesExec,
     RepartitionExec, ShuffleWriterExec, ShuffleReaderExec, DefaultExecutionEngine, TaskContext,
     CoalesceTasksExec, CoalescePartitionsExec, SortPreservingMergeExec, UnionExec, LocalLimitExec, GlobalLimitExec,
-    RepartitionExchangeExec, BroadcastExec,
+    RepartitionExchangeExec, BroadcastExec, RangeRepartitionExec,
 )
 
 __all__ = [
@@ -25,5 +25,5 @@ __all__ = [
     "DeviceColumn", "DeviceTable", "MemoryExec", "FilterExec", "ProjectionExec", "AggregateExec",
     "HashJoinExec", "SortExec", "CoalesceBatchesExec", "RepartitionExec", "ShuffleWriterExec", "ShuffleReaderExec",
     "DefaultExecutionEngine", "TaskContext", "CoalesceTasksExec", "CoalescePartitionsExec", "SortPreservingMergeExec",
-    "UnionExec", "LocalLimitExec", "GlobalLimitExec", "RepartitionExchangeExec", "BroadcastExec",
+    "UnionExec", "LocalLimitExec", "GlobalLimitExec", "RepartitionExchangeExec", "BroadcastExec", "RangeRepartitionExec",
 ]

@@ -164,6 +164,7 @@ def lib():
         "gpuq_plan_set_comm": (i32, [vp, vp]),
         "gpuq_plan_exec_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "gpuq_comm_unique_id": (i32, [vp]),
+        "gpuq_table_piece_rows": (i32, [vp, C.POINTER(i64), i32, C.POINTER(i32)]),
         "gpuq_comm_set_status": (i32, [vp, i32]),
         "gpuq_comm_announce": (i32, [vp, vp]),
         "gpuq_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),

@@ -253,7 +253,7 @@ gpuq_table* exchange_impl(gpuq_comm* c, hipStream_t st, const gpuq_column* cols,
 
   // ---- 3. every buffer of the table in one grouped round
   std::unique_ptr<gpuq_table> out(new gpuq_table());
-  out->ctx = c->ctx; out->n_rows = total;
+  out->ctx = c->ctx; out->n_rows = total; out->piece_rows = rrows;
   std::vector<gpuq_comm::Piece> pieces;
   std::vector<std::unique_ptr<DevBuf>> scratch;      // send-side bitmap pieces, received bitmap pieces, received offsets: alive until the round has run
   struct BitJob { const DevBuf* rbits; std::vector<int64_t> roff; DevBuf* dst; };
@@ -390,6 +390,12 @@ void gpuq_comm_free(gpuq_comm* c) {
   if (!c) return;
   if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
   delete c;
+}
+int gpuq_table_piece_rows(const gpuq_table* t, int64_t* rows_out, int cap, int* n_out) {
+  if (!t || !n_out) return GPUQ_ERR_INVALID;
+  *n_out = (int)t->piece_rows.size();
+  if (rows_out) { if (cap < *n_out) return GPUQ_ERR_CAPACITY; for (int i = 0; i < *n_out; ++i) rows_out[i] = t->piece_rows[(size_t)i]; }
+  return GPUQ_OK;
 }
 int gpuq_comm_set_status(gpuq_comm* c, int status) { if (!c || status < 0 || status > 2) return GPUQ_ERR_INVALID; c->status = status; return GPUQ_OK; }
 int gpuq_comm_announce(gpuq_comm* c, void* stream) {

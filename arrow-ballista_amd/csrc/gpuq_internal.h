@@ -24,4 +24,7 @@ struct gpuq_ctx {
 
 // a table whose buffers the library owns (gpuq_table_import_arrow, gpuq_exchange_*): freed by gpuq_table_free
 struct ImportedCol { gpuq_column col{}; gpuq_field_info field{}; gpuq::DevBuf data, offsets, validity; };
-struct gpuq_table { gpuq_ctx* ctx = nullptr; int64_t n_rows = 0; std::vector<std::unique_ptr<ImportedCol>> cols; };
+struct gpuq_table {
+  gpuq_ctx* ctx = nullptr; int64_t n_rows = 0; std::vector<std::unique_ptr<ImportedCol>> cols;
+  std::vector<int64_t> piece_rows;      // a table that came out of an exchange: rows received from rank 0, 1, ... (in this order)
+};

@@ -1833,6 +1833,109 @@ struct BroadcastExec : PNode {
   }
 };
 
+// Distributed SortExec over the ranks of a node (SURVEY.md section 8e "Sort", BASELINE configs[4]: "range-partition over xGMI"): what the
+// reference runs as a single-partition SortPreservingMergeExec stage (ballista/scheduler/src/planner.rs:120-136) becomes
+//   1. every rank contributes a strided sample of its rows; the gathered samples are sorted (identically on every rank: same rows,
+//      same stable sort) and world-1 of them become the splitters;
+//   2. the local rows and the splitters are sorted TOGETHER by the engine's own SortExec (a tag column puts a splitter behind the rows
+//      it equals): where the splitters land are the range boundaries of the locally sorted run -- no key is ever compared outside the
+//      device sort, so every type / direction / NULL placement SortExec knows works here;
+//   3. range r of every rank goes to rank r in ONE exchange; the received pieces are sorted runs and are MERGED (gpuq_merge_run).
+// Output: this rank's range, sorted; ranks hold ascending, non-overlapping ranges (rank order = global order).
+struct RangeRepartitionExec : PNode {
+  PNodeP input; Json expr; int64_t partition_count = 0, samples = 1024;
+  std::vector<PNode*> children() override { return {input.get()}; }
+  int partitions() override { return input->partitions(); }
+  static PCol tag_column(Exec& x, int64_t n, int32_t value, std::vector<BufP>& keep) {
+    BufP b = dev_alloc((size_t)std::max<int64_t>(n, 1) * 4 + 16);
+    if (value == 0) HIPCHECK(hipMemsetAsync(b->p, 0, (size_t)std::max<int64_t>(n, 1) * 4, (hipStream_t)x.stream));
+    else { std::vector<int32_t> h((size_t)std::max<int64_t>(n, 1), value); HIPCHECK(hipMemcpyAsync(b->p, h.data(), h.size() * 4, hipMemcpyHostToDevice, (hipStream_t)x.stream)); HIPCHECK(hipStreamSynchronize((hipStream_t)x.stream)); }
+    keep.push_back(b);
+    PCol c; c.name = "__gpuq_splitter"; c.type = jstr("Int32"); c.nullable = false;
+    c.c.type = T_INT32; c.c.repr = GPUQ_REPR_ARROW; c.c.data = b->p; c.c.length = n;
+    return c;
+  }
+  static BufP upload_u32(Exec& x, const std::vector<uint32_t>& v) {
+    BufP b = dev_alloc(std::max<size_t>(v.size(), 1) * 4 + 16);
+    if (!v.empty()) { HIPCHECK(hipMemcpyAsync(b->p, v.data(), v.size() * 4, hipMemcpyHostToDevice, (hipStream_t)x.stream)); HIPCHECK(hipStreamSynchronize((hipStream_t)x.stream)); }
+    return b;
+  }
+  PTable execute(int part, Exec& x) override {
+    if (!x.comm) throw Unsupported("RangeRepartitionExec needs the ranks of the node (gpuq_plan_set_comm)");
+    const int W = gpuq_comm_world(x.comm);
+    if (partition_count != W) throw Unsupported("RangeRepartitionExec: partition_count " + std::to_string(partition_count) + " != number of ranks " + std::to_string(W));
+    std::chrono::steady_clock::time_point t0;
+    PTable t, samp; PSchema ps;
+    std::vector<gpuq_column> cols; std::vector<gpuq_field_info> fields;
+    // ---- 1. sample
+    announce_failures(x, [&]() {
+      t = input->execute(part, x);
+      resolve(x, t);
+      t0 = std::chrono::steady_clock::now();
+      ps = plain_schema(t);
+      t = materialize(x, t, true);      // fixed-width layout: the pieces below are concatenated and sliced
+      const int64_t k = std::min<int64_t>(t.n, samples), stride = std::max<int64_t>(1, t.n / std::max<int64_t>(k, 1));
+      std::vector<uint32_t> idx((size_t)k); for (int64_t i = 0; i < k; ++i) idx[(size_t)i] = (uint32_t)(i * stride);
+      BufP di = upload_u32(x, idx);
+      samp = materialize(x, select_view(x, t, (const uint32_t*)di->p, k, di), true);
+      table_c_arrays(samp, cols, fields);
+      for (size_t i = 0; i < fields.size(); ++i) fields[i].nullable = ps[i].nullable ? 1 : 0;
+      return 0;
+    });
+    gpuq_table* gathered = nullptr;
+    xcheck(gpuq_allgather_table(x.comm, x.stream, cols.data(), fields.data(), (int)cols.size(), samp.n, &gathered));
+    // ---- 2. splitters -> range boundaries of the locally sorted run
+    PTable grouped; std::vector<int64_t> doff;
+    announce_failures(x, [&]() {
+      PTable all = table_from_owned(gathered, samp);
+      for (size_t i = 0; i < all.cols.size(); ++i) all.cols[i].nullable = ps[i].nullable;
+      PTable ssorted = materialize(x, sort_table(x, all, expr, -1, this, 0), true);
+      const int64_t m = ssorted.n;
+      std::vector<uint32_t> cut;
+      if (m > 0) for (int j = 1; j < W; ++j) cut.push_back((uint32_t)std::min<int64_t>(m - 1, std::max<int64_t>(0, (int64_t)j * m / W)));
+      std::vector<PTable> parts;
+      { PTable a = t; for (auto& c : a.cols) c.nullable = true; a.cols.push_back(tag_column(x, a.n, 0, a.keep)); a.sides.push_back(0); a.record_cap = 0; parts.push_back(a); }
+      if (!cut.empty()) {
+        BufP dc = upload_u32(x, cut);
+        PTable spl = materialize(x, select_view(x, ssorted, (const uint32_t*)dc->p, (int64_t)cut.size(), dc), true);
+        for (auto& c : spl.cols) c.nullable = true;
+        spl.cols.push_back(tag_column(x, spl.n, 1, spl.keep)); spl.sides.push_back(0); spl.record_cap = 0;
+        parts.push_back(spl);
+      }
+      PTable both = parts.size() == 1 ? parts[0] : concat_tables(x, parts);
+      Json keys = expr; keys.a.push_back(jobj({{"expr", jobj({{"column", jobj({{"name", jstr("__gpuq_splitter")}})}})}, {"asc", jbool(true)}, {"nulls_first", jbool(false)}}));
+      PTable run = sort_table(x, both, keys, -1, this, 1);
+      // positions of the splitters in the sorted run: filter on the tag, read the W-1 positions back
+      const Json tagc = jobj({{"column", jobj({{"name", jstr("__gpuq_splitter")}})}});
+      auto lit_i32 = [](int v) { return jobj({{"literal", jobj({{"type", jstr("Int32")}, {"value", jstr(std::to_string(v))}})}}); };
+      PTable run_m = materialize(x, run);
+      BufP sel; const int64_t ns = filter_sel(x, run_m, jobj({{"binary_expr", jobj({{"l", tagc}, {"r", lit_i32(1)}, {"op", jstr("=")}})}}), this, 2, sel);
+      std::vector<uint32_t> pos((size_t)ns);
+      if (ns > 0) { HIPCHECK(hipMemcpyAsync(pos.data(), sel->p, (size_t)ns * 4, hipMemcpyDeviceToHost, (hipStream_t)x.stream)); HIPCHECK(hipStreamSynchronize((hipStream_t)x.stream)); }
+      doff.assign(1, 0);
+      for (int64_t j = 0; j < ns; ++j) doff.push_back((int64_t)pos[(size_t)j] - j);      // boundaries in the run with the splitters taken out
+      while ((int)doff.size() < W) doff.push_back(t.n);                                  // (fewer splitters than ranks: empty ranges at the end)
+      doff.push_back(t.n);
+      PTable rows_only = filter_table(x, run_m, jobj({{"binary_expr", jobj({{"l", tagc}, {"r", lit_i32(0)}, {"op", jstr("=")}})}}), this, 3);
+      rows_only.cols.pop_back(); rows_only.sides.pop_back();
+      grouped = materialize(x, rows_only, true);
+      resolve(x, grouped);
+      table_c_arrays(grouped, cols, fields);
+      for (size_t i = 0; i < fields.size(); ++i) fields[i].nullable = ps[i].nullable ? 1 : 0;
+      return 0;
+    });
+    // ---- 3. one exchange of ranges, then an ordered fan-in of the received runs
+    gpuq_table* tab = nullptr;
+    xcheck(gpuq_exchange_partitions(x.comm, x.stream, cols.data(), fields.data(), (int)cols.size(), doff.data(), &tab));
+    PTable mine = table_from_owned(tab, grouped);
+    for (size_t i = 0; i < mine.cols.size(); ++i) mine.cols[i].nullable = ps[i].nullable;
+    std::vector<int64_t> pr((size_t)W, 0); int np = 0;
+    xcheck(gpuq_table_piece_rows(tab, pr.data(), W, &np));
+    std::vector<int64_t> offs{0}; for (int i = 0; i < np; ++i) offs.push_back(offs.back() + pr[(size_t)i]);
+    return timed(x, t0, merge_table(x, mine, offs, expr, -1, this, 4));
+  }
+};
+
 PNodeP build_node(const Json& j) {
   if (!j.is_obj() || j.o.size() != 1) throw std::runtime_error("plan: a node is an object with one key (the node type): " + j.dump().substr(0, 80));
   const std::string& kind = j.o[0].first; const Json& v = j.o[0].second;
@@ -1884,6 +1987,9 @@ PNodeP build_node(const Json& j) {
     auto n = std::make_unique<RepartitionExec>(); n->input = build_child(v, "input"); n->hash_expr = v.at("hash_expr"); n->partition_count = v.at("partition_count").i64(); out = std::move(n);
   } else if (kind == "BroadcastExec") {
     auto n = std::make_unique<BroadcastExec>(); n->input = build_child(v, "input"); out = std::move(n);
+  } else if (kind == "RangeRepartitionExec") {
+    auto n = std::make_unique<RangeRepartitionExec>(); n->input = build_child(v, "input"); n->expr = v.at("expr"); n->partition_count = v.at("partition_count").i64();
+    n->samples = v.get_i64("samples", 1024); out = std::move(n);
   } else if (kind == "ShuffleWriterExec") {
     auto n = std::make_unique<ShuffleWriterExec>(); n->input = build_child(v, "input");
     n->job_id = v.at("job_id").str(); n->stage_id = v.at("stage_id").i64(); n->work_dir = v.at("work_dir").str(); n->batch_rows = v.get_i64("batch_rows", 1 << 20);

@@ -91,6 +91,8 @@ def plan_to_json(node, tc, inputs):
         return {"LocalLimitExec": {"input": sub(node.input), "fetch": int(node.fetch)}}
     if isinstance(node, P.RepartitionExchangeExec):
         return {"RepartitionExec": {"input": sub(node.input), "hash_expr": list(node.hash_expr), "partition_count": int(node.partition_count)}}
+    if isinstance(node, P.RangeRepartitionExec):
+        return {"RangeRepartitionExec": {"input": sub(node.input), "expr": list(node.expr), "partition_count": int(node.partition_count), "samples": int(node.samples)}}
     if isinstance(node, P.BroadcastExec):
         return {"BroadcastExec": {"input": sub(node.input)}}
     if isinstance(node, P.ShuffleWriterExec):

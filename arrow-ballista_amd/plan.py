@@ -1031,6 +1031,16 @@ class BroadcastExec(ExchangeExec):
     """Every rank receives all ranks' rows (a CollectLeft build side read by every reduce task)."""
 
 
+class RangeRepartitionExec(ExchangeExec):
+    """Distributed SortExec (SURVEY.md section 8e "Sort"; the single-partition SortPreservingMergeExec stage of planner.rs:120-136 as
+    sample -> splitters -> ONE range exchange -> ordered fan-in of the received runs): this rank ends up with the `expr`-ordered rows
+    of one range; rank order is the global order."""
+
+    def __init__(self, input, expr, partition_count, samples=1024):
+        super().__init__(input)
+        self.expr, self.partition_count, self.samples = list(expr), int(partition_count), int(samples)
+
+
 def partition_perm(tc, table, hash_expr, partition_count):
     """(perm, offsets): driving positions grouped by partition (input order inside a partition) and the partition_count + 1
     boundaries as a host list -- gpuq_partition_run."""

@@ -588,6 +588,9 @@ void gpuq_comm_free(gpuq_comm* comm);
    exchange return GPUQ_ERR_PEER instead of hanging, and with status 0 everywhere it is the barrier that closes a deferred execution
    ("nobody has to redo anything").  A second, one-word round agrees on limits the counts imply (2^32 rows / 2 GiB of strings on a
    rank) before any payload moves; a failure inside the payload round aborts the communicator (ncclCommAbort).  Collective. */
+/* The rows an exchanged table received from rank 0, 1, ... (it holds them in this order): the run boundaries of an ordered fan-in
+   (gpuq_merge_run) after a range exchange.  n_out = number of ranks; rows_out may be NULL to ask for it. */
+int gpuq_table_piece_rows(const gpuq_table* t, int64_t* rows_out, int cap, int* n_out);
 int gpuq_comm_set_status(gpuq_comm* comm, int status);
 int gpuq_comm_announce(gpuq_comm* comm, void* stream);
 int gpuq_comm_rank(const gpuq_comm* comm);

@@ -40,6 +40,18 @@ def main():
         for jt in ("Inner", "Left"):
             res["join_" + jt] = rows(parallel.partitioned_hash_join(tc, ltab, rtab, [(col("k64", ls), col("r_k64", rs))], jt, comm=comm))
         res["bcast_rows"] = rows(parallel.broadcast_table(tc, g.plan.slice_table(tc, ltab, 0, 10 + rank), comm=comm))
+        # distributed SortExec through the native RangeRepartitionExec (config #5's shape): sample -> splitters -> one range exchange ->
+        # ordered fan-in; twice more deferred.  Sorted by (flag asc nulls last, dec desc nulls first), and by one Decimal128 key.
+        st = rand_table(1000 + rank, 3000 + 100 * rank, 0.2)
+        S = g.MemoryExec([st]); ss = S.schema()
+        for name, order in (("sort2", [{"expr": col("flag", ss), "asc": True, "nulls_first": False}, {"expr": col("dec", ss), "asc": False, "nulls_first": True}]),
+                            ("sort1", [{"expr": col("dec", ss), "asc": True, "nulls_first": False}])):
+            sp = g.NativePlan(g.RangeRepartitionExec(S, order, world, samples=64), tc)
+            sp.set_comm(comm)
+            first = [list(r) for r in arrow_rows(sp.execute(0).to_arrow())]
+            res["native_" + name] = first
+            again = [list(r) for r in arrow_rows(sp.execute(0).to_arrow())]
+            res["native_%s_again" % name] = [[int(again == first)]]
         # distributed q3 through the native executor: shards of the three generated tables
         n_li, n_cust = 60_000, 1500            # per rank / in total
         cols = ("l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate")

@@ -188,3 +188,21 @@ def test_native_distributed_plans_run_deferred_and_fail_together(native_ranks):
     e0, e1 = native_ranks[0]["peer_failure"][0], native_ranks[1]["peer_failure"][0]
     assert e0[0] == "GpuqError" and "15 bytes" in e0[1], e0
     assert e1[0] == "GpuqError" and "rank 0 failed" in e1[1], e1
+
+
+@pytest.mark.parametrize("name,order", [
+    ("sort2", [{"expr": {"column": {"name": "flag"}}, "asc": True, "nulls_first": False}, {"expr": {"column": {"name": "dec"}}, "asc": False, "nulls_first": True}]),
+    ("sort1", [{"expr": {"column": {"name": "dec"}}, "asc": True, "nulls_first": False}])])
+def test_native_range_partition_sort_is_the_sort_of_the_union(native_ranks, name, order):
+    """RangeRepartitionExec in the native executor (csrc/plan_exec.cpp; planner.rs:120-136's single-partition merge stage as a range
+    exchange): rank 0's rows followed by rank 1's are a permutation of the union in the oracle's key order, both ranges are populated,
+    and a second (deferred) execution returns the same rows."""
+    lts, _ = _shards()
+    ot = O.Table.from_arrow(pa.concat_tables(lts))
+    got = native_ranks[0]["native_" + name] + native_ranks[1]["native_" + name]
+    assert norm(got) == norm(_orows(ot))
+    gt = O.Table(ot.names, ot.types, [[r[c] for r in got] for c in range(len(ot.names))])
+    keys = O.sort_keys(gt, order)
+    assert all(keys[i] <= keys[i + 1] for i in range(len(keys) - 1))
+    assert all(len(r["native_" + name]) > 200 for r in native_ranks)
+    assert all(r["native_%s_again" % name] == [(1,)] for r in native_ranks)
