@@ -214,6 +214,9 @@ def main_q3():
             extra["sf100_q1"] = bench_extras.q1_pipeline(tc, T, g, 100)
             tp = bench_extras.tpch_pipelines(tc, T, g, 100)
             extra["sf100_q3"], extra["sf100_q5"] = tp["q3"], tp["q5"]
+            torch.cuda.empty_cache()
+            # BASELINE configs[4]: the per-GPU shard of the SF300 lineitem sort (the N>1 run below does the range exchange around it)
+            extra["sort_sf300_shard"] = bench_extras.sort_shard(tc, T, g)
         else:
             # second legs, every rank takes part: q3 with the build side of orders |x| lineitem BROADCAST instead (what a cost-based
             # planner picks when the build side is 20 x smaller: 1/60 of the bytes cross the links), distributed q5, and q1
@@ -236,7 +239,18 @@ def main_q3():
             tc.ctx.jit_wait()
             d5, r5 = timed_steps(lambda: p5.execute(0), k)
             extra["q5_partitioned_join"] = {"ms_per_step": d5 / k * 1e3, "lineitem_rows_per_s": rows_job * k / d5, "result_groups": r5.num_rows}
-            del p2, r2, p5, r5, su, li, od, cu
+            # BASELINE configs[4]: ORDER BY l_extendedprice across the ranks -- RangeRepartitionExec (sample -> splitters -> one range
+            # exchange -> ordered fan-in); every rank ends with one ascending range
+            from arrow_ballista_amd.expr import col as _col
+            lsrc = g.MemoryExec([g.DeviceTable([c for c in li.columns if c.name in ("l_orderkey", "l_extendedprice")], li.num_rows)])
+            lss = lsrc.schema()
+            ps_ = g.NativePlan(g.RangeRepartitionExec(lsrc, [{"expr": _col("l_extendedprice", lss), "asc": True, "nulls_first": False}], world), tc)
+            ps_.set_comm(comm)
+            for _ in range(2):
+                ps_.execute(0)
+            ds, rs_ = timed_steps(lambda: ps_.execute(0), k)
+            extra["sort_by_extendedprice_range_partitioned"] = {"ms_per_step": ds / k * 1e3, "lineitem_rows_per_s": rows_job * k / ds, "rows_on_rank0": rs_.num_rows}
+            del p2, r2, p5, r5, su, li, od, cu, ps_, rs_, lsrc
             torch.cuda.empty_cache()
             l1 = T.gen_lineitem_device(tc, n_li, row0=rank * n_li)
             p3 = g.NativePlan(T.q1_dist_plan(l1), tc)

@@ -512,6 +512,39 @@ def sort_micro(tc, T, g, log2n=27, reps=5):
     return out
 
 
+def sort_shard(tc, T, g, rows=224_998_637, reps=4):
+    """BASELINE configs[4] on one GPU: the shard an 8-GPU SF300 `lineitem ORDER BY l_extendedprice` leaves each GPU with (1,799,989,091 / 8
+    rows), key l_extendedprice Decimal128(15,2) + the l_orderkey payload, through the native executor's SortExec (deferred from the second
+    execution on).  Floor = SURVEY.md section 8d: N x (K + 8) x 2 bytes with K = 16 (one read and one write of key + row id)."""
+    import torch
+    from arrow_ballista_amd.expr import col
+    li = T.gen_lineitem_device(tc, rows, columns=("l_orderkey", "l_extendedprice"))
+    src = g.MemoryExec([li]); s = src.schema()
+    plan = g.NativePlan(g.SortExec([{"expr": col("l_extendedprice", s), "asc": True, "nulls_first": False}], src), tc)
+    ts = []
+    for r in range(reps + 1):
+        if r == 1:
+            plan.profile(True)
+        _sync(tc); t0 = time.perf_counter(); res = plan.execute(0); _sync(tc)
+        ts.append(time.perf_counter() - t0)
+    ops = plan.profile_all(); plan.profile(False)
+    perm_ms = sum(o.get("op_ms", 0.0) for o in ops if o["op"] == "sort") / max(1, reps)       # SortExec's own kernels: sample, pack, passes -> the permutation
+    st = plan.exec_stats()
+    # sortedness of the result (outside the timing): the key column of the result must be non-decreasing
+    t = res.to_device_table(tc.device)
+    kc = t.columns[[c.name for c in t.columns].index("l_extendedprice")]
+    k = kc.data[: 16 * t.num_rows].view(torch.int64)[0::2]
+    ok = bool((k[1:] >= k[:-1]).all().item()) and t.num_rows == rows
+    best = min(ts[1:])
+    floor = rows * (16 + 8) * 2
+    del res, t, li
+    torch.cuda.empty_cache()
+    return {"rows": rows, "ms_best": best * 1e3, "ms_first": ts[0] * 1e3, "rows_per_s": rows / best, "sorted": ok, "deferred": st["deferred"], "host_round_trips": st["settles"] + st["host_syncs"],
+            "floor_bytes": floor, "floor_GBs": floor / best / 1e9, "frac_hbm_peak": floor / best / 1e9 / 8000.0,
+            "permutation_ms": perm_ms, "permutation_frac_hbm_peak": (floor / (perm_ms * 1e-3) / 1e9 / 8000.0) if perm_ms > 0 else None,
+            "note": "ms_best = SortExec + the gather of key and payload into sorted order (random 8 / 16-byte reads: the larger part); permutation_ms = SortExec's own kernels"}
+
+
 def merge_micro(tc, T, g, log2n=27, runs=8, reps=3):
     """Ordered fan-in alone (gpuq_merge_run behind CoalesceTasksExec with an order): `runs` partitions of 2^log2n / runs rows, each
     already sorted by l_extendedprice, merged into one order; next to it the stable sort of their concatenation (what round 1 did)."""

@@ -20,15 +20,21 @@ def biggest(ds):
     return ds[: max(1, len(ds) // 2)]
 
 
-kern = "join_probe_unique"
-fetch = biggest(per_dispatch(sys.argv[1], "FETCH_SIZE", kern))
-write = biggest(per_dispatch(sys.argv[2], "WRITE_SIZE", kern))
+# round 3: the executor labels run-time compiled kernels with their plan node (gpuq_jit_join_probe_unique_probe_n3), and with the chain
+# fusion the lineitem probe is the only unique probe of a q3 step: every dispatch of the labelled kernel counts
+kern = "join_probe_unique_probe_n"
+fetch = per_dispatch(sys.argv[1], "FETCH_SIZE", kern)
+write = per_dispatch(sys.argv[2], "WRITE_SIZE", kern)
+if not fetch:
+    kern = "join_probe_unique"
+    fetch = biggest(per_dispatch(sys.argv[1], "FETCH_SIZE", kern))
+    write = biggest(per_dispatch(sys.argv[2], "WRITE_SIZE", kern))
 line = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1])
 f_kb = sum(e["v"] for e in fetch) / len(fetch)
 w_kb = sum(e["v"] for e in write) / len(write)
 alg = line["roofline"]["algorithmic_bytes_per_launch"]
 out = {
-    "kernel": "gpuq_jit_join_probe_unique (HashJoinExec probe of lineitem: fused l_shipdate filter + direct-addressed lookup + probe-ordered pair emit)",
+    "kernel": line["roofline"].get("kernel_name", "gpuq_jit_join_probe_unique") + " (HashJoinExec probe of lineitem: fused l_shipdate filter + direct-addressed lookup + probe-ordered pair emit)",
     "workload": line["config"]["workload"],
     "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras",
     "launches_averaged": {"FETCH_SIZE": len(fetch), "WRITE_SIZE": len(write)},
