@@ -319,6 +319,15 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
     if (a.get_bool("distinct", false)) throw Unsupported("DISTINCT aggregates are not supported on device");
     if (!is_final) {
       NodeP arg = a.has("expr") ? ec.from_json(a.at("expr")) : nullptr;
+      // per-aggregate FILTER (AggregateExecNode.filter_expr, datafusion.proto:1437-1450): agg(x) FILTER (WHERE p) is agg over the rows
+      // where p is true, i.e. agg(CASE WHEN p THEN x END) -- every accumulator here skips NULL arguments; COUNT(*) counts the 1s
+      if (a.has("filter") && !a.at("filter").is_null()) {
+        NodeP p = ec.from_json(a.at("filter"));
+        if (p->type.id != T_BOOL) throw std::runtime_error("aggregate FILTER must be boolean");
+        if (!arg) arg = ec.lit_int(t_of(T_INT64), 1);
+        arg = ec.select(p, arg, ec.lit_null(arg->type));
+        if (a.has("expr2")) throw Unsupported("FILTER on a two-argument aggregate");
+      }
       if (pl.fn == "COUNT") {
         if (!arg || !arg->nullable) pl.acc_cnt = find_or_add_acc(accs, ACC_COUNT_STAR, nullptr, t_of(T_INT64));
         else pl.acc_cnt = find_or_add_acc(accs, ACC_COUNT, arg, t_of(T_INT64));

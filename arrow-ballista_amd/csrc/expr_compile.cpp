@@ -1,5 +1,7 @@
 #include "expr_compile.h"
+#include "devbuf.h"
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <functional>
 #include <set>
@@ -379,6 +381,40 @@ NodeP ExprCompiler::from_json(const Json& e) {
     if (!acc) acc = lit_int(mk(T_BOOL), 0);
     return v.get_bool("negated", false) ? not_(acc) : acc;
   }
+  if (kind == "scalar_function") {
+    // PhysicalScalarFunctionNode (datafusion.proto: name, fun, args, return_type).  Two of the harness's functions are built:
+    //   date_part('YEAR' | 'MONTH' | 'DAY', Date32) -> Float64 (extract(year from l_shipdate): q7, q8, q9)
+    //   substr(Utf8, start [, len]) with literal start >= 1 / len >= 0, ASCII (substring(c_phone from 1 for 2): q22)
+    std::string nm = v.get_str("name", v.get_str("fun", ""));
+    for (auto& ch : nm) ch = (char)std::tolower((unsigned char)ch);
+    const auto& args = v.at("args").a;
+    auto lit_arg = [&](const Json& a, const char* what) -> const Json& {
+      if (!(a.is_obj() && a.o.size() == 1 && a.o[0].first == "literal" && a.o[0].second.find("value") && !a.o[0].second.at("value").is_null()))
+        throw Unsupported(std::string("scalar function ") + nm + ": " + what + " must be a non-NULL literal");
+      return a.o[0].second.at("value");
+    };
+    if (nm == "date_part" || nm == "datepart") {
+      if (args.size() != 2) throw std::runtime_error("date_part takes (part, date)");
+      std::string part = lit_arg(args[0], "the part").str();
+      for (auto& ch : part) ch = (char)std::toupper((unsigned char)ch);
+      const int which = part == "YEAR" ? 0 : part == "MONTH" ? 1 : part == "DAY" ? 2 : -1;
+      if (which < 0) throw Unsupported("date_part('" + part + "', ..): YEAR, MONTH and DAY are built");
+      NodeP x = from_json(args[1]);
+      if (x->type.id != T_DATE32) throw Unsupported("date_part over " + x->type.to_string() + " (Date32 is built)");
+      return cast(raw(OP_DATEPART, mk(T_INT64), x->nullable, 24, {x}, (uint32_t)which), mk(T_FLOAT64));      // [UPSTREAM-KNOWLEDGE] datafusion 34 date_part returns Float64
+    }
+    if (nm == "substr" || nm == "substring") {
+      if (args.size() != 2 && args.size() != 3) throw std::runtime_error("substr takes (string, start [, length])");
+      NodeP x = from_json(args[0]);
+      if (x->type.id != T_UTF8) throw Unsupported("substr over " + x->type.to_string());
+      const i128 start = parse_i128(lit_arg(args[1], "start").s);
+      const i128 len = args.size() == 3 ? parse_i128(lit_arg(args[2], "length").s) : (i128)255;
+      if (start < 1 || start > 16) throw Unsupported("substr: a start outside 1..16 (the packed form holds 15 bytes)");
+      if (len < 0 || (args.size() == 3 && len > 15)) throw Unsupported("substr: a length outside 0..15");
+      return raw(OP_SUBSTR, mk(T_UTF8), x->nullable, 127, {x}, (uint32_t)(start - 1) | ((uint32_t)len << 8));
+    }
+    throw Unsupported("scalar function '" + nm + "' is not built on the device (date_part, substr are)");
+  }
   if (kind == "case_") {
     NodeP base = v.has("expr") ? from_json(v.at("expr")) : nullptr;
     NodeP acc = v.has("else_expr") ? from_json(v.at("else_expr")) : lit_null(mk(T_NULL));
@@ -450,7 +486,9 @@ CompiledProgram ExprCompiler::finish() {
         if (!is_this(rep(n->ch[k].get()))) continue;
         if (n->op == OP_ISNULL || n->op == OP_ISNOTNULL) continue;
         const bool eq_lit = (n->op == OP_EQ || n->op == OP_NE) && n->ch.size() == 2 && rep(n->ch[1 - k].get())->kind == Node::LIT;
-        if (!eq_lit) loose = false;
+        // a substring that lies inside the first 15 bytes is exact whatever the value's length (the packed form holds them all)
+        const bool prefix_substr = n->op == OP_SUBSTR && ((n->imm >> 8) & 0xFFu) != 255u && (n->imm & 0xFFu) + ((n->imm >> 8) & 0xFFu) <= 15u;
+        if (!eq_lit && !prefix_substr) loose = false;
       }
     }
     C.col_loose[c] = loose;
@@ -737,6 +775,14 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
         break;
       }
       case OP_SHL: e = "(i128)((u128)" + as128(a) + " << " + std::to_string(n->imm) + ")"; ne = N(a); break;
+      case OP_DATEPART: e = "date_part_of_days((i64)" + V(a) + ", " + std::to_string(n->imm) + ")"; ne = N(a); break;
+      case OP_SUBSTR: {
+        L("bool " + t + "_bad = false; const u128 " + t + "_x = substr_packed(((u128)" + V(a) + "_hi << 64) | (u128)" + V(a) + "_lo, " + std::to_string(n->imm & 0xFFu) + "u, " +
+          std::to_string((n->imm >> 8) & 0xFFu) + "u, " + t + "_bad);");
+        L("if (" + t + "_bad && !(" + N(a) + ") && P.flags) atomicOr(P.flags, FLAG_STR_TRUNC);");
+        L("const u64 " + t + "_lo = (u64)" + t + "_x, " + t + "_hi = (u64)(" + t + "_x >> 64);");
+        two_vars = true; ne = N(a); break;
+      }
       case OP_BOR: e = "(" + as128(a) + " | " + as128(b) + ")"; break;
       case OP_NULLIF0: {
         Node* rb = rep(b.get());

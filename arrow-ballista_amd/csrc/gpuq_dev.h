@@ -29,8 +29,8 @@ typedef unsigned __int128 u128;
 
 constexpr int MAX_COLS = 16;   // input columns referenced by one program
 constexpr int NREG = 16;       // 128-bit virtual registers per lane
-constexpr int MAX_INSNS = 96;
-constexpr int MAX_IMMS = 16;
+constexpr int MAX_INSNS = 192;   // (q19's JoinFilter: three OR-ed groups of six conjuncts over twelve container names)
+constexpr int MAX_IMMS = 48;
 constexpr int MAX_VIA = 3;     // index vectors (selection / join pair sides)
 constexpr uint32_t NULL_ROW = 0xFFFFFFFFu;  // index-vector entry meaning "no row" (outer join)
 
@@ -70,6 +70,8 @@ enum Op : uint8_t {
   OP_BOR,     // dst <- a | b      (bitwise; key packing)
   OP_NULLIF0, // dst <- a, NULL when b == 0 (guards OP_DIV by zero -> NULL)
   OP_COALESCE0, // dst <- a, or 0 (non-null) when a is NULL
+  OP_DATEPART,  // dst <- field imm (0 year, 1 month, 2 day) of the Date32 a (days since 1970-01-01), as an integer
+  OP_SUBSTR,    // dst <- substr(a, start, len) of a packed Utf8 value, ASCII only; imm = (start - 1) | len << 8 (len 255 = to the end)
 };
 
 struct DevInsn { uint8_t op, dst, a, b; uint32_t imm; };
@@ -138,6 +140,36 @@ __device__ __forceinline__ i64 f64_total_key(u64 bits) {
   // IEEE-754 totalOrder as a signed integer compare [UPSTREAM-KNOWLEDGE: arrow-ord 49 cmp kernels]
   i64 s = (i64)bits;
   return s ^ (i64)((u64)(s >> 63) >> 1);
+}
+
+// Calendar field of a day number (proleptic Gregorian; the days-from-civil inverse) [UPSTREAM-KNOWLEDGE: arrow-arith 49 temporal
+// kernels behind datafusion's date_part]: which = 0 year, 1 month (1-12), 2 day of month (1-31).
+__device__ __forceinline__ i64 date_part_of_days(i64 days, int which) {
+  const i64 z = days + 719468;
+  const i64 era = (z >= 0 ? z : z - 146096) / 146097;
+  const i64 doe = z - era * 146097;                                           // [0, 146096]
+  const i64 yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;      // [0, 399]
+  const i64 doy = doe - (365 * yoe + yoe / 4 - yoe / 100);                    // [0, 365]
+  const i64 mp = (5 * doy + 2) / 153;                                         // [0, 11]
+  const i64 d = doy - (153 * mp + 2) / 5 + 1;
+  const i64 m = mp < 10 ? mp + 3 : mp - 9;
+  const i64 y = yoe + era * 400 + (m <= 2 ? 1 : 0);
+  return which == 0 ? y : (which == 1 ? m : d);
+}
+// substr over the packed form (<= 15 bytes big-endian in bits 127..8, true length in bits 7..0): `skip` leading bytes dropped, at most
+// `len` kept (255 = the rest).  Exact whenever skip + kept <= 15 even for a longer value (its first 15 bytes are all there); `bad`
+// is raised when bytes beyond the packed prefix would be needed, or when a kept byte is not ASCII (SQL counts characters).
+__device__ __forceinline__ u128 substr_packed(u128 x, uint32_t skip, uint32_t len, bool& bad) {
+  const uint32_t L = (uint32_t)x & 0xFFu;
+  uint32_t keep = L > skip ? L - skip : 0u;
+  if (len != 255u && keep > len) keep = len;
+  if (skip + keep > 15u) { bad = true; keep = skip < 15u ? 15u - skip : 0u; }
+  const u128 body = (x >> 8) << 8;                                   // bytes only
+  const u128 shifted = skip >= 16u ? (u128)0 : (body << (8u * skip));
+  const u128 mask = keep ? (~(u128)0 << (128u - 8u * keep)) : (u128)0;
+  const u128 out = shifted & mask;
+  if ((out >> 8) & ((u128)0x80808080808080ull << 64 | (u128)0x8080808080808080ull)) bad = true;
+  return out | (u128)keep;
 }
 
 // Truncating signed 128-bit division (hardware has none; the AMDGPU backend has no __divti3).
@@ -365,6 +397,9 @@ __device__ __forceinline__ void run_program(const DevProgram& P, GPUQ_REGS_PARAM
         zn = t ? bn : (bool)((rnulls >> e) & 1); break;
       }
       case OP_SHL: { u128 z = (u128)mk128(alo, ahi) << imm; zlo = (u64)z; zhi = (u64)(z >> 64); zn = an; break; }
+      case OP_DATEPART: { const i64 z = date_part_of_days((i64)alo, (int)imm); zlo = (u64)z; zhi = (u64)(z >> 63); zn = an; break; }
+      case OP_SUBSTR: { bool bad = false; const u128 z = substr_packed((u128)mk128(alo, ahi), imm & 0xFFu, (imm >> 8) & 0xFFu, bad); zlo = (u64)z; zhi = (u64)(z >> 64); zn = an;
+                        if (bad && !an && P.flags) atomicOr(P.flags, FLAG_STR_TRUNC); break; }
       case OP_BOR: zlo = alo | blo; zhi = ahi | bhi; break;
       case OP_NULLIF0: zlo = alo; zhi = ahi; zn = an || bn || (blo == 0 && bhi == 0); break;
       case OP_COALESCE0: zlo = an ? 0 : alo; zhi = an ? 0 : ahi; zn = false; break;

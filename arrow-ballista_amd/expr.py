@@ -105,6 +105,20 @@ def like(e, pattern, negated=False, case_insensitive=False):
                           "pattern": pattern if isinstance(pattern, dict) else lit(pattern)}}
 
 
+def scalar_function(name, args):
+    """PhysicalScalarFunctionNode (datafusion.proto): built on the device are date_part('YEAR' | 'MONTH' | 'DAY', Date32) -> Float64 and
+    substr(Utf8, start [, length]) with literal bounds (ASCII)."""
+    return {"scalar_function": {"name": name, "args": list(args)}}
+
+
+def date_part(part, e):
+    return scalar_function("date_part", [lit(part), e])
+
+
+def substr(e, start, length=None):
+    return scalar_function("substr", [e, lit(int(start), "Int64")] + ([lit(int(length), "Int64")] if length is not None else []))
+
+
 def case(when_then, else_expr=None, expr=None):
     return {"case_": {"expr": expr, "when_then_expr": [{"when_expr": w, "then_expr": t} for w, t in when_then],
                       "else_expr": else_expr}}

@@ -584,7 +584,7 @@ class AggregateExec(ExecutionPlan):
     def _descriptor(self, schema, pred, m):
         d = {"op": "aggregate", "mode": self.mode, "input": {"fields": schema}, "strategy": self.strategy,
              "group_expr": [{"expr": E.rebind(_inl(e, m), schema), "name": n} for e, n in self.group_expr],
-             "aggr_expr": [dict(fn=a["fn"], name=a["name"], **{k: E.rebind(_inl(a[k], m), schema) for k in ("expr", "expr2") if a.get(k) is not None})
+             "aggr_expr": [dict(fn=a["fn"], name=a["name"], **{k: E.rebind(_inl(a[k], m), schema) for k in ("expr", "expr2", "filter") if a.get(k) is not None})
                            for a in self.aggr_expr]}
         if pred is not None:
             d["predicate"] = E.rebind(pred, schema)

@@ -372,3 +372,176 @@ def q5_dist_plan(customer, orders, lineitem, supplier, nation, region, world):
     fin = g.AggregateExec("Final", [(col("n_name", fs), "n_name")], [dict(a, expr=None) for a in aggs], g.BroadcastExec(part))
     as_ = fin.schema()
     return g.SortExec([{"expr": col("revenue", as_), "asc": False, "nulls_first": True}], fin)
+
+
+# ------------------------------------------------------------------ more of the harness's queries (benchmarks/queries/q{6,7,12,14,16,19,22}.sql)
+# Physical plans in the shape DataFusion builds (build sides on the LEFT, filters below the joins, computed aggregate arguments in a
+# ProjectionExec below the AggregateExec).  Sources are MemoryExec nodes over tables with the reference's column names and types
+# (benchmarks/src/bin/tpch.rs:864-957); tests/test_gpu_tpch_more.py runs them over small generated tables against plain Python.
+D_1994, D_1995, D_1995_09, D_1995_10, D_1996_12_31, D_1995_01 = 8766, 9131, 9374, 9404, 9861, 9131
+
+
+def _dec_lit(unscaled, p=15, s=2):
+    from arrow_ballista_amd.expr import lit
+    return lit(unscaled, ("Decimal128", p, s))
+
+
+def _revenue(schema):
+    from arrow_ballista_amd.expr import col, lit, binary, Operator as Op
+    return binary(col("l_extendedprice", schema), Op.Multiply, binary(lit(1, ("Decimal128", 20, 0)), Op.Minus, col("l_discount", schema)))
+
+
+def q6_plan(lineitem):
+    """q6.sql: one filter, SUM(l_extendedprice * l_discount)."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, Operator as Op
+    s = lineitem.schema()
+    pred = and_(binary(col("l_shipdate", s), Op.GtEq, lit(D_1994, "Date32")), binary(col("l_shipdate", s), Op.Lt, lit(D_1995, "Date32")),
+                binary(col("l_discount", s), Op.GtEq, _dec_lit(5)), binary(col("l_discount", s), Op.LtEq, _dec_lit(7)),
+                binary(col("l_quantity", s), Op.Lt, _dec_lit(2400)))
+    f = g.FilterExec(pred, lineitem)
+    return g.AggregateExec("Single", [], [{"fn": "SUM", "expr": binary(col("l_extendedprice", s), Op.Multiply, col("l_discount", s)), "name": "revenue"}], g.CoalesceBatchesExec(f))
+
+
+def q12_plan(orders, lineitem):
+    """q12.sql: lineitem |x| orders, two SUM(CASE ..) by l_shipmode, ORDER BY l_shipmode."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, or_, in_list, case, Operator as Op
+    os_, ls = orders.schema(), lineitem.schema()
+    pred = and_(in_list(col("l_shipmode", ls), [lit("MAIL"), lit("SHIP")]), binary(col("l_commitdate", ls), Op.Lt, col("l_receiptdate", ls)),
+                binary(col("l_shipdate", ls), Op.Lt, col("l_commitdate", ls)), binary(col("l_receiptdate", ls), Op.GtEq, lit(D_1994, "Date32")),
+                binary(col("l_receiptdate", ls), Op.Lt, lit(D_1995, "Date32")))
+    l = g.FilterExec(pred, lineitem)
+    j = g.HashJoinExec(orders, g.CoalesceBatchesExec(l), [(col("o_orderkey", os_), col("l_orderkey", ls))], None, "Inner", "CollectLeft", False)
+    js = j.schema()
+    urgent = or_(binary(col("o_orderpriority", js), Op.Eq, lit("1-URGENT")), binary(col("o_orderpriority", js), Op.Eq, lit("2-HIGH")))
+    not_urgent = and_(binary(col("o_orderpriority", js), Op.NotEq, lit("1-URGENT")), binary(col("o_orderpriority", js), Op.NotEq, lit("2-HIGH")))
+    proj = g.ProjectionExec([(col("l_shipmode", js), "l_shipmode"), (case([(urgent, lit(1))], lit(0)), "hi"), (case([(not_urgent, lit(1))], lit(0)), "lo")], j)
+    ps = proj.schema()
+    agg = g.AggregateExec("Single", [(col("l_shipmode", ps), "l_shipmode")],
+                          [{"fn": "SUM", "expr": col("hi", ps), "name": "high_line_count"}, {"fn": "SUM", "expr": col("lo", ps), "name": "low_line_count"}], proj)
+    as_ = agg.schema()
+    return g.SortExec([{"expr": col("l_shipmode", as_), "asc": True, "nulls_first": False}], agg)
+
+
+def q14_plan(part, lineitem):
+    """q14.sql: lineitem |x| part, the two sums (promo revenue and revenue) and 100.00 * promo / total."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, like, case, Operator as Op
+    ps_, ls = part.schema(), lineitem.schema()
+    l = g.FilterExec(and_(binary(col("l_shipdate", ls), Op.GtEq, lit(D_1995_09, "Date32")), binary(col("l_shipdate", ls), Op.Lt, lit(D_1995_10, "Date32"))), lineitem)
+    j = g.HashJoinExec(part, g.CoalesceBatchesExec(l), [(col("p_partkey", ps_), col("l_partkey", ls))], None, "Inner", "CollectLeft", False)
+    js = j.schema()
+    rev = _revenue(js)
+    proj = g.ProjectionExec([(case([(like(col("p_type", js), "PROMO%"), rev)], lit(0, ("Decimal128", 38, 4))), "promo"), (rev, "rev")], j)
+    ps = proj.schema()
+    agg = g.AggregateExec("Single", [], [{"fn": "SUM", "expr": col("promo", ps), "name": "promo_sum"}, {"fn": "SUM", "expr": col("rev", ps), "name": "rev_sum"}], proj)
+    as_ = agg.schema()
+    ratio = binary(binary(lit(10000, ("Decimal128", 5, 2)), Op.Multiply, col("promo_sum", as_)), Op.Divide, col("rev_sum", as_))
+    return g.ProjectionExec([(ratio, "promo_revenue"), (col("promo_sum", as_), "promo_sum"), (col("rev_sum", as_), "rev_sum")], agg)
+
+
+def q19_plan(part, lineitem):
+    """q19.sql: lineitem |x| part on the key; the three OR-ed groups are the join's filter (JoinFilter over both sides' columns);
+    l_shipinstruct = 'DELIVER IN PERSON' is a literal beyond 15 bytes (runs as LIKE without wildcards)."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, or_, in_list, Operator as Op
+    ps_, ls = part.schema(), lineitem.schema()
+    # what all three groups share goes below the join (DataFusion pushes it there)
+    l = g.FilterExec(and_(in_list(col("l_shipmode", ls), [lit("AIR"), lit("AIR REG")]), binary(col("l_shipinstruct", ls), Op.Eq, lit("DELIVER IN PERSON"))), lineitem)
+    j0 = g.HashJoinExec(part, g.CoalesceBatchesExec(l), [(col("p_partkey", ps_), col("l_partkey", ls))], None, "Inner", "CollectLeft", False)
+    js = j0.schema()
+
+    def grp(brand, containers, qlo, size_hi):
+        return and_(binary(col("p_brand", js), Op.Eq, lit(brand)), in_list(col("p_container", js), [lit(c) for c in containers]),
+                    binary(col("l_quantity", js), Op.GtEq, _dec_lit(qlo * 100)), binary(col("l_quantity", js), Op.LtEq, _dec_lit((qlo + 10) * 100)),
+                    binary(col("p_size", js), Op.GtEq, lit(1, "Int32")), binary(col("p_size", js), Op.LtEq, lit(size_hi, "Int32")))
+    filt = or_(grp("Brand#12", ("SM CASE", "SM BOX", "SM PACK", "SM PKG"), 1, 5), grp("Brand#23", ("MED BAG", "MED BOX", "MED PKG", "MED PACK"), 10, 10),
+               grp("Brand#34", ("LG CASE", "LG BOX", "LG PACK", "LG PKG"), 20, 15))
+    j = g.HashJoinExec(part, g.CoalesceBatchesExec(l), [(col("p_partkey", ps_), col("l_partkey", ls))], filt, "Inner", "CollectLeft", False)
+    return g.AggregateExec("Single", [], [{"fn": "SUM", "expr": _revenue(js), "name": "revenue"}], j)
+
+
+def q16_plan(supplier, part, partsupp):
+    """q16.sql: partsupp |x| part, NOT IN (complaining suppliers) as a RightAnti join, COUNT(DISTINCT ps_suppkey) by (p_brand, p_type,
+    p_size), ORDER BY supplier_cnt DESC, p_brand, p_type, p_size.  p_type is longer than 15 bytes: dictionary-coded group keys."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, in_list, like, Operator as Op
+    ss, ps_, pss = supplier.schema(), part.schema(), partsupp.schema()
+    p = g.FilterExec(and_(binary(col("p_brand", ps_), Op.NotEq, lit("Brand#45")), like(col("p_type", ps_), "MEDIUM POLISHED%", negated=True),
+                          in_list(col("p_size", ps_), [lit(v, "Int32") for v in (49, 14, 23, 45, 19, 3, 36, 9)])), part)
+    j1 = g.HashJoinExec(g.CoalesceBatchesExec(p), partsupp, [(col("p_partkey", ps_), col("ps_partkey", pss))], None, "Inner", "CollectLeft", False)
+    j1s = j1.schema()
+    bad = g.ProjectionExec([(col("s_suppkey", ss), "s_suppkey")], g.FilterExec(like(col("s_comment", ss), "%Customer%Complaints%"), supplier))
+    bs = bad.schema()
+    j2 = g.HashJoinExec(bad, j1, [(col("s_suppkey", bs), col("ps_suppkey", j1s))], None, "RightAnti", "CollectLeft", False)
+    j2s = j2.schema()
+    agg = g.AggregateExec("Single", [(col("p_brand", j2s), "p_brand"), (col("p_type", j2s), "p_type"), (col("p_size", j2s), "p_size")],
+                          [{"fn": "COUNT", "expr": col("ps_suppkey", j2s), "name": "supplier_cnt", "distinct": True}], j2)
+    as_ = agg.schema()
+    return g.SortExec([{"expr": col("supplier_cnt", as_), "asc": False, "nulls_first": True}, {"expr": col("p_brand", as_), "asc": True, "nulls_first": False},
+                       {"expr": col("p_type", as_), "asc": True, "nulls_first": False}, {"expr": col("p_size", as_), "asc": True, "nulls_first": False}], agg)
+
+
+Q22_CODES = ("13", "31", "23", "29", "30", "18", "17")
+
+
+def q22_avg_plan(customer):
+    """q22.sql's scalar subquery: AVG(c_acctbal) over the positive balances of the seven country codes (run first; its value is a
+    literal of the main plan -- the reference's planner turns the uncorrelated scalar subquery into a join with a one-row side)."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, in_list, substr, Operator as Op
+    cs = customer.schema()
+    f = g.FilterExec(and_(binary(col("c_acctbal", cs), Op.Gt, _dec_lit(0)), in_list(substr(col("c_phone", cs), 1, 2), [lit(c) for c in Q22_CODES])), customer)
+    return g.AggregateExec("Single", [], [{"fn": "AVG", "expr": col("c_acctbal", cs), "name": "avg_bal"}], g.CoalesceBatchesExec(f))
+
+
+def q22_plan(orders, customer, avg_unscaled):
+    """q22.sql with the subquery's value in (Decimal128(19,6) unscaled): customers of the seven country codes with an above-average
+    balance and NO order (RightAnti against orders' customer keys), COUNT(*) and SUM(c_acctbal) by country code."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, in_list, substr, cast, Operator as Op
+    os_, cs = orders.schema(), customer.schema()
+    code = substr(col("c_phone", cs), 1, 2)
+    f = g.FilterExec(and_(in_list(code, [lit(c) for c in Q22_CODES]),
+                          binary(cast(col("c_acctbal", cs), ("Decimal128", 19, 6)), Op.Gt, lit(avg_unscaled, ("Decimal128", 19, 6)))), customer)
+    okeys = g.ProjectionExec([(col("o_custkey", os_), "o_custkey")], orders)
+    ks = okeys.schema()
+    j = g.HashJoinExec(okeys, g.CoalesceBatchesExec(f), [(col("o_custkey", ks), col("c_custkey", cs))], None, "RightAnti", "CollectLeft", False)
+    js = j.schema()
+    proj = g.ProjectionExec([(substr(col("c_phone", js), 1, 2), "cntrycode"), (col("c_acctbal", js), "c_acctbal")], j)
+    ps = proj.schema()
+    agg = g.AggregateExec("Single", [(col("cntrycode", ps), "cntrycode")], [{"fn": "COUNT", "expr": lit(1), "name": "numcust"}, {"fn": "SUM", "expr": col("c_acctbal", ps), "name": "totacctbal"}], proj)
+    as_ = agg.schema()
+    return g.SortExec([{"expr": col("cntrycode", as_), "asc": True, "nulls_first": False}], agg)
+
+
+def q7_plan(supplier, lineitem, orders, customer, nation):
+    """q7.sql: supplier |x| lineitem |x| orders |x| customer |x| nation n1 |x| nation n2, the (FRANCE, GERMANY) pair either way round,
+    extract(year from l_shipdate) as a group key (date_part -> Float64), SUM(volume), ORDER BY the three keys."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, or_, in_list, date_part, Operator as Op
+    ss, ls, os_, cs, ns = supplier.schema(), lineitem.schema(), orders.schema(), customer.schema(), nation.schema()
+    two = in_list(col("n_name", ns), [lit("FRANCE"), lit("GERMANY")])
+    n1 = g.ProjectionExec([(col("n_nationkey", ns), "n1_key"), (col("n_name", ns), "supp_nation")], g.FilterExec(two, nation))
+    n2 = g.ProjectionExec([(col("n_nationkey", ns), "n2_key"), (col("n_name", ns), "cust_nation")], g.FilterExec(two, nation))
+    n1s, n2s = n1.schema(), n2.schema()
+    sj = g.HashJoinExec(n1, supplier, [(col("n1_key", n1s), col("s_nationkey", ss))], None, "Inner", "CollectLeft", False)          # suppliers of the two nations
+    sjs = sj.schema()
+    l = g.FilterExec(and_(binary(col("l_shipdate", ls), Op.GtEq, lit(D_1995_01, "Date32")), binary(col("l_shipdate", ls), Op.LtEq, lit(D_1996_12_31, "Date32"))), lineitem)
+    lj = g.HashJoinExec(sj, g.CoalesceBatchesExec(l), [(col("s_suppkey", sjs), col("l_suppkey", ls))], None, "Inner", "CollectLeft", False)
+    ljs = lj.schema()
+    cj = g.HashJoinExec(n2, customer, [(col("n2_key", n2s), col("c_nationkey", cs))], None, "Inner", "CollectLeft", False)          # customers of the two nations
+    cjs = cj.schema()
+    oj = g.HashJoinExec(cj, orders, [(col("c_custkey", cjs), col("o_custkey", os_))], None, "Inner", "CollectLeft", False)
+    ojs = oj.schema()
+    pair = or_(and_(binary(col("supp_nation", ljs), Op.Eq, lit("FRANCE")), binary(col("cust_nation", ojs), Op.Eq, lit("GERMANY"))),
+               and_(binary(col("supp_nation", ljs), Op.Eq, lit("GERMANY")), binary(col("cust_nation", ojs), Op.Eq, lit("FRANCE"))))
+    j = g.HashJoinExec(oj, lj, [(col("o_orderkey", ojs), col("l_orderkey", ljs))], pair, "Inner", "CollectLeft", False)
+    js = j.schema()
+    proj = g.ProjectionExec([(col("supp_nation", js), "supp_nation"), (col("cust_nation", js), "cust_nation"), (date_part("YEAR", col("l_shipdate", js)), "l_year"),
+                             (_revenue(js), "volume")], j)
+    ps = proj.schema()
+    agg = g.AggregateExec("Single", [(col(n, ps), n) for n in ("supp_nation", "cust_nation", "l_year")], [{"fn": "SUM", "expr": col("volume", ps), "name": "revenue"}], proj)
+    as_ = agg.schema()
+    return g.SortExec([{"expr": col(n, as_), "asc": True, "nulls_first": False} for n in ("supp_nation", "cust_nation", "l_year")], agg)

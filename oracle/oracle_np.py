@@ -243,6 +243,24 @@ def eval_expr(e, tab):
             bv = _cast(bv, bt, rt) if bt != "Null" else [None] * n
             out = [bv[i] if cond[i] else out[i] for i in range(n)]
         return rt, out
+    if kind == "scalar_function":
+        # PhysicalScalarFunctionNode.  date_part [UPSTREAM-KNOWLEDGE: datafusion 34 returns Float64; arrow-arith 49 temporal kernels]
+        # and substr (1-based start, characters) -- the two functions TPC-H q7-q9 / q22 need (benchmarks/queries/q7.sql:11, q22.sql:8)
+        nm = v["name"].lower()
+        if nm in ("date_part", "datepart"):
+            import datetime
+            part = v["args"][0]["literal"]["value"].upper()
+            _, vals = eval_expr(v["args"][1], tab)
+            def f(d):
+                x = datetime.date(1970, 1, 1) + datetime.timedelta(days=int(d))
+                return float({"YEAR": x.year, "MONTH": x.month, "DAY": x.day}[part])
+            return "Float64", [None if d is None else f(d) for d in vals]
+        if nm in ("substr", "substring"):
+            _, vals = eval_expr(v["args"][0], tab)
+            start = int(v["args"][1]["literal"]["value"])
+            ln = int(v["args"][2]["literal"]["value"]) if len(v["args"]) > 2 else None
+            return "Utf8", [None if x is None else (x[start - 1:] if ln is None else x[start - 1: start - 1 + ln]) for x in vals]
+        raise NotImplementedError(nm)
     if kind == "binary_expr":
         op = _OPS.get(v["op"], v["op"])
         lt, lv = eval_expr(v["l"], tab)
@@ -411,6 +429,21 @@ def aggregate(tab, group_exprs, aggs, mode="Single", predicate=None):
                 at, av = "Int64", [1] * tab.n
             else:
                 at, av = eval_expr(a["expr"], tab)
+            if a.get("filter") is not None:
+                # agg(x) FILTER (WHERE p): only the rows where p is TRUE take part (AggregateExecNode.filter_expr, datafusion.proto:1437-1450)
+                _, fv_ = eval_expr(a["filter"], tab)
+                av = [x if f is True else None for x, f in zip(av, fv_)]
+            if a.get("distinct"):
+                # agg(DISTINCT x): every value counts once per group (NULLs never count)
+                seen_ = {}
+                for k_ in order:
+                    s_ = set()
+                    for i in groups[k_]:
+                        if av[i] is not None and av[i] in s_:
+                            seen_[i] = True
+                        elif av[i] is not None:
+                            s_.add(av[i])
+                av = [None if seen_.get(i) else x for i, x in enumerate(av)]
             if fn == "COUNT":
                 names.append(a["name"] + ("[count]" if mode == "Partial" else "")); types.append("Int64")
                 cols.append([sum(1 for i in groups[k] if av[i] is not None) for k in order])

@@ -1,0 +1,208 @@
+"""More of the harness's 22 queries through the native executor (benchmarks/tpch.py: q6, q7, q12, q14, q16, q19, q22 -- with q1, q3, q5
+ten of them), over small generated tables with the reference's column names and types, against the same queries written as plain
+Python over the host rows.  What they exercise beyond q1 / q3 / q5: date_part (extract(year ..)), substr, COUNT(DISTINCT), LIKE /
+NOT LIKE inside plans, a JoinFilter of OR-ed conjunctions over both sides, RightAnti joins (NOT IN / NOT EXISTS), a literal beyond
+15 bytes, long Utf8 group and sort keys, decimal division.  Every plan also runs twice more deferred (native_rows)."""
+import collections
+import datetime
+import decimal
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import arrow_ballista_amd as g
+import tpch_util as T
+from oracle import oracle_np as O
+from test_gpu_native_plan import native_rows
+
+pytestmark = pytest.mark.gpu
+D = decimal.Decimal
+
+
+def _dec(vals, scale=2):
+    return pa.array([D(int(v)).scaleb(-scale) for v in vals], pa.decimal128(15, scale))
+
+
+def _date(days):
+    return pa.array(np.asarray(days, np.int32), pa.int32()).cast(pa.date32())
+
+
+@pytest.fixture(scope="module")
+def db():
+    r = np.random.default_rng(77)
+    n_part, n_supp, n_cust, n_ord, n_li = 400, 60, 300, 3000, 12000
+    nations = [n for n, _ in T.NATIONS]
+    brands = ["Brand#%d%d" % (a, b) for a in range(1, 6) for b in range(1, 6)]
+    types = ["%s %s %s" % (a, b, c) for a in ("STANDARD", "SMALL", "MEDIUM", "LARGE", "ECONOMY", "PROMO") for b in ("ANODIZED", "BURNISHED", "PLATED", "POLISHED", "BRUSHED") for c in ("TIN", "NICKEL", "BRASS", "STEEL", "COPPER")]
+    containers = ["%s %s" % (a, b) for a in ("SM", "LG", "MED", "JUMBO", "WRAP") for b in ("CASE", "BOX", "BAG", "JAR", "PKG", "PACK", "CAN", "DRUM")]
+    t = {}
+    t["nation"] = pa.table({"n_nationkey": pa.array(np.arange(25), pa.int64()), "n_name": pa.array(nations)})
+    t["part"] = pa.table({"p_partkey": pa.array(np.arange(1, n_part + 1), pa.int64()), "p_brand": pa.array([brands[i] for i in r.integers(0, 25, n_part)]),
+                          "p_type": pa.array([types[i] for i in r.integers(0, len(types), n_part)]), "p_size": pa.array(r.integers(1, 51, n_part).astype(np.int32)),
+                          "p_container": pa.array([containers[i] for i in r.integers(0, len(containers), n_part)])})
+    comments = ["quick deposits", "Customer service Complaints pending", "carefully Customer ironic Complaints", "regular packages", "final Customer accounts"]
+    t["supplier"] = pa.table({"s_suppkey": pa.array(np.arange(1, n_supp + 1), pa.int64()), "s_nationkey": pa.array(r.integers(0, 25, n_supp), pa.int64()),
+                              "s_comment": pa.array([comments[i] for i in r.integers(0, len(comments), n_supp)])})
+    t["partsupp"] = pa.table({"ps_partkey": pa.array(np.repeat(np.arange(1, n_part + 1), 4), pa.int64()), "ps_suppkey": pa.array(r.integers(1, n_supp + 1, n_part * 4), pa.int64())})
+    phones = ["%02d-%03d-%03d-%04d" % (c, a, b, d) for c, a, b, d in zip(r.integers(10, 35, n_cust), r.integers(100, 999, n_cust), r.integers(100, 999, n_cust), r.integers(1000, 9999, n_cust))]
+    t["customer"] = pa.table({"c_custkey": pa.array(np.arange(1, n_cust + 1), pa.int64()), "c_nationkey": pa.array(r.integers(0, 25, n_cust), pa.int64()),
+                              "c_phone": pa.array(phones), "c_acctbal": _dec(r.integers(-99999, 999999, n_cust))})
+    prios = ["1-URGENT", "2-HIGH", "3-MEDIUM", "4-NOT SPECIFIED", "5-LOW"]
+    t["orders"] = pa.table({"o_orderkey": pa.array(np.arange(1, n_ord + 1) * 4, pa.int64()), "o_custkey": pa.array(r.integers(1, n_cust * 2 // 3, n_ord), pa.int64()),
+                            "o_orderdate": _date(r.integers(8035, 10440, n_ord)), "o_orderpriority": pa.array([prios[i] for i in r.integers(0, 5, n_ord)])})
+    ship = r.integers(8400, 10000, n_li)
+    commit = ship + r.integers(-30, 60, n_li)
+    receipt = ship + r.integers(1, 31, n_li)
+    modes = ["REG AIR", "AIR", "RAIL", "SHIP", "TRUCK", "MAIL", "FOB", "AIR REG"]
+    instr = ["DELIVER IN PERSON", "COLLECT COD", "NONE", "TAKE BACK RETURN"]
+    t["lineitem"] = pa.table({"l_orderkey": pa.array(r.integers(1, n_ord + 1, n_li) * 4, pa.int64()), "l_partkey": pa.array(r.integers(1, n_part + 1, n_li), pa.int64()),
+                              "l_suppkey": pa.array(r.integers(1, n_supp + 1, n_li), pa.int64()), "l_quantity": _dec(r.integers(1, 51, n_li) * 100),
+                              "l_extendedprice": _dec(r.integers(90100, 10494950, n_li)), "l_discount": _dec(r.integers(0, 11, n_li)),
+                              "l_shipdate": _date(ship), "l_commitdate": _date(commit), "l_receiptdate": _date(receipt),
+                              "l_shipmode": pa.array([modes[i] for i in r.integers(0, 8, n_li)]), "l_shipinstruct": pa.array([instr[i] for i in r.integers(0, 4, n_li)])})
+    # non-nullable fields, as in the reference's schema (tpch.rs:871-952)
+    t = {k: v.cast(pa.schema([pa.field(f.name, f.type, False) for f in v.schema])) for k, v in t.items()}
+    rows = {k: [dict(zip(v.column_names, r_)) for r_ in zip(*[c.to_pylist() for c in v.columns])] for k, v in t.items()}
+    return t, rows
+
+
+def _u(x, scale=2):
+    return int(x.scaleb(scale))
+
+
+def _days(d):
+    return (d - datetime.date(1970, 1, 1)).days
+
+
+def _src(t):
+    return g.MemoryExec([t])
+
+
+def test_q6(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q6_plan(_src(t["lineitem"])))
+    exp = sum(_u(l["l_extendedprice"]) * _u(l["l_discount"]) for l in rows["lineitem"]
+              if T.D_1994 <= _days(l["l_shipdate"]) < T.D_1995 and 5 <= _u(l["l_discount"]) <= 7 and _u(l["l_quantity"]) < 2400)
+    assert got == [(exp,)] and exp > 0
+
+
+def test_q12(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q12_plan(_src(t["orders"]), _src(t["lineitem"])))
+    prio = {o["o_orderkey"]: o["o_orderpriority"] for o in rows["orders"]}
+    acc = collections.defaultdict(lambda: [0, 0])
+    for l in rows["lineitem"]:
+        if l["l_shipmode"] in ("MAIL", "SHIP") and l["l_commitdate"] < l["l_receiptdate"] and l["l_shipdate"] < l["l_commitdate"] and T.D_1994 <= _days(l["l_receiptdate"]) < T.D_1995 and l["l_orderkey"] in prio:
+            hi = prio[l["l_orderkey"]] in ("1-URGENT", "2-HIGH")
+            acc[l["l_shipmode"]][0 if hi else 1] += 1
+    assert got == sorted((k, a, b) for k, (a, b) in acc.items()) and len(got) == 2
+
+
+def test_q14(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q14_plan(_src(t["part"]), _src(t["lineitem"])))
+    ptype = {p["p_partkey"]: p["p_type"] for p in rows["part"]}
+    promo = total = 0
+    for l in rows["lineitem"]:
+        if T.D_1995_09 <= _days(l["l_shipdate"]) < T.D_1995_10:
+            v = _u(l["l_extendedprice"]) * (100 - _u(l["l_discount"]))
+            total += v
+            if ptype[l["l_partkey"]].startswith("PROMO"):
+                promo += v
+    assert got[0][1:] == (promo, total) and total > 0 and promo > 0
+    # 100.00 * promo / total with the decimal division rule the engine follows (arrow-arith 49: quotient scale = s1 + 4, truncation), via the oracle
+    one = O.Table(["p", "r"], [O.dec(38, 4), O.dec(38, 4)], [[promo], [total]])
+    e = {"binary_expr": {"l": {"binary_expr": {"l": {"literal": {"type": {"Decimal128": [5, 2]}, "value": "10000"}}, "r": {"column": {"name": "p"}}, "op": "*"}}, "r": {"column": {"name": "r"}}, "op": "/"}}
+    assert got[0][0] == O.eval_expr(e, one)[1][0]
+
+
+def test_q19(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q19_plan(_src(t["part"]), _src(t["lineitem"])))
+    part = {p["p_partkey"]: p for p in rows["part"]}
+    groups = (("Brand#12", ("SM CASE", "SM BOX", "SM PACK", "SM PKG"), 1, 5), ("Brand#23", ("MED BAG", "MED BOX", "MED PKG", "MED PACK"), 10, 10), ("Brand#34", ("LG CASE", "LG BOX", "LG PACK", "LG PKG"), 20, 15))
+    exp = 0; hits = 0
+    for l in rows["lineitem"]:
+        p = part[l["l_partkey"]]
+        if l["l_shipmode"] in ("AIR", "AIR REG") and l["l_shipinstruct"] == "DELIVER IN PERSON" and any(
+                p["p_brand"] == b and p["p_container"] in cs and q * 100 <= _u(l["l_quantity"]) <= (q + 10) * 100 and 1 <= p["p_size"] <= s for b, cs, q, s in groups):
+            exp += _u(l["l_extendedprice"]) * (100 - _u(l["l_discount"])); hits += 1
+    assert got == [(exp if hits else None,)]
+
+
+def test_q16(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q16_plan(_src(t["supplier"]), _src(t["part"]), _src(t["partsupp"])))
+    import re
+    bad = {s["s_suppkey"] for s in rows["supplier"] if re.search("Customer.*Complaints", s["s_comment"])}
+    part = {p["p_partkey"]: p for p in rows["part"] if p["p_brand"] != "Brand#45" and not p["p_type"].startswith("MEDIUM POLISHED") and p["p_size"] in (49, 14, 23, 45, 19, 3, 36, 9)}
+    acc = collections.defaultdict(set)
+    for ps in rows["partsupp"]:
+        p = part.get(ps["ps_partkey"])
+        if p is not None and ps["ps_suppkey"] not in bad:
+            acc[(p["p_brand"], p["p_type"], p["p_size"])].add(ps["ps_suppkey"])
+    exp = sorted(((b, ty, s, len(v)) for (b, ty, s), v in acc.items()), key=lambda r_: (-r_[3], r_[0], r_[1], r_[2]))
+    assert got == exp and len(exp) > 5 and len(bad) > 0
+
+
+def test_q22(tc, db):
+    t, rows = db
+    avg_rows, _ = native_rows(tc, T.q22_avg_plan(_src(t["customer"])))
+    sel = [c for c in rows["customer"] if c["c_phone"][:2] in T.Q22_CODES]
+    pos = [_u(c["c_acctbal"]) for c in sel if _u(c["c_acctbal"]) > 0]
+    # AVG(Decimal128(15,2)) -> Decimal128(19,6): sum * 10^4 / count, truncated (the rule pinned on alltypes_plain in test_oracle_pins)
+    avg_unscaled = (sum(pos) * 10**4) // len(pos)
+    assert avg_rows == [(avg_unscaled,)]
+    got, _ = native_rows(tc, T.q22_plan(_src(t["orders"]), _src(t["customer"]), avg_unscaled))
+    with_orders = {o["o_custkey"] for o in rows["orders"]}
+    acc = collections.defaultdict(lambda: [0, 0])
+    for c in sel:
+        if _u(c["c_acctbal"]) * 10**4 > avg_unscaled and c["c_custkey"] not in with_orders:
+            acc[c["c_phone"][:2]][0] += 1; acc[c["c_phone"][:2]][1] += _u(c["c_acctbal"])
+    assert got == sorted((k, n, s) for k, (n, s) in acc.items()) and len(got) > 0
+
+
+def test_q7(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q7_plan(_src(t["supplier"]), _src(t["lineitem"]), _src(t["orders"]), _src(t["customer"]), _src(t["nation"])))
+    nname = {n["n_nationkey"]: n["n_name"] for n in rows["nation"]}
+    supp = {s["s_suppkey"]: nname[s["s_nationkey"]] for s in rows["supplier"]}
+    cust = {c["c_custkey"]: nname[c["c_nationkey"]] for c in rows["customer"]}
+    order_cust = {o["o_orderkey"]: o["o_custkey"] for o in rows["orders"]}
+    acc = collections.defaultdict(int)
+    for l in rows["lineitem"]:
+        if not (T.D_1995_01 <= _days(l["l_shipdate"]) <= T.D_1996_12_31) or l["l_orderkey"] not in order_cust:
+            continue
+        sn, cn = supp[l["l_suppkey"]], cust[order_cust[l["l_orderkey"]]]
+        if (sn, cn) in (("FRANCE", "GERMANY"), ("GERMANY", "FRANCE")):
+            acc[(sn, cn, float(l["l_shipdate"].year))] += _u(l["l_extendedprice"]) * (100 - _u(l["l_discount"]))
+    assert got == sorted((a, b, y, v) for (a, b, y), v in acc.items()) and len(got) >= 2
+
+
+def test_scalar_functions_and_aggregate_filter_against_the_oracle(tc):
+    """date_part / substr over nullable columns and edge values (leap days, the epoch, dates before 1970, empty strings, a start
+    beyond the end), and per-aggregate FILTER clauses, against oracle_np."""
+    from arrow_ballista_amd.expr import Operator as Op, binary, col, date_part, lit, substr
+    r = np.random.default_rng(5)
+    n = 5000
+    days = np.concatenate([r.integers(-20000, 30000, n - 6), [0, -1, 59, 60, 11016, 11017]]).astype(np.int32)      # ... 1970-03-01, 2000-02-28/29
+    strs = ["", "a", "13-555", "31-999-000", "exactly15bytes!", "sixteen bytes!!!", "a much longer string than the packed form holds"]
+    t = pa.table({"d": pa.array(days, pa.int32(), mask=r.random(n) < 0.1).cast(pa.date32()), "s": pa.array([strs[i] for i in r.integers(0, len(strs), n)], pa.string(), mask=r.random(n) < 0.1),
+                  "k": pa.array(r.integers(0, 5, n), pa.int64()), "v": pa.array(r.integers(-100, 100, n), pa.int64(), mask=r.random(n) < 0.1)})
+    src = g.MemoryExec([t]); s = src.schema(); ot = O.Table.from_arrow(t)
+    exprs = [(date_part("YEAR", col("d", s)), "y"), (date_part("MONTH", col("d", s)), "m"), (date_part("DAY", col("d", s)), "dd"),
+             (substr(col("s", s), 1, 2), "s12"), (substr(col("s", s), 4, 3), "s43"), (substr(col("s", s), 14, 2), "s14")]
+    got, _ = native_rows(tc, g.ProjectionExec(exprs, src))
+    exp = [tuple(r_) for r_ in O.project(ot, [e for e, _ in exprs], [n_ for _, n_ in exprs]).rows()]
+    assert got == exp
+    aggs = [{"fn": "SUM", "expr": col("v", s), "name": "s_pos", "filter": binary(col("v", s), Op.Gt, lit(0))},
+            {"fn": "COUNT", "expr": lit(1), "name": "n_2000s", "filter": binary(date_part("YEAR", col("d", s)), Op.GtEq, lit(2000.0))},
+            {"fn": "MIN", "expr": col("v", s), "name": "mn_13", "filter": binary(substr(col("s", s), 1, 2), Op.Eq, lit("13"))},
+            {"fn": "COUNT", "expr": col("v", s), "name": "c_all"}]
+    got, _ = native_rows(tc, g.AggregateExec("Single", [(col("k", s), "k")], aggs, src))
+    exp = [tuple(r_) for r_ in O.aggregate(ot, [(col("k", s), "k")], aggs, "Single").rows()]
+    assert sorted(got) == sorted(exp)
+    got, _ = native_rows(tc, g.AggregateExec("Single", [(col("k", s), "k")], [{"fn": "COUNT", "expr": col("v", s), "name": "dv", "distinct": True}, {"fn": "SUM", "expr": col("v", s), "name": "sv", "distinct": True}], src))
+    exp = [tuple(r_) for r_ in O.aggregate(ot, [(col("k", s), "k")], [{"fn": "COUNT", "expr": col("v", s), "name": "dv", "distinct": True}, {"fn": "SUM", "expr": col("v", s), "name": "sv", "distinct": True}], "Single").rows()]
+    assert sorted(got) == sorted(exp)
