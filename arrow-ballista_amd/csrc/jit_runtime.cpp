@@ -126,7 +126,11 @@ static std::string cache_dir() {
     else if (const char* h = std::getenv("HOME")) d = std::string(h) + "/.cache/gpuq-jit";
     else d = "/tmp/gpuq-jit-" + std::to_string((long)getuid());
     for (size_t i = 1; i <= d.size(); ++i)
-      if (i == d.size() || d[i] == '/') { const std::string p = d.substr(0, i); if (::mkdir(p.c_str(), 0777) != 0 && errno != EEXIST) return std::string(); }
+      if (i == d.size() || d[i] == '/') { const std::string p = d.substr(0, i); if (::mkdir(p.c_str(), i == d.size() ? 0700 : 0777) != 0 && errno != EEXIST) return std::string(); }
+    // Code objects loaded from this directory run on the device unauthenticated: it is only trusted when it is a directory that
+    // belongs to this user and that nobody else can write to (a pre-created /tmp/gpuq-jit-<uid> of another owner is refused).
+    struct stat st;
+    if (::lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != ::getuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return std::string();
     return d;
   }();
   return dir;
