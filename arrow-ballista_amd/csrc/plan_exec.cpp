@@ -444,6 +444,11 @@ const uint32_t* take_u32(Exec& x, const uint32_t* vec, int64_t vec_len, const ui
 PTable materialize(Exec& x, const PTable& t, bool force = false);
 
 // address `t`'s rows through idx[0..n): a view
+// drop the columns nothing above reads (PNode::require): what a join carries along is what its materialisations gather
+void prune_columns(PTable& t, const std::set<std::string>& keep) {
+  for (size_t i = t.cols.size(); i-- > 0;)
+    if (!keep.count(t.cols[i].name)) { t.cols.erase(t.cols.begin() + (long)i); t.sides.erase(t.sides.begin() + (long)i); t.record_cap = 0; }
+}
 // count: the table whose (device-side) row count the n positions of idx have -- the view's count; nullptr = n is exact
 PTable select_view(Exec& x, const PTable& t, const uint32_t* idx, int64_t n, const BufP& idx_owner, const PTable* count = nullptr) {
   PTable out; out.n = n; out.own(t); if (idx_owner) out.keep.push_back(idx_owner);
@@ -1136,8 +1141,19 @@ struct HashJoinExec : PNode {
     return in;
   }
   bool chain_build(Exec& x, HashJoinExec* in, Side& Li, Side& Ri, Chain& ch) {
-    if (Li.t.is_view() || Ri.t.via.size() > 2) return false;      // A's rows are addressed by position; B may bring up to two index vectors
-    for (auto& c : Ri.t.cols) if (c.c.type == T_UTF8 && false) return false;
+    if (Ri.t.via.size() > 2) return false;      // B may bring up to two index vectors
+    if (Li.t.is_view()) {
+      // A's rows are addressed by position: a view (the output of a join below: q5's ASIA customers) is brought to plain columns first,
+      // only the ones somebody reads (its keys, and what flows up)
+      if (!in->out_need_all) {
+        Names keep = in->out_need;
+        for (auto& o : in->on.a) collect_columns(o.at("left"), keep);
+        if (Li.has_pred) collect_columns(Li.pred, keep);
+        prune_columns(Li.t, keep);
+      }
+      if (Li.has_pred) { Li.t = filter_table(x, Li.t, Li.pred, in, 13); Li.has_pred = false; }
+      Li.t = materialize(x, Li.t);
+    }
     // 1. A's table, exactly as the inner join would build it
     gpuq_op* bop1 = cached_op(x, in, 0, table_sig(Li.t), [&]() {
       const auto ln = names_of(Li.t);
@@ -1191,6 +1207,16 @@ struct HashJoinExec : PNode {
     return true;
   }
   PTable join_sides(Exec& x, Side L, Side R, const bool long_keys, Chain* chain = nullptr) {
+    // columns nobody above this join reads are dropped before anything is gathered through the pair vectors (q5: the region / nation /
+    // customer columns that only served the joins below; SF100: the materialisation of the orders-side view took 0.7 ms with them)
+    if (!out_need_all) {
+      Names keep = out_need;
+      for (auto& o : on.a) { collect_columns(o.at("left"), keep); collect_columns(o.at("right"), keep); }
+      if (has_filter) collect_columns(filter, keep);
+      if (L.has_pred) collect_columns(L.pred, keep);
+      if (R.has_pred) collect_columns(R.pred, keep);
+      prune_columns(L.t, keep); prune_columns(R.t, keep);
+    }
     const bool residual = has_filter && join_type != "Inner";
     const std::string jt = residual ? std::string("Inner") : join_type;
     if (residual) {      // rows that fail a side's own predicate are not part of the join at all: apply those first
@@ -1764,6 +1790,11 @@ PTable table_from_owned(gpuq_table* tab, const PTable& like) {
 struct RepartitionExec : PNode {
   PNodeP input; Json hash_expr; int64_t partition_count = 0;
   std::vector<PNode*> children() override { return {input.get()}; }
+  bool need_all = true; Names need;      // columns somebody above reads: the others do not cross the links
+  void require(const Names* n) override {
+    need_all = n == nullptr; if (n) { need = *n; for (auto& e : hash_expr.a) collect_columns(e, need); }
+    input->require(n ? &need : nullptr);
+  }
   int partitions() override { return input->partitions(); }
   PTable execute(int part, Exec& x) override {
     if (!x.comm) throw Unsupported("RepartitionExec inside a stage needs the ranks of the node (gpuq_plan_set_comm); without them the reference's planner splits the stage here");
@@ -1775,6 +1806,7 @@ struct RepartitionExec : PNode {
     announce_failures(x, [&]() {
     PTable t = input->execute(part, x);
     resolve(x, t);      // (a settle: everything deferred below this exchange is looked at before a row leaves the rank)
+    if (!need_all) prune_columns(t, need);
     t0 = std::chrono::steady_clock::now();
     ps = plain_schema(t);
     std::vector<std::string> names; for (auto& f : ps) names.push_back(f.name);
@@ -1808,6 +1840,8 @@ struct RepartitionExec : PNode {
 struct BroadcastExec : PNode {
   PNodeP input;
   std::vector<PNode*> children() override { return {input.get()}; }
+  bool need_all = true; Names need;
+  void require(const Names* n) override { need_all = n == nullptr; if (n) need = *n; input->require(n); }
   int partitions() override { return input->partitions(); }
   PTable execute(int part, Exec& x) override {
     if (!x.comm) throw Unsupported("BroadcastExec needs the ranks of the node (gpuq_plan_set_comm)");
@@ -1817,6 +1851,7 @@ struct BroadcastExec : PNode {
     announce_failures(x, [&]() {
     PTable t = input->execute(part, x);
     resolve(x, t);
+    if (!need_all) prune_columns(t, need);
     t0 = std::chrono::steady_clock::now();
     ps = plain_schema(t);
     plain = materialize(x, t);
