@@ -599,7 +599,7 @@ static BufP sort_perm(Exec& x, PTable& t, const Json& sort_exprs, const void* si
 // long strings go through in groups of up to four, as one composite key per pass.  Every pass sorts the rows in the order the
 // later keys left them, so ties keep that order.  Nothing is paid on the common path: this runs only after the loud failure.
 struct PermOut { const uint32_t* p = nullptr; std::vector<BufP> keep; };
-static PermOut sort_perm_long(Exec& x, const PTable& t, const Json& sort_exprs, const void* site, int tag) {
+static PermOut sort_perm_long(Exec& x, const PTable& t, const Json& sort_exprs, const void* site, int tag, size_t max_group = 4) {
   PTable w = t;
   std::vector<Json> groups; Json cur = jarr();
   auto flush = [&]() { if (!cur.a.empty()) { groups.push_back(cur); cur = jarr(); } };
@@ -608,7 +608,7 @@ static PermOut sort_perm_long(Exec& x, const PTable& t, const Json& sort_exprs, 
     const int ci = long_key_column(t, s.at("expr"));
     int32_t maxlen = 0;
     if (ci >= 0) { const int sd = t.sides[(size_t)ci]; check(x, gpuq_utf8_max_len(x.ctx, x.stream, &t.cols[(size_t)ci].c, sd > 0 ? t.via[(size_t)sd - 1] : nullptr, t.n, &maxlen)); }
-    if (ci < 0 || maxlen <= 15) { cur.a.push_back(s); if (cur.a.size() == 4) flush(); continue; }
+    if (ci < 0 || maxlen <= 15) { cur.a.push_back(s); if (cur.a.size() >= max_group) flush(); continue; }
     flush();
     const bool asc = s.get_bool("asc", true);
     for (int j = 0; j < (maxlen + 13) / 14; ++j) {
@@ -638,17 +638,20 @@ static PermOut sort_perm_long(Exec& x, const PTable& t, const Json& sort_exprs, 
   return out;
 }
 
+static bool is_wide_sort_key(const std::exception& e) { return std::string(e.what()).find("composite sort key needs") != std::string::npos; }
 PTable sort_table(Exec& x, const PTable& t_in, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
-  PTable t = t_in;
+  PTable t = t_in; bool wide = false;
   try {
     BufP perm = sort_perm(x, t, sort_exprs, site, tag);
     // deferred: the first *n_dev entries of the permutation are the sorted rows (padding sorts behind them); a fetch bounds both
     const int64_t k = (fetch < 0 || fetch > t.n) ? t.n : fetch;
     return select_view(x, t, (const uint32_t*)perm->p, k, perm, t.n_dev ? &t : nullptr);
-  } catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+  } catch (const Unsupported& e) { if (!is_long_string_failure(e) && !is_wide_sort_key(e)) throw; wide = is_wide_sort_key(e); }
   resolve(x, t);
   const int64_t k = (fetch < 0 || fetch > t.n) ? t.n : fetch;
-  PermOut po = sort_perm_long(x, t, sort_exprs, site, tag);
+  // strings beyond 15 bytes: stable passes over 14-byte pieces; a composite key beyond 128 bits (two packed strings and a Float64 whose bit
+  // patterns span 2^40: q7's ORDER BY supp_nation, cust_nation, l_year): one stable pass per key, least significant first
+  PermOut po = sort_perm_long(x, t, sort_exprs, site, tag, wide ? 1 : 4);
   PTable out = select_view(x, t, po.p, k, nullptr);
   for (auto& b : po.keep) out.keep.push_back(b);
   return out;

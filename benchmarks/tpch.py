@@ -545,3 +545,68 @@ def q7_plan(supplier, lineitem, orders, customer, nation):
     agg = g.AggregateExec("Single", [(col(n, ps), n) for n in ("supp_nation", "cust_nation", "l_year")], [{"fn": "SUM", "expr": col("volume", ps), "name": "revenue"}], proj)
     as_ = agg.schema()
     return g.SortExec([{"expr": col(n, as_), "asc": True, "nulls_first": False} for n in ("supp_nation", "cust_nation", "l_year")], agg)
+
+
+D_1993_07, D_1993_10 = 8582, 8674
+
+
+def q4_plan(orders, lineitem):
+    """q4.sql: orders of one quarter that have a late lineitem (EXISTS -> semi join: lineitem is the build side, the surviving ORDERS
+    rows are the probe side: RightSemi), COUNT(*) by o_orderpriority, ORDER BY o_orderpriority."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, Operator as Op
+    os_, ls = orders.schema(), lineitem.schema()
+    o = g.FilterExec(and_(binary(col("o_orderdate", os_), Op.GtEq, lit(D_1993_07, "Date32")), binary(col("o_orderdate", os_), Op.Lt, lit(D_1993_10, "Date32"))), orders)
+    l = g.ProjectionExec([(col("l_orderkey", ls), "l_orderkey")], g.FilterExec(binary(col("l_commitdate", ls), Op.Lt, col("l_receiptdate", ls)), lineitem))
+    lks = l.schema()
+    j = g.HashJoinExec(l, g.CoalesceBatchesExec(o), [(col("l_orderkey", lks), col("o_orderkey", os_))], None, "RightSemi", "CollectLeft", False)
+    js = j.schema()
+    agg = g.AggregateExec("Single", [(col("o_orderpriority", js), "o_orderpriority")], [{"fn": "COUNT", "expr": lit(1), "name": "order_count"}], j)
+    as_ = agg.schema()
+    return g.SortExec([{"expr": col("o_orderpriority", as_), "asc": True, "nulls_first": False}], agg)
+
+
+def q13_plan(customer, orders):
+    """q13.sql: customer LEFT JOIN orders (the ON clause's NOT LIKE filters the orders side), COUNT(o_orderkey) per customer, then the
+    distribution of those counts; ORDER BY custdist DESC, c_count DESC."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, like
+    cs, os_ = customer.schema(), orders.schema()
+    o = g.FilterExec(like(col("o_comment", os_), "%special%requests%", negated=True), orders)
+    ck = g.ProjectionExec([(col("c_custkey", cs), "c_custkey")], customer)
+    cks = ck.schema()
+    j = g.HashJoinExec(ck, g.CoalesceBatchesExec(o), [(col("c_custkey", cks), col("o_custkey", os_))], None, "Left", "CollectLeft", False)
+    js = j.schema()
+    per = g.AggregateExec("Single", [(col("c_custkey", js), "c_custkey")], [{"fn": "COUNT", "expr": col("o_orderkey", js), "name": "c_count"}], j)
+    ps = per.schema()
+    dist = g.AggregateExec("Single", [(col("c_count", ps), "c_count")], [{"fn": "COUNT", "expr": lit(1), "name": "custdist"}], per)
+    ds = dist.schema()
+    return g.SortExec([{"expr": col("custdist", ds), "asc": False, "nulls_first": True}, {"expr": col("c_count", ds), "asc": False, "nulls_first": True}], dist)
+
+
+def q9_plan(part, supplier, lineitem, partsupp, orders, nation):
+    """q9.sql: the green parts' lineitems joined to supplier / nation, partsupp (two-column key) and orders; profit =
+    l_extendedprice * (1 - l_discount) - ps_supplycost * l_quantity by (nation, extract(year from o_orderdate)); ORDER BY nation, o_year DESC."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, binary, like, date_part, Operator as Op
+    ps_, ss, ls, pss, os_, ns = part.schema(), supplier.schema(), lineitem.schema(), partsupp.schema(), orders.schema(), nation.schema()
+    p = g.ProjectionExec([(col("p_partkey", ps_), "p_partkey")], g.FilterExec(like(col("p_name", ps_), "%green%"), part))
+    pks = p.schema()
+    j1 = g.HashJoinExec(p, lineitem, [(col("p_partkey", pks), col("l_partkey", ls))], None, "Inner", "CollectLeft", False)
+    j1s = j1.schema()
+    sn = g.HashJoinExec(nation, supplier, [(col("n_nationkey", ns), col("s_nationkey", ss))], None, "Inner", "CollectLeft", False)
+    sns = sn.schema()
+    j2 = g.HashJoinExec(sn, j1, [(col("s_suppkey", sns), col("l_suppkey", j1s))], None, "Inner", "CollectLeft", False)
+    j2s = j2.schema()
+    j3 = g.HashJoinExec(partsupp, j2, [(col("ps_suppkey", pss), col("l_suppkey", j2s)), (col("ps_partkey", pss), col("l_partkey", j2s))], None, "Inner", "CollectLeft", False)
+    j3s = j3.schema()
+    ok = g.ProjectionExec([(col("o_orderkey", os_), "o_orderkey"), (col("o_orderdate", os_), "o_orderdate")], orders)
+    oks = ok.schema()
+    j4 = g.HashJoinExec(ok, j3, [(col("o_orderkey", oks), col("l_orderkey", j3s))], None, "Inner", "CollectLeft", False)
+    j4s = j4.schema()
+    amount = binary(_revenue(j4s), Op.Minus, binary(col("ps_supplycost", j4s), Op.Multiply, col("l_quantity", j4s)))
+    proj = g.ProjectionExec([(col("n_name", j4s), "nation"), (date_part("YEAR", col("o_orderdate", j4s)), "o_year"), (amount, "amount")], j4)
+    prs = proj.schema()
+    agg = g.AggregateExec("Single", [(col("nation", prs), "nation"), (col("o_year", prs), "o_year")], [{"fn": "SUM", "expr": col("amount", prs), "name": "sum_profit"}], proj)
+    as_ = agg.schema()
+    return g.SortExec([{"expr": col("nation", as_), "asc": True, "nulls_first": False}, {"expr": col("o_year", as_), "asc": False, "nulls_first": True}], agg)

@@ -35,22 +35,27 @@ def db():
     nations = [n for n, _ in T.NATIONS]
     brands = ["Brand#%d%d" % (a, b) for a in range(1, 6) for b in range(1, 6)]
     types = ["%s %s %s" % (a, b, c) for a in ("STANDARD", "SMALL", "MEDIUM", "LARGE", "ECONOMY", "PROMO") for b in ("ANODIZED", "BURNISHED", "PLATED", "POLISHED", "BRUSHED") for c in ("TIN", "NICKEL", "BRASS", "STEEL", "COPPER")]
+    colors = ["almond", "green", "blue", "forest", "ghost", "khaki", "lime", "navy", "olive", "peach"]
     containers = ["%s %s" % (a, b) for a in ("SM", "LG", "MED", "JUMBO", "WRAP") for b in ("CASE", "BOX", "BAG", "JAR", "PKG", "PACK", "CAN", "DRUM")]
     t = {}
     t["nation"] = pa.table({"n_nationkey": pa.array(np.arange(25), pa.int64()), "n_name": pa.array(nations)})
     t["part"] = pa.table({"p_partkey": pa.array(np.arange(1, n_part + 1), pa.int64()), "p_brand": pa.array([brands[i] for i in r.integers(0, 25, n_part)]),
                           "p_type": pa.array([types[i] for i in r.integers(0, len(types), n_part)]), "p_size": pa.array(r.integers(1, 51, n_part).astype(np.int32)),
-                          "p_container": pa.array([containers[i] for i in r.integers(0, len(containers), n_part)])})
+                          "p_container": pa.array([containers[i] for i in r.integers(0, len(containers), n_part)]),
+                          "p_name": pa.array([" ".join(colors[i] for i in r.integers(0, len(colors), 4)) for _ in range(n_part)])})
     comments = ["quick deposits", "Customer service Complaints pending", "carefully Customer ironic Complaints", "regular packages", "final Customer accounts"]
     t["supplier"] = pa.table({"s_suppkey": pa.array(np.arange(1, n_supp + 1), pa.int64()), "s_nationkey": pa.array(r.integers(0, 25, n_supp), pa.int64()),
                               "s_comment": pa.array([comments[i] for i in r.integers(0, len(comments), n_supp)])})
-    t["partsupp"] = pa.table({"ps_partkey": pa.array(np.repeat(np.arange(1, n_part + 1), 4), pa.int64()), "ps_suppkey": pa.array(r.integers(1, n_supp + 1, n_part * 4), pa.int64())})
+    t["partsupp"] = pa.table({"ps_partkey": pa.array(np.repeat(np.arange(1, n_part + 1), 4), pa.int64()), "ps_suppkey": pa.array((np.repeat(np.arange(n_part), 4) * 7 + np.tile(np.arange(4), n_part) * 13) % n_supp + 1, pa.int64()),
+                              "ps_supplycost": _dec(r.integers(100, 100000, n_part * 4))})
     phones = ["%02d-%03d-%03d-%04d" % (c, a, b, d) for c, a, b, d in zip(r.integers(10, 35, n_cust), r.integers(100, 999, n_cust), r.integers(100, 999, n_cust), r.integers(1000, 9999, n_cust))]
     t["customer"] = pa.table({"c_custkey": pa.array(np.arange(1, n_cust + 1), pa.int64()), "c_nationkey": pa.array(r.integers(0, 25, n_cust), pa.int64()),
                               "c_phone": pa.array(phones), "c_acctbal": _dec(r.integers(-99999, 999999, n_cust))})
+    ocomments = ["carefully final deposits", "special packages about the requests", "quickly special requests haggle", "ironic accounts", "requests are special"]
     prios = ["1-URGENT", "2-HIGH", "3-MEDIUM", "4-NOT SPECIFIED", "5-LOW"]
     t["orders"] = pa.table({"o_orderkey": pa.array(np.arange(1, n_ord + 1) * 4, pa.int64()), "o_custkey": pa.array(r.integers(1, n_cust * 2 // 3, n_ord), pa.int64()),
-                            "o_orderdate": _date(r.integers(8035, 10440, n_ord)), "o_orderpriority": pa.array([prios[i] for i in r.integers(0, 5, n_ord)])})
+                            "o_orderdate": _date(r.integers(8035, 10440, n_ord)), "o_orderpriority": pa.array([prios[i] for i in r.integers(0, 5, n_ord)]),
+                            "o_comment": pa.array([ocomments[i] for i in r.integers(0, len(ocomments), n_ord)])})
     ship = r.integers(8400, 10000, n_li)
     commit = ship + r.integers(-30, 60, n_li)
     receipt = ship + r.integers(1, 31, n_li)
@@ -206,3 +211,42 @@ def test_scalar_functions_and_aggregate_filter_against_the_oracle(tc):
     got, _ = native_rows(tc, g.AggregateExec("Single", [(col("k", s), "k")], [{"fn": "COUNT", "expr": col("v", s), "name": "dv", "distinct": True}, {"fn": "SUM", "expr": col("v", s), "name": "sv", "distinct": True}], src))
     exp = [tuple(r_) for r_ in O.aggregate(ot, [(col("k", s), "k")], [{"fn": "COUNT", "expr": col("v", s), "name": "dv", "distinct": True}, {"fn": "SUM", "expr": col("v", s), "name": "sv", "distinct": True}], "Single").rows()]
     assert sorted(got) == sorted(exp)
+
+
+def test_q4(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q4_plan(_src(t["orders"]), _src(t["lineitem"])))
+    late = {l["l_orderkey"] for l in rows["lineitem"] if l["l_commitdate"] < l["l_receiptdate"]}
+    acc = collections.Counter(o["o_orderpriority"] for o in rows["orders"] if T.D_1993_07 <= _days(o["o_orderdate"]) < T.D_1993_10 and o["o_orderkey"] in late)
+    assert got == sorted(acc.items()) and len(got) == 5
+
+
+def test_q13(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q13_plan(_src(t["customer"]), _src(t["orders"])))
+    import re
+    per = collections.Counter()
+    for o in rows["orders"]:
+        if not re.search("special.*requests", o["o_comment"]):
+            per[o["o_custkey"]] += 1
+    dist = collections.Counter(per.get(c["c_custkey"], 0) for c in rows["customer"])
+    assert got == sorted(dist.items(), key=lambda kv: (-kv[1], -kv[0])) and dist[0] > 0
+
+
+def test_q9(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q9_plan(_src(t["part"]), _src(t["supplier"]), _src(t["lineitem"]), _src(t["partsupp"]), _src(t["orders"]), _src(t["nation"])))
+    green = {p["p_partkey"] for p in rows["part"] if "green" in p["p_name"]}
+    nname = {n["n_nationkey"]: n["n_name"] for n in rows["nation"]}
+    snat = {s["s_suppkey"]: nname[s["s_nationkey"]] for s in rows["supplier"]}
+    cost = collections.defaultdict(list)
+    for ps in rows["partsupp"]:
+        cost[(ps["ps_suppkey"], ps["ps_partkey"])].append(_u(ps["ps_supplycost"]))
+    oyear = {o["o_orderkey"]: float(o["o_orderdate"].year) for o in rows["orders"]}
+    acc = collections.defaultdict(int)
+    for l in rows["lineitem"]:
+        if l["l_partkey"] in green and l["l_orderkey"] in oyear:
+            for c in cost.get((l["l_suppkey"], l["l_partkey"]), ()):
+                acc[(snat[l["l_suppkey"]], oyear[l["l_orderkey"]])] += _u(l["l_extendedprice"]) * (100 - _u(l["l_discount"])) - c * _u(l["l_quantity"])
+    exp = sorted(((n, y, v) for (n, y), v in acc.items()), key=lambda r_: (r_[0], -r_[1]))
+    assert got == exp and len(exp) > 10
