@@ -620,9 +620,12 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
           fieldP("int32_t", oa); fieldP("int32_t", ob);
           LP("q." + oa + " = P.cols[" + cs + "].offsets[row0]; q." + ob + " = P.cols[" + cs + "].offsets[row0 + 1];");
           LL("w." + oa + " = q." + oa + "; w." + ob + " = q." + ob + ";");
-          fieldR("uint32_t", "fb" + cs);
-          // unconditional load through a selected address: a branch here would make the wave wait for the byte at once
-          LL("w.fb" + cs + " = (uint32_t)*((q." + ob + " > q." + oa + ") ? (const uint8_t*)col" + cs + ".data + q." + oa + " : (const uint8_t*)P.code);");
+          // the (up to three) aligned 8-byte words that hold the first 15 bytes, in the load stage: unconditional loads through selected
+          // addresses (a word the string does not reach is read from the program block instead: a branch here would make the wave wait)
+          fieldR("u64", "sw" + cs + "a"); fieldR("u64", "sw" + cs + "b"); fieldR("u64", "sw" + cs + "c");
+          LL("{ const unsigned long long sa = (unsigned long long)col" + cs + ".data + (unsigned long long)(uint32_t)q." + oa + "; const int sl = q." + ob + " - q." + oa + "; const uint32_t sn = (uint32_t)(sl < 15 ? sl : 15), span = (uint32_t)(sa & 7ull) + sn;");
+          LL("  const u64* swp = (const u64*)(sa & ~7ull); const u64* dummy = (const u64*)P.code;");
+          LL("  w.sw" + cs + "a = *(sl > 0 ? swp : dummy); w.sw" + cs + "b = *(span > 8u ? swp + 1 : dummy); w.sw" + cs + "c = *(span > 16u ? swp + 2 : dummy); }");
         } else {
           LL("w." + oa + " = col" + cs + ".offsets[r" + cs + "]; w." + ob + " = col" + cs + ".offsets[r" + cs + " + 1];");
         }
@@ -638,8 +641,7 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
     const std::string cs = std::to_string(c);
     L("const int32_t len" + cs + " = o" + cs + "b - o" + cs + "a;");
     L("const uint8_t* sp" + cs + " = (const uint8_t*)col" + cs + ".data + o" + cs + "a;");
-    if (f.side == 0) L("const u64 fb" + cs + " = (len" + cs + " > 0) ? (u64)w.fb" + cs + " : 0ull;");
-    else L("const u64 fb" + cs + " = (len" + cs + " > 0) ? (u64)sp" + cs + "[0] : 0ull;");
+    (void)0;
   }
   // ---- phase B2: typed column values
   std::map<int, std::string> col_null;
@@ -662,8 +664,9 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
       if (f.raw128) { L("const u64 c" + cs + "_lo = a" + cs + ".x, c" + cs + "_hi = a" + cs + ".y;"); }
       else {
         if (!(c < C.col_loose.size() && C.col_loose[c])) L("if (len" + cs + " > 15 && P.flags) atomicOr(P.flags, FLAG_STR_TRUNC);");
-        L("u64 c" + cs + "_hi = fb" + cs + " << 56, c" + cs + "_lo = 0;");
-        L("{ const int nb = len" + cs + " < 15 ? len" + cs + " : 15; for (int k = 1; k < nb; ++k) { const u64 b = sp" + cs + "[k]; if (k < 8) c" + cs + "_hi |= b << (56 - 8 * k); else c" + cs + "_lo |= b << (56 - 8 * (k - 8)); } }");
+        L("u64 c" + cs + "_hi, c" + cs + "_lo;");
+        if (f.side == 0) L("str15_assemble(w.sw" + cs + "a, w.sw" + cs + "b, w.sw" + cs + "c, (uint32_t)(((unsigned long long)col" + cs + ".data + (unsigned long long)(uint32_t)o" + cs + "a) & 7ull), len" + cs + " < 15 ? len" + cs + " : 15, c" + cs + "_hi, c" + cs + "_lo);");
+        else L("load_str15((const uint8_t*)col" + cs + ".data, o" + cs + "a, len" + cs + ", c" + cs + "_hi, c" + cs + "_lo);");
         L("c" + cs + "_lo |= (u64)(len" + cs + " < 255 ? len" + cs + " : 255);");
       }
       name[n] = "c" + cs;
