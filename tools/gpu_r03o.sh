@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 3 step o: the fused orders-side build taken apart: no insert / bitmap atomic only / row store only (results are WRONG with these
+# switches; only the build kernel's time is read)
+set -o pipefail
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+O=gpurun_out/r03o; mkdir -p $O
+for v in base "GPUQ_EXP_NTSTORE=1" "GPUQ_EXP_NTSTORE=1;GPUQ_SEMI_ROWS=8"; do
+  if [ "$v" = base ]; then unset GPUQ_JIT_DEFINES; else export GPUQ_JIT_DEFINES="$v"; fi
+  timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+  python3 - "$v" <<'PY'
+import json, sys
+d = json.loads(open("gpurun_out/r03o/bench.json").read().strip().splitlines()[-1])
+print("%-40s ms_per_step %.3f" % (sys.argv[1], d["ms_per_step"]), [(o["label"] or o["op"], round(o["op_ms_per_step"], 3)) for o in d["operators"][:3]])
+PY
+done
