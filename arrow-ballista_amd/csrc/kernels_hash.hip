@@ -903,24 +903,9 @@ __device__ __forceinline__ void build_insert_dense(const DevProgram& P, const Ha
     // presence bitmap + uninitialised row array: valid for unique keys only; a duplicate raises the flag and the host rebuilds
     // with the initialised array (chains need a defined head)
     const uint32_t bit = 1u << (idx & 31);
-#if defined(GPUQ_EXP_SKIP)
-    // experiment (tools/gpu_r03o.sh): what the parts of an insert cost -- 1 = no insert at all, 2 = bitmap only, 3 = row store only
-    if (GPUQ_EXP_SKIP == 2) (void)__hip_atomic_fetch_or(T.dense_bits + (idx >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (GPUQ_EXP_SKIP == 3) T.dense[idx] = row;
-    inserted = true;
-#elif defined(GPUQ_EXP_NORETURN_OR)
-    (void)__hip_atomic_fetch_or(T.dense_bits + (idx >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // experiment: no duplicate detection
-    T.dense[idx] = row;
-    inserted = true;
-#else
     const uint32_t was = atomicOr(T.dense_bits + (idx >> 5), bit);
-#ifdef GPUQ_EXP_NTSTORE
-    __builtin_nontemporal_store(row, T.dense + idx);
-#else
     T.dense[idx] = row;
-#endif
     inserted = !(was & bit);
-#endif
   } else {
     // the table word is the chain head; an exchange both claims the key and links a duplicate
     old = __hip_atomic_exchange(T.dense + idx, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1105,11 +1090,7 @@ __device__ __forceinline__ void k_join_build_semi1_body(const DevProgram P, cons
         i1[u] = key1[u] - (u64)S.T.dense_min;
         in[u] = act[u] && !n1[u] && i1[u] < S.T.dense_range;
         bw[u] = 0;
-#ifdef GPUQ_EXP_NOLOOKUP
-        if (in[u]) bw[u] = 0x11111111u;      // experiment: one key in four "found" without touching the other table
-#else
         if (in[u]) bw[u] = sbits ? sbits[i1[u] >> 5] : S.T.dense[i1[u]];
-#endif
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
