@@ -4,6 +4,7 @@ import json
 import os
 
 T_NULL, T_BOOL, T_INT32, T_INT64, T_DATE32, T_FLOAT64, T_DECIMAL128, T_UTF8, T_UINT32, T_UINT64 = range(10)
+T_INT8, T_INT16, T_UINT8, T_UINT16, T_FLOAT32, T_TIMESTAMP, T_DATE64 = range(10, 17)
 REPR_ARROW, REPR_PACKED15 = 0, 1
 _STATUS = {6: "CANCELLED", 1: "INVALID", 2: "HIP", 3: "UNSUPPORTED", 4: "CAPACITY", 5: "INTERNAL"}
 

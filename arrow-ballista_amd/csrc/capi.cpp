@@ -340,8 +340,10 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
           if (arg->type.is_decimal()) {
             pl.acc_sum = find_or_add_acc(accs, ACC_SUM, arg, dec_t(arg->type.p + 10, arg->type.s));
           } else if (arg->type.is_int() && pl.fn == "SUM") {
-            NodeP x = ec.cast(arg, t_of(T_INT64));
-            pl.acc_sum = find_or_add_acc(accs, ACC_SUM, x, t_of(T_INT64));
+            // sum_return_type [UPSTREAM-KNOWLEDGE]: signed integers of any width -> Int64, unsigned -> UInt64
+            const DType st = t_of(arg->type.is_unsigned() ? T_UINT64 : T_INT64);
+            NodeP x = ec.cast(arg, st);
+            pl.acc_sum = find_or_add_acc(accs, ACC_SUM, x, st);
           } else if (arg->type.is_float() || arg->type.is_int()) {
             NodeP x = ec.cast(arg, t_of(T_FLOAT64)); pl.is_float = true;
             pl.acc_sum = find_or_add_acc(accs, ACC_FSUM, x, t_of(T_FLOAT64));
@@ -350,7 +352,7 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
         } else if (pl.fn == "MIN" || pl.fn == "MAX") {
           const bool mn = pl.fn == "MIN";
           if (arg->type.is_float()) { pl.is_float = true; pl.acc_mm = find_or_add_acc(accs, mn ? ACC_FMIN : ACC_FMAX, arg, arg->type); }
-          else if (arg->type.is_int() || arg->type.is_decimal() || arg->type.id == T_DATE32) pl.acc_mm = find_or_add_acc(accs, mn ? ACC_MIN : ACC_MAX, arg, arg->type);
+          else if (arg->type.is_int() || arg->type.is_decimal() || arg->type.is_temporal()) pl.acc_mm = find_or_add_acc(accs, mn ? ACC_MIN : ACC_MAX, arg, arg->type);
           else throw Unsupported(pl.fn + " over " + arg->type.to_string());
           if (pl.arg_nullable) pl.acc_cnt = count_of(arg);
         } else if (var_family(pl.fn)) {
@@ -2053,25 +2055,8 @@ struct Staging {   // two pinned buffers, copies alternate between them (H2D ove
 thread_local Staging g_staging;
 
 
-DType dtype_from_format(const char* f) {
-  DType t; const std::string s = f ? f : "";
-  if (s == "i") t.id = T_INT32; else if (s == "l") t.id = T_INT64; else if (s == "tdD") t.id = T_DATE32; else if (s == "g") t.id = T_FLOAT64;
-  else if (s == "u") t.id = T_UTF8; else if (s == "b") t.id = T_BOOL; else if (s == "I") t.id = T_UINT32; else if (s == "L") t.id = T_UINT64;
-  else if (s.rfind("d:", 0) == 0) {
-    int p = 0, sc = 0, bits = 128;
-    if (std::sscanf(s.c_str(), "d:%d,%d,%d", &p, &sc, &bits) < 2 || bits != 128) throw Unsupported("decimal format '" + s + "'");
-    t.id = T_DECIMAL128; t.p = p; t.s = sc;
-  } else throw Unsupported("Arrow format '" + s + "' is not supported on device");
-  return t;
-}
-std::string format_of(const gpuq_field_info& f) {
-  switch (f.type) {
-    case T_INT32: return "i"; case T_INT64: return "l"; case T_DATE32: return "tdD"; case T_FLOAT64: return "g"; case T_UTF8: return "u";
-    case T_BOOL: return "b"; case T_UINT32: return "I"; case T_UINT64: return "L";
-    case T_DECIMAL128: return "d:" + std::to_string(f.precision) + "," + std::to_string(f.scale);
-  }
-  throw Unsupported("type has no Arrow format");
-}
+DType dtype_from_format(const char* f, bool* large) { return dtype_from_arrow_format(f, large); }
+std::string format_of(const gpuq_field_info& f) { DType t; t.id = f.type; t.p = f.precision; t.s = f.scale; return arrow_format_of(t); }
 // copy `nbits` bits starting at bit `off` of src into a fresh LSB-aligned bitmap
 std::vector<uint8_t> realign_bits(const uint8_t* src, int64_t off, int64_t nbits) {
   std::vector<uint8_t> out((size_t)(nbits + 7) / 8 + 8, 0);
@@ -2104,30 +2089,78 @@ int gpuq_table_import_arrow(gpuq_ctx* ctx, void* stream, const struct ArrowArray
     t = new gpuq_table(); t->ctx = ctx; t->n_rows = batch->length;
     for (int64_t c = 0; c < batch->n_children; ++c) {
       const ArrowArray* a = batch->children[c]; const ArrowSchema* f = schema->children[c];
-      if (a->dictionary) throw Unsupported("dictionary-encoded column '" + std::string(f->name ? f->name : "") + "'");
-      const DType ty = dtype_from_format(f->format);
+      // Dictionary(K, V) (datafusion.proto Dictionary{key, value}): decoded while it is staged -- inside, the column has its value type.
+      // The indices may be any integer type; a NULL index or a NULL dictionary entry is a NULL value.
+      const ArrowArray* idx = nullptr; const ArrowSchema* idx_f = nullptr;
+      if (a->dictionary) {
+        if (!f->dictionary) throw std::runtime_error("dictionary array without a dictionary schema");
+        idx = a; idx_f = f; a = idx->dictionary; f = idx_f->dictionary;
+      }
+      bool large = false;
+      const DType ty = dtype_from_format(f->format, &large);
       auto ic = std::make_unique<ImportedCol>();
-      const int64_t n = a->length, off = a->offset + batch->offset;
-      ic->field = make_field(f->name ? f->name : "", ty, (f->flags & 2) != 0);
+      const ArrowArray* top = idx ? idx : a;
+      const int64_t n = top->length, off = top->offset + batch->offset;
+      const char* nm = (idx ? idx_f : f)->name;
+      ic->field = make_field(nm ? nm : "", ty, (((idx ? idx_f : f)->flags) & 2) != 0);
       ic->field.repr = GPUQ_REPR_ARROW;
       ic->col.type = ty.id; ic->col.precision = ty.p; ic->col.scale = ty.s; ic->col.repr = GPUQ_REPR_ARROW; ic->col.length = n;
-      if (a->null_count != 0 && a->n_buffers > 0 && a->buffers[0]) {
-        std::vector<uint8_t> bits = realign_bits((const uint8_t*)a->buffers[0], off, n);
+      // the values of column rows [0, n): for a dictionary column picked through the indices on the host (this entry point stages
+      // through host memory anyway), otherwise the array's own buffers
+      std::vector<uint8_t> v_valid, v_data; std::vector<int64_t> v_offs;
+      const uint8_t* valid_src = nullptr; int64_t valid_off = 0;
+      const int w = (ty.id == T_UTF8 || ty.id == T_BOOL) ? 0 : type_width(ty);
+      auto utf8_off = [&](const ArrowArray* arr, int64_t i) -> int64_t { return large ? ((const int64_t*)arr->buffers[1])[i] : (int64_t)((const int32_t*)arr->buffers[1])[i]; };
+      if (idx) {
+        const std::string kf = idx_f->format ? idx_f->format : "";
+        auto key_at = [&](int64_t i) -> int64_t {
+          const void* kb = idx->buffers[1];
+          if (kf == "c") return ((const int8_t*)kb)[i]; if (kf == "C") return ((const uint8_t*)kb)[i]; if (kf == "s") return ((const int16_t*)kb)[i];
+          if (kf == "S") return ((const uint16_t*)kb)[i]; if (kf == "i") return ((const int32_t*)kb)[i]; if (kf == "I") return ((const uint32_t*)kb)[i];
+          if (kf == "l") return ((const int64_t*)kb)[i]; if (kf == "L") return (int64_t)((const uint64_t*)kb)[i];
+          throw Unsupported("dictionary index format '" + kf + "'");
+        };
+        const uint8_t* kval = (idx->null_count != 0 && idx->n_buffers > 0) ? (const uint8_t*)idx->buffers[0] : nullptr;
+        const uint8_t* dval = (a->null_count != 0 && a->n_buffers > 0) ? (const uint8_t*)a->buffers[0] : nullptr;
+        const int64_t doff = a->offset, dn = a->length;
+        v_valid.assign((size_t)(n + 7) / 8 + 8, 0); bool any_null = false;
+        if (ty.id == T_UTF8) v_offs.assign((size_t)n + 1, 0); else if (ty.id == T_BOOL) v_data.assign((size_t)(n + 7) / 8 + 8, 0); else v_data.assign((size_t)n * (size_t)w + 16, 0);
+        for (int64_t i = 0; i < n; ++i) {
+          bool ok = !kval || ((kval[(off + i) >> 3] >> ((off + i) & 7)) & 1);
+          int64_t k = 0;
+          if (ok) { k = key_at(off + i); if (k < 0 || k >= dn) throw std::runtime_error("dictionary index out of range"); ok = !dval || ((dval[(doff + k) >> 3] >> ((doff + k) & 7)) & 1); }
+          if (ok) v_valid[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7)); else any_null = true;
+          if (ty.id == T_UTF8) {
+            const int64_t len = ok ? utf8_off(a, doff + k + 1) - utf8_off(a, doff + k) : 0;
+            if (len > 0) { const uint8_t* src = (const uint8_t*)a->buffers[2] + utf8_off(a, doff + k); v_data.insert(v_data.end(), src, src + len); }
+            v_offs[(size_t)i + 1] = (int64_t)v_data.size();
+          } else if (ty.id == T_BOOL) { if (ok && ((((const uint8_t*)a->buffers[1])[(doff + k) >> 3] >> ((doff + k) & 7)) & 1)) v_data[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7)); }
+          else if (ok) std::memcpy(v_data.data() + (size_t)i * (size_t)w, (const char*)a->buffers[1] + (size_t)(doff + k) * (size_t)w, (size_t)w);
+        }
+        if (any_null) { valid_src = v_valid.data(); valid_off = 0; }
+      } else if (a->null_count != 0 && a->n_buffers > 0 && a->buffers[0]) { valid_src = (const uint8_t*)a->buffers[0]; valid_off = off; }
+      if (valid_src) {
+        std::vector<uint8_t> bits = realign_bits(valid_src, valid_off, n);
         ic->validity.ensure(bits.size()); g_staging.h2d(s, ic->validity.p, bits.data(), bits.size()); g_staging.drain();
         ic->col.validity = (const uint8_t*)ic->validity.p;
       }
       if (ty.id == T_UTF8) {
-        const int32_t* offs = (const int32_t*)a->buffers[1] + off;
-        const int32_t last = n > 0 ? offs[n] : 0;
-        ic->offsets.ensure((size_t)(n + 1) * 4 + 16); g_staging.h2d(s, ic->offsets.p, offs, (size_t)(n + 1) * 4);
-        ic->data.ensure((size_t)last + 16); if (last > 0) g_staging.h2d(s, ic->data.p, a->buffers[2], (size_t)last);
+        // 32-bit offsets on the device, starting at 0 (LargeUtf8 and dictionary values are re-based here)
+        std::vector<int32_t> o32((size_t)n + 1);
+        const int64_t base = idx ? 0 : utf8_off(a, off);
+        const int64_t last = idx ? v_offs[(size_t)n] : (n > 0 ? utf8_off(a, off + n) - base : 0);
+        if (last > 0x7FFFFFFFll) throw Unsupported("a Utf8 column of more than 2^31 bytes (split the batch)");
+        for (int64_t i = 0; i <= n; ++i) o32[(size_t)i] = (int32_t)(idx ? v_offs[(size_t)i] : utf8_off(a, off + i) - base);
+        ic->offsets.ensure((size_t)(n + 1) * 4 + 16); g_staging.h2d(s, ic->offsets.p, o32.data(), (size_t)(n + 1) * 4); g_staging.drain();
+        ic->data.ensure((size_t)last + 16);
+        if (last > 0) { g_staging.h2d(s, ic->data.p, idx ? (const void*)v_data.data() : (const void*)((const char*)a->buffers[2] + base), (size_t)last); g_staging.drain(); }
         ic->col.offsets = (const int32_t*)ic->offsets.p;
       } else if (ty.id == T_BOOL) {
-        std::vector<uint8_t> bits = realign_bits((const uint8_t*)a->buffers[1], off, n);
+        std::vector<uint8_t> bits = idx ? v_data : realign_bits((const uint8_t*)a->buffers[1], off, n);
         ic->data.ensure(bits.size()); g_staging.h2d(s, ic->data.p, bits.data(), bits.size()); g_staging.drain();
       } else {
-        const int w = type_width(ty);
-        ic->data.ensure((size_t)n * w + 16); if (n > 0) g_staging.h2d(s, ic->data.p, (const char*)a->buffers[1] + (size_t)off * w, (size_t)n * w);
+        ic->data.ensure((size_t)n * w + 16);
+        if (n > 0) { g_staging.h2d(s, ic->data.p, idx ? (const char*)v_data.data() : (const char*)a->buffers[1] + (size_t)off * w, (size_t)n * w); if (idx) g_staging.drain(); }
       }
       ic->col.data = ic->data.p;
       t->cols.push_back(std::move(ic));

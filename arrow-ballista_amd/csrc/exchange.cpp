@@ -90,8 +90,10 @@ struct PinnedHost {
 int width_of(const gpuq_column& c) {
   if (c.type == GPUQ_UTF8 && c.repr == GPUQ_REPR_PACKED15) return 16;
   switch (c.type) {
-    case GPUQ_INT32: case GPUQ_DATE32: case GPUQ_UINT32: return 4;
-    case GPUQ_INT64: case GPUQ_FLOAT64: case GPUQ_UINT64: return 8;
+    case GPUQ_INT32: case GPUQ_DATE32: case GPUQ_UINT32: case GPUQ_FLOAT32: return 4;
+    case GPUQ_INT64: case GPUQ_FLOAT64: case GPUQ_UINT64: case GPUQ_TIMESTAMP: case GPUQ_DATE64: return 8;
+    case GPUQ_INT8: case GPUQ_UINT8: return 1;
+    case GPUQ_INT16: case GPUQ_UINT16: return 2;
     case GPUQ_DECIMAL128: return 16;
     default: return 0;
   }

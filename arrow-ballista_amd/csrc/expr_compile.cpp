@@ -51,6 +51,9 @@ std::string DType::to_string() const {
     case T_NULL: return "Null"; case T_BOOL: return "Boolean"; case T_INT32: return "Int32"; case T_INT64: return "Int64";
     case T_DATE32: return "Date32"; case T_FLOAT64: return "Float64"; case T_UTF8: return "Utf8";
     case T_UINT32: return "UInt32"; case T_UINT64: return "UInt64";
+    case T_INT8: return "Int8"; case T_INT16: return "Int16"; case T_UINT8: return "UInt8"; case T_UINT16: return "UInt16";
+    case T_FLOAT32: return "Float32"; case T_DATE64: return "Date64";
+    case T_TIMESTAMP: { static const char* u[4] = {"Second", "Millisecond", "Microsecond", "Nanosecond"}; return std::string("Timestamp(") + u[p & 3] + ")"; }
     case T_DECIMAL128: return "Decimal128(" + std::to_string(p) + "," + std::to_string(s) + ")";
   }
   return "?";
@@ -62,6 +65,9 @@ DType dtype_from_json(const Json& j) {
     if (s == "Int32") t.id = T_INT32; else if (s == "Int64") t.id = T_INT64; else if (s == "Date32") t.id = T_DATE32;
     else if (s == "Float64") t.id = T_FLOAT64; else if (s == "Utf8") t.id = T_UTF8; else if (s == "Boolean") t.id = T_BOOL;
     else if (s == "UInt32") t.id = T_UINT32; else if (s == "UInt64") t.id = T_UINT64; else if (s == "Null") t.id = T_NULL;
+    else if (s == "Int8") t.id = T_INT8; else if (s == "Int16") t.id = T_INT16; else if (s == "UInt8") t.id = T_UINT8; else if (s == "UInt16") t.id = T_UINT16;
+    else if (s == "Float32") t.id = T_FLOAT32; else if (s == "Date64") t.id = T_DATE64;
+    else if (s == "LargeUtf8") t.id = T_UTF8;      // 64-bit offsets exist only at the boundary (gpuq_table_import_arrow / gpuq_ingest_push narrow them); the schema layer keeps the name
     else throw std::runtime_error("unsupported type '" + s + "'");
     return t;
   }
@@ -71,13 +77,60 @@ DType dtype_from_json(const Json& j) {
     if (t.p < 1 || t.p > 38 || t.s < 0 || t.s > t.p) throw std::runtime_error("bad Decimal128 precision/scale");
     return t;
   }
+  if (j.is_obj() && j.has("Timestamp")) {
+    // {"Timestamp": [unit, tz]} (datafusion.proto Timestamp{time_unit, timezone}); the time zone does not change what is stored or how
+    // values compare: it stays with the schema layer
+    const Json& a = j.at("Timestamp");
+    std::string u = a.is_arr() ? a.a.at(0).str() : a.str();
+    t.id = T_TIMESTAMP;
+    if (u == "Second" || u == "s") t.p = 0; else if (u == "Millisecond" || u == "ms") t.p = 1; else if (u == "Microsecond" || u == "us") t.p = 2;
+    else if (u == "Nanosecond" || u == "ns") t.p = 3; else throw std::runtime_error("bad Timestamp unit '" + u + "'");
+    return t;
+  }
+  if (j.is_obj() && j.has("Dictionary")) {
+    // {"Dictionary": [key type, value type]}: dictionary-encoded columns are decoded where they enter (gpuq_table_import_arrow); inside, the
+    // column has its value type
+    return dtype_from_json(j.at("Dictionary").a.at(1));
+  }
   throw std::runtime_error("unsupported type descriptor " + j.dump());
+}
+// Arrow C data interface format strings (the host boundary: gpuq_import_arrow / gpuq_export_arrow / gpuq_ingest_*).  large = "U"
+// (LargeUtf8): 64-bit offsets on the host side, narrowed while staging.
+DType dtype_from_arrow_format(const char* f, bool* large) {
+  DType t; const std::string s = f ? f : "";
+  if (large) *large = false;
+  if (s == "i") t.id = T_INT32; else if (s == "l") t.id = T_INT64; else if (s == "tdD") t.id = T_DATE32; else if (s == "g") t.id = T_FLOAT64;
+  else if (s == "u") t.id = T_UTF8; else if (s == "b") t.id = T_BOOL; else if (s == "I") t.id = T_UINT32; else if (s == "L") t.id = T_UINT64;
+  else if (s == "c") t.id = T_INT8; else if (s == "C") t.id = T_UINT8; else if (s == "s") t.id = T_INT16; else if (s == "S") t.id = T_UINT16;
+  else if (s == "f") t.id = T_FLOAT32; else if (s == "tdm") t.id = T_DATE64;
+  else if (s == "U") { t.id = T_UTF8; if (large) *large = true; else throw Unsupported("LargeUtf8 where 32-bit offsets are required"); }
+  else if (s.size() >= 4 && s.compare(0, 2, "ts") == 0 && s[3] == ':') {
+    t.id = T_TIMESTAMP;
+    switch (s[2]) { case 's': t.p = 0; break; case 'm': t.p = 1; break; case 'u': t.p = 2; break; case 'n': t.p = 3; break; default: throw Unsupported("Arrow format '" + s + "'"); }
+  }
+  else if (s.rfind("d:", 0) == 0) {
+    int p = 0, sc = 0, bits = 128;
+    if (std::sscanf(s.c_str(), "d:%d,%d,%d", &p, &sc, &bits) < 2 || bits != 128) throw Unsupported("decimal format '" + s + "'");
+    t.id = T_DECIMAL128; t.p = p; t.s = sc;
+  } else throw Unsupported("Arrow format '" + s + "' is not supported on device (supported: b c C s S i I l L f g tdD tdm ts{s,m,u,n}: d:p,s u U)");
+  return t;
+}
+std::string arrow_format_of(const DType& t) {
+  switch (t.id) {
+    case T_INT32: return "i"; case T_INT64: return "l"; case T_DATE32: return "tdD"; case T_FLOAT64: return "g"; case T_UTF8: return "u";
+    case T_BOOL: return "b"; case T_UINT32: return "I"; case T_UINT64: return "L";
+    case T_INT8: return "c"; case T_UINT8: return "C"; case T_INT16: return "s"; case T_UINT16: return "S"; case T_FLOAT32: return "f"; case T_DATE64: return "tdm";
+    case T_TIMESTAMP: return std::string("ts") + "smun"[t.p & 3] + ":";
+    case T_DECIMAL128: return "d:" + std::to_string(t.p) + "," + std::to_string(t.s);
+  }
+  throw Unsupported("type has no Arrow format");
 }
 int col_class_for(const DType& t) {
   switch (t.id) {
     case T_INT32: case T_DATE32: return CC_I32;
     case T_UINT32: return CC_U32;
-    case T_INT64: case T_UINT64: case T_FLOAT64: return CC_I64;
+    case T_INT64: case T_UINT64: case T_FLOAT64: case T_TIMESTAMP: case T_DATE64: return CC_I64;
+    case T_INT8: return CC_I8; case T_INT16: return CC_I16; case T_UINT8: return CC_U8; case T_UINT16: return CC_U16; case T_FLOAT32: return CC_F32;
     case T_DECIMAL128: return CC_I128;
     case T_UTF8: return CC_STR;
     case T_BOOL: return CC_BIT;
@@ -85,7 +138,7 @@ int col_class_for(const DType& t) {
   }
 }
 int type_width(const DType& t) {
-  switch (col_class_for(t)) { case CC_I32: case CC_U32: return 4; case CC_I64: return 8; case CC_I128: case CC_STR: return 16; default: return 0; }
+  switch (col_class_for(t)) { case CC_I32: case CC_U32: case CC_F32: return 4; case CC_I64: return 8; case CC_I128: case CC_STR: return 16; case CC_I8: case CC_U8: return 1; case CC_I16: case CC_U16: return 2; default: return 0; }
 }
 int Schema::index_of(const std::string& name) const {
   for (size_t i = 0; i < fields.size(); ++i) if (fields[i].name == name) return (int)i;
@@ -104,7 +157,8 @@ Schema schema_from_json(const Json& j) {
 
 static int type_bits(const DType& t) {
   switch (t.id) {
-    case T_BOOL: return 2; case T_INT32: case T_DATE32: return 32; case T_UINT32: return 33; case T_INT64: return 64;
+    case T_BOOL: return 2; case T_INT32: case T_DATE32: return 32; case T_UINT32: return 33; case T_INT64: case T_TIMESTAMP: case T_DATE64: return 64;
+    case T_INT8: return 8; case T_UINT8: return 9; case T_INT16: return 16; case T_UINT16: return 17;
     case T_UINT64: return 65; case T_DECIMAL128: return bits_for_precision(t.p); default: return 127;
   }
 }
@@ -134,6 +188,12 @@ NodeP ExprCompiler::lit_f64(double v) {
   u64 b; std::memcpy(&b, &v, 8); n->lit_lo = b; n->key = "lf:" + std::to_string(b);
   return intern(n);
 }
+NodeP ExprCompiler::lit_f32(float v) {      // registers hold a Float32 as the double of the same value
+  auto n = std::make_shared<Node>();
+  n->kind = Node::LIT; n->type.id = T_FLOAT32; n->nullable = false;
+  const double d = (double)v; u64 b; std::memcpy(&b, &d, 8); n->lit_lo = b; n->key = "lf32:" + std::to_string(b);
+  return intern(n);
+}
 NodeP ExprCompiler::lit_null(DType t) {
   auto n = std::make_shared<Node>();
   n->kind = Node::LIT; n->type = t; n->nullable = true; n->lit_null = true; n->bits = 1; n->key = "ln:" + t.to_string();
@@ -158,6 +218,8 @@ NodeP ExprCompiler::raw(int op, DType t, bool nullable, int bits, std::vector<No
 static DType dec_type(int p, int s) { DType t; t.id = T_DECIMAL128; t.p = p > 38 ? 38 : p; t.s = s > 38 ? 38 : s; return t; }
 static DType as_decimal(const DType& t) {
   if (t.id == T_DECIMAL128) return t;
+  if (t.id == T_INT8 || t.id == T_UINT8) return dec_type(3, 0);      // datafusion's coercion of integers to decimals [UPSTREAM-KNOWLEDGE]
+  if (t.id == T_INT16 || t.id == T_UINT16) return dec_type(5, 0);
   if (t.id == T_INT32 || t.id == T_UINT32) return dec_type(10, 0);
   if (t.id == T_INT64 || t.id == T_UINT64) return dec_type(20, 0);
   throw std::runtime_error("cannot treat " + t.to_string() + " as decimal");
@@ -197,11 +259,47 @@ NodeP ExprCompiler::rescale(NodeP e, int new_scale) {
   return raw(OP_ADD, rt, e->nullable, e->bits, {q, adj});
 }
 
+static i64 units_per_second(int unit) { static const i64 k[4] = {1, 1000, 1000000, 1000000000}; return k[unit & 3]; }
+// floor(e / d) for a positive constant d (days of a timestamp before the epoch round down, as chrono's date of a datetime does)
+NodeP ExprCompiler::floor_div(NodeP e, i64 d, DType rt) {
+  if (d == 1) return raw(OP_MOV, rt, e->nullable, e->bits, {e});
+  const DType i64t = mk(T_INT64);
+  NodeP dv = lit_int(i64t, d), zero = lit_int(i64t, 0), mone = lit_int(i64t, -1);
+  NodeP q = raw(OP_DIV, i64t, e->nullable, e->bits, {e, dv});
+  NodeP r = raw(OP_MOD, i64t, e->nullable, dv->bits, {e, dv});
+  NodeP adj = raw(OP_SELECT, i64t, e->nullable, 2, {raw(OP_LT, mk(T_BOOL), e->nullable, 2, {r, zero}), mone, zero});
+  return raw(OP_ADD, rt, e->nullable, e->bits, {q, adj});
+}
+// a count of `from_per_s` units per second as a count of `to_per_s` units (arrow-cast: multiply, or divide truncating toward zero)
+NodeP ExprCompiler::rescale_time(NodeP e, i64 from_per_s, i64 to_per_s, DType rt) {
+  if (from_per_s == to_per_s) return raw(OP_MOV, rt, e->nullable, e->bits, {e});
+  if (to_per_s > from_per_s) { NodeP f = lit_int(mk(T_INT64), to_per_s / from_per_s); return raw(OP_MULW, rt, e->nullable, std::min(127, e->bits + f->bits), {e, f}); }
+  return raw(OP_DIV, rt, e->nullable, e->bits, {e, lit_int(mk(T_INT64), from_per_s / to_per_s)});
+}
+
 NodeP ExprCompiler::cast(NodeP e, DType to) {
   const DType from = e->type;
   if (from == to) return e;
   if (from.id == T_NULL) return lit_null(to);
+  // temporal <-> temporal (arrow-cast 49 cast_with_options [UPSTREAM-KNOWLEDGE]: Date32 = days, Date64 = milliseconds, Timestamp = count of its unit)
+  if (from.is_temporal() && to.is_temporal()) {
+    const i64 day_ms = 86400000;
+    if (from.id == T_TIMESTAMP && to.id == T_TIMESTAMP) return rescale_time(e, units_per_second(from.p), units_per_second(to.p), to);
+    if (from.id == T_TIMESTAMP && to.id == T_DATE32) return floor_div(e, units_per_second(from.p) * 86400, to);
+    if (from.id == T_TIMESTAMP && to.id == T_DATE64) return rescale_time(e, units_per_second(from.p), 1000, to);
+    if (from.id == T_DATE32 && to.id == T_TIMESTAMP) return raw(OP_MULW, to, e->nullable, 64, {e, lit_int(mk(T_INT64), units_per_second(to.p) * 86400)});
+    if (from.id == T_DATE32 && to.id == T_DATE64) return raw(OP_MULW, to, e->nullable, 64, {e, lit_int(mk(T_INT64), day_ms)});
+    if (from.id == T_DATE64 && to.id == T_DATE32) return raw(OP_DIV, to, e->nullable, 32, {e, lit_int(mk(T_INT64), day_ms)});
+    if (from.id == T_DATE64 && to.id == T_TIMESTAMP) return rescale_time(e, 1000, units_per_second(to.p), to);
+  }
+  if (to.id == T_FLOAT32) {
+    // one rounding to double and one to float; the second is exact in effect for every operand a double holds exactly (all narrow integers,
+    // Int32, Date32, decimals of <= 15 digits), an Int64 beyond 2^53 can round twice
+    if (from.id == T_FLOAT64) return raw(OP_F32R, to, e->nullable, 127, {e});
+    return raw(OP_F32R, to, e->nullable, 127, {cast(e, mk(T_FLOAT64))});
+  }
   if (to.id == T_FLOAT64) {
+    if (from.id == T_FLOAT32) return raw(OP_MOV, to, e->nullable, 127, {e});      // the register already holds the double of that value
     if (from.is_int() || from.id == T_DATE32 || from.id == T_BOOL) return raw(OP_I2F, to, e->nullable, 127, {e});
     if (from.is_decimal()) {
       NodeP f = raw(OP_I2F, to, e->nullable, 127, {e});
@@ -216,12 +314,14 @@ NodeP ExprCompiler::cast(NodeP e, DType to) {
       return raw(OP_MOV, to, e->nullable, std::min(r->bits, bits_for_precision(to.p)), {r});
     }
   }
-  if (to.is_int() || to.id == T_DATE32) {
-    if (from.is_int() || from.id == T_DATE32 || from.id == T_BOOL) return raw(OP_MOV, to, e->nullable, std::min(e->bits, type_bits(to)), {e});
+  if (to.is_int() || to.is_temporal()) {
+    // the storage integer of a temporal type casts to and from plain integers unchanged
+    if ((from.is_int() || from.id == T_BOOL || from.is_temporal()) && (to.is_int() || from.is_int())) return raw(OP_MOV, to, e->nullable, std::min(e->bits, type_bits(to)), {e});
     if (from.is_decimal()) { NodeP r = rescale(e, 0); return raw(OP_MOV, to, e->nullable, std::min(r->bits, type_bits(to)), {r}); }
     if (from.is_float()) return raw(OP_F2I, to, e->nullable, type_bits(to), {e});
   }
   if (to.id == T_BOOL && from.is_int()) return raw(OP_NE, to, e->nullable, 2, {e, lit_int(from, 0)});
+  if (to.id == T_BOOL && from.is_float()) return raw(OP_FNE, to, e->nullable, 2, {cast(e, mk(T_FLOAT64)), lit_f64(0.0)});
   throw std::runtime_error("unsupported cast " + from.to_string() + " -> " + to.to_string());
 }
 
@@ -258,8 +358,8 @@ NodeP ExprCompiler::binary(const std::string& op_in, NodeP l, NodeP r) {
     }
     const bool lu = l->type.id == T_UTF8, ru = r->type.id == T_UTF8;
     if (lu != ru) throw std::runtime_error("cannot compare " + l->type.to_string() + " with " + r->type.to_string());
-    const bool ld = l->type.id == T_DATE32, rd = r->type.id == T_DATE32;
-    if ((ld && !(rd || r->type.is_int())) || (rd && !(ld || l->type.is_int())))
+    const bool ld = l->type.is_temporal(), rd = r->type.is_temporal();
+    if ((ld && !(r->type == l->type || r->type.is_int())) || (rd && !(l->type == r->type || l->type.is_int())))
       throw std::runtime_error("cannot compare " + l->type.to_string() + " with " + r->type.to_string());
     return raw(pr.first, mk(T_BOOL), nullable, 2, {l, r});
   }
@@ -267,7 +367,10 @@ NodeP ExprCompiler::binary(const std::string& op_in, NodeP l, NodeP r) {
   if (l->type.is_float() || r->type.is_float()) {
     static const std::map<std::string, int> fo = {{"+", OP_FADD}, {"-", OP_FSUB}, {"*", OP_FMUL}, {"/", OP_FDIV}};
     auto it = fo.find(op); if (it == fo.end()) throw std::runtime_error("unsupported float operator " + op);
-    return raw(it->second, mk(T_FLOAT64), nullable, 127, {cast(l, mk(T_FLOAT64)), cast(r, mk(T_FLOAT64))});
+    NodeP z = raw(it->second, mk(T_FLOAT64), nullable, 127, {cast(l, mk(T_FLOAT64)), cast(r, mk(T_FLOAT64))});
+    // Float32 op Float32: the double result rounded to float IS the correctly rounded float result for + - * / (53 >= 2 * 24 + 2 bits)
+    if (l->type.id == T_FLOAT32 && r->type.id == T_FLOAT32) return raw(OP_F32R, mk(T_FLOAT32), nullable, 127, {z});
+    return z;
   }
   if (l->type.is_decimal() || r->type.is_decimal()) {
     if (!(l->type.is_decimal() || l->type.is_int()) || !(r->type.is_decimal() || r->type.is_int()))
@@ -303,6 +406,7 @@ NodeP ExprCompiler::binary(const std::string& op_in, NodeP l, NodeP r) {
   }
   if ((l->type.is_int() || l->type.id == T_DATE32) && (r->type.is_int() || r->type.id == T_DATE32)) {
     DType rt = mk((l->type.id == T_INT64 || r->type.id == T_INT64 || l->type.id == T_UINT64 || r->type.id == T_UINT64) ? T_INT64 : T_INT32);
+    if (l->type == r->type && l->type.is_int()) rt = l->type;      // the planner has coerced both sides: the result wraps to that width where it is stored
     if (l->type.id == T_DATE32 && r->type.id == T_DATE32 && op == "-") rt = mk(T_INT32);
     else if (l->type.id == T_DATE32 || r->type.id == T_DATE32) rt = mk(T_DATE32);
     if (op == "+") return raw(OP_ADD, rt, nullable, std::max(l->bits, r->bits) + 1, {l, r});
@@ -361,6 +465,7 @@ NodeP ExprCompiler::from_json(const Json& e) {
     switch (t.id) {
       case T_UTF8: return lit_str(val->str());
       case T_FLOAT64: return lit_f64(val->f64());
+      case T_FLOAT32: return lit_f32((float)val->f64());
       case T_BOOL: return lit_int(t, val->boolean() ? 1 : 0);
       default: return lit_int(t, parse_i128(val->is_str() ? val->s : val->s));
     }
@@ -400,7 +505,8 @@ NodeP ExprCompiler::from_json(const Json& e) {
       const int which = part == "YEAR" ? 0 : part == "MONTH" ? 1 : part == "DAY" ? 2 : -1;
       if (which < 0) throw Unsupported("date_part('" + part + "', ..): YEAR, MONTH and DAY are built");
       NodeP x = from_json(args[1]);
-      if (x->type.id != T_DATE32) throw Unsupported("date_part over " + x->type.to_string() + " (Date32 is built)");
+      if (x->type.id == T_TIMESTAMP || x->type.id == T_DATE64) x = cast(x, mk(T_DATE32));      // the date of the instant (UTC), then as for a date
+      if (x->type.id != T_DATE32) throw Unsupported("date_part over " + x->type.to_string() + " (Date32, Date64 and Timestamp are built)");
       return cast(raw(OP_DATEPART, mk(T_INT64), x->nullable, 24, {x}, (uint32_t)which), mk(T_FLOAT64));      // [UPSTREAM-KNOWLEDGE] datafusion 34 date_part returns Float64
     }
     if (nm == "substr" || nm == "substring") {
@@ -545,7 +651,7 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
   std::map<Node*, std::string> name;       // value expression of a node (variable name)
   std::map<Node*, std::string> nul;        // null expression ("false" or variable)
   auto is_str = [](const Node* n) { return n->type.id == T_UTF8; };
-  auto is_f = [](const Node* n) { return n->type.id == T_FLOAT64; };
+  auto is_f = [](const Node* n) { return n->type.is_float(); };
   auto is_b = [](const Node* n) { return n->type.id == T_BOOL; };
   auto wide = [&](const Node* n) { return !is_str(n) && !is_f(n) && !is_b(n) && n->bits > 64; };
   auto ctype = [&](const Node* n) { return is_f(n) ? std::string("double") : (is_b(n) ? std::string("bool") : (wide(n) ? std::string("i128") : std::string("i64"))); };
@@ -612,6 +718,9 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
         } else { fieldR("ulonglong2", A); LL("w." + A + " = ((const ulonglong2*)col" + cs + ".data)[r" + cs + "];"); L("const ulonglong2 " + A + " = w." + A + ";"); }
         break;
       case CC_BIT: fieldR("uint32_t", A); LL("w." + A + " = ((const uint8_t*)col" + cs + ".data)[r" + cs + " >> 3];"); L("const uint32_t " + A + " = w." + A + ";"); break;
+      case CC_F32: fieldR("uint32_t", A); LL("w." + A + " = " + std::string(f.side == 0 ? "GPUQ_LD_STREAM" : "*") + "(((const uint32_t*)col" + cs + ".data) + r" + cs + ");"); L("const uint32_t " + A + " = w." + A + ";"); break;
+      case CC_I8: case CC_U8: fieldR("uint32_t", A); LL("w." + A + " = ((const uint8_t*)col" + cs + ".data)[r" + cs + "];"); L("const uint32_t " + A + " = w." + A + ";"); break;
+      case CC_I16: case CC_U16: fieldR("uint32_t", A); LL("w." + A + " = ((const uint16_t*)col" + cs + ".data)[r" + cs + "];"); L("const uint32_t " + A + " = w." + A + ";"); break;
       case CC_STR: {
         const std::string oa = "o" + cs + "a", ob = "o" + cs + "b";
         fieldR("int32_t", oa); fieldR("int32_t", ob);
@@ -675,7 +784,10 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
     std::string v;
     switch (cls) {
       case CC_I32: v = "(i64)(int32_t)a" + cs; break;
-      case CC_U32: v = "(i64)a" + cs; break;
+      case CC_U32: case CC_U8: case CC_U16: v = "(i64)a" + cs; break;
+      case CC_I8: v = "(i64)(int8_t)a" + cs; break;
+      case CC_I16: v = "(i64)(int16_t)a" + cs; break;
+      case CC_F32: v = "(double)__uint_as_float(a" + cs + ")"; break;
       case CC_I64: v = is_f(n) ? "__longlong_as_double((i64)a" + cs + ")" : "(i64)a" + cs; break;
       case CC_I128:
         if (is_f(n)) v = "__longlong_as_double((i64)a" + cs + ".x)";
@@ -758,6 +870,7 @@ std::string ExprCompiler::jit_source(const CompiledProgram& C, const std::vector
         ne = N(a); break;
       }
       case OP_F2I: e = "(i64)" + V(a); ne = N(a); break;
+      case OP_F32R: e = "(double)(float)" + V(a); ne = N(a); break;
       case OP_AND: {
         const std::string af = "(!(" + N(a) + ") && !" + V(a) + ")", bf = "(!(" + N(b) + ") && !" + V(b) + ")";
         e = "!(" + af + " || " + bf + ")"; ne = "(!(" + af + " || " + bf + ") && (" + orn({N(a), N(b)}) + "))"; break;

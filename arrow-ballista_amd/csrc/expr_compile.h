@@ -23,20 +23,29 @@ namespace gpuq {
 enum TypeId : int32_t {
   T_NULL = 0, T_BOOL = 1, T_INT32 = 2, T_INT64 = 3, T_DATE32 = 4, T_FLOAT64 = 5,
   T_DECIMAL128 = 6, T_UTF8 = 7, T_UINT32 = 8, T_UINT64 = 9,
+  // the second wave (datafusion.proto:1004-1040 ArrowType): narrow integers and Float32 stay narrow in memory (column classes of
+  // their own) and are widened on load: registers hold them as the first-wave types do (64-bit integers, doubles)
+  T_INT8 = 10, T_INT16 = 11, T_UINT8 = 12, T_UINT16 = 13, T_FLOAT32 = 14,
+  T_TIMESTAMP = 15,   // p = TimeUnit (0 Second, 1 Millisecond, 2 Microsecond, 3 Nanosecond); 8-byte count since the epoch; tz is schema metadata
+  T_DATE64 = 16,      // milliseconds since the epoch
 };
 
 struct DType {
   int32_t id = T_NULL;
   int32_t p = 0, s = 0;
-  bool operator==(const DType& o) const { return id == o.id && (id != T_DECIMAL128 || (p == o.p && s == o.s)); }
+  bool operator==(const DType& o) const { return id == o.id && (id != T_DECIMAL128 || (p == o.p && s == o.s)) && (id != T_TIMESTAMP || p == o.p); }
   bool operator!=(const DType& o) const { return !(*this == o); }
-  bool is_int() const { return id == T_INT32 || id == T_INT64 || id == T_UINT32 || id == T_UINT64; }
+  bool is_int() const { return id == T_INT32 || id == T_INT64 || id == T_UINT32 || id == T_UINT64 || id == T_INT8 || id == T_INT16 || id == T_UINT8 || id == T_UINT16; }
+  bool is_unsigned() const { return id == T_UINT8 || id == T_UINT16 || id == T_UINT32 || id == T_UINT64; }
+  bool is_temporal() const { return id == T_DATE32 || id == T_DATE64 || id == T_TIMESTAMP; }
   bool is_decimal() const { return id == T_DECIMAL128; }
-  bool is_float() const { return id == T_FLOAT64; }
+  bool is_float() const { return id == T_FLOAT64 || id == T_FLOAT32; }
   std::string to_string() const;
 };
 DType dtype_from_json(const Json& j);
 Json dtype_to_json_text(const DType& t);
+DType dtype_from_arrow_format(const char* f, bool* large_utf8);   // Arrow C data interface format string; large_utf8 = nullptr refuses "U"
+std::string arrow_format_of(const DType& t);
 int col_class_for(const DType& t);   // ColClass used to load / store this type
 int type_width(const DType& t);      // bytes per value in the fixed-width device layout (Utf8: 16, packed)
 
@@ -91,6 +100,9 @@ class ExprCompiler {
   NodeP column(int field_index);
   NodeP lit_int(DType t, i128 v);
   NodeP lit_f64(double v);
+  NodeP lit_f32(float v);
+  NodeP floor_div(NodeP e, i64 d, DType rt);
+  NodeP rescale_time(NodeP e, i64 from_per_s, i64 to_per_s, DType rt);
   NodeP lit_null(DType t);
   NodeP lit_str(const std::string& s);
   NodeP binary(const std::string& op, NodeP l, NodeP r);

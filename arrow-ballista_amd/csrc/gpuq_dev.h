@@ -42,6 +42,8 @@ enum ColClass : int32_t {
   CC_STR = 3,   // Utf8: first <=15 bytes big-endian in bits 127..8, length in bits 7..0
   CC_BIT = 4,   // Boolean (Arrow bit-packed) -> 0/1
   CC_U32 = 5,   // 4-byte unsigned (row ids)
+  CC_I8 = 7, CC_I16 = 8, CC_U8 = 9, CC_U16 = 10,   // narrow integers: 1 / 2 bytes in memory, sign- / zero-extended on load, truncated on store
+  CC_F32 = 11,  // Float32: 4 bytes in memory, the double of the same value in a register
   CC_STRQ = 6,  // Utf8 as CC_STR, for a column the program only compares for (in)equality with literals or tests for NULL: the length
                 // byte alone tells a value beyond 15 bytes from every literal a register can hold, so such a value is not an error
 };
@@ -72,6 +74,7 @@ enum Op : uint8_t {
   OP_COALESCE0, // dst <- a, or 0 (non-null) when a is NULL
   OP_DATEPART,  // dst <- field imm (0 year, 1 month, 2 day) of the Date32 a (days since 1970-01-01), as an integer
   OP_SUBSTR,    // dst <- substr(a, start, len) of a packed Utf8 value, ASCII only; imm = (start - 1) | len << 8 (len 255 = to the end)
+  OP_F32R,      // dst <- (double)(float)a: a double rounded to the nearest Float32 (Float32 arithmetic and casts)
 };
 
 struct DevInsn { uint8_t op, dst, a, b; uint32_t imm; };
@@ -256,7 +259,9 @@ __device__ __forceinline__ void load_phase_a(const DevProgram& P, const RowIdx& 
       if (ok) {
         if (col.validity) r.v = col.validity[row >> 3];
         switch (col.cls) {
-          case CC_I32: case CC_U32: r.r0 = ((const uint32_t*)col.data)[row]; break;
+          case CC_I32: case CC_U32: case CC_F32: r.r0 = ((const uint32_t*)col.data)[row]; break;
+          case CC_I8: case CC_U8: r.r0 = ((const uint8_t*)col.data)[row]; break;
+          case CC_I16: case CC_U16: r.r0 = ((const uint16_t*)col.data)[row]; break;
           case CC_I64: { const uint2 v = ((const uint2*)col.data)[row]; r.r0 = v.x; r.r1 = v.y; break; }
           case CC_I128: { const uint4 v = ((const uint4*)col.data)[row]; r.r0 = v.x; r.r1 = v.y; r.r2 = v.z; r.r3 = v.w; break; }
           case CC_BIT: r.r0 = ((const uint8_t*)col.data)[row >> 3]; break;
@@ -298,7 +303,10 @@ __device__ __forceinline__ void load_phase_b2(const DevProgram& P, const RowIdx&
       else {
         switch (col.cls) {
           case CC_I32: { const i64 v = (int32_t)r.r0; lo = (u64)v; hi = (u64)(v >> 63); break; }
-          case CC_U32: lo = r.r0; break;
+          case CC_U32: case CC_U8: case CC_U16: lo = r.r0; break;
+          case CC_I8: { const i64 v = (int8_t)r.r0; lo = (u64)v; hi = (u64)(v >> 63); break; }
+          case CC_I16: { const i64 v = (int16_t)r.r0; lo = (u64)v; hi = (u64)(v >> 63); break; }
+          case CC_F32: { lo = (u64)__double_as_longlong((double)__uint_as_float(r.r0)); hi = (u64)((i64)lo >> 63); break; }
           case CC_I64: lo = (u64)r.r0 | ((u64)r.r1 << 32); hi = (u64)((i64)lo >> 63); break;
           case CC_I128: lo = (u64)r.r0 | ((u64)r.r1 << 32); hi = (u64)r.r2 | ((u64)r.r3 << 32); break;
           case CC_BIT: lo = (r.r0 >> (row & 7)) & 1u; break;
@@ -395,6 +403,7 @@ __device__ __forceinline__ void run_program(const DevProgram& P, GPUQ_REGS_PARAM
         zlo = (u64)__double_as_longlong(v); zn = an; break;
       }
       case OP_F2I: { i64 v = (i64)__longlong_as_double((i64)alo); zlo = (u64)v; zhi = (u64)(v >> 63); zn = an; break; }
+      case OP_F32R: { zlo = (u64)__double_as_longlong((double)(float)__longlong_as_double((i64)alo)); zhi = (u64)((i64)zlo >> 63); zn = an; break; }
       case OP_AND: {  // Kleene: false AND x = false
         bool af = !an && alo == 0, bf = !bn && blo == 0;
         zn = !(af || bf) && (an || bn);

@@ -248,7 +248,7 @@ void launch_csv_count_lines(hipStream_t s, const uint8_t* text, i64 n, i64 chunk
 void launch_csv_line_starts(hipStream_t s, const uint8_t* text, i64 n, i64 chunk, int nblocks, const uint32_t* block_offsets, i64* starts);
 void launch_csv_parse(hipStream_t s, const uint8_t* text, i64 n_bytes, const i64* starts, i64 row0, i64 n_rows, const CsvSpec& S, const CsvOut& O, uint32_t* flags);
 void launch_csv_copy_strings(hipStream_t s, const uint8_t* text, const uint32_t* start, const int32_t* offsets, i64 n, uint8_t* out);
-enum PqPhys : int32_t { PQ_BOOL = 0, PQ_I32 = 1, PQ_I64 = 2, PQ_F64 = 5, PQ_BYTE_ARRAY = 6, PQ_FLBA = 7 };
+enum PqPhys : int32_t { PQ_BOOL = 0, PQ_I32 = 1, PQ_I64 = 2, PQ_I96 = 3 /* nanoseconds of the day + Julian day -> Timestamp(ns) */, PQ_F32 = 4, PQ_F64 = 5, PQ_BYTE_ARRAY = 6, PQ_FLBA = 7 };
 enum PqEnc : int32_t { PQE_PLAIN = 0, PQE_DICT = 2, PQE_RLE = 3 };
 struct PqPage { i64 src; int32_t bytes; int32_t n_values; i64 row0; int32_t enc; int32_t def_bytes; int32_t def_v2; int32_t dict; };
 struct PqDict { i64 values; i64 str_offsets; int32_t n; int32_t pad; };

@@ -32,14 +32,6 @@ template <class F> int guarded_i(F&& f) {
   catch (const Capacity& e) { g_ierr = e.what(); return GPUQ_ERR_CAPACITY; }
   catch (const std::exception& e) { g_ierr = e.what(); return GPUQ_ERR_INVALID; }
 }
-DType dtype_of_format(const char* f) {
-  DType t; const std::string s = f ? f : "";
-  if (s == "i") t.id = T_INT32; else if (s == "l") t.id = T_INT64; else if (s == "tdD") t.id = T_DATE32; else if (s == "g") t.id = T_FLOAT64;
-  else if (s == "u") t.id = T_UTF8; else if (s == "b") t.id = T_BOOL; else if (s == "I") t.id = T_UINT32; else if (s == "L") t.id = T_UINT64;
-  else if (s.rfind("d:", 0) == 0) { t.id = T_DECIMAL128; int p = 38, sc = 0, bits = 128; std::sscanf(s.c_str(), "d:%d,%d,%d", &p, &sc, &bits); if (bits != 128) throw Unsupported("decimal width " + std::to_string(bits)); t.p = p; t.s = sc; }
-  else throw Unsupported("Arrow format '" + s + "' (supported: i l tdD g d:p,s u b I L)");
-  return t;
-}
 // bits [src_off, src_off + n) of src -> bits [dst_off, ...) of dst (dst bytes beyond the range are preserved by OR-ing into zeroed memory)
 void copy_bits_host(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64_t src_off, int64_t n) {
   if (((dst_off | src_off) & 7) == 0) { std::memcpy(dst + (dst_off >> 3), src + (src_off >> 3), (size_t)((n + 7) >> 3)); return; }
@@ -49,7 +41,9 @@ void copy_bits_host(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64_t s
 
 struct gpuq_ingest {
   gpuq_ctx* ctx = nullptr;
-  struct Col { DType type; bool nullable = false; std::string name; DevBuf data, offsets, validity; int64_t bytes_cap = 0; };
+  struct Col { DType type; bool nullable = false, large = false; std::string name; DevBuf data, offsets, validity; int64_t bytes_cap = 0; };
+  // Utf8 / LargeUtf8 offset i of a host array
+  static int64_t utf8_off(const Col& k, const ArrowArray* a, int64_t i) { return k.large ? ((const int64_t*)a->buffers[1])[i] : (int64_t)((const int32_t*)a->buffers[1])[i]; }
   std::deque<Col> cols;      // DevBuf is not movable: a deque never relocates its elements
   int64_t cap_rows = 0;
   // producer side (gpuq_ingest_push): row / byte cursors
@@ -97,7 +91,7 @@ struct gpuq_ingest {
     for (size_t c = 0; c < cols.size(); ++c) {
       const ArrowArray* a = b.children[c];
       const Col& k = cols[c];
-      if (k.type.id == T_UTF8) { const int32_t* o = (const int32_t*)a->buffers[1] + a->offset + b.offset; need += (size_t)(job.rows + 1) * 4 + (size_t)(o[job.rows] - o[0]) + 128; }
+      if (k.type.id == T_UTF8) { const int64_t o0 = utf8_off(k, a, a->offset + b.offset), o1 = utf8_off(k, a, a->offset + b.offset + job.rows); need += (size_t)(job.rows + 1) * 4 + (size_t)(o1 - o0) + 128; }
       else if (k.type.id == T_BOOL) need += (size_t)(job.rows + 7) / 8 + 72;
       else need += (size_t)job.rows * (size_t)type_width(k.type) + 64;
       if (k.nullable) need += (size_t)(job.rows + 7) / 8 + 72;
@@ -122,15 +116,16 @@ struct gpuq_ingest {
         } else throw Unsupported("ingest: a nullable column needs every batch but the last to hold a multiple of 8 rows");
       }
       if (k.type.id == T_UTF8) {
-        const int32_t* o = (const int32_t*)a->buffers[1] + off;
-        const int64_t nbytes = (int64_t)o[n] - (int64_t)o[0];
+        // (LargeUtf8: 64-bit offsets on the host side; the partition's own offsets are 32-bit, its byte total is bounded by max_utf8_bytes)
+        const int64_t o0 = utf8_off(k, a, off);
+        const int64_t nbytes = utf8_off(k, a, off + n) - o0;
         int32_t* q = (int32_t*)stage((size_t)(n + 1) * 4);
-        const int64_t delta = job.byte0[c] - (int64_t)o[0];
-        for (int64_t i = 0; i <= n; ++i) q[i] = (int32_t)((int64_t)o[i] + delta);      // rebased to the partition's running byte total
+        const int64_t delta = job.byte0[c] - o0;
+        for (int64_t i = 0; i <= n; ++i) q[i] = (int32_t)(utf8_off(k, a, off + i) + delta);      // rebased to the partition's running byte total
         HIPCHECK(hipMemcpyAsync((int32_t*)k.offsets.p + job.row0, q, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, w.stream));
         if (nbytes > 0) {
           char* d = stage((size_t)nbytes);
-          std::memcpy(d, (const char*)a->buffers[2] + o[0], (size_t)nbytes);
+          std::memcpy(d, (const char*)a->buffers[2] + o0, (size_t)nbytes);
           HIPCHECK(hipMemcpyAsync((char*)k.data.p + job.byte0[c], d, (size_t)nbytes, hipMemcpyHostToDevice, w.stream));
         }
         bytes_copied += (n + 1) * 4 + nbytes;
@@ -171,7 +166,7 @@ int gpuq_ingest_create(gpuq_ctx* ctx, const struct ArrowSchema* schema, int64_t 
       const ArrowSchema* f = schema->children[c];
       if (f->dictionary) throw Unsupported("dictionary-encoded column");
       g->cols.emplace_back();
-      gpuq_ingest::Col& k = g->cols.back(); k.type = dtype_of_format(f->format); k.nullable = (f->flags & 2) != 0; k.name = f->name ? f->name : "";
+      gpuq_ingest::Col& k = g->cols.back(); k.type = dtype_from_arrow_format(f->format, &k.large); k.nullable = (f->flags & 2) != 0; k.name = f->name ? f->name : "";
     }
     (void)use_stream(nullptr);
     for (auto& k : g->cols) {
@@ -205,8 +200,7 @@ int gpuq_ingest_push(gpuq_ingest* g, struct ArrowArray* batch) {
     for (size_t c = 0; c < g->cols.size(); ++c) {
       if (g->cols[c].type.id != T_UTF8 || n == 0) continue;
       const ArrowArray* a = batch->children[c];
-      const int32_t* o = (const int32_t*)a->buffers[1] + a->offset + batch->offset;
-      const int64_t nb = (int64_t)o[n] - (int64_t)o[0];
+      const int64_t nb = gpuq_ingest::utf8_off(g->cols[c], a, a->offset + batch->offset + n) - gpuq_ingest::utf8_off(g->cols[c], a, a->offset + batch->offset);
       if (g->next_byte[c] + nb > g->cols[c].bytes_cap || g->next_byte[c] + nb > 0x7FFFFFFFll) throw Capacity("ingest: column '" + g->cols[c].name + "' exceeds max_utf8_bytes");
       g->next_byte[c] += nb;
     }

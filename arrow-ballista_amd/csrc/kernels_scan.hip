@@ -156,6 +156,9 @@ __device__ __forceinline__ void k_project_body(const DevProgram P, const i64 n_a
         switch (oc.cls) {
           case CC_I32: case CC_U32: if (active) ((uint32_t*)oc.data)[pos] = (uint32_t)lo; break;
           case CC_I64: if (active) ((u64*)oc.data)[pos] = lo; break;
+          case CC_I8: case CC_U8: if (active) ((uint8_t*)oc.data)[pos] = (uint8_t)lo; break;
+          case CC_I16: case CC_U16: if (active) ((uint16_t*)oc.data)[pos] = (uint16_t)lo; break;
+          case CC_F32: if (active) ((float*)oc.data)[pos] = (float)__longlong_as_double((i64)lo); break;
           case CC_I128: case CC_STR: if (active) ((ulonglong2*)oc.data)[pos] = make_ulonglong2(lo, hi); break;
           case CC_BIT: { const u64 bm = __ballot(active && lo != 0); if (lane_id() == 0) ((u64*)oc.data)[w] = bm; break; }
           default: break;

@@ -271,6 +271,12 @@ __device__ __forceinline__ bool pq_hybrid(const uint8_t* p, const uint8_t* end, 
 }
 
 // one wave per page
+// INT96 (Impala / Spark timestamps): 8 bytes nanoseconds of the day, 4 bytes Julian day, little-endian -> nanoseconds since 1970-01-01
+// (Julian day 2440588), as parquet-rs' Int96::to_nanos [UPSTREAM-KNOWLEDGE]
+__device__ __forceinline__ i64 pq_int96_ns(const uint8_t* q) {
+  i64 nanos; int32_t jd; __builtin_memcpy(&nanos, q, 8); __builtin_memcpy(&jd, q + 8, 4);
+  return ((i64)jd - 2440588) * 86400000000000ll + nanos;
+}
 __global__ void __launch_bounds__(64) k_pq_decode(const uint8_t* __restrict__ file, const i64 file_bytes, const PqPage* __restrict__ pages, const int n_pages, const PqCol C,
                                                   const PqDict* __restrict__ dicts, const uint8_t* __restrict__ dict_values, const int32_t* __restrict__ dict_str_offsets,
                                                   uint32_t* __restrict__ scratch /* per page: n_values u32 (value index of every row, or NIL) */, const i64 scratch_stride,
@@ -349,6 +355,8 @@ __global__ void __launch_bounds__(64) k_pq_decode(const uint8_t* __restrict__ fi
       const uint32_t k = ix[vi];
       if ((int)k >= D.n) { atomicOr(flags, PQF_MALFORMED); continue; }
       if (C.phys == PQ_BYTE_ARRAY) { const int32_t* so = dict_str_offsets + D.str_offsets; C.str_len[r] = so[k + 1] - so[k]; C.str_src[r] = -(2 + (D.values + so[k])); }   // negative: position in the dictionary bytes
+      else if (C.width == 1) ((uint8_t*)C.data)[r] = ((const uint8_t*)(dict_values + D.values))[k];
+      else if (C.width == 2) ((uint16_t*)C.data)[r] = ((const uint16_t*)(dict_values + D.values))[k];
       else if (C.width == 4) ((uint32_t*)C.data)[r] = ((const uint32_t*)(dict_values + D.values))[k];
       else if (C.width == 8) ((u64*)C.data)[r] = ((const u64*)(dict_values + D.values))[k];
       else { ((u64*)C.data)[2 * r] = ((const u64*)(dict_values + D.values))[2 * k]; ((u64*)C.data)[2 * r + 1] = ((const u64*)(dict_values + D.values))[2 * k + 1]; }
@@ -385,7 +393,7 @@ __global__ void __launch_bounds__(64) k_pq_decode(const uint8_t* __restrict__ fi
   }
   {      // the page must hold every value its header and levels announce: nothing below reads past `end`
     const i64 have = end - p;
-    const i64 need = C.phys == PQ_BOOL ? ((i64)n_present + 7) / 8 : (i64)n_present * (C.phys == PQ_I32 ? 4 : (C.phys == PQ_FLBA ? C.flba_len : 8));
+    const i64 need = C.phys == PQ_BOOL ? ((i64)n_present + 7) / 8 : (i64)n_present * ((C.phys == PQ_I32 || C.phys == PQ_F32) ? 4 : (C.phys == PQ_FLBA ? C.flba_len : (C.phys == PQ_I96 ? 12 : 8)));
     if (need > have) { if (flane() == 0) atomicOr(flags, PQF_MALFORMED); return; }
   }
   for (int i = flane(); i < n; i += 64) {
@@ -394,7 +402,9 @@ __global__ void __launch_bounds__(64) k_pq_decode(const uint8_t* __restrict__ fi
     const i64 r = P.row0 + i;
     switch (C.phys) {
       case PQ_BOOL: { const uint8_t byte = file[voff + (vi >> 3)]; if ((byte >> (vi & 7)) & 1) atomicOr((unsigned long long*)&((u64*)C.data)[r >> 6], 1ull << (r & 63)); break; }
-      case PQ_I32: { uint32_t v; __builtin_memcpy(&v, file + voff + (i64)vi * 4, 4); if (C.width == 4) ((uint32_t*)C.data)[r] = v; else { const i64 w = (int32_t)v; if (C.width == 8) ((i64*)C.data)[r] = w; else { ((u64*)C.data)[2 * r] = (u64)w; ((u64*)C.data)[2 * r + 1] = (u64)(w >> 63); } } break; }
+      case PQ_I96: ((i64*)C.data)[r] = pq_int96_ns(file + voff + (i64)vi * 12); break;
+      case PQ_F32: { uint32_t v; __builtin_memcpy(&v, file + voff + (i64)vi * 4, 4); ((uint32_t*)C.data)[r] = v; break; }
+      case PQ_I32: { uint32_t v; __builtin_memcpy(&v, file + voff + (i64)vi * 4, 4); if (C.width == 4) ((uint32_t*)C.data)[r] = v; else if (C.width == 1) ((uint8_t*)C.data)[r] = (uint8_t)v; else if (C.width == 2) ((uint16_t*)C.data)[r] = (uint16_t)v; else { const i64 w = (int32_t)v; if (C.width == 8) ((i64*)C.data)[r] = w; else { ((u64*)C.data)[2 * r] = (u64)w; ((u64*)C.data)[2 * r + 1] = (u64)(w >> 63); } } break; }
       case PQ_I64: case PQ_F64: { u64 v; __builtin_memcpy(&v, file + voff + (i64)vi * 8, 8); if (C.width == 8) ((u64*)C.data)[r] = v; else { ((u64*)C.data)[2 * r] = v; ((u64*)C.data)[2 * r + 1] = (u64)((i64)v >> 63); } break; }
       case PQ_FLBA: {      // big-endian two's complement decimal of flba_len bytes -> little-endian 128 bits
         const uint8_t* q = file + voff + (i64)vi * C.flba_len;
@@ -440,10 +450,13 @@ __global__ void __launch_bounds__(FBLOCK) k_pq_dict_fixed(const uint8_t* __restr
                                                           const int32_t width, uint8_t* __restrict__ out) {
   for (int i = blockIdx.x * FBLOCK + threadIdx.x; i < n; i += gridDim.x * FBLOCK) {
     u128 v = 0;
-    if (phys == PQ_I32) { int32_t x; __builtin_memcpy(&x, file + src + (i64)i * 4, 4); v = (u128)(i128)x; }
+    if (phys == PQ_I32 || phys == PQ_F32) { int32_t x; __builtin_memcpy(&x, file + src + (i64)i * 4, 4); v = (u128)(i128)x; }
+    else if (phys == PQ_I96) v = (u128)(i128)pq_int96_ns(file + src + (i64)i * 12);
     else if (phys == PQ_I64 || phys == PQ_F64) { i64 x; __builtin_memcpy(&x, file + src + (i64)i * 8, 8); v = (u128)(i128)x; }
     else { const uint8_t* q = file + src + (i64)i * flba_len; v = (q[0] & 0x80) ? ~(u128)0 : 0; for (int k = 0; k < flba_len; ++k) v = (v << 8) | q[k]; }
     if (width == 4) ((uint32_t*)out)[i] = (uint32_t)v;
+    else if (width == 1) out[i] = (uint8_t)v;
+    else if (width == 2) ((uint16_t*)out)[i] = (uint16_t)v;
     else if (width == 8) ((u64*)out)[i] = (u64)v;
     else { ((u64*)out)[2 * i] = (u64)v; ((u64*)out)[2 * i + 1] = (u64)(v >> 64); }
   }

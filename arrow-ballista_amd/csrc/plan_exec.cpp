@@ -59,7 +59,10 @@ Json type_json_of(int tid, int p, int s) {
   switch (tid) {
     case T_BOOL: return jstr("Boolean"); case T_INT32: return jstr("Int32"); case T_INT64: return jstr("Int64"); case T_DATE32: return jstr("Date32");
     case T_FLOAT64: return jstr("Float64"); case T_UTF8: return jstr("Utf8"); case T_UINT32: return jstr("UInt32"); case T_UINT64: return jstr("UInt64");
+    case T_INT8: return jstr("Int8"); case T_INT16: return jstr("Int16"); case T_UINT8: return jstr("UInt8"); case T_UINT16: return jstr("UInt16");
+    case T_FLOAT32: return jstr("Float32"); case T_DATE64: return jstr("Date64");
     case T_DECIMAL128: return jobj({{"Decimal128", jarr({jnum(p), jnum(s)})}});
+    case T_TIMESTAMP: { static const char* u[4] = {"Second", "Millisecond", "Microsecond", "Nanosecond"}; return jobj({{"Timestamp", jarr({jstr(u[p & 3]), Json()})}}); }
   }
   throw std::runtime_error("plan: type id " + std::to_string(tid) + " has no name");
 }

@@ -235,7 +235,8 @@ struct TReader {
   uint64_t list_header(int& elem_type) { need(1); const uint8_t h = *p++; uint64_t n = h >> 4; elem_type = h & 0x0F; if (n == 15) n = varint(); return n; }
 };
 
-struct PqSchemaElem { int type = -1, type_length = 0, repetition = 0, num_children = 0, converted = -1, scale = 0, precision = 0; std::string name; bool logical_decimal = false, logical_date = false, logical_string = false; };
+struct PqSchemaElem { int type = -1, type_length = 0, repetition = 0, num_children = 0, converted = -1, scale = 0, precision = 0; std::string name; bool logical_decimal = false, logical_date = false, logical_string = false;
+                      int int_bits = 0; bool int_signed = true; int ts_unit = -1; };      // LogicalType INTEGER {bitWidth, isSigned}, TIMESTAMP {unit}: gpuq TimeUnit 1 ms / 2 us / 3 ns
 struct PqChunk { int type = -1, codec = 0; int64_t num_values = 0, total_compressed = 0, data_page_offset = 0, dict_page_offset = -1; std::vector<std::string> path; };
 struct PqRowGroup { std::vector<PqChunk> cols; int64_t num_rows = 0; };
 struct PqFileMeta { std::vector<PqSchemaElem> schema; std::vector<PqRowGroup> groups; int64_t num_rows = 0; };
@@ -254,6 +255,15 @@ PqSchemaElem read_schema_elem(TReader& r) {
           if (id2 == 5) {      // DecimalType {1 scale, 2 precision}
             s.logical_decimal = true; int t3, id3, last3 = 0;
             while (r.field(t3, id3, last3)) { if (id3 == 1) s.scale = (int)r.zigzag(); else if (id3 == 2) s.precision = (int)r.zigzag(); else r.skip(t3); }
+          } else if (id2 == 10) {      // IntType {1 bitWidth: i8, 2 isSigned: bool (in the field header)}
+            int t3, id3, last3 = 0;
+            while (r.field(t3, id3, last3)) { if (id3 == 1 && t3 == 3) { r.need(1); s.int_bits = (int)(int8_t)*r.p++; } else if (id3 == 2 && (t3 == 1 || t3 == 2)) s.int_signed = t3 == 1; else r.skip(t3); }
+          } else if (id2 == 8) {      // TimestampType {1 isAdjustedToUTC, 2 unit: union {1 MILLIS, 2 MICROS, 3 NANOS}}
+            int t3, id3, last3 = 0;
+            while (r.field(t3, id3, last3)) {
+              if (id3 == 2 && t3 == 12) { int t4, id4, last4 = 0; while (r.field(t4, id4, last4)) { if (id4 >= 1 && id4 <= 3) s.ts_unit = id4; r.skip(t4); } }
+              else r.skip(t3);
+            }
           } else r.skip(t2);
         }
         break;
@@ -262,6 +272,31 @@ PqSchemaElem read_schema_elem(TReader& r) {
     }
   }
   return s;
+}
+// parquet.thrift Type / ConvertedType / LogicalType of a leaf -> gpuq_type (+ precision / scale / bytes per value on the device); false = not read
+// on the device.  INT96 is Impala's timestamp (nanoseconds of the day + Julian day) -> Timestamp(Nanosecond), as arrow's reader maps it.
+bool pq_leaf_type(const PqSchemaElem& L, int& gt, int& gp, int& gs, int& width) {
+  const bool dec = L.logical_decimal || L.converted == 5;
+  gp = 0; gs = 0; width = 0;
+  switch (L.type) {
+    case 0: gt = T_BOOL; return true;
+    case 1:
+      if (dec) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; width = 16; return true; }
+      if (L.logical_date || L.converted == 6) { gt = T_DATE32; width = 4; return true; }
+      if (L.int_bits == 8 || L.converted == 15 || L.converted == 11) { const bool sg = L.int_bits ? L.int_signed : L.converted == 15; gt = sg ? T_INT8 : T_UINT8; width = 1; return true; }
+      if (L.int_bits == 16 || L.converted == 16 || L.converted == 12) { const bool sg = L.int_bits ? L.int_signed : L.converted == 16; gt = sg ? T_INT16 : T_UINT16; width = 2; return true; }
+      gt = ((L.int_bits == 32 && !L.int_signed) || L.converted == 13) ? T_UINT32 : T_INT32; width = 4; return true;
+    case 2:
+      if (dec) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; width = 16; return true; }
+      if (L.ts_unit > 0 || L.converted == 9 || L.converted == 10) { gt = T_TIMESTAMP; gp = L.ts_unit > 0 ? L.ts_unit : (L.converted == 9 ? 1 : 2); width = 8; return true; }
+      gt = ((L.int_bits == 64 && !L.int_signed) || L.converted == 14) ? T_UINT64 : T_INT64; width = 8; return true;
+    case 3: gt = T_TIMESTAMP; gp = 3; width = 8; return true;
+    case 4: gt = T_FLOAT32; width = 4; return true;
+    case 5: gt = T_FLOAT64; width = 8; return true;
+    case 6: if (dec) return false; gt = T_UTF8; return true;
+    case 7: if (!dec || L.type_length < 1 || L.type_length > 16) return false; gt = T_DECIMAL128; gp = L.precision; gs = L.scale; width = 16; return true;
+    default: return false;
+  }
 }
 PqChunk read_chunk(TReader& r) {
   PqChunk c; int t, id, last = 0;
@@ -385,16 +420,8 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
       const PqSchemaElem& L = leaves[(size_t)li];
       auto P = std::make_unique<ColPlan>();
       // type mapping (parquet.thrift Type / ConvertedType / LogicalType -> gpuq_type)
-      const bool is_decimal = L.logical_decimal || L.converted == 5;
-      switch (L.type) {
-        case 0: P->gt = T_BOOL; break;
-        case 1: if (is_decimal) { P->gt = T_DECIMAL128; P->gp = L.precision; P->gs = L.scale; P->width = 16; } else if (L.logical_date || L.converted == 6) { P->gt = T_DATE32; P->width = 4; } else { P->gt = T_INT32; P->width = 4; } break;
-        case 2: if (is_decimal) { P->gt = T_DECIMAL128; P->gp = L.precision; P->gs = L.scale; P->width = 16; } else { P->gt = T_INT64; P->width = 8; } break;
-        case 5: P->gt = T_FLOAT64; P->width = 8; break;
-        case 6: if (is_decimal) throw Unsupported("parquet: BYTE_ARRAY decimals ('" + L.name + "')"); P->gt = T_UTF8; break;
-        case 7: if (!is_decimal || L.type_length < 1 || L.type_length > 16) throw Unsupported("parquet: FIXED_LEN_BYTE_ARRAY column '" + L.name + "' (only decimals of 1..16 bytes; type_length " + std::to_string(L.type_length) + ")"); P->gt = T_DECIMAL128; P->gp = L.precision; P->gs = L.scale; P->width = 16; break;
-        default: throw Unsupported("parquet: physical type " + std::to_string(L.type) + " of column '" + L.name + "' (FLOAT / INT96 are not read on the device)");
-      }
+      if (!pq_leaf_type(L, P->gt, P->gp, P->gs, P->width))
+        throw Unsupported("parquet: column '" + L.name + "' (physical type " + std::to_string(L.type) + (L.type == 7 ? ", type_length " + std::to_string(L.type_length) : std::string()) + ": BYTE_ARRAY decimals and FIXED_LEN_BYTE_ARRAY other than decimals of 1..16 bytes are not read on the device)");
       P->optional = L.repetition == 1;
       int64_t row = 0;
       for (const PqRowGroup& G : M.groups) {
@@ -476,7 +503,7 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
         PqDict D{}; D.values = (i64)va; D.str_offsets = (i64)(oa / 4); D.n = d.n;
         if (gt == T_UTF8) { launch_pq_dict_strings(s, pages_base, d.src, d.bytes, d.n, (int32_t*)P.dstroffs.p + oa / 4, (uint8_t*)P.dvalues.p + va, (uint32_t*)flags.p); va += ((size_t)d.bytes + 63) & ~(size_t)63; oa += ((size_t)d.n + 2) * 4; }
         else {
-          const int64_t elem = L.type == 1 ? 4 : (L.type == 7 ? L.type_length : 8);
+          const int64_t elem = (L.type == 1 || L.type == 4) ? 4 : (L.type == 7 ? L.type_length : (L.type == 3 ? 12 : 8));
           if ((int64_t)d.n * elem > d.bytes) throw std::runtime_error("parquet: dictionary page of '" + L.name + "' is shorter than its value count");
           launch_pq_dict_fixed(s, pages_base, d.src, d.n, L.type, L.type_length, width, (uint8_t*)P.dvalues.p + va); va += ((size_t)d.n * (size_t)width + 63) & ~(size_t)63; }
         P.dicts.push_back(D);
@@ -531,17 +558,8 @@ int gpuq_parquet_schema(const uint8_t* file, int64_t n_bytes, gpuq_field_info* f
     if (!fields_out || cap < n) { if (!fields_out && cap == 0) return; throw Capacity("parquet schema has " + std::to_string(n) + " columns"); }
     for (int i = 0; i < n; ++i) {
       const PqSchemaElem& L = M.schema[(size_t)i + 1];
-      const bool dec = L.logical_decimal || L.converted == 5;
-      int gt = -1, gp = 0, gs = 0;
-      switch (L.type) {
-        case 0: gt = T_BOOL; break;
-        case 1: if (dec) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; } else gt = (L.logical_date || L.converted == 6) ? T_DATE32 : T_INT32; break;
-        case 2: if (dec) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; } else gt = T_INT64; break;
-        case 5: gt = T_FLOAT64; break;
-        case 6: gt = dec ? -1 : T_UTF8; break;
-        case 7: if (dec && L.type_length >= 1 && L.type_length <= 16) { gt = T_DECIMAL128; gp = L.precision; gs = L.scale; } break;
-        default: break;
-      }
+      int gt = -1, gp = 0, gs = 0, gw = 0;
+      if (!pq_leaf_type(L, gt, gp, gs, gw)) gt = -1;
       if (L.num_children > 0 || L.repetition == 2) gt = -1;
       gpuq_field_info f{}; std::snprintf(f.name, sizeof(f.name), "%s", L.name.c_str());
       f.type = gt; f.precision = gp; f.scale = gs; f.nullable = L.repetition == 1; f.repr = GPUQ_REPR_ARROW;

@@ -175,8 +175,10 @@ std::vector<uint8_t> build_schema_metadata(const gpuq_field_info* fields, int n_
     const gpuq_field_info& f = fields[c];
     int type_type = 0;
     switch (f.type) {
-      case GPUQ_INT32: case GPUQ_INT64: case GPUQ_UINT32: case GPUQ_UINT64: type_type = 2; break;
-      case GPUQ_FLOAT64: type_type = 3; break;
+      case GPUQ_INT32: case GPUQ_INT64: case GPUQ_UINT32: case GPUQ_UINT64: case GPUQ_INT8: case GPUQ_INT16: case GPUQ_UINT8: case GPUQ_UINT16: type_type = 2; break;
+      case GPUQ_FLOAT64: case GPUQ_FLOAT32: type_type = 3; break;
+      case GPUQ_DATE64: type_type = 8; break;
+      case GPUQ_TIMESTAMP: type_type = 10; break;
       case GPUQ_UTF8: type_type = 5; break;
       case GPUQ_BOOL: type_type = 6; break;
       case GPUQ_DECIMAL128: type_type = 7; break;
@@ -194,6 +196,13 @@ std::vector<uint8_t> build_schema_metadata(const gpuq_field_info* fields, int n_
       case GPUQ_INT64: tt = w.table(2, {{0, 4, 64}, {1, 1, 1}}, ta); break;
       case GPUQ_UINT32: tt = w.table(2, {{0, 4, 32}, {1, 1, 0}}, ta); break;
       case GPUQ_UINT64: tt = w.table(2, {{0, 4, 64}, {1, 1, 0}}, ta); break;
+      case GPUQ_INT8: tt = w.table(2, {{0, 4, 8}, {1, 1, 1}}, ta); break;
+      case GPUQ_INT16: tt = w.table(2, {{0, 4, 16}, {1, 1, 1}}, ta); break;
+      case GPUQ_UINT8: tt = w.table(2, {{0, 4, 8}, {1, 1, 0}}, ta); break;
+      case GPUQ_UINT16: tt = w.table(2, {{0, 4, 16}, {1, 1, 0}}, ta); break;
+      case GPUQ_FLOAT32: tt = w.table(1, {{0, 2, 1 /* SINGLE */}}, ta); break;
+      case GPUQ_DATE64: tt = w.table(1, {{0, 2, 1 /* DateUnit MILLISECOND */}}, ta); break;
+      case GPUQ_TIMESTAMP: tt = w.table(1, {{0, 2, (uint64_t)(f.precision & 3) /* TimeUnit; no timezone: the schema layer owns it */}}, ta); break;
       case GPUQ_FLOAT64: tt = w.table(1, {{0, 2, 2 /* DOUBLE */}}, ta); break;
       case GPUQ_UTF8: case GPUQ_BOOL: tt = w.table(0, {}, ta); break;
       case GPUQ_DECIMAL128: tt = w.table(3, {{0, 4, (uint64_t)f.precision}, {1, 4, (uint64_t)f.scale}, {2, 4, 128}}, ta); break;
@@ -224,8 +233,10 @@ std::vector<uint8_t> build_schema_metadata(const gpuq_field_info* fields, int n_
 
 int type_width_of(int type) {
   switch (type) {
-    case GPUQ_INT32: case GPUQ_DATE32: case GPUQ_UINT32: return 4;
-    case GPUQ_INT64: case GPUQ_FLOAT64: case GPUQ_UINT64: return 8;
+    case GPUQ_INT32: case GPUQ_DATE32: case GPUQ_UINT32: case GPUQ_FLOAT32: return 4;
+    case GPUQ_INT64: case GPUQ_FLOAT64: case GPUQ_UINT64: case GPUQ_TIMESTAMP: case GPUQ_DATE64: return 8;
+    case GPUQ_INT8: case GPUQ_UINT8: return 1;
+    case GPUQ_INT16: case GPUQ_UINT16: return 2;
     case GPUQ_DECIMAL128: return 16;
     default: return 0;
   }

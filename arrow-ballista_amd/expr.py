@@ -15,6 +15,8 @@ class Operator:
 def _type_json(t):
     if isinstance(t, (list, tuple)) and t[0] == "Decimal128":
         return {"Decimal128": [int(t[1]), int(t[2])]}
+    if isinstance(t, (list, tuple)) and t[0] == "Timestamp":      # ("Timestamp", unit[, tz])
+        return {"Timestamp": [t[1], t[2] if len(t) > 2 else None]}
     return t
 
 
@@ -33,7 +35,7 @@ def col(name, schema=None, index=None):
 
 def lit(value, type=None):
     """Literal.  Python int -> Int64, float -> Float64, str -> Utf8, bool -> Boolean unless `type` says otherwise.
-    Decimal128: lit(unscaled_int, ("Decimal128", p, s)).  Date32: lit(days, "Date32")."""
+    Decimal128: lit(unscaled_int, ("Decimal128", p, s)).  Date32: lit(days, "Date32").  Timestamp: lit(count, ("Timestamp", "Microsecond"))."""
     if type is None:
         if isinstance(value, bool):
             type = "Boolean"
@@ -48,7 +50,7 @@ def lit(value, type=None):
     t = _type_json(type)
     if value is None:
         return {"literal": {"type": t, "value": None}}
-    if t in ("Utf8", "Boolean", "Float64"):
+    if t in ("Utf8", "Boolean", "Float64", "Float32"):
         return {"literal": {"type": t, "value": value}}
     return {"literal": {"type": t, "value": str(int(value))}}
 

@@ -19,7 +19,7 @@ import uuid
 
 from . import binding as B
 from . import expr as E
-from .table import DeviceColumn, DeviceTable, record_layout, type_id, type_json, type_width
+from .table import DeviceColumn, DeviceTable, arrow_type_json, record_layout, type_id, type_json, type_width
 
 NULL_ROW = 0xFFFFFFFF
 
@@ -453,12 +453,9 @@ def _arrow_schema(s):
     import pyarrow as pa
     out = []
     for f in s:
-        t = f.type
-        if pa.types.is_decimal128(t):
-            tj = {"Decimal128": [t.precision, t.scale]}
-        else:
-            tj = {pa.int32(): "Int32", pa.int64(): "Int64", pa.date32(): "Date32", pa.float64(): "Float64", pa.string(): "Utf8",
-                  pa.large_string(): "Utf8", pa.bool_(): "Boolean", pa.uint32(): "UInt32", pa.uint64(): "UInt64", pa.binary(): "Utf8"}[t]
+        tj = arrow_type_json(f.type)
+        if tj is None:
+            raise B.GpuqError(3, "Arrow type %s is not supported on device" % f.type)
         out.append({"name": f.name, "type": tj, "nullable": f.nullable})
     return out
 

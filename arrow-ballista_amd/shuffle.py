@@ -10,7 +10,7 @@ then one encapsulated message per batch, then the end-of-stream marker."""
 import ctypes as C
 
 from . import binding as B
-from .table import DeviceColumn, DeviceTable, type_id, type_json
+from .table import DeviceColumn, DeviceTable, json_arrow_type, type_id, type_json
 
 EOS = b"\xff\xff\xff\xff\x00\x00\x00\x00"
 # Rows per RecordBatch the device sink writes: the reference cuts its stream at the session batch size (8192) because that is
@@ -30,9 +30,7 @@ def _check(L, rc):
 
 def _arrow_type(t):
     import pyarrow as pa
-    tid, p, s = type_id(t)
-    return {B.T_INT32: pa.int32(), B.T_INT64: pa.int64(), B.T_DATE32: pa.date32(), B.T_FLOAT64: pa.float64(), B.T_UINT32: pa.uint32(),
-            B.T_UINT64: pa.uint64(), B.T_UTF8: pa.string(), B.T_BOOL: pa.bool_()}.get(tid) or pa.decimal128(p, s)
+    return json_arrow_type(t)
 
 
 def _arrow_schema(table):

@@ -4,25 +4,69 @@ import ctypes as C
 from . import binding as B
 
 _TYPE_IDS = {"Boolean": B.T_BOOL, "Int32": B.T_INT32, "Int64": B.T_INT64, "Date32": B.T_DATE32, "Float64": B.T_FLOAT64,
-             "Utf8": B.T_UTF8, "UInt32": B.T_UINT32, "UInt64": B.T_UINT64}
+             "Utf8": B.T_UTF8, "UInt32": B.T_UINT32, "UInt64": B.T_UINT64, "Int8": B.T_INT8, "Int16": B.T_INT16, "UInt8": B.T_UINT8,
+             "UInt16": B.T_UINT16, "Float32": B.T_FLOAT32, "Date64": B.T_DATE64}
 _ID_TYPES = {v: k for k, v in _TYPE_IDS.items()}
+_TIME_UNITS = ["Second", "Millisecond", "Microsecond", "Nanosecond"]
+_PA_UNITS = ["s", "ms", "us", "ns"]
 
 
 def type_id(t):
+    """(gpuq_type, precision, scale) of a type descriptor (the JSON form of datafusion.proto's ArrowType)."""
     if isinstance(t, dict):
+        if "Timestamp" in t:
+            u = t["Timestamp"][0] if isinstance(t["Timestamp"], (list, tuple)) else t["Timestamp"]
+            return B.T_TIMESTAMP, (_TIME_UNITS.index(u) if u in _TIME_UNITS else _PA_UNITS.index(u)), 0
+        if "Dictionary" in t:
+            return type_id(t["Dictionary"][1])
         return B.T_DECIMAL128, int(t["Decimal128"][0]), int(t["Decimal128"][1])
+    if t == "LargeUtf8":
+        return B.T_UTF8, 0, 0
     return _TYPE_IDS[t], 0, 0
 
 
 def type_json(tid, p=0, s=0):
     if tid == B.T_DECIMAL128:
         return {"Decimal128": [int(p), int(s)]}
+    if tid == B.T_TIMESTAMP:
+        return {"Timestamp": [_TIME_UNITS[int(p) & 3], None]}
     return _ID_TYPES[tid]
 
 
 def type_width(t):
     tid = type_id(t)[0]
-    return {B.T_INT32: 4, B.T_DATE32: 4, B.T_UINT32: 4, B.T_INT64: 8, B.T_UINT64: 8, B.T_FLOAT64: 8, B.T_DECIMAL128: 16, B.T_UTF8: 16}.get(tid, 0)
+    return {B.T_INT32: 4, B.T_DATE32: 4, B.T_UINT32: 4, B.T_INT64: 8, B.T_UINT64: 8, B.T_FLOAT64: 8, B.T_DECIMAL128: 16, B.T_UTF8: 16,
+            B.T_INT8: 1, B.T_UINT8: 1, B.T_INT16: 2, B.T_UINT16: 2, B.T_FLOAT32: 4, B.T_TIMESTAMP: 8, B.T_DATE64: 8}.get(tid, 0)
+
+
+def arrow_type_json(t):
+    """Type descriptor of a pyarrow type, or None.  LargeUtf8 / Binary / Dictionary columns are described by what they are inside
+    the engine (Utf8 / the value type): from_arrow converts them where they enter."""
+    import pyarrow as pa
+    if pa.types.is_decimal128(t):
+        return {"Decimal128": [t.precision, t.scale]}
+    if pa.types.is_timestamp(t):
+        return {"Timestamp": [_TIME_UNITS[_PA_UNITS.index(t.unit)], t.tz]}
+    if pa.types.is_dictionary(t):
+        return arrow_type_json(t.value_type)
+    return {pa.int32(): "Int32", pa.int64(): "Int64", pa.date32(): "Date32", pa.float64(): "Float64", pa.string(): "Utf8",
+            pa.large_string(): "Utf8", pa.bool_(): "Boolean", pa.uint32(): "UInt32", pa.uint64(): "UInt64", pa.binary(): "Utf8",
+            pa.int8(): "Int8", pa.int16(): "Int16", pa.uint8(): "UInt8", pa.uint16(): "UInt16", pa.float32(): "Float32",
+            pa.date64(): "Date64"}.get(t)
+
+
+def json_arrow_type(t):
+    """pyarrow type of a type descriptor."""
+    import pyarrow as pa
+    tid, p, s = type_id(t)
+    if tid == B.T_DECIMAL128:
+        return pa.decimal128(p, s)
+    if tid == B.T_TIMESTAMP:
+        tz = t["Timestamp"][1] if isinstance(t, dict) and isinstance(t.get("Timestamp"), (list, tuple)) and len(t["Timestamp"]) > 1 else None
+        return pa.timestamp(_PA_UNITS[p], tz=tz)
+    return {B.T_INT32: pa.int32(), B.T_INT64: pa.int64(), B.T_DATE32: pa.date32(), B.T_FLOAT64: pa.float64(), B.T_UINT32: pa.uint32(),
+            B.T_UINT64: pa.uint64(), B.T_UTF8: pa.string(), B.T_BOOL: pa.bool_(), B.T_INT8: pa.int8(), B.T_INT16: pa.int16(),
+            B.T_UINT8: pa.uint8(), B.T_UINT16: pa.uint16(), B.T_FLOAT32: pa.float32(), B.T_DATE64: pa.date64()}[tid]
 
 
 RECORD_HEADER = 256
@@ -153,30 +197,17 @@ class DeviceTable:
         cols = []
         for name, chunked in zip(tbl.schema.names, tbl.columns):
             arr = chunked.combine_chunks() if chunked.num_chunks != 1 else chunked.chunk(0)
+            # (this is the tests' and benches' way in; the C ABI's own is gpuq_import_arrow / gpuq_ingest_*, which convert LargeUtf8
+            # offsets and decode dictionaries themselves)
+            if pa.types.is_dictionary(arr.type):
+                arr = arr.cast(arr.type.value_type)
             if pa.types.is_large_string(arr.type) or pa.types.is_binary(arr.type):
                 arr = arr.cast(pa.string())
             if arr.offset != 0:
                 arr = pa.concat_arrays([arr])
             t = arr.type
-            if pa.types.is_int32(t):
-                tj = "Int32"
-            elif pa.types.is_int64(t):
-                tj = "Int64"
-            elif pa.types.is_date32(t):
-                tj = "Date32"
-            elif pa.types.is_float64(t):
-                tj = "Float64"
-            elif pa.types.is_decimal128(t):
-                tj = {"Decimal128": [t.precision, t.scale]}
-            elif pa.types.is_string(t):
-                tj = "Utf8"
-            elif pa.types.is_boolean(t):
-                tj = "Boolean"
-            elif pa.types.is_uint32(t):
-                tj = "UInt32"
-            elif pa.types.is_uint64(t):
-                tj = "UInt64"
-            else:
+            tj = arrow_type_json(t)
+            if tj is None:
                 raise B.GpuqError(3, "Arrow type %s is not supported on device" % t)
             bufs = arr.buffers()
 
@@ -236,8 +267,7 @@ class DeviceTable:
                 db = c.data.cpu().numpy().view(np.uint8)[: (n + 7) // 8].tobytes()
                 arrays.append(pa.Array.from_buffers(pa.bool_(), n, [validity, pa.py_buffer(db)], null_count=null_count))
             else:
-                pt = {B.T_INT32: pa.int32(), B.T_INT64: pa.int64(), B.T_DATE32: pa.date32(), B.T_FLOAT64: pa.float64(),
-                      B.T_UINT32: pa.uint32(), B.T_UINT64: pa.uint64()}.get(tid) or pa.decimal128(p, s)
+                pt = json_arrow_type(c.type)
                 w = type_width(c.type)
                 db = c.data.cpu().numpy().view(np.uint8)[: n * w].tobytes()
                 arrays.append(pa.Array.from_buffers(pt, n, [validity, pa.py_buffer(db)], null_count=null_count))

@@ -52,7 +52,12 @@ typedef enum gpuq_status {
 /* Logical types (subset of ballista/core/proto/datafusion.proto:1004-1040 ArrowType). */
 typedef enum gpuq_type {
   GPUQ_NULL = 0, GPUQ_BOOL = 1, GPUQ_INT32 = 2, GPUQ_INT64 = 3, GPUQ_DATE32 = 4, GPUQ_FLOAT64 = 5,
-  GPUQ_DECIMAL128 = 6, GPUQ_UTF8 = 7, GPUQ_UINT32 = 8, GPUQ_UINT64 = 9
+  GPUQ_DECIMAL128 = 6, GPUQ_UTF8 = 7, GPUQ_UINT32 = 8, GPUQ_UINT64 = 9,
+  /* second wave: Arrow physical layout as well (1 / 2 / 4 / 8 bytes per value); kernels widen on load and narrow on store */
+  GPUQ_INT8 = 10, GPUQ_INT16 = 11, GPUQ_UINT8 = 12, GPUQ_UINT16 = 13, GPUQ_FLOAT32 = 14,
+  GPUQ_TIMESTAMP = 15, /* int64 count of `precision` = TimeUnit (0 s, 1 ms, 2 us, 3 ns) since the epoch; the time zone is schema metadata */
+  GPUQ_DATE64 = 16     /* int64 milliseconds since the epoch */
+  /* LargeUtf8 and Dictionary(_, T) columns are converted where they enter: gpuq_table_import_arrow and gpuq_ingest_* narrow the offsets / decode the dictionary while staging; inside, Utf8 has 32-bit offsets */
 } gpuq_type;
 
 /* Device representation of an output column. */
@@ -146,7 +151,9 @@ int gpuq_copy_h2d(gpuq_ctx* ctx, void* stream, void* dst_dev, const void* src_ho
 int gpuq_copy_d2h(gpuq_ctx* ctx, void* stream, void* dst_host, const void* src_dev, size_t bytes); /* synchronous */
 
 /* Import one RecordBatch (a struct-typed ArrowArray + its ArrowSchema).  The batch is NOT consumed: the
-   caller keeps ownership and releases it as usual.  Supported column formats: i l tdD g d:p,s u b I L. */
+   caller keeps ownership and releases it as usual.  Supported column formats: b c C s S i I l L f g tdD tdm ts{s,m,u,n}:tz d:p,s u,
+   and, converted while they are staged: U (LargeUtf8 -> 32-bit offsets; a column beyond 2^31 bytes is refused) and dictionary-encoded
+   columns of any of these (decoded: the device column has the value type). */
 int gpuq_table_import_arrow(gpuq_ctx* ctx, void* stream, const struct ArrowArray* batch, const struct ArrowSchema* schema, gpuq_table** out);
 int64_t gpuq_table_num_rows(const gpuq_table* t);
 int gpuq_table_num_columns(const gpuq_table* t);

@@ -382,8 +382,8 @@ def test_parquet_footer_is_read_on_the_host():
     fields, rows = scan.parquet_schema(L, os.path.join(os.path.dirname(__file__), "golden", "alltypes_plain.parquet"))
     assert rows == 8
     assert fields == [("id", "Int32", True), ("bool_col", "Boolean", True), ("tinyint_col", "Int32", True), ("smallint_col", "Int32", True),
-                      ("int_col", "Int32", True), ("bigint_col", "Int64", True), ("float_col", None, True), ("double_col", "Float64", True),
-                      ("date_string_col", "Utf8", True), ("string_col", "Utf8", True), ("timestamp_col", None, True)]
+                      ("int_col", "Int32", True), ("bigint_col", "Int64", True), ("float_col", "Float32", True), ("double_col", "Float64", True),
+                      ("date_string_col", "Utf8", True), ("string_col", "Utf8", True), ("timestamp_col", {"Timestamp": ["Nanosecond", None]}, True)]
     t = pa.table({"d": pa.array([1, 2], pa.date32()), "x": pa.array([1, None], pa.decimal128(15, 2)), "s": ["a", "b"]})
     t = t.cast(pa.schema([pa.field("d", pa.date32(), False), pa.field("x", pa.decimal128(15, 2), True), pa.field("s", pa.string(), False)]))
     buf = io.BytesIO()

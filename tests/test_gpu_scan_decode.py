@@ -57,7 +57,8 @@ def same(got, want):
         assert a.type == b.type, (name, a.type, b.type)
         assert a.null_count == b.null_count, name
         if pa.types.is_floating(a.type):      # bit patterns, not ==
-            assert np.array_equal(np.asarray(a.fill_null(0.0)).view(np.uint64), np.asarray(b.fill_null(0.0)).view(np.uint64)), name
+            bits = np.uint32 if a.type == pa.float32() else np.uint64
+            assert np.array_equal(np.asarray(a.fill_null(0.0)).view(bits), np.asarray(b.fill_null(0.0)).view(bits)), name
             assert a.is_null().equals(b.is_null()), name
         else:
             assert a.equals(b), (name, a.to_pylist()[:5], b.to_pylist()[:5])
@@ -177,19 +178,22 @@ DEVICE_COLS = ["id", "bool_col", "tinyint_col", "smallint_col", "int_col", "bigi
 
 def test_reference_alltypes_plain_parquet(tc):
     """ballista/client/testdata/alltypes_plain.parquet (Impala-written, v1 pages, PLAIN_DICTIONARY, optional columns): the file the
-    reference's client KATs read (context.rs:762-967).  float_col (FLOAT) and timestamp_col (INT96) have no device decoder and are
-    announced as such by gpuq_parquet_schema; asking for them is refused."""
+    reference's client KATs read (context.rs:762-967).  Round 3: every column is decoded on the device -- float_col (FLOAT ->
+    Float32) and timestamp_col (INT96 -> Timestamp(Nanosecond), as arrow's reader maps Impala's timestamps) included."""
     path = os.path.join(GOLD, "alltypes_plain.parquet")
     fields, rows = scan.parquet_schema(tc.ctx.L, path)
-    assert rows == 8 and [f[0] for f in fields if f[1] is None] == ["float_col", "timestamp_col"]
+    assert rows == 8 and [f[0] for f in fields if f[1] is None] == []
     got = scan.read_parquet(tc, path, DEVICE_COLS).to_arrow(tc.ctx)
     want = pq.read_table(path, columns=DEVICE_COLS)
     want = want.cast(pa.schema([pa.field(f.name, pa.string() if pa.types.is_binary(f.type) else f.type) for f in want.schema]))
     same(got, want)
     assert got.column("id").to_pylist() == [4, 5, 6, 7, 2, 3, 0, 1]
-    with pytest.raises(g.GpuqError) as e:
-        scan.read_parquet(tc, path)
-    assert e.value.status == 3
+    allc = scan.read_parquet(tc, path).to_arrow(tc.ctx)
+    want = pq.read_table(path)
+    assert allc.schema.field("float_col").type == pa.float32() and allc.schema.field("timestamp_col").type == pa.timestamp("ns")
+    assert allc.column("float_col").to_pylist() == want.column("float_col").to_pylist() == [0.0, 1.100000023841858] * 4
+    assert allc.column("timestamp_col").cast(pa.int64()).to_pylist() == want.column("timestamp_col").cast(pa.int64()).to_pylist()
+    assert allc.column("timestamp_col").cast(pa.int64()).to_pylist()[0] == 1235865600000000000      # 2009-03-01T00:00:00
 
 
 def parquet_table(n, seed):
