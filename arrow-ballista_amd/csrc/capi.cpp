@@ -64,6 +64,7 @@ struct gpuq_op {
   // partition
   uint32_t nparts = 0;
   // deferred execution (include/gpuq.h): what the last completed synchronous run learned, and what a deferred run may leave behind
+  std::string refuse;               // the operator compiles (its output types are known) but cannot run: why
   std::string label;                // descriptor "label": appended to the run-time compiled kernels' names (a plan node id: profiles tell call sites apart)
   bool deferred = false, defer_client = false;
   uint32_t expect_flags = 0;        // status bits a deferred run is allowed to raise (a build side known to hold duplicate keys)
@@ -309,9 +310,51 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
     NodeP n = ec.from_json(g.at("expr"));
     key_nodes.push_back(n); key_names.push_back(g.get_str("name", "group" + std::to_string(key_nodes.size() - 1)));
   }
-  if (key_nodes.size() > (size_t)MAX_KEYS) throw Unsupported("more than " + std::to_string(MAX_KEYS) + " group-by columns");
   std::vector<AccDef> accs; std::vector<AggPlan> plans;
-  size_t state_col = key_nodes.size();   // Final modes: state columns follow the group columns positionally
+  // More than MAX_KEYS group columns (q10 groups by seven, q18 by five): the table still holds at most MAX_KEYS keys of up to 128 bits, so
+  // narrow keys are PACKED -- each biased to a non-negative number of `bits + 1` bits (+ 1 bit "is NULL"), shifted and OR-ed into 126-bit
+  // composites -- and the table groups by the composites.  The declared key columns are unpacked again over the GROUPS (the result
+  // projection divides by powers of two), so the table carries no extra state.  Utf8 / float keys take a slot of their own (the
+  // executor hands long or many Utf8 keys over as dictionary codes, which pack well).
+  std::vector<NodeP> orig_keys = key_nodes; std::vector<std::string> orig_names = key_names;
+  struct Packed { int slot = -1, shift = 0, width = 0; bool own = false; };      // own: the key IS column `slot` of the result
+  std::vector<Packed> pk(orig_keys.size());
+  const bool packed = orig_keys.size() > (size_t)MAX_KEYS;
+  if (packed) {
+    struct Slot { std::vector<size_t> ks; int bits = 0; bool solo = false; };
+    std::vector<Slot> slots;
+    for (size_t k = 0; k < orig_keys.size(); ++k) {
+      const NodeP& n = orig_keys[k];
+      const int b = (n->type.id == T_UTF8 || n->type.is_float() || n->type.id == T_BOOL) ? 0 : n->bits + 1 + (n->nullable ? 1 : 0);
+      if (b == 0 || b > 126) { Slot sl; sl.ks.push_back(k); sl.solo = true; slots.push_back(sl); continue; }
+      bool placed = false;
+      for (auto& sl : slots) if (!sl.solo && sl.bits + b <= 126) { sl.ks.push_back(k); sl.bits += b; placed = true; break; }
+      if (!placed) { Slot sl; sl.ks.push_back(k); sl.bits = b; slots.push_back(sl); }
+    }
+    if (slots.size() > (size_t)MAX_KEYS) op->refuse = std::to_string(orig_keys.size()) + " group-by columns need " + std::to_string(slots.size()) + " packed keys (" + std::to_string(MAX_KEYS) + " are held)";
+    key_nodes.clear(); key_names.clear();
+    const DType wide = dec_t(38, 0);
+    for (size_t si = 0; si < slots.size() && si < (size_t)MAX_KEYS; ++si) {
+      const Slot& sl = slots[si];
+      if (sl.solo) { pk[sl.ks[0]].slot = (int)key_nodes.size(); pk[sl.ks[0]].own = true; key_nodes.push_back(orig_keys[sl.ks[0]]); key_names.push_back(orig_names[sl.ks[0]]); continue; }
+      NodeP acc; int shift = 0;
+      for (size_t k : sl.ks) {
+        const NodeP& n = orig_keys[k];
+        NodeP v = ec.raw(OP_ADD, wide, n->nullable, n->bits + 1, {n, ec.lit_int(wide, (i128)1 << n->bits)});      // |value| < 2^bits  ->  [0, 2^(bits+1))
+        if (n->nullable) {
+          v = ec.coalesce0(v);
+          NodeP flag = ec.raw(OP_SHL, wide, false, n->bits + 2, {ec.raw(OP_MOV, wide, false, 1, {ec.is_null(n, false)})}, (uint32_t)(n->bits + 1));
+          v = ec.raw(OP_BOR, wide, false, n->bits + 2, {v, flag});
+        }
+        NodeP sh = shift ? ec.raw(OP_SHL, wide, false, 127, {v}, (uint32_t)shift) : v;
+        acc = acc ? ec.raw(OP_BOR, wide, false, 127, {acc, sh}) : sh;
+        pk[k].slot = (int)key_nodes.size(); pk[k].shift = shift; pk[k].width = n->bits + 1 + (n->nullable ? 1 : 0);
+        shift += pk[k].width;
+      }
+      key_nodes.push_back(acc); key_names.push_back("__packed" + std::to_string(si));
+    }
+  }
+  size_t state_col = orig_keys.size();   // Final modes: state columns follow the group columns positionally
   const Json& aggs = d.at("aggr_expr");
   for (const Json& a : aggs.a) {
     AggPlan pl; pl.fn = a.at("fn").str(); pl.name = a.get_str("name", pl.fn);
@@ -450,7 +493,19 @@ void compile_aggregate(gpuq_op* op, const Json& d) {
   // The post program runs in the same 16-register machine: when all outputs do not fit, the plan list is split and
   // each chunk becomes its own program over the same SoA columns (a few extra launches over <= n_groups rows).
   auto build_chunk = [&](ExprCompiler& pc, size_t lo, size_t hi, bool with_keys, std::vector<std::string>& out_names) {
-  if (with_keys) for (int k = 0; k < nk; ++k) { pc.add_output(pc.column(k)); out_names.push_back(key_names[k]); }
+  if (with_keys && !packed) for (int k = 0; k < nk; ++k) { pc.add_output(pc.column(k)); out_names.push_back(key_names[k]); }
+  if (with_keys && packed) for (size_t k = 0; k < orig_keys.size(); ++k) {      // the group columns in their declared order, unpacked
+    const NodeP& n = orig_keys[k];
+    if (pk[k].slot < 0) { pc.add_output(pc.lit_null(n->type)); out_names.push_back(orig_names[k]); continue; }      // (refused operator: types only)
+    if (pk[k].own) { pc.add_output(pc.column(pk[k].slot)); out_names.push_back(orig_names[k]); continue; }
+    const DType wide = dec_t(38, 0);
+    NodeP f = pc.column(pk[k].slot);      // non-negative, < 2^126: truncating division is the shift
+    if (pk[k].shift) f = pc.raw(OP_DIV, wide, false, 127, {f, pc.lit_int(wide, (i128)1 << pk[k].shift)});
+    f = pc.raw(OP_MOD, wide, false, pk[k].width, {f, pc.lit_int(wide, (i128)1 << pk[k].width)});
+    NodeP v = pc.raw(OP_SUB, n->type, false, n->bits, {f, pc.lit_int(wide, (i128)1 << n->bits)});
+    if (n->nullable) v = pc.select(pc.raw(OP_GE, t_of(T_BOOL), false, 2, {f, pc.lit_int(wide, (i128)1 << (n->bits + 1))}), pc.lit_null(n->type), v);
+    pc.add_output(v); out_names.push_back(orig_names[k]);
+  }
   for (size_t pi = lo; pi < hi; ++pi) {
     const AggPlan& pl = plans[pi];
     auto acc = [&](int i) { return pc.column(nk + i); };
@@ -895,6 +950,7 @@ static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, g
   return guarded(op->ctx, [&]() {
     check_ctx(op->ctx);
     if (op->kind != K_AGG) throw std::runtime_error("not an aggregate operator");
+    if (!op->refuse.empty()) throw Unsupported(op->refuse);
     hipStream_t s = use_stream(stream);
     ProfTotal ptot(op, s);
     DevProgram P = bind_program(op->prog, op->in_schema, op->code_dev.as<DevCode>(), op->flags_dev.as<uint32_t>(), in);
@@ -1902,8 +1958,8 @@ int gpuq_utf8_code_rows(gpuq_ctx* ctx, void* stream, const gpuq_column* codes, i
   return guarded(ctx, [&]() {
     check_ctx(ctx);
     if (!codes || (n > 0 && !rows_out)) throw std::runtime_error("codes / rows_out is NULL");
-    if (codes->type != T_INT64) throw std::runtime_error("gpuq_utf8_code_rows: the code column is Int64");
-    launch_utf8_code_rows(use_stream(stream), (const i64*)codes->data, codes->validity, n, rows_out);
+    if (codes->type != T_INT64 && codes->type != T_UINT32) throw std::runtime_error("gpuq_utf8_code_rows: the code column is Int64 (or UInt32: a code is a row id)");
+    launch_utf8_code_rows(use_stream(stream), codes->data, codes->type == T_INT64 ? 8 : 4, codes->validity, n, rows_out);
     HIPCHECK(hipGetLastError());
   });
 }

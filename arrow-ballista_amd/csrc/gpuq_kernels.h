@@ -223,7 +223,7 @@ void launch_utf8_piece_validate(hipStream_t s, const Utf8Piece* pieces, int n_pi
 void launch_utf8_piece_compact(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_bytes, const uint8_t* from, uint8_t* to);
 struct UnpackJob { int64_t src, dst, src_len, dst_len, raw_prefix; int32_t mode /* 0 stored, 1 snappy */, pad; };      // one Parquet page (kernels_lz4.hip)
 void launch_unpack_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, int n_jobs, uint32_t* status);
-void launch_utf8_code_rows(hipStream_t s, const i64* codes, const uint8_t* validity, i64 n, uint32_t* rows);
+void launch_utf8_code_rows(hipStream_t s, const void* codes, int width, const uint8_t* validity, i64 n, uint32_t* rows);      // width 8 (Int64) or 4 (UInt32)
 void launch_utf8_sort_piece(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int piece, void* out, u64* valid_out);
 void launch_utf8_max_len(hipStream_t s, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int32_t* out);
 void launch_utf8_intern(hipStream_t s, const uint8_t* ddata, const int32_t* doffs, const uint8_t* data, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n,

@@ -1193,12 +1193,12 @@ __global__ void __launch_bounds__(BLOCK) k_utf8_intern(const uint8_t* __restrict
   }
 }
 // codes (Int64 + validity) -> row ids for a take: NULL -> 0xFFFFFFFF
-__global__ void __launch_bounds__(BLOCK) k_utf8_code_rows(const i64* __restrict__ codes, const uint8_t* __restrict__ validity, const i64 n, uint32_t* __restrict__ rows) {
+__global__ void __launch_bounds__(BLOCK) k_utf8_code_rows(const void* __restrict__ codes, const int width, const uint8_t* __restrict__ validity, const i64 n, uint32_t* __restrict__ rows) {
   for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK)
-    rows[i] = (validity && !((validity[i >> 3] >> (i & 7)) & 1)) ? 0xFFFFFFFFu : (uint32_t)codes[i];
+    rows[i] = (validity && !((validity[i >> 3] >> (i & 7)) & 1)) ? 0xFFFFFFFFu : (width == 8 ? (uint32_t)((const i64*)codes)[i] : ((const uint32_t*)codes)[i]);
 }
-void launch_utf8_code_rows(hipStream_t s, const i64* codes, const uint8_t* validity, i64 n, uint32_t* rows) {
-  if (n > 0) hipLaunchKernelGGL(k_utf8_code_rows, dim3(lin_grid(n)), dim3(BLOCK), 0, s, codes, validity, n, rows);
+void launch_utf8_code_rows(hipStream_t s, const void* codes, int width, const uint8_t* validity, i64 n, uint32_t* rows) {
+  if (n > 0) hipLaunchKernelGGL(k_utf8_code_rows, dim3(lin_grid(n)), dim3(BLOCK), 0, s, codes, width, validity, n, rows);
 }
 // Order-preserving fixed-width pieces of a Utf8 column (sort keys of any length): piece j of a string = bytes [14 j, 14 j + 14) as a
 // big-endian integer, zero padded, times 256 plus the number of bytes the piece holds (0..14).  Comparing the pieces of two

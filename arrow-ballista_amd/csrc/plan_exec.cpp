@@ -891,8 +891,17 @@ struct AggregateExec : PNode {
     Fused f; if (final_) f.src = input.get(); else f = fuse(input.get());
     PTable t = f.src->execute(part, x);
     auto t0 = std::chrono::steady_clock::now();
-    try { return timed(x, t0, run(x, t, f, false)); }
-    catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+    // (more group columns than the table holds keys, some of them strings: codes from the start -- a 128-bit packed string takes a key
+    // slot of its own, a 32-bit code is packed with its neighbours, see compile_aggregate)
+    bool many_string_keys = false;
+    if (group_expr.a.size() > 4) {
+      const ColMap* cm0 = f.has_map ? &f.map : nullptr;
+      for (auto& g : group_expr.a) if (long_key_column(t, inline_projection(g.at("expr"), cm0)) >= 0) many_string_keys = true;
+    }
+    if (!many_string_keys) {
+      try { return timed(x, t0, run(x, t, f, false)); }
+      catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+    }
     resolve(x, t);
     return timed(x, t0, run(x, t, f, true));      // a group key holds strings of more than 15 bytes: again, over dictionary codes
   }
@@ -909,6 +918,8 @@ struct AggregateExec : PNode {
         check(x, gpuq_utf8_dict_create(x.ctx, x.stream, std::min<int64_t>(t_src.n, t_src.cols[(size_t)ci].c.length), &dicts[nd].d));
         append_code_column(x, t, ci, dicts[nd].d, true, nm); ++nd;
         e = jobj({{"column", jobj({{"name", jstr(nm)}})}});
+        // a code is a row id: as UInt32 it takes 35 bits of a packed key instead of 66 (more group columns than key slots, compile_aggregate)
+        if (group_expr.a.size() > 4) e = jobj({{"cast", jobj({{"expr", e}, {"arrow_type", jstr("UInt32")}})}});
       } else ci = -1;
       gexprs.push_back(e); coded.push_back(ci);
     }

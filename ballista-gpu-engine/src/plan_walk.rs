@@ -63,6 +63,17 @@ pub fn type_json(t: &DataType) -> Result<Value> {
         DataType::Float64 => json!("Float64"),
         DataType::Utf8 => json!("Utf8"),
         DataType::Decimal128(p, s) => json!({"Decimal128": [p, s]}),
+        DataType::Int8 => json!("Int8"),
+        DataType::Int16 => json!("Int16"),
+        DataType::UInt8 => json!("UInt8"),
+        DataType::UInt16 => json!("UInt16"),
+        DataType::Float32 => json!("Float32"),
+        DataType::Date64 => json!("Date64"),
+        // the engine keeps the unit; the zone travels in the descriptor and comes back with this plan's schema (batches are built with it)
+        DataType::Timestamp(u, tz) => json!({"Timestamp": [format!("{u:?}"), tz.as_ref().map(|z| z.to_string())]}),
+        // converted where the batches enter (gpuq_table_import_arrow / gpuq_ingest_push): inside, 32-bit offsets / the value type
+        DataType::LargeUtf8 => json!("LargeUtf8"),
+        DataType::Dictionary(k, v) => json!({"Dictionary": [type_json(k)?, type_json(v)?]}),
         other => return unsupported(format!("column type {other:?}")),
     })
 }
@@ -83,6 +94,17 @@ fn literal(v: &ScalarValue) -> Result<Value> {
         ScalarValue::Date32(x) => json!({"type": "Date32", "value": x}),
         ScalarValue::Float64(x) => json!({"type": "Float64", "value": x}),
         ScalarValue::Utf8(x) => json!({"type": "Utf8", "value": x}),
+        ScalarValue::LargeUtf8(x) => json!({"type": "Utf8", "value": x}),
+        ScalarValue::Int8(x) => json!({"type": "Int8", "value": x}),
+        ScalarValue::Int16(x) => json!({"type": "Int16", "value": x}),
+        ScalarValue::UInt8(x) => json!({"type": "UInt8", "value": x}),
+        ScalarValue::UInt16(x) => json!({"type": "UInt16", "value": x}),
+        ScalarValue::Float32(x) => json!({"type": "Float32", "value": x}),
+        ScalarValue::Date64(x) => json!({"type": "Date64", "value": x.map(|v| v.to_string())}),
+        ScalarValue::TimestampSecond(x, tz) => json!({"type": {"Timestamp": ["Second", tz.as_ref().map(|z| z.to_string())]}, "value": x.map(|v| v.to_string())}),
+        ScalarValue::TimestampMillisecond(x, tz) => json!({"type": {"Timestamp": ["Millisecond", tz.as_ref().map(|z| z.to_string())]}, "value": x.map(|v| v.to_string())}),
+        ScalarValue::TimestampMicrosecond(x, tz) => json!({"type": {"Timestamp": ["Microsecond", tz.as_ref().map(|z| z.to_string())]}, "value": x.map(|v| v.to_string())}),
+        ScalarValue::TimestampNanosecond(x, tz) => json!({"type": {"Timestamp": ["Nanosecond", tz.as_ref().map(|z| z.to_string())]}, "value": x.map(|v| v.to_string())}),
         ScalarValue::Decimal128(x, p, s) => json!({"type": {"Decimal128": [p, s]}, "value": x.map(|v| v.to_string())}),
         other => return unsupported(format!("literal {other:?}")),
     })

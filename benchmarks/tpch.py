@@ -610,3 +610,88 @@ def q9_plan(part, supplier, lineitem, partsupp, orders, nation):
     agg = g.AggregateExec("Single", [(col("nation", prs), "nation"), (col("o_year", prs), "o_year")], [{"fn": "SUM", "expr": col("amount", prs), "name": "sum_profit"}], proj)
     as_ = agg.schema()
     return g.SortExec([{"expr": col("nation", as_), "asc": True, "nulls_first": False}, {"expr": col("o_year", as_), "asc": False, "nulls_first": True}], agg)
+
+
+D_1993_10_01, D_1994_01_01 = 8674, 8766
+
+
+def q10_plan(customer, orders, lineitem, nation):
+    """q10.sql: returned items of one quarter: customer |x| orders |x| lineitem |x| nation, SUM(revenue) grouped by SEVEN columns (c_custkey,
+    c_name, c_acctbal, c_phone, n_name, c_address, c_comment: more than the aggregate's table holds keys -- the narrow ones are packed,
+    the strings travel as dictionary codes), ORDER BY revenue DESC."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, Operator as Op
+    cs, os_, ls, ns = customer.schema(), orders.schema(), lineitem.schema(), nation.schema()
+    o = g.FilterExec(and_(binary(col("o_orderdate", os_), Op.GtEq, lit(D_1993_10_01, "Date32")), binary(col("o_orderdate", os_), Op.Lt, lit(D_1994_01_01, "Date32"))), orders)
+    l = g.FilterExec(binary(col("l_returnflag", ls), Op.Eq, lit("R")), lineitem)
+    nc = g.HashJoinExec(nation, customer, [(col("n_nationkey", ns), col("c_nationkey", cs))], None, "Inner", "CollectLeft", False)
+    ncs = nc.schema()
+    co = g.HashJoinExec(nc, g.CoalesceBatchesExec(o), [(col("c_custkey", ncs), col("o_custkey", os_))], None, "Inner", "CollectLeft", False)
+    cos = co.schema()
+    j = g.HashJoinExec(co, g.CoalesceBatchesExec(l), [(col("o_orderkey", cos), col("l_orderkey", ls))], None, "Inner", "CollectLeft", False)
+    js = j.schema()
+    keys = ("c_custkey", "c_name", "c_acctbal", "c_phone", "n_name", "c_address", "c_comment")
+    proj = g.ProjectionExec([(col(k, js), k) for k in keys] + [(_revenue(js), "rev")], j)
+    ps = proj.schema()
+    agg = g.AggregateExec("Single", [(col(k, ps), k) for k in keys], [{"fn": "SUM", "expr": col("rev", ps), "name": "revenue"}], proj)
+    as_ = agg.schema()
+    out = g.ProjectionExec([(col(k, as_), k) for k in ("c_custkey", "c_name", "revenue", "c_acctbal", "n_name", "c_address", "c_phone", "c_comment")], agg)
+    return g.SortExec([{"expr": col("revenue", out.schema()), "asc": False, "nulls_first": True}], out)
+
+
+def q18_plan(customer, orders, lineitem, quantity_unscaled=30000):
+    """q18.sql: large-volume customers: o_orderkey IN (SELECT l_orderkey .. GROUP BY l_orderkey HAVING SUM(l_quantity) > 300) is a semi join with the
+    filtered aggregate as its build side; then customer |x| orders |x| lineitem, SUM(l_quantity) grouped by FIVE columns, ORDER BY
+    o_totalprice DESC, o_orderdate."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, Operator as Op
+    cs, os_, ls = customer.schema(), orders.schema(), lineitem.schema()
+    per = g.AggregateExec("Single", [(col("l_orderkey", ls), "l_orderkey")], [{"fn": "SUM", "expr": col("l_quantity", ls), "name": "q"}], lineitem)
+    pers = per.schema()
+    big = g.ProjectionExec([(col("l_orderkey", pers), "big_orderkey")], g.FilterExec(binary(col("q", pers), Op.Gt, lit(quantity_unscaled, ("Decimal128", 25, 2))), per))
+    bs = big.schema()
+    o = g.HashJoinExec(big, orders, [(col("big_orderkey", bs), col("o_orderkey", os_))], None, "RightSemi", "CollectLeft", False)
+    oss = o.schema()
+    co = g.HashJoinExec(customer, o, [(col("c_custkey", cs), col("o_custkey", oss))], None, "Inner", "CollectLeft", False)
+    cos = co.schema()
+    j = g.HashJoinExec(co, lineitem, [(col("o_orderkey", cos), col("l_orderkey", ls))], None, "Inner", "CollectLeft", False)
+    js = j.schema()
+    keys = ("c_name", "c_custkey", "o_orderkey", "o_orderdate", "o_totalprice")
+    agg = g.AggregateExec("Single", [(col(k, js), k) for k in keys], [{"fn": "SUM", "expr": col("l_quantity", js), "name": "sum_qty"}], j)
+    as_ = agg.schema()
+    return g.SortExec([{"expr": col("o_totalprice", as_), "asc": False, "nulls_first": True}, {"expr": col("o_orderdate", as_), "asc": True, "nulls_first": False}], agg)
+
+
+def q8_plan(part, supplier, lineitem, orders, customer, nation, region):
+    """q8.sql: market share of BRAZIL within AMERICA for one part type, by extract(year from o_orderdate): eight tables,
+    SUM(CASE WHEN nation = 'BRAZIL' THEN volume ELSE 0 END) / SUM(volume) (decimal division), ORDER BY o_year."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, case, date_part, Operator as Op
+    ps_, ss, ls, os_, cs, ns, rs = part.schema(), supplier.schema(), lineitem.schema(), orders.schema(), customer.schema(), nation.schema(), region.schema()
+    p = g.ProjectionExec([(col("p_partkey", ps_), "p_partkey")], g.FilterExec(binary(col("p_type", ps_), Op.Eq, lit("ECONOMY ANODIZED STEEL")), part))
+    pl = g.HashJoinExec(p, lineitem, [(col("p_partkey", p.schema()), col("l_partkey", ls))], None, "Inner", "CollectLeft", False)
+    pls = pl.schema()
+    n2 = g.ProjectionExec([(col("n_nationkey", ns), "n2_key"), (col("n_name", ns), "nation")], nation)
+    sn = g.HashJoinExec(n2, supplier, [(col("n2_key", n2.schema()), col("s_nationkey", ss))], None, "Inner", "CollectLeft", False)
+    sns = sn.schema()
+    sl = g.HashJoinExec(sn, pl, [(col("s_suppkey", sns), col("l_suppkey", pls))], None, "Inner", "CollectLeft", False)
+    sls = sl.schema()
+    r = g.FilterExec(binary(col("r_name", rs), Op.Eq, lit("AMERICA")), region)
+    n1 = g.HashJoinExec(r, nation, [(col("r_regionkey", rs), col("n_regionkey", ns))], None, "Inner", "CollectLeft", False)
+    n1s = n1.schema()
+    n1k = g.ProjectionExec([(col("n_nationkey", n1s), "n1_key")], n1)
+    c = g.HashJoinExec(n1k, customer, [(col("n1_key", n1k.schema()), col("c_nationkey", cs))], None, "RightSemi", "CollectLeft", False)      # customers of AMERICA
+    cks = c.schema()
+    o = g.FilterExec(and_(binary(col("o_orderdate", os_), Op.GtEq, lit(D_1995_01, "Date32")), binary(col("o_orderdate", os_), Op.LtEq, lit(D_1996_12_31, "Date32"))), orders)
+    co = g.HashJoinExec(g.ProjectionExec([(col("c_custkey", cks), "c_custkey")], c), g.CoalesceBatchesExec(o), [(col("c_custkey", cks), col("o_custkey", os_))], None, "RightSemi", "CollectLeft", False)
+    cos = co.schema()
+    j = g.HashJoinExec(co, sl, [(col("o_orderkey", cos), col("l_orderkey", sls))], None, "Inner", "CollectLeft", False)
+    js = j.schema()
+    proj = g.ProjectionExec([(date_part("YEAR", col("o_orderdate", js)), "o_year"), (_revenue(js), "volume"), (col("nation", js), "nation")], j)
+    pj = proj.schema()
+    zero = lit(0, ("Decimal128", 38, 4))
+    brazil = case([(binary(col("nation", pj), Op.Eq, lit("BRAZIL")), col("volume", pj))], zero)
+    agg = g.AggregateExec("Single", [(col("o_year", pj), "o_year")], [{"fn": "SUM", "expr": brazil, "name": "brazil"}, {"fn": "SUM", "expr": col("volume", pj), "name": "total"}], proj)
+    as_ = agg.schema()
+    share = g.ProjectionExec([(col("o_year", as_), "o_year"), (binary(col("brazil", as_), Op.Divide, col("total", as_)), "mkt_share"), (col("brazil", as_), "brazil"), (col("total", as_), "total")], agg)
+    return g.SortExec([{"expr": col("o_year", share.schema()), "asc": True, "nulls_first": False}], share)

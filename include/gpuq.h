@@ -396,7 +396,7 @@ int gpuq_utf8_max_len(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const
 int gpuq_utf8_dict_create(gpuq_ctx* ctx, void* stream, int64_t capacity_rows, gpuq_utf8_dict** out);
 int gpuq_utf8_intern(gpuq_utf8_dict* dict, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, int insert, int64_t* codes_out, uint8_t* validity_out);
 void gpuq_utf8_dict_free(gpuq_utf8_dict* dict);
-/* an Int64 code column (with or without validity) -> the row ids a take wants (NULL -> 0xFFFFFFFF) */
+/* an Int64 (or UInt32: codes are row ids) code column, with or without validity -> the row ids a take wants (NULL -> 0xFFFFFFFF) */
 int gpuq_utf8_code_rows(gpuq_ctx* ctx, void* stream, const gpuq_column* codes, int64_t n, uint32_t* rows_out);
 
 /* LikeExpr (PhysicalLikeExprNode, datafusion.proto:1240-1245: negated, case_insensitive, expr, pattern) of a Utf8 column in Arrow

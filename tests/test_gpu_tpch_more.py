@@ -38,7 +38,8 @@ def db():
     colors = ["almond", "green", "blue", "forest", "ghost", "khaki", "lime", "navy", "olive", "peach"]
     containers = ["%s %s" % (a, b) for a in ("SM", "LG", "MED", "JUMBO", "WRAP") for b in ("CASE", "BOX", "BAG", "JAR", "PKG", "PACK", "CAN", "DRUM")]
     t = {}
-    t["nation"] = pa.table({"n_nationkey": pa.array(np.arange(25), pa.int64()), "n_name": pa.array(nations)})
+    t["nation"] = pa.table({"n_nationkey": pa.array(np.arange(25), pa.int64()), "n_name": pa.array(nations), "n_regionkey": pa.array([rk for _, rk in T.NATIONS], pa.int64())})
+    t["region"] = pa.table({"r_regionkey": pa.array(np.arange(5), pa.int64()), "r_name": pa.array(T.REGIONS)})
     t["part"] = pa.table({"p_partkey": pa.array(np.arange(1, n_part + 1), pa.int64()), "p_brand": pa.array([brands[i] for i in r.integers(0, 25, n_part)]),
                           "p_type": pa.array([types[i] for i in r.integers(0, len(types), n_part)]), "p_size": pa.array(r.integers(1, 51, n_part).astype(np.int32)),
                           "p_container": pa.array([containers[i] for i in r.integers(0, len(containers), n_part)]),
@@ -48,14 +49,19 @@ def db():
                               "s_comment": pa.array([comments[i] for i in r.integers(0, len(comments), n_supp)])})
     t["partsupp"] = pa.table({"ps_partkey": pa.array(np.repeat(np.arange(1, n_part + 1), 4), pa.int64()), "ps_suppkey": pa.array((np.repeat(np.arange(n_part), 4) * 7 + np.tile(np.arange(4), n_part) * 13) % n_supp + 1, pa.int64()),
                               "ps_supplycost": _dec(r.integers(100, 100000, n_part * 4))})
+    ocomments_c = ["furiously even accounts wake carefully across the regular deposits", "slyly bold requests", "", "pending packages haggle quickly about the ironic, final theodolites"]
     phones = ["%02d-%03d-%03d-%04d" % (c, a, b, d) for c, a, b, d in zip(r.integers(10, 35, n_cust), r.integers(100, 999, n_cust), r.integers(100, 999, n_cust), r.integers(1000, 9999, n_cust))]
     t["customer"] = pa.table({"c_custkey": pa.array(np.arange(1, n_cust + 1), pa.int64()), "c_nationkey": pa.array(r.integers(0, 25, n_cust), pa.int64()),
-                              "c_phone": pa.array(phones), "c_acctbal": _dec(r.integers(-99999, 999999, n_cust))})
+                              "c_phone": pa.array(phones), "c_acctbal": _dec(r.integers(-99999, 999999, n_cust)),
+                              "c_name": pa.array(["Customer#%09d" % i for i in range(1, n_cust + 1)]),
+                              "c_address": pa.array(["%d %s street, no. %d" % (i % 7, "abcdefghij"[i % 10] * (3 + i % 29), i) for i in range(n_cust)]),
+                              "c_comment": pa.array([ocomments_c[i % 4] + (" %d" % (i % 11)) for i in range(n_cust)])})
     ocomments = ["carefully final deposits", "special packages about the requests", "quickly special requests haggle", "ironic accounts", "requests are special"]
     prios = ["1-URGENT", "2-HIGH", "3-MEDIUM", "4-NOT SPECIFIED", "5-LOW"]
     t["orders"] = pa.table({"o_orderkey": pa.array(np.arange(1, n_ord + 1) * 4, pa.int64()), "o_custkey": pa.array(r.integers(1, n_cust * 2 // 3, n_ord), pa.int64()),
                             "o_orderdate": _date(r.integers(8035, 10440, n_ord)), "o_orderpriority": pa.array([prios[i] for i in r.integers(0, 5, n_ord)]),
-                            "o_comment": pa.array([ocomments[i] for i in r.integers(0, len(ocomments), n_ord)])})
+                            "o_comment": pa.array([ocomments[i] for i in r.integers(0, len(ocomments), n_ord)]),
+                            "o_totalprice": _dec(r.integers(100000, 50000000, n_ord))})
     ship = r.integers(8400, 10000, n_li)
     commit = ship + r.integers(-30, 60, n_li)
     receipt = ship + r.integers(1, 31, n_li)
@@ -65,7 +71,8 @@ def db():
                               "l_suppkey": pa.array(r.integers(1, n_supp + 1, n_li), pa.int64()), "l_quantity": _dec(r.integers(1, 51, n_li) * 100),
                               "l_extendedprice": _dec(r.integers(90100, 10494950, n_li)), "l_discount": _dec(r.integers(0, 11, n_li)),
                               "l_shipdate": _date(ship), "l_commitdate": _date(commit), "l_receiptdate": _date(receipt),
-                              "l_shipmode": pa.array([modes[i] for i in r.integers(0, 8, n_li)]), "l_shipinstruct": pa.array([instr[i] for i in r.integers(0, 4, n_li)])})
+                              "l_shipmode": pa.array([modes[i] for i in r.integers(0, 8, n_li)]), "l_shipinstruct": pa.array([instr[i] for i in r.integers(0, 4, n_li)]),
+                              "l_returnflag": pa.array([["R", "A", "N"][i] for i in r.integers(0, 3, n_li)])})
     # non-nullable fields, as in the reference's schema (tpch.rs:871-952)
     t = {k: v.cast(pa.schema([pa.field(f.name, f.type, False) for f in v.schema])) for k, v in t.items()}
     rows = {k: [dict(zip(v.column_names, r_)) for r_ in zip(*[c.to_pylist() for c in v.columns])] for k, v in t.items()}
@@ -183,6 +190,64 @@ def test_q7(tc, db):
         if (sn, cn) in (("FRANCE", "GERMANY"), ("GERMANY", "FRANCE")):
             acc[(sn, cn, float(l["l_shipdate"].year))] += _u(l["l_extendedprice"]) * (100 - _u(l["l_discount"]))
     assert got == sorted((a, b, y, v) for (a, b, y), v in acc.items()) and len(got) >= 2
+
+
+def test_q10_groups_by_seven_columns(tc, db):
+    """More group columns than the aggregate's table holds keys (4): narrow keys are packed into 126-bit composites, strings travel as
+    dictionary codes, the declared key values come out as any-value accumulators (compile_aggregate)."""
+    t, rows = db
+    got, _ = native_rows(tc, T.q10_plan(_src(t["customer"]), _src(t["orders"]), _src(t["lineitem"]), _src(t["nation"])))
+    nname = {n["n_nationkey"]: n["n_name"] for n in rows["nation"]}
+    cust = {c["c_custkey"]: c for c in rows["customer"]}
+    order_cust = {o["o_orderkey"]: o["o_custkey"] for o in rows["orders"] if T.D_1993_10_01 <= _days(o["o_orderdate"]) < T.D_1994_01_01}
+    acc = collections.defaultdict(int)
+    for l in rows["lineitem"]:
+        if l["l_returnflag"] == "R" and l["l_orderkey"] in order_cust and order_cust[l["l_orderkey"]] in cust:
+            acc[order_cust[l["l_orderkey"]]] += _u(l["l_extendedprice"]) * (100 - _u(l["l_discount"]))
+    exp = [(k, cust[k]["c_name"], v, _u(cust[k]["c_acctbal"]), nname[cust[k]["c_nationkey"]], cust[k]["c_address"], cust[k]["c_phone"], cust[k]["c_comment"]) for k, v in acc.items()]
+    assert len(exp) > 20 and [r_[2] for r_ in got] == sorted((r_[2] for r_ in exp), reverse=True)          # ORDER BY revenue DESC
+    assert sorted(got) == sorted(exp)
+
+
+def test_q18_in_subquery_and_five_group_columns(tc, db):
+    t, rows = db
+    threshold = 12000          # (the fixture's orders have ~4 lineitems of <= 50: "sum(l_quantity) > 120" plays the query's "> 300")
+    got, _ = native_rows(tc, T.q18_plan(_src(t["customer"]), _src(t["orders"]), _src(t["lineitem"]), quantity_unscaled=threshold))
+    qty = collections.defaultdict(int)
+    for l in rows["lineitem"]:
+        qty[l["l_orderkey"]] += _u(l["l_quantity"])
+    cust = {c["c_custkey"]: c for c in rows["customer"]}
+    exp = []
+    for o in rows["orders"]:
+        if qty.get(o["o_orderkey"], 0) > threshold and o["o_custkey"] in cust:
+            exp.append((cust[o["o_custkey"]]["c_name"], o["o_custkey"], o["o_orderkey"], _days(o["o_orderdate"]), _u(o["o_totalprice"]), qty[o["o_orderkey"]]))
+    exp.sort(key=lambda r_: (-r_[4], r_[3]))
+    assert len(exp) > 10 and [(r_[4], r_[3]) for r_ in got] == [(r_[4], r_[3]) for r_ in exp] and sorted(got) == sorted(exp)
+
+
+def test_q8_market_share(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q8_plan(_src(t["part"]), _src(t["supplier"]), _src(t["lineitem"]), _src(t["orders"]), _src(t["customer"]), _src(t["nation"]), _src(t["region"])))
+    nname = {n["n_nationkey"]: n["n_name"] for n in rows["nation"]}
+    america = {n["n_nationkey"] for n in rows["nation"] if T.REGIONS[n["n_regionkey"]] == "AMERICA"}
+    parts = {p["p_partkey"] for p in rows["part"] if p["p_type"] == "ECONOMY ANODIZED STEEL"}
+    supp = {s["s_suppkey"]: nname[s["s_nationkey"]] for s in rows["supplier"]}
+    cust = {c["c_custkey"] for c in rows["customer"] if c["c_nationkey"] in america}
+    orders = {o["o_orderkey"]: o["o_orderdate"].year for o in rows["orders"] if T.D_1995_01 <= _days(o["o_orderdate"]) <= T.D_1996_12_31 and o["o_custkey"] in cust}
+    acc = collections.defaultdict(lambda: [0, 0])
+    for l in rows["lineitem"]:
+        if l["l_partkey"] in parts and l["l_orderkey"] in orders:
+            v = _u(l["l_extendedprice"]) * (100 - _u(l["l_discount"]))
+            a = acc[float(orders[l["l_orderkey"]])]
+            a[1] += v
+            if supp[l["l_suppkey"]] == "BRAZIL":
+                a[0] += v
+    assert len(acc) >= 1 and [(r_[0], r_[2], r_[3]) for r_ in got] == sorted((y, b, tot) for y, (b, tot) in acc.items())
+    # mkt_share = brazil / total with arrow-arith 49's decimal division (quotient scale s1 + 4, truncation), through the oracle
+    for y, share, b, tot in got:
+        one = O.Table(["b", "t"], [O.dec(38, 4), O.dec(38, 4)], [[b], [tot]])
+        e = {"binary_expr": {"l": {"column": {"name": "b"}}, "r": {"column": {"name": "t"}}, "op": "/"}}
+        assert share == O.eval_expr(e, one)[1][0]
 
 
 def test_scalar_functions_and_aggregate_filter_against_the_oracle(tc):
