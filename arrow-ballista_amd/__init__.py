@@ -14,7 +14,7 @@ from . import expr  # noqa: F401
 from .native import NativePlan, NativeResult  # noqa: F401
 from .table import DeviceColumn, DeviceTable  # noqa: F401
 from .plan import (  # noqa: F401
-    MemoryExec, FilterExec, ProjectionExec, AggregateExec, HashJoinExec, SortExec, CoalesceBatchesExec,
+    MemoryExec, FilterExec, ProjectionExec, AggregateExec, HashJoinExec, CrossJoinExec, SortExec, CoalesceBatchesExec,
     RepartitionExec, ShuffleWriterExec, ShuffleReaderExec, DefaultExecutionEngine, TaskContext,
     CoalesceTasksExec, CoalescePartitionsExec, SortPreservingMergeExec, UnionExec, LocalLimitExec, GlobalLimitExec,
     RepartitionExchangeExec, BroadcastExec, RangeRepartitionExec,
@@ -23,7 +23,7 @@ from .plan import (  # noqa: F401
 __all__ = [
     "GpuqError", "Context", "Op", "JoinTable", "lib", "lib_path", "compile_check", "expr",
     "DeviceColumn", "DeviceTable", "MemoryExec", "FilterExec", "ProjectionExec", "AggregateExec",
-    "HashJoinExec", "SortExec", "CoalesceBatchesExec", "RepartitionExec", "ShuffleWriterExec", "ShuffleReaderExec",
+    "HashJoinExec", "CrossJoinExec", "SortExec", "CoalesceBatchesExec", "RepartitionExec", "ShuffleWriterExec", "ShuffleReaderExec",
     "DefaultExecutionEngine", "TaskContext", "CoalesceTasksExec", "CoalescePartitionsExec", "SortPreservingMergeExec",
     "UnionExec", "LocalLimitExec", "GlobalLimitExec", "RepartitionExchangeExec", "BroadcastExec", "RangeRepartitionExec",
 ]

@@ -89,6 +89,7 @@ def lib():
         "gpuq_copy_h2d": (i32, [vp, vp, vp, vp, C.c_size_t]),
         "gpuq_copy_d2h": (i32, [vp, vp, vp, vp, C.c_size_t]),
         "gpuq_table_import_arrow": (i32, [vp, vp, vp, vp, C.POINTER(vp)]),
+        "gpuq_cross_pairs": (i32, [vp, vp, i64, i64, vp, vp]),
         "gpuq_ingest_create": (i32, [vp, vp, i64, i64, i32, C.POINTER(vp)]),
         "gpuq_ingest_push": (i32, [vp, vp]),
         "gpuq_ingest_rows_landed": (i32, [vp, C.POINTER(i64)]),

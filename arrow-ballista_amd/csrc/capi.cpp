@@ -1912,6 +1912,17 @@ int gpuq_mark_rows(gpuq_ctx* ctx, void* stream, const uint32_t* rows, int64_t n,
   });
 }
 
+int gpuq_cross_pairs(gpuq_ctx* ctx, void* stream, int64_t n_left, int64_t n_right, uint32_t* left_rows_out, uint32_t* right_rows_out) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (n_left < 0 || n_right < 0) throw std::runtime_error("bad arguments");
+    if (n_left > 0 && n_right > 0 && n_left > (int64_t)0xFFFFFFFEll / n_right) throw Capacity("cross join of " + std::to_string(n_left) + " x " + std::to_string(n_right) + " rows exceeds 2^32 pairs");
+    if (n_left * n_right > 0 && (!left_rows_out || !right_rows_out)) throw std::runtime_error("output vectors are NULL");
+    launch_cross_pairs(use_stream(stream), n_left, n_right, left_rows_out, right_rows_out);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
 // ---------------------------------------------------------------- Utf8 dictionary codes (keys longer than 15 bytes)
 struct gpuq_utf8_dict { gpuq_ctx* ctx; DevBuf table; u64 mask = 0; gpuq_column dict_col{}; bool filled = false; };
 

@@ -1246,6 +1246,14 @@ __global__ void __launch_bounds__(BLOCK) k_mark_rows(const uint32_t* __restrict_
     if (r != 0xFFFFFFFFu) atomicOr(bitmap + (r >> 5), 1u << (r & 31));
   }
 }
+// CrossJoinExec: pair i of left x right, left-major
+__global__ void __launch_bounds__(BLOCK) k_cross_pairs(const i64 total, const i64 n_right, uint32_t* __restrict__ lrows, uint32_t* __restrict__ rrows) {
+  for (i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (i64)gridDim.x * BLOCK) { const i64 l = i / n_right; lrows[i] = (uint32_t)l; rrows[i] = (uint32_t)(i - l * n_right); }
+}
+void launch_cross_pairs(hipStream_t s, i64 n_left, i64 n_right, uint32_t* left_rows, uint32_t* right_rows) {
+  const i64 total = n_left * n_right;
+  if (total > 0) hipLaunchKernelGGL(k_cross_pairs, dim3(lin_grid(total)), dim3(BLOCK), 0, s, total, n_right, left_rows, right_rows);
+}
 void launch_mark_rows(hipStream_t s, const uint32_t* rows, i64 n, uint8_t* bitmap) {
   if (n > 0) hipLaunchKernelGGL(k_mark_rows, dim3(lin_grid(n)), dim3(BLOCK), 0, s, rows, n, (unsigned int*)bitmap);
 }

@@ -1462,6 +1462,24 @@ PTable slice_table(Exec& x, PTable t, int64_t skip, int64_t count) {
   return t;
 }
 
+// CrossJoinExec (datafusion.proto:1382-1385): every row of the (collected) left input with every row of the right partition.  What
+// DataFusion plans for an uncorrelated scalar subquery -- the one-row side of q11 / q15 / q22's threshold -- followed by a FilterExec.
+struct CrossJoinExec : HashJoinExec {
+  void require(const Names* need) override { left->require(need); right->require(need); }
+  PSchema schema() override { PSchema l = left->schema(), r = right->schema(); l.insert(l.end(), r.begin(), r.end()); return l; }
+  PTable execute(int part, Exec& x) override {
+    std::vector<PTable> ls;
+    for (int p = 0; p < left->partitions(); ++p) { ls.push_back(left->execute(p, x)); resolve(x, ls.back()); }
+    PTable lt = ls.size() == 1 ? ls[0] : concat_tables(x, std::move(ls));
+    PTable rt = right->execute(part, x); resolve(x, rt);
+    auto t0 = std::chrono::steady_clock::now();
+    const int64_t k = lt.n * rt.n;
+    BufP ob = dev_alloc((size_t)std::max<int64_t>(k, 1) * 4 + 16), opb = dev_alloc((size_t)std::max<int64_t>(k, 1) * 4 + 16);
+    check(x, gpuq_cross_pairs(x.ctx, x.stream, lt.n, rt.n, (uint32_t*)ob->p, (uint32_t*)opb->p));
+    return timed(x, t0, join_view(x, lt, rt, (const uint32_t*)ob->p, (const uint32_t*)opb->p, k, ob, opb));
+  }
+};
+
 struct UnionExec : PNode {       // output partitions = the inputs' partitions, one input after another (UNION ALL)
   std::vector<PNodeP> inputs;
   std::vector<PNode*> children() override { std::vector<PNode*> v; for (auto& i : inputs) v.push_back(i.get()); return v; }
@@ -2043,6 +2061,8 @@ PNodeP build_node(const Json& j) {
     n->join_type = v.get_str("join_type", "Inner"); n->partition_mode = v.get_str("partition_mode", "CollectLeft"); n->null_equals_null = v.get_bool("null_equals_null", false);
     if (v.has("filter")) { n->has_filter = true; n->filter = v.at("filter"); }
     out = std::move(n);
+  } else if (kind == "CrossJoinExec") {
+    auto n = std::make_unique<CrossJoinExec>(); n->left = build_child(v, "left"); n->right = build_child(v, "right"); n->on = jarr(); out = std::move(n);
   } else if (kind == "UnionExec") {
     auto n = std::make_unique<UnionExec>(); for (auto& i : v.at("inputs").a) n->inputs.push_back(build_node(i)); out = std::move(n);
   } else if (kind == "CoalescePartitionsExec") {

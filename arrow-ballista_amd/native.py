@@ -72,6 +72,8 @@ def plan_to_json(node, tc, inputs):
         if node.filter is not None:
             d["filter"] = node.filter
         return {"HashJoinExec": d}
+    if isinstance(node, P.CrossJoinExec):
+        return {"CrossJoinExec": {"left": sub(node.left), "right": sub(node.right)}}
     if isinstance(node, P.SortPreservingMergeExec):
         return {"SortPreservingMergeExec": {"input": sub(node.input), "expr": node.expr, "fetch": -1 if node.fetch is None else int(node.fetch)}}
     if isinstance(node, P.SortExec):

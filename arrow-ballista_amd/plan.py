@@ -903,6 +903,28 @@ class CoalescePartitionsExec(CoalesceTasksExec):
         return "CoalescePartitionsExec"
 
 
+class CrossJoinExec(ExecutionPlan):
+    """CrossJoinExec(left, right) -- datafusion.proto:1382-1385.  Every row of the (collected) left input with every row of the right
+    partition; DataFusion plans an uncorrelated scalar subquery this way (a one-row side, then a FilterExec).  Executed by the native
+    executor (NativePlan); this mirror only types it."""
+
+    def __init__(self, left, right):
+        super().__init__()
+        self.left, self.right = left, right
+
+    def children(self):
+        return [self.left, self.right]
+
+    def output_partition_count(self):
+        return self.right.output_partition_count()
+
+    def schema(self):
+        return list(self.left.schema()) + list(self.right.schema())
+
+    def execute(self, partition, context):
+        raise B.GpuqError(3, "CrossJoinExec runs in the native executor (NativePlan)")
+
+
 class UnionExec(ExecutionPlan):
     """UnionExec(inputs) -- datafusion.proto:1319-1321: output partitions are the inputs' partitions, one after another
     (UNION ALL; UNION adds an AggregateExec over all columns, client/src/context.rs:691-733)."""

@@ -695,3 +695,154 @@ def q8_plan(part, supplier, lineitem, orders, customer, nation, region):
     as_ = agg.schema()
     share = g.ProjectionExec([(col("o_year", as_), "o_year"), (binary(col("brazil", as_), Op.Divide, col("total", as_)), "mkt_share"), (col("brazil", as_), "brazil"), (col("total", as_), "total")], agg)
     return g.SortExec([{"expr": col("o_year", share.schema()), "asc": True, "nulls_first": False}], share)
+
+
+def _europe_suppliers(supplier, nation, region, region_name):
+    """region(r_name) |x| nation |x| supplier: the suppliers of one region with their nation's name"""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, Operator as Op
+    ss, ns, rs = supplier.schema(), nation.schema(), region.schema()
+    r = g.ProjectionExec([(col("r_regionkey", rs), "r_regionkey")], g.FilterExec(binary(col("r_name", rs), Op.Eq, lit(region_name)), region))
+    rn = g.HashJoinExec(r, nation, [(col("r_regionkey", r.schema()), col("n_regionkey", ns))], None, "Inner", "CollectLeft", False)
+    rns = rn.schema()
+    rnk = g.ProjectionExec([(col("n_nationkey", rns), "n_nationkey"), (col("n_name", rns), "n_name")], rn)
+    return g.HashJoinExec(rnk, supplier, [(col("n_nationkey", rnk.schema()), col("s_nationkey", ss))], None, "Inner", "CollectLeft", False)
+
+
+def q2_plan(part, supplier, partsupp, nation, region, size=15, type_suffix="BRASS", region_name="EUROPE"):
+    """q2.sql: minimum-cost supplier.  The correlated scalar subquery (min(ps_supplycost) over the region's suppliers of THIS part) is what
+    DataFusion's decorrelation makes of it: MIN grouped by ps_partkey, joined back on (p_partkey, ps_supplycost = min)."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, like, Operator as Op
+    ps_, pss = part.schema(), partsupp.schema()
+    es = _europe_suppliers(supplier, nation, region, region_name)
+    ess = es.schema()
+    pse = g.HashJoinExec(es, partsupp, [(col("s_suppkey", ess), col("ps_suppkey", pss))], None, "Inner", "CollectLeft", False)      # the region's offers
+    pses = pse.schema()
+    minc = g.AggregateExec("Single", [(col("ps_partkey", pses), "min_partkey")], [{"fn": "MIN", "expr": col("ps_supplycost", pses), "name": "min_cost"}], pse)
+    ms = minc.schema()
+    p = g.FilterExec(and_(binary(col("p_size", ps_), Op.Eq, lit(size, "Int32")), like(col("p_type", ps_), "%" + type_suffix)), part)
+    pk = g.ProjectionExec([(col("p_partkey", ps_), "p_partkey"), (col("p_mfgr", ps_), "p_mfgr")], p)
+    j1 = g.HashJoinExec(pk, pse, [(col("p_partkey", pk.schema()), col("ps_partkey", pses))], None, "Inner", "CollectLeft", False)
+    j1s = j1.schema()
+    j2 = g.HashJoinExec(minc, j1, [(col("min_partkey", ms), col("p_partkey", j1s)), (col("min_cost", ms), col("ps_supplycost", j1s))], None, "Inner", "CollectLeft", False)
+    j2s = j2.schema()
+    out = g.ProjectionExec([(col(n, j2s), n) for n in ("s_acctbal", "s_name", "n_name", "p_partkey", "p_mfgr", "s_address", "s_phone", "s_comment")], j2)
+    os_ = out.schema()
+    return g.SortExec([{"expr": col("s_acctbal", os_), "asc": False, "nulls_first": True}, {"expr": col("n_name", os_), "asc": True, "nulls_first": False},
+                       {"expr": col("s_name", os_), "asc": True, "nulls_first": False}, {"expr": col("p_partkey", os_), "asc": True, "nulls_first": False}], out)
+
+
+def q11_plan(partsupp, supplier, nation, nation_name="GERMANY", fraction_unscaled=1):
+    """q11.sql: important stock: SUM(ps_supplycost * ps_availqty) per part of one nation's suppliers HAVING it above 0.0001 of the nation's total --
+    the uncorrelated scalar subquery is a one-row aggregate, CROSS JOINed to the groups and filtered (DataFusion's plan shape).  The
+    fraction is a decimal literal here (0.0001 = 1 at scale 4), so the comparison is exact."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, Operator as Op
+    pss, ss, ns = partsupp.schema(), supplier.schema(), nation.schema()
+    n = g.ProjectionExec([(col("n_nationkey", ns), "n_nationkey")], g.FilterExec(binary(col("n_name", ns), Op.Eq, lit(nation_name)), nation))
+    sn = g.HashJoinExec(n, supplier, [(col("n_nationkey", n.schema()), col("s_nationkey", ss))], None, "Inner", "CollectLeft", False)
+    sk = g.ProjectionExec([(col("s_suppkey", sn.schema()), "s_suppkey")], sn)
+    j = g.HashJoinExec(sk, partsupp, [(col("s_suppkey", sk.schema()), col("ps_suppkey", pss))], None, "Inner", "CollectLeft", False)
+    js = j.schema()
+    v = g.ProjectionExec([(col("ps_partkey", js), "ps_partkey"), (binary(col("ps_supplycost", js), Op.Multiply, col("ps_availqty", js)), "v")], j)
+    vs = v.schema()
+    per = g.AggregateExec("Single", [(col("ps_partkey", vs), "ps_partkey")], [{"fn": "SUM", "expr": col("v", vs), "name": "value"}], v)
+    tot = g.AggregateExec("Single", [], [{"fn": "SUM", "expr": col("v", vs), "name": "total"}], v)
+    thr = g.ProjectionExec([(binary(col("total", tot.schema()), Op.Multiply, lit(fraction_unscaled, ("Decimal128", 5, 4))), "threshold")], tot)
+    cj = g.CrossJoinExec(thr, per)
+    cs = cj.schema()
+    f = g.FilterExec(binary(col("value", cs), Op.Gt, col("threshold", cs)), cj)
+    out = g.ProjectionExec([(col("ps_partkey", cs), "ps_partkey"), (col("value", cs), "value")], f)
+    return g.SortExec([{"expr": col("value", out.schema()), "asc": False, "nulls_first": True}], out)
+
+
+D_1996_01, D_1996_04 = 9496, 9587
+
+
+def q15_plan(supplier, lineitem):
+    """q15.sql: top supplier: the view revenue0 (SUM(revenue) by l_suppkey over one quarter) is computed, its MAX is the scalar subquery,
+    `total_revenue = (select max ..)` an inner join on that one row; ORDER BY s_suppkey."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, Operator as Op
+    ss, ls = supplier.schema(), lineitem.schema()
+    l = g.FilterExec(and_(binary(col("l_shipdate", ls), Op.GtEq, lit(D_1996_01, "Date32")), binary(col("l_shipdate", ls), Op.Lt, lit(D_1996_04, "Date32"))), lineitem)
+    lp = g.ProjectionExec([(col("l_suppkey", ls), "supplier_no"), (_revenue(ls), "rev")], l)
+    rev = g.AggregateExec("Single", [(col("supplier_no", lp.schema()), "supplier_no")], [{"fn": "SUM", "expr": col("rev", lp.schema()), "name": "total_revenue"}], lp)
+    rs = rev.schema()
+    mx = g.AggregateExec("Single", [], [{"fn": "MAX", "expr": col("total_revenue", rs), "name": "max_revenue"}], rev)
+    top = g.HashJoinExec(mx, rev, [(col("max_revenue", mx.schema()), col("total_revenue", rs))], None, "Inner", "CollectLeft", False)
+    ts = top.schema()
+    tp = g.ProjectionExec([(col("supplier_no", ts), "supplier_no"), (col("total_revenue", ts), "total_revenue")], top)
+    j = g.HashJoinExec(tp, supplier, [(col("supplier_no", tp.schema()), col("s_suppkey", ss))], None, "Inner", "CollectLeft", False)
+    js = j.schema()
+    out = g.ProjectionExec([(col(n, js), n) for n in ("s_suppkey", "s_name", "s_address", "s_phone", "total_revenue")], j)
+    return g.SortExec([{"expr": col("s_suppkey", out.schema()), "asc": True, "nulls_first": False}], out)
+
+
+def q17_plan(lineitem, part, brand="Brand#23", container="MED BOX"):
+    """q17.sql: small-quantity-order revenue: the correlated subquery 0.2 * avg(l_quantity) per part is AVG grouped by l_partkey joined back
+    on the part key, `l_quantity < 0.2 * avg` the join's filter; SUM(l_extendedprice) / 7.0."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, Operator as Op
+    ls, ps_ = lineitem.schema(), part.schema()
+    avgq = g.AggregateExec("Single", [(col("l_partkey", ls), "avg_partkey")], [{"fn": "AVG", "expr": col("l_quantity", ls), "name": "avg_qty"}], lineitem)
+    as_ = avgq.schema()
+    p = g.ProjectionExec([(col("p_partkey", ps_), "p_partkey")], g.FilterExec(and_(binary(col("p_brand", ps_), Op.Eq, lit(brand)), binary(col("p_container", ps_), Op.Eq, lit(container))), part))
+    j1 = g.HashJoinExec(p, lineitem, [(col("p_partkey", p.schema()), col("l_partkey", ls))], None, "Inner", "CollectLeft", False)
+    j1s = j1.schema()
+    small = binary(col("l_quantity", j1s), Op.Lt, binary(lit(2, ("Decimal128", 2, 1)), Op.Multiply, col("avg_qty", as_)))
+    j2 = g.HashJoinExec(avgq, j1, [(col("avg_partkey", as_), col("p_partkey", j1s))], small, "Inner", "CollectLeft", False)
+    agg = g.AggregateExec("Single", [], [{"fn": "SUM", "expr": col("l_extendedprice", j2.schema()), "name": "s"}], j2)
+    return g.ProjectionExec([(binary(col("s", agg.schema()), Op.Divide, lit(70, ("Decimal128", 2, 1))), "avg_yearly"), (col("s", agg.schema()), "s")], agg)
+
+
+def q20_plan(supplier, nation, partsupp, part, lineitem, prefix="forest", nation_name="CANADA"):
+    """q20.sql: potential part promotion: nested IN subqueries are semi joins, the correlated 0.5 * sum(l_quantity) over (part, supplier) of one
+    year an aggregate joined on both keys with `ps_availqty > 0.5 * sum` as the join filter; ORDER BY s_name."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, and_, like, Operator as Op
+    ss, ns, pss, ps_, ls = supplier.schema(), nation.schema(), partsupp.schema(), part.schema(), lineitem.schema()
+    p = g.ProjectionExec([(col("p_partkey", ps_), "p_partkey")], g.FilterExec(like(col("p_name", ps_), prefix + "%"), part))
+    ps1 = g.HashJoinExec(p, partsupp, [(col("p_partkey", p.schema()), col("ps_partkey", pss))], None, "RightSemi", "CollectLeft", False)
+    p1s = ps1.schema()
+    l = g.FilterExec(and_(binary(col("l_shipdate", ls), Op.GtEq, lit(D_1994, "Date32")), binary(col("l_shipdate", ls), Op.Lt, lit(D_1995, "Date32"))), lineitem)
+    lq = g.AggregateExec("Single", [(col("l_partkey", ls), "q_partkey"), (col("l_suppkey", ls), "q_suppkey")], [{"fn": "SUM", "expr": col("l_quantity", ls), "name": "q"}], l)
+    qs = lq.schema()
+    enough = binary(col("ps_availqty", p1s), Op.Gt, binary(lit(5, ("Decimal128", 2, 1)), Op.Multiply, col("q", qs)))
+    ps2 = g.HashJoinExec(lq, ps1, [(col("q_partkey", qs), col("ps_partkey", p1s)), (col("q_suppkey", qs), col("ps_suppkey", p1s))], enough, "Inner", "CollectLeft", False)
+    sk = g.ProjectionExec([(col("ps_suppkey", ps2.schema()), "ok_suppkey")], ps2)
+    n = g.ProjectionExec([(col("n_nationkey", ns), "n_nationkey")], g.FilterExec(binary(col("n_name", ns), Op.Eq, lit(nation_name)), nation))
+    sn = g.HashJoinExec(n, supplier, [(col("n_nationkey", n.schema()), col("s_nationkey", ss))], None, "Inner", "CollectLeft", False)
+    sns = sn.schema()
+    r = g.HashJoinExec(sk, sn, [(col("ok_suppkey", sk.schema()), col("s_suppkey", sns))], None, "RightSemi", "CollectLeft", False)
+    out = g.ProjectionExec([(col("s_name", r.schema()), "s_name"), (col("s_address", r.schema()), "s_address")], r)
+    return g.SortExec([{"expr": col("s_name", out.schema()), "asc": True, "nulls_first": False}], out)
+
+
+def q21_plan(supplier, lineitem, orders, nation, nation_name="SAUDI ARABIA"):
+    """q21.sql: suppliers who kept orders waiting: EXISTS (another supplier's lineitem in the order) is a semi join, NOT EXISTS (another supplier's
+    LATE lineitem) an anti join, both on l_orderkey with `l_suppkey <> l1.l_suppkey` as the join filter; COUNT(*) by s_name, ORDER BY
+    numwait DESC, s_name."""
+    import arrow_ballista_amd as g
+    from arrow_ballista_amd.expr import col, lit, binary, Operator as Op
+    ss, ls, os_, ns = supplier.schema(), lineitem.schema(), orders.schema(), nation.schema()
+    late = binary(col("l_receiptdate", ls), Op.Gt, col("l_commitdate", ls))
+    n = g.ProjectionExec([(col("n_nationkey", ns), "n_nationkey")], g.FilterExec(binary(col("n_name", ns), Op.Eq, lit(nation_name)), nation))
+    sn = g.HashJoinExec(n, supplier, [(col("n_nationkey", n.schema()), col("s_nationkey", ss))], None, "Inner", "CollectLeft", False)
+    s = g.ProjectionExec([(col("s_suppkey", sn.schema()), "s_suppkey"), (col("s_name", sn.schema()), "s_name")], sn)
+    l1 = g.ProjectionExec([(col("l_orderkey", ls), "l_orderkey"), (col("l_suppkey", ls), "l_suppkey")], g.FilterExec(late, lineitem))
+    j = g.HashJoinExec(s, l1, [(col("s_suppkey", s.schema()), col("l_suppkey", l1.schema()))], None, "Inner", "CollectLeft", False)
+    js = j.schema()
+    o = g.ProjectionExec([(col("o_orderkey", os_), "o_orderkey")], g.FilterExec(binary(col("o_orderstatus", os_), Op.Eq, lit("F")), orders))
+    jo = g.HashJoinExec(o, j, [(col("o_orderkey", o.schema()), col("l_orderkey", js))], None, "RightSemi", "CollectLeft", False)
+    jos = jo.schema()
+    l2 = g.ProjectionExec([(col("l_orderkey", ls), "l2_orderkey"), (col("l_suppkey", ls), "l2_suppkey")], lineitem)
+    l2s = l2.schema()
+    ex = g.HashJoinExec(l2, jo, [(col("l2_orderkey", l2s), col("l_orderkey", jos))], binary(col("l2_suppkey", l2s), Op.NotEq, col("l_suppkey", jos)), "RightSemi", "CollectLeft", False)
+    l3 = g.ProjectionExec([(col("l_orderkey", ls), "l3_orderkey"), (col("l_suppkey", ls), "l3_suppkey")], g.FilterExec(late, lineitem))
+    l3s = l3.schema()
+    nx = g.HashJoinExec(l3, ex, [(col("l3_orderkey", l3s), col("l_orderkey", ex.schema()))], binary(col("l3_suppkey", l3s), Op.NotEq, col("l_suppkey", ex.schema())), "RightAnti", "CollectLeft", False)
+    agg = g.AggregateExec("Single", [(col("s_name", nx.schema()), "s_name")], [{"fn": "COUNT", "expr": lit(1), "name": "numwait"}], nx)
+    as_ = agg.schema()
+    return g.SortExec([{"expr": col("numwait", as_), "asc": False, "nulls_first": True}, {"expr": col("s_name", as_), "asc": True, "nulls_first": False}], agg)

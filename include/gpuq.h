@@ -313,6 +313,11 @@ int gpuq_join_build_side_rows(gpuq_join_table* t, void* stream, int matched, uin
    over that Boolean column.  Asynchronous. */
 int gpuq_mark_rows(gpuq_ctx* ctx, void* stream, const uint32_t* rows, int64_t n, uint8_t* bitmap);
 
+/* CrossJoinExec (datafusion.proto:1382-1385; what DataFusion plans for an uncorrelated scalar subquery: q11 / q15 / q22's threshold is a
+   one-row side): the row pairs of left x right, left-major -- left_rows_out[i] = i / n_right, right_rows_out[i] = i % n_right for
+   i < n_left * n_right (< 2^32).  The executor reads both sides through these index vectors like a hash join's pairs.  Asynchronous. */
+int gpuq_cross_pairs(gpuq_ctx* ctx, void* stream, int64_t n_left, int64_t n_right, uint32_t* left_rows_out, uint32_t* right_rows_out);
+
 /* SortExec: writes the permutation (driving positions in sorted order; stable) to perm_out (n_rows).
    The call reads the key range back (one stream synchronisation in the middle).  From 2^22 rows on the range comes from a row
    sample and the pack kernel verifies it; the call then waits for one word at the end and re-runs with the exact range when the

@@ -1,4 +1,4 @@
-"""More of the harness's 22 queries through the native executor (benchmarks/tpch.py: q6, q7, q12, q14, q16, q19, q22 -- with q1, q3, q5
+"""The rest of the harness's 22 queries through the native executor (benchmarks/tpch.py: q2, q4, q6-q22 -- with q1, q3, q5 all 22;
 ten of them), over small generated tables with the reference's column names and types, against the same queries written as plain
 Python over the host rows.  What they exercise beyond q1 / q3 / q5: date_part (extract(year ..)), substr, COUNT(DISTINCT), LIKE /
 NOT LIKE inside plans, a JoinFilter of OR-ed conjunctions over both sides, RightAnti joins (NOT IN / NOT EXISTS), a literal beyond
@@ -73,6 +73,17 @@ def db():
                               "l_shipdate": _date(ship), "l_commitdate": _date(commit), "l_receiptdate": _date(receipt),
                               "l_shipmode": pa.array([modes[i] for i in r.integers(0, 8, n_li)]), "l_shipinstruct": pa.array([instr[i] for i in r.integers(0, 4, n_li)]),
                               "l_returnflag": pa.array([["R", "A", "N"][i] for i in r.integers(0, 3, n_li)])})
+    # columns added for q2 / q11 / q15 / q17 / q20 / q21 (a generator of their own: the columns above keep their values)
+    r2 = np.random.default_rng(78)
+    hot = np.array([2, 3, 6, 7, 19, 20, 22, 23])          # BRAZIL, CANADA, FRANCE, GERMANY, ROMANIA, SAUDI ARABIA, RUSSIA, UNITED KINGDOM
+    snat = np.where(r2.random(n_supp) < 0.75, hot[r2.integers(0, len(hot), n_supp)], r2.integers(0, 25, n_supp))
+    sup = t["supplier"].set_column(t["supplier"].schema.get_field_index("s_nationkey"), "s_nationkey", pa.array(snat, pa.int64()))
+    sup = sup.append_column("s_acctbal", _dec(r2.integers(-99999, 999999, n_supp))).append_column("s_name", pa.array(["Supplier#%09d" % i for i in range(1, n_supp + 1)]))
+    sup = sup.append_column("s_address", pa.array(["%d industrial road %s" % (i, "xyz"[i % 3] * (i % 17)) for i in range(n_supp)]))
+    t["supplier"] = sup.append_column("s_phone", pa.array(["%02d-%03d-%03d-%04d" % (10 + i % 25, 100 + i, 200 + i, 1000 + i) for i in range(n_supp)]))
+    t["part"] = t["part"].append_column("p_mfgr", pa.array(["Manufacturer#%d" % (1 + i % 5) for i in range(n_part)]))
+    t["partsupp"] = t["partsupp"].append_column("ps_availqty", pa.array(r2.integers(1, 10000, n_part * 4).astype(np.int32)))
+    t["orders"] = t["orders"].append_column("o_orderstatus", pa.array([["F", "O", "P"][i] for i in r2.integers(0, 3, n_ord)]))
     # non-nullable fields, as in the reference's schema (tpch.rs:871-952)
     t = {k: v.cast(pa.schema([pa.field(f.name, f.type, False) for f in v.schema])) for k, v in t.items()}
     rows = {k: [dict(zip(v.column_names, r_)) for r_ in zip(*[c.to_pylist() for c in v.columns])] for k, v in t.items()}
@@ -248,6 +259,133 @@ def test_q8_market_share(tc, db):
         one = O.Table(["b", "t"], [O.dec(38, 4), O.dec(38, 4)], [[b], [tot]])
         e = {"binary_expr": {"l": {"column": {"name": "b"}}, "r": {"column": {"name": "t"}}, "op": "/"}}
         assert share == O.eval_expr(e, one)[1][0]
+
+
+def test_q2_minimum_cost_supplier(tc, db):
+    t, rows = db
+    nname = {n["n_nationkey"]: n["n_name"] for n in rows["nation"]}
+    europe = {n["n_nationkey"] for n in rows["nation"] if T.REGIONS[n["n_regionkey"]] == "EUROPE"}
+    supp = {s_["s_suppkey"]: s_ for s_ in rows["supplier"] if s_["s_nationkey"] in europe}
+    offers = collections.defaultdict(list)
+    for ps in rows["partsupp"]:
+        if ps["ps_suppkey"] in supp:
+            offers[ps["ps_partkey"]].append(ps)
+    total = 0
+    for size in (15, 7, 23, 42, 3):
+        got, _ = native_rows(tc, T.q2_plan(_src(t["part"]), _src(t["supplier"]), _src(t["partsupp"]), _src(t["nation"]), _src(t["region"]), size=size))
+        exp = []
+        for p in rows["part"]:
+            if p["p_size"] == size and p["p_type"].endswith("BRASS") and offers.get(p["p_partkey"]):
+                mn = min(o["ps_supplycost"] for o in offers[p["p_partkey"]])
+                for o in offers[p["p_partkey"]]:
+                    if o["ps_supplycost"] == mn:
+                        s_ = supp[o["ps_suppkey"]]
+                        exp.append((_u(s_["s_acctbal"]), s_["s_name"], nname[s_["s_nationkey"]], p["p_partkey"], p["p_mfgr"], s_["s_address"], s_["s_phone"], s_["s_comment"]))
+        exp.sort(key=lambda r_: (-r_[0], r_[2], r_[1], r_[3]))
+        assert got == exp
+        total += len(exp)
+    assert total > 0
+
+
+def test_q11_important_stock(tc, db):
+    t, rows = db
+    germany = {n["n_nationkey"] for n in rows["nation"] if n["n_name"] == "GERMANY"}
+    supp = {s_["s_suppkey"] for s_ in rows["supplier"] if s_["s_nationkey"] in germany}
+    per = collections.defaultdict(int)
+    for ps in rows["partsupp"]:
+        if ps["ps_suppkey"] in supp:
+            per[ps["ps_partkey"]] += _u(ps["ps_supplycost"]) * ps["ps_availqty"]
+    tot = sum(per.values())
+    for frac in (1, 100):          # the query's 0.0001, and 0.01 (so that the HAVING clause actually removes groups here)
+        got, _ = native_rows(tc, T.q11_plan(_src(t["partsupp"]), _src(t["supplier"]), _src(t["nation"]), fraction_unscaled=frac))
+        exp = sorted(((k, v) for k, v in per.items() if v * 10**4 > tot * frac), key=lambda r_: -r_[1])
+        assert [r_[1] for r_ in got] == [r_[1] for r_ in exp] and sorted(got) == sorted(exp) and len(exp) > 0
+    assert len(exp) < len(per)
+
+
+def test_q15_top_supplier(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q15_plan(_src(t["supplier"]), _src(t["lineitem"])))
+    rev = collections.defaultdict(int)
+    for l in rows["lineitem"]:
+        if T.D_1996_01 <= _days(l["l_shipdate"]) < T.D_1996_04:
+            rev[l["l_suppkey"]] += _u(l["l_extendedprice"]) * (100 - _u(l["l_discount"]))
+    mx = max(rev.values())
+    supp = {s_["s_suppkey"]: s_ for s_ in rows["supplier"]}
+    exp = sorted((k, supp[k]["s_name"], supp[k]["s_address"], supp[k]["s_phone"], v) for k, v in rev.items() if v == mx)
+    assert got == exp and len(exp) >= 1
+
+
+def test_q17_small_quantity_order_revenue(tc, db):
+    t, rows = db
+    by_part = collections.defaultdict(list)
+    for l in rows["lineitem"]:
+        by_part[l["l_partkey"]].append(l)
+    # the query's (Brand#23, MED BOX) selects no part of a 400-part fixture: also run the pair that selects the most lineitems
+    pairs = collections.Counter()
+    for p in rows["part"]:
+        pairs[(p["p_brand"], p["p_container"])] += len(by_part[p["p_partkey"]])
+    hits = 0
+    for brand, container in (("Brand#23", "MED BOX"), pairs.most_common(1)[0][0]):
+        got, _ = native_rows(tc, T.q17_plan(_src(t["lineitem"]), _src(t["part"]), brand, container))
+        tot = None
+        for p in rows["part"]:
+            if p["p_brand"] == brand and p["p_container"] == container and by_part[p["p_partkey"]]:
+                ls_ = by_part[p["p_partkey"]]
+                avg = (sum(_u(l["l_quantity"]) for l in ls_) * 10**4) // len(ls_)          # AVG(Decimal(15,2)) -> scale 6, truncated
+                for l in ls_:
+                    if _u(l["l_quantity"]) * 10**5 < 2 * avg:                                # scale 2 against 0.2 * avg at scale 7
+                        tot = (tot or 0) + _u(l["l_extendedprice"]); hits += 1
+        assert got[0][1] == tot
+        if tot is not None:
+            one = O.Table(["s"], [O.dec(25, 2)], [[tot]])
+            e = {"binary_expr": {"l": {"column": {"name": "s"}}, "r": {"literal": {"type": {"Decimal128": [2, 1]}, "value": "70"}}, "op": "/"}}
+            assert got[0][0] == O.eval_expr(e, one)[1][0]
+    assert hits > 0
+
+
+def test_q20_potential_part_promotion(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q20_plan(_src(t["supplier"]), _src(t["nation"]), _src(t["partsupp"]), _src(t["part"]), _src(t["lineitem"])))
+    forest = {p["p_partkey"] for p in rows["part"] if p["p_name"].startswith("forest")}
+    q = collections.defaultdict(int)
+    for l in rows["lineitem"]:
+        if T.D_1994 <= _days(l["l_shipdate"]) < T.D_1995:
+            q[(l["l_partkey"], l["l_suppkey"])] += _u(l["l_quantity"])
+    ok = {ps["ps_suppkey"] for ps in rows["partsupp"] if ps["ps_partkey"] in forest and (ps["ps_partkey"], ps["ps_suppkey"]) in q
+          and ps["ps_availqty"] * 1000 > 5 * q[(ps["ps_partkey"], ps["ps_suppkey"])]}          # availqty > 0.5 * sum: scale 3 on both sides
+    canada = {n["n_nationkey"] for n in rows["nation"] if n["n_name"] == "CANADA"}
+    exp = sorted((s_["s_name"], s_["s_address"]) for s_ in rows["supplier"] if s_["s_suppkey"] in ok and s_["s_nationkey"] in canada)
+    assert got == exp and len(ok) > 0
+
+
+def test_q21_suppliers_who_kept_orders_waiting(tc, db):
+    t, rows = db
+    got, _ = native_rows(tc, T.q21_plan(_src(t["supplier"]), _src(t["lineitem"]), _src(t["orders"]), _src(t["nation"])))
+    saudi = {n["n_nationkey"] for n in rows["nation"] if n["n_name"] == "SAUDI ARABIA"}
+    sname = {s_["s_suppkey"]: s_["s_name"] for s_ in rows["supplier"] if s_["s_nationkey"] in saudi}
+    f_orders = {o["o_orderkey"] for o in rows["orders"] if o["o_orderstatus"] == "F"}
+    by_order = collections.defaultdict(list)
+    for l in rows["lineitem"]:
+        by_order[l["l_orderkey"]].append(l)
+    acc = collections.Counter()
+    for l1 in rows["lineitem"]:
+        if l1["l_suppkey"] in sname and l1["l_orderkey"] in f_orders and l1["l_receiptdate"] > l1["l_commitdate"]:
+            others = [l for l in by_order[l1["l_orderkey"]] if l["l_suppkey"] != l1["l_suppkey"]]
+            if others and not any(l["l_receiptdate"] > l["l_commitdate"] for l in others):
+                acc[sname[l1["l_suppkey"]]] += 1
+    exp = sorted(acc.items(), key=lambda r_: (-r_[1], r_[0]))
+    assert got == exp and len(exp) > 0
+
+
+def test_cross_join_exec(tc):
+    """CrossJoinExec: every pair, left-major; an empty side gives no rows."""
+    l = pa.table({"a": pa.array([1, 2, 3], pa.int64()), "s": pa.array(["x", None, "a string longer than fifteen bytes"])})
+    r_ = pa.table({"b": pa.array(np.arange(1000), pa.int32())})
+    got, _ = native_rows(tc, g.CrossJoinExec(_src(l), _src(r_)))
+    assert got == [(a, s_, b) for a, s_ in zip([1, 2, 3], ["x", None, "a string longer than fifteen bytes"]) for b in range(1000)]
+    got, _ = native_rows(tc, g.CrossJoinExec(_src(l.slice(0, 0)), _src(r_)))
+    assert got == []
 
 
 def test_scalar_functions_and_aggregate_filter_against_the_oracle(tc):
