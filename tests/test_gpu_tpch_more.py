@@ -1,5 +1,5 @@
-"""The rest of the harness's 22 queries through the native executor (benchmarks/tpch.py: q2, q4, q6-q22 -- with q1, q3, q5 all 22;
-ten of them), over small generated tables with the reference's column names and types, against the same queries written as plain
+"""The rest of the harness's 22 queries through the native executor (benchmarks/tpch.py: q2, q4, q6-q22 -- with q1, q3, q5 that
+is all of them), over small generated tables with the reference's column names and types, against the same queries written as plain
 Python over the host rows.  What they exercise beyond q1 / q3 / q5: date_part (extract(year ..)), substr, COUNT(DISTINCT), LIKE /
 NOT LIKE inside plans, a JoinFilter of OR-ed conjunctions over both sides, RightAnti joins (NOT IN / NOT EXISTS), a literal beyond
 15 bytes, long Utf8 group and sort keys, decimal division.  Every plan also runs twice more deferred (native_rows)."""
