@@ -20,7 +20,7 @@ use datafusion::physical_plan::expressions::{
     PhysicalSortExpr, Sum, TryCastExpr,
 };
 use datafusion::physical_plan::filter::FilterExec;
-use datafusion::physical_plan::joins::{HashJoinExec, PartitionMode};
+use datafusion::physical_plan::joins::{CrossJoinExec, HashJoinExec, PartitionMode};
 use datafusion::physical_plan::limit::{GlobalLimitExec, LocalLimitExec};
 use datafusion::physical_plan::projection::ProjectionExec;
 use datafusion::physical_plan::sorts::sort::SortExec;
@@ -227,6 +227,10 @@ fn walk_node(p: &Arc<dyn ExecutionPlan>, leaves: &mut Vec<(Arc<dyn ExecutionPlan
             j["filter"] = crate::plan_walk::join_filter(f, n.left().schema().fields().len())?;
         }
         return Ok(json!({"HashJoinExec": j}));
+    }
+    if let Some(n) = a.downcast_ref::<CrossJoinExec>() {
+        // (an uncorrelated scalar subquery arrives as a one-row left side; gpuq refuses more than 2^32 pairs)
+        return Ok(json!({"CrossJoinExec": {"left": walk(n.left(), leaves)?, "right": walk(n.right(), leaves)?}}));
     }
     if let Some(n) = a.downcast_ref::<SortExec>() {
         if n.preserve_partitioning() && n.input().output_partitioning().partition_count() > 1 {
