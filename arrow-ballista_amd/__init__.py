@@ -7,7 +7,7 @@ anywhere (so descriptors can be compiled and validated on a host without a GPU),
 :class:`Context` without a HIP device raises.
 """
 from .binding import (  # noqa: F401
-    GpuqError, Context, Op, JoinTable, lib, lib_path, compile_check, compile_jit_source,
+    GpuqError, Context, Op, JoinTable, lib, lib_path, compile_check, compile_jit_source, memory_limit, memory_stats,
     T_NULL, T_BOOL, T_INT32, T_INT64, T_DATE32, T_FLOAT64, T_DECIMAL128, T_UTF8, T_UINT32, T_UINT64,
 )
 from . import expr  # noqa: F401
@@ -21,7 +21,7 @@ from .plan import (  # noqa: F401
 )
 
 __all__ = [
-    "GpuqError", "Context", "Op", "JoinTable", "lib", "lib_path", "compile_check", "expr",
+    "GpuqError", "Context", "Op", "JoinTable", "lib", "lib_path", "compile_check", "memory_limit", "memory_stats", "expr",
     "DeviceColumn", "DeviceTable", "MemoryExec", "FilterExec", "ProjectionExec", "AggregateExec",
     "HashJoinExec", "CrossJoinExec", "SortExec", "CoalesceBatchesExec", "RepartitionExec", "ShuffleWriterExec", "ShuffleReaderExec",
     "DefaultExecutionEngine", "TaskContext", "CoalesceTasksExec", "CoalescePartitionsExec", "SortPreservingMergeExec",

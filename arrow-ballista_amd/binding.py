@@ -90,6 +90,9 @@ def lib():
         "gpuq_copy_d2h": (i32, [vp, vp, vp, vp, C.c_size_t]),
         "gpuq_table_import_arrow": (i32, [vp, vp, vp, vp, C.POINTER(vp)]),
         "gpuq_cross_pairs": (i32, [vp, vp, i64, i64, vp, vp]),
+        "gpuq_memory_limit": (i32, [i64]),
+        "gpuq_memory_stats": (i32, [C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), i32]),
+        "gpuq_utf8_compare": (i32, [vp, vp, C.POINTER(gpuq_column), vp, C.POINTER(gpuq_column), vp, C.c_char_p, i64, i64, i32, vp, vp]),
         "gpuq_ingest_create": (i32, [vp, vp, i64, i64, i32, C.POINTER(vp)]),
         "gpuq_ingest_push": (i32, [vp, vp]),
         "gpuq_ingest_rows_landed": (i32, [vp, C.POINTER(i64)]),
@@ -218,6 +221,19 @@ def lib():
     atexit.register(L.gpuq_jit_quiesce)      # background compiles must not outlive the interpreter (include/gpuq.h)
     _LIB = L
     return L
+
+
+def memory_limit(nbytes):
+    """Process-wide budget for the device memory the library holds (0 = none): include/gpuq.h gpuq_memory_limit."""
+    rc = lib().gpuq_memory_limit(int(nbytes))
+    if rc != 0:
+        raise GpuqError(rc, "bad memory limit")
+
+
+def memory_stats(reset_peak=False):
+    a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    lib().gpuq_memory_stats(C.byref(a), C.byref(b), C.byref(c), C.byref(d), 1 if reset_peak else 0)
+    return {"in_use": a.value, "peak": b.value, "cached": c.value, "limit": d.value}
 
 
 def compile_check(descriptor):

@@ -1912,6 +1912,23 @@ int gpuq_mark_rows(gpuq_ctx* ctx, void* stream, const uint32_t* rows, int64_t n,
   });
 }
 
+int gpuq_memory_limit(int64_t bytes) {
+  if (bytes < 0) return GPUQ_ERR_INVALID;
+  DevPool& P = DevPool::get();
+  std::lock_guard<std::mutex> lk(P.mu);
+  P.limit = (size_t)bytes;
+  return GPUQ_OK;
+}
+int gpuq_memory_stats(int64_t* in_use_out, int64_t* peak_out, int64_t* cached_out, int64_t* limit_out, int reset_peak) {
+  DevPool& P = DevPool::get();
+  std::lock_guard<std::mutex> lk(P.mu);
+  if (in_use_out) *in_use_out = (int64_t)P.in_use;
+  if (peak_out) *peak_out = (int64_t)P.peak;
+  if (cached_out) *cached_out = (int64_t)P.held;
+  if (limit_out) *limit_out = (int64_t)P.limit;
+  if (reset_peak) P.peak = P.in_use;
+  return GPUQ_OK;
+}
 int gpuq_cross_pairs(gpuq_ctx* ctx, void* stream, int64_t n_left, int64_t n_right, uint32_t* left_rows_out, uint32_t* right_rows_out) {
   return guarded(ctx, [&]() {
     check_ctx(ctx);
@@ -1996,6 +2013,22 @@ int gpuq_utf8_intern(gpuq_utf8_dict* d, void* stream, const gpuq_column* col, co
 }
 
 // ---------------------------------------------------------------- LIKE
+int gpuq_utf8_compare(gpuq_ctx* ctx, void* stream, const gpuq_column* a, const uint32_t* idx_a, const gpuq_column* b, const uint32_t* idx_b, const char* literal,
+                      int64_t literal_len, int64_t n, int op, uint8_t* bits_out, uint8_t* validity_out) {
+  return guarded(ctx, [&]() {
+    check_ctx(ctx);
+    if (!a || (n > 0 && !bits_out) || op < 0 || op > 5) throw std::runtime_error("gpuq_utf8_compare: bad arguments");
+    auto arrow = [&](const gpuq_column* c) { if (c->type != T_UTF8 || c->repr != GPUQ_REPR_ARROW || (n > 0 && !c->offsets)) throw Unsupported("gpuq_utf8_compare needs Utf8 columns in Arrow layout (offsets + bytes)"); };
+    arrow(a); if (b) arrow(b);
+    if (!b && (!literal || literal_len < 0 || literal_len > 0x7FFFFFFFll)) throw std::runtime_error("gpuq_utf8_compare: neither a second column nor a literal");
+    hipStream_t s = use_stream(stream);
+    DevBuf lit;      // released to the pool behind the launch on this stream
+    if (!b) { lit.ensure((size_t)literal_len + 16); if (literal_len) HIPCHECK(hipMemcpyAsync(lit.p, literal, (size_t)literal_len, hipMemcpyHostToDevice, s)); }      // (pageable source: staged before the call returns)
+    launch_utf8_compare(s, (const uint8_t*)a->data, a->offsets, a->validity, idx_a, b ? (const uint8_t*)b->data : (const uint8_t*)lit.p, b ? b->offsets : nullptr,
+                        b ? b->validity : nullptr, idx_b, (int32_t)literal_len, n, op, (u64*)bits_out, (u64*)validity_out);
+    HIPCHECK(hipGetLastError());
+  });
+}
 int gpuq_like_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, const char* pattern, int negated, int case_insensitive,
                    uint8_t* bits_out, uint8_t* validity_out) {
   return guarded(ctx, [&]() {

@@ -202,7 +202,13 @@ NodeP ExprCompiler::lit_null(DType t) {
 NodeP ExprCompiler::lit_str(const std::string& s) {
   auto n = std::make_shared<Node>();
   n->kind = Node::LIT; n->type.id = T_UTF8; n->nullable = false;
-  if (!pack_str15(s, n->lit_lo, n->lit_hi)) throw std::runtime_error("Utf8 literal longer than 15 bytes is not supported on device: '" + s + "'");
+  if (!pack_str15(s, n->lit_lo, n->lit_hi)) {
+    // beyond what a register holds: the node stands for the literal in COMPARISONS only (binary() compares with its 15-byte prefix, which
+    // is exact for every value a register can hold; longer values raise FLAG_STR_TRUNC when they are loaded and the executor then lowers the
+    // comparison to gpuq_utf8_compare).  Anything else that consumes it fails when the program is generated.
+    pack_str15(s.substr(0, 15), n->lit_lo, n->lit_hi); n->lit_long = true; n->key = "lsL:" + s;
+    return intern(n);
+  }
   n->key = "ls:" + s;
   return intern(n);
 }
@@ -358,6 +364,19 @@ NodeP ExprCompiler::binary(const std::string& op_in, NodeP l, NodeP r) {
     }
     const bool lu = l->type.id == T_UTF8, ru = r->type.id == T_UTF8;
     if (lu != ru) throw std::runtime_error("cannot compare " + l->type.to_string() + " with " + r->type.to_string());
+    if (lu && (l->lit_long || r->lit_long) && !(l->lit_long && r->lit_long)) {
+      // c OP L with L beyond 15 bytes, c a value of at most 15 (longer ones were flagged at their load): with P = L's first 15 bytes,
+      // c == P means c is a proper prefix of L, hence c < L  <=>  c <= P,  c <= L  <=>  c <= P,  c > L  <=>  c > P,  c >= L  <=>  c > P,
+      // c = L never, c != L always (NULL in -> NULL out in every case)
+      const bool lit_left = l->lit_long;
+      NodeP c = lit_left ? r : l;
+      NodeP P = raw(OP_MOV, mk(T_UTF8), false, 127, {lit_left ? l : r}, 0xC0DEu);      // the packed prefix as an ordinary value (the marker: finish() lets only this use through)
+      std::string o = op;
+      if (lit_left) o = op == "<" ? ">" : op == "<=" ? ">=" : op == ">" ? "<" : op == ">=" ? "<=" : op;      // L OP c  ==  c mirror(OP) L
+      if (o == "=") return raw(OP_LT, mk(T_BOOL), nullable, 2, {c, c});
+      if (o == "!=") return raw(OP_EQ, mk(T_BOOL), nullable, 2, {c, c});
+      return raw((o == "<" || o == "<=") ? OP_LE : OP_GT, mk(T_BOOL), nullable, 2, {c, P});
+    }
     const bool ld = l->type.is_temporal(), rd = r->type.is_temporal();
     if ((ld && !(r->type == l->type || r->type.is_int())) || (rd && !(l->type == r->type || l->type.is_int())))
       throw std::runtime_error("cannot compare " + l->type.to_string() + " with " + r->type.to_string());
@@ -569,6 +588,19 @@ CompiledProgram ExprCompiler::finish() {
     for (auto& c : n->ch) topo(c.get());
     order.push_back(n);
   };
+  {      // a Utf8 literal beyond 15 bytes may only feed the prefix comparison binary() builds for it
+    const char* msg = "Utf8 literal longer than 15 bytes is not supported on device outside a comparison";
+    std::set<Node*> walked;
+    std::function<void(Node*)> chk = [&](Node* n) {
+      if (!walked.insert(n).second) return;
+      for (auto& c : n->ch) {
+        if (c->kind == Node::LIT && c->lit_long && !(n->kind == Node::OPN && n->op == OP_MOV && n->imm == 0xC0DEu)) throw std::runtime_error(msg);
+        chk(c.get());
+      }
+    };
+    if (pred_) { if (pred_->kind == Node::LIT && pred_->lit_long) throw std::runtime_error(msg); chk(pred_.get()); }
+    for (auto& o : outs_) { if (o->kind == Node::LIT && o->lit_long) throw std::runtime_error(msg); chk(o.get()); }
+  }
   if (pred_) topo(pred_.get());
   for (auto& o : outs_) topo(o.get());
   for (Node* n : order) if (n->kind == Node::COL) {

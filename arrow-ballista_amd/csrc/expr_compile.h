@@ -75,6 +75,7 @@ struct Node {
   int bits = 127;            // bound on the magnitude: |value| < 2^bits (integers / decimals)
   int col = -1;              // COL: schema field index
   u64 lit_lo = 0, lit_hi = 0; bool lit_null = false;   // LIT
+  bool lit_long = false;     // LIT: a Utf8 literal beyond 15 bytes -- lit_lo / lit_hi pack its first 15; only a comparison may consume it (binary())
   std::string key;           // canonical text, CSE key
 };
 

@@ -1123,6 +1123,46 @@ void launch_like_utf8(hipStream_t s, const uint8_t* data, const int32_t* offsets
                       u64* bits_out, u64* valid_out) {
   if (n > 0) hipLaunchKernelGGL(k_like_utf8, dim3(lin_grid(n)), dim3(BLOCK), 0, s, data, offsets, validity, idx, n, pat, negated, bits_out, valid_out);
 }
+// ------------------------------------------------------------------ Utf8 comparisons at any length
+// The register programs compare strings of up to 15 bytes; an ordering comparison (or column = column) over longer values is run here,
+// over the Arrow-layout bytes: op 0 = , 1 != , 2 < , 3 <= , 4 > , 5 >=  by bytes (memcmp, then the shorter string first: arrow's order).
+// b is another column (boffs != nullptr, read through bidx) or ONE literal (bdata = its bytes, blen its length).  Either side NULL -> NULL.
+struct Utf8Side { const uint8_t* data; const int32_t* offsets; const uint8_t* validity; const uint32_t* idx; };
+__global__ void __launch_bounds__(BLOCK) k_utf8_compare(const Utf8Side A, const Utf8Side B, const int32_t blen, const i64 n, const int op, u64* __restrict__ bits_out, u64* __restrict__ valid_out) {
+  const i64 words = (n + 63) >> 6;
+  for (i64 w = (i64)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); w < words; w += (i64)gridDim.x * (BLOCK / 64)) {
+    const i64 i = w * 64 + (threadIdx.x & 63);
+    bool valid = false, m = false;
+    if (i < n) {
+      const uint32_t ra = A.idx ? A.idx[i] : (uint32_t)i;
+      valid = ra != 0xFFFFFFFFu && (!A.validity || ((A.validity[ra >> 3] >> (ra & 7)) & 1));
+      const uint8_t* pb = B.data; int32_t lb = blen;
+      if (B.offsets) {
+        const uint32_t rb = B.idx ? B.idx[i] : (uint32_t)i;
+        valid = valid && rb != 0xFFFFFFFFu && (!B.validity || ((B.validity[rb >> 3] >> (rb & 7)) & 1));
+        if (valid) { pb = B.data + B.offsets[rb]; lb = B.offsets[rb + 1] - B.offsets[rb]; }
+      }
+      if (valid) {
+        const uint8_t* pa = A.data + A.offsets[ra]; const int32_t la = A.offsets[ra + 1] - A.offsets[ra];
+        const int32_t k = la < lb ? la : lb;
+        int c = 0; int32_t j = 0;
+        for (; j + 8 <= k; j += 8) {      // eight bytes at a time, big-endian so that the integer order is the byte order
+          u64 x, y; __builtin_memcpy(&x, pa + j, 8); __builtin_memcpy(&y, pb + j, 8);
+          if (x != y) { x = __builtin_bswap64(x); y = __builtin_bswap64(y); c = x < y ? -1 : 1; break; }
+        }
+        if (c == 0) for (; j < k; ++j) if (pa[j] != pb[j]) { c = pa[j] < pb[j] ? -1 : 1; break; }
+        if (c == 0) c = la < lb ? -1 : (la > lb ? 1 : 0);
+        m = op == 0 ? c == 0 : op == 1 ? c != 0 : op == 2 ? c < 0 : op == 3 ? c <= 0 : op == 4 ? c > 0 : c >= 0;
+      }
+    }
+    const u64 mb = __ballot(valid && m), vb = __ballot(valid);
+    if ((threadIdx.x & 63) == 0) { bits_out[w] = mb; if (valid_out) valid_out[w] = vb; }
+  }
+}
+void launch_utf8_compare(hipStream_t s, const uint8_t* adata, const int32_t* aoffs, const uint8_t* avalid, const uint32_t* aidx, const uint8_t* bdata, const int32_t* boffs,
+                         const uint8_t* bvalid, const uint32_t* bidx, int32_t blen, i64 n, int op, u64* bits_out, u64* valid_out) {
+  if (n > 0) hipLaunchKernelGGL(k_utf8_compare, dim3(lin_grid(n)), dim3(BLOCK), 0, s, Utf8Side{adata, aoffs, avalid, aidx}, Utf8Side{bdata, boffs, bvalid, bidx}, blen, n, op, bits_out, valid_out);
+}
 // ------------------------------------------------------------------ Utf8 values as exact dictionary codes (f-4: keys longer than 15 bytes)
 // Strings of any length become group / join keys through a device dictionary: an open-addressing table of 8-byte entries
 // (hash tag << 32 | representative row of the dictionary column).  One 64-bit CAS both claims an entry and publishes its row, the

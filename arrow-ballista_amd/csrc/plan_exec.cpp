@@ -369,6 +369,72 @@ PTable lower_like(Exec& x, const PTable& t, std::vector<Json>& exprs) {
   return out;
 }
 
+// Comparisons of Utf8 operands beyond what a register holds (15 bytes): `<` `<=` `>` `>=` between a column and a literal or another
+// column, `=` / `!=` between two columns.  The register program refuses them at run time (a value longer than 15 bytes reached the
+// comparison); the executor then runs the expression again with every such comparison lowered to a Boolean helper column computed over
+// the Arrow-layout bytes (gpuq_utf8_compare) -- the same move LIKE makes.  Operands must be bare columns of `t` / Utf8 literals.
+bool strcmp_operand(const PTable& t, const Json& e, int& col, std::string& lit) {
+  col = -1;
+  if (!(e.is_obj() && e.o.size() == 1)) return false;
+  if (e.o[0].first == "column" && e.o[0].second.is_obj() && e.o[0].second.find("name")) {
+    const std::string& n = e.o[0].second.at("name").str();
+    for (size_t i = 0; i < t.cols.size(); ++i) if (t.cols[i].name == n) { if (t.cols[i].c.type == T_UTF8 && t.cols[i].c.repr == GPUQ_REPR_ARROW) { col = (int)i; return true; } return false; }
+    return false;
+  }
+  if (e.o[0].first == "literal") {
+    const Json& v = e.o[0].second;
+    const Json* ty = v.find("type"); const Json* val = v.find("value");
+    if (ty && ty->is_str() && (ty->s == "Utf8" || ty->s == "LargeUtf8") && val && !val->is_null()) { lit = val->str(); return true; }
+  }
+  return false;
+}
+PTable lower_strcmp(Exec& x, const PTable& t, std::vector<Json>& exprs) {
+  struct Found { int a, b; std::string lit; int op; };
+  std::vector<Found> found;
+  std::function<Json(const Json&)> walk = [&](const Json& e) -> Json {
+    if (e.is_obj()) {
+      if (e.o.size() == 1 && e.o[0].first == "binary_expr") {
+        const Json& v = e.o[0].second;
+        static const std::map<std::string, int> ops = {{"=", 0}, {"Eq", 0}, {"==", 0}, {"!=", 1}, {"NotEq", 1}, {"<>", 1}, {"<", 2}, {"Lt", 2}, {"<=", 3}, {"LtEq", 3}, {">", 4}, {"Gt", 4}, {">=", 5}, {"GtEq", 5}};
+        auto it = ops.find(v.get_str("op", ""));
+        int ca = -1, cb = -1; std::string la, lb;
+        if (it != ops.end() && strcmp_operand(t, v.at("l"), ca, la) && strcmp_operand(t, v.at("r"), cb, lb) && (ca >= 0 || cb >= 0)) {
+          static const int mirror[6] = {0, 1, 4, 5, 2, 3};      // literal OP column  ==  column mirror(OP) literal
+          Found f;
+          if (ca >= 0) { f.a = ca; f.b = cb; f.lit = lb; f.op = it->second; } else { f.a = cb; f.b = -1; f.lit = la; f.op = mirror[it->second]; }
+          found.push_back(f);
+          return jobj({{"column", jobj({{"name", jstr("__cmp_" + std::to_string(found.size() - 1))}})}});
+        }
+      }
+      Json r = jobj();
+      for (auto& kv : e.o) r.o.emplace_back(kv.first, walk(kv.second));
+      return r;
+    }
+    if (e.is_arr()) { Json r = jarr(); for (auto& v : e.a) r.a.push_back(walk(v)); return r; }
+    return e;
+  };
+  for (auto& e : exprs) e = walk(e);
+  if (found.empty()) return t;
+  PTable out = t;
+  hipStream_t s = (hipStream_t)x.stream;
+  const size_t nb = (size_t)((t.n + 63) / 64) * 8 + 8;
+  for (size_t k = 0; k < found.size(); ++k) {
+    const Found& f = found[k];
+    const PCol& a = t.cols[(size_t)f.a]; const int sa = t.sides[(size_t)f.a];
+    const PCol* b = f.b >= 0 ? &t.cols[(size_t)f.b] : nullptr; const int sb = f.b >= 0 ? t.sides[(size_t)f.b] : 0;
+    const bool nullable = a.nullable || (sa > 0 && !t.dense) || (b && (b->nullable || (sb > 0 && !t.dense)));
+    BufP bits = dev_alloc(nb), valid = nullable ? dev_alloc(nb) : nullptr;
+    HIPCHECK(hipMemsetAsync(bits->p, 0, nb, s)); if (valid) HIPCHECK(hipMemsetAsync(valid->p, 0, nb, s));
+    check(x, gpuq_utf8_compare(x.ctx, x.stream, &a.c, sa > 0 ? t.via[(size_t)sa - 1] : nullptr, b ? &b->c : nullptr, sb > 0 ? t.via[(size_t)sb - 1] : nullptr,
+                               b ? nullptr : f.lit.data(), b ? 0 : (int64_t)f.lit.size(), t.n, f.op, (uint8_t*)bits->p, valid ? (uint8_t*)valid->p : nullptr));
+    PCol c; c.name = "__cmp_" + std::to_string(k); c.type = jstr("Boolean"); c.nullable = nullable;
+    c.c.type = T_BOOL; c.c.repr = GPUQ_REPR_ARROW; c.c.data = bits->p; c.c.validity = valid ? (const uint8_t*)valid->p : nullptr; c.c.length = t.n;
+    out.cols.push_back(c); out.sides.push_back(0);
+    out.keep.push_back(bits); if (valid) out.keep.push_back(valid);
+  }
+  return out;
+}
+
 // ---------------------------------------------------------------- Utf8 keys longer than 15 bytes
 // The expression programs carry a string as one 16-byte integer (<= 15 bytes).  When an aggregate or a join reports that a longer
 // value reached a key, the executor runs the operator again over exact dictionary codes (gpuq_utf8_intern): a group / join key
@@ -401,11 +467,18 @@ void strip_code_columns(PTable& t) {
     if (t.cols[i].name.rfind("__code_", 0) == 0) { t.cols.erase(t.cols.begin() + (long)i); t.sides.erase(t.sides.begin() + (long)i); t.record_cap = 0; }
 }
 
+static PTable project_impl(Exec& x, const PTable& t_in, const std::vector<Json>& exprs_in, const std::vector<std::string>& names, const void* site, int tag, bool long_cmp);
 PTable project(Exec& x, const PTable& t_in, const std::vector<Json>& exprs_in, const std::vector<std::string>& names, const void* site, int tag) {
+  try { return project_impl(x, t_in, exprs_in, names, site, tag, false); }
+  catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+  return project_impl(x, t_in, exprs_in, names, site, tag + 64, true);      // string comparisons beyond 15 bytes: lowered to helper columns (lower_strcmp)
+}
+static PTable project_impl(Exec& x, const PTable& t_in, const std::vector<Json>& exprs_in, const std::vector<std::string>& names, const void* site, int tag, const bool long_cmp) {
   std::vector<Json> exprs = exprs_in;
   bool any_like = false; for (auto& e : exprs) any_like = any_like || has_like(e);
-  PTable t_res = t_in; if (any_like) resolve(x, t_res);      // the LIKE kernel takes an exact row count
+  PTable t_res = t_in; if (any_like || long_cmp) resolve(x, t_res);      // the LIKE / compare kernels take an exact row count
   PTable t = lower_like(x, t_res, exprs);
+  if (long_cmp) t = lower_strcmp(x, t, exprs);
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     Json ex = jarr();
     const auto nm = names_of(t);
@@ -538,10 +611,17 @@ PTable materialize(Exec& x, const PTable& t_in, bool force) {
 }
 
 // the passing driving positions of `source` (in order) and their number
+static int64_t filter_sel_impl(Exec& x, const PTable& source_in, const Json& predicate_in, const void* site, int tag, BufP& sel_out, bool long_cmp);
 int64_t filter_sel(Exec& x, const PTable& source_in, const Json& predicate_in, const void* site, int tag, BufP& sel_out) {
+  try { return filter_sel_impl(x, source_in, predicate_in, site, tag, sel_out, false); }
+  catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+  return filter_sel_impl(x, source_in, predicate_in, site, tag + 64, sel_out, true);
+}
+static int64_t filter_sel_impl(Exec& x, const PTable& source_in, const Json& predicate_in, const void* site, int tag, BufP& sel_out, const bool long_cmp) {
   std::vector<Json> pe{predicate_in};
   PTable source = source_in; resolve(x, source);      // (the callers of this form need the exact count back)
-  const PTable t = lower_like(x, source, pe);
+  PTable t = lower_like(x, source, pe);
+  if (long_cmp) t = lower_strcmp(x, t, pe);
   const Json& predicate = pe[0];
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     return jobj({{"op", jstr("filter")}, {"input", jobj({{"fields", table_fields(t)}})}, {"predicate", rebind(predicate, names_of(t))}});
@@ -555,11 +635,18 @@ int64_t filter_sel(Exec& x, const PTable& source_in, const Json& predicate_in, c
   return k;
 }
 
+static PTable filter_table_impl(Exec& x, const PTable& source_in, const Json& predicate_in, const void* site, int tag, bool long_cmp);
 PTable filter_table(Exec& x, const PTable& source_in, const Json& predicate_in, const void* site, int tag) {
+  try { return filter_table_impl(x, source_in, predicate_in, site, tag, false); }
+  catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
+  return filter_table_impl(x, source_in, predicate_in, site, tag + 64, true);      // string comparisons beyond 15 bytes: lowered to helper columns (lower_strcmp)
+}
+static PTable filter_table_impl(Exec& x, const PTable& source_in, const Json& predicate_in, const void* site, int tag, const bool long_cmp) {
   std::vector<Json> pe{predicate_in};
   PTable source = source_in;
-  if (has_like(predicate_in)) resolve(x, source);      // the LIKE kernel takes an exact row count
+  if (has_like(predicate_in) || long_cmp) resolve(x, source);      // the LIKE / compare kernels take an exact row count
   PTable t = lower_like(x, source, pe);          // helper columns are visible to the predicate only: the view is over `source`
+  if (long_cmp) t = lower_strcmp(x, t, pe);
   const Json& predicate = pe[0];
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     return jobj({{"op", jstr("filter")}, {"input", jobj({{"fields", table_fields(t)}})}, {"predicate", rebind(predicate, names_of(t))}});
@@ -903,7 +990,12 @@ struct AggregateExec : PNode {
       catch (const Unsupported& e) { if (!is_long_string_failure(e)) throw; }
     }
     resolve(x, t);
-    return timed(x, t0, run(x, t, f, true));      // a group key holds strings of more than 15 bytes: again, over dictionary codes
+    try { return timed(x, t0, run(x, t, f, true)); }      // a group key holds strings of more than 15 bytes: again, over dictionary codes
+    catch (const Unsupported& e) { if (!is_long_string_failure(e) || !f.has_pred) throw; }
+    // it was the fused FILTER that compared long strings: apply it on its own (filter_table lowers such comparisons), then aggregate
+    Fused f2 = f; f2.has_pred = false;
+    PTable t2 = filter_table(x, t, f.pred, this, 9);
+    return timed(x, t0, run(x, t2, f2, true));
   }
   PTable run(Exec& x, PTable t, const Fused& f, const bool long_keys) {
     const ColMap* cm0 = f.has_map ? &f.map : nullptr;
@@ -1110,7 +1202,16 @@ struct HashJoinExec : PNode {
     // a join key holds strings of more than 15 bytes: again, with those key columns replaced by exact dictionary codes (the
     // build side fills the dictionary, the probe side is looked up in it; a probe string that is not in it gets no code = no match)
     resolve(x, L.t); resolve(x, R.t);
-    PTable out = join_sides(x, L, R, true);
+    PTable out;
+    try { out = join_sides(x, L, R, true); }
+    catch (const Unsupported& e) {
+      if (!is_long_string_failure(e) || !(L.has_pred || R.has_pred)) throw;
+      // it was a filter fused into a side that compared long strings: apply the filters on their own (filter_table lowers such comparisons)
+      if (L.has_pred) { L.t = filter_table(x, L.t, L.pred, this, 41); L.has_pred = false; }
+      if (R.has_pred) { R.t = filter_table(x, R.t, R.pred, this, 42); R.has_pred = false; }
+      strip_code_columns(L.t); strip_code_columns(R.t);
+      out = join_sides(x, L, R, true);
+    }
     strip_code_columns(out);
     return timed(x, t0, out);
   }

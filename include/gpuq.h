@@ -145,6 +145,18 @@ struct ArrowArray {
 };
 typedef struct gpuq_table gpuq_table;
 
+/* Memory budget.  The reference runs operators under DataFusion's MemoryPool (RuntimeConfig::with_memory_limit; a SortExec or a join
+   build that cannot reserve fails with ResourcesExhausted).  Every device byte this library holds -- operator workspaces, join tables,
+   plan intermediates, imported / decoded tables -- is counted process-wide; with a limit set (bytes > 0; 0 = none; also the environment
+   variable GPUQ_MEMORY_LIMIT at start-up) the allocation that would cross it fails with GPUQ_ERR_CAPACITY ("Resources exhausted: ...") and
+   the call that needed it returns that status: the task fails, the process and its other tasks go on.  The caller's own input columns
+   are not counted.  Nothing is spilled: the executors hold whole partitions, a partition that does not fit the budget has to be split
+   by the planner (more partitions), as on the reference when spilling is disabled.
+   gpuq_memory_stats: bytes in use now, the high-water mark (reset_peak != 0 sets it back to the current value after reading), bytes cached
+   in the library's free list, and the limit. */
+int gpuq_memory_limit(int64_t bytes);
+int gpuq_memory_stats(int64_t* in_use_out, int64_t* peak_out, int64_t* cached_out, int64_t* limit_out, int reset_peak);
+
 int gpuq_buffer_alloc(gpuq_ctx* ctx, size_t bytes, void** dev_out);
 int gpuq_buffer_free(gpuq_ctx* ctx, void* dev);
 int gpuq_copy_h2d(gpuq_ctx* ctx, void* stream, void* dst_dev, const void* src_host, size_t bytes); /* returns after the copy is enqueued and the host buffer is reusable */
@@ -412,6 +424,14 @@ int gpuq_utf8_code_rows(gpuq_ctx* ctx, void* stream, const gpuq_column* codes, i
    expression can read like any other. */
 int gpuq_like_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const uint32_t* idx, int64_t n, const char* pattern, int negated, int case_insensitive,
                    uint8_t* bits_out, uint8_t* validity_out);
+
+/* A comparison of two Utf8 operands of ANY length -- the register programs hold 15 bytes: `<` between longer values, or `=` between two
+   columns, is refused there and the executors lower the comparison to a Boolean column computed here, over the Arrow-layout bytes
+   (arrow-ord's order: bytewise, a proper prefix first).  op: 0 = , 1 != , 2 < , 3 <= , 4 > , 5 >= .  a (through idx_a) against b (through
+   idx_b) or, with b == NULL, against the `literal_len` bytes at `literal` (host memory).  A NULL on either side gives NULL.
+   bits_out / validity_out as gpuq_like_utf8.  Asynchronous. */
+int gpuq_utf8_compare(gpuq_ctx* ctx, void* stream, const gpuq_column* a, const uint32_t* idx_a, const gpuq_column* b, const uint32_t* idx_b, const char* literal,
+                      int64_t literal_len, int64_t n, int op, uint8_t* bits_out, uint8_t* validity_out);
 
 /* dst[i] = src[i] + delta for n Utf8 offsets: joining the offset arrays of partitions that are concatenated (fan-in). */
 int gpuq_offsets_rebase(gpuq_ctx* ctx, void* stream, const int32_t* src, int64_t n, int32_t delta, int32_t* dst);

@@ -86,7 +86,9 @@ def test_descriptor_errors_are_loud():
     for bad, msg in [
         ({"op": "filter", "input": {"fields": FIELDS}, "predicate": col("q", FIELDS)}, "predicate must be boolean"),
         ({"op": "project", "input": {"fields": FIELDS}, "exprs": [{"expr": binary(col("s", FIELDS), Op.Plus, lit(1)), "name": "x"}]}, "unsupported operands"),
-        ({"op": "project", "input": {"fields": FIELDS}, "exprs": [{"expr": binary(col("s", FIELDS), Op.Eq, lit("a string longer than fifteen bytes")), "name": "x"}]}, "15 bytes"),
+        # (a long literal is taken in COMPARISONS since round 3 -- compared through its 15-byte prefix, exact for every value a register holds --
+        # and still refused as a value)
+        ({"op": "project", "input": {"fields": FIELDS}, "exprs": [{"expr": lit("a string longer than fifteen bytes"), "name": "x"}]}, "15 bytes"),
         ({"op": "frobnicate", "input": {"fields": FIELDS}}, "unknown op"),
         ({"op": "sort", "input": {"fields": FIELDS}, "expr": []}, "sort needs"),
         ({"op": "aggregate", "mode": "Single", "input": {"fields": FIELDS}, "group_expr": [], "aggr_expr": [{"fn": "MEDIAN", "expr": col("q", FIELDS), "name": "m"}]}, "MEDIAN"),

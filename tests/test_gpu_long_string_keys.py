@@ -10,6 +10,7 @@ import pytest
 import arrow_ballista_amd as g
 from arrow_ballista_amd.expr import Operator as Op
 from arrow_ballista_amd.expr import binary, col, lit
+from test_gpu_native_plan import native_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -190,3 +191,53 @@ def test_equality_with_a_long_literal(tc, native):
         assert run(g.FilterExec(both, src)) == [x for x in rows if x[0] == literal or x[1] < 5]
     got = run(g.ProjectionExec([(binary(col("s", s), Op.Eq, lit("DELIVER IN PERSON")), "is_dip"), (col("rid", s), "rid")], src))
     assert got == [((None if x[0] is None else x[0] == "DELIVER IN PERSON"), x[1]) for x in rows]
+
+
+# ------------------------------------------------------------------ comparisons of long strings (ordering, column against column)
+def _cmp_table(n=6000, seed=5):
+    r = np.random.default_rng(seed)
+    stems = ["Customer#000000", "Customer#000001", "a", "", "exactly15bytes!", "exactly15bytes!!", "zebra crossing on a long and winding road", "δοκιμή utf-8 ✓ multibyte"]
+    a = [stems[i] + ("%03d" % j if i < 2 else "") for i, j in zip(r.integers(0, len(stems), n), r.integers(0, 40, n))]
+    b = [stems[i] + ("%03d" % j if i < 2 else "") for i, j in zip(r.integers(0, len(stems), n), r.integers(0, 40, n))]
+    return pa.table({"a": pa.array(a, pa.string(), mask=r.random(n) < 0.1), "b": pa.array(b, pa.string(), mask=r.random(n) < 0.1),
+                     "k": pa.array(r.integers(0, 7, n), pa.int64()), "id": pa.array(np.arange(n), pa.int64())})
+
+
+def _py_cmp(op, x, y):
+    if x is None or y is None:
+        return None
+    x, y = x.encode(), y.encode()
+    return {"=": x == y, "!=": x != y, "<": x < y, "<=": x <= y, ">": x > y, ">=": x >= y}[op]
+
+
+@pytest.mark.parametrize("op", ["=", "!=", "<", "<=", ">", ">="])
+def test_long_string_comparisons_in_filter_and_projection(tc, op):
+    """`a OP b` between two Utf8 columns and `a OP literal` (15, 16 and 41 bytes; also literal OP a) with values beyond 15 bytes: the
+    register program refuses, the native executor lowers the comparison to gpuq_utf8_compare over the bytes (bytewise order, NULL in
+    -> NULL out), in a FilterExec, in a computed projection, and twice more deferred."""
+    from arrow_ballista_amd.expr import Operator as Op, binary
+    t = _cmp_table()
+    src = g.MemoryExec([t]); s = src.schema()
+    lits = ["exactly15bytes!", "exactly15bytes!!", "Customer#000000020", "zebra crossing on a long and winding road"]
+    exprs = [(binary(col("a", s), op, col("b", s)), "ab")] + [(binary(col("a", s), op, lit(v)), "l%d" % i) for i, v in enumerate(lits)] + [(binary(lit(lits[2]), op, col("b", s)), "rev")]
+    got, _ = native_rows(tc, g.ProjectionExec(exprs + [(col("id", s), "id")], src))
+    A, B = t["a"].to_pylist(), t["b"].to_pylist()
+    exp = [tuple([_py_cmp(op, x, y)] + [_py_cmp(op, x, v) for v in lits] + [_py_cmp(op, lits[2], y), i]) for i, (x, y) in enumerate(zip(A, B))]
+    assert got == exp
+    got, _ = native_rows(tc, g.FilterExec(binary(col("a", s), op, col("b", s)), src))
+    assert [r_[3] for r_ in got] == [i for i, (x, y) in enumerate(zip(A, B)) if _py_cmp(op, x, y)]
+
+
+def test_long_string_comparison_in_a_filter_fused_into_an_aggregate_and_a_join(tc):
+    from arrow_ballista_amd.expr import Operator as Op, binary
+    t = _cmp_table()
+    src = g.MemoryExec([t]); s = src.schema()
+    f = g.FilterExec(binary(col("a", s), Op.Lt, lit("Customer#000001017")), src)
+    got, _ = native_rows(tc, g.AggregateExec("Single", [(col("k", s), "k")], [{"fn": "COUNT", "expr": lit(1), "name": "c"}], f))
+    A = t["a"].to_pylist(); K = t["k"].to_pylist()
+    exp = collections.Counter(k for x, k in zip(A, K) if _py_cmp("<", x, "Customer#000001017"))
+    assert sorted(got) == sorted(exp.items())
+    small = pa.table({"jk": pa.array(np.arange(7), pa.int64())})
+    j = g.HashJoinExec(g.MemoryExec([small]), f, [(col("jk", g.MemoryExec([small]).schema()), col("k", s))], None, "Inner", "CollectLeft", False)
+    got, _ = native_rows(tc, j)
+    assert sorted(r_[4] for r_ in got) == [i for i, x in enumerate(A) if _py_cmp("<", x, "Customer#000001017")]
