@@ -51,6 +51,13 @@ impl GpuExecutionEngine {
         }
         Ok(Self { ctx: Arc::new(Ctx(ctx)), fallback: DefaultExecutionEngine {} })
     }
+
+    /// The device-memory budget of this executor's tasks: what `RuntimeConfig::with_memory_limit` is to the stock engine.  A task that
+    /// would cross it fails with ResourcesExhausted (GPUQ_ERR_CAPACITY); the executor goes on.  0 = no limit.
+    pub fn with_memory_limit(self, bytes: usize) -> Self {
+        unsafe { gpuq_memory_limit(bytes as i64) };
+        self
+    }
 }
 
 impl ExecutionEngine for GpuExecutionEngine {

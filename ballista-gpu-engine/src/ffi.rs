@@ -57,6 +57,8 @@ extern "C" {
     pub fn gpuq_ctx_create(device_ordinal: c_int, json_opts: *const c_char) -> *mut gpuq_ctx;
     pub fn gpuq_ctx_free(ctx: *mut gpuq_ctx);
     pub fn gpuq_jit_quiesce();
+    pub fn gpuq_memory_limit(bytes: i64) -> c_int;
+    pub fn gpuq_memory_stats(in_use: *mut i64, peak: *mut i64, cached: *mut i64, limit: *mut i64, reset_peak: c_int) -> c_int;
     pub fn gpuq_last_error(ctx: *mut gpuq_ctx) -> *const c_char;
 
     pub fn gpuq_plan_create(ctx: *mut gpuq_ctx, plan_json: *const c_char, out: *mut *mut gpuq_plan) -> c_int;
