@@ -212,6 +212,7 @@ def main_q3():
                                    + [bench_extras.join_probe_micro(tc, g, b, 28, 1.0, zipf=1.05) for b in (20, 24, 27)]}
             torch.cuda.empty_cache()
             extra["sf100_q1"] = bench_extras.q1_pipeline(tc, T, g, 100)
+            extra["sf100_q6"] = bench_extras.q6_pipeline(tc, T, g, 100)
             tp = bench_extras.tpch_pipelines(tc, T, g, 100)
             extra["sf100_q3"], extra["sf100_q5"] = tp["q3"], tp["q5"]
             torch.cuda.empty_cache()
