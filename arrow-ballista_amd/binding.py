@@ -35,23 +35,6 @@ class gpuq_input(C.Structure):
                 ("via", C.c_void_p * 3), ("n_rows_dev", C.c_void_p)]
 
 
-class gpuq_lineitem_cols(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("l_orderkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount", "l_tax",
-                                          "l_shipdate", "l_returnflag", "l_returnflag_off", "l_linestatus", "l_linestatus_off")]
-
-
-class gpuq_orders_cols(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("o_orderkey", "o_custkey", "o_orderdate", "o_shippriority")]
-
-
-class gpuq_customer_cols(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("c_custkey", "c_nationkey", "c_mktsegment", "c_mktsegment_off")]
-
-
-class gpuq_supplier_cols(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("s_suppkey", "s_nationkey")]
-
-
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
@@ -200,10 +183,6 @@ def lib():
         "gpuq_ipc_batch_column": (i32, [vp, i32, C.POINTER(gpuq_column)]),
         "gpuq_ipc_batch_free": (None, [vp]),
         "gpuq_ipc_last_error": (C.c_char_p, []),
-        "gpuq_gen_lineitem": (i32, [vp, vp, u64, u64, i64, i64, i64, C.POINTER(gpuq_lineitem_cols)]),
-        "gpuq_gen_orders": (i32, [vp, vp, u64, i64, i64, i64, C.POINTER(gpuq_orders_cols)]),
-        "gpuq_gen_customer": (i32, [vp, vp, u64, i64, i64, C.POINTER(gpuq_customer_cols)]),
-        "gpuq_gen_supplier": (i32, [vp, vp, u64, i64, i64, C.POINTER(gpuq_supplier_cols)]),
         "gpuq_timer_create": (i32, [vp, C.POINTER(vp)]),
         "gpuq_timer_start": (i32, [vp, vp]),
         "gpuq_timer_stop": (i32, [vp, vp]),

@@ -2087,44 +2087,6 @@ int gpuq_unpack_utf8(gpuq_ctx* ctx, void* stream, const void* packed, int64_t n,
   });
 }
 
-// ---------------------------------------------------------------- generators
-int gpuq_gen_lineitem(gpuq_ctx* ctx, void* stream, uint64_t seed, uint64_t seed_orders, int64_t row0, int64_t n, int64_t n_supp, const gpuq_lineitem_cols* c) {
-  return guarded(ctx, [&]() {
-    check_ctx(ctx);
-    if (!c || n < 0 || n_supp < 1) throw std::runtime_error("bad arguments");
-    LineitemCols d{c->l_orderkey ? (i64*)c->l_orderkey : nullptr, (i64*)c->l_suppkey, (u64*)c->l_quantity, (u64*)c->l_extendedprice, (u64*)c->l_discount,
-                   (u64*)c->l_tax, c->l_shipdate, c->l_returnflag, c->l_returnflag_off, c->l_linestatus, c->l_linestatus_off};
-    launch_gen_lineitem(use_stream(stream), seed, seed_orders, row0, n, n_supp, d);
-    HIPCHECK(hipGetLastError());
-  });
-}
-int gpuq_gen_orders(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, int64_t n_cust, const gpuq_orders_cols* c) {
-  return guarded(ctx, [&]() {
-    check_ctx(ctx);
-    if (!c || n < 0 || n_cust < 3) throw std::runtime_error("bad arguments");
-    OrdersCols d{(i64*)c->o_orderkey, (i64*)c->o_custkey, c->o_orderdate, c->o_shippriority};
-    launch_gen_orders(use_stream(stream), seed, row0, n, n_cust, d);
-    HIPCHECK(hipGetLastError());
-  });
-}
-int gpuq_gen_customer(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, const gpuq_customer_cols* c) {
-  return guarded(ctx, [&]() {
-    check_ctx(ctx);
-    if (!c || n < 0 || row0 % 5 != 0) throw std::runtime_error("bad arguments (row0 must be a multiple of 5)");
-    CustomerCols d{(i64*)c->c_custkey, (i64*)c->c_nationkey, c->c_mktsegment, c->c_mktsegment_off};
-    launch_gen_customer(use_stream(stream), seed, row0, n, d);
-    HIPCHECK(hipGetLastError());
-  });
-}
-int gpuq_gen_supplier(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, const gpuq_supplier_cols* c) {
-  return guarded(ctx, [&]() {
-    check_ctx(ctx);
-    if (!c || n < 0) throw std::runtime_error("bad arguments");
-    SupplierCols d{(i64*)c->s_suppkey, (i64*)c->s_nationkey};
-    launch_gen_supplier(use_stream(stream), seed, row0, n, d);
-    HIPCHECK(hipGetLastError());
-  });
-}
 }  // extern "C"
 
 // ---------------------------------------------------------------- device memory + Arrow C Data Interface

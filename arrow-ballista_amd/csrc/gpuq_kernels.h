@@ -102,16 +102,7 @@ struct AggSoA {
 };
 
 // generator (kernels_gen.hip)
-struct LineitemCols {
-  i64* l_orderkey; i64* l_suppkey;
-  u64* l_quantity; u64* l_extendedprice; u64* l_discount; u64* l_tax;   // Decimal128 as (lo,hi)
-  int32_t* l_shipdate;
-  uint8_t* l_returnflag; int32_t* l_returnflag_off;
-  uint8_t* l_linestatus; int32_t* l_linestatus_off;
-};
-struct OrdersCols { i64* o_orderkey; i64* o_custkey; int32_t* o_orderdate; int32_t* o_shippriority; };
-struct CustomerCols { i64* c_custkey; i64* c_nationkey; uint8_t* c_mktsegment; int32_t* c_mktsegment_off; };
-struct SupplierCols { i64* s_suppkey; i64* s_nationkey; };
+
 
 // deferred execution: up to 64 device words gathered into one contiguous block (gpuq_ops_settle)
 struct GatherWords { int32_t n; int32_t pad; const u64* src[64]; };
@@ -232,10 +223,6 @@ void launch_utf8_max_len(hipStream_t s, const int32_t* offsets, const uint8_t* v
 void launch_utf8_intern(hipStream_t s, const uint8_t* ddata, const int32_t* doffs, const uint8_t* data, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n,
                         u64* table, u64 mask, int insert, i64* codes, u64* valid_out, uint32_t* flags);
 void launch_popcount_bits(hipStream_t s, const uint8_t* bits, int64_t n_bits, unsigned long long* out);
-void launch_gen_lineitem(hipStream_t s, u64 seed, u64 seed_orders, i64 row0, i64 n, i64 n_supp, const LineitemCols& c);
-void launch_gen_orders(hipStream_t s, u64 seed, i64 row0, i64 n, i64 n_cust, const OrdersCols& c);
-void launch_gen_customer(hipStream_t s, u64 seed, i64 row0, i64 n, const CustomerCols& c);
-void launch_gen_supplier(hipStream_t s, u64 seed, i64 row0, i64 n, const SupplierCols& c);
 
 // ----- scan-side decode (kernels_scanfmt.hip): delimited text and Parquet pages
 enum CsvKind : int32_t { CSV_SKIP = 0, CSV_I32 = 1, CSV_I64 = 2, CSV_DATE32 = 3, CSV_DEC128 = 4, CSV_F64 = 5, CSV_BOOL = 6, CSV_UTF8 = 7 };

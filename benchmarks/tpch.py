@@ -25,6 +25,57 @@ LINEITEM_ROWS = {1: 6_001_215, 10: 59_986_052, 100: 600_037_902}
 
 
 # ------------------------------------------------------------------ device generator
+# benchmarks/libgpuq_tpchgen.so (benchmarks/tpchgen/: built by arrow-ballista_amd/build.py next to libgpuq.so, but a library of its own:
+# the product carries no test scaffolding).  Runs on the current device (torch's, = the TaskContext's) on the TaskContext's stream.
+class gpuq_lineitem_cols(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("l_orderkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount", "l_tax",
+                                          "l_shipdate", "l_returnflag", "l_returnflag_off", "l_linestatus", "l_linestatus_off")]
+
+
+class gpuq_orders_cols(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("o_orderkey", "o_custkey", "o_orderdate", "o_shippriority")]
+
+
+class gpuq_customer_cols(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("c_custkey", "c_nationkey", "c_mktsegment", "c_mktsegment_off")]
+
+
+class gpuq_supplier_cols(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("s_suppkey", "s_nationkey")]
+
+
+_GEN = None
+
+
+def _gen():
+    global _GEN
+    if _GEN is None:
+        p = os.path.join(ROOT, "benchmarks", "libgpuq_tpchgen.so")
+        if not os.path.exists(p):
+            raise RuntimeError("benchmarks/libgpuq_tpchgen.so is not built: run `python arrow-ballista_amd/build.py`")
+        import arrow_ballista_amd as g
+        g.lib()                          # (one HIP runtime per process: torch's, loaded by the binding first)
+        L = C.CDLL(p)
+        vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+        L.gpuq_tpchgen_lineitem.argtypes = [vp, u64, u64, i64, i64, i64, C.POINTER(gpuq_lineitem_cols)]
+        L.gpuq_tpchgen_orders.argtypes = [vp, u64, i64, i64, i64, C.POINTER(gpuq_orders_cols)]
+        L.gpuq_tpchgen_customer.argtypes = [vp, u64, i64, i64, C.POINTER(gpuq_customer_cols)]
+        L.gpuq_tpchgen_supplier.argtypes = [vp, u64, i64, i64, C.POINTER(gpuq_supplier_cols)]
+        L.gpuq_tpchgen_last_error.restype = C.c_char_p
+        for f in (L.gpuq_tpchgen_lineitem, L.gpuq_tpchgen_orders, L.gpuq_tpchgen_customer, L.gpuq_tpchgen_supplier):
+            f.restype = i32
+        _GEN = L
+    return _GEN
+
+
+def _gen_check(tc, rc):
+    if rc != 0:
+        raise RuntimeError("tpchgen: " + (_gen().gpuq_tpchgen_last_error() or b"").decode())
+
+
+def _on_device(tc):
+    import torch
+    return torch.cuda.device(tc.device)
 def gen_lineitem_device(tc, n, seed=SEED_LINEITEM, seed_orders=SEED_ORDERS, row0=0, n_supp=10_000,
                         columns=("l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate")):
     """Device-resident lineitem columns (Arrow physical layout) produced by the HIP generator."""
@@ -32,7 +83,7 @@ def gen_lineitem_device(tc, n, seed=SEED_LINEITEM, seed_orders=SEED_ORDERS, row0
     import arrow_ballista_amd as g
     from arrow_ballista_amd import binding as B
     dev = tc.device
-    bufs, cs = {}, B.gpuq_lineitem_cols()
+    bufs, cs = {}, gpuq_lineitem_cols()
     cols = []
 
     def alloc(nbytes):
@@ -50,7 +101,8 @@ def gen_lineitem_device(tc, n, seed=SEED_LINEITEM, seed_orders=SEED_ORDERS, row0
             cols.append(g.DeviceColumn(name, "Utf8", t, n, offsets=o, nullable=False))
         else:
             raise KeyError(name)
-    tc.ctx.check(tc.ctx.L.gpuq_gen_lineitem(tc.ctx.h, tc.stream_ptr(), seed, seed_orders, row0, n, n_supp, C.byref(cs)))
+    with _on_device(tc):
+        _gen_check(tc, _gen().gpuq_tpchgen_lineitem(tc.stream_ptr(), seed, seed_orders, row0, n, n_supp, C.byref(cs)))
     tc.sync()
     return g.DeviceTable(cols, n)
 
@@ -203,8 +255,9 @@ def gen_orders_device(tc, n, n_cust, seed=SEED_ORDERS, row0=0):
     import arrow_ballista_amd as g
     from arrow_ballista_amd import binding as B
     cols, p = _dev_cols(tc, [("o_orderkey", "Int64", 8), ("o_custkey", "Int64", 8), ("o_orderdate", "Date32", 4), ("o_shippriority", "Int32", 4)], n)
-    cs = B.gpuq_orders_cols(**p)
-    tc.ctx.check(tc.ctx.L.gpuq_gen_orders(tc.ctx.h, tc.stream_ptr(), seed, row0, n, n_cust, C.byref(cs)))
+    cs = gpuq_orders_cols(**p)
+    with _on_device(tc):
+        _gen_check(tc, _gen().gpuq_tpchgen_orders(tc.stream_ptr(), seed, row0, n, n_cust, C.byref(cs)))
     tc.sync()
     return g.DeviceTable(cols, n)
 
@@ -214,8 +267,9 @@ def gen_customer_device(tc, n, seed=SEED_CUSTOMER, row0=0):
     from arrow_ballista_amd import binding as B
     assert n % 5 == 0 and row0 % 5 == 0
     cols, p = _dev_cols(tc, [("c_custkey", "Int64", 8), ("c_nationkey", "Int64", 8), ("c_mktsegment", "Utf8", ("utf8", n * 9))], n)
-    cs = B.gpuq_customer_cols(**p)
-    tc.ctx.check(tc.ctx.L.gpuq_gen_customer(tc.ctx.h, tc.stream_ptr(), seed, row0, n, C.byref(cs)))
+    cs = gpuq_customer_cols(**p)
+    with _on_device(tc):
+        _gen_check(tc, _gen().gpuq_tpchgen_customer(tc.stream_ptr(), seed, row0, n, C.byref(cs)))
     tc.sync()
     return g.DeviceTable(cols, n)
 
@@ -224,8 +278,9 @@ def gen_supplier_device(tc, n, seed=SEED_SUPPLIER, row0=0):
     import arrow_ballista_amd as g
     from arrow_ballista_amd import binding as B
     cols, p = _dev_cols(tc, [("s_suppkey", "Int64", 8), ("s_nationkey", "Int64", 8)], n)
-    cs = B.gpuq_supplier_cols(**p)
-    tc.ctx.check(tc.ctx.L.gpuq_gen_supplier(tc.ctx.h, tc.stream_ptr(), seed, row0, n, C.byref(cs)))
+    cs = gpuq_supplier_cols(**p)
+    with _on_device(tc):
+        _gen_check(tc, _gen().gpuq_tpchgen_supplier(tc.stream_ptr(), seed, row0, n, C.byref(cs)))
     tc.sync()
     return g.DeviceTable(cols, n)
 

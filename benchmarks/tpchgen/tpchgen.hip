@@ -1,4 +1,5 @@
-// TPC-H-shaped synthetic table generator (bench / test input only; not part of the operator path).
+// TPC-H-shaped synthetic table generator: bench / test input only.  Its own shared library (benchmarks/libgpuq_tpchgen.so, built by
+// arrow-ballista_amd/build.py): nothing of it is part of libgpuq.so or include/gpuq.h.
 // Distributions follow SURVEY.md §8(d); the schema is the reference's
 // (benchmarks/src/bin/tpch.rs:864-957): Int64 keys, Decimal128(15,2) money, Date32 dates, Utf8 flags.
 // Counter-based: value = f(seed, column id, row), so any row range can be produced independently on
@@ -6,9 +7,23 @@
 //
 // Deviation from dbgen, stated once: every order has exactly 4 lineitems (dbgen: 1..7, mean 4), so
 // lineitem row i belongs to order index i>>2 and offsets have a closed form.
-#include "gpuq_kernels.h"
+#include "gpuq_kernels.h"      // mix64, the integer typedefs (csrc/, on the include path)
+#include "gpuq_tpchgen.h"
+#include <cstdio>
 
 namespace gpuq {
+
+struct LineitemCols {
+  i64* l_orderkey; i64* l_suppkey;
+  u64* l_quantity; u64* l_extendedprice; u64* l_discount; u64* l_tax;   // Decimal128 as (lo,hi)
+  int32_t* l_shipdate;
+  uint8_t* l_returnflag; int32_t* l_returnflag_off;
+  uint8_t* l_linestatus; int32_t* l_linestatus_off;
+};
+struct OrdersCols { i64* o_orderkey; i64* o_custkey; int32_t* o_orderdate; int32_t* o_shippriority; };
+struct CustomerCols { i64* c_custkey; i64* c_nationkey; uint8_t* c_mktsegment; int32_t* c_mktsegment_off; };
+struct SupplierCols { i64* s_suppkey; i64* s_nationkey; };
+static int gen_cus() { static int n = []() { int d = 0, v = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v > 0 ? v : 256; }(); return n; }
 
 __device__ __host__ __forceinline__ u64 gen_u64(u64 seed, u64 col, u64 row) {
   return mix64((seed + col * 0xD1B54A32D192ED03ull) ^ (row * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull));
@@ -24,7 +39,6 @@ __device__ __host__ __forceinline__ i64 order_key(i64 o) { return (o >> 3) * 32 
 __device__ __host__ __forceinline__ int32_t order_date(u64 seed_orders, i64 o) { return 8035 + (int32_t)gen_mod(seed_orders, 4, (u64)o, 2406u); }
 
 // column ids: lineitem 1..9, orders 1..5, customer 1..3, supplier 1..2
-#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(256) k_gen_lineitem(const u64 seed, const u64 seed_orders, const i64 row0, const i64 n, const i64 n_supp,
                                                       const LineitemCols c) {
   for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
@@ -52,9 +66,7 @@ __global__ void __launch_bounds__(256) k_gen_lineitem(const u64 seed, const u64 
     }
   }
 }
-#endif
 
-#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(256) k_gen_orders(const u64 seed, const i64 row0, const i64 n, const i64 n_cust, const OrdersCols c) {
   for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
     const i64 o = row0 + j;
@@ -67,7 +79,6 @@ __global__ void __launch_bounds__(256) k_gen_orders(const u64 seed, const i64 ro
     if (c.o_shippriority) c.o_shippriority[j] = 0;
   }
 }
-#endif
 
 __constant__ const char kSegments[5][11] = {"AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"};
 __constant__ const int kSegLen[5] = {10, 8, 9, 9, 9};
@@ -89,7 +100,6 @@ __device__ __forceinline__ void seg_perm(u64 x64, int (&perm)[5]) {
   }
 }
 
-#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(256) k_gen_customer(const u64 seed, const i64 row0, const i64 n, const CustomerCols c) {
   // row0 must be a multiple of 5
   for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
@@ -112,9 +122,7 @@ __global__ void __launch_bounds__(256) k_gen_customer(const u64 seed, const i64 
     }
   }
 }
-#endif
 
-#ifndef GPUQ_JIT
 __global__ void __launch_bounds__(256) k_gen_supplier(const u64 seed, const i64 row0, const i64 n, const SupplierCols c) {
   for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
     const i64 i = row0 + j;
@@ -122,12 +130,10 @@ __global__ void __launch_bounds__(256) k_gen_supplier(const u64 seed, const i64 
     if (c.s_nationkey) c.s_nationkey[j] = (i64)gen_mod(seed, 2, (u64)i, 25u);
   }
 }
-#endif
 
-#ifndef GPUQ_JIT
 static int ggrid(i64 n) {
   i64 need = (n + 255) / 256; if (need < 1) need = 1;
-  const i64 cap = (i64)num_cus() * 16;
+  const i64 cap = (i64)gen_cus() * 16;
   return (int)(need < cap ? need : cap);
 }
 void launch_gen_lineitem(hipStream_t s, u64 seed, u64 seed_orders, i64 row0, i64 n, i64 n_supp, const LineitemCols& c) {
@@ -143,6 +149,42 @@ void launch_gen_supplier(hipStream_t s, u64 seed, i64 row0, i64 n, const Supplie
   if (n > 0) hipLaunchKernelGGL(k_gen_supplier, dim3(ggrid(n)), dim3(256), 0, s, seed, row0, n, c);
 }
 
-#endif  // GPUQ_JIT
 
 }  // namespace gpuq
+
+// ---- the C entry points (benchmarks/tpchgen/gpuq_tpchgen.h): the current device, the caller's stream
+extern "C" {
+static thread_local char g_gen_err[256] = "";
+const char* gpuq_tpchgen_last_error(void) { return g_gen_err; }
+static int gen_done(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  std::snprintf(g_gen_err, sizeof(g_gen_err), "%s: %s", what, hipGetErrorString(e));
+  return 2;
+}
+int gpuq_tpchgen_lineitem(void* stream, uint64_t seed, uint64_t seed_orders, int64_t row0, int64_t n, int64_t n_supp, const gpuq_lineitem_cols* c) {
+  if (!c || n < 0 || n_supp < 1) { std::snprintf(g_gen_err, sizeof(g_gen_err), "bad arguments"); return 1; }
+  gpuq::LineitemCols d{c->l_orderkey ? (gpuq::i64*)c->l_orderkey : nullptr, (gpuq::i64*)c->l_suppkey, (gpuq::u64*)c->l_quantity, (gpuq::u64*)c->l_extendedprice, (gpuq::u64*)c->l_discount,
+                       (gpuq::u64*)c->l_tax, c->l_shipdate, c->l_returnflag, c->l_returnflag_off, c->l_linestatus, c->l_linestatus_off};
+  gpuq::launch_gen_lineitem((hipStream_t)stream, seed, seed_orders, row0, n, n_supp, d);
+  return gen_done("gpuq_tpchgen_lineitem");
+}
+int gpuq_tpchgen_orders(void* stream, uint64_t seed, int64_t row0, int64_t n, int64_t n_cust, const gpuq_orders_cols* c) {
+  if (!c || n < 0 || n_cust < 3) { std::snprintf(g_gen_err, sizeof(g_gen_err), "bad arguments"); return 1; }
+  gpuq::OrdersCols d{(gpuq::i64*)c->o_orderkey, (gpuq::i64*)c->o_custkey, c->o_orderdate, c->o_shippriority};
+  gpuq::launch_gen_orders((hipStream_t)stream, seed, row0, n, n_cust, d);
+  return gen_done("gpuq_tpchgen_orders");
+}
+int gpuq_tpchgen_customer(void* stream, uint64_t seed, int64_t row0, int64_t n, const gpuq_customer_cols* c) {
+  if (!c || n < 0 || row0 % 5 != 0) { std::snprintf(g_gen_err, sizeof(g_gen_err), "bad arguments (row0 must be a multiple of 5)"); return 1; }
+  gpuq::CustomerCols d{(gpuq::i64*)c->c_custkey, (gpuq::i64*)c->c_nationkey, c->c_mktsegment, c->c_mktsegment_off};
+  gpuq::launch_gen_customer((hipStream_t)stream, seed, row0, n, d);
+  return gen_done("gpuq_tpchgen_customer");
+}
+int gpuq_tpchgen_supplier(void* stream, uint64_t seed, int64_t row0, int64_t n, const gpuq_supplier_cols* c) {
+  if (!c || n < 0) { std::snprintf(g_gen_err, sizeof(g_gen_err), "bad arguments"); return 1; }
+  gpuq::SupplierCols d{(gpuq::i64*)c->s_suppkey, (gpuq::i64*)c->s_nationkey};
+  gpuq::launch_gen_supplier((hipStream_t)stream, seed, row0, n, d);
+  return gen_done("gpuq_tpchgen_supplier");
+}
+}  // extern "C"

@@ -3,13 +3,14 @@
  *   q1_native PLAN.json N_ROWS [SEED]
  *
  * 1. create a device context, allocate the seven lineitem columns q1 reads in device memory (Arrow physical layout) and fill
- *    them with the library's synthetic TPC-H-shaped generator;
+ *    them with the benches' synthetic TPC-H-shaped generator (benchmarks/libgpuq_tpchgen.so: a library of its own, not part of libgpuq);
  * 2. hand the stage plan (JSON mirror of the reference's PhysicalPlanNode tree, see include/gpuq.h) to the native plan
  *    executor: gpuq_plan_create + gpuq_plan_execute -- the counterpart of `plan.execute(0, ctx)` in
  *    ballista/core/src/execution_plans/shuffle_writer.rs:255;
  * 3. copy the result columns back and print one line per group (decimals as unscaled integers).
  * tests/test_gpu_c_example.py runs it on the GPU box and compares the lines with the oracle. */
 #include "../include/gpuq.h"
+#include "gpuq_tpchgen.h"      /* benchmarks/tpchgen/ (-I) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -61,7 +62,7 @@ int main(int argc, char** argv) {
   gpuq_lineitem_cols gen; memset(&gen, 0, sizeof gen);
   gen.l_quantity = qty; gen.l_extendedprice = ext; gen.l_discount = disc; gen.l_tax = tax; gen.l_shipdate = (int32_t*)ship;
   gen.l_returnflag = (uint8_t*)rf; gen.l_returnflag_off = (int32_t*)rfo; gen.l_linestatus = (uint8_t*)ls; gen.l_linestatus_off = (int32_t*)lso;
-  CHECK(gpuq_gen_lineitem(ctx, NULL, seed, 2 /* orders seed */, 0, n, 10000, &gen));
+  if (gpuq_tpchgen_lineitem(NULL, seed, 2 /* orders seed */, 0, n, 10000, &gen) != 0) { fprintf(stderr, "generator: %s\n", gpuq_tpchgen_last_error()); return 1; }
 
   /* column order = the MemoryExec schema of the plan file */
   gpuq_column cols[7]; memset(cols, 0, sizeof cols);

@@ -639,24 +639,6 @@ int gpuq_exchange_partitions(gpuq_comm* comm, void* stream, const gpuq_column* c
 int gpuq_allgather_table(gpuq_comm* comm, void* stream, const gpuq_column* cols, const gpuq_field_info* fields, int n_cols, int64_t n_rows, gpuq_table** out);
 const char* gpuq_exchange_last_error(void);
 
-/* ---- synthetic TPC-H-shaped input (bench/test support) ------------------- */
-typedef struct gpuq_lineitem_cols {
-  int64_t* l_orderkey; int64_t* l_suppkey;
-  void* l_quantity; void* l_extendedprice; void* l_discount; void* l_tax; /* Decimal128(15,2), 16 B/row */
-  int32_t* l_shipdate;
-  uint8_t* l_returnflag; int32_t* l_returnflag_off;  /* Utf8: n bytes, n+1 offsets */
-  uint8_t* l_linestatus; int32_t* l_linestatus_off;
-} gpuq_lineitem_cols;
-typedef struct gpuq_orders_cols { int64_t* o_orderkey; int64_t* o_custkey; int32_t* o_orderdate; int32_t* o_shippriority; } gpuq_orders_cols;
-typedef struct gpuq_customer_cols { int64_t* c_custkey; int64_t* c_nationkey; uint8_t* c_mktsegment; int32_t* c_mktsegment_off; } gpuq_customer_cols;
-typedef struct gpuq_supplier_cols { int64_t* s_suppkey; int64_t* s_nationkey; } gpuq_supplier_cols;
-/* Any pointer may be NULL (column skipped).  Rows [row0, row0+n) of the table. */
-int gpuq_gen_lineitem(gpuq_ctx* ctx, void* stream, uint64_t seed, uint64_t seed_orders, int64_t row0, int64_t n, int64_t n_supp,
-                      const gpuq_lineitem_cols* cols);
-int gpuq_gen_orders(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, int64_t n_cust, const gpuq_orders_cols* cols);
-int gpuq_gen_customer(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, const gpuq_customer_cols* cols);
-int gpuq_gen_supplier(gpuq_ctx* ctx, void* stream, uint64_t seed, int64_t row0, int64_t n, const gpuq_supplier_cols* cols);
-
 /* ---- timing support for bench.py: HIP events on the caller's stream ---------------------- */
 typedef struct gpuq_timer gpuq_timer;
 int gpuq_timer_create(gpuq_ctx* ctx, gpuq_timer** out);
