@@ -129,6 +129,48 @@ class NativeResult:
         self.ctx.check(L.gpuq_export_arrow(self.ctx.h, None, cols, fields, nc, self.num_rows, C.addressof(oa), C.addressof(osch)))
         return pa.Table.from_batches([pa.RecordBatch._import_from_c(C.addressof(oa), C.addressof(osch))])
 
+    def to_device_table(self, device):
+        """The result as a DeviceTable whose tensors alias the library's buffers (no copy); they keep this NativeResult alive."""
+        import torch
+        from .table import DeviceColumn, DeviceTable, type_json
+        cols, fields = self.columns_c()
+        n = self.num_rows
+        owner = self
+
+        def alias(ptr, nb):
+            if not ptr or nb <= 0:
+                return torch.zeros(max(int(nb), 16), dtype=torch.uint8, device=device)
+
+            class _A:
+                pass
+            a = _A()
+            a.__cuda_array_interface__ = {"shape": (int(nb),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+            a.owner = owner
+            return torch.as_tensor(a, device=device)
+        out = []
+        words = ((n + 63) // 64) * 8
+        for i in range(self.num_columns):
+            c, f = cols[i], fields[i]
+            ty = type_json(f.type, f.precision, f.scale)
+            validity = alias(c.validity, max(words, 8)) if c.validity else None
+            packed = f.type == B.T_UTF8 and (c.repr == B.REPR_PACKED15 or f.repr == B.REPR_PACKED15 or (not c.offsets and n > 0))
+            if f.type == B.T_UTF8 and not packed:
+                offs = alias(c.offsets, (n + 1) * 4).view(torch.int32) if c.offsets else torch.zeros(4, dtype=torch.int32, device=device)
+                last = int(offs[n].item()) if n and c.offsets else 0
+                out.append(DeviceColumn(f.name.decode(), ty, alias(c.data, max(last, 1)), n, offsets=offs, validity=validity, nullable=bool(f.nullable)))
+            elif f.type == B.T_UTF8:
+                out.append(DeviceColumn(f.name.decode(), ty, alias(c.data, max(n, 1) * 16), n, validity=validity, nullable=bool(f.nullable), repr=B.REPR_PACKED15))
+            elif f.type == B.T_BOOL:
+                out.append(DeviceColumn(f.name.decode(), ty, alias(c.data, max(words, 8)), n, validity=validity, nullable=bool(f.nullable)))
+            else:
+                out.append(DeviceColumn(f.name.decode(), ty, alias(c.data, max(n, 1) * max(int(f.width), 1)), n, validity=validity, nullable=bool(f.nullable)))
+        t = DeviceTable(out, n)
+        t._keep = self
+        rec = self.record(device)
+        if rec is not None:
+            t._record = rec
+        return t
+
     def columns_c(self):
         """(gpuq_column array, gpuq_field_info array) describing the result's device buffers."""
         L = self.ctx.L
@@ -153,35 +195,6 @@ class NativeResult:
         a.__cuda_array_interface__ = {"shape": (int(nbytes.value),), "typestr": "|u1", "data": (int(base.value), False), "version": 2}
         a.owner = self
         return torch.as_tensor(a, device=device), int(cap.value)
-
-    def to_device_table(self, device):
-        """DeviceTable whose columns alias the result's buffers (no copy); keeps the result alive."""
-        import torch
-        from .table import DeviceColumn, type_json
-        cols, fields = self.columns_c()
-        out = []
-        for i in range(self.num_columns):
-            f, c = fields[i], cols[i]
-            n = self.num_rows
-            w = f.width
-            dbytes = ((n + 63) // 64) * 8 + 8 if f.type == B.T_BOOL else max(1, n) * w + 16
-
-            def alias(ptr, nb):
-                class _A:
-                    pass
-                a = _A()
-                a.__cuda_array_interface__ = {"shape": (int(nb),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-                a.owner = self
-                return torch.as_tensor(a, device=device)
-            data = alias(c.data, dbytes) if c.data else torch.zeros(16, dtype=torch.uint8, device=device)
-            validity = alias(c.validity, ((n + 63) // 64) * 8 + 8) if c.validity else None
-            out.append(DeviceColumn(f.name.decode(), type_json(f.type, f.precision, f.scale), data, n, validity=validity, nullable=bool(f.nullable), repr=f.repr))
-        t = DeviceTable(out, self.num_rows)
-        t._keep = self
-        rec = self.record(device)
-        if rec is not None:
-            t._record = rec
-        return t
 
     def close(self):
         if self.h:

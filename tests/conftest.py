@@ -21,3 +21,10 @@ def tc():
         pytest.skip("no GPU")
     import arrow_ballista_amd as g
     return g.TaskContext(device=0)
+
+
+@pytest.fixture
+def mirror_layer(monkeypatch):
+    """`node.execute()` through the Python restatement of the executor instead of the native one (plan.py: GPUQ_PLAN_LAYER): for tests
+    about the mirror itself -- its refusals, its late-materialised views (`.via`), its per-node metrics."""
+    monkeypatch.setenv("GPUQ_PLAN_LAYER", "mirror")

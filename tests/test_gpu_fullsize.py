@@ -43,7 +43,7 @@ def test_q1_linearity_and_row_conservation_sf10(tc):
         assert int(r["avg_qty"].scaleb(6)) == int(r["sum_qty"].scaleb(2)) * 10_000 // r["count_order"]
 
 
-def test_sort_is_a_sorted_permutation_2p26(tc):
+def test_sort_is_a_sorted_permutation_2p26(tc, mirror_layer):
     n = 1 << 26
     li = T.gen_lineitem_device(tc, n, columns=("l_orderkey", "l_extendedprice"))
     s = li.schema()
@@ -84,7 +84,7 @@ def test_hash_partition_conserves_rows_and_separates_keys_2p26(tc):
         assert set(O.hash_partition(tab, [{"column": {"name": "l_orderkey"}}], parts)) == {p}
 
 
-def test_fk_join_finds_every_order_sf10(tc):
+def test_fk_join_finds_every_order_sf10(tc, mirror_layer):
     n_orders = (N + 3) // 4
     li = T.gen_lineitem_device(tc, N, columns=("l_orderkey", "l_extendedprice"))
     od = T.gen_orders_device(tc, n_orders, 1_500_000)

@@ -17,6 +17,11 @@ from test_gpu_operators import dev_rows, norm
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(autouse=True)
+def _node_execute_is_the_mirror(mirror_layer):
+    """In this module `plan.execute(0, tc)` is the second opinion the native executor's result (NativePlan / native_rows) is compared with."""
+
+
 
 def _tables(seed, na, nb, nc, dup_a=False, nulls=0.1):
     r = np.random.default_rng(seed)

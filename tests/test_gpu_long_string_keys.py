@@ -90,7 +90,7 @@ def test_join_on_long_strings(tc, jt):
     assert got == sorted(exp, key=repr) and len(exp) > 0
 
 
-def test_the_mirror_still_refuses_and_says_why(tc):
+def test_the_mirror_still_refuses_and_says_why(tc, mirror_layer):
     """The Python mirror (test-side) has no dictionary path: it fails loudly, it does not truncate keys."""
     t = names_table(100, 3, 10)
     src = g.MemoryExec([t])
@@ -158,7 +158,7 @@ def test_order_by_strings_that_differ_only_beyond_a_piece_boundary_or_by_trailin
     assert got == sorted(rows, key=lambda x: sort_key(x, [(0, True, True)]))[:7]
 
 
-def test_the_mirror_refuses_a_long_sort_key(tc):
+def test_the_mirror_refuses_a_long_sort_key(tc, mirror_layer):
     """SortExec used to order such rows by their first 15 bytes without a word; the mirror has no piece passes and must say so."""
     t = names_table(500, 3, 50)
     src = g.MemoryExec([t])
@@ -173,7 +173,9 @@ def test_the_mirror_refuses_a_long_sort_key(tc):
 
 # ------------------------------------------------------------------ = / != against a literal beyond 15 bytes (q19: l_shipinstruct = 'DELIVER IN PERSON')
 @pytest.mark.parametrize("native", [False, True], ids=["mirror", "native"])
-def test_equality_with_a_long_literal(tc, native):
+def test_equality_with_a_long_literal(tc, native, monkeypatch):
+    if not native:
+        monkeypatch.setenv("GPUQ_PLAN_LAYER", "mirror")
     vals = ["DELIVER IN PERSON", "TAKE BACK RETURN", "COLLECT COD", "NONE", "DELIVER IN PERSON!", "DELIVER IN PERSO", "100%_sure it is long", "100%xsure it is long", "100%_sure it is lon", None]
     r = np.random.default_rng(19)
     pick = r.integers(0, len(vals), 20_000)

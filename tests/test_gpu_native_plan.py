@@ -14,6 +14,11 @@ from test_gpu_operators import JOIN_TYPES, agg_cases, close_rows, dev_rows, norm
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(autouse=True)
+def _node_execute_is_the_mirror(mirror_layer):
+    """In this module `plan.execute(0, tc)` is the second opinion the native executor's result (NativePlan / native_rows) is compared with."""
+
+
 
 def arrow_rows(t):
     cols = []

@@ -460,7 +460,7 @@ def test_hash_join_null_equals_null_and_fused_filters(tc):
 
 
 @pytest.mark.parametrize("jt", JOIN_TYPES[1:])
-def test_hash_join_filter_on_outer_semi_anti(tc, jt):
+def test_hash_join_filter_on_outer_semi_anti(tc, jt, monkeypatch):
     """JoinFilter on the non-inner join types (q21 / q22 shape: semi / anti join with a residual predicate): a key match the
     filter rejects -- False or NULL -- is no match; sides' own predicates apply before the join."""
     nl, nr = 1500, 4000
@@ -485,6 +485,8 @@ def test_hash_join_filter_on_outer_semi_anti(tc, jt):
         plan = g.HashJoinExec(left, right, on, jf, jt, "CollectLeft", False)
         exp_pairs = O.hash_join(ol, orr, on, jt, left_pred=lpred, right_pred=rpred, pair_filter=pf)
         for runner in ("mirror", "native"):
+            monkeypatch.setenv("GPUQ_PLAN_LAYER", runner)      # (node.execute() goes through the native executor by default)
+
             def rows(p):
                 return dev_rows(tc, p.execute(0, tc)) if runner == "mirror" else __import__("test_gpu_native_plan").native_rows(tc, p)[0]
             if jt in ("LeftSemi", "LeftAnti"):
@@ -689,7 +691,7 @@ def test_limits_and_union_kat(tc):
 
 
 # ------------------------------------------------------------------------------------ run-time failures are loud
-def test_runtime_limits_fail_loudly(tc):
+def test_runtime_limits_fail_loudly(tc, mirror_layer):
     """What the device path cannot do is reported as an error (GPUQ_ERR_UNSUPPORTED / CAPACITY), never answered wrongly or
     by a fallback: a Utf8 value longer than 15 bytes reaching a comparison or a group key, more groups than the LDS
     strategy was asked to hold."""

@@ -38,7 +38,7 @@ def test_generator_matches_oracle_restatement(tc):
             assert (c.offsets.cpu().numpy()[: n + 1] == host[c.name + "_off"]).all()
 
 
-def test_q1_rank_records_merge_as_in_bench(tc):
+def test_q1_rank_records_merge_as_in_bench(tc, mirror_layer):
     """bench.py's N>1 step replayed on one GPU: the partial-aggregate results of two shards are fixed-layout records; laid
     back to back (what RCCL's all-gather delivers) they are read in place by the final aggregate through a view."""
     import torch

@@ -172,7 +172,7 @@ def test_malformed_streams_fail_loudly(tc):
     assert e.value.status == 3
 
 
-def test_two_stages_through_shuffle_files(tc, tmp_path):
+def test_two_stages_through_shuffle_files(tc, tmp_path, mirror_layer):
     """Map stage: ShuffleWriterExec hash-partitions its input into files (device LZ4).  Reduce stage: ShuffleReaderExec reads
     output partition q of every map task (device decode) and a FinalPartitioned-style aggregate runs on it -- the file-based
     shuffle of the reference (shuffle_writer.rs:234-456 -> shuffle_reader.rs:149-177), result identical to the one-stage oracle."""
