@@ -214,9 +214,13 @@ struct JitScope {
   JitScope(gpuq_op* op, const CompiledProgram& cp, int kernel_id, i64 n, const std::string& spec = std::string()) {
     gpuq_ctx* c = op->ctx;
     if (cp.jit_src.empty() || c->jit_mode == 0) return;
-    const bool use = c->jit_mode == 2 || (c->jit_mode == 1 && n >= c->jit_min_rows);
-    // auto mode, small input: only a program that keeps coming back (third run on) is worth a compile, and nobody waits for it
-    const bool hot = !use && ++op->jit_runs[{(const void*)&cp, kernel_id}] > 2;
+    const bool big = c->jit_mode == 1 && n >= c->jit_min_rows;
+    // force: wait for the compile (failures are errors).  wait (jit = "wait"): a large input waits for it too (steady-state benches).
+    // auto (the default): NOBODY waits -- a large input hands its source to the worker thread on its first run and runs the interpreter
+    // kernels meanwhile (a one-shot SF100 q3 used to spend 1.3 s in hiprtc for a 4 ms query); a small input is only worth a compile
+    // when its program keeps coming back (third run on).
+    const bool use = c->jit_mode == 2 || (big && c->jit_wait);
+    const bool hot = !use && (big || ++op->jit_runs[{(const void*)&cp, kernel_id}] > 2);
     if (!use && !hot) return;
     try {
       // the process-wide cache is keyed by the whole generated source (kilobytes of text to concatenate and compare): an
@@ -644,6 +648,7 @@ gpuq_ctx* gpuq_ctx_create(int device_ordinal, const char* json_opts) {
     std::string jm = std::getenv("GPUQ_JIT") ? std::getenv("GPUQ_JIT") : "";
     if (json_opts && *json_opts) { Json o = JsonParser(json_opts).parse(); jm = o.get_str("jit", jm); c->jit_min_rows = o.get_i64("jit_min_rows", c->jit_min_rows); }
     if (jm == "off" || jm == "0") c->jit_mode = 0; else if (jm == "force" || jm == "2") c->jit_mode = 2; else c->jit_mode = 1;
+    c->jit_wait = jm == "wait";
     if (!jit_available() && c->jit_mode == 1) c->jit_mode = 0;
     if (const char* e = std::getenv("GPUQ_JOIN_DENSE")) c->join_dense = std::atoi(e) != 0;
   });
@@ -2315,8 +2320,9 @@ int gpuq_ctx_set_jit(gpuq_ctx* ctx, const char* mode, int64_t min_rows) {
   return guarded(ctx, [&]() {
     if (!ctx || !mode) throw std::runtime_error("ctx/mode is NULL");
     const std::string m = mode;
-    if (m == "off") ctx->jit_mode = 0; else if (m == "auto") ctx->jit_mode = jit_available() ? 1 : 0; else if (m == "force") ctx->jit_mode = 2;
-    else throw std::runtime_error("jit mode must be off|auto|force");
+    if (m == "off") ctx->jit_mode = 0; else if (m == "auto" || m == "wait") ctx->jit_mode = jit_available() ? 1 : 0; else if (m == "force") ctx->jit_mode = 2;
+    else throw std::runtime_error("jit mode must be off|auto|wait|force");
+    ctx->jit_wait = m == "wait";
     if (min_rows >= 0) ctx->jit_min_rows = min_rows;
   });
 }

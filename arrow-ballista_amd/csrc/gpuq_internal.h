@@ -11,7 +11,8 @@ using gpuq::i64;
 
 struct gpuq_ctx {
   int device = 0; int cus = 256; size_t hbm = 0; std::string name, arch;
-  int jit_mode = 1;                 // 0 off, 1 auto (inputs >= jit_min_rows), 2 force
+  int jit_mode = 1;                 // 0 off, 1 auto, 2 force
+  bool jit_wait = false;            // auto: a large input (>= jit_min_rows) WAITS for its compile (jit = "wait"); default: the worker thread compiles, the interpreter runs meanwhile
   i64 jit_min_rows = 1ll << 21;
   std::string last_jit_error;       // auto mode: why the last specialisation fell back to the interpreter kernels
   int jit_launches = 0;

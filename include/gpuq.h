@@ -114,8 +114,12 @@ int gpuq_ctx_set_option(gpuq_ctx* ctx, const char* key, const char* value);
 /* The row front-end (column loads + expressions) of every operator exists twice: as interpreter kernels
    compiled ahead of time (always available, best for small inputs) and as a typed straight-line function
    generated from the same expression DAG and compiled with hiprtc on first use (best for large inputs).
-   mode: "off" | "auto" (inputs >= min_rows, falls back to the interpreter kernels when hiprtc is missing)
-   | "force" (errors are reported).  Default "auto", 2^21 rows; env GPUQ_JIT overrides at ctx creation. */
+   mode: "off" | "auto" | "wait" | "force".  "auto" (the default): nobody waits for a compile -- an input of >= min_rows rows hands its
+   source to a worker thread on its first run and runs the interpreter kernels until the code object is there (a one-shot query does not
+   pay hiprtc's 0.2-0.3 s per pipeline; smaller inputs are specialised when their program comes back a third time); gpuq_jit_wait
+   blocks until the queue is empty (steady-state benches call it after their warm-up).  "wait": an input of >= min_rows rows waits for
+   its compile (round 2's "auto").  "force": every input waits, errors are reported.  Falls back to the interpreter kernels when hiprtc
+   is missing.  min_rows default 2^21; env GPUQ_JIT overrides at ctx creation. */
 int gpuq_ctx_set_jit(gpuq_ctx* ctx, const char* mode, int64_t min_rows /* <0 = keep */);
 int gpuq_ctx_jit_stats(gpuq_ctx* ctx, int* available, int* launches, char* last_error, size_t cap);
 /* In "auto" mode a program that runs for the third time on inputs below min_rows is handed to a background thread for

@@ -10,6 +10,7 @@ import arrow_ballista_amd as g
 import tpch_util as T
 import bench_extras
 tc = g.TaskContext(device=0)
+tc.ctx.set_jit("wait")
 out = {"q6": bench_extras.q6_pipeline(tc, T, g, 100)}
 g.memory_stats(reset_peak=True)
 tp = bench_extras.tpch_pipelines(tc, T, g, 100)

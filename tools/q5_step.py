@@ -7,6 +7,7 @@ import arrow_ballista_amd as g
 from benchmarks import tpch as T
 sf = float(sys.argv[1]) if len(sys.argv) > 1 else 100
 tc = g.TaskContext(device=0)
+tc.ctx.set_jit("wait")
 n_li = T.LINEITEM_ROWS.get(int(sf), int(6_000_000 * sf))
 n_orders, n_cust, n_supp = (n_li + 3) // 4, int(150_000 * sf), int(10_000 * sf)
 li = T.gen_lineitem_device(tc, n_li, n_supp=n_supp, columns=("l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate"))
