@@ -2061,6 +2061,22 @@ int gpuq_like_utf8(gpuq_ctx* ctx, void* stream, const gpuq_column* col, const ui
       else if (c == '_') push(256);
       else push((uint8_t)c);
     }
+    // literal segments between '%' (the segment search of k_like_utf8); '_' anywhere, a literal newline under the regex rule, or more
+    // segments than the descriptor holds leave the general matcher in charge
+    pat.n_seg = 0; pat.anchored_start = pat.n > 0 && pat.tok[0] != 257; pat.anchored_end = pat.n > 0 && pat.tok[pat.n - 1] != 257;
+    if (pat.n == 0) { pat.anchored_start = pat.anchored_end = 1; }
+    for (int i = 0; i < pat.n && pat.n_seg >= 0;) {
+      if (pat.tok[i] == 257) { ++i; continue; }
+      int j = i; bool bad = false;
+      while (j < pat.n && pat.tok[j] != 257) { if (pat.tok[j] == 256 || (pat.regex_mode && pat.tok[j] == (uint16_t)'\n')) bad = true; ++j; }
+      if (bad || pat.n_seg >= LIKE_MAX_SEGS) { pat.n_seg = -1; break; }
+      const int k = pat.n_seg++;
+      pat.seg_off[k] = i; pat.seg_len[k] = j - i;
+      unsigned long long f8 = 0, m8 = 0;
+      for (int q = 0; q < j - i && q < 8; ++q) { f8 |= (unsigned long long)(pat.tok[i + q] & 0xFF) << (8 * q); m8 |= 0xFFull << (8 * q); }
+      pat.seg_first8[k] = f8; pat.seg_mask8[k] = m8;
+      i = j;
+    }
     launch_like_utf8(use_stream(stream), (const uint8_t*)col->data, col->offsets, col->validity, idx, n, pat, negated ? 1 : 0, (u64*)bits_out, (u64*)validity_out);
     HIPCHECK(hipGetLastError());
   });

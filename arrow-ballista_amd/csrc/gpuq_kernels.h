@@ -184,7 +184,14 @@ void launch_agg_emit(hipStream_t s, const AggOut& raw, int n_keys, int n_accs, u
 void launch_concat_bitmap(hipStream_t s, u64* dst, i64 dst_bit_offset, const uint8_t* src, i64 src_bit_offset, i64 n_bits);
 void launch_unpack_utf8_lengths(hipStream_t s, const ulonglong2* packed, i64 n, int32_t* lens_out, uint32_t* too_long);
 constexpr int LIKE_MAX_TOKENS = 256;
-struct LikePattern { int32_t n; int32_t regex_mode; uint16_t tok[LIKE_MAX_TOKENS]; };     // 0..255 literal byte, 256 '_', 257 '%'
+constexpr int LIKE_MAX_SEGS = 8;
+struct LikePattern {
+  int32_t n; int32_t regex_mode; uint16_t tok[LIKE_MAX_TOKENS];     // 0..255 literal byte, 256 '_', 257 '%'
+  // the pattern as literal segments between '%' (n_seg < 0: it holds '_' or too many segments: the general matcher runs)
+  int32_t n_seg, anchored_start, anchored_end, pad;
+  int32_t seg_off[LIKE_MAX_SEGS], seg_len[LIKE_MAX_SEGS];
+  unsigned long long seg_first8[LIKE_MAX_SEGS], seg_mask8[LIKE_MAX_SEGS];
+};
 void launch_like_utf8(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, const LikePattern& pat, int negated,
                       u64* bits_out, u64* valid_out);
 void launch_mark_rows(hipStream_t s, const uint32_t* rows, i64 n, uint8_t* bitmap);

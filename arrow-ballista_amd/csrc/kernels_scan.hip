@@ -1068,6 +1068,92 @@ void launch_concat_bitmap(hipStream_t s, u64* dst, i64 off, const uint8_t* src, 
 // regex_mode: the pattern is none of arrow's fast shapes (equality, prefix%, %suffix, %infix%) and goes through its regex
 // translation, where '.' does not match a newline: '_' and '%' then refuse '\n' [UPSTREAM-KNOWLEDGE, arrow-string 49 like.rs].
 __device__ __forceinline__ int utf8_len(uint8_t b) { return b < 0x80 ? 1 : (b < 0xE0 ? 2 : (b < 0xF0 ? 3 : 4)); }
+// The match itself: `at(i)` = byte i of the string.
+template <class At>
+__device__ __forceinline__ bool like_match(const int len, const int plen, const uint16_t* tok, const bool regex_mode, At at) {
+  int s = 0, p = 0, star_p = -1, star_s = 0;
+  bool fail = false;
+  while (s < len) {
+    const int t = p < plen ? (int)tok[p] : -1;
+    const uint8_t ch = at(s);
+    if (t >= 0 && t < 256 && ch == (uint8_t)t) { ++s; ++p; }
+    else if (t == 256 && !(regex_mode && ch == '\n')) { s += utf8_len(ch); ++p; }
+    else if (t == 257) { star_p = p; star_s = s; ++p; }
+    else if (star_p >= 0) {
+      const uint8_t sc = at(star_s);
+      if (regex_mode && sc == '\n') { fail = true; break; }
+      star_s += utf8_len(sc); s = star_s; p = star_p + 1;
+    } else { fail = true; break; }
+  }
+  if (!fail && s > len) fail = true;                 // a truncated multi-byte character
+  while (!fail && p < plen && tok[p] == 257) ++p;
+  return !fail && p == plen;
+}
+// Patterns made of literal segments and '%' only (no '_'): prefix% / %suffix / %infix% / a%b%c ... -- the segments are searched for in
+// order, leftmost first (which is what greedy '%' matching comes to), through a 16-byte funnel over the string: one masked 8-byte
+// compare per position instead of the general matcher's state machine per byte (lanes of a wave hold strings in different states: the
+// general loop runs all its branches every step; measured 4-7 % of the HBM peak on 50-byte comments, this path: see profiles/).
+// seg k = tok[seg_off[k] .. +seg_len[k]) (literal bytes); first8 / mask8 = its first <= 8 bytes as a little-endian word.
+__device__ __forceinline__ u64 like_load8(const uint8_t* __restrict__ str, const int q, const int len) {      // bytes [q, q+8) of the string, zero beyond its end
+  if (q + 8 <= len) { u64 w; __builtin_memcpy(&w, str + q, 8); return w; }
+  u64 w = 0; for (int k = q; k < len; ++k) w |= (u64)str[k] << (8 * (k - q));
+  return w;
+}
+__device__ __forceinline__ bool like_seg_at(const uint8_t* __restrict__ str, const int len, const int q, const uint16_t* seg, const int L, const u64 first8, const u64 mask8) {
+  if (q < 0 || q + L > len) return false;
+  if ((like_load8(str, q, len) & mask8) != first8) return false;
+  for (int k = 8; k < L; ++k) if (str[q + k] != (uint8_t)seg[k]) return false;
+  return true;
+}
+__device__ __forceinline__ bool like_segments(const uint8_t* __restrict__ str, const int len, const LikePattern& pat, const uint16_t* tok) {
+  if (pat.regex_mode) {      // '.' refuses a newline and the pattern holds none: eight bytes at a time (zero-byte test on x ^ 0x0A..)
+    for (int k = 0; k < len; k += 8) {
+      const u64 x = like_load8(str, k, len) ^ 0x0A0A0A0A0A0A0A0Aull;      // (the zero padding beyond the end becomes 0x0A ^ 0 = 0x0A: never zero)
+      if ((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) return false;
+    }
+  }
+  int pos = 0;
+  const int ns = pat.n_seg;
+  for (int k = 0; k < ns; ++k) {
+    const int L = pat.seg_len[k]; const uint16_t* seg = tok + pat.seg_off[k];
+    const u64 f8 = pat.seg_first8[k], m8 = pat.seg_mask8[k];
+    const bool first = k == 0, last = k + 1 == ns;
+    if (first && pat.anchored_start) { if (!like_seg_at(str, len, 0, seg, L, f8, m8)) return false; pos = L; if (last && pat.anchored_end && len != L) return false; continue; }
+    if (last && pat.anchored_end) return len - L >= pos && like_seg_at(str, len, len - L, seg, L, f8, m8);
+    // leftmost occurrence at or after pos.  Per aligned 8-byte block: the positions that hold the segment's FIRST byte (zero-byte test on
+    // block ^ splat(byte): exact for the lowest hit, later hits may be false positives, every candidate is verified), then one masked
+    // 8-byte compare per candidate through a 16-byte funnel (cur = bytes [b, b+8), nxt = [b+8, b+16))
+    int q = pos; bool found = false;
+    const int lastq = len - L;
+    const u64 splat = (f8 & 0xFFull) * 0x0101010101010101ull;
+    while (q <= lastq && !found) {
+      const int b = q & ~7;
+      const u64 cur = like_load8(str, b, len);
+      const u64 x = cur ^ splat;
+      u64 cand = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+      if (q > b) cand &= ~0ull << (8 * (q - b));                     // positions before q are behind us
+      if (cand) {
+        const u64 nxt = like_load8(str, b + 8, len);
+        while (cand) {
+          const int k = __builtin_ctzll(cand) >> 3; cand &= cand - 1;
+          const int at = b + k;
+          if (at > lastq) break;
+          const int sh = 8 * k;
+          const u64 w = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur;
+          if ((w & m8) == f8) {
+            bool ok = true;
+            for (int j = 8; j < L; ++j) if (str[at + j] != (uint8_t)seg[j]) { ok = false; break; }
+            if (ok) { found = true; q = at; break; }
+          }
+        }
+      }
+      if (!found) q = b + 8;
+    }
+    if (!found) return false;
+    pos = q + L;
+  }
+  return ns > 0 ? true : (pat.anchored_start && pat.anchored_end ? len == 0 : true);      // no segment at all: '' matches only '', '%' everything
+}
 __global__ void __launch_bounds__(BLOCK) k_like_utf8(const uint8_t* __restrict__ data, const int32_t* __restrict__ offsets, const uint8_t* __restrict__ validity,
                                                      const uint32_t* __restrict__ idx, const i64 n, const LikePattern pat, const int negated,
                                                      u64* __restrict__ bits_out, u64* __restrict__ valid_out) {
@@ -1084,34 +1170,20 @@ __global__ void __launch_bounds__(BLOCK) k_like_utf8(const uint8_t* __restrict__
       if (valid) {
         const uint8_t* str = data + offsets[r];
         const int len = offsets[r + 1] - offsets[r], plen = pat.n;
-        int s = 0, p = 0, star_p = -1, star_s = 0;
-        bool fail = false;
-        // the string is walked through an 8-byte register window (one unaligned 8-byte load per 8 bytes instead of a byte load
-        // per step); the last < 8 bytes of a string are read byte-wise so that nothing beyond its end is touched
-        int wbase = -8; u64 win = 0;
-        auto at = [&](int i) -> uint8_t {
-          if ((unsigned)(i - wbase) >= 8u) {
-            wbase = i & ~7;
-            if (wbase + 8 <= len) __builtin_memcpy(&win, str + wbase, 8);
-            else { win = 0; for (int q = wbase; q < len; ++q) win |= (u64)str[q] << (8 * (q - wbase)); }
-          }
-          return (uint8_t)(win >> (8 * (i - wbase)));
-        };
-        while (s < len) {
-          const int t = p < plen ? (int)tok[p] : -1;
-          const uint8_t ch = at(s);
-          if (t >= 0 && t < 256 && ch == (uint8_t)t) { ++s; ++p; }
-          else if (t == 256 && !(pat.regex_mode && ch == '\n')) { s += utf8_len(ch); ++p; }
-          else if (t == 257) { star_p = p; star_s = s; ++p; }
-          else if (star_p >= 0) {
-            const uint8_t sc = at(star_s);
-            if (pat.regex_mode && sc == '\n') { fail = true; break; }
-            star_s += utf8_len(sc); s = star_s; p = star_p + 1;
-          } else { fail = true; break; }
+        if (pat.n_seg >= 0) m = like_segments(str, len, pat, tok);
+        else {
+          // the string is walked through an 8-byte register window (one unaligned 8-byte load per 8 bytes instead of a byte load
+          // per step); the last < 8 bytes of a string are read byte-wise so that nothing beyond its end is touched
+          int wbase = -8; u64 win = 0;
+          m = like_match(len, plen, tok, pat.regex_mode != 0, [&](int q) -> uint8_t {
+            if ((unsigned)(q - wbase) >= 8u) {
+              wbase = q & ~7;
+              if (wbase + 8 <= len) __builtin_memcpy(&win, str + wbase, 8);
+              else { win = 0; for (int k = wbase; k < len; ++k) win |= (u64)str[k] << (8 * (k - wbase)); }
+            }
+            return (uint8_t)(win >> (8 * (q - wbase)));
+          });
         }
-        if (!fail && s > len) fail = true;                 // a truncated multi-byte character
-        while (!fail && p < plen && tok[p] == 257) ++p;
-        m = !fail && p == plen;
         if (negated) m = !m;
       }
     }
