@@ -117,3 +117,43 @@ def test_filter_output_equals_aceros(tc):
         got, _ = native_rows(tc, g.FilterExec(pred, src))
         a = t.filter(mask, null_selection_behavior="drop")
         assert got == list(zip(*[a[c].to_pylist() for c in t.column_names])) and a.num_rows > 0
+
+
+def test_more_than_four_group_columns_equal_aceros(tc):
+    """GROUP BY over six and seven columns (the aggregate's table holds four keys: narrow keys are packed into 126-bit composites --
+    biased, with a NULL bit -- and unpacked over the groups; strings take a slot of their own or travel as dictionary codes): nullable
+    keys, negative values, narrow integer types, a date, a short and a long string, two-phase as well."""
+    r = np.random.default_rng(51)
+    n = 120_000
+
+    def mask(p=0.15):
+        return r.random(n) < p
+    words = np.array(["", "a", "BUILDING", "exactly15bytes!", "a key that is longer than fifteen bytes", "another long key, same length.........."])
+    t = pa.table({
+        "a": pa.array(r.integers(-3, 4, n).astype(np.int8), pa.int8(), mask=mask()),
+        "b": pa.array(r.integers(-300, 300, n).astype(np.int16) // 100, pa.int16()),
+        "c": pa.array(r.integers(-2**31, 2**31 - 1, n).astype(np.int32) // 2**29, pa.int32(), mask=mask()),
+        "d": pa.array(r.integers(-2**62, 2**62, n) // 2**60, pa.int64(), mask=mask()),
+        "e": pa.array(r.integers(9000, 9004, n).astype(np.int32), pa.int32()).cast(pa.date32()),
+        "s": pa.array(words[r.integers(0, 4, n)], pa.string(), mask=mask()),
+        "l": pa.array(words[r.integers(0, 6, n)], pa.string(), mask=mask(0.05)),
+        "v": pa.array(r.integers(-10**6, 10**6, n), pa.int64(), mask=mask()),
+    })
+    src = g.MemoryExec([t])
+    s = src.schema()
+    aggs = [{"fn": "SUM", "expr": col("v", s), "name": "sv"}, {"fn": "COUNT", "expr": lit(1), "name": "n"}, {"fn": "MIN", "expr": col("v", s), "name": "mn"}]
+    for keys in (["a", "b", "c", "d", "e", "s"], ["a", "b", "c", "d", "e", "s", "l"], ["l", "d", "c", "b", "a"]):
+        got, _ = native_rows(tc, g.AggregateExec("Single", [(col(k, s), k) for k in keys], aggs, src))
+        a = t.group_by(keys, use_threads=False).aggregate([("v", "sum"), ([], "count_all"), ("v", "min")])
+        cols = [a[k].cast(pa.int32()).to_pylist() if k == "e" else a[k].to_pylist() for k in keys] + [a["v_sum"].to_pylist(), a["count_all"].to_pylist(), a["v_min"].to_pylist()]
+        exp = list(zip(*cols))
+        key = lambda rows: sorted(rows, key=lambda r_: tuple((x is None, "" if x is None else (x if isinstance(x, str) else 0), 0 if x is None or isinstance(x, str) else x) for x in r_))
+        assert key(got) == key(exp) and len(exp) > 500, keys
+    keys = ["a", "b", "c", "d", "e"]
+    part = g.AggregateExec("Partial", [(col(k, s), k) for k in keys], aggs, src)
+    fs = part.schema()
+    fin = g.AggregateExec("FinalPartitioned", [(col(k, fs), k) for k in keys], [dict(x, expr=None) for x in aggs], part)
+    got, _ = native_rows(tc, fin)
+    a = t.group_by(keys, use_threads=False).aggregate([("v", "sum"), ([], "count_all"), ("v", "min")])
+    exp = list(zip(*([a[k].cast(pa.int32()).to_pylist() if k == "e" else a[k].to_pylist() for k in keys] + [a["v_sum"].to_pylist(), a["count_all"].to_pylist(), a["v_min"].to_pylist()])))
+    assert _key(got) == _key(exp)
