@@ -73,6 +73,7 @@ def lib():
         "gpuq_copy_d2h": (i32, [vp, vp, vp, vp, C.c_size_t]),
         "gpuq_table_import_arrow": (i32, [vp, vp, vp, vp, C.POINTER(vp)]),
         "gpuq_cross_pairs": (i32, [vp, vp, i64, i64, vp, vp]),
+        "gpuq_sort_run_keys": (i32, [vp, vp, C.POINTER(gpuq_input), vp, vp, vp, C.POINTER(i32)]),
         "gpuq_memory_limit": (i32, [i64]),
         "gpuq_memory_stats": (i32, [C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), i32]),
         "gpuq_utf8_compare": (i32, [vp, vp, C.POINTER(gpuq_column), vp, C.POINTER(gpuq_column), vp, C.c_char_p, i64, i64, i32, vp, vp]),

@@ -64,6 +64,8 @@ struct gpuq_op {
   // partition
   uint32_t nparts = 0;
   // deferred execution (include/gpuq.h): what the last completed synchronous run learned, and what a deferred run may leave behind
+  struct { void* data = nullptr; u64* valid = nullptr; bool done = false; } sort_dec;      // gpuq_sort_run_keys: where the sorted key column goes
+  DType sort_key0;                  // sort: type of the first key expression
   std::string refuse;               // the operator compiles (its output types are known) but cannot run: why
   std::string label;                // descriptor "label": appended to the run-time compiled kernels' names (a plan node id: profiles tell call sites apart)
   bool deferred = false, defer_client = false;
@@ -728,6 +730,7 @@ static void compile_op(gpuq_op* op, const Json& d) {
         op->sort.nulls_first[k] = es[k].get_bool("nulls_first", !asc) ? 1 : 0;
         op->sort.kind[k] = ks[k]->type.is_float() ? 1 : (ks[k]->type.id == T_UTF8 ? 2 : 0);
       }
+      op->sort_key0 = ks[0]->type;
       op->fetch = d.get_i64("fetch", -1);
     } else if (kind == "partition") {
       op->kind = K_PARTITION;
@@ -1642,6 +1645,15 @@ static SortPack sort_key_plan(gpuq_op* op, hipStream_t s, const DevProgram& P, i
 }
 
 static void sort_with_plan(gpuq_op* op, hipStream_t s, const DevProgram& P, const i64 n, const SortPack& K, const int total, uint32_t* perm_out);
+int gpuq_sort_run_keys(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out, void* key_data_out, uint8_t* key_validity_out, int* decoded_out) {
+  if (decoded_out) *decoded_out = 0;
+  if (!op) return GPUQ_ERR_INVALID;
+  op->sort_dec.data = key_data_out; op->sort_dec.valid = (u64*)key_validity_out; op->sort_dec.done = false;
+  const int rc = gpuq_sort_run(op, stream, in, perm_out);
+  if (decoded_out) *decoded_out = (rc == GPUQ_OK && op->sort_dec.done) ? 1 : 0;
+  op->sort_dec.data = nullptr; op->sort_dec.valid = nullptr;
+  return rc;
+}
 int gpuq_sort_run(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out) {
   if (!op) return GPUQ_ERR_INVALID;
   return guarded(op->ctx, [&]() {
@@ -1722,6 +1734,9 @@ static void sort_with_plan(gpuq_op* op, hipStream_t s, const DevProgram& P, cons
     const int np_all = (total + 7) / 8;
     u64* ghist = (u64*)op->ws[6].ensure(((size_t)sort_max_passes() * 256 + 1) * 8);      // + the "guessed layout does not hold" word
     const bool small = n <= sort_small_max();
+    // gpuq_sort_run_keys: one integer-like key whose field IS value - base (no string shift), at most one 64-bit word of composite
+    const int dec_width = (op->sort_dec.data && S.n_keys == 1 && S.kind[0] == 0 && K.rshift[0] == 0 && total >= 1 && total <= 64 && !small) ? type_width(op->sort_key0) : 0;
+    const bool decode = dec_width == 1 || dec_width == 2 || dec_width == 4 || dec_width == 8 || (dec_width == 16 && op->sort_key0.id == T_DECIMAL128);
     { JitScope js(op, op->prog, 9, n); launch_sort_pack(s, P, n, S, K, klo, khi, ids, small || total == 0 ? nullptr : ghist, np_all); }
     if (small) {      // one block sorts it in LDS: no histogram / scan / scatter launches
       launch_sort_small(s, klo, khi, ids, n, perm_out);
@@ -1736,12 +1751,17 @@ static void sort_with_plan(gpuq_op* op, hipStream_t s, const DevProgram& P, cons
       if (np == 0) { if (last_word) HIPCHECK(hipMemcpyAsync(perm_out, ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s)); return; }
       for (int p = 0; p < np; ++p) {
         const bool final_pass = last_word && p + 1 == np;
-        launch_onesweep_pass(s, klo, ids, n, shift0 + 8 * p, ghist + (size_t)(pass0 + p) * 256, lws, lwb, klo2, final_pass ? perm_out : ids2, final_pass ? 1 : 0);
+        // (decode: the last pass keeps its records as well -- packed: records AND ids, otherwise keys and ids -- the key column is rebuilt from them)
+        launch_onesweep_pass(s, klo, ids, n, shift0 + 8 * p, ghist + (size_t)(pass0 + p) * 256, lws, lwb, klo2, final_pass ? perm_out : ids2, final_pass ? (decode ? (packed ? 2 : 0) : 1) : 0);
         std::swap(klo, klo2); if (!final_pass) std::swap(ids, ids2);
       }
     };
     if (packed) {
       run_passes(total, 32, 0, true);
+      if (decode) { launch_sort_decode(s, klo, 32, n, K, S.desc[0], S.nulls_first[0], dec_width, op->sort_dec.data, op->sort_dec.valid); op->sort_dec.done = true; }
+    } else if (decode) {
+      run_passes(total, 0, 0, true);
+      launch_sort_decode(s, klo, 0, n, K, S.desc[0], S.nulls_first[0], dec_width, op->sort_dec.data, op->sort_dec.valid); op->sort_dec.done = true;
     } else {
       run_passes(std::min(total, 64), 0, 0, total <= 64);
       if (total > 64) {

@@ -197,6 +197,7 @@ void launch_like_utf8(hipStream_t s, const uint8_t* data, const int32_t* offsets
 void launch_mark_rows(hipStream_t s, const uint32_t* rows, i64 n, uint8_t* bitmap);
 void launch_utf8_compare(hipStream_t s, const uint8_t* adata, const int32_t* aoffs, const uint8_t* avalid, const uint32_t* aidx, const uint8_t* bdata, const int32_t* boffs,
                          const uint8_t* bvalid, const uint32_t* bidx, int32_t blen, i64 n, int op, u64* bits_out, u64* valid_out);
+void launch_sort_decode(hipStream_t s, const u64* recs, int rec_shift, i64 n, const SortPack& K, int desc, int nulls_first, int width, void* out, u64* valid_out);
 void launch_cross_pairs(hipStream_t s, i64 n_left, i64 n_right, uint32_t* left_rows, uint32_t* right_rows);
 void launch_offsets_rebase(hipStream_t s, const int32_t* src, i64 n, int32_t delta, int32_t* dst);
 void launch_take_utf8_lengths(hipStream_t s, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int32_t* lens, u64* valid_out);

@@ -703,6 +703,41 @@ void launch_radix_ghist(hipStream_t s, const u64* keys, i64 n, int shift0, int n
   i64 need = (n + SBLOCK * 16 - 1) / (SBLOCK * 16); const i64 cap = (i64)num_cus() * 8;
   hipLaunchKernelGGL(k_radix_ghist, dim3((unsigned)std::max<i64>(1, std::min(need, cap))), dim3(SBLOCK), 0, s, keys, n, shift0, npasses, ghist);
 }
+// ORDER BY one integer-like key: the key column IN SORTED ORDER is rebuilt from the sorted records (value = base +- field) instead of gathered
+// through the permutation -- a sequential read and write where the gather pays a 64-byte line per 16-byte value (SF300 sort shard: the
+// l_extendedprice gather was ~6 of 16.6 ms).  recs: the last pass's output (packed: composite in the high 32 bits); width: bytes per value.
+__global__ void __launch_bounds__(SBLOCK) k_sort_decode(const u64* __restrict__ recs, const int rec_shift, const i64 n, const SortPack K, const int desc, const int nulls_first,
+                                                        const int width, uint8_t* __restrict__ out, u64* __restrict__ valid_out) {
+  const i64 nwords = (n + 63) >> 6;
+  const i128 base = mk128(K.base_lo[0], K.base_hi[0]);
+  const u64 vmask = K.vbits[0] >= 64 ? ~0ull : ((1ull << K.vbits[0]) - 1);
+  for (i64 w = (i64)blockIdx.x * SWAVES + swave(); w < nwords; w += (i64)gridDim.x * SWAVES) {
+    const i64 i = (w << 6) + slane();
+    bool valid = false;
+    if (i < n) {
+      const u64 comp = recs[i] >> rec_shift;
+      bool isn = false;
+      if (K.null_bit[0] >= 0) isn = (((comp >> K.null_bit[0]) & 1ull) != 0) != (nulls_first != 0);      // flag = isnull XOR nulls_first (k_sort_pack)
+      const u64 field = comp & vmask;
+      const i128 v = isn ? (i128)0 : (desc ? base - (i128)field : base + (i128)field);
+      valid = !isn;
+      switch (width) {
+        case 1: out[i] = (uint8_t)v; break;
+        case 2: ((uint16_t*)out)[i] = (uint16_t)v; break;
+        case 4: ((uint32_t*)out)[i] = (uint32_t)v; break;
+        case 8: ((u64*)out)[i] = (u64)v; break;
+        default: ((ulonglong2*)out)[i] = make_ulonglong2((u64)v, (u64)((u128)v >> 64)); break;
+      }
+    }
+    if (valid_out) { const u64 vb = __ballot(valid); if (slane() == 0) valid_out[w] = vb; }
+  }
+}
+void launch_sort_decode(hipStream_t s, const u64* recs, int rec_shift, i64 n, const SortPack& K, int desc, int nulls_first, int width, void* out, u64* valid_out) {
+  if (n <= 0) return;
+  i64 need = ((n + 63) / 64 + SWAVES - 1) / SWAVES; const i64 cap = (i64)num_cus() * 16;
+  hipLaunchKernelGGL(k_sort_decode, dim3((unsigned)(need < cap ? need : cap)), dim3(SBLOCK), 0, s, recs, rec_shift, n, K, desc, nulls_first, width, (uint8_t*)out, valid_out);
+}
+
 // one stable 8-bit pass; vals == NULL: packed (key << 32 | row) records; ids_only: only vals_out is written (the last pass)
 void launch_onesweep_pass(hipStream_t s, const u64* keys, const uint32_t* vals, i64 n, int shift, u64* gexcl, void* ws, size_t ws_bytes,
                           u64* keys_out, uint32_t* vals_out, int ids_only) {

@@ -666,7 +666,10 @@ static PTable filter_table_impl(Exec& x, const PTable& source_in, const Json& pr
 }
 
 // the stable permutation that puts `t` in `sort_exprs` order (one gpuq_sort_run: <= 4 keys whose composite fits 128 bits)
-static BufP sort_perm(Exec& x, PTable& t, const Json& sort_exprs, const void* site, int tag) {      // (t's count is made exact when the operator cannot run deferred)
+// ORDER BY one plain column of an integer-like type: the operator can hand that column back IN ORDER (rebuilt from its sorted records,
+// gpuq_sort_run_keys) -- the view over the sorted table then reads it directly instead of through the permutation.
+struct SortedKey { int col = -1; BufP data, valid; bool decoded = false; };
+static BufP sort_perm(Exec& x, PTable& t, const Json& sort_exprs, const void* site, int tag, SortedKey* sk = nullptr) {      // (t's count is made exact when the operator cannot run deferred)
   gpuq_op* op = cached_op(x, site, tag, table_sig(t), [&]() {
     const auto nm = names_of(t);
     Json ex = jarr();
@@ -679,6 +682,18 @@ static BufP sort_perm(Exec& x, PTable& t, const Json& sort_exprs, const void* si
   prep(x, op, t);
   BufP perm = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * 4 + 16);
   InputC ic; make_input(t, ic);
+  if (sk && sk->col >= 0) {
+    const PCol& kc = t.cols[(size_t)sk->col];
+    DType dt = dtype_from_json(kc.type);
+    const size_t w = (size_t)type_width(dt);
+    sk->data = dev_alloc((size_t)std::max<int64_t>(t.n, 1) * w + 16);
+    const bool nullable = kc.nullable || (t.sides[(size_t)sk->col] > 0 && !t.dense);
+    if (nullable) sk->valid = dev_alloc((size_t)((t.n + 63) / 64) * 8 + 8);
+    int decoded = 0;
+    check(x, gpuq_sort_run_keys(op, x.stream, &ic.in, (uint32_t*)perm->p, sk->data->p, sk->valid ? (uint8_t*)sk->valid->p : nullptr, &decoded));
+    sk->decoded = decoded != 0;
+    return perm;
+  }
   check(x, gpuq_sort_run(op, x.stream, &ic.in, (uint32_t*)perm->p));
   return perm;
 }
@@ -732,10 +747,33 @@ static bool is_wide_sort_key(const std::exception& e) { return std::string(e.wha
 PTable sort_table(Exec& x, const PTable& t_in, const Json& sort_exprs, int64_t fetch, const void* site, int tag) {
   PTable t = t_in; bool wide = false;
   try {
-    BufP perm = sort_perm(x, t, sort_exprs, site, tag);
+    // one key that is a plain fixed-width column of a materialised table with enough rows for the radix passes: ask for it in order
+    SortedKey sk;
+    if (sort_exprs.a.size() == 1 && !t.is_view() && t.n >= (1 << 20)) {
+      const Json& e = sort_exprs.a[0].at("expr");
+      if (e.is_obj() && e.o.size() == 1 && e.o[0].first == "column" && e.o[0].second.find("name")) {
+        const std::string& nm = e.o[0].second.at("name").str();
+        for (size_t i = 0; i < t.cols.size(); ++i) if (t.cols[i].name == nm) {
+          const int ty = t.cols[i].c.type;
+          if (ty == T_INT8 || ty == T_INT16 || ty == T_INT32 || ty == T_INT64 || ty == T_UINT8 || ty == T_UINT16 || ty == T_UINT32 || ty == T_DATE32 || ty == T_DATE64 ||
+              ty == T_TIMESTAMP || ty == T_DECIMAL128) sk.col = (int)i;
+          break;
+        }
+      }
+    }
+    BufP perm = sort_perm(x, t, sort_exprs, site, tag, sk.col >= 0 ? &sk : nullptr);
     // deferred: the first *n_dev entries of the permutation are the sorted rows (padding sorts behind them); a fetch bounds both
     const int64_t k = (fetch < 0 || fetch > t.n) ? t.n : fetch;
-    return select_view(x, t, (const uint32_t*)perm->p, k, perm, t.n_dev ? &t : nullptr);
+    PTable out = select_view(x, t, (const uint32_t*)perm->p, k, perm, t.n_dev ? &t : nullptr);
+    if (sk.decoded) {      // the key column lies in order already: read it as it lies (side 0), everything else through the permutation
+      PCol& kc = out.cols[(size_t)sk.col];
+      kc.c.data = sk.data->p; kc.c.validity = sk.valid ? (const uint8_t*)sk.valid->p : nullptr; kc.c.length = k;
+      kc.nullable = sk.valid != nullptr;
+      out.sides[(size_t)sk.col] = 0;
+      out.keep.push_back(sk.data); if (sk.valid) out.keep.push_back(sk.valid);
+      out.record_cap = 0;
+    }
+    return out;
   } catch (const Unsupported& e) { if (!is_long_string_failure(e) && !is_wide_sort_key(e)) throw; wide = is_wide_sort_key(e); }
   resolve(x, t);
   const int64_t k = (fetch < 0 || fetch > t.n) ? t.n : fetch;

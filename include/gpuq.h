@@ -334,6 +334,12 @@ int gpuq_mark_rows(gpuq_ctx* ctx, void* stream, const uint32_t* rows, int64_t n,
    i < n_left * n_right (< 2^32).  The executor reads both sides through these index vectors like a hash join's pairs.  Asynchronous. */
 int gpuq_cross_pairs(gpuq_ctx* ctx, void* stream, int64_t n_left, int64_t n_right, uint32_t* left_rows_out, uint32_t* right_rows_out);
 
+/* gpuq_sort_run that also hands back the FIRST key's column in sorted order when it can be rebuilt from the sorted records (one key of
+   an integer-like type -- Int8..Int64, UInt*, Date32 / Date64, Timestamp, Decimal128 -- whose values span at most 2^63, more rows than one block
+   sorts): key_data_out = n values of the key's width, key_validity_out = (n + 63) / 64 * 8 bytes (NULL when the key cannot be NULL).
+   *decoded_out = 1: written (a sequential pass; the caller need not gather that column through the permutation), 0: not written. */
+int gpuq_sort_run_keys(gpuq_op* op, void* stream, const gpuq_input* in, uint32_t* perm_out, void* key_data_out, uint8_t* key_validity_out, int* decoded_out);
+
 /* SortExec: writes the permutation (driving positions in sorted order; stable) to perm_out (n_rows).
    The call reads the key range back (one stream synchronisation in the middle).  From 2^22 rows on the range comes from a row
    sample and the pack kernel verifies it; the call then waits for one word at the end and re-runs with the exact range when the

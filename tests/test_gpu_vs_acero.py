@@ -157,3 +157,40 @@ def test_more_than_four_group_columns_equal_aceros(tc):
     a = t.group_by(keys, use_threads=False).aggregate([("v", "sum"), ([], "count_all"), ("v", "min")])
     exp = list(zip(*([a[k].cast(pa.int32()).to_pylist() if k == "e" else a[k].to_pylist() for k in keys] + [a["v_sum"].to_pylist(), a["count_all"].to_pylist(), a["v_min"].to_pylist()])))
     assert _key(got) == _key(exp)
+
+
+@pytest.mark.parametrize("asc,nulls_first", [(True, False), (False, True), (True, True), (False, False)])
+def test_single_key_sort_hands_the_key_column_back_in_order(tc, asc, nulls_first):
+    """ORDER BY one plain integer-like column over more rows than one block sorts: the sorted key column is rebuilt from the sort's own
+    records (gpuq_sort_run_keys) instead of gathered -- values, NULLs, and every other column (through the permutation) must be what a stable
+    sort gives, for every key type the decode takes, ascending and descending, NULLS FIRST and LAST; then once more deferred."""
+    import decimal
+    r = np.random.default_rng(61)
+    n = (1 << 20) + 12345
+
+    def m():
+        return r.random(n) < 0.05
+    t = pa.table({
+        "i64": pa.array(r.integers(-10**12, 10**12, n), pa.int64(), mask=m()),
+        "i32": pa.array(r.integers(-2**31, 2**31 - 1, n).astype(np.int32), pa.int32(), mask=m()),
+        "i16": pa.array(r.integers(-2**15, 2**15, n).astype(np.int16), pa.int16()),
+        "u8": pa.array(r.integers(0, 256, n).astype(np.uint8), pa.uint8(), mask=m()),
+        "d32": pa.array(r.integers(-5000, 20000, n).astype(np.int32), pa.int32()).cast(pa.date32()),
+        "ts": pa.array(r.integers(0, 10**15, n), pa.timestamp("us"), mask=m()),
+        "dec": pa.array(r.integers(-10**11, 10**11, n), pa.int64()).cast(pa.decimal128(19, 0)).cast(pa.decimal128(21, 2)),
+        "id": pa.array(np.arange(n), pa.int64()),
+        "s": pa.array(np.array(["a", "bb", "a string longer than fifteen bytes"])[r.integers(0, 3, n)]),
+    })
+    src = g.MemoryExec([t])
+    s = src.schema()
+    for key in ("i64", "i32", "i16", "u8", "d32", "ts", "dec"):
+        plan = g.NativePlan(g.SortExec([{"expr": col(key, s), "asc": asc, "nulls_first": nulls_first}], src), tc)
+        idx = pc.sort_indices(t, sort_keys=[(key, "ascending" if asc else "descending")], null_placement="at_start" if nulls_first else "at_end")
+        want = t.take(idx)
+        for _ in range(2):      # synchronous, then deferred
+            out = plan.execute(0).to_arrow()
+            for name in t.column_names:
+                a, b = out[name].combine_chunks(), want[name].combine_chunks()
+                if pa.types.is_timestamp(b.type):
+                    a, b = a.cast(pa.int64()), b.cast(pa.int64())
+                assert a.equals(b), (key, name)
