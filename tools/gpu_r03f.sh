@@ -2,7 +2,7 @@
 # round 3 step f: evidence for the headline: bench line, kernel trace + stats of the same command, PMC traffic passes for the probe kernel
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-O=gpurun_out/r03f; mkdir -p $O
+O=gpurun_out/r03f; rm -rf $O/q3_trace $O/pmc_fetch $O/pmc_write; mkdir -p $O
 timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 echo "bench done"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/q3_trace -- python3 bench.py --no-cpu-baseline --no-extras > $O/q3_trace.log 2>&1 || { tail -20 $O/q3_trace.log; exit 1; }
