@@ -2253,7 +2253,13 @@ int gpuq_table_import_arrow(gpuq_ctx* ctx, void* stream, const struct ArrowArray
         const int64_t base = idx ? 0 : utf8_off(a, off);
         const int64_t last = idx ? v_offs[(size_t)n] : (n > 0 ? utf8_off(a, off + n) - base : 0);
         if (last > 0x7FFFFFFFll) throw Unsupported("a Utf8 column of more than 2^31 bytes (split the batch)");
-        for (int64_t i = 0; i <= n; ++i) o32[(size_t)i] = (int32_t)(idx ? v_offs[(size_t)i] : utf8_off(a, off + i) - base);
+        if (last < 0) throw std::runtime_error("Utf8 offsets of column '" + std::string(nm ? nm : "") + "' decrease");
+        int64_t prev = 0;
+        for (int64_t i = 0; i <= n; ++i) {      // (the offsets are the producer's: a decreasing or negative one must not become a copy length)
+          const int64_t o = idx ? v_offs[(size_t)i] : utf8_off(a, off + i) - base;
+          if (o < prev || o > last) throw std::runtime_error("Utf8 offsets of column '" + std::string(nm ? nm : "") + "' are not non-decreasing");
+          o32[(size_t)i] = (int32_t)o; prev = o;
+        }
         ic->offsets.ensure((size_t)(n + 1) * 4 + 16); g_staging.h2d(s, ic->offsets.p, o32.data(), (size_t)(n + 1) * 4); g_staging.drain();
         ic->data.ensure((size_t)last + 16);
         if (last > 0) { g_staging.h2d(s, ic->data.p, idx ? (const void*)v_data.data() : (const void*)((const char*)a->buffers[2] + base), (size_t)last); g_staging.drain(); }

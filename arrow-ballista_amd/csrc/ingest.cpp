@@ -119,9 +119,14 @@ struct gpuq_ingest {
         // (LargeUtf8: 64-bit offsets on the host side; the partition's own offsets are 32-bit, its byte total is bounded by max_utf8_bytes)
         const int64_t o0 = utf8_off(k, a, off);
         const int64_t nbytes = utf8_off(k, a, off + n) - o0;
+        if (nbytes < 0) throw std::runtime_error("ingest: Utf8 offsets of column '" + k.name + "' decrease");
         int32_t* q = (int32_t*)stage((size_t)(n + 1) * 4);
         const int64_t delta = job.byte0[c] - o0;
-        for (int64_t i = 0; i <= n; ++i) q[i] = (int32_t)(utf8_off(k, a, off + i) + delta);      // rebased to the partition's running byte total
+        for (int64_t i = 0; i <= n; ++i) {      // rebased to the partition's running byte total
+          const int64_t o = utf8_off(k, a, off + i);
+          if (o < o0 || o > o0 + nbytes || (i > 0 && o < utf8_off(k, a, off + i - 1))) throw std::runtime_error("ingest: Utf8 offsets of column '" + k.name + "' are not non-decreasing");
+          q[i] = (int32_t)(o + delta);
+        }
         HIPCHECK(hipMemcpyAsync((int32_t*)k.offsets.p + job.row0, q, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, w.stream));
         if (nbytes > 0) {
           char* d = stage((size_t)nbytes);
@@ -201,6 +206,7 @@ int gpuq_ingest_push(gpuq_ingest* g, struct ArrowArray* batch) {
       if (g->cols[c].type.id != T_UTF8 || n == 0) continue;
       const ArrowArray* a = batch->children[c];
       const int64_t nb = gpuq_ingest::utf8_off(g->cols[c], a, a->offset + batch->offset + n) - gpuq_ingest::utf8_off(g->cols[c], a, a->offset + batch->offset);
+      if (nb < 0) throw std::runtime_error("ingest: Utf8 offsets of column '" + g->cols[c].name + "' decrease");
       if (g->next_byte[c] + nb > g->cols[c].bytes_cap || g->next_byte[c] + nb > 0x7FFFFFFFll) throw Capacity("ingest: column '" + g->cols[c].name + "' exceeds max_utf8_bytes");
       g->next_byte[c] += nb;
     }

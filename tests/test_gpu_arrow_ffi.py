@@ -90,3 +90,18 @@ def test_import_filter_export_round_trip(tc):
     for b in bufs + [sel, cnt]:
         L.gpuq_buffer_free(ctx.h, b)
     L.gpuq_table_free(h)
+
+
+def test_import_refuses_offsets_that_decrease(tc):
+    """The Utf8 offsets of an imported batch are the producer's: a decreasing pair must be an error, not a copy length."""
+    ctx, L = tc.ctx, tc.ctx.L
+    good = pa.array(["ab", "cde", "", "f"])
+    bufs = good.buffers()
+    bad_offsets = np.array([0, 2, 5, 4, 6], dtype=np.int32)          # 5 -> 4
+    bad = pa.Array.from_buffers(pa.string(), 4, [bufs[0], pa.py_buffer(bad_offsets.tobytes()), bufs[2]])
+    batch = pa.RecordBatch.from_arrays([bad], ["s"])
+    ca, cs = ArrowArray(), ArrowSchema()
+    batch._export_to_c(C.addressof(ca), C.addressof(cs))
+    h = C.c_void_p()
+    rc = L.gpuq_table_import_arrow(ctx.h, None, C.addressof(ca), C.addressof(cs), C.byref(h))
+    assert rc == 1 and b"non-decreasing" in L.gpuq_last_error(ctx.h)
