@@ -1187,7 +1187,9 @@ static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, g
       const bool use_lds = strat == "lds" || (strat == "auto" && lslots > 0 && n >= (1ll << 17) && known > 0 && known <= (i64)lslots * 4);
       if (strat == "lds" && !lslots) throw Unsupported("lds aggregate: the group state does not fit an LDS table");
       for (;;) {
-        T.n_slots = next_pow2(est * 2);
+        // (tuning switch: GPUQ_AGG_SLOT_PCT = slots per estimated group in percent before rounding up to a power of two; 200 = the default)
+        static const u64 slot_pct = []() { const char* e = std::getenv("GPUQ_AGG_SLOT_PCT"); const long v = e ? std::atol(e) : 200; return (u64)(v >= 110 && v <= 800 ? v : 200); }();
+        T.n_slots = next_pow2(est * slot_pct / 100);
         T.slots = (u64*)op->ws[5].ensure((size_t)T.n_slots * T.slot_words * 8);
         launch_ht_init(s, T, &op->agg);
         reset_flags(op, s);
