@@ -223,8 +223,17 @@ void launch_utf8_piece_starts(hipStream_t s, Utf8Piece* pieces, int n_pieces, ui
 void launch_utf8_piece_offsets(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_rows);
 void launch_utf8_piece_validate(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_rows, uint32_t* status);
 void launch_utf8_piece_compact(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_bytes, const uint8_t* from, uint8_t* to);
-struct UnpackJob { int64_t src, dst, src_len, dst_len, raw_prefix; int32_t mode /* 0 stored, 1 snappy */, pad; };      // one Parquet page (kernels_lz4.hip)
+struct UnpackJob { int64_t src, dst, src_len, dst_len, raw_prefix; int32_t mode /* 0 stored, 1 snappy */, pad; int64_t s_off, c_off; };      // one Parquet page (kernels_lz4.hip); s_off / c_off: its place in the resolve array / the per-position arrays
 void launch_unpack_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, int n_jobs, uint32_t* status);
+// Snappy without a serial element walk (kernels_lz4.hip).  resolve: one 32-bit word per uncompressed byte of the Snappy jobs (s_off); blkmap: (job, first
+// byte) per 4096 of them.  jump_a / jump_b / olen (32-bit) and mark (8-bit): one entry per compressed byte + one per job (c_off; c_slots in all, + 1 for the
+// scan); cmap: (job, first position) per 4096 of those.  counts: (mark_rounds + rounds + 3) * n_jobs zeroed words.
+struct SnappyPjBuffers {
+  uint32_t* resolve; const uint2* blkmap; int n_blocks; int rounds;
+  uint32_t* jump_a; uint32_t* jump_b; uint32_t* olen; uint8_t* mark; const uint2* cmap; int n_cblocks; int mark_rounds; int64_t c_slots;
+  void* scan_ws; size_t scan_ws_bytes; uint32_t* counts;
+};
+void launch_unpack_pages_pj(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, int n_jobs, const SnappyPjBuffers& B, uint32_t* status);
 void launch_utf8_code_rows(hipStream_t s, const void* codes, int width, const uint8_t* validity, i64 n, uint32_t* rows);      // width 8 (Int64) or 4 (UInt32)
 void launch_utf8_sort_piece(hipStream_t s, const uint8_t* data, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int piece, void* out, u64* valid_out);
 void launch_utf8_max_len(hipStream_t s, const int32_t* offsets, const uint8_t* validity, const uint32_t* idx, i64 n, int32_t* out);

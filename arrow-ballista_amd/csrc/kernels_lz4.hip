@@ -505,6 +505,206 @@ void launch_popcount_bits(hipStream_t s, const uint8_t* bits, int64_t n_bits, un
   hipLaunchKernelGGL(k_popcount_bits, dim3((unsigned)blocks), dim3(256), 0, s, (const u64*)bits, n_bits, out);
 }
 
+// ---------------------------------------------------------------- Snappy by pointer jumping
+// The element chain of k_unpack_pages is serial AND moves the bytes: ~1000 cycles per element (LDS ring round trips, two wave barriers per
+// copy), 10 MB/s per page.  Here the serial part only WALKS the elements: every output byte gets a 32-bit word -- bit 31 set: resolved, the
+// byte's value in the low 8 bits (literals); clear: the position in the page it is a copy of (always earlier) -- and the copies are
+// resolved afterwards by pointer jumping, all bytes of all pages in parallel: word[p] = word[word[p]] until bit 31 is set.  A chain of d
+// copies (sorted 64-bit keys: every value's high bytes are a copy of the previous value's, d = rows per page) resolves in log2(d) rounds;
+// updates in place only ever shorten a chain, and a resolved word carries the value itself, so there is nothing to order between
+// threads.  The last kernel writes the bytes.  Malformed input: the same checks as k_unpack_pages (an offset of 0 or beyond the output so
+// far, lengths past either end); a word still unresolved after ceil(log2(page bytes)) + 1 rounds cannot happen for a checked stream and
+// is reported as malformed.
+constexpr uint32_t PJ_DONE = 0x80000000u;
+constexpr int PJ_BLOCK_BYTES = 4096;
+// -- the front half, parallel too.  An element's size and output length depend only on the bytes at its own position, so next(p) and
+// olen(p) are computed for EVERY position of the compressed stream as if an element started there; the real elements are the positions on
+// the path start -> next(start) -> ... -> end, found by doubling: marked positions mark jump(p), then jump = jump o jump (ping-pong arrays; a
+// round that marks nothing new has closed the path).  An exclusive scan of olen over the marked positions gives every element its place
+// in the output, and the elements are expanded into resolve words all at once.  (Walking the elements one after the other, as
+// k_unpack_pages and a first version of this path did, costs ~1000 cycles per element on a lone wave: 112 ms for a 1 MB page of sorted
+// keys, whatever the copying costs.)
+struct SnElem { int64_t size; uint32_t olen; int kind; uint32_t off; int64_t lit; };      // kind 0 literal (lit = first data byte), 1 copy
+__device__ __forceinline__ SnElem sn_element(const uint8_t* __restrict__ in, const int64_t p, const int64_t L) {
+  SnElem e{1, 0u, 0, 0u, 0};
+  uint32_t b[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) b[k] = p + k < L ? in[p + k] : 0u;
+  const uint32_t tag = b[0];
+  if ((tag & 3) == 0) {
+    int64_t len = (int64_t)(tag >> 2) + 1; int nb = 0;
+    if (len > 60) { nb = (int)len - 60; uint32_t v = 0; for (int k = 0; k < nb; ++k) v |= b[1 + k] << (8 * k); len = (int64_t)v + 1; }
+    e.size = 1 + nb + len; e.olen = (uint32_t)len; e.kind = 0; e.lit = p + 1 + nb;
+  } else if ((tag & 3) == 1) { e.size = 2; e.olen = 4 + ((tag >> 2) & 7); e.kind = 1; e.off = ((tag >> 5) << 8) | b[1]; }
+  else if ((tag & 3) == 2) { e.size = 3; e.olen = (tag >> 2) + 1; e.kind = 1; e.off = b[1] | (b[2] << 8); }
+  else { e.size = 5; e.olen = (tag >> 2) + 1; e.kind = 1; e.off = b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24); }
+  return e;
+}
+constexpr uint32_t SN_BAD = 0xFFFFFFFFu;
+// per job (one wave): the raw prefix and stored pages are copied; a Snappy page's length preamble is read and its first element marked
+__global__ __launch_bounds__(64) void k_sn_head(const uint8_t* __restrict__ src_base, uint8_t* __restrict__ dst_base, const UnpackJob* __restrict__ jobs, int n_jobs,
+                                                uint8_t* __restrict__ mark, uint32_t* __restrict__ status) {
+  const int u = (int)blockIdx.x;
+  if (u >= n_jobs) return;
+  const UnpackJob J = jobs[u];
+  const int lane = lane_id();
+  const uint8_t* in = src_base + J.src; uint8_t* out = dst_base + J.dst;
+  if (J.raw_prefix > J.src_len || J.raw_prefix > J.dst_len) { if (lane == 0) atomicOr(status, 1u); return; }
+  for (int64_t i = lane; i < J.raw_prefix; i += 64) out[i] = in[i];
+  in += J.raw_prefix; out += J.raw_prefix;
+  const int64_t L = J.src_len - J.raw_prefix, out_len = J.dst_len - J.raw_prefix;
+  if (J.mode == 0) {
+    if (L != out_len) { if (lane == 0) atomicOr(status, 1u); return; }
+    for (int64_t i = lane; i < L; i += 64) out[i] = in[i];
+    return;
+  }
+  if (lane == 0) {
+    uint64_t ulen = 0; int sh = 0; int64_t ip = 0; bool bad = false;
+    for (;;) { if (ip >= L || sh > 35) { bad = true; break; } const uint32_t c = in[ip++]; ulen |= (uint64_t)(c & 0x7F) << sh; if (!(c & 0x80)) break; sh += 7; }
+    if (bad || (int64_t)ulen != out_len || out_len >= (int64_t)PJ_DONE) atomicOr(status, 1u);
+    else mark[J.c_off + ip] = 1;      // (an empty page: ip == L, the terminal slot)
+  }
+}
+// every position: where the element that would start here ends, and how many bytes it would produce
+__global__ __launch_bounds__(256) void k_sn_next(const uint8_t* __restrict__ src_base, const uint2* __restrict__ cmap, const UnpackJob* __restrict__ jobs, uint32_t* __restrict__ jump, uint32_t* __restrict__ olen) {
+  const uint2 m = cmap[blockIdx.x];
+  const UnpackJob J = jobs[m.x];
+  const uint8_t* in = src_base + J.src + J.raw_prefix;
+  const int64_t L = J.src_len - J.raw_prefix;
+  for (int k = 0; k < PJ_BLOCK_BYTES / 256; ++k) {
+    const int64_t p = (int64_t)m.y + k * 256 + threadIdx.x;
+    if (p > L) continue;
+    uint32_t nx = (uint32_t)L, ol = 0;
+    if (p < L) {
+      const SnElem e = sn_element(in, p, L);
+      if (p + e.size > L) ol = SN_BAD; else { nx = (uint32_t)(p + e.size); ol = e.olen; }
+    }
+    jump[J.c_off + p] = nx; olen[J.c_off + p] = ol;
+  }
+}
+// one doubling round: marked positions mark where they jump to; jump_out = jump_in o jump_in
+__global__ __launch_bounds__(256) void k_sn_mark(const uint2* __restrict__ cmap, const UnpackJob* __restrict__ jobs, const uint32_t* __restrict__ jin, uint32_t* __restrict__ jout, uint8_t* __restrict__ mark,
+                                                 const uint32_t* __restrict__ cnt_prev, uint32_t* __restrict__ cnt_cur, const int first) {
+  const uint2 m = cmap[blockIdx.x];
+  if (!first && cnt_prev[m.x] == 0) return;
+  const UnpackJob J = jobs[m.x];
+  const int64_t L = J.src_len - J.raw_prefix;
+  uint32_t fresh = 0;
+  for (int k = 0; k < PJ_BLOCK_BYTES / 256; ++k) {
+    const int64_t p = (int64_t)m.y + k * 256 + threadIdx.x;
+    if (p > L) continue;
+    const uint32_t j = jin[J.c_off + p];
+    if (mark[J.c_off + p] && !mark[J.c_off + j]) { mark[J.c_off + j] = 1; ++fresh; }
+    jout[J.c_off + p] = jin[J.c_off + j];
+  }
+  for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+  if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&cnt_cur[m.x], fresh);
+}
+// scan input: the output length of every real element
+__global__ __launch_bounds__(256) void k_sn_lens(const uint2* __restrict__ cmap, const UnpackJob* __restrict__ jobs, const uint8_t* __restrict__ mark, const uint32_t* __restrict__ olen,
+                                                 int32_t* __restrict__ pos, uint32_t* __restrict__ status) {
+  const uint2 m = cmap[blockIdx.x];
+  const UnpackJob J = jobs[m.x];
+  const int64_t L = J.src_len - J.raw_prefix;
+  for (int k = 0; k < PJ_BLOCK_BYTES / 256; ++k) {
+    const int64_t p = (int64_t)m.y + k * 256 + threadIdx.x;
+    if (p > L) continue;
+    uint32_t v = 0;
+    if (mark[J.c_off + p] && p < L) { v = olen[J.c_off + p]; if (v == SN_BAD || v >= PJ_DONE) { v = 0; atomicOr(status, 1u); } }      // an element that runs past the end of the page
+    if (p == L && !mark[J.c_off + p]) atomicOr(status, 1u);                                                                             // the path must end exactly at the end
+    pos[J.c_off + p] = (int32_t)v;
+  }
+}
+// every real element into its resolve words
+__global__ __launch_bounds__(256) void k_sn_fill(const uint8_t* __restrict__ src_base, const uint2* __restrict__ cmap, const UnpackJob* __restrict__ jobs, const uint8_t* __restrict__ mark,
+                                                 const int32_t* __restrict__ pos, uint32_t* __restrict__ resolve, uint32_t* __restrict__ status) {
+  const uint2 m = cmap[blockIdx.x];
+  const UnpackJob J = jobs[m.x];
+  const uint8_t* in = src_base + J.src + J.raw_prefix;
+  const int64_t L = J.src_len - J.raw_prefix, out_len = J.dst_len - J.raw_prefix;
+  uint32_t* S = resolve + J.s_off;
+  const int64_t base = pos[J.c_off];
+  for (int k = 0; k < PJ_BLOCK_BYTES / 256; ++k) {
+    const int64_t p = (int64_t)m.y + k * 256 + threadIdx.x;
+    if (p > L || !mark[J.c_off + p]) continue;
+    const int64_t o = (int64_t)pos[J.c_off + p] - base;
+    if (p == L) { if (o != out_len) atomicOr(status, 1u); continue; }      // the elements must produce exactly the announced length
+    const SnElem e = sn_element(in, p, L);
+    if (p + e.size > L || o + (int64_t)e.olen > out_len) { atomicOr(status, 1u); continue; }
+    if (e.kind == 0) { for (uint32_t i = 0; i < e.olen; ++i) S[o + i] = PJ_DONE | (uint32_t)in[e.lit + i]; }
+    else {
+      if (e.off == 0 || (int64_t)e.off > o) { atomicOr(status, 1u); continue; }
+      const uint32_t from = (uint32_t)(o - e.off);
+      for (uint32_t i = 0; i < e.olen; ++i) S[o + i] = from + (e.off >= e.olen ? i : i % e.off);
+    }
+  }
+}
+// one round: word[p] = word[word[p]] for every unresolved word of every page that still had one after the previous round
+__global__ __launch_bounds__(256) void k_snappy_round(uint32_t* __restrict__ resolve, const uint2* __restrict__ blkmap, const UnpackJob* __restrict__ jobs, const uint32_t* __restrict__ cnt_prev,
+                                                      uint32_t* __restrict__ cnt_cur, const int first) {
+  const uint2 m = blkmap[blockIdx.x];
+  if (!first && cnt_prev[m.x] == 0) return;
+  const UnpackJob J = jobs[m.x];
+  uint32_t* S = resolve + J.s_off;
+  const int64_t len = J.dst_len - J.raw_prefix;
+  uint32_t left = 0;
+#pragma unroll 4
+  for (int k = 0; k < PJ_BLOCK_BYTES / 256; ++k) {
+    const int64_t p = (int64_t)m.y + k * 256 + threadIdx.x;
+    if (p < len) {
+      const uint32_t v = S[p];
+      if (!(v & PJ_DONE)) {
+        const uint32_t w = (int64_t)v < p ? S[v] : PJ_DONE;      // (v < p always for a checked stream; anything else ends here, harmlessly)
+        S[p] = w;
+        left += (w & PJ_DONE) ? 0u : 1u;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) left += __shfl_xor(left, o);
+  if ((threadIdx.x & 63) == 0 && left) atomicAdd(&cnt_cur[m.x], left);
+}
+// the bytes: four resolved words -> one 32-bit store (the pages start 64-byte aligned)
+__global__ __launch_bounds__(256) void k_snappy_emit(const uint32_t* __restrict__ resolve, const uint2* __restrict__ blkmap, const UnpackJob* __restrict__ jobs, uint8_t* __restrict__ dst_base,
+                                                     uint32_t* __restrict__ status) {
+  const uint2 m = blkmap[blockIdx.x];
+  const UnpackJob J = jobs[m.x];
+  const uint32_t* S = resolve + J.s_off;
+  uint8_t* out = dst_base + J.dst + J.raw_prefix;
+  const int64_t len = J.dst_len - J.raw_prefix;
+  bool bad = false;
+  for (int k = 0; k < PJ_BLOCK_BYTES / 1024; ++k) {
+    const int64_t p = (int64_t)m.y + (int64_t)(k * 256 + threadIdx.x) * 4;
+    if (p >= len) continue;
+    if (p + 4 <= len && (((uintptr_t)(out + p)) & 3) == 0) {
+      const uint4 v = *(const uint4*)(S + p);      // s_off and m.y are multiples of 4 words: aligned
+      bad = bad || !((v.x & v.y & v.z & v.w) & PJ_DONE);
+      *(uint32_t*)(out + p) = (v.x & 0xFF) | ((v.y & 0xFF) << 8) | ((v.z & 0xFF) << 16) | ((v.w & 0xFF) << 24);
+    } else for (int64_t q = p; q < p + 4 && q < len; ++q) { const uint32_t v = S[q]; bad = bad || !(v & PJ_DONE); out[q] = (uint8_t)v; }
+  }
+  if (bad) atomicOr(status, 1u);
+}
+void launch_unpack_pages_pj(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, int n_jobs, const SnappyPjBuffers& B, uint32_t* status) {
+  if (n_jobs <= 0) return;
+  // front: which positions of the compressed streams are elements, and where their output goes
+  hipLaunchKernelGGL(k_sn_head, dim3((unsigned)n_jobs), dim3(64), 0, s, src, dst, jobs, n_jobs, B.mark, status);
+  if (B.n_cblocks <= 0 || B.n_blocks <= 0) return;
+  hipLaunchKernelGGL(k_sn_next, dim3((unsigned)B.n_cblocks), dim3(256), 0, s, src, B.cmap, jobs, B.jump_a, B.olen);
+  uint32_t* ja = B.jump_a; uint32_t* jb = B.jump_b;
+  for (int r = 0; r < B.mark_rounds; ++r) {
+    hipLaunchKernelGGL(k_sn_mark, dim3((unsigned)B.n_cblocks), dim3(256), 0, s, B.cmap, jobs, (const uint32_t*)ja, jb, B.mark, B.counts + (size_t)r * n_jobs, B.counts + (size_t)(r + 1) * n_jobs, r == 0 ? 1 : 0);
+    std::swap(ja, jb);
+  }
+  int32_t* pos = (int32_t*)B.jump_b;      // (both jump arrays are free now)
+  hipLaunchKernelGGL(k_sn_lens, dim3((unsigned)B.n_cblocks), dim3(256), 0, s, B.cmap, jobs, (const uint8_t*)B.mark, (const uint32_t*)B.olen, pos, status);
+  launch_exclusive_scan_i32(s, pos, B.c_slots, B.scan_ws, B.scan_ws_bytes);
+  hipLaunchKernelGGL(k_sn_fill, dim3((unsigned)B.n_cblocks), dim3(256), 0, s, src, B.cmap, jobs, (const uint8_t*)B.mark, (const int32_t*)pos, B.resolve, status);
+  // back: copies resolved by pointer jumping, then the bytes
+  uint32_t* c2 = B.counts + (size_t)(B.mark_rounds + 1) * n_jobs;
+  for (int r = 0; r < B.rounds; ++r)
+    hipLaunchKernelGGL(k_snappy_round, dim3((unsigned)B.n_blocks), dim3(256), 0, s, B.resolve, B.blkmap, jobs, c2 + (size_t)r * n_jobs, c2 + (size_t)(r + 1) * n_jobs, r == 0 ? 1 : 0);
+  hipLaunchKernelGGL(k_snappy_emit, dim3((unsigned)B.n_blocks), dim3(256), 0, s, (const uint32_t*)B.resolve, B.blkmap, jobs, dst, status);
+}
+
 void launch_unpack_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, int n_jobs, uint32_t* status) {
   if (n_jobs > 0) hipLaunchKernelGGL(k_unpack_pages, dim3((unsigned)n_jobs), dim3(64), 0, s, src, dst, jobs, n_jobs, status);
 }

@@ -413,7 +413,7 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
     auto place = [&](int64_t src, int comp, int uncomp, int raw_prefix, int mode) -> int64_t {      // -> the page's position for the decoders
       if (!any_compressed) return src;
       const int64_t dst = page_bytes; page_bytes += ((int64_t)uncomp + 63) & ~(int64_t)63;
-      jobs.push_back({src, dst, comp, uncomp, raw_prefix, mode, 0});
+      jobs.push_back({src, dst, comp, uncomp, raw_prefix, mode, 0, 0, 0});
       return dst;
     };
     for (int li : proj) {
@@ -471,11 +471,52 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
     DevBuf dfile; dfile.ensure((size_t)up_bytes + 64);
     g_uploader.copy_segments(ctx->device, s, dfile.p, segs);
     DevBuf flags; flags.ensure(16); HIPCHECK(hipMemsetAsync(flags.p, 0, 16, s));
-    DevBuf dpagebuf, djobs;
+    DevBuf dpagebuf, djobs, dresolve, dblk, dcblk, dcnt, dja, djb, dolen, dmark, dscan;
     const uint8_t* pages_base = (const uint8_t*)dfile.p; int64_t pages_bytes = up_bytes;
     if (any_compressed) {
       dpagebuf.ensure((size_t)page_bytes + 64); djobs.ensure(jobs.size() * sizeof(UnpackJob) + 64);
       HIPCHECK(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(UnpackJob), hipMemcpyHostToDevice, s));
+      // Snappy pages are decoded without a serial element walk (kernels_lz4.hip: positions -> path by doubling -> scan -> resolve words ->
+      // pointer jumping) when the scratch fits the budget: a 32-bit word per uncompressed byte (<= 2 Gi words per call: row groups of ~1 GB)
+      // and 13 bytes per compressed byte; beyond that, or with GPUQ_SNAPPY_PJ=0, the serial decoder
+      static const bool pj_on = []() { const char* e = std::getenv("GPUQ_SNAPPY_PJ"); return !(e && e[0] == '0'); }();
+      int64_t words = 0, max_len = 0, slots = 0, max_in = 0; bool any_snappy = false;
+      for (auto& j : jobs) {
+        j.s_off = words; j.c_off = slots;
+        if (j.mode == 1 && j.raw_prefix <= j.src_len && j.raw_prefix <= j.dst_len) {
+          const int64_t len = j.dst_len - j.raw_prefix, cl = j.src_len - j.raw_prefix;
+          any_snappy = true; words += (len + 3) & ~(int64_t)3; slots += cl + 1;
+          if (len > max_len) max_len = len; if (cl > max_in) max_in = cl;
+        }
+      }
+      if (pj_on && any_snappy && words > 0 && words <= (int64_t)1 << 31 && slots < ((int64_t)1 << 31) && max_len < ((int64_t)1 << 31)) {
+        std::vector<uint2> blk, cblk;
+        for (size_t k = 0; k < jobs.size(); ++k) if (jobs[k].mode == 1 && jobs[k].raw_prefix <= jobs[k].src_len && jobs[k].raw_prefix <= jobs[k].dst_len) {
+          const int64_t len = jobs[k].dst_len - jobs[k].raw_prefix, cl = jobs[k].src_len - jobs[k].raw_prefix;
+          for (int64_t b = 0; b < len; b += 4096) blk.push_back(make_uint2((uint32_t)k, (uint32_t)b));
+          for (int64_t b = 0; b <= cl; b += 4096) cblk.push_back(make_uint2((uint32_t)k, (uint32_t)b));
+        }
+        int rounds = 1; while (((int64_t)1 << rounds) < max_len) ++rounds;
+        rounds += 1;
+        int mrounds = 1; while (((int64_t)1 << mrounds) < max_in + 1) ++mrounds;
+        mrounds += 1;
+        const size_t nj = jobs.size();
+        dresolve.ensure((size_t)words * 4 + 64); dblk.ensure(blk.size() * sizeof(uint2) + 64); dcblk.ensure(cblk.size() * sizeof(uint2) + 64);
+        dcnt.ensure((size_t)(rounds + mrounds + 3) * nj * 4 + 64);
+        dja.ensure((size_t)(slots + 1) * 4 + 64); djb.ensure((size_t)(slots + 1) * 4 + 64); dolen.ensure((size_t)(slots + 1) * 4 + 64); dmark.ensure((size_t)slots + 64);
+        const size_t swb = exclusive_scan_ws_bytes(slots + 1); dscan.ensure(swb);
+        HIPCHECK(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(UnpackJob), hipMemcpyHostToDevice, s));      // (again: with the s_off / c_off fields)
+        if (!blk.empty()) HIPCHECK(hipMemcpyAsync(dblk.p, blk.data(), blk.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+        if (!cblk.empty()) HIPCHECK(hipMemcpyAsync(dcblk.p, cblk.data(), cblk.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemsetAsync(dcnt.p, 0, (size_t)(rounds + mrounds + 3) * nj * 4, s));
+        HIPCHECK(hipMemsetAsync(dmark.p, 0, (size_t)slots + 64, s));
+        SnappyPjBuffers B{};
+        B.resolve = (uint32_t*)dresolve.p; B.blkmap = (const uint2*)dblk.p; B.n_blocks = (int)blk.size(); B.rounds = rounds;
+        B.jump_a = (uint32_t*)dja.p; B.jump_b = (uint32_t*)djb.p; B.olen = (uint32_t*)dolen.p; B.mark = (uint8_t*)dmark.p; B.cmap = (const uint2*)dcblk.p; B.n_cblocks = (int)cblk.size();
+        B.mark_rounds = mrounds; B.c_slots = slots; B.scan_ws = dscan.p; B.scan_ws_bytes = swb; B.counts = (uint32_t*)dcnt.p;
+        launch_unpack_pages_pj(s, (const uint8_t*)dfile.p, (uint8_t*)dpagebuf.p, (const UnpackJob*)djobs.p, (int)jobs.size(), B, (uint32_t*)flags.p + 1);
+        HIPCHECK(hipStreamSynchronize(s));      // the block maps (pageable host memory) must outlive their copies
+      } else
       launch_unpack_pages(s, (const uint8_t*)dfile.p, (uint8_t*)dpagebuf.p, (const UnpackJob*)djobs.p, (int)jobs.size(), (uint32_t*)flags.p + 1);
       pages_base = (const uint8_t*)dpagebuf.p; pages_bytes = page_bytes;
     }
