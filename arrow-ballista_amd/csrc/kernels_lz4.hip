@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void k_sn_fill(const uint8_t* __restrict__ src
     const int64_t o = (int64_t)pos[J.c_off + p] - base;
     if (p == L) { if (o != out_len) atomicOr(status, 1u); continue; }      // the elements must produce exactly the announced length
     const SnElem e = sn_element(in, p, L);
-    if (p + e.size > L || o + (int64_t)e.olen > out_len) { atomicOr(status, 1u); continue; }
+    if (p + e.size > L || o < 0 || o + (int64_t)e.olen > out_len) { atomicOr(status, 1u); continue; }      // (o < 0: a corrupted stream whose announced lengths wrapped the 32-bit scan)
     if (e.kind == 0) { for (uint32_t i = 0; i < e.olen; ++i) S[o + i] = PJ_DONE | (uint32_t)in[e.lit + i]; }
     else {
       if (e.off == 0 || (int64_t)e.off > o) { atomicOr(status, 1u); continue; }
