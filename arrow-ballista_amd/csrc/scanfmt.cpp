@@ -477,45 +477,54 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
       dpagebuf.ensure((size_t)page_bytes + 64); djobs.ensure(jobs.size() * sizeof(UnpackJob) + 64);
       HIPCHECK(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(UnpackJob), hipMemcpyHostToDevice, s));
       // Snappy pages are decoded without a serial element walk (kernels_lz4.hip: positions -> path by doubling -> scan -> resolve words ->
-      // pointer jumping) when the scratch fits the budget: a 32-bit word per uncompressed byte (<= 2 Gi words per call: row groups of ~1 GB)
-      // and 13 bytes per compressed byte; beyond that, or with GPUQ_SNAPPY_PJ=0, the serial decoder
+      // pointer jumping), in batches of consecutive pages whose scratch -- a 32-bit word per uncompressed byte, 13 bytes per compressed
+      // byte -- stays within ~5 GB (2^30 words); GPUQ_SNAPPY_PJ=0 (or a single page beyond that) keeps the serial decoder
       static const bool pj_on = []() { const char* e = std::getenv("GPUQ_SNAPPY_PJ"); return !(e && e[0] == '0'); }();
-      int64_t words = 0, max_len = 0, slots = 0, max_in = 0; bool any_snappy = false;
-      for (auto& j : jobs) {
-        j.s_off = words; j.c_off = slots;
-        if (j.mode == 1 && j.raw_prefix <= j.src_len && j.raw_prefix <= j.dst_len) {
-          const int64_t len = j.dst_len - j.raw_prefix, cl = j.src_len - j.raw_prefix;
-          any_snappy = true; words += (len + 3) & ~(int64_t)3; slots += cl + 1;
-          if (len > max_len) max_len = len; if (cl > max_in) max_in = cl;
+      const int64_t max_words = (int64_t)1 << 30;
+      bool any_snappy = false, fits = true;
+      for (auto& j : jobs) if (j.mode == 1) { any_snappy = true; if (j.dst_len > max_words || j.src_len > max_words) fits = false; }
+      if (pj_on && any_snappy && fits) {
+        HIPCHECK(hipMemsetAsync(dmark.ensure(64), 0, 64, s));
+        size_t first = 0;
+        while (first < jobs.size()) {
+          int64_t words = 0, max_len = 0, slots = 0, max_in = 0;
+          size_t last = first;
+          std::vector<uint2> blk, cblk;
+          for (; last < jobs.size(); ++last) {
+            UnpackJob& j = jobs[last];
+            const bool sn = j.mode == 1 && j.raw_prefix <= j.src_len && j.raw_prefix <= j.dst_len;
+            const int64_t len = sn ? j.dst_len - j.raw_prefix : 0, cl = sn ? j.src_len - j.raw_prefix : 0;
+            if (last > first && sn && (words + len > max_words || slots + cl + 1 > max_words)) break;
+            j.s_off = words; j.c_off = slots;
+            if (!sn) continue;
+            const uint32_t k = (uint32_t)(last - first);
+            for (int64_t bb = 0; bb < len; bb += 4096) blk.push_back(make_uint2(k, (uint32_t)bb));
+            for (int64_t bb = 0; bb <= cl; bb += 4096) cblk.push_back(make_uint2(k, (uint32_t)bb));
+            words += (len + 3) & ~(int64_t)3; slots += cl + 1;
+            if (len > max_len) max_len = len; if (cl > max_in) max_in = cl;
+          }
+          const size_t nj = last - first;
+          int rounds = 1; while (((int64_t)1 << rounds) < max_len) ++rounds;
+          rounds += 1;
+          int mrounds = 1; while (((int64_t)1 << mrounds) < max_in + 1) ++mrounds;
+          mrounds += 1;
+          dresolve.ensure((size_t)words * 4 + 64); dblk.ensure(blk.size() * sizeof(uint2) + 64); dcblk.ensure(cblk.size() * sizeof(uint2) + 64);
+          dcnt.ensure((size_t)(rounds + mrounds + 3) * nj * 4 + 64);
+          dja.ensure((size_t)(slots + 1) * 4 + 64); djb.ensure((size_t)(slots + 1) * 4 + 64); dolen.ensure((size_t)(slots + 1) * 4 + 64); dmark.ensure((size_t)slots + 64);
+          const size_t swb = exclusive_scan_ws_bytes(slots + 1); dscan.ensure(swb);
+          HIPCHECK(hipMemcpyAsync((UnpackJob*)djobs.p + first, jobs.data() + first, nj * sizeof(UnpackJob), hipMemcpyHostToDevice, s));      // (again: with the s_off / c_off fields)
+          if (!blk.empty()) HIPCHECK(hipMemcpyAsync(dblk.p, blk.data(), blk.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+          if (!cblk.empty()) HIPCHECK(hipMemcpyAsync(dcblk.p, cblk.data(), cblk.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+          HIPCHECK(hipMemsetAsync(dcnt.p, 0, (size_t)(rounds + mrounds + 3) * nj * 4, s));
+          HIPCHECK(hipMemsetAsync(dmark.p, 0, (size_t)slots + 64, s));
+          SnappyPjBuffers B{};
+          B.resolve = (uint32_t*)dresolve.p; B.blkmap = (const uint2*)dblk.p; B.n_blocks = (int)blk.size(); B.rounds = rounds;
+          B.jump_a = (uint32_t*)dja.p; B.jump_b = (uint32_t*)djb.p; B.olen = (uint32_t*)dolen.p; B.mark = (uint8_t*)dmark.p; B.cmap = (const uint2*)dcblk.p; B.n_cblocks = (int)cblk.size();
+          B.mark_rounds = mrounds; B.c_slots = slots; B.scan_ws = dscan.p; B.scan_ws_bytes = swb; B.counts = (uint32_t*)dcnt.p;
+          launch_unpack_pages_pj(s, (const uint8_t*)dfile.p, (uint8_t*)dpagebuf.p, (const UnpackJob*)djobs.p + first, (int)nj, B, (uint32_t*)flags.p + 1);
+          HIPCHECK(hipStreamSynchronize(s));      // the block maps (pageable host memory) and the scratch are reused by the next batch
+          first = last;
         }
-      }
-      if (pj_on && any_snappy && words > 0 && words <= (int64_t)1 << 31 && slots < ((int64_t)1 << 31) && max_len < ((int64_t)1 << 31)) {
-        std::vector<uint2> blk, cblk;
-        for (size_t k = 0; k < jobs.size(); ++k) if (jobs[k].mode == 1 && jobs[k].raw_prefix <= jobs[k].src_len && jobs[k].raw_prefix <= jobs[k].dst_len) {
-          const int64_t len = jobs[k].dst_len - jobs[k].raw_prefix, cl = jobs[k].src_len - jobs[k].raw_prefix;
-          for (int64_t b = 0; b < len; b += 4096) blk.push_back(make_uint2((uint32_t)k, (uint32_t)b));
-          for (int64_t b = 0; b <= cl; b += 4096) cblk.push_back(make_uint2((uint32_t)k, (uint32_t)b));
-        }
-        int rounds = 1; while (((int64_t)1 << rounds) < max_len) ++rounds;
-        rounds += 1;
-        int mrounds = 1; while (((int64_t)1 << mrounds) < max_in + 1) ++mrounds;
-        mrounds += 1;
-        const size_t nj = jobs.size();
-        dresolve.ensure((size_t)words * 4 + 64); dblk.ensure(blk.size() * sizeof(uint2) + 64); dcblk.ensure(cblk.size() * sizeof(uint2) + 64);
-        dcnt.ensure((size_t)(rounds + mrounds + 3) * nj * 4 + 64);
-        dja.ensure((size_t)(slots + 1) * 4 + 64); djb.ensure((size_t)(slots + 1) * 4 + 64); dolen.ensure((size_t)(slots + 1) * 4 + 64); dmark.ensure((size_t)slots + 64);
-        const size_t swb = exclusive_scan_ws_bytes(slots + 1); dscan.ensure(swb);
-        HIPCHECK(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(UnpackJob), hipMemcpyHostToDevice, s));      // (again: with the s_off / c_off fields)
-        if (!blk.empty()) HIPCHECK(hipMemcpyAsync(dblk.p, blk.data(), blk.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
-        if (!cblk.empty()) HIPCHECK(hipMemcpyAsync(dcblk.p, cblk.data(), cblk.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
-        HIPCHECK(hipMemsetAsync(dcnt.p, 0, (size_t)(rounds + mrounds + 3) * nj * 4, s));
-        HIPCHECK(hipMemsetAsync(dmark.p, 0, (size_t)slots + 64, s));
-        SnappyPjBuffers B{};
-        B.resolve = (uint32_t*)dresolve.p; B.blkmap = (const uint2*)dblk.p; B.n_blocks = (int)blk.size(); B.rounds = rounds;
-        B.jump_a = (uint32_t*)dja.p; B.jump_b = (uint32_t*)djb.p; B.olen = (uint32_t*)dolen.p; B.mark = (uint8_t*)dmark.p; B.cmap = (const uint2*)dcblk.p; B.n_cblocks = (int)cblk.size();
-        B.mark_rounds = mrounds; B.c_slots = slots; B.scan_ws = dscan.p; B.scan_ws_bytes = swb; B.counts = (uint32_t*)dcnt.p;
-        launch_unpack_pages_pj(s, (const uint8_t*)dfile.p, (uint8_t*)dpagebuf.p, (const UnpackJob*)djobs.p, (int)jobs.size(), B, (uint32_t*)flags.p + 1);
-        HIPCHECK(hipStreamSynchronize(s));      // the block maps (pageable host memory) must outlive their copies
       } else
       launch_unpack_pages(s, (const uint8_t*)dfile.p, (uint8_t*)dpagebuf.p, (const UnpackJob*)djobs.p, (int)jobs.size(), (uint32_t*)flags.p + 1);
       pages_base = (const uint8_t*)dpagebuf.p; pages_bytes = page_bytes;
