@@ -223,7 +223,11 @@ void launch_utf8_piece_starts(hipStream_t s, Utf8Piece* pieces, int n_pieces, ui
 void launch_utf8_piece_offsets(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_rows);
 void launch_utf8_piece_validate(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_rows, uint32_t* status);
 void launch_utf8_piece_compact(hipStream_t s, const Utf8Piece* pieces, int n_pieces, int64_t max_bytes, const uint8_t* from, uint8_t* to);
-struct UnpackJob { int64_t src, dst, src_len, dst_len, raw_prefix; int32_t mode /* 0 stored, 1 snappy */, pad; int64_t s_off, c_off; };      // one Parquet page (kernels_lz4.hip); s_off / c_off: its place in the resolve array / the per-position arrays
+// one Parquet page, or one block of a linked LZ4 frame (kernels_lz4.hip).  mode: 0 stored, 1 Snappy, 2 LZ4 block of a linked frame, 3 stored block of a
+// linked frame (its bytes can be the source of later blocks' matches).  s_off / c_off: the job's place in the resolve array / the per-position arrays;
+// linked frames: f_off = the FRAME's place in the resolve array and p_base = the block's position in the frame's output (copies may reach back
+// across blocks; s_off = f_off + p_base), elsewhere f_off = s_off and p_base = 0
+struct UnpackJob { int64_t src, dst, src_len, dst_len, raw_prefix; int32_t mode, pad; int64_t s_off, c_off, f_off, p_base; };
 void launch_unpack_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, int n_jobs, uint32_t* status);
 // Snappy without a serial element walk (kernels_lz4.hip).  resolve: one 32-bit word per uncompressed byte of the Snappy jobs (s_off); blkmap: (job, first
 // byte) per 4096 of them.  jump_a / jump_b / olen (32-bit) and mark (8-bit): one entry per compressed byte + one per job (c_off; c_slots in all, + 1 for the

@@ -540,10 +540,33 @@ __device__ __forceinline__ SnElem sn_element(const uint8_t* __restrict__ in, con
   else { e.size = 5; e.olen = (tag >> 2) + 1; e.kind = 1; e.off = b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24); }
   return e;
 }
+// one LZ4 sequence starting at p of a block [0, L): token, literal length (+255-runs), literals, then -- unless the literals end the block -- a
+// 2-byte offset and the match length (+255-runs, + 4).  lit = first literal byte, olen = literals + match
+struct Lz4Elem { int64_t size; int64_t lit_len, match_len; uint32_t off; int64_t lit; bool ok; };
+__device__ __forceinline__ Lz4Elem lz4_element(const uint8_t* __restrict__ in, const int64_t p, const int64_t L) {
+  Lz4Elem e{0, 0, 0, 0u, 0, false};
+  int64_t q = p;
+  const uint32_t token = in[q++];
+  int64_t lit = token >> 4;
+  // (a length cannot legitimately run longer than the block; positions that are NOT sequence starts -- inside a run of 0xFF bytes, say --
+  // must not walk it to its end each: the bound keeps the all-positions pass linear in practice)
+  const int max_run = (int)(L / 255) + 2;
+  if (lit == 15) { uint32_t x; int guard = 0; do { if (q >= L || ++guard > max_run) return e; x = in[q++]; lit += x; } while (x == 255); }
+  e.lit = q; e.lit_len = lit;
+  if (lit > L - q) return e;
+  q += lit;
+  if (q == L) { e.size = q - p; e.ok = true; return e; }      // the last sequence of a block: literals only
+  if (q + 2 > L) return e;
+  e.off = (uint32_t)in[q] | ((uint32_t)in[q + 1] << 8); q += 2;
+  int64_t ml = token & 15;
+  if (ml == 15) { uint32_t x; int guard = 0; do { if (q >= L) return e; x = in[q++]; ml += x; (void)guard; } while (x == 255); }      // (bounded by the block's end; positions inside a 0xFF run leave through the literal bound above)
+  e.match_len = ml + 4; e.size = q - p; e.ok = true;
+  return e;
+}
 constexpr uint32_t SN_BAD = 0xFFFFFFFFu;
 // per job (one wave): the raw prefix and stored pages are copied; a Snappy page's length preamble is read and its first element marked
 __global__ __launch_bounds__(64) void k_sn_head(const uint8_t* __restrict__ src_base, uint8_t* __restrict__ dst_base, const UnpackJob* __restrict__ jobs, int n_jobs,
-                                                uint8_t* __restrict__ mark, uint32_t* __restrict__ status) {
+                                                uint8_t* __restrict__ mark, uint32_t* __restrict__ resolve, uint32_t* __restrict__ status) {
   const int u = (int)blockIdx.x;
   if (u >= n_jobs) return;
   const UnpackJob J = jobs[u];
@@ -558,6 +581,13 @@ __global__ __launch_bounds__(64) void k_sn_head(const uint8_t* __restrict__ src_
     for (int64_t i = lane; i < L; i += 64) out[i] = in[i];
     return;
   }
+  if (J.mode == 3) {      // stored block of a linked frame: every byte a resolved word (k_snappy_emit writes the bytes)
+    if (L != out_len) { if (lane == 0) atomicOr(status, 1u); return; }
+    uint32_t* S = resolve + J.s_off;
+    for (int64_t i = lane; i < L; i += 64) S[i] = PJ_DONE | (uint32_t)in[i];
+    return;
+  }
+  if (J.mode == 2) { if (lane == 0) mark[J.c_off] = 1; return; }      // an LZ4 block starts with its first sequence
   if (lane == 0) {
     uint64_t ulen = 0; int sh = 0; int64_t ip = 0; bool bad = false;
     for (;;) { if (ip >= L || sh > 35) { bad = true; break; } const uint32_t c = in[ip++]; ulen |= (uint64_t)(c & 0x7F) << sh; if (!(c & 0x80)) break; sh += 7; }
@@ -576,8 +606,13 @@ __global__ __launch_bounds__(256) void k_sn_next(const uint8_t* __restrict__ src
     if (p > L) continue;
     uint32_t nx = (uint32_t)L, ol = 0;
     if (p < L) {
-      const SnElem e = sn_element(in, p, L);
-      if (p + e.size > L) ol = SN_BAD; else { nx = (uint32_t)(p + e.size); ol = e.olen; }
+      if (J.mode == 2) {
+        const Lz4Elem e = lz4_element(in, p, L);
+        if (!e.ok || p + e.size > L || e.lit_len + e.match_len >= (int64_t)PJ_DONE) ol = SN_BAD; else { nx = (uint32_t)(p + e.size); ol = (uint32_t)(e.lit_len + e.match_len); }
+      } else {
+        const SnElem e = sn_element(in, p, L);
+        if (p + e.size > L) ol = SN_BAD; else { nx = (uint32_t)(p + e.size); ol = e.olen; }
+      }
     }
     jump[J.c_off + p] = nx; olen[J.c_off + p] = ol;
   }
@@ -629,6 +664,19 @@ __global__ __launch_bounds__(256) void k_sn_fill(const uint8_t* __restrict__ src
     if (p > L || !mark[J.c_off + p]) continue;
     const int64_t o = (int64_t)pos[J.c_off + p] - base;
     if (p == L) { if (o != out_len) atomicOr(status, 1u); continue; }      // the elements must produce exactly the announced length
+    if (J.mode == 2) {
+      const Lz4Elem e = lz4_element(in, p, L);
+      if (!e.ok || p + e.size > L || o < 0 || o + e.lit_len + e.match_len > out_len) { atomicOr(status, 1u); continue; }
+      for (int64_t i = 0; i < e.lit_len; ++i) S[o + i] = PJ_DONE | (uint32_t)in[e.lit + i];
+      if (e.match_len) {
+        const int64_t at = J.p_base + o + e.lit_len;      // position in the FRAME's output: a match may reach back into earlier blocks
+        if (e.off == 0 || (int64_t)e.off > at) { atomicOr(status, 1u); continue; }
+        const uint32_t from = (uint32_t)(at - e.off);
+        uint32_t* M = S + o + e.lit_len;
+        for (int64_t i = 0; i < e.match_len; ++i) M[i] = from + (uint32_t)((int64_t)e.off >= e.match_len ? i : i % (int64_t)e.off);
+      }
+      continue;
+    }
     const SnElem e = sn_element(in, p, L);
     if (p + e.size > L || o < 0 || o + (int64_t)e.olen > out_len) { atomicOr(status, 1u); continue; }      // (o < 0: a corrupted stream whose announced lengths wrapped the 32-bit scan)
     if (e.kind == 0) { for (uint32_t i = 0; i < e.olen; ++i) S[o + i] = PJ_DONE | (uint32_t)in[e.lit + i]; }
@@ -645,17 +693,18 @@ __global__ __launch_bounds__(256) void k_snappy_round(uint32_t* __restrict__ res
   const uint2 m = blkmap[blockIdx.x];
   if (!first && cnt_prev[m.x] == 0) return;
   const UnpackJob J = jobs[m.x];
-  uint32_t* S = resolve + J.s_off;
+  uint32_t* S = resolve + J.f_off;      // positions are the frame's (a page is its own frame: f_off = s_off, p_base = 0)
   const int64_t len = J.dst_len - J.raw_prefix;
   uint32_t left = 0;
 #pragma unroll 4
   for (int k = 0; k < PJ_BLOCK_BYTES / 256; ++k) {
     const int64_t p = (int64_t)m.y + k * 256 + threadIdx.x;
     if (p < len) {
-      const uint32_t v = S[p];
+      const int64_t a = J.p_base + p;
+      const uint32_t v = S[a];
       if (!(v & PJ_DONE)) {
-        const uint32_t w = (int64_t)v < p ? S[v] : PJ_DONE;      // (v < p always for a checked stream; anything else ends here, harmlessly)
-        S[p] = w;
+        const uint32_t w = (int64_t)v < a ? S[v] : PJ_DONE;      // (v < a always for a checked stream; anything else ends here, harmlessly)
+        S[a] = w;
         left += (w & PJ_DONE) ? 0u : 1u;
       }
     }
@@ -686,7 +735,7 @@ __global__ __launch_bounds__(256) void k_snappy_emit(const uint32_t* __restrict_
 void launch_unpack_pages_pj(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, int n_jobs, const SnappyPjBuffers& B, uint32_t* status) {
   if (n_jobs <= 0) return;
   // front: which positions of the compressed streams are elements, and where their output goes
-  hipLaunchKernelGGL(k_sn_head, dim3((unsigned)n_jobs), dim3(64), 0, s, src, dst, jobs, n_jobs, B.mark, status);
+  hipLaunchKernelGGL(k_sn_head, dim3((unsigned)n_jobs), dim3(64), 0, s, src, dst, jobs, n_jobs, B.mark, B.resolve, status);
   if (B.n_cblocks <= 0 || B.n_blocks <= 0) return;
   hipLaunchKernelGGL(k_sn_next, dim3((unsigned)B.n_cblocks), dim3(256), 0, s, src, B.cmap, jobs, B.jump_a, B.olen);
   uint32_t* ja = B.jump_a; uint32_t* jb = B.jump_b;

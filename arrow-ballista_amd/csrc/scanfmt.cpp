@@ -413,7 +413,7 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
     auto place = [&](int64_t src, int comp, int uncomp, int raw_prefix, int mode) -> int64_t {      // -> the page's position for the decoders
       if (!any_compressed) return src;
       const int64_t dst = page_bytes; page_bytes += ((int64_t)uncomp + 63) & ~(int64_t)63;
-      jobs.push_back({src, dst, comp, uncomp, raw_prefix, mode, 0, 0, 0});
+      jobs.push_back({src, dst, comp, uncomp, raw_prefix, mode, 0, 0, 0, 0, 0});
       return dst;
     };
     for (int li : proj) {
@@ -495,7 +495,7 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
             const bool sn = j.mode == 1 && j.raw_prefix <= j.src_len && j.raw_prefix <= j.dst_len;
             const int64_t len = sn ? j.dst_len - j.raw_prefix : 0, cl = sn ? j.src_len - j.raw_prefix : 0;
             if (last > first && sn && (words + len > max_words || slots + cl + 1 > max_words)) break;
-            j.s_off = words; j.c_off = slots;
+            j.s_off = words; j.c_off = slots; j.f_off = words; j.p_base = 0;
             if (!sn) continue;
             const uint32_t k = (uint32_t)(last - first);
             for (int64_t bb = 0; bb < len; bb += 4096) blk.push_back(make_uint2(k, (uint32_t)bb));

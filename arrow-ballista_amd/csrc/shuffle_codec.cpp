@@ -515,6 +515,11 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
     const uint8_t* db = dsrc.as<uint8_t>();
     std::vector<Lz4Unit> units, units_seq;      // fast path (independent blocks assumed full) and the always-valid per-frame walk
     bool split_any = false;
+    // linked frames of two blocks or more (what Arrow C++ writes: every block may copy from the 64 KB before it) are decoded WITHOUT the
+    // serial walk (kernels_lz4.hip, launch_unpack_pages_pj: the machinery of the Snappy pages with LZ4's sequences as elements and the
+    // frame as the space copies point into) -- one job per block; the per-frame walk stays as the fallback (units_seq)
+    std::vector<UnpackJob> ljobs; int64_t lwords = 0, lslots = 0, lmax_frame = 0, lmax_in = 0;
+    static const bool lz4_pj_on = []() { const char* e = std::getenv("GPUQ_LZ4_PJ"); return !(e && e[0] == '0'); }();
     // uncompressed length of buffer j of message g (host only)
     struct CopyFix { uint8_t* dst; const uint8_t* src; int64_t n; };       // device-to-device copies, in issue order
     std::vector<CopyFix> copyfix;
@@ -555,7 +560,30 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
       if (hp + 4 > flen) throw std::runtime_error("truncated LZ4 frame");
       Lz4Unit whole{off + 8 + hp, (int64_t)(uintptr_t)dst, flen - hp, ulen, LZ4_UNIT_FRAME_BLOCKS, bchk ? LZ4_UNIT_BLOCK_CHECKSUM : 0};
       units_seq.push_back(whole);
-      if (!indep) { units.push_back(whole); return; }
+      if (!indep) {
+        // the block index, on the host (as for independent blocks below): every block but the last decodes to the frame's block size
+        std::vector<UnpackJob> fj; int64_t ip = hp, op = 0; bool okw = lz4_pj_on && ulen > bmax && ulen < ((int64_t)1 << 30);
+        int64_t words0 = (lwords + 3) & ~(int64_t)3, slots = lslots, max_in = 0;
+        while (okw) {
+          if (ip + 4 > flen) { okw = false; break; }
+          uint32_t h; std::memcpy(&h, f + ip, 4); ip += 4;
+          if (h == 0) break;
+          const int64_t bs = h & 0x7FFFFFFFu;
+          if (bs > flen - ip || op >= ulen || bs == 0) { okw = false; break; }
+          const int64_t dl = std::min(bmax, ulen - op);
+          const bool stored = (h & 0x80000000u) != 0;
+          UnpackJob j{off + 8 + ip, (int64_t)(uintptr_t)dst + op, bs, dl, 0, stored ? 3 : 2, 0, words0 + op, slots, words0, op};
+          fj.push_back(j);
+          if (!stored) { slots += bs + 1; if (bs > max_in) max_in = bs; }
+          ip += bs + (bchk ? 4 : 0); op += dl;
+        }
+        if (okw && op == ulen && fj.size() >= 2 && words0 + ulen < ((int64_t)1 << 30) && slots < ((int64_t)1 << 30)) {
+          for (auto& j : fj) ljobs.push_back(j);
+          lwords = words0 + ulen; lslots = slots; lmax_frame = std::max(lmax_frame, ulen); lmax_in = std::max(lmax_in, max_in);
+          return;
+        }
+        units.push_back(whole); return;
+      }
       // independent blocks: walk the block index on the host, one unit per block (all but the last assumed full; verified on the device)
       int64_t ip = hp, op = 0; const size_t first_unit = units.size(); bool okw = true;
       while (true) {
@@ -663,6 +691,7 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
       B->cols.push_back(std::move(col));
     }
     DevBuf dunits, dstatus, dpieces; dstatus.ensure(16);
+    DevBuf pj_resolve, pj_blk, pj_cblk, pj_jobs, pj_cnt, pj_ja, pj_jb, pj_olen, pj_mark, pj_scan;
     // Utf8 piece descriptors of all columns in one upload
     size_t n_pieces = checks.size(); for (auto& u : utf8_cols) { n_pieces += u.pieces.size(); max_check_rows = std::max(max_check_rows, u.max_rows); }
     std::vector<size_t> piece0;
@@ -685,6 +714,33 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
         HIPCHECK(hipMemcpyAsync(dunits.p, up, sizeof(Lz4Unit) * us.size(), hipMemcpyHostToDevice, s));
         launch_lz4_decode(s, db, pos, nullptr, (const Lz4Unit*)dunits.p, (int)us.size(), dstatus.as<uint32_t>());
       }
+      if (&us == &units && !ljobs.empty()) {      // (the fallback list holds those frames as whole units)
+        std::vector<uint2> blk, cblk;
+        for (size_t k = 0; k < ljobs.size(); ++k) {
+          for (int64_t bb = 0; bb < ljobs[k].dst_len; bb += 4096) blk.push_back(make_uint2((uint32_t)k, (uint32_t)bb));
+          if (ljobs[k].mode == 2) for (int64_t bb = 0; bb <= ljobs[k].src_len; bb += 4096) cblk.push_back(make_uint2((uint32_t)k, (uint32_t)bb));
+        }
+        int rounds = 1; while (((int64_t)1 << rounds) < lmax_frame) ++rounds;
+        rounds += 1;
+        int mrounds = 1; while (((int64_t)1 << mrounds) < lmax_in + 1) ++mrounds;
+        mrounds += 1;
+        const size_t nj = ljobs.size();
+        pj_resolve.ensure((size_t)lwords * 4 + 64); pj_blk.ensure(blk.size() * sizeof(uint2) + 64); pj_cblk.ensure(cblk.size() * sizeof(uint2) + 64); pj_jobs.ensure(nj * sizeof(UnpackJob) + 64);
+        pj_cnt.ensure((size_t)(rounds + mrounds + 3) * nj * 4 + 64);
+        pj_ja.ensure((size_t)(lslots + 1) * 4 + 64); pj_jb.ensure((size_t)(lslots + 1) * 4 + 64); pj_olen.ensure((size_t)(lslots + 1) * 4 + 64); pj_mark.ensure((size_t)lslots + 64);
+        const size_t swb = exclusive_scan_ws_bytes(lslots + 1); pj_scan.ensure(swb);
+        HIPCHECK(hipMemcpyAsync(pj_jobs.p, ljobs.data(), nj * sizeof(UnpackJob), hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemcpyAsync(pj_blk.p, blk.data(), blk.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+        if (!cblk.empty()) HIPCHECK(hipMemcpyAsync(pj_cblk.p, cblk.data(), cblk.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemsetAsync(pj_cnt.p, 0, (size_t)(rounds + mrounds + 3) * nj * 4, s));
+        HIPCHECK(hipMemsetAsync(pj_mark.p, 0, (size_t)lslots + 64, s));
+        SnappyPjBuffers PB{};
+        PB.resolve = (uint32_t*)pj_resolve.p; PB.blkmap = (const uint2*)pj_blk.p; PB.n_blocks = (int)blk.size(); PB.rounds = rounds;
+        PB.jump_a = (uint32_t*)pj_ja.p; PB.jump_b = (uint32_t*)pj_jb.p; PB.olen = (uint32_t*)pj_olen.p; PB.mark = (uint8_t*)pj_mark.p; PB.cmap = (const uint2*)pj_cblk.p; PB.n_cblocks = (int)cblk.size();
+        PB.mark_rounds = mrounds; PB.c_slots = lslots; PB.scan_ws = pj_scan.p; PB.scan_ws_bytes = swb; PB.counts = (uint32_t*)pj_cnt.p;
+        launch_unpack_pages_pj(s, db, nullptr, (const UnpackJob*)pj_jobs.p, (int)nj, PB, dstatus.as<uint32_t>());
+        HIPCHECK(hipStreamSynchronize(s));      // the block maps are pageable host memory
+      }
       for (auto& x : copyfix) HIPCHECK(hipMemcpyAsync(x.dst, x.src, (size_t)x.n, hipMemcpyDeviceToDevice, s));
       for (auto& x : bitfix) launch_concat_bitmap(s, (u64*)x.dst, x.bit0, x.src, 0, x.n);
       // untrusted offsets: monotone, from >= 0, ending inside their data buffer -- before anything is derived from them
@@ -702,7 +758,7 @@ int gpuq_ipc_decode_stream(gpuq_ctx* ctx, void* stream, const uint8_t* bytes, in
     };
     HIPCHECK(hipMemsetAsync(dstatus.p, 0, 16, s));
     uint32_t st = run(units);
-    if (st && split_any) {       // a frame whose inner blocks are not full-size: decode frame by frame (bitmaps are OR-merged: clear them first)
+    if (st && (split_any || !ljobs.empty())) {       // a frame whose inner blocks are not full-size: decode frame by frame (bitmaps are OR-merged: clear them first)
       for (auto& c : B->cols) {
         if (c->col.validity) HIPCHECK(hipMemsetAsync(c->validity.p, 0, vbytes + 80, s));
         if (c->col.type == GPUQ_BOOL) HIPCHECK(hipMemsetAsync(c->data.p, 0, vbytes + 80, s));
