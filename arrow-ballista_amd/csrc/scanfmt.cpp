@@ -409,7 +409,7 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
     // Snappy chunks: every page (of every projected column) goes through one unpack launch into a second buffer the decoders read
     bool any_compressed = false;
     for (int li : proj) for (const PqRowGroup& G : M.groups) if ((size_t)li < G.cols.size() && G.cols[(size_t)li].num_values > 0 && G.cols[(size_t)li].codec != 0) any_compressed = true;
-    std::vector<UnpackJob> jobs; int64_t page_bytes = 0;
+    std::vector<UnpackJob> jobs; int64_t page_bytes = 0; bool any_lz4 = false;
     auto place = [&](int64_t src, int comp, int uncomp, int raw_prefix, int mode) -> int64_t {      // -> the page's position for the decoders
       if (!any_compressed) return src;
       const int64_t dst = page_bytes; page_bytes += ((int64_t)uncomp + 63) & ~(int64_t)63;
@@ -429,8 +429,9 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
         const PqChunk& K = G.cols[(size_t)li];
         if (K.num_values == 0) continue;
         if (K.num_values < 0 || K.total_compressed <= 0 || K.data_page_offset < 0) throw std::runtime_error("parquet: negative size / offset in a column chunk's metadata");
-        if (K.codec != 0 && K.codec != 1) throw Unsupported("parquet: compressed column chunk (codec " + std::to_string(K.codec) + ") in '" + L.name + "': UNCOMPRESSED and SNAPPY pages are decoded on the device");
-        const int cmode = K.codec == 1 ? 1 : 0;
+        if (K.codec != 0 && K.codec != 1 && K.codec != 7) throw Unsupported("parquet: compressed column chunk (codec " + std::to_string(K.codec) + ") in '" + L.name + "': UNCOMPRESSED, SNAPPY and LZ4_RAW pages are decoded on the device");
+        const int cmode = K.codec == 1 ? 1 : (K.codec == 7 ? 2 : 0);      // UnpackJob::mode: 1 Snappy, 2 one raw LZ4 block per page (LZ4_RAW)
+        if (cmode == 2) any_lz4 = true;
         int64_t pos = K.dict_page_offset >= 0 && K.dict_page_offset < K.data_page_offset ? K.dict_page_offset : K.data_page_offset;
         const int64_t chunk_end = pos + K.total_compressed;
         if (pos < 4 || chunk_end > n_bytes - 8) throw std::runtime_error("parquet: column chunk outside the file");
@@ -482,7 +483,8 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
       static const bool pj_on = []() { const char* e = std::getenv("GPUQ_SNAPPY_PJ"); return !(e && e[0] == '0'); }();
       const int64_t max_words = (int64_t)1 << 30;
       bool any_snappy = false, fits = true;
-      for (auto& j : jobs) if (j.mode == 1) { any_snappy = true; if (j.dst_len > max_words || j.src_len > max_words) fits = false; }
+      for (auto& j : jobs) if (j.mode == 1 || j.mode == 2) { any_snappy = true; if (j.dst_len > max_words || j.src_len > max_words) fits = false; }
+      if (any_lz4 && !(pj_on && fits)) throw Unsupported("parquet: LZ4_RAW pages are decoded by the parallel path only (GPUQ_SNAPPY_PJ=0, or a page beyond 2^30 bytes)");
       if (pj_on && any_snappy && fits) {
         HIPCHECK(hipMemsetAsync(dmark.ensure(64), 0, 64, s));
         size_t first = 0;
@@ -492,7 +494,7 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
           std::vector<uint2> blk, cblk;
           for (; last < jobs.size(); ++last) {
             UnpackJob& j = jobs[last];
-            const bool sn = j.mode == 1 && j.raw_prefix <= j.src_len && j.raw_prefix <= j.dst_len;
+            const bool sn = (j.mode == 1 || j.mode == 2) && j.raw_prefix <= j.src_len && j.raw_prefix <= j.dst_len;
             const int64_t len = sn ? j.dst_len - j.raw_prefix : 0, cl = sn ? j.src_len - j.raw_prefix : 0;
             if (last > first && sn && (words + len > max_words || slots + cl + 1 > max_words)) break;
             j.s_off = words; j.c_off = slots; j.f_off = words; j.p_base = 0;

@@ -236,7 +236,9 @@ def write(t, **kw):
     dict(use_dictionary=["lowcard", "s", "ns"], data_page_version="1.0", data_page_size=2048, row_group_size=20_000, dictionary_pagesize_limit=64),
     dict(use_dictionary=True, data_page_version="1.0", compression="SNAPPY", data_page_size=16384),
     dict(use_dictionary=["lowcard", "s"], data_page_version="2.0", compression="SNAPPY", data_page_size=4096, row_group_size=25_000),
-], ids=["dict-v1", "plain-v1", "dict-v2-smallpages", "plain-v2-rowgroups", "mixed-dict-fallback", "snappy-v1", "snappy-v2"])
+    dict(use_dictionary=True, data_page_version="1.0", compression="LZ4", data_page_size=16384),
+    dict(use_dictionary=["lowcard", "s"], data_page_version="2.0", compression="LZ4", data_page_size=4096, row_group_size=25_000),
+], ids=["dict-v1", "plain-v1", "dict-v2-smallpages", "plain-v2-rowgroups", "mixed-dict-fallback", "snappy-v1", "snappy-v2", "lz4raw-v1", "lz4raw-v2"])
 def test_pyarrow_written_files(tc, n, opts):
     """Required and optional columns of every decoded type; dictionary and PLAIN pages, v1 and v2 headers, many small pages, several
     row groups, a dictionary that overflows and falls back to PLAIN mid-chunk; decimals as FIXED_LEN_BYTE_ARRAY (15,2) and (38,2)."""
@@ -261,8 +263,9 @@ def test_snappy_streams_with_long_literals_and_overlapping_copies(tc):
                   "noise": pa.array(r.integers(-2**62, 2**62, n)), "txt": pa.array(["abcabcabc-%d" % (j % 13) for j in range(n)]),
                   "opt": pa.array(r.integers(0, 3, n), type=pa.int32(), mask=r.random(n) < 0.5)})
     for opts in (dict(use_dictionary=False, data_page_size=1 << 20), dict(use_dictionary=False, data_page_size=1 << 14, data_page_version="2.0")):
-        data = write(t, compression="SNAPPY", **opts)
-        same(scan.read_parquet(tc, data).to_arrow(tc.ctx), pq.read_table(io.BytesIO(data)))
+        for codec in ("SNAPPY", "LZ4"):      # (LZ4 = LZ4_RAW: one raw block per page, long matches and 255-runs of length bytes in the repetitive columns)
+            data = write(t, compression=codec, **opts)
+            same(scan.read_parquet(tc, data).to_arrow(tc.ctx), pq.read_table(io.BytesIO(data)))
 
 
 def test_decimals_stored_as_integers_and_projection_order(tc):
@@ -314,7 +317,7 @@ def test_decoded_leaves_feed_q1(tc):
     assert T.q1_result_to_rows(tc, T.run_q1(tc, from_text)) == want
 
 
-@pytest.mark.parametrize("compression", ["NONE", "SNAPPY"])
+@pytest.mark.parametrize("compression", ["NONE", "SNAPPY", "LZ4"])
 def test_corrupted_pages_never_read_out_of_bounds(tc, compression):
     """Page bytes are untrusted: random corruptions of the data region of a valid file (levels, run headers, dictionary indices, length
     prefixes, Snappy tags) must end in an error or in (different) in-bounds values -- every length the kernels follow is checked
