@@ -221,6 +221,9 @@ def main_q3():
             torch.cuda.empty_cache()
             # BASELINE configs[4]: the per-GPU shard of the SF300 lineitem sort (the N>1 run below does the range exchange around it)
             extra["sort_sf300_shard"] = bench_extras.sort_shard(tc, T, g)
+            torch.cuda.empty_cache()
+            # the scan leaves at SF1 (host bytes -> Arrow-layout columns in HBM): '|' text, Parquet plain and Snappy (decoded without a serial walk), pyarrow on the host beside them
+            extra["scan_decode_sf1"] = bench_extras.scan_decode(tc, T, g, sf=1)
         else:
             # second legs, every rank takes part: q3 with the build side of orders |x| lineitem BROADCAST instead (what a cost-based
             # planner picks when the build side is 20 x smaller: 1/60 of the bytes cross the links), distributed q5, and q1

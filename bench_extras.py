@@ -613,7 +613,10 @@ def scan_decode(tc, T, g, sf=1):
     import pyarrow.parquet as pq
     from arrow_ballista_amd import scan
     n = T.LINEITEM_ROWS.get(sf, int(6_000_000 * sf))
-    li = T.lineitem_host_to_arrow(T.gen_lineitem_host(n), n)
+    if hasattr(T, "gen_lineitem_host"):      # (tests/tpch_util: the oracle's host generator; same rows)
+        li = T.lineitem_host_to_arrow(T.gen_lineitem_host(n), n)
+    else:                                    # bench.py: the device generator's rows, copied back once
+        li = T.gen_lineitem_device(tc, n, columns=("l_orderkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate")).to_arrow(tc.ctx)
     li = li.cast(pa.schema([pa.field(f.name, f.type, nullable=False) for f in li.schema]))
     arrow_bytes = sum(c.nbytes for c in li.columns)
     buf = io.BytesIO()
