@@ -269,11 +269,19 @@ def main_q3():
             extra["q1_partial_states_gathered"] = {"ms_per_step": d3 / k * 1e3, "lineitem_rows_per_s": rows_job * k / d3, "result_groups": r3.num_rows}
         line["extra"] = extra
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         comm.close()
         dist.destroy_process_group()
+    # The line is out and every rank has left the collectives.  What remains is the teardown of three runtimes in one process (torch,
+    # Arrow C++'s thread pools after the host-side comparison legs, hiprtc's worker): one run of a tool of this repo that ended with a
+    # multi-threaded pyarrow read aborted in that teardown ("terminate called without an active exception") after printing its result.
+    # The library's own exit path is the subject of tests/test_gpu_exit.py; here the background compiles are waited for and the process
+    # leaves without running the other runtimes' static destructors, so that a teardown race cannot turn a finished measurement into rc 134.
+    g.lib().gpuq_jit_quiesce()
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
 
 
 def check_q3_result(torch, T, tc, res, li, od, cu):
