@@ -952,6 +952,14 @@ int gpuq_project_run(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_colum
 
 // ---------------------------------------------------------------- aggregate
 // ndev_out != NULL: the deferred form is allowed (gpuq_aggregate_run_deferred)
+// Slots per estimated group, in percent, before rounding up to a power of two.  An estimate that is the operator's own last group count plus a
+// quarter (the deferred runs of a plan, the partitions of a stage) is trusted with 130: the true load ends up in (0.31, 0.62], and the
+// table is half the size 200 gave -- SF100 q3's 1.2 M groups: 2 Mi slots instead of 4 Mi, aggregate 0.66 -> 0.57 ms (initialise + extract halve,
+// the hash kernel keeps its time).  A hint or a sampled estimate keeps 200.  GPUQ_AGG_SLOT_PCT overrides both (tuning).
+static u64 agg_slot_pct(const bool from_last_run) {
+  static const long env = []() { const char* e = std::getenv("GPUQ_AGG_SLOT_PCT"); const long x = e ? std::atol(e) : 0; return (x >= 110 && x <= 800) ? x : 0; }();
+  return env ? (u64)env : (from_last_run ? 130u : 200u);
+}
 static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, gpuq_column* outs, int n_outs, int64_t cap, int64_t* n_groups_out, const uint64_t** ndev_out) {
   if (!op) return GPUQ_ERR_INVALID;
   if (ndev_out) *ndev_out = nullptr;
@@ -1032,7 +1040,7 @@ static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, g
         const u64 est = std::min<u64>(std::max<u64>(op->ag.est, 64), (u64)(op->ag.groups + op->ag.groups / 4 + 64));
         i64 rcap = op->ag.groups + op->ag.groups / 4 + 1024; if (rcap > cap) rcap = cap;
         if (rcap >= 1 && rcap <= 0x7FFFFFFFll) {
-          T.n_slots = next_pow2(est * 2);
+          T.n_slots = next_pow2(est * agg_slot_pct(true) / 100);
           T.slots = (u64*)op->ws[5].ensure((size_t)T.n_slots * T.slot_words * 8);
           launch_ht_init(s, T, &op->agg);
           if (op->ag.use_lds) {
@@ -1187,9 +1195,7 @@ static int aggregate_run_impl(gpuq_op* op, void* stream, const gpuq_input* in, g
       const bool use_lds = strat == "lds" || (strat == "auto" && lslots > 0 && n >= (1ll << 17) && known > 0 && known <= (i64)lslots * 4);
       if (strat == "lds" && !lslots) throw Unsupported("lds aggregate: the group state does not fit an LDS table");
       for (;;) {
-        // (tuning switch: GPUQ_AGG_SLOT_PCT = slots per estimated group in percent before rounding up to a power of two; 200 = the default)
-        static const u64 slot_pct = []() { const char* e = std::getenv("GPUQ_AGG_SLOT_PCT"); const long v = e ? std::atol(e) : 200; return (u64)(v >= 110 && v <= 800 ? v : 200); }();
-        T.n_slots = next_pow2(est * slot_pct / 100);
+        T.n_slots = next_pow2(est * agg_slot_pct(known_groups >= 0 && op->expected_groups <= 0 && est == (u64)known) / 100);
         T.slots = (u64*)op->ws[5].ensure((size_t)T.n_slots * T.slot_words * 8);
         launch_ht_init(s, T, &op->agg);
         reset_flags(op, s);

@@ -3,7 +3,7 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 O=gpurun_out/r03t; mkdir -p $O
-for v in 200 140 110 300; do
+for v in 200 130 110; do
   export GPUQ_AGG_SLOT_PCT=$v
   timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
   python3 - "$v" <<'PY'
