@@ -229,6 +229,10 @@ void launch_utf8_piece_compact(hipStream_t s, const Utf8Piece* pieces, int n_pie
 // across blocks; s_off = f_off + p_base), elsewhere f_off = s_off and p_base = 0
 struct UnpackJob { int64_t src, dst, src_len, dst_len, raw_prefix; int32_t mode, pad; int64_t s_off, c_off, f_off, p_base; };
 void launch_unpack_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, int n_jobs, uint32_t* status);
+// mode 4 = ZSTD frames (kernels_zstd.hip; the unpack kernels copy such a job's raw prefix and leave the rest to this launch);
+// `which`: indices of the mode-4 jobs, `scratch`: zstd_scratch_bytes(n) bytes
+size_t zstd_scratch_bytes(int n_pages);
+void launch_zstd_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, const int32_t* which, int n, uint8_t* scratch, uint32_t* status);
 // Snappy without a serial element walk (kernels_lz4.hip).  resolve: one 32-bit word per uncompressed byte of the Snappy jobs (s_off); blkmap: (job, first
 // byte) per 4096 of them.  jump_a / jump_b / olen (32-bit) and mark (8-bit): one entry per compressed byte + one per job (c_off; c_slots in all, + 1 for the
 // scan); cmap: (job, first position) per 4096 of those.  counts: (mark_rounds + rounds + 3) * n_jobs zeroed words.

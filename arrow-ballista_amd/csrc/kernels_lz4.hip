@@ -399,6 +399,7 @@ __global__ __launch_bounds__(64) void k_unpack_pages(const uint8_t* __restrict__
   if (J.raw_prefix > J.src_len || J.raw_prefix > J.dst_len) { if (lane == 0) atomicOr(status, 1u); return; }
   for (int64_t i = lane; i < J.raw_prefix; i += 64) out[i] = in[i];
   in += J.raw_prefix; out += J.raw_prefix;
+  if (J.mode == 4) return;      // ZSTD frames: k_zstd_pages
   const int64_t in_len = J.src_len - J.raw_prefix, out_len = J.dst_len - J.raw_prefix;
   if (J.mode == 0) {
     if (in_len != out_len) { if (lane == 0) atomicOr(status, 1u); return; }
@@ -576,6 +577,7 @@ __global__ __launch_bounds__(64) void k_sn_head(const uint8_t* __restrict__ src_
   for (int64_t i = lane; i < J.raw_prefix; i += 64) out[i] = in[i];
   in += J.raw_prefix; out += J.raw_prefix;
   const int64_t L = J.src_len - J.raw_prefix, out_len = J.dst_len - J.raw_prefix;
+  if (J.mode == 4) return;      // ZSTD frames: k_zstd_pages
   if (J.mode == 0) {
     if (L != out_len) { if (lane == 0) atomicOr(status, 1u); return; }
     for (int64_t i = lane; i < L; i += 64) out[i] = in[i];

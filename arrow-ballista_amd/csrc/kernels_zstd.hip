@@ -1,0 +1,28 @@
+// gpuq -- ZSTD Parquet pages: one wave per page (the decoder itself: zstd_dec.h).
+#include <hip/hip_runtime.h>
+#include "gpuq_kernels.h"
+#include "zstd_dec.h"
+
+namespace gpuq {
+
+// jobs[which[b]] with mode 4: frames at src + raw_prefix -> dst + raw_prefix (the prefix itself is copied by the unpack kernels);
+// scratch: (BLOCK_MAX + 64) bytes per workgroup of the launch (the literals of the block being decoded)
+__global__ __launch_bounds__(64) void k_zstd_pages(const uint8_t* __restrict__ src_base, uint8_t* dst_base, const UnpackJob* __restrict__ jobs, const int32_t* __restrict__ which,
+                                                   int n, uint8_t* scratch, uint32_t* __restrict__ status) {
+  __shared__ zs::Shared S;
+  const int b = (int)blockIdx.x;
+  if (b >= n) return;
+  const UnpackJob J = jobs[which[b]];
+  if (J.mode != 4 || J.raw_prefix < 0 || J.raw_prefix > J.src_len || J.raw_prefix > J.dst_len) { if (threadIdx.x == 0) atomicOr(status, 1u); return; }
+  const bool ok = zs::decode_frames(src_base + J.src + J.raw_prefix, J.src_len - J.raw_prefix, dst_base + J.dst + J.raw_prefix, J.dst_len - J.raw_prefix,
+                                    scratch + (size_t)b * (size_t)(zs::BLOCK_MAX + 64), S);
+  if (!ok && threadIdx.x == 0) atomicOr(status, 1u);
+}
+
+size_t zstd_scratch_bytes(int n_pages) { return (size_t)n_pages * (size_t)(zs::BLOCK_MAX + 64); }
+
+void launch_zstd_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, const int32_t* which, int n, uint8_t* scratch, uint32_t* status) {
+  if (n > 0) hipLaunchKernelGGL(k_zstd_pages, dim3((unsigned)n), dim3(64), 0, s, src, dst, jobs, which, n, scratch, status);
+}
+
+}  // namespace gpuq

@@ -429,8 +429,8 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
         const PqChunk& K = G.cols[(size_t)li];
         if (K.num_values == 0) continue;
         if (K.num_values < 0 || K.total_compressed <= 0 || K.data_page_offset < 0) throw std::runtime_error("parquet: negative size / offset in a column chunk's metadata");
-        if (K.codec != 0 && K.codec != 1 && K.codec != 7) throw Unsupported("parquet: compressed column chunk (codec " + std::to_string(K.codec) + ") in '" + L.name + "': UNCOMPRESSED, SNAPPY and LZ4_RAW pages are decoded on the device");
-        const int cmode = K.codec == 1 ? 1 : (K.codec == 7 ? 2 : 0);      // UnpackJob::mode: 1 Snappy, 2 one raw LZ4 block per page (LZ4_RAW)
+        if (K.codec != 0 && K.codec != 1 && K.codec != 6 && K.codec != 7) throw Unsupported("parquet: compressed column chunk (codec " + std::to_string(K.codec) + ") in '" + L.name + "': UNCOMPRESSED, SNAPPY, ZSTD and LZ4_RAW pages are decoded on the device");
+        const int cmode = K.codec == 1 ? 1 : (K.codec == 7 ? 2 : (K.codec == 6 ? 4 : 0));      // UnpackJob::mode: 1 Snappy, 2 one raw LZ4 block per page (LZ4_RAW), 4 ZSTD frames
         if (cmode == 2) any_lz4 = true;
         int64_t pos = K.dict_page_offset >= 0 && K.dict_page_offset < K.data_page_offset ? K.dict_page_offset : K.data_page_offset;
         const int64_t chunk_end = pos + K.total_compressed;
@@ -529,6 +529,19 @@ int gpuq_parquet_decode_groups(gpuq_ctx* ctx, void* stream, const uint8_t* file,
         }
       } else
       launch_unpack_pages(s, (const uint8_t*)dfile.p, (uint8_t*)dpagebuf.p, (const UnpackJob*)djobs.p, (int)jobs.size(), (uint32_t*)flags.p + 1);
+      // ZSTD pages (the reference's `tpch convert` default): one wave per page, in launches of at most 4096 pages
+      std::vector<int32_t> zjobs;
+      for (size_t j = 0; j < jobs.size(); ++j) if (jobs[j].mode == 4) zjobs.push_back((int32_t)j);
+      DevBuf dzwhich, dzscratch;
+      if (!zjobs.empty()) {
+        const int zbatch = 4096;
+        dzwhich.ensure(zjobs.size() * 4 + 64); dzscratch.ensure(zstd_scratch_bytes((int)std::min<size_t>(zjobs.size(), (size_t)zbatch)) + 64);
+        HIPCHECK(hipMemcpyAsync(dzwhich.p, zjobs.data(), zjobs.size() * 4, hipMemcpyHostToDevice, s));
+        for (size_t z = 0; z < zjobs.size(); z += (size_t)zbatch)
+          launch_zstd_pages(s, (const uint8_t*)dfile.p, (uint8_t*)dpagebuf.p, (const UnpackJob*)djobs.p, (const int32_t*)dzwhich.p + z, (int)std::min<size_t>((size_t)zbatch, zjobs.size() - z),
+                            (uint8_t*)dzscratch.p, (uint32_t*)flags.p + 1);
+        HIPCHECK(hipStreamSynchronize(s));      // (zjobs is pageable host memory; the scratch goes away with this scope)
+      }
       pages_base = (const uint8_t*)dpagebuf.p; pages_bytes = page_bytes;
     }
     // ---- pass 2 (device): dictionaries, pages, strings; one synchronisation at the end

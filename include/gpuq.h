@@ -213,7 +213,9 @@ const char* gpuq_ingest_last_error(void);
    path (> 15 significant digits or |exponent| > 22), lines whose field count differs from the schema (blank lines included), > 4 GiB per call.
    gpuq_parquet_decode: flat schemas; physical BOOLEAN INT32 INT64 DOUBLE BYTE_ARRAY FIXED_LEN_BYTE_ARRAY(decimal); DATE and
    DECIMAL annotations; required / optional columns; PLAIN, PLAIN_DICTIONARY / RLE_DICTIONARY and RLE-boolean pages (v1 and v2); UNCOMPRESSED
-   SNAPPY and LZ4_RAW column chunks (pages are decompressed without a serial walk: element positions by doubling, copies by pointer jumping; any other codec -- the reference's `convert` defaults to zstd -- is GPUQ_ERR_UNSUPPORTED).  `columns` (or NULL = all) projects by name; only the projected
+   SNAPPY, LZ4_RAW and ZSTD column chunks (Snappy / LZ4 pages are decompressed without a serial walk: element positions by doubling, copies by
+   pointer jumping; ZSTD pages -- the reference's `convert` default -- one wave per page: FSE / Huffman tables in LDS, the four literal streams on four
+   lanes, copies on all 64; GZIP, BROTLI, LZO and the deprecated framed LZ4 are GPUQ_ERR_UNSUPPORTED).  `columns` (or NULL = all) projects by name; only the projected
    chunks' bytes cross PCIe.  The host parses the Thrift footer and page headers, one wave decodes one page.
    Errors: gpuq_scan_last_error() (thread-local). */
 typedef struct gpuq_csv_options { char delimiter; char quote; int32_t has_header; } gpuq_csv_options;   /* 0 = default ',' / '"' */

@@ -238,7 +238,11 @@ def write(t, **kw):
     dict(use_dictionary=["lowcard", "s"], data_page_version="2.0", compression="SNAPPY", data_page_size=4096, row_group_size=25_000),
     dict(use_dictionary=True, data_page_version="1.0", compression="LZ4", data_page_size=16384),
     dict(use_dictionary=["lowcard", "s"], data_page_version="2.0", compression="LZ4", data_page_size=4096, row_group_size=25_000),
-], ids=["dict-v1", "plain-v1", "dict-v2-smallpages", "plain-v2-rowgroups", "mixed-dict-fallback", "snappy-v1", "snappy-v2", "lz4raw-v1", "lz4raw-v2"])
+    dict(use_dictionary=True, data_page_version="1.0", compression="ZSTD", data_page_size=16384),
+    dict(use_dictionary=["lowcard", "s"], data_page_version="2.0", compression="ZSTD", data_page_size=4096, row_group_size=25_000),
+    dict(use_dictionary=False, data_page_version="1.0", compression="ZSTD", compression_level=19),
+], ids=["dict-v1", "plain-v1", "dict-v2-smallpages", "plain-v2-rowgroups", "mixed-dict-fallback", "snappy-v1", "snappy-v2", "lz4raw-v1", "lz4raw-v2",
+        "zstd-v1", "zstd-v2", "zstd-19-bigpages"])
 def test_pyarrow_written_files(tc, n, opts):
     """Required and optional columns of every decoded type; dictionary and PLAIN pages, v1 and v2 headers, many small pages, several
     row groups, a dictionary that overflows and falls back to PLAIN mid-chunk; decimals as FIXED_LEN_BYTE_ARRAY (15,2) and (38,2)."""
@@ -263,7 +267,7 @@ def test_snappy_streams_with_long_literals_and_overlapping_copies(tc):
                   "noise": pa.array(r.integers(-2**62, 2**62, n)), "txt": pa.array(["abcabcabc-%d" % (j % 13) for j in range(n)]),
                   "opt": pa.array(r.integers(0, 3, n), type=pa.int32(), mask=r.random(n) < 0.5)})
     for opts in (dict(use_dictionary=False, data_page_size=1 << 20), dict(use_dictionary=False, data_page_size=1 << 14, data_page_version="2.0")):
-        for codec in ("SNAPPY", "LZ4"):      # (LZ4 = LZ4_RAW: one raw block per page, long matches and 255-runs of length bytes in the repetitive columns)
+        for codec in ("SNAPPY", "LZ4", "ZSTD"):      # (ZSTD: pages of several 128 KiB blocks, RLE / raw / Huffman literals, repeat offsets; LZ4 = LZ4_RAW: one raw block per page, long matches and 255-runs of length bytes in the repetitive columns)
             data = write(t, compression=codec, **opts)
             same(scan.read_parquet(tc, data).to_arrow(tc.ctx), pq.read_table(io.BytesIO(data)))
 
@@ -280,10 +284,26 @@ def test_decimals_stored_as_integers_and_projection_order(tc):
     same(got, pq.read_table(io.BytesIO(data), columns=["dec18", "ns", "dec"]))
 
 
+def test_zstd_pages_as_the_reference_convert_writes_them(tc):
+    """`tpch convert` writes ZSTD Parquet unless told otherwise (/root/reference/benchmarks/src/bin/tpch.rs:225-226, 777): lineitem-shaped
+    columns at several levels, pages of 1 MiB (eight zstd blocks each), against pyarrow's reader (libzstd)."""
+    n = 400_000
+    r = np.random.default_rng(11)
+    modes = np.array(["DELIVER IN PERSON", "COLLECT COD", "NONE", "TAKE BACK RETURN"])
+    t = pa.table({"l_orderkey": pa.array(np.sort(r.integers(1, 6_000_000, n))), "l_quantity": pa.array(r.integers(1, 51, n).astype(np.float64)),
+                  "l_extendedprice": pa.array(np.round(r.uniform(900, 105000, n), 2)), "l_shipdate": pa.array(r.integers(8036, 10561, n).astype(np.int32), type=pa.date32()),
+                  "l_returnflag": pa.array(np.array(["A", "N", "R"])[r.integers(0, 3, n)]), "l_shipinstruct": pa.array(modes[r.integers(0, 4, n)]),
+                  "l_comment": pa.array(["%s the %s foxes %d" % ("carefully" if j % 3 else "quickly", "final" if j % 5 else "bold", j % 977) for j in range(n)])})
+    for level in (1, 3, 12):
+        for dic in (True, False):
+            data = write(t, compression="ZSTD", compression_level=level, use_dictionary=dic)
+            same(scan.read_parquet(tc, data).to_arrow(tc.ctx), pq.read_table(io.BytesIO(data)))
+
+
 def test_compressed_chunks_and_garbage_are_refused(tc):
     t = parquet_table(100, 1)
     buf = io.BytesIO()
-    pq.write_table(t, buf, compression="ZSTD")
+    pq.write_table(t, buf, compression="GZIP")
     with pytest.raises(g.GpuqError) as e:
         scan.read_parquet(tc, buf.getvalue())
     assert e.value.status == 3 and "compressed" in str(e.value)
@@ -317,7 +337,7 @@ def test_decoded_leaves_feed_q1(tc):
     assert T.q1_result_to_rows(tc, T.run_q1(tc, from_text)) == want
 
 
-@pytest.mark.parametrize("compression", ["NONE", "SNAPPY", "LZ4"])
+@pytest.mark.parametrize("compression", ["NONE", "SNAPPY", "LZ4", "ZSTD"])
 def test_corrupted_pages_never_read_out_of_bounds(tc, compression):
     """Page bytes are untrusted: random corruptions of the data region of a valid file (levels, run headers, dictionary indices, length
     prefixes, Snappy tags) must end in an error or in (different) in-bounds values -- every length the kernels follow is checked
