@@ -22,5 +22,5 @@ for _ in range(3):
 rows = r.num_rows
 ok = r.to_arrow(tc.ctx).column("l_orderkey").equals(li.column("l_orderkey")) if sf <= 1 else None
 del r
-t0 = time.perf_counter(); pq.read_table(io.BytesIO(sfile)); host = time.perf_counter() - t0
+t0 = time.perf_counter(); pq.read_table(pa.BufferReader(sfile)); host = time.perf_counter() - t0
 print(json.dumps({"sf": sf, "codec": codec, "level": lvl.get("compression_level"), "rows": rows, "file_bytes": len(sfile), "device_ms": best * 1e3, "rows_per_s": rows / best, "pyarrow_host_ms": host * 1e3, "orderkey_equal": ok}))
