@@ -24,6 +24,8 @@
 #define ZS_NL 64
 #define ZS_SYNC() __syncthreads()
 #define ZS_GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads(); } while (0)
+// LDS written by some lanes of the wave, read by others: LDS operations of one wave complete in order, the compiler must not move them
+#define ZS_LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #else
 #define ZS_FN static inline
 #define ZS_M inline
@@ -31,12 +33,20 @@
 #define ZS_NL 1
 #define ZS_SYNC() ((void)0)
 #define ZS_GSYNC() ((void)0)
+#define ZS_LSYNC() ((void)0)
 #endif
 
 namespace gpuq {
 namespace zs {
 
 constexpr int64_t BLOCK_MAX = 131072;      // Block_Maximum_Size: literals and the output of one block never exceed it
+// The device keeps the last RING bytes of the page's output and a window of the block's literals in LDS: a match or a literal run
+// fetched from global memory costs a full L2 round trip per sequence (and a match needs the stores before it to have landed).
+// So does the sequence bitstream: on gfx9 a load's data is waited for with vmcnt, which also counts the stores in front of it -- a
+// bitstream refill from global memory would wait for every output byte stored so far (measured: ~1 us per sequence).
+// Each of the four lanes that decode a block's Huffman streams reads its stream through a private HUFW-byte window, too.
+constexpr int64_t RING = 32768, LITW = 4096, BITW = 4096, HUFW = 256;
+struct Lds { uint8_t* ring; uint8_t* litw; uint64_t* bitw; uint64_t* hufw; };      // ring[RING], litw[LITW], bitw[BITW / 8 + 2], hufw[4][HUFW / 8 + 2]; all null in the host build
 
 struct FseEnt { uint8_t sym, nbits; uint16_t base; };
 struct Shared {
@@ -66,19 +76,46 @@ ZS_FN uint64_t ld64(const uint8_t* p, int64_t off, int64_t len) {
 // a bitstream written forwards and read backwards: the last byte's highest set bit marks the end
 struct Back {
   const uint8_t* p; int64_t len; int64_t pos;      // pos: bits not read yet; negative once more was read than there is
+  uint64_t c; int cb;                              // the cb bits right below pos (one load serves several reads)
   ZS_M bool init(const uint8_t* q, int64_t n) {
-    p = q; len = n; pos = 0;
+    p = q; len = n; pos = 0; c = 0; cb = 0; win = nullptr; wb = -BITW - 64;
     if (n < 1 || q[n - 1] == 0) return false;
     pos = (n - 1) * 8 + highbit(q[n - 1]);
     return true;
   }
+  uint64_t* win; int64_t wb;                       // an LDS window over p[wb, wb + BITW + 16) (the sequence bitstream; every lane calls alike)
+  ZS_M uint64_t load(int64_t q) {                  // 57+ bits from bit q on
+    const int64_t b = q >> 3;
+    if (!win) return ld64(p, b, len) >> (q & 7);
+    if (b < wb || b + 8 > wb + BITW + 8) {
+      wb = b + 8 - BITW; if (wb < 0) wb = 0; wb &= ~(int64_t)7;
+      ZS_LSYNC();
+      for (int64_t j = (int64_t)ZS_LANE * 16; j < BITW + 16; j += ZS_NL * 16) {
+        uint64_t lo = 0, hi = 0;
+        if (wb + j + 16 <= len) { __builtin_memcpy(&lo, p + wb + j, 8); __builtin_memcpy(&hi, p + wb + j + 8, 8); }
+        else { lo = ld64(p, wb + j, len); hi = ld64(p, wb + j + 8, len); }
+        win[j >> 3] = lo; win[(j >> 3) + 1] = hi;
+      }
+      ZS_LSYNC();
+    }
+    const int64_t r = b - wb; const int sh = (int)((r & 7) * 8 + (q & 7));
+    const uint64_t lo = win[r >> 3], hi = win[(r >> 3) + 1];
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+  }
+  ZS_M void refill() {
+    if (pos >= 57) { c = load(pos - 57) & mask64(57); cb = 57; }
+    else if (pos > 0) { c = load(0) & mask64((int)pos); cb = (int)pos; }
+    else { c = 0; cb = 0; }
+  }
   ZS_M uint64_t read(int n) {      // n <= 32; bits in front of the stream's first byte read as zeros
     if (n == 0) return 0;
+    if (cb < n) refill();
     pos -= n;
-    if (pos >= 0) return (ld64(p, pos >> 3, len) >> (pos & 7)) & mask64(n);
-    const int64_t have = n + pos;
-    if (have <= 0) return 0;
-    return (ld64(p, 0, len) & mask64((int)have)) << (n - have);
+    const uint64_t m = (1ull << n) - 1;
+    if (cb >= n) { cb -= n; return (c >> cb) & m; }
+    const uint64_t v = (c << (n - cb)) & m;      // fewer than n bits are left in the whole stream
+    cb = 0;
+    return v;
   }
 };
 
@@ -186,23 +223,47 @@ ZS_FN int64_t huf_read_tree(const uint8_t* p, int64_t len, Shared& S) {
   return used;
 }
 
-// one Huffman stream: n_out symbols, and the stream must be used up exactly
-ZS_FN bool huf_stream(const uint8_t* p, int64_t len, const uint16_t* tab, int mb, uint8_t* out, int64_t n_out) {
+// one Huffman stream: n_out symbols, and the stream must be used up exactly.  hw: this lane's own window (HUFW + 16 bytes) or null
+ZS_FN bool huf_stream(const uint8_t* p, int64_t len, const uint16_t* tab, int mb, uint8_t* out, int64_t n_out, uint64_t* hw) {
   Back b; if (!b.init(p, len)) return false;
-  int64_t pos = b.pos; uint64_t c = 0; int cb = 0;      // c: the cb bits right below pos
+  int64_t pos = b.pos, wb = -HUFW - 64; uint64_t c = 0; int cb = 0;      // c: the cb bits right below pos
+  auto load = [&](int64_t q) -> uint64_t {      // 57+ bits from bit q on
+    const int64_t at = q >> 3;
+    if (!hw) return ld64(p, at, len) >> (q & 7);
+    if (at < wb || at + 8 > wb + HUFW + 8) {
+      wb = at + 8 - HUFW; if (wb < 0) wb = 0; wb &= ~(int64_t)7;
+      constexpr int NW = (int)(HUFW / 8) + 2;
+      uint64_t t[NW];
+      if (wb + HUFW + 16 <= len) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) __builtin_memcpy(&t[k], p + wb + 8 * k, 8);      // (all loads in flight together)
+      } else {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) t[k] = ld64(p, wb + 8 * k, len);
+      }
+#pragma unroll
+      for (int k = 0; k < NW; ++k) hw[k] = t[k];
+    }
+    const int64_t r = at - wb; const int sh = (int)((r & 7) * 8 + (q & 7));
+    const uint64_t lo = hw[r >> 3], hi = hw[(r >> 3) + 1];
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+  };
   const uint32_t m = (1u << mb) - 1;
+  uint64_t acc = 0;      // eight symbols leave in one store
   for (int64_t i = 0; i < n_out; ++i) {
     if (cb < mb) {
-      if (pos >= 57) { const int64_t q = pos - 57; c = (ld64(p, q >> 3, len) >> (q & 7)) & mask64(57); cb = 57; }
-      else if (pos > 0) { c = ld64(p, 0, len) & mask64((int)pos); cb = (int)pos; }
+      if (pos >= 57) { c = load(pos - 57) & mask64(57); cb = 57; }
+      else if (pos > 0) { c = load(0) & mask64((int)pos); cb = (int)pos; }
       else { c = 0; cb = 0; }
     }
     const uint32_t v = cb >= mb ? (uint32_t)(c >> (cb - mb)) & m : (uint32_t)(c << (mb - cb)) & m;
     const uint16_t e = tab[v];
-    out[i] = (uint8_t)e;
+    acc |= (uint64_t)(e & 255) << (8 * (int)(i & 7));
+    if ((i & 7) == 7) { __builtin_memcpy(out + i - 7, &acc, 8); acc = 0; }
     const int nb = e >> 8;
     pos -= nb; cb -= nb; if (cb < 0) cb = 0;
   }
+  for (int64_t i = n_out & ~(int64_t)7; i < n_out; ++i) out[i] = (uint8_t)(acc >> (8 * (int)(i & 7)));
   return pos == 0;
 }
 
@@ -235,7 +296,7 @@ ZS_FN bool seq_table(int mode, const uint8_t* sp, int64_t sl, int64_t& k, int wh
 }
 
 // block bp[0, bsz) -> out[op ...); rep: the frame's three repeat offsets; base: bytes of this frame in front of op
-ZS_FN bool decode_block(const uint8_t* bp, int64_t bsz, uint8_t* out, int64_t& op, int64_t out_len, int64_t frame_start, uint32_t* rep, uint8_t* scratch, Shared& S) {
+ZS_FN bool decode_block(const uint8_t* bp, int64_t bsz, uint8_t* out, int64_t& op, int64_t out_len, int64_t frame_start, uint32_t* rep, uint8_t* scratch, Shared& S, const Lds W) {
   static constexpr uint32_t LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
   static constexpr uint8_t LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
   static constexpr uint32_t ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
@@ -277,7 +338,7 @@ ZS_FN bool decode_block(const uint8_t* bp, int64_t bsz, uint8_t* out, int64_t& o
     if (lane == 0) S.err = 0;
     ZS_SYNC();
     if (streams == 1) {
-      if (lane == 0 && !huf_stream(q, qlen, S.huf, mb, scratch, regen)) S.err = 1;
+      if (lane == 0 && !huf_stream(q, qlen, S.huf, mb, scratch, regen, W.hufw)) S.err = 1;
     } else {
       if (qlen < 6) return false;
       const int64_t s1 = q[0] | (q[1] << 8), s2 = q[2] | (q[3] << 8), s3 = q[4] | (q[5] << 8), s4 = qlen - 6 - s1 - s2 - s3;
@@ -285,7 +346,7 @@ ZS_FN bool decode_block(const uint8_t* bp, int64_t bsz, uint8_t* out, int64_t& o
       if (s4 < 1 || lastn < 0) return false;
       for (int st = lane; st < 4; st += ZS_NL) {
         const int64_t so = st == 0 ? 0 : (st == 1 ? s1 : (st == 2 ? s1 + s2 : s1 + s2 + s3)), sn = st == 0 ? s1 : (st == 1 ? s2 : (st == 2 ? s3 : s4));
-        if (!huf_stream(q + 6 + so, sn, S.huf, mb, scratch + st * per, st == 3 ? lastn : per)) S.err = 1;
+        if (!huf_stream(q + 6 + so, sn, S.huf, mb, scratch + st * per, st == 3 ? lastn : per, W.hufw ? W.hufw + st * (HUFW / 8 + 2) : nullptr)) S.err = 1;
       }
     }
     ZS_GSYNC();
@@ -300,7 +361,7 @@ ZS_FN bool decode_block(const uint8_t* bp, int64_t bsz, uint8_t* out, int64_t& o
     if (c < 128) { nseq = c; k = 1; }
     else if (c < 255) { if (sl < 2) return false; nseq = ((int64_t)(c - 128) << 8) + sp[1]; k = 2; }
     else { if (sl < 3) return false; nseq = (int64_t)sp[1] + ((int64_t)sp[2] << 8) + 0x7F00; k = 3; } }
-  int64_t lp = 0;
+  int64_t lp = 0, lw0 = -LITW - 1;      // lw0: the literal position W.litw[0] holds
   if (nseq > 0) {
     if (k >= sl) return false;
     const uint32_t modes = sp[k++];
@@ -317,6 +378,7 @@ ZS_FN bool decode_block(const uint8_t* bp, int64_t bsz, uint8_t* out, int64_t& o
     if (S.used < 0) return false;
     k = S.used;
     Back b; if (!b.init(sp + k, sl - k)) return false;
+    b.win = W.bitw;
     uint32_t lls = (uint32_t)b.read(S.ll_al), ofs = (uint32_t)b.read(S.of_al), mls = (uint32_t)b.read(S.ml_al);
     if (b.pos < 0) return false;
     for (int64_t i = 0; i < nseq; ++i) {
@@ -342,24 +404,53 @@ ZS_FN bool decode_block(const uint8_t* bp, int64_t bsz, uint8_t* out, int64_t& o
       }
       if (b.pos < 0) return false;
       if (lp + llen > regen || op + llen + mlen > out_len || (int64_t)off > op + llen - frame_start) return false;
-      for (int64_t j = lane; j < llen; j += ZS_NL) out[op + j] = lit[lp + j];
+      // (a lone wave issues an instruction every few cycles: the copies below index with 32-bit values, and the 64-bit modulo of an
+      // overlapping match -- a couple of hundred instructions -- is a 32-bit one, taken only when the match overlaps itself)
+      const uint32_t ll32 = (uint32_t)llen, ml32 = (uint32_t)mlen, rop = (uint32_t)op & (uint32_t)(RING - 1);
+      uint8_t* const dst = out + op;
+      if (W.litw && llen <= LITW) {
+        if (llen > 0 && (lp < lw0 || lp + llen > lw0 + LITW)) {
+          lw0 = lp;
+          for (int64_t j = (int64_t)lane * 16; j < LITW; j += ZS_NL * 16) {
+            if (lw0 + j + 16 <= regen) { uint64_t a, b2; __builtin_memcpy(&a, lit + lw0 + j, 8); __builtin_memcpy(&b2, lit + lw0 + j + 8, 8); *(uint64_t*)(W.litw + j) = a; *(uint64_t*)(W.litw + j + 8) = b2; }
+            else for (int q = 0; q < 16; ++q) if (lw0 + j + q < regen) W.litw[j + q] = lit[lw0 + j + q];
+          }
+          ZS_LSYNC();
+        }
+        const uint8_t* const lw = W.litw + (uint32_t)(lp - lw0);
+        for (uint32_t j = (uint32_t)lane; j < ll32; j += ZS_NL) { const uint8_t v = lw[j]; dst[j] = v; W.ring[(rop + j) & (uint32_t)(RING - 1)] = v; }
+      } else {
+        const uint8_t* const ls = lit + lp;
+        for (uint32_t j = (uint32_t)lane; j < ll32; j += ZS_NL) { const uint8_t v = ls[j]; dst[j] = v; if (W.ring) W.ring[(rop + j) & (uint32_t)(RING - 1)] = v; }
+      }
       lp += llen; op += llen;
-      ZS_GSYNC();      // bytes stored by other lanes are this copy's source
       const int64_t o = (int64_t)off;
-      for (int64_t j = lane; j < mlen; j += ZS_NL) out[op + j] = out[op - o + (o >= mlen ? j : j % o)];
+      uint8_t* const md = out + op;
+      const uint32_t mrop = (uint32_t)op & (uint32_t)(RING - 1);
+      if (W.ring && o + mlen <= RING) {      // every source byte is still in the ring, and this copy's own bytes land elsewhere in it
+        ZS_LSYNC();
+        const uint32_t o32 = (uint32_t)o, sbase = mrop + (uint32_t)RING - o32;
+        if (o32 >= ml32) for (uint32_t j = (uint32_t)lane; j < ml32; j += ZS_NL) { const uint8_t v = W.ring[(sbase + j) & (uint32_t)(RING - 1)]; md[j] = v; W.ring[(mrop + j) & (uint32_t)(RING - 1)] = v; }
+        else for (uint32_t j = (uint32_t)lane; j < ml32; j += ZS_NL) { const uint8_t v = W.ring[(sbase + j % o32) & (uint32_t)(RING - 1)]; md[j] = v; W.ring[(mrop + j) & (uint32_t)(RING - 1)] = v; }
+      } else {
+        ZS_GSYNC();      // bytes stored by other lanes are this copy's source
+        const uint8_t* const ms = md - o;
+        if (o >= mlen) for (uint32_t j = (uint32_t)lane; j < ml32; j += ZS_NL) { const uint8_t v = ms[j]; md[j] = v; if (W.ring) W.ring[(mrop + j) & (uint32_t)(RING - 1)] = v; }
+        else { const uint32_t o32 = (uint32_t)o; for (uint32_t j = (uint32_t)lane; j < ml32; j += ZS_NL) { const uint8_t v = ms[j % o32]; md[j] = v; if (W.ring) W.ring[(mrop + j) & (uint32_t)(RING - 1)] = v; } }
+      }
       op += mlen;
     }
     if (b.pos != 0) return false;
   }
   const int64_t rest = regen - lp;
   if (op + rest > out_len) return false;
-  for (int64_t j = lane; j < rest; j += ZS_NL) out[op + j] = lit[lp + j];
+  for (int64_t j = lane; j < rest; j += ZS_NL) { const uint8_t v = lit[lp + j]; out[op + j] = v; if (W.ring) W.ring[(op + j) & (RING - 1)] = v; }
   op += rest;
   return true;
 }
 
 // every frame of in[0, in_len) -> out[0, out_len), exactly; scratch: BLOCK_MAX bytes of this wave's own
-ZS_FN bool decode_frames(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_len, uint8_t* scratch, Shared& S) {
+ZS_FN bool decode_frames(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_len, uint8_t* scratch, Shared& S, const Lds W = Lds{nullptr, nullptr, nullptr, nullptr}) {
   const int lane = ZS_LANE;
   int64_t ip = 0, op = 0;
   auto le = [&](int64_t at, int n) -> uint64_t { uint64_t v = 0; for (int i = 0; i < n; ++i) v |= (uint64_t)in[at + i] << (8 * i); return v; };
@@ -390,16 +481,16 @@ ZS_FN bool decode_frames(const uint8_t* in, int64_t in_len, uint8_t* out, int64_
       const int last = (int)(bh & 1), type = (int)((bh >> 1) & 3); const int64_t bsz = bh >> 3;
       if (type == 0) {
         if (bsz > in_len - ip || bsz > out_len - op) return false;
-        for (int64_t j = lane; j < bsz; j += ZS_NL) out[op + j] = in[ip + j];
+        for (int64_t j = lane; j < bsz; j += ZS_NL) { const uint8_t v = in[ip + j]; out[op + j] = v; if (W.ring) W.ring[(op + j) & (RING - 1)] = v; }
         ip += bsz; op += bsz;
       } else if (type == 1) {
         if (in_len - ip < 1 || bsz > out_len - op) return false;
         const uint8_t v = in[ip++];
-        for (int64_t j = lane; j < bsz; j += ZS_NL) out[op + j] = v;
+        for (int64_t j = lane; j < bsz; j += ZS_NL) { out[op + j] = v; if (W.ring) W.ring[(op + j) & (RING - 1)] = v; }
         op += bsz;
       } else if (type == 2) {
         if (bsz > in_len - ip || bsz > BLOCK_MAX) return false;
-        if (!decode_block(in + ip, bsz, out, op, out_len, frame_start, rep, scratch, S)) return false;
+        if (!decode_block(in + ip, bsz, out, op, out_len, frame_start, rep, scratch, S, W)) return false;
         ip += bsz;
       } else return false;
       if (last) break;

@@ -20,7 +20,11 @@ HARNESS = r'''
 extern "C" int zs_host_decode(const unsigned char* in, long in_len, unsigned char* out, long out_len) {
   static gpuq::zs::Shared S;
   std::vector<unsigned char> c(in, in + in_len), o((unsigned long)out_len), scratch(gpuq::zs::BLOCK_MAX + 64);      // exact-size heap copies: an overrun is ASan's
-  const bool ok = gpuq::zs::decode_frames(c.data(), in_len, o.data(), out_len, scratch.data(), S);
+  // every other call with the device's LDS ring and literal window (here: heap arrays of exactly their size)
+  static int flip = 0; flip ^= 1;
+  std::vector<unsigned char> ring(gpuq::zs::RING), litw(gpuq::zs::LITW); std::vector<uint64_t> bitw(gpuq::zs::BITW / 8 + 2), hufw(4 * (gpuq::zs::HUFW / 8 + 2));
+  const bool ok = flip ? gpuq::zs::decode_frames(c.data(), in_len, o.data(), out_len, scratch.data(), S, gpuq::zs::Lds{ring.data(), litw.data(), bitw.data(), hufw.data()})
+                       : gpuq::zs::decode_frames(c.data(), in_len, o.data(), out_len, scratch.data(), S);
   for (long i = 0; i < out_len; ++i) out[i] = o[(unsigned long)i];
   return ok ? 0 : 1;
 }
@@ -63,8 +67,9 @@ for name, raw in cases.items():
     for level in (1, 3, 9, 19):
         c = pa.Codec("zstd", compression_level=level).compress(raw, asbytes=True)
         out = ctypes.create_string_buffer(max(len(raw), 1))
-        if L.zs_host_decode(c, len(c), out, len(raw)) != 0 or out.raw[:len(raw)] != raw:
-            bad.append((name, level))
+        for variant in (0, 1):      # (the harness alternates: with and without the LDS ring / literal window)
+            if L.zs_host_decode(c, len(c), out, len(raw)) != 0 or out.raw[:len(raw)] != raw:
+                bad.append((name, level, variant))
         if len(raw) <= 300000 and level in (1, 19):
             frames.append((c, raw))
 # two frames back to back, and a skippable frame in front
