@@ -18,8 +18,10 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define ZS_FN __device__ static inline
-#define ZS_M __device__ inline
+// Everything is inlined into the kernel on purpose: a `Shared&` or an LDS pointer that crosses a real call is a generic pointer, its
+// loads become FLAT instructions, and a FLAT load is waited for with vmcnt(0) -- i.e. behind every output byte stored so far.
+#define ZS_FN __device__ __forceinline__ static
+#define ZS_M __device__ __forceinline__
 #define ZS_LANE ((int)threadIdx.x)
 #define ZS_NL 64
 #define ZS_SYNC() __syncthreads()
