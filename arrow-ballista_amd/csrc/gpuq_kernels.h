@@ -229,7 +229,7 @@ void launch_utf8_piece_compact(hipStream_t s, const Utf8Piece* pieces, int n_pie
 // across blocks; s_off = f_off + p_base), elsewhere f_off = s_off and p_base = 0
 struct UnpackJob { int64_t src, dst, src_len, dst_len, raw_prefix; int32_t mode, pad; int64_t s_off, c_off, f_off, p_base; };
 void launch_unpack_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, int n_jobs, uint32_t* status);
-// mode 4 = ZSTD frames (kernels_zstd.hip; the unpack kernels copy such a job's raw prefix and leave the rest to this launch);
+// mode 4 = ZSTD frames (kernels_zstd_dev.hip + zstd_launch.cpp; the unpack kernels copy such a job's raw prefix and leave the rest to this launch);
 // `which`: indices of the mode-4 jobs, `scratch`: zstd_scratch_bytes(n) bytes
 size_t zstd_scratch_bytes(int n_pages);
 void launch_zstd_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, const int32_t* which, int n, uint8_t* scratch, uint32_t* status);

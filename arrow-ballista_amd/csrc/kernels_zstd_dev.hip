@@ -1,14 +1,18 @@
 // gpuq -- ZSTD Parquet pages: one wave per page (the decoder itself: zstd_dec.h).
+//
+// This file is NOT linked into libgpuq.so's fat binary: build.py compiles it to a code object of its own (`--genco`), embeds the bytes,
+// and zstd_launch.cpp loads them as a module when the first ZSTD page arrives.  The runtime loads a library's device code when its first
+// kernel is launched, and this one kernel is as large as the rest of the scan path together: inside the fat binary it cost every process
+// 0.25-0.5 s of its first launch (SF100 q3's first execution 33 -> 275-520 ms), whether or not it ever saw a ZSTD file.
 #include <hip/hip_runtime.h>
 #include "gpuq_kernels.h"
 #include "zstd_dec.h"
 
-namespace gpuq {
-
 // jobs[which[b]] with mode 4: frames at src + raw_prefix -> dst + raw_prefix (the prefix itself is copied by the unpack kernels);
 // scratch: (BLOCK_MAX + 64) bytes per workgroup of the launch (the literals of the block being decoded)
-__global__ __launch_bounds__(64) void k_zstd_pages(const uint8_t* __restrict__ src_base, uint8_t* dst_base, const UnpackJob* __restrict__ jobs, const int32_t* __restrict__ which,
-                                                   int n, uint8_t* scratch, uint32_t* __restrict__ status) {
+extern "C" __global__ __launch_bounds__(64) void gpuq_k_zstd_pages(const uint8_t* __restrict__ src_base, uint8_t* dst_base, const gpuq::UnpackJob* __restrict__ jobs,
+                                                                   const int32_t* __restrict__ which, int n, uint8_t* scratch, uint32_t* __restrict__ status) {
+  using namespace gpuq;
   __shared__ zs::Shared S;
   __shared__ __attribute__((aligned(16))) uint8_t ring[zs::RING];
   __shared__ __attribute__((aligned(16))) uint8_t litw[zs::LITW];
@@ -22,11 +26,3 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const uint8_t* __restrict__ s
                                     scratch + (size_t)b * (size_t)(zs::BLOCK_MAX + 64), S, zs::Lds{ring, litw, bitw, hufw});
   if (!ok && threadIdx.x == 0) atomicOr(status, 1u);
 }
-
-size_t zstd_scratch_bytes(int n_pages) { return (size_t)n_pages * (size_t)(zs::BLOCK_MAX + 64); }
-
-void launch_zstd_pages(hipStream_t s, const uint8_t* src, uint8_t* dst, const UnpackJob* jobs, const int32_t* which, int n, uint8_t* scratch, uint32_t* status) {
-  if (n > 0) hipLaunchKernelGGL(k_zstd_pages, dim3((unsigned)n), dim3(64), 0, s, src, dst, jobs, which, n, scratch, status);
-}
-
-}  // namespace gpuq

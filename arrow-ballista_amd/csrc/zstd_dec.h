@@ -2,7 +2,7 @@
 //
 // The reference's `tpch convert` writes its Parquet files with ZSTD unless told otherwise
 // (/root/reference/benchmarks/src/bin/tpch.rs:225-226, 777); the CPU path hands those pages to the `zstd` crate.  This is the
-// device side of that: `k_zstd_pages` (kernels_zstd.hip) runs `decode_frames` with one 64-lane wave per page.
+// device side of that: `gpuq_k_zstd_pages` (kernels_zstd_dev.hip) runs `decode_frames` with one 64-lane wave per page.
 //
 // What runs where inside the wave:
 //   * headers, the FSE table descriptions, table builds and the Huffman tree  -- lane 0, tables in LDS (`Shared`, ~11 KB);
@@ -18,10 +18,10 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-// Everything is inlined into the kernel on purpose: a `Shared&` or an LDS pointer that crosses a real call is a generic pointer, its
-// loads become FLAT instructions, and a FLAT load is waited for with vmcnt(0) -- i.e. behind every output byte stored so far.
-#define ZS_FN __device__ __forceinline__ static
-#define ZS_M __device__ __forceinline__
+// (Forcing everything inline -- so that no LDS access goes through a generic pointer and a FLAT instruction -- was measured: 256 VGPRs,
+// twice the code, 10 % slower.  The compiler's own choice stays.)
+#define ZS_FN __device__ static inline
+#define ZS_M __device__ inline
 #define ZS_LANE ((int)threadIdx.x)
 #define ZS_NL 64
 #define ZS_SYNC() __syncthreads()
