@@ -14,7 +14,7 @@ extern "C" __global__ __launch_bounds__(64) void gpuq_k_zstd_pages(const uint8_t
                                                                    const int32_t* __restrict__ which, int n, uint8_t* scratch, uint32_t* __restrict__ status) {
   using namespace gpuq;
   __shared__ zs::Shared S;
-  __shared__ __attribute__((aligned(16))) uint8_t ring[zs::RING];
+  // (no output ring: measured, it does not shorten a sequence -- the wave is issue-bound -- and its 32 KB would halve the pages in flight per CU)
   __shared__ __attribute__((aligned(16))) uint8_t litw[zs::LITW];
   __shared__ __attribute__((aligned(16))) uint64_t bitw[zs::BITW / 8 + 2];
   __shared__ __attribute__((aligned(16))) uint64_t hufw[4 * (zs::HUFW / 8 + 2)];
@@ -23,6 +23,6 @@ extern "C" __global__ __launch_bounds__(64) void gpuq_k_zstd_pages(const uint8_t
   const UnpackJob J = jobs[which[b]];
   if (J.mode != 4 || J.raw_prefix < 0 || J.raw_prefix > J.src_len || J.raw_prefix > J.dst_len) { if (threadIdx.x == 0) atomicOr(status, 1u); return; }
   const bool ok = zs::decode_frames(src_base + J.src + J.raw_prefix, J.src_len - J.raw_prefix, dst_base + J.dst + J.raw_prefix, J.dst_len - J.raw_prefix,
-                                    scratch + (size_t)b * (size_t)(zs::BLOCK_MAX + 64), S, zs::Lds{ring, litw, bitw, hufw});
+                                    scratch + (size_t)b * (size_t)(zs::BLOCK_MAX + 64), S, zs::Lds{nullptr, litw, bitw, hufw});
   if (!ok && threadIdx.x == 0) atomicOr(status, 1u);
 }

@@ -420,7 +420,7 @@ ZS_FN bool decode_block(const uint8_t* bp, int64_t bsz, uint8_t* out, int64_t& o
           ZS_LSYNC();
         }
         const uint8_t* const lw = W.litw + (uint32_t)(lp - lw0);
-        for (uint32_t j = (uint32_t)lane; j < ll32; j += ZS_NL) { const uint8_t v = lw[j]; dst[j] = v; W.ring[(rop + j) & (uint32_t)(RING - 1)] = v; }
+        for (uint32_t j = (uint32_t)lane; j < ll32; j += ZS_NL) { const uint8_t v = lw[j]; dst[j] = v; if (W.ring) W.ring[(rop + j) & (uint32_t)(RING - 1)] = v; }
       } else {
         const uint8_t* const ls = lit + lp;
         for (uint32_t j = (uint32_t)lane; j < ll32; j += ZS_NL) { const uint8_t v = ls[j]; dst[j] = v; if (W.ring) W.ring[(rop + j) & (uint32_t)(RING - 1)] = v; }

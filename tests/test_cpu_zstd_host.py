@@ -21,9 +21,9 @@ extern "C" int zs_host_decode(const unsigned char* in, long in_len, unsigned cha
   static gpuq::zs::Shared S;
   std::vector<unsigned char> c(in, in + in_len), o((unsigned long)out_len), scratch(gpuq::zs::BLOCK_MAX + 64);      // exact-size heap copies: an overrun is ASan's
   // every other call with the device's LDS ring and literal window (here: heap arrays of exactly their size)
-  static int flip = 0; flip ^= 1;
+  static int flip = 0; flip = (flip + 1) % 3;      // 1: ring + windows, 2: windows without the ring (what the kernel passes), 0: neither
   std::vector<unsigned char> ring(gpuq::zs::RING), litw(gpuq::zs::LITW); std::vector<uint64_t> bitw(gpuq::zs::BITW / 8 + 2), hufw(4 * (gpuq::zs::HUFW / 8 + 2));
-  const bool ok = flip ? gpuq::zs::decode_frames(c.data(), in_len, o.data(), out_len, scratch.data(), S, gpuq::zs::Lds{ring.data(), litw.data(), bitw.data(), hufw.data()})
+  const bool ok = flip ? gpuq::zs::decode_frames(c.data(), in_len, o.data(), out_len, scratch.data(), S, gpuq::zs::Lds{flip == 1 ? ring.data() : nullptr, litw.data(), bitw.data(), hufw.data()})
                        : gpuq::zs::decode_frames(c.data(), in_len, o.data(), out_len, scratch.data(), S);
   for (long i = 0; i < out_len; ++i) out[i] = o[(unsigned long)i];
   return ok ? 0 : 1;
@@ -67,7 +67,7 @@ for name, raw in cases.items():
     for level in (1, 3, 9, 19):
         c = pa.Codec("zstd", compression_level=level).compress(raw, asbytes=True)
         out = ctypes.create_string_buffer(max(len(raw), 1))
-        for variant in (0, 1):      # (the harness alternates: with and without the LDS ring / literal window)
+        for variant in (0, 1, 2):      # (the harness cycles: ring + windows, windows only, neither)
             if L.zs_host_decode(c, len(c), out, len(raw)) != 0 or out.raw[:len(raw)] != raw:
                 bad.append((name, level, variant))
         if len(raw) <= 300000 and level in (1, 19):
